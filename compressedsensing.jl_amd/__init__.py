@@ -1,0 +1,17 @@
+"""compressedsensing.jl_amd -- MI355X-native matching pursuit (mp / omp / gomp / sp).
+
+Host-side mirror of CompressedSensing.jl's matching-pursuit interface over libcsmp.so
+(hand-written gfx950 HIP kernels behind the C ABI of include/csmp.h).  The directory name
+contains a dot (layout contract), so load this package with `csmp_pkg.load()`.
+"""
+from .sparsevec import SparseVector, spzeros
+from .data import sparse_vector, sparse_data, gaussian_data, perturb, samesupport
+from ._lib import CsmpError, Context, LIB_PATH
+from .api import (Dictionary, mp, omp, gomp, sp, omp_batch, MP, OMP, GOMP, update_, argmaxinner)
+from .sharded import omp_sharded, shard_range
+
+__all__ = [
+    "SparseVector", "spzeros", "sparse_vector", "sparse_data", "gaussian_data", "perturb", "samesupport",
+    "CsmpError", "Context", "Dictionary", "mp", "omp", "gomp", "sp", "omp_batch", "MP", "OMP", "GOMP",
+    "update_", "argmaxinner", "omp_sharded", "shard_range",
+]

@@ -1,0 +1,295 @@
+"""ctypes binding of csrc/libcsmp.so -- the C ABI declared in include/csmp.h.
+
+This is the Python twin of the `ccall` stubs in julia/CompressedSensingAMD.jl.  There is NO CPU
+fallback: if the shared library is missing, or no MI355X is visible, every compute entry point
+raises `CsmpError` loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
+
+OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+ALGO_MP, ALGO_OMP, ALGO_GOMP = 0, 1, 2
+STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
+
+i64 = C.c_int64
+vp = C.c_void_p
+
+# name -> (restype, argtypes): every symbol include/csmp.h declares
+SIGNATURES = {
+    "csmp_version": (C.c_int, []),
+    "csmp_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "csmp_destroy": (C.c_int, [vp]),
+    "csmp_last_error": (C.c_char_p, [vp]),
+    "csmp_set_stream": (C.c_int, [vp, vp]),
+    "csmp_sync": (C.c_int, [vp]),
+    "csmp_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
+    "csmp_set_dictionary": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int]),
+    "csmp_mp": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
+    "csmp_omp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
+    "csmp_gomp": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
+    "csmp_sp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
+    "csmp_solver_step": (C.c_int, [vp, i64]),
+    "csmp_solver_state": (C.c_int, [vp, vp, vp, C.POINTER(i64), C.POINTER(C.c_double), vp, C.POINTER(C.c_int)]),
+    "csmp_sweep": (C.c_int, [vp, vp, vp, i64, vp, vp]),
+    "csmp_lstsq": (C.c_int, [vp, vp, i64, vp, C.c_int, vp]),
+    "csmp_profile_enable": (C.c_int, [vp, C.c_int]),
+    "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
+    "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+}
+
+
+class CsmpError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcsmp error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libcsmp.so (built by `make -C csrc` / __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CsmpError(ESTATE, f"{LIB_PATH} is missing -- build it with `make -C {os.path.dirname(LIB_PATH)}`; "
+                                    "there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            f = getattr(L, name)  # AttributeError if the ABI and the header disagree
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise TypeError(f"unsupported element type {dt}: the dictionary and b must be float32 or float64")
+
+
+class Context:
+    """One GPU + one HIP stream + the resident dictionary (csmp_ctx)."""
+
+    def __init__(self, device=0):
+        self._h = vp()
+        L = lib()
+        rc = L.csmp_create(C.byref(self._h), int(device))
+        if rc != OK:
+            msg = L.csmp_last_error(None).decode()
+            self._h = None
+            raise CsmpError(rc, msg)
+        self.M = self.N = 0
+        self.dtype = None
+        self._keep = None  # keeps a borrowed device tensor alive
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().csmp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc != OK:
+            raise CsmpError(rc, lib().csmp_last_error(self._h).decode())
+
+    def call(self, name, *args):
+        self.check(getattr(lib(), name)(self._h, *args))
+
+    # ---- dictionary
+    def set_dictionary(self, A):
+        """A: numpy array (host; copied once to HBM) or a torch CUDA tensor holding the
+        column-major dictionary as a (N, M) row-major tensor, i.e. `A_torch[j]` is atom j."""
+        if isinstance(A, np.ndarray):
+            if A.ndim != 2:
+                raise ValueError("A must be a matrix")
+            if not A.flags.f_contiguous:
+                A = np.asfortranarray(A)
+            M, N = A.shape
+            self.call("csmp_set_dictionary", ptr(A), i64(M), i64(N), i64(M), dtype_code(A.dtype), HOST)
+            self.dtype = A.dtype
+            self._keep = None
+        else:  # torch tensor on the GPU, shape (N, M): rows are atoms
+            import torch
+            if not (isinstance(A, torch.Tensor) and A.is_cuda and A.dim() == 2 and A.is_contiguous()):
+                raise ValueError("device dictionary must be a contiguous 2-D CUDA tensor of shape (N atoms, M rows)")
+            N, M = A.shape
+            dt = np.float32 if A.dtype == torch.float32 else np.float64 if A.dtype == torch.float64 else None
+            if dt is None:
+                raise TypeError("device dictionary must be float32 or float64")
+            self.call("csmp_set_dictionary", vp(A.data_ptr()), i64(M), i64(N), i64(M), dtype_code(dt), DEVICE)
+            self.dtype = np.dtype(dt)
+            self._keep = A
+        self.M, self.N = int(M), int(N)
+
+    def sync(self):
+        self.call("csmp_sync")
+
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cus = C.c_int(0)
+        mem = i64(0)
+        self.call("csmp_device_info", name, 256, C.byref(cus), C.byref(mem))
+        return name.value.decode(), cus.value, mem.value
+
+    def _b(self, b):
+        b = np.ascontiguousarray(b)
+        if b.dtype not in (np.float32, np.float64):
+            b = b.astype(np.float64)
+        if b.shape != (self.M,):
+            raise CsmpError(EDIM, f"length(b) = {b.shape} but size(A, 1) = {self.M}")
+        return b
+
+    # ---- drivers
+    def omp(self, b, k, eps):
+        b = self._b(b)
+        cap = max(int(k), 1)
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        order = np.zeros(cap, np.int64)
+        nnz = i64(0)
+        self.call("csmp_omp", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(eps), ptr(idx), ptr(val),
+                  C.byref(nnz), ptr(order))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), order[:n].copy()
+
+    def gomp(self, b, l, k, eps):
+        b = self._b(b)
+        cap = max(int(k) + int(l), 1)
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        order = np.zeros(cap, np.int64)
+        nnz = i64(0)
+        self.call("csmp_gomp", ptr(b), dtype_code(b.dtype), i64(int(l)), i64(int(k)), C.c_double(eps), ptr(idx),
+                  ptr(val), C.byref(nnz), ptr(order))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), order[:n].copy()
+
+    def mp(self, b, k, idx0=None, val0=None):
+        b = self._b(b)
+        idx0 = np.zeros(0, np.int64) if idx0 is None else np.ascontiguousarray(idx0, dtype=np.int64)
+        val0 = np.zeros(0, np.float64) if val0 is None else np.ascontiguousarray(val0, dtype=np.float64)
+        cap = max(int(k) + len(idx0), 1)
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        nnz = i64(0)
+        self.call("csmp_mp", ptr(b), dtype_code(b.dtype), i64(int(k)), ptr(idx0), ptr(val0), i64(len(idx0)),
+                  ptr(idx), ptr(val), C.byref(nnz))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy()
+
+    def sp(self, b, k, delta, maxiter=-1):
+        b = self._b(b)
+        cap = max(2 * int(k), 1)
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        nnz = i64(0)
+        iters = i64(0)
+        self.call("csmp_sp", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
+                  ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), iters.value
+
+    def omp_batch(self, B, k, eps):
+        """Host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz) numpy arrays."""
+        B = np.asfortranarray(B)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        M, nsig = B.shape
+        if M != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {M} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), nsig), np.int64, order="F")
+        val = np.zeros((int(k), nsig), np.float64, order="F")
+        nnz = np.zeros(nsig, np.int64)
+        self.call("csmp_omp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
+                  C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
+        return idx, val, nnz
+
+    def omp_batch_device(self, B, k, eps, idx, val, nnz):
+        """torch CUDA tensors: B (nsig, M) rows = signals; outputs idx (nsig, k) int64,
+        val (nsig, k) float64, nnz (nsig,) int64.  Only enqueues work; call sync()."""
+        import torch
+        nsig, M = B.shape
+        assert B.is_cuda and B.is_contiguous() and M == self.M
+        assert idx.dtype == torch.int64 and val.dtype == torch.float64 and nnz.dtype == torch.int64
+        assert idx.is_contiguous() and val.is_contiguous() and idx.shape == (nsig, int(k)) and val.shape == (nsig, int(k))
+        code = F32 if B.dtype == torch.float32 else F64
+        self.call("csmp_omp_batch", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(k)), C.c_double(eps),
+                  vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
+
+    # ---- step level
+    def solver_begin(self, algo, b, kcap, idx0=None, val0=None):
+        b = self._b(b)
+        idx0 = np.zeros(0, np.int64) if idx0 is None else np.ascontiguousarray(idx0, dtype=np.int64)
+        val0 = np.zeros(0, np.float64) if val0 is None else np.ascontiguousarray(val0, dtype=np.float64)
+        self.call("csmp_solver_begin", int(algo), ptr(b), dtype_code(b.dtype), i64(int(kcap)), ptr(idx0), ptr(val0),
+                  i64(len(idx0)))
+
+    def solver_step(self, l=1):
+        self.call("csmp_solver_step", i64(int(l)))
+
+    def solver_state(self, cap):
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        order = np.zeros(cap, np.int64)
+        nnz = i64(0)
+        res = C.c_double(0)
+        stop = C.c_int(0)
+        self.call("csmp_solver_state", ptr(idx), ptr(val), C.byref(nnz), C.byref(res), ptr(order), C.byref(stop))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), res.value, order[:n].copy(), stop.value
+
+    # ---- primitives
+    def sweep(self, r, topk=1, want_abs=True):
+        r = np.ascontiguousarray(r, dtype=np.float64)
+        if r.shape != (self.M,):
+            raise CsmpError(EDIM, "length(r) != size(A, 1)")
+        out = np.zeros(self.N, np.float64) if want_abs else None
+        ti = np.zeros(max(int(topk), 1), np.int64)
+        tv = np.zeros(max(int(topk), 1), np.float64)
+        self.call("csmp_sweep", ptr(r), ptr(out), i64(int(topk)), ptr(ti), ptr(tv))
+        return out, ti[:int(topk)], tv[:int(topk)]
+
+    def lstsq(self, cols, b):
+        b = self._b(b)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        coef = np.zeros(len(cols), np.float64)
+        self.call("csmp_lstsq", ptr(cols), i64(len(cols)), ptr(b), dtype_code(b.dtype), ptr(coef))
+        return coef
+
+    # ---- measurement
+    def profile_enable(self, on=True):
+        self.call("csmp_profile_enable", int(bool(on)))
+
+    def profile_read(self, reset=True):
+        n = i64(0)
+        ms = C.c_double(0)
+        self.call("csmp_profile_read", C.byref(n), C.byref(ms), int(bool(reset)))
+        return n.value, ms.value
+
+    def bench_sweep(self, variant=0, reps=20):
+        ms = C.c_double(0)
+        self.call("csmp_bench_sweep", int(variant), int(reps), C.byref(ms))
+        return ms.value

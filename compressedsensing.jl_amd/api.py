@@ -1,0 +1,272 @@
+"""Host-side mirror of the reference's matching-pursuit interface, over libcsmp.so.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to it):
+
+    mp(A, b, k[, x])                         src/matchingpursuit.jl:34-40
+    omp(A, b, k) / omp(A, b, eps, k) / omp(A, b; max_residual, sparsity)   :73-91
+    gomp(A, b, l, k) / gomp(A, b, l, eps, k) / gomp(A, b, l; ...)          :126-148
+    sp(A, b, k, delta=1e-12; maxiter=16k)    src/twostage.jl:87-101
+    MP / OMP / GOMP functors with update!    src/matchingpursuit.jl:10-31,44-70,95-123
+    argmaxinner!(P[, k])                     src/matchingpursuit.jl:181-193
+
+`A` is either a numpy matrix (uploaded to HBM for the duration of the call) or a `Dictionary`
+(uploaded once, resident -- what a caller looping over many signals wants).  Results are
+`SparseVector`s with 0-based sorted `nzind`.  The reference throws bare strings
+(`throw("eps = ... has to be non-negative")`); here those become ValueError with the same text.
+There is no CPU path: without libcsmp.so and an MI355X every call raises `CsmpError`.
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import CsmpError
+from .sparsevec import SparseVector, spzeros
+
+
+class Dictionary:
+    """The measurement matrix resident in HBM (the `A` field of MP/OMP/GOMP/SP)."""
+
+    def __init__(self, A, device=0):
+        self.ctx = _lib.Context(device)
+        self.ctx.set_dictionary(A)
+        self.shape = (self.ctx.M, self.ctx.N)
+        self.dtype = np.dtype(self.ctx.dtype)
+
+    @property
+    def eps(self):  # eps(eltype(A)): the drivers' default tolerance (:85,89,142,146)
+        return float(np.finfo(self.dtype).eps)
+
+    def close(self):
+        self.ctx.close()
+
+
+def _dict(A):
+    return (A, False) if isinstance(A, Dictionary) else (Dictionary(A), True)
+
+
+def _meta(A):
+    """(M, N, eps(eltype(A))) without touching the GPU, so argument errors surface first."""
+    if isinstance(A, Dictionary):
+        return A.shape[0], A.shape[1], A.eps
+    A = np.asarray(A) if not hasattr(A, "dtype") else A
+    if A.ndim != 2:
+        raise ValueError("A must be a matrix")
+    dt = np.dtype(A.dtype) if A.dtype in (np.float32, np.float64) else np.dtype(np.float64)
+    return A.shape[0], A.shape[1], float(np.finfo(dt).eps)
+
+
+def _is_int(v):
+    return isinstance(v, (int, np.integer)) and not isinstance(v, bool)
+
+
+def _check_eps(eps):
+    if not eps >= 0:
+        raise ValueError(f"ε = {eps} has to be non-negative")  # src/matchingpursuit.jl:74,127
+
+
+# ------------------------------------------------------------------------------------ drivers
+def omp(A, b, *args, max_residual=None, sparsity=None):
+    """omp(A,b,k) | omp(A,b,eps[,k]) | omp(A,b; max_residual=eps(T), sparsity=min(size(A)...))"""
+    M, N, eps0 = _meta(A)
+    if len(args) == 0:  # keyword form :88-91
+        eps = eps0 if max_residual is None else max_residual
+        k = min(M, N) if sparsity is None else sparsity
+    elif len(args) == 1 and _is_int(args[0]):  # omp(A,b,k::Int) :84-86
+        eps, k = eps0, args[0]
+    elif len(args) == 1:  # omp(A,b,eps) with k = size(A,1) :73
+        eps, k = args[0], M
+    elif len(args) == 2:
+        eps, k = args
+    else:
+        raise TypeError("omp(A, b, [eps,] k)")
+    _check_eps(eps)
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.omp(b, int(k), float(eps))
+        return SparseVector(N, idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def gomp(A, b, l, *args, max_residual=None, sparsity=None):
+    """gomp(A,b,l,k) | gomp(A,b,l,eps[,k]) | gomp(A,b,l; max_residual=eps(T), sparsity=size(A,2))"""
+    M, N, eps0 = _meta(A)
+    if len(args) == 0:  # :145-148
+        eps = eps0 if max_residual is None else max_residual
+        k = N if sparsity is None else sparsity
+    elif len(args) == 1 and _is_int(args[0]):  # :141-143
+        eps, k = eps0, args[0]
+    elif len(args) == 1:  # gomp(A,b,l,eps) with k = size(A,1) :126
+        eps, k = args[0], M
+    elif len(args) == 2:
+        eps, k = args
+    else:
+        raise TypeError("gomp(A, b, l, [eps,] k)")
+    _check_eps(eps)
+    if int(l) < 1:
+        raise ValueError("l has to be positive")
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.gomp(b, int(l), int(k), float(eps))
+        return SparseVector(N, idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def mp(A, b, k, x=None):
+    """mp(A,b,k,x=spzeros(N)): k steps; x is a warm start and is updated in place like the reference."""
+    D, tmp = _dict(A)
+    try:
+        M, N = D.shape
+        i0 = v0 = None
+        if x is not None and x.nnz:
+            i0, v0 = x.nzind, x.nzval
+        idx, val = D.ctx.mp(b, int(k), i0, v0)
+        if x is None:
+            return SparseVector(N, idx, val)
+        x.nzind, x.nzval = idx, val
+        return x
+    finally:
+        if tmp:
+            D.close()
+
+
+def sp(A, b, k, delta=1e-12, maxiter=None):
+    """sp(A,b,k,delta=1e-12; maxiter=16k).  2k > length(b) is an error (src/twostage.jl:55)."""
+    M, N, _ = _meta(A)
+    if 2 * k > M:
+        raise ValueError(f"2k = {2 * k} > {M} = length(b) is invalid for Subspace Pursuit")
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.sp(b, int(k), float(delta), -1 if maxiter is None else int(maxiter))
+        return SparseVector(N, idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def omp_batch(A, B, k, eps=None):
+    """[omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU; returns a list of SparseVectors."""
+    eps = _meta(A)[2] if eps is None else eps
+    _check_eps(eps)
+    D, tmp = _dict(A)
+    try:
+        idx, val, nnz = D.ctx.omp_batch(B, int(k), float(eps))
+        return [SparseVector(D.shape[1], idx[:n, s], val[:n, s]) for s, n in enumerate(nnz)]
+    finally:
+        if tmp:
+            D.close()
+
+
+# ------------------------------------------------------------------------------------ functors
+class _Update:
+    """abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)"""
+
+    def __call__(self, x=None):
+        return self.update_(x)
+
+
+class _DevicePursuit(_Update):
+    ALGO = None
+
+    def __init__(self, A, b, kcap, l=1):
+        self.D, self._tmp = _dict(A)
+        self.A, self.b = A, np.asarray(b)
+        self.l = int(l)
+        M, N = self.D.shape
+        self.kcap = int(kcap)
+        self.D.ctx.solver_begin(self.ALGO, b, self.kcap)
+        self._x = spzeros(N)  # the x this object has been evolving
+
+    def _sync_x(self, x):
+        idx, val, res, order, stop = self.D.ctx.solver_state(max(self.kcap, 1))
+        self._x = SparseVector(self.D.shape[1], idx, val)
+        self.resnorm, self.order, self.stop = res, order, stop
+        if x is None:
+            return self._x.copy()
+        x.nzind, x.nzval = idx.copy(), val.copy()
+        return x
+
+    def _same(self, x):
+        return x is None or (x.nnz == self._x.nnz and np.array_equal(x.nzind, self._x.nzind))
+
+    def residual_norm(self):
+        return self.D.ctx.solver_state(max(self.kcap, 1))[2]
+
+    def close(self):
+        if self._tmp:
+            self.D.close()
+
+
+class OMP(_DevicePursuit):
+    """OMP(A, b, k=size(A,1)); update!(P, x): src/matchingpursuit.jl:54-70.  The updatable QR and
+    the residual live on the device, tied to the x this object returned last."""
+    ALGO = _lib.ALGO_OMP
+
+    def __init__(self, A, b, k=None):
+        M = A.shape[0]
+        super().__init__(A, b, M if k is None else min(int(k), M))
+
+    def update_(self, x=None):
+        if not self._same(x):
+            raise ValueError("update!(P::OMP, x): x is not the support this OMP object's QR was built for")
+        self.D.ctx.solver_step(1)
+        return self._sync_x(x)
+
+
+class GOMP(_DevicePursuit):
+    """GOMP(A, b, l, k=size(A,1)); update!(P, x, l=P.l): src/matchingpursuit.jl:108-123."""
+    ALGO = _lib.ALGO_GOMP
+
+    def __init__(self, A, b, l, k=None):
+        M = A.shape[0]
+        super().__init__(A, b, M if k is None else min(int(k), M), l)
+
+    def update_(self, x=None, l=None):
+        if not self._same(x):
+            raise ValueError("update!(P::GOMP, x): x is not the support this GOMP object's QR was built for")
+        self.D.ctx.solver_step(self.l if l is None else int(l))
+        return self._sync_x(x)
+
+
+class MP(_DevicePursuit):
+    """MP(A, b); update!(P, x): src/matchingpursuit.jl:19-31.  Any x may be passed (the reference
+    recomputes the residual from x every step): a foreign x restarts the device residual from it."""
+    ALGO = _lib.ALGO_MP
+
+    def __init__(self, A, b, steps=4096):
+        super().__init__(A, b, steps)
+
+    def update_(self, x=None):
+        if x is not None and not (self._same(x) and np.array_equal(x.nzval, self._x.nzval)):
+            self.D.ctx.solver_begin(self.ALGO, self.b, self.kcap, x.nzind, x.nzval)
+            self._base = x.copy()
+        self.D.ctx.solver_step(1)
+        idx, val, res, order, stop = self.D.ctx.solver_state(max(self.kcap, 1))
+        base = getattr(self, "_base", None)
+        out = base.copy() if base is not None else spzeros(self.D.shape[1])
+        for i, v in zip(idx, val):  # steps since the (re)start, merged per atom by the library
+            out[i] = out[i] + v
+        self._x = out
+        if x is None:
+            return out.copy()
+        x.nzind, x.nzval = out.nzind.copy(), out.nzval.copy()
+        return x
+
+
+def update_(P, x=None, *a):
+    """update!(P, x)"""
+    return P.update_(x, *a)
+
+
+def argmaxinner(A, r, k=None):
+    """argmaxinner!(P) -> index of the largest |<a_i, r>| (first on ties);
+    argmaxinner!(P, k) -> the k largest, descending, ties by ascending index (:181-193)."""
+    D, tmp = _dict(A)
+    try:
+        _, ti, _ = D.ctx.sweep(r, 1 if k is None else int(k), want_abs=False)
+        return int(ti[0]) if k is None else ti
+    finally:
+        if tmp:
+            D.close()

@@ -1,0 +1,769 @@
+// csmp.hip -- host side of libcsmp.so: the C ABI of include/csmp.h over the gfx950 kernels in
+// csmp_kernels.hpp.  One ctx = one GPU + one HIP stream.  A solve is a chain of asynchronous
+// launches with all control state (support, stop flags) in device memory: the host never
+// synchronises inside a solve, only when results are copied back.
+#include "../../include/csmp.h"
+#include "csmp_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace csmp;
+
+static std::string g_create_err;
+
+struct Solver {
+    int kcap = 0, outcap = 0;
+    int64_t ldq = 0;
+    int G = 0, Mpad = 0, jpad = 0;
+    double *b = nullptr, *r = nullptr, *cvec = nullptr, *pval = nullptr;
+    int* pidx = nullptr;
+    double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr;
+    double *avec = nullptr, *vvec = nullptr, *coef = nullptr, *scal = nullptr;
+    int *sel = nullptr, *cands = nullptr, *ncands = nullptr;
+    DevState* st = nullptr;
+    double* bstage = nullptr;  // Mpad doubles: host-uploaded b
+    int64_t *out_idx = nullptr, *out_order = nullptr, *out_nnz = nullptr;
+    double* out_val = nullptr;
+    int algo = -1;
+    bool begun = false;
+};
+
+struct csmp_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipDeviceProp_t prop{};
+    std::string err;
+    // dictionary
+    void* dA = nullptr;
+    bool ownA = false;
+    int dtype = CSMP_F32;
+    int64_t M = 0, N = 0, ld = 0;
+    int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
+    int sweep_grid = 0, sweep_U = 1;
+    bool sweep_full = false, sweep_nt = false;
+    size_t sweep_lds = 0;
+    Solver s;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    int64_t prof_n = 0;
+    double prof_ms = 0.0;
+};
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[512];                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                       \
+            ctx->err = buf_;                                                                    \
+            return CSMP_EHIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+#define CHECK(expr)                  \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != CSMP_OK) return rc_; \
+    } while (0)
+
+static int fail(csmp_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <typename T>
+static int dmalloc(csmp_ctx* ctx, T** p, size_t n) {
+    HIPCHECK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return CSMP_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------ lifetime
+extern "C" int csmp_version(void) { return 100; }
+
+extern "C" const char* csmp_last_error(const csmp_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int csmp_create(csmp_ctx** out, int device_id) {
+    if (!out) return CSMP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_err = std::string("no HIP device visible: ") + hipGetErrorString(e) +
+                       " -- libcsmp has no CPU fallback";
+        return CSMP_EHIP;
+    }
+    if (device_id < 0 || device_id >= ndev) {
+        g_create_err = "device_id out of range";
+        return CSMP_EINVAL;
+    }
+    csmp_ctx* ctx = new csmp_ctx();
+    ctx->dev = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&ctx->prop, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_err = "hipSetDevice / hipStreamCreate failed";
+        delete ctx;
+        return CSMP_EHIP;
+    }
+    *out = ctx;
+    return CSMP_OK;
+}
+
+static void solver_free(Solver& s) {
+    dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
+    dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
+    dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
+    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val);
+    s = Solver();
+}
+
+extern "C" int csmp_destroy(csmp_ctx* ctx) {
+    if (!ctx) return CSMP_OK;
+    (void)hipSetDevice(ctx->dev);
+    (void)hipStreamSynchronize(ctx->stream);
+    solver_free(ctx->s);
+    if (ctx->ownA) dfree(ctx->dA);
+    for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_set_stream(csmp_ctx* ctx, void* hip_stream) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (hip_stream) {
+        ctx->stream = (hipStream_t)hip_stream;
+        ctx->own_stream = false;
+    } else {
+        HIPCHECK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return CSMP_OK;
+}
+
+extern "C" int csmp_sync(csmp_ctx* ctx) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
+}
+
+extern "C" int csmp_device_info(csmp_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes) {
+    if (!ctx) return CSMP_EINVAL;
+    if (name && name_len > 0) {
+        std::string n = std::string(ctx->prop.name) + " (" + ctx->prop.gcnArchName + ")";
+        snprintf(name, (size_t)name_len, "%s", n.c_str());
+    }
+    if (compute_units) *compute_units = ctx->prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ sweep launch
+template <typename TA, typename TACC, int U, bool FULL, bool NT>
+static hipError_t sweep_launch_t(csmp_ctx* ctx, int grid, size_t lds, const double* r, double eps, int check_eps, int skipmask) {
+    auto kern = k_sweep<TA, TACC, U, FULL, NT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                       ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask);
+    return hipGetLastError();
+}
+
+template <typename TA, typename TACC>
+static hipError_t sweep_dispatch(csmp_ctx* ctx, int U, bool full, bool nt, int grid, size_t lds, const double* r,
+                                 double eps, int check_eps, int skipmask) {
+    if (!full) return sweep_launch_t<TA, TACC, 1, false, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    if (U == 4) return nt ? sweep_launch_t<TA, TACC, 4, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
+                          : sweep_launch_t<TA, TACC, 4, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    if (U == 2) return nt ? sweep_launch_t<TA, TACC, 2, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
+                          : sweep_launch_t<TA, TACC, 2, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    return nt ? sweep_launch_t<TA, TACC, 1, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
+              : sweep_launch_t<TA, TACC, 1, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+}
+
+static int prof_mark(csmp_ctx* ctx) {
+    if (ctx->ev_used == ctx->ev.size()) {
+        hipEvent_t e;
+        HIPCHECK(hipEventCreate(&e));
+        ctx->ev.push_back(e);
+    }
+    HIPCHECK(hipEventRecord(ctx->ev[ctx->ev_used++], ctx->stream));
+    return CSMP_OK;
+}
+
+// one sweep with the product configuration (or an explicit experimental one)
+static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, int U, bool nt,
+                            bool f32acc, int grid) {
+    const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
+    const int rows = kWave * vec;
+    bool full = (ctx->Mv % (rows * U)) == 0;
+    if (!full && (ctx->Mv % rows) == 0) {  // fall back to the largest U that divides
+        for (int u : {2, 1})
+            if (u < U && ctx->Mv % (rows * u) == 0) {
+                U = u;
+                full = true;
+                break;
+            }
+    }
+    if (ctx->prof) CHECK(prof_mark(ctx));
+    hipError_t e;
+    if (ctx->dtype == CSMP_F32)
+        e = f32acc ? sweep_dispatch<float, float>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask)
+                   : sweep_dispatch<float, double>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
+    else
+        e = sweep_dispatch<double, double>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
+    HIPCHECK(e);
+    if (ctx->prof) CHECK(prof_mark(ctx));
+    return CSMP_OK;
+}
+
+static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
+    return launch_sweep_cfg(ctx, r, eps, check_eps, skipmask, ctx->sweep_U, ctx->sweep_nt, false, ctx->sweep_grid);
+}
+
+// ------------------------------------------------------------------------------------------ dictionary
+static int configure_sweep(csmp_ctx* ctx) {
+    const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
+    ctx->sweep_lds = sweep_lds_bytes(ctx->Mv, vec);
+    if (ctx->sweep_lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "M too large: the residual must fit the 160 KiB LDS");
+    ctx->sweep_U = 4;
+    ctx->sweep_nt = false;
+    // resident workgroups: LDS- and wave-limited (<=128 VGPRs -> 4 waves/SIMD -> 4 workgroups/CU)
+    int per_cu = (int)std::min<size_t>(4, (160 * 1024) / ctx->sweep_lds);
+    if (per_cu < 1) per_cu = 1;
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kCPW - 1) / ((kSweepThreads / kWave) * kCPW);
+    int64_t grid = (int64_t)ctx->prop.multiProcessorCount * per_cu;
+    ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
+    return CSMP_OK;
+}
+
+extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!A || M < 1 || N < 1 || ldA < M) return fail(ctx, CSMP_EDIM, "set_dictionary: need A != NULL, M,N >= 1, ldA >= M");
+    if (dtype != CSMP_F32 && dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "set_dictionary: dtype must be CSMP_F32 or CSMP_F64");
+    if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->ownA) dfree(ctx->dA);
+    ctx->dA = nullptr;
+    ctx->ownA = false;
+    solver_free(ctx->s);
+    const size_t es = dtype == CSMP_F32 ? 4 : 8;
+    const int vec = 16 / (int)es;
+    const bool borrow = loc == CSMP_DEVICE && ((uintptr_t)A % 16 == 0) && (M % vec == 0) && (ldA % vec == 0);
+    ctx->dtype = dtype;
+    ctx->M = M;
+    ctx->N = N;
+    if (borrow) {
+        ctx->dA = const_cast<void*>(A);
+        ctx->ld = ldA;
+        ctx->Mv = (int)M;
+    } else {
+        const int64_t ld = ((M + vec - 1) / vec) * vec;
+        void* d = nullptr;
+        HIPCHECK(hipMalloc(&d, (size_t)ld * (size_t)N * es));
+        ctx->dA = d;
+        ctx->ownA = true;
+        ctx->ld = ld;
+        ctx->Mv = (int)ld;
+        if (ld != M) HIPCHECK(hipMemsetAsync(d, 0, (size_t)ld * (size_t)N * es, ctx->stream));
+        HIPCHECK(hipMemcpy2DAsync(d, (size_t)ld * es, A, (size_t)ldA * es, (size_t)M * es, (size_t)N,
+                                  loc == CSMP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return configure_sweep(ctx);
+}
+
+// ------------------------------------------------------------------------------------------ solver buffers
+static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    Solver& s = ctx->s;
+    if (s.kcap >= kcap && s.outcap >= outcap) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    kcap = std::max(kcap, s.kcap);
+    outcap = std::max(outcap, s.outcap);
+    solver_free(s);
+    const int M = (int)ctx->M;
+    s.kcap = kcap;
+    s.outcap = outcap;
+    s.ldq = ((M + kSlabRows - 1) / kSlabRows) * kSlabRows;
+    s.G = (int)(s.ldq / kSlabRows);
+    s.Mpad = ((M + 255) / 256) * 256;
+    s.jpad = qr_jpad(kcap);
+    if (qr_lds_bytes(kcap) > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "sparsity too large for the on-device QR (LDS)");
+    const int maxgrid = ctx->prop.multiProcessorCount * 8 + 8;
+    CHECK(dmalloc(ctx, &s.b, s.Mpad));
+    CHECK(dmalloc(ctx, &s.r, s.Mpad));
+    CHECK(dmalloc(ctx, &s.bstage, s.Mpad));
+    CHECK(dmalloc(ctx, &s.avec, s.Mpad));
+    CHECK(dmalloc(ctx, &s.vvec, s.Mpad));
+    CHECK(dmalloc(ctx, &s.cvec, (size_t)ctx->N));
+    CHECK(dmalloc(ctx, &s.pval, maxgrid));
+    CHECK(dmalloc(ctx, &s.pidx, maxgrid));
+    CHECK(dmalloc(ctx, &s.Q, (size_t)s.ldq * kcap));
+    CHECK(dmalloc(ctx, &s.R, (size_t)kcap * kcap));
+    CHECK(dmalloc(ctx, &s.z, kcap));
+    CHECK(dmalloc(ctx, &s.W1, kcap));
+    CHECK(dmalloc(ctx, &s.coef, kcap));
+    CHECK(dmalloc(ctx, &s.P1, (size_t)s.G * kcap));
+    CHECK(dmalloc(ctx, &s.P2, (size_t)s.G * kcap));
+    CHECK(dmalloc(ctx, &s.P2s, (size_t)2 * s.G));
+    CHECK(dmalloc(ctx, &s.scal, 8));
+    CHECK(dmalloc(ctx, &s.sel, kcap));
+    CHECK(dmalloc(ctx, &s.cands, kcap));
+    CHECK(dmalloc(ctx, &s.ncands, 4));
+    CHECK(dmalloc(ctx, &s.st, 1));
+    CHECK(dmalloc(ctx, &s.out_idx, outcap));
+    CHECK(dmalloc(ctx, &s.out_order, outcap));
+    CHECK(dmalloc(ctx, &s.out_val, outcap));
+    CHECK(dmalloc(ctx, &s.out_nnz, 1));
+    HIPCHECK(hipMemsetAsync(s.st, 0, sizeof(DevState), ctx->stream));
+    return CSMP_OK;
+}
+
+// b (host, any dtype) -> device Float64 b and r, state reset
+static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
+    Solver& s = ctx->s;
+    const int M = (int)ctx->M;
+    std::vector<double> hb((size_t)M);
+    if (b_dtype == CSMP_F32)
+        for (int i = 0; i < M; ++i) hb[i] = (double)((const float*)b)[i];
+    else if (b_dtype == CSMP_F64)
+        memcpy(hb.data(), b, (size_t)M * sizeof(double));
+    else
+        return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    HIPCHECK(hipMemcpyAsync(s.bstage, hb.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // hb goes out of scope
+    hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+template <typename TB>
+static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ step chains
+static int launch_select(csmp_ctx* ctx, int mode, int skipmask) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_select, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx,
+                       ctx->sweep_grid, (const double*)s.cvec, (const int*)s.sel, s.st, (int)ctx->M, s.kcap, mode, skipmask);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// add_column!(AiQR, A[:, cand]) + residual update for the candidate the control kernel accepted
+static int launch_append(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    const size_t lds = qr_lds_bytes(s.kcap);
+    if (lds > 64 * 1024) {
+        HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_qr2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHECK(hipFuncSetAttribute((const void*)k_qr3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)ctx->dA, ctx->ld,
+                           (int)ctx->M, (const double*)s.Q, s.ldq, (const DevState*)s.st, s.avec, s.P1, s.kcap, s.jpad);
+    else
+        hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)ctx->dA, ctx->ld,
+                           (int)ctx->M, (const double*)s.Q, s.ldq, (const DevState*)s.st, s.avec, s.P1, s.kcap, s.jpad);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)s.Q, s.ldq,
+                       (const DevState*)s.st, (const double*)s.avec, (const double*)s.r, (const double*)s.P1, s.G, s.W1,
+                       s.vvec, s.P2, s.P2s, s.kcap, s.jpad);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_qr3, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.vvec, s.r,
+                       (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, s.jpad);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+static int launch_mp_update(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    const int grid = ((int)ctx->M + 255) / 256;
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_mp_update<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, s.r, s.st, s.sel, s.z);
+    else
+        hipLaunchKernelGGL(k_mp_update<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, s.r, s.st, s.sel, s.z);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// update!(P::OMP, x) + the driver's residual check of the PREVIOUS iteration (src/matchingpursuit.jl:62-70,79)
+static int omp_step(csmp_ctx* ctx, double eps, int check_eps) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL;
+    CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skip));
+    CHECK(launch_select(ctx, 1, skip));
+    return launch_append(ctx);
+}
+
+// ldiv! + SparseVector assembly into device outputs
+static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap) {
+    Solver& s = ctx->s;
+    const size_t lds = (size_t)(s.kcap + 2) * sizeof(double);
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
+                       (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+static int download_result(csmp_ctx* ctx, int outcap, int64_t* idx, double* val, int64_t* nnz, int64_t* order) {
+    Solver& s = ctx->s;
+    std::vector<int64_t> hi((size_t)outcap), ho((size_t)outcap);
+    std::vector<double> hv((size_t)outcap);
+    int64_t hn = 0;
+    HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(ho.data(), s.out_order, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(&hn, s.out_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (int64_t t = 0; t < hn; ++t) {
+        if (idx) idx[t] = hi[t];
+        if (val) val[t] = hv[t];
+        if (order) order[t] = ho[t];
+    }
+    if (nnz) *nnz = hn;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ drivers
+extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double eps, int64_t* idx, double* val,
+                        int64_t* nnz, int64_t* order) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:74
+    if (!b || k < 0) return fail(ctx, CSMP_EINVAL, "omp: b == NULL or k < 0");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // UpdatableQR(T, n, k): :58
+    CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k, 1)));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    for (int64_t t = 0; t < k; ++t) CHECK(omp_step(ctx, eps, t > 0));
+    CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+}
+
+extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                              double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (!B || nsig < 0 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    CHECK(solver_ensure(ctx, kc, (int)k));
+    ctx->s.begun = false;
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    bool ownB = false;
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(hipMalloc(&dB, (size_t)ldB * (size_t)nsig * es));
+        ownB = true;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(hipMalloc((void**)&d_idx, (size_t)k * nsig * 8));
+        HIPCHECK(hipMalloc((void**)&d_val, (size_t)k * nsig * 8));
+        HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
+    }
+    int rc = CSMP_OK;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
+                                 : init_from_device_t<double>(ctx, (const double*)col);
+        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0);
+        if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k);
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_idx);
+        (void)hipFree(d_val);
+        (void)hipFree(d_nnz);
+    }
+    if (ownB) {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dB);
+    }
+    return rc;
+}
+
+// warm start: support/values -> device lists, r = b - A x
+static int upload_support(csmp_ctx* ctx, const int64_t* idx0, const double* val0, int64_t nnz0) {
+    Solver& s = ctx->s;
+    std::vector<int> hi((size_t)nnz0);
+    for (int64_t t = 0; t < nnz0; ++t) {
+        if (idx0[t] < 0 || idx0[t] >= ctx->N) return fail(ctx, CSMP_ERANGE, "warm start: index out of range");
+        hi[t] = (int)idx0[t];
+    }
+    HIPCHECK(hipMemcpyAsync(s.cands, hi.data(), (size_t)nnz0 * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.coef, val0, (size_t)nnz0 * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int grid = ((int)ctx->M + 255) / 256;
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_residual<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M,
+                           (const int*)s.cands, (const double*)s.coef, (const int*)nullptr, (int)nnz0, (const double*)s.b, s.r);
+    else
+        hipLaunchKernelGGL(k_residual<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M,
+                           (const int*)s.cands, (const double*)s.coef, (const int*)nullptr, (int)nnz0, (const double*)s.b, s.r);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// MP bookkeeping on the host side of the boundary: the device returns the k (atom, <a,r>) pairs in
+// step order; x[i] += d is replayed in that order (same summation order as src/matchingpursuit.jl:29)
+static int mp_collect(csmp_ctx* ctx, const int64_t* idx0, const double* val0, int64_t nnz0, int64_t* idx, double* val,
+                      int64_t* nnz) {
+    Solver& s = ctx->s;
+    DevState hs;
+    HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int n = hs.nsel;
+    std::vector<int> hsel((size_t)std::max(n, 1));
+    std::vector<double> hz((size_t)std::max(n, 1));
+    HIPCHECK(hipMemcpy(hsel.data(), s.sel, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(hz.data(), s.z, (size_t)n * 8, hipMemcpyDeviceToHost));
+    std::vector<std::pair<int64_t, double>> x;
+    for (int64_t t = 0; t < nnz0; ++t) x.push_back({idx0[t], val0[t]});
+    std::sort(x.begin(), x.end(), [](auto& a, auto& c) { return a.first < c.first; });
+    for (int t = 0; t < n; ++t) {
+        auto it = std::lower_bound(x.begin(), x.end(), (int64_t)hsel[t], [](auto& a, int64_t v) { return a.first < v; });
+        if (it != x.end() && it->first == hsel[t])
+            it->second += hz[t];
+        else if (hz[t] != 0.0)  // SparseVector setindex! does not store a structural zero
+            x.insert(it, {(int64_t)hsel[t], hz[t]});
+    }
+    for (size_t t = 0; t < x.size(); ++t) {
+        if (idx) idx[t] = x[t].first;
+        if (val) val[t] = x[t].second;
+    }
+    if (nnz) *nnz = (int64_t)x.size();
+    return CSMP_OK;
+}
+
+static int mp_step(csmp_ctx* ctx) {
+    CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+    CHECK(launch_select(ctx, 0, 0));
+    return launch_mp_update(ctx);
+}
+
+extern "C" int csmp_mp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, const int64_t* idx0, const double* val0,
+                       int64_t nnz0, int64_t* idx, double* val, int64_t* nnz) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 0 || nnz0 < 0 || (nnz0 > 0 && (!idx0 || !val0))) return fail(ctx, CSMP_EINVAL, "mp: bad arguments");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(std::max(k, nnz0), 1), 1));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    if (nnz0 > 0) CHECK(upload_support(ctx, idx0, val0, nnz0));
+    for (int64_t t = 0; t < k; ++t) CHECK(mp_step(ctx));
+    return mp_collect(ctx, idx0, val0, nnz0, idx, val, nnz);
+}
+
+// ------------------------------------------------------------------------------------------ step-level API
+extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_dtype, int64_t kcap, const int64_t* idx0,
+                                 const double* val0, int64_t nnz0) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || kcap < 1) return fail(ctx, CSMP_EINVAL, "solver_begin: bad arguments");
+    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP) return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = algo == CSMP_ALGO_MP ? (int)kcap : (int)std::min<int64_t>(kcap, ctx->M);
+    CHECK(solver_ensure(ctx, kc, kc));
+    CHECK(upload_b(ctx, b, b_dtype));
+    if (nnz0 > 0) {
+        if (algo != CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "warm start is only defined for MP (src/matchingpursuit.jl:34)");
+        CHECK(upload_support(ctx, idx0, val0, nnz0));
+    }
+    ctx->s.algo = algo;
+    ctx->s.begun = true;
+    return CSMP_OK;
+}
+
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask);
+
+extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_step: no solver begun");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    switch (ctx->s.algo) {
+        case CSMP_ALGO_MP: return mp_step(ctx);
+        case CSMP_ALGO_OMP: {
+            // update!(P::OMP, x) alone: no eps logic (that belongs to the omp driver)
+            CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
+            CHECK(launch_select(ctx, 1, STOP_FULL));
+            return launch_append(ctx);
+        }
+        default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL);
+    }
+}
+
+extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64_t* nnz, double* resnorm, int64_t* order,
+                                 int* stop) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_state: no solver begun");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Solver& s = ctx->s;
+    if (resnorm) {
+        hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+        HIPCHECK(hipGetLastError());
+        double n2 = 0.0;
+        HIPCHECK(hipMemcpyAsync(&n2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        *resnorm = std::sqrt(n2);
+    }
+    if (stop) {
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        *stop = hs.done;
+    }
+    if (s.algo == CSMP_ALGO_MP) return mp_collect(ctx, nullptr, nullptr, 0, idx, val, nnz);
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    return download_result(ctx, s.outcap, idx, val, nnz, order);
+}
+
+// ------------------------------------------------------------------------------------------ not yet built
+static int gomp_update(csmp_ctx* ctx, int64_t, double, int, int) { return fail(ctx, CSMP_ESTATE, "gomp: not built yet"); }
+extern "C" int csmp_gomp(csmp_ctx* ctx, const void*, int, int64_t, int64_t, double, int64_t*, double*, int64_t*, int64_t*) {
+    return fail(ctx, CSMP_ESTATE, "gomp: not built yet");
+}
+extern "C" int csmp_sp(csmp_ctx* ctx, const void*, int, int64_t, double, int64_t, int64_t*, double*, int64_t*, int64_t*) {
+    return fail(ctx, CSMP_ESTATE, "sp: not built yet");
+}
+extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t*, int64_t, const void*, int, double*) {
+    return fail(ctx, CSMP_ESTATE, "lstsq: not built yet");
+}
+
+// ------------------------------------------------------------------------------------------ primitives
+extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int64_t topk, int64_t* top_idx, double* top_val) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!r || topk < 0) return fail(ctx, CSMP_EINVAL, "sweep: bad arguments");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (topk > 1) return fail(ctx, CSMP_ESTATE, "sweep: topk > 1 not built yet");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, 1, 1));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, r, CSMP_F64));
+    CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+    CHECK(launch_select(ctx, 0, 0));
+    if (abs_corr) {
+        HIPCHECK(hipMemcpyAsync(abs_corr, ctx->s.cvec, (size_t)ctx->N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < ctx->N; ++i) abs_corr[i] = std::fabs(abs_corr[i]);  // @. Ar = abs(Ar) on the way out
+    }
+    if (topk == 1) {
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (top_idx) top_idx[0] = hs.cand;
+        if (top_val) top_val[0] = std::fabs(hs.cval);
+    }
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ measurement
+extern "C" int csmp_profile_enable(csmp_ctx* ctx, int on) {
+    if (!ctx) return CSMP_EINVAL;
+    ctx->prof = on != 0;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double* sweep_ms, int reset) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+        ctx->prof_ms += ms;
+        ctx->prof_n += 1;
+    }
+    ctx->ev_used = 0;
+    if (sweep_launches) *sweep_launches = ctx->prof_n;
+    if (sweep_ms) *sweep_ms = ctx->prof_ms;
+    if (reset) {
+        ctx->prof_n = 0;
+        ctx->prof_ms = 0.0;
+    }
+    return CSMP_OK;
+}
+
+// variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (0 = product configuration)
+extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
+    if (!ctx || reps < 1) return CSMP_EINVAL;
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, 1, 1));
+    ctx->s.begun = false;
+    std::vector<double> r((size_t)ctx->M);
+    uint64_t sd = 0x9E3779B97F4A7C15ull;
+    for (auto& v : r) {
+        sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+        v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5;
+    }
+    CHECK(upload_b(ctx, r.data(), CSMP_F64));
+    int U = ctx->sweep_U, grid = ctx->sweep_grid;
+    bool nt = ctx->sweep_nt, f32acc = false;
+    if (variant != 0) {
+        U = variant & 7;
+        nt = (variant & 8) != 0;
+        f32acc = (variant & 16) != 0;
+        const int per_cu = (variant >> 8) & 0xff;
+        if (per_cu > 0) {
+            const int64_t groups = (ctx->N + 15) / 16;
+            grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * per_cu, groups));
+        }
+        if (U != 1 && U != 2 && U != 4) return fail(ctx, CSMP_EINVAL, "bench_sweep: U must be 1, 2 or 4");
+    }
+    const bool was = ctx->prof;
+    ctx->prof = false;
+    for (int i = 0; i < 3; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
+    HIPCHECK(hipEventRecord(e1, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->prof = was;
+    if (avg_ms) *avg_ms = (double)ms / reps;
+    return CSMP_OK;
+}

@@ -1,0 +1,141 @@
+/*
+ * csmp.h -- C ABI of libcsmp.so: the MI355X (gfx950) matching-pursuit path of
+ * CompressedSensing.jl (mp / omp / gomp / sp and their step primitives).
+ *
+ * The reference is pure Julia and has no FFI seam of its own; the seam is the set of methods
+ * dispatched on AbstractMatchingPursuit plus the UpdatableQR API they call.
+ * Each entry point below names the reference interface it replaces (paths relative to the
+ * reference repository).  A Julia host binds these with `ccall` (see INTEGRATION.md and
+ * compressedsensing.jl_amd/julia/CompressedSensingAMD.jl); the Python host mirror binds them
+ * with ctypes (compressedsensing.jl_amd/_lib.py).
+ *
+ * Conventions
+ *   - A: dense column-major, M rows (signal length) x N columns (atoms), leading dimension ldA
+ *     in elements, element type CSMP_F32 or CSMP_F64.  NOTE the reference names these
+ *     `n, m = size(A)` (src/matchingpursuit.jl:20); BASELINE.json uses m=rows, n=cols.
+ *   - All selection arithmetic is Float64 on the exactly promoted dictionary values, so an f32
+ *     dictionary yields the support a Float64 run of the reference would select on the same values.
+ *   - Results follow SparseVector{Float64,Int64} (src/matchingpursuit.jl:76): indices sorted
+ *     ascending (0-BASED here; the Julia wrapper adds 1), values aligned, nnz may be < k.
+ *   - Every call returns a status (0 = ok, negative = error); csmp_last_error() gives the text.
+ *   - A ctx is bound to one GPU and one HIP stream and is not thread-safe (the reference is
+ *     single-threaded too).  Caller owns every buffer passed in; the library owns device memory
+ *     behind the opaque ctx.  `loc` says where a caller buffer lives: CSMP_HOST or CSMP_DEVICE.
+ */
+#ifndef CSMP_H
+#define CSMP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSMP_OK 0
+#define CSMP_EINVAL (-1) /* eps < 0 (reference: throw("eps has to be non-negative"), src/matchingpursuit.jl:74,127), bad argument */
+#define CSMP_EDIM (-2)   /* length(b) != size(A,1) and the like */
+#define CSMP_ERANGE (-3) /* 2k > M for SP (reference: error(...), src/twostage.jl:55); k out of range */
+#define CSMP_EHIP (-4)   /* HIP runtime failure / no gfx950 device */
+#define CSMP_ESTATE (-5) /* no dictionary set / no solver begun */
+#define CSMP_ENOMEM (-6)
+
+#define CSMP_F32 0
+#define CSMP_F64 1
+#define CSMP_HOST 0
+#define CSMP_DEVICE 1
+
+#define CSMP_ALGO_MP 0
+#define CSMP_ALGO_OMP 1
+#define CSMP_ALGO_GOMP 2
+
+/* why a solve stopped early (csmp_solver_state: *stop) */
+#define CSMP_STOP_NONE 0
+#define CSMP_STOP_EPS 1    /* norm(residual) < eps: src/matchingpursuit.jl:79,132 */
+#define CSMP_STOP_STAG 2   /* arg-max atom already selected: src/matchingpursuit.jl:66 */
+#define CSMP_STOP_FULL 4   /* nnz(x) == size(A,1): src/matchingpursuit.jl:63,117 */
+
+typedef struct csmp_ctx csmp_ctx;
+
+/* ------------------------------------------------------------------ lifetime */
+int csmp_version(void);
+int csmp_create(csmp_ctx **out, int device_id);
+int csmp_destroy(csmp_ctx *ctx);
+const char *csmp_last_error(const csmp_ctx *ctx); /* ctx may be NULL: last create error */
+/* borrow a caller's hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = own stream */
+int csmp_set_stream(csmp_ctx *ctx, void *hip_stream);
+int csmp_sync(csmp_ctx *ctx);
+/* name (<=255 chars), compute-unit count and total HBM bytes of the bound device */
+int csmp_device_info(csmp_ctx *ctx, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------ dictionary
+ * Replaces the `A` field of MP/OMP/GOMP/SP (src/matchingpursuit.jl:10-24,44-60,95-114;
+ * src/twostage.jl:42-61).  Uploaded once, stays resident in HBM.  A CSMP_DEVICE pointer that is
+ * 16-byte aligned with M and ldA multiples of 16 bytes is borrowed without a copy. */
+int csmp_set_dictionary(csmp_ctx *ctx, const void *A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc);
+
+/* ------------------------------------------------------------------ drivers (synchronous)
+ * b: length M, element type b_dtype, host memory.  idx/val/order: caller arrays of capacity
+ * given per function; *nnz receives the count.  order (may be NULL): atoms in selection order. */
+
+/* mp(A,b,k,x): src/matchingpursuit.jl:26-40.  x0 = optional warm start (idx0 sorted or not).
+ * idx/val capacity k + nnz0. */
+int csmp_mp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, const int64_t *idx0, const double *val0,
+            int64_t nnz0, int64_t *idx, double *val, int64_t *nnz);
+
+/* omp(A,b,eps,k): src/matchingpursuit.jl:62-82 (update! :62-70).  The caller supplies eps
+ * (the Julia/Python wrappers default it to eps(eltype(A)): :85,89).  Capacity k. */
+int csmp_omp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double eps, int64_t *idx, double *val,
+             int64_t *nnz, int64_t *order);
+
+/* gomp(A,b,l,eps,k): src/matchingpursuit.jl:116-139, including the remainder step :134-137.
+ * Capacity k + l. */
+int csmp_gomp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t l, int64_t k, double eps, int64_t *idx,
+              double *val, int64_t *nnz, int64_t *order);
+
+/* sp(A,b,k,delta;maxiter): src/twostage.jl:54-107.  maxiter < 0 selects the default 16k.
+ * Capacity 2k.  *iters (may be NULL) = number of update! calls made. */
+int csmp_sp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t *idx,
+            double *val, int64_t *nnz, int64_t *iters);
+
+/* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
+ * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
+ * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);
+ * outputs idx (k x nsig, int64, unused tail = -1), val (k x nsig, f64, unused tail = 0),
+ * nnz (nsig) on host or device (out_loc).  With out_loc == CSMP_DEVICE the call only enqueues
+ * work on the ctx stream (no host synchronisation): call csmp_sync() before reading. */
+int csmp_omp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                   double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+
+/* ------------------------------------------------------------------ step-level API
+ * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) then update!(P,x)
+ * (src/CompressedSensing.jl:22-23; src/matchingpursuit.jl:26,62,116).  The solver state
+ * (residual, on-device QR, support) lives in the ctx. */
+int csmp_solver_begin(csmp_ctx *ctx, int algo, const void *b, int b_dtype, int64_t kcap,
+                      const int64_t *idx0, const double *val0, int64_t nnz0);
+/* one update!: MP/OMP ignore l; GOMP adds the l best atoms */
+int csmp_solver_step(csmp_ctx *ctx, int64_t l);
+/* current x (sorted), ||b - A x||_2, selection order, stop reason.  Any pointer may be NULL. */
+int csmp_solver_state(csmp_ctx *ctx, int64_t *idx, double *val, int64_t *nnz, double *resnorm,
+                      int64_t *order, int *stop);
+
+/* ------------------------------------------------------------------ primitives
+ * argmaxinner!(P) / argmaxinner!(P,k): src/matchingpursuit.jl:181-193.  r: length-M Float64
+ * host vector.  abs_corr (may be NULL): receives |A' r| (length N).  top_idx/top_val: the
+ * topk atoms, descending by |<a_i, r>|, ties by ascending index (partialsortperm, :192). */
+int csmp_sweep(csmp_ctx *ctx, const double *r, double *abs_corr, int64_t topk, int64_t *top_idx, double *top_val);
+
+/* A[:, cols] \ b by the on-device QR: the UpdatableQR solve pinned by test/forward.jl:23-28
+ * ("P.AiQR \ y ~ A[:, nzind] \ y").  cols in any order; coef aligned with cols. */
+int csmp_lstsq(csmp_ctx *ctx, const int64_t *cols, int64_t ncols, const void *b, int b_dtype, double *coef);
+
+/* ------------------------------------------------------------------ measurement
+ * When enabled, every sweep launch is bracketed by HIP events on the ctx stream. */
+int csmp_profile_enable(csmp_ctx *ctx, int on);
+/* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
+int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);
+/* one-off sweep bandwidth probe: runs `reps` sweeps on a random residual, returns avg ms.
+ * variant: 0 = product kernel; others = experimental variants */
+int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,510 @@
+/*
+ * csmp_oracle.c -- CPU restatement (Float64) of CompressedSensing.jl's mp / omp / gomp / sp.
+ *
+ * TEST INFRASTRUCTURE ONLY -- see csmp_oracle.h for the rules and the parity-pin status
+ * ("parity unpinned" for step order / stagnation / eps-stop / tie-breaks: the reference's
+ * tests do not cover them and the reference cannot be run here).
+ *
+ * Every function cites the reference lines it restates (paths relative to /root/reference).
+ * The third-party UpdatableQRFactorizations.jl (v1.0.0, not vendored) is replaced by an
+ * append-style Householder QR (hqr_*): the least-squares solution on a full-column-rank
+ * support is unique, so any backward-stable QR returns the same coefficients to ~cond*eps;
+ * the reference's "insert at sorted position" (src/util.jl:122-123) only permutes them, which
+ * we reproduce by reporting coefficients in sorted-index order.
+ */
+#include "csmp_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ---------------------------------------------------------------- element access */
+static inline double a_at(const void *A, int dtype, int64_t ld, int64_t row, int64_t col) {
+    return dtype == CSO_F32 ? (double)((const float *)A)[col * ld + row]
+                            : ((const double *)A)[col * ld + row];
+}
+
+static void col_to_f64(const void *A, int dtype, int64_t M, int64_t ld, int64_t col, double *out) {
+    if (dtype == CSO_F32) {
+        const float *p = (const float *)A + col * ld;
+        for (int64_t i = 0; i < M; ++i) out[i] = (double)p[i];
+    } else {
+        memcpy(out, (const double *)A + col * ld, (size_t)M * sizeof(double));
+    }
+}
+
+static double col_dot(const void *A, int dtype, int64_t M, int64_t ld, int64_t col, const double *r) {
+    double acc = 0.0;
+    if (dtype == CSO_F32) {
+        const float *p = (const float *)A + col * ld;
+#pragma omp simd reduction(+ : acc)
+        for (int64_t i = 0; i < M; ++i) acc += (double)p[i] * r[i];
+    } else {
+        const double *p = (const double *)A + col * ld;
+#pragma omp simd reduction(+ : acc)
+        for (int64_t i = 0; i < M; ++i) acc += p[i] * r[i];
+    }
+    return acc;
+}
+
+static double nrm2(const double *x, int64_t n) { /* norm(): 2-norm */
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += x[i] * x[i];
+    return sqrt(s);
+}
+
+/* ---------------------------------------------------------------- sparse vector x
+ * SparseVector{Float64,Int64}: sorted nzind + aligned nzval (src/matchingpursuit.jl:76). */
+typedef struct {
+    int64_t *idx;
+    double *val;
+    int64_t nnz, cap;
+} spvec_t;
+
+static int sp_init(spvec_t *x, int64_t cap) {
+    x->idx = (int64_t *)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(int64_t));
+    x->val = (double *)malloc((size_t)(cap > 0 ? cap : 1) * sizeof(double));
+    x->nnz = 0;
+    x->cap = cap;
+    return (x->idx && x->val) ? 0 : -1;
+}
+static void sp_free(spvec_t *x) {
+    free(x->idx);
+    free(x->val);
+}
+/* position of i in nzind, or -(insertion point)-1 */
+static int64_t sp_find(const spvec_t *x, int64_t i) {
+    int64_t lo = 0, hi = x->nnz;
+    while (lo < hi) {
+        int64_t mid = (lo + hi) / 2;
+        if (x->idx[mid] < i)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    if (lo < x->nnz && x->idx[lo] == i) return lo;
+    return -lo - 1;
+}
+/* x[i] = v on a SparseVector: overwrite if stored, else insert keeping nzind sorted */
+static int64_t sp_set(spvec_t *x, int64_t i, double v) {
+    int64_t p = sp_find(x, i);
+    if (p >= 0) {
+        x->val[p] = v;
+        return p;
+    }
+    p = -p - 1;
+    if (x->nnz == x->cap) {
+        int64_t nc = x->cap * 2 + 4;
+        x->idx = (int64_t *)realloc(x->idx, (size_t)nc * sizeof(int64_t));
+        x->val = (double *)realloc(x->val, (size_t)nc * sizeof(double));
+        x->cap = nc;
+    }
+    memmove(x->idx + p + 1, x->idx + p, (size_t)(x->nnz - p) * sizeof(int64_t));
+    memmove(x->val + p + 1, x->val + p, (size_t)(x->nnz - p) * sizeof(double));
+    x->idx[p] = i;
+    x->val[p] = v;
+    x->nnz++;
+    return p;
+}
+
+/* ---------------------------------------------------------------- residual!
+ * src/matchingpursuit.jl:158-161: copyto!(r, b); mul!(r, A, x, -1, 1) */
+void cso_residual(const void *A, int dtype, int64_t M, int64_t ld, const int64_t *idx,
+                  const double *val, int64_t nnz, const double *b, double *r) {
+    memcpy(r, b, (size_t)M * sizeof(double));
+    for (int64_t t = 0; t < nnz; ++t) {
+        const double xv = val[t];
+        const int64_t c = idx[t];
+        if (dtype == CSO_F32) {
+            const float *p = (const float *)A + c * ld;
+            for (int64_t i = 0; i < M; ++i) r[i] -= (double)p[i] * xv;
+        } else {
+            const double *p = (const double *)A + c * ld;
+            for (int64_t i = 0; i < M; ++i) r[i] -= p[i] * xv;
+        }
+    }
+}
+
+/* ---------------------------------------------------------------- argmaxinner!
+ * src/matchingpursuit.jl:181-185: mul!(Ar, A', r); Ar = abs(Ar); argmax(Ar)
+ * Julia's argmax returns the FIRST maximal index. */
+int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,
+                      double *out, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t j = 0; j < N; ++j) out[j] = fabs(col_dot(A, dtype, M, ld, j, r));
+    int64_t best = 0;
+    for (int64_t j = 1; j < N; ++j)
+        if (out[j] > out[best]) best = j;
+    return best;
+}
+
+/* signed variant for mp's coefficient dot(A[:,i], r): src/matchingpursuit.jl:29 */
+static double signed_dot(const void *A, int dtype, int64_t M, int64_t ld, int64_t col, const double *r) {
+    return col_dot(A, dtype, M, ld, col, r);
+}
+
+/* ---------------------------------------------------------------- partialsortperm(v,1:k,rev=true)
+ * src/matchingpursuit.jl:192.  Julia's Perm ordering: descending by value, ties broken by
+ * ascending index. */
+typedef struct {
+    double v;
+    int64_t i;
+} vi_t;
+static int cmp_desc(const void *pa, const void *pb) {
+    const vi_t *a = (const vi_t *)pa, *b = (const vi_t *)pb;
+    if (a->v > b->v) return -1;
+    if (a->v < b->v) return 1;
+    return (a->i > b->i) - (a->i < b->i);
+}
+static int cmp_asc(const void *pa, const void *pb) {
+    const vi_t *a = (const vi_t *)pa, *b = (const vi_t *)pb;
+    if (a->v < b->v) return -1;
+    if (a->v > b->v) return 1;
+    return (a->i > b->i) - (a->i < b->i);
+}
+void cso_topk_desc(const double *v, int64_t n, int64_t k, int64_t *out) {
+    vi_t *t = (vi_t *)malloc((size_t)n * sizeof(vi_t));
+    for (int64_t i = 0; i < n; ++i) {
+        t[i].v = v[i];
+        t[i].i = i;
+    }
+    qsort(t, (size_t)n, sizeof(vi_t), cmp_desc);
+    if (k > n) k = n;
+    for (int64_t i = 0; i < k; ++i) out[i] = t[i].i;
+    free(t);
+}
+
+/* ---------------------------------------------------------------- append-style Householder QR
+ * Stands in for UpdatableQR(T, n, k) + add_column! + ldiv! (call sites:
+ * src/matchingpursuit.jl:58,112,175; src/util.jl:123) and for qr!/ldiv! in factorize!/solve!
+ * (src/matchingpursuit.jl:219-227; src/twostage.jl:104-107). */
+typedef struct {
+    int64_t M, cap, j;
+    double *V;    /* M x cap: reflector i lives in V[i*M + i .. i*M + M) */
+    double *beta; /* cap */
+    double *R;    /* cap x cap, column-major, upper triangular */
+    double *w;    /* M scratch */
+} hqr_t;
+
+static int hqr_init(hqr_t *F, int64_t M, int64_t cap) {
+    if (cap > M) cap = M;
+    if (cap < 1) cap = 1;
+    F->M = M;
+    F->cap = cap;
+    F->j = 0;
+    F->V = (double *)calloc((size_t)M * (size_t)cap, sizeof(double));
+    F->beta = (double *)calloc((size_t)cap, sizeof(double));
+    F->R = (double *)calloc((size_t)cap * (size_t)cap, sizeof(double));
+    F->w = (double *)calloc((size_t)M, sizeof(double));
+    return (F->V && F->beta && F->R && F->w) ? 0 : -1;
+}
+static void hqr_free(hqr_t *F) {
+    free(F->V);
+    free(F->beta);
+    free(F->R);
+    free(F->w);
+}
+
+static void hqr_apply_qt(const hqr_t *F, double *y) { /* y <- Q' y */
+    const int64_t M = F->M;
+    for (int64_t i = 0; i < F->j; ++i) {
+        const double *v = F->V + i * M;
+        double s = 0.0;
+        for (int64_t t = i; t < M; ++t) s += v[t] * y[t];
+        s *= F->beta[i];
+        for (int64_t t = i; t < M; ++t) y[t] -= s * v[t];
+    }
+}
+
+/* add_column!(F, a): append a (length M) as the last column */
+static int hqr_append(hqr_t *F, const double *a) {
+    const int64_t M = F->M, j = F->j;
+    if (j >= F->cap) return -1;
+    double *w = F->w;
+    memcpy(w, a, (size_t)M * sizeof(double));
+    hqr_apply_qt(F, w);
+    double nrm = 0.0;
+    for (int64_t t = j; t < M; ++t) nrm += w[t] * w[t];
+    nrm = sqrt(nrm);
+    const double alpha = (w[j] > 0.0) ? -nrm : nrm;
+    double *v = F->V + j * M;
+    for (int64_t t = 0; t < j; ++t) v[t] = 0.0;
+    for (int64_t t = j; t < M; ++t) v[t] = w[t];
+    v[j] -= alpha;
+    double vtv = 0.0;
+    for (int64_t t = j; t < M; ++t) vtv += v[t] * v[t];
+    F->beta[j] = (vtv > 0.0) ? 2.0 / vtv : 0.0;
+    for (int64_t t = 0; t < j; ++t) F->R[j * F->cap + t] = w[t];
+    F->R[j * F->cap + j] = alpha;
+    F->j = j + 1;
+    return 0;
+}
+
+/* ldiv!(F, b): coefficient vector (insertion order) minimising ||A_S c - b|| */
+static void hqr_solve(const hqr_t *F, const double *b, double *c) {
+    const int64_t M = F->M, j = F->j;
+    double *y = (double *)malloc((size_t)M * sizeof(double));
+    memcpy(y, b, (size_t)M * sizeof(double));
+    hqr_apply_qt(F, y);
+    for (int64_t i = j - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int64_t t = i + 1; t < j; ++t) s -= F->R[t * F->cap + i] * c[t];
+        c[i] = s / F->R[i * F->cap + i];
+    }
+    free(y);
+}
+
+int cso_lstsq_cols(const void *A, int dtype, int64_t M, int64_t ld, const int64_t *cols, int64_t j,
+                   const double *b, double *coef) {
+    hqr_t F;
+    if (hqr_init(&F, M, j) != 0) return CSO_ENOMEM;
+    double *a = (double *)malloc((size_t)M * sizeof(double));
+    for (int64_t t = 0; t < j; ++t) {
+        col_to_f64(A, dtype, M, ld, cols[t], a);
+        hqr_append(&F, a);
+    }
+    hqr_solve(&F, b, coef);
+    free(a);
+    hqr_free(&F);
+    return CSO_OK;
+}
+
+/* ---------------------------------------------------------------- active set with updatable QR
+ * x (sorted) + the QR in insertion order + the map between the two.
+ * addindex!: src/util.jl:118-126;  ldiv!!: src/matchingpursuit.jl:170-176. */
+typedef struct {
+    spvec_t x;
+    hqr_t F;
+    int64_t *order; /* order[t] = atom appended t-th */
+    int64_t norder;
+    double *acol, *coef;
+} active_t;
+
+static int act_init(active_t *S, int64_t M, int64_t cap) {
+    if (cap > M) cap = M;
+    if (cap < 1) cap = 1;
+    memset(S, 0, sizeof(*S));
+    if (sp_init(&S->x, cap) != 0) return -1;
+    if (hqr_init(&S->F, M, cap) != 0) return -1;
+    S->order = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    S->acol = (double *)malloc((size_t)M * sizeof(double));
+    S->coef = (double *)malloc((size_t)cap * sizeof(double));
+    S->norder = 0;
+    return (S->order && S->acol && S->coef) ? 0 : -1;
+}
+static void act_free(active_t *S) {
+    sp_free(&S->x);
+    hqr_free(&S->F);
+    free(S->order);
+    free(S->acol);
+    free(S->coef);
+}
+/* addindex!(x, AiQR, a, i): only if i is not already in the support (src/util.jl:119) */
+static int act_add(active_t *S, const void *A, int dtype, int64_t M, int64_t ld, int64_t i) {
+    if (sp_find(&S->x, i) >= 0) return 0;
+    if (S->F.j >= S->F.cap) return 0; /* capacity = M: a thin QR cannot take more columns */
+    sp_set(&S->x, i, NAN);            /* x[i] = NaN placeholder (src/util.jl:120) */
+    col_to_f64(A, dtype, M, ld, i, S->acol);
+    hqr_append(&S->F, S->acol);
+    S->order[S->norder++] = i;
+    return 1;
+}
+/* ldiv!!(x.nzval, AiQR, b, r): x.nzval = AiQR \ b, in sorted-index order */
+static void act_solve(active_t *S, const double *b) {
+    hqr_solve(&S->F, b, S->coef);
+    for (int64_t t = 0; t < S->norder; ++t) {
+        int64_t p = sp_find(&S->x, S->order[t]);
+        S->x.val[p] = S->coef[t];
+    }
+}
+
+static void emit(const spvec_t *x, int64_t *idx, double *val, int64_t *nnz) {
+    for (int64_t t = 0; t < x->nnz; ++t) {
+        idx[t] = x->idx[t];
+        val[t] = x->val[t];
+    }
+    *nnz = x->nnz;
+}
+
+/* ---------------------------------------------------------------- mp
+ * src/matchingpursuit.jl:26-40.  update!: residual!; i = argmaxinner!; x[i] += dot(A[:,i], r) */
+int cso_mp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+           int64_t k, const int64_t *idx0, const double *val0, int64_t nnz0,
+           int64_t *idx, double *val, int64_t *nnz, int nthreads) {
+    spvec_t x;
+    if (sp_init(&x, k + nnz0) != 0) return CSO_ENOMEM;
+    for (int64_t t = 0; t < nnz0; ++t) sp_set(&x, idx0[t], val0[t]);
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *Ar = (double *)malloc((size_t)N * sizeof(double));
+    for (int64_t it = 0; it < k; ++it) {
+        cso_residual(A, dtype, M, ld, x.idx, x.val, x.nnz, b, r);     /* :27 */
+        const int64_t i = cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads); /* :28 */
+        const double d = signed_dot(A, dtype, M, ld, i, r);           /* :29 */
+        const int64_t p = sp_find(&x, i);
+        if (p >= 0)
+            x.val[p] += d;
+        else if (d != 0.0) /* SparseVector setindex! does not store a structural zero */
+            sp_set(&x, i, d);
+    }
+    emit(&x, idx, val, nnz);
+    free(r);
+    free(Ar);
+    sp_free(&x);
+    return CSO_OK;
+}
+
+/* ---------------------------------------------------------------- omp
+ * update!(P::OMP, x): src/matchingpursuit.jl:62-70;  driver omp(A,b,eps,k): :73-82 */
+int cso_omp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+            int64_t k, double eps, int64_t *idx, double *val, int64_t *nnz, int64_t *order,
+            int nthreads) {
+    if (!(eps >= 0.0)) return CSO_EINVAL; /* :74 */
+    active_t S;
+    if (act_init(&S, M, k) != 0) return CSO_ENOMEM; /* OMP(A,b,k): UpdatableQR(T,n,k) :58 */
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *Ar = (double *)malloc((size_t)N * sizeof(double));
+    for (int64_t it = 0; it < k; ++it) { /* :77 */
+        int progressed = 0;
+        if (S.x.nnz < M) {                                                       /* :63 */
+            cso_residual(A, dtype, M, ld, S.x.idx, S.x.val, S.x.nnz, b, r);      /* :64 */
+            const int64_t i = cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads); /* :65 */
+            if (sp_find(&S.x, i) < 0) {                                          /* :66 */
+                progressed = act_add(&S, A, dtype, M, ld, i);                    /* :67 */
+                act_solve(&S, b);                                                /* :68 */
+            }
+        }
+        cso_residual(A, dtype, M, ld, S.x.idx, S.x.val, S.x.nnz, b, r);
+        if (!(nrm2(r, M) >= eps)) break; /* :79  norm(residual!) >= eps || break */
+        /* a no-op update! (support full, or the arg-max already selected: :63,:66) leaves x
+         * unchanged, so every remaining iteration repeats it verbatim: stop here. */
+        if (!progressed) break;
+    }
+    emit(&S.x, idx, val, nnz);
+    if (order)
+        for (int64_t t = 0; t < S.norder; ++t) order[t] = S.order[t];
+    free(r);
+    free(Ar);
+    act_free(&S);
+    return CSO_OK;
+}
+
+/* ---------------------------------------------------------------- gomp
+ * update!(P::GOMP, x, l): src/matchingpursuit.jl:116-123;  driver: :126-139 */
+static void gomp_update(active_t *S, const void *A, int dtype, int64_t M, int64_t N, int64_t ld,
+                        const double *b, int64_t l, double *r, double *Ar, int64_t *top,
+                        int nthreads) {
+    if (!(S->x.nnz < M)) return;                                       /* :117 */
+    cso_residual(A, dtype, M, ld, S->x.idx, S->x.val, S->x.nnz, b, r); /* :118 */
+    cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads);                /* :190-191 */
+    if (l > N) l = N;
+    cso_topk_desc(Ar, N, l, top);                                      /* :192 */
+    for (int64_t t = 0; t < l; ++t) act_add(S, A, dtype, M, ld, top[t]); /* :120, util.jl:129-134 */
+    act_solve(S, b);                                                   /* :121 */
+}
+
+int cso_gomp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+             int64_t l, int64_t k, double eps, int64_t *idx, double *val, int64_t *nnz,
+             int64_t *order, int nthreads) {
+    if (!(eps >= 0.0)) return CSO_EINVAL; /* :127 */
+    if (l < 1) return CSO_EINVAL;
+    active_t S;
+    /* GOMP(A,b,l): QR capacity defaults to M (:108,:128); k only bounds what is ever added */
+    if (act_init(&S, M, (k + l < M) ? k + l : M) != 0) return CSO_ENOMEM;
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *Ar = (double *)malloc((size_t)N * sizeof(double));
+    int64_t *top = (int64_t *)malloc((size_t)(l > 0 ? l : 1) * sizeof(int64_t));
+    for (int64_t it = 0; it < k / l; ++it) { /* :130 */
+        gomp_update(&S, A, dtype, M, N, ld, b, l, r, Ar, top, nthreads);
+        cso_residual(A, dtype, M, ld, S.x.idx, S.x.val, S.x.nnz, b, r);
+        if (!(nrm2(r, M) >= eps)) break; /* :132 */
+    }
+    const int64_t rem = k % l; /* :134 */
+    if (rem > 0) gomp_update(&S, A, dtype, M, N, ld, b, rem, r, Ar, top, nthreads); /* :135-137 */
+    emit(&S.x, idx, val, nnz);
+    if (order)
+        for (int64_t t = 0; t < S.norder; ++t) order[t] = S.order[t];
+    free(r);
+    free(Ar);
+    free(top);
+    act_free(&S);
+    return CSO_OK;
+}
+
+/* ---------------------------------------------------------------- sp
+ * SP ctor: src/twostage.jl:54-61;  sp_acquisition!: :67-72;  update!: :75-83;  sp: :87-101;
+ * solve!: :104-107 -> factorize! (src/matchingpursuit.jl:219-227): dense QR of A[:, nzind]. */
+static void sp_solve(spvec_t *x, const void *A, int dtype, int64_t M, int64_t ld, const double *b) {
+    cso_lstsq_cols(A, dtype, M, ld, x->idx, x->nnz, b, x->val);
+}
+static void sp_acquire(spvec_t *x, const void *A, int dtype, int64_t M, int64_t N, int64_t ld,
+                       const double *b, int64_t k, double *r, double *Ar, int64_t *top,
+                       int nthreads) {
+    cso_residual(A, dtype, M, ld, x->idx, x->val, x->nnz, b, r); /* :68 */
+    cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads);
+    cso_topk_desc(Ar, N, k, top);                                /* :69 */
+    for (int64_t t = 0; t < k; ++t) sp_set(x, top[t], NAN);      /* :70  @. x[i] = NaN */
+    sp_solve(x, A, dtype, M, ld, b);                             /* :71 */
+}
+
+int cso_sp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+           double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
+           int nthreads) {
+    if (2 * k > M) return CSO_ERANGE; /* :55 */
+    if (k > N) return CSO_ERANGE;
+    if (maxiter < 0) maxiter = 16 * k; /* :87 default */
+    spvec_t x;
+    if (sp_init(&x, 2 * k) != 0) return CSO_ENOMEM;
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *Ar = (double *)malloc((size_t)N * sizeof(double));
+    int64_t *top = (int64_t *)malloc((size_t)(k > 0 ? k : 1) * sizeof(int64_t));
+    vi_t *small = (vi_t *)malloc((size_t)(2 * k > 0 ? 2 * k : 1) * sizeof(vi_t));
+    sp_acquire(&x, A, dtype, M, N, ld, b, k, r, Ar, top, nthreads); /* :90 */
+    cso_residual(A, dtype, M, ld, x.idx, x.val, x.nnz, b, r);
+    double resnorm = nrm2(r, M); /* :91 */
+    int64_t it = 0;
+    for (; it < maxiter;) { /* :92 */
+        const double oldnorm = resnorm;
+        /* update!(P::SP, x): :75-83 (nnz(x) == k holds by construction) */
+        sp_acquire(&x, A, dtype, M, N, ld, b, k, r, Ar, top, nthreads); /* :77 */
+        const int64_t drop = x.nnz - k;
+        if (drop > 0) { /* :78-81: remove the (nnz-k) smallest |coef|, ties by position */
+            for (int64_t t = 0; t < x.nnz; ++t) {
+                small[t].v = fabs(x.val[t]);
+                small[t].i = t;
+            }
+            qsort(small, (size_t)x.nnz, sizeof(vi_t), cmp_asc);
+            char *kill = (char *)calloc((size_t)x.nnz, 1);
+            for (int64_t t = 0; t < drop; ++t) kill[small[t].i] = 1;
+            int64_t w = 0;
+            for (int64_t t = 0; t < x.nnz; ++t)
+                if (!kill[t]) {
+                    x.idx[w] = x.idx[t];
+                    x.val[w] = x.val[t];
+                    ++w;
+                }
+            x.nnz = w;
+            free(kill);
+        }
+        sp_solve(&x, A, dtype, M, ld, b); /* :82 */
+        ++it;
+        cso_residual(A, dtype, M, ld, x.idx, x.val, x.nnz, b, r);
+        resnorm = nrm2(r, M);                              /* :95 */
+        if (resnorm <= delta || oldnorm <= resnorm) break; /* :96 */
+    }
+    emit(&x, idx, val, nnz);
+    if (iters) *iters = it;
+    free(r);
+    free(Ar);
+    free(top);
+    free(small);
+    sp_free(&x);
+    return CSO_OK;
+}

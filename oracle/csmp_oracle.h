@@ -1,0 +1,78 @@
+/*
+ * csmp_oracle.h -- CPU restatement of CompressedSensing.jl's matching-pursuit path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and there only as the checker / the reported CPU baseline -- never as the thing measured.
+ * The product library (compressedsensing.jl_amd/csrc/libcsmp.so) neither links nor calls it.
+ *
+ * PARITY PIN STATUS: the reference (pure Julia, plus the un-vendored dependency
+ * UpdatableQRFactorizations.jl v1.0.0, Manifest.toml:446-450) cannot be executed in the build
+ * container (no julia, no network) and its tests hold no golden vectors -- only
+ * known-answer planted-recovery checks on unseeded random data (test/matchingpursuit.jl:15-45,
+ * test/twostage.jl:42-52, test/forward.jl:23-28).  This oracle is pinned against exactly
+ * those known-answer tests re-run on seeded data (tests/test_oracle.py), against an
+ * independent numpy twin (oracle/oracle_np.py) and against scikit-learn's OMP.  Step order,
+ * stagnation, eps-stop and tie-breaking are NOT tested by the reference: for those
+ * behaviours parity is UNPINNED and follows the cited source lines + Julia stdlib semantics.
+ *
+ * Conventions: A is dense column-major (M rows = signal length, N columns = atoms; the
+ * reference calls these n, m: src/matchingpursuit.jl:20), element type f32 or f64
+ * (dtype 0 / 1).  All arithmetic is Float64 on the exactly promoted values.  Indices are
+ * 0-based here (the reference's are 1-based).  Outputs follow the reference's
+ * SparseVector: indices sorted ascending, values aligned (src/matchingpursuit.jl:76).
+ */
+#ifndef CSMP_ORACLE_H
+#define CSMP_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSO_OK 0
+#define CSO_EINVAL (-1) /* eps < 0: src/matchingpursuit.jl:74,127 */
+#define CSO_ERANGE (-3) /* 2k > M for SP: src/twostage.jl:55 */
+#define CSO_ENOMEM (-6)
+
+#define CSO_F32 0
+#define CSO_F64 1
+
+/* mp(A,b,k[,x]): src/matchingpursuit.jl:26-40.  idx/val sized >= min(k + nnz0, N).
+ * idx0/val0/nnz0 = optional warm start x (may be NULL/0). */
+int cso_mp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+           int64_t k, const int64_t *idx0, const double *val0, int64_t nnz0,
+           int64_t *idx, double *val, int64_t *nnz, int nthreads);
+
+/* omp(A,b,eps,k): src/matchingpursuit.jl:62-82.  order (may be NULL) receives the atoms in
+ * selection order.  idx/val/order sized >= k. */
+int cso_omp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+            int64_t k, double eps, int64_t *idx, double *val, int64_t *nnz, int64_t *order,
+            int nthreads);
+
+/* gomp(A,b,l,eps,k): src/matchingpursuit.jl:116-139 (incl. the remainder step :134-137). */
+int cso_gomp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+             int64_t l, int64_t k, double eps, int64_t *idx, double *val, int64_t *nnz,
+             int64_t *order, int nthreads);
+
+/* sp(A,b,k,delta;maxiter): src/twostage.jl:54-107.  iters (may be NULL) = update! calls made. */
+int cso_sp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+           double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
+           int nthreads);
+
+/* step primitives, exported so tests can pin them one by one */
+/* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
+int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,
+                      double *out, int nthreads);
+/* partialsortperm(v, 1:k, rev=true): descending by value, ties by ascending index (:189-193) */
+void cso_topk_desc(const double *v, int64_t n, int64_t k, int64_t *out);
+/* least squares on the columns cols[0..j) of A via Householder QR ("AiQR \\ y", test/forward.jl:23-28) */
+int cso_lstsq_cols(const void *A, int dtype, int64_t M, int64_t ld, const int64_t *cols, int64_t j,
+                   const double *b, double *coef);
+/* residual!: r = b - A x (src/matchingpursuit.jl:158-161) */
+void cso_residual(const void *A, int dtype, int64_t M, int64_t ld, const int64_t *idx,
+                  const double *val, int64_t nnz, const double *b, double *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

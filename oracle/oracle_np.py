@@ -1,0 +1,143 @@
+"""Independent numpy twin of the C oracle (csmp_oracle.c): same reference semantics, different code.
+
+TEST INFRASTRUCTURE ONLY (see csmp_oracle.h).  Written separately from the C restatement so
+that the two can be diffed against each other: this one re-solves the least-squares problem
+from scratch with LAPACK (numpy.linalg.lstsq) at every step instead of updating a QR, and
+uses numpy's BLAS products for the sweep.  Small/medium sizes only.
+
+Reference lines restated (paths relative to /root/reference):
+  mp    src/matchingpursuit.jl:26-40      omp   src/matchingpursuit.jl:62-82
+  gomp  src/matchingpursuit.jl:116-139    sp    src/twostage.jl:54-107
+  helpers src/matchingpursuit.jl:152-193, src/util.jl:118-134
+All arithmetic is Float64 on exactly promoted inputs; indices are 0-based.
+"""
+import numpy as np
+
+
+def _f64(A, b):
+    return np.asarray(A, dtype=np.float64), np.asarray(b, dtype=np.float64)
+
+
+def _residual(A, b, idx, val):  # residual!: src/matchingpursuit.jl:158-161
+    if len(idx) == 0:
+        return b.copy()
+    return b - A[:, idx] @ val
+
+
+def _abs_corr(A, r):  # argmaxinner!: src/matchingpursuit.jl:182-183
+    return np.abs(A.T @ r)
+
+
+def _topk(v, k):  # partialsortperm(v, 1:k, rev=true): desc by value, ties by ascending index
+    order = np.lexsort((np.arange(len(v)), -v))
+    return order[:k]
+
+
+def _ls(A, idx, b):  # AiQR \ b on the sorted support
+    return np.linalg.lstsq(A[:, idx], b, rcond=None)[0]
+
+
+def omp(A, b, k, eps):
+    A, b = _f64(A, b)
+    if not eps >= 0:
+        raise ValueError("eps has to be non-negative")  # :74
+    M, N = A.shape
+    idx = np.zeros(0, np.int64)
+    val = np.zeros(0)
+    order = []
+    for _ in range(k):  # :77
+        progressed = False
+        if len(idx) < M:  # :63
+            r = _residual(A, b, idx, val)
+            i = int(np.argmax(_abs_corr(A, r)))  # first max, :184
+            if i not in idx:  # :66
+                idx = np.sort(np.append(idx, i))  # util.jl:120-122
+                order.append(i)
+                val = _ls(A, idx, b)  # :68
+                progressed = True
+        if not (np.linalg.norm(_residual(A, b, idx, val)) >= eps):  # :79
+            break
+        if not progressed:  # a no-op step repeats forever: same result as running it out
+            break
+    return idx, val, np.array(order, np.int64)
+
+
+def gomp(A, b, l, k, eps):
+    A, b = _f64(A, b)
+    if not eps >= 0:
+        raise ValueError("eps has to be non-negative")  # :127
+    M, N = A.shape
+    idx = np.zeros(0, np.int64)
+    val = np.zeros(0)
+    order = []
+
+    def update(idx, val, l):  # :116-123
+        if not len(idx) < M:
+            return idx, val
+        r = _residual(A, b, idx, val)
+        for i in _topk(_abs_corr(A, r), l):  # :119, util.jl:129-134 (skip duplicates)
+            if i not in idx and len(idx) < M:
+                idx = np.sort(np.append(idx, i))
+                order.append(int(i))
+        val = _ls(A, idx, b)
+        return idx, val
+
+    for _ in range(k // l):  # :130
+        idx, val = update(idx, val, l)
+        if not (np.linalg.norm(_residual(A, b, idx, val)) >= eps):  # :132
+            break
+    if k % l > 0:  # :134-137 (runs even after an eps-break)
+        idx, val = update(idx, val, k % l)
+    return idx, val, np.array(order, np.int64)
+
+
+def mp(A, b, k, x0=None):
+    A, b = _f64(A, b)
+    x = {}
+    if x0 is not None:
+        for i, v in zip(*x0):
+            x[int(i)] = float(v)
+    for _ in range(k):  # :36
+        idx = np.array(sorted(x), np.int64)
+        val = np.array([x[i] for i in idx])
+        r = _residual(A, b, idx, val)  # :27
+        i = int(np.argmax(_abs_corr(A, r)))  # :28
+        d = float(A[:, i] @ r)  # :29
+        if i in x:
+            x[i] += d
+        elif d != 0.0:
+            x[i] = d
+    idx = np.array(sorted(x), np.int64)
+    return idx, np.array([x[i] for i in idx])
+
+
+def sp(A, b, k, delta=1e-12, maxiter=None):
+    A, b = _f64(A, b)
+    M, N = A.shape
+    if 2 * k > M:
+        raise ValueError("2k > length(b) is invalid for Subspace Pursuit")  # twostage.jl:55
+    if maxiter is None:
+        maxiter = 16 * k
+
+    def acquire(idx, val):  # :67-72
+        r = _residual(A, b, idx, val)
+        idx = np.union1d(idx, _topk(_abs_corr(A, r), k)).astype(np.int64)
+        return idx, _ls(A, idx, b)
+
+    idx, val = acquire(np.zeros(0, np.int64), np.zeros(0))  # :90
+    resnorm = np.linalg.norm(_residual(A, b, idx, val))
+    iters = 0
+    for _ in range(maxiter):  # :92
+        oldnorm = resnorm
+        idx, val = acquire(idx, val)  # :77
+        drop = len(idx) - k
+        if drop > 0:  # :78-81
+            kill = np.lexsort((np.arange(len(val)), np.abs(val)))[:drop]
+            keep = np.setdiff1d(np.arange(len(idx)), kill)
+            idx = idx[keep]
+        val = _ls(A, idx, b)  # :82
+        iters += 1
+        resnorm = np.linalg.norm(_residual(A, b, idx, val))
+        if resnorm <= delta or oldnorm <= resnorm:  # :96
+            break
+    return idx, val, iters

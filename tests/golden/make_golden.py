@@ -1,0 +1,147 @@
+"""Generates tests/golden/golden_small.npz.
+
+The reference (Julia) cannot run in the build container and its tests hold no golden vectors
+(test/matchingpursuit.jl:7 -- unseeded random data), so these vectors are produced by the C
+oracle (oracle/csmp_oracle.c) and accepted only where the independent numpy twin
+(oracle/oracle_np.py) returns the identical support/order and coefficients to 1e-10: they pin
+the oracle against regressions and give the GPU path committed known answers, including the
+edge cases the reference's code path has but its tests never exercise (ties, stagnation,
+eps-stop, full support, the gomp remainder step).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from csmp_pkg import load  # noqa: E402
+from oracle import oracle_c as oc, oracle_np as on  # noqa: E402
+
+cs = load()
+EPS64 = float(np.finfo(np.float64).eps)
+EPS32 = float(np.finfo(np.float32).eps)
+out = {}
+names = []
+
+
+def agree(a, b, what):
+    assert np.array_equal(a[0], b[0]), (what, a[0], b[0])
+    assert np.allclose(a[1], b[1], rtol=1e-10, atol=1e-13), (what, np.abs(a[1] - b[1]).max())
+    if len(a) > 2 and isinstance(a[2], np.ndarray):
+        assert np.array_equal(a[2], b[2]), (what, "order")
+
+
+def add(name, algo, A, b, params, res):
+    names.append(name)
+    out[f"{name}.A"] = A
+    out[f"{name}.b"] = b
+    out[f"{name}.algo"] = np.array(algo)
+    out[f"{name}.params"] = np.array(params, dtype=np.float64)
+    out[f"{name}.idx"] = res[0]
+    out[f"{name}.val"] = res[1]
+    out[f"{name}.order"] = res[2] if len(res) > 2 and isinstance(res[2], np.ndarray) else np.zeros(0, np.int64)
+
+
+def omp_case(name, A, b, k, eps, twin=True):
+    r = oc.omp(A, b, k, eps)
+    if twin:
+        agree(r, on.omp(A, b, k, eps), name)
+    add(name, "omp", A, b, [k, eps], r)
+
+
+def gomp_case(name, A, b, l, k, eps, twin=True):
+    r = oc.gomp(A, b, l, k, eps)
+    if twin:
+        agree(r, on.gomp(A, b, l, k, eps), name)
+    add(name, "gomp", A, b, [l, k, eps], r)
+
+
+def mp_case(name, A, b, k):
+    r = oc.mp(A, b, k)
+    agree(r, on.mp(A, b, k), name)
+    add(name, "mp", A, b, [k], r)
+
+
+def sp_case(name, A, b, k, delta):
+    r = oc.sp(A, b, k, delta)
+    r2 = on.sp(A, b, k, delta)
+    agree(r[:2], r2[:2], name)
+    assert r[2] == r2[2]
+    add(name, "sp", A, b, [k, delta, r[2]], r[:2])
+
+
+# 1-2: the reference's own test shape (test/matchingpursuit.jl:10-29), seeded, noiseless + noisy
+A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=11)
+y = cs.perturb(b, 5e-3, rng=12)
+omp_case("omp_ref_32x48_noisy", A, y, 3, EPS64)
+mp_case("mp_ref_32x48", A, b, 30)
+gomp_case("gomp_ref_32x48_l2", A, y, 2, 3, EPS64)
+out["omp_ref_32x48_noisy.x0_idx"] = x.nzind
+out["omp_ref_32x48_noisy.x0_val"] = x.nzval
+
+# 3-4: medium f64 / f32 dictionaries
+A, x, b = cs.sparse_data(n=64, m=256, k=8, rng=21)
+y = cs.perturb(b, 5e-3, rng=22)
+omp_case("omp_f64_64x256_k8", A, y, 8, EPS64)
+A32 = np.asfortranarray(A.astype(np.float32))
+y32 = cs.perturb(A32[:, x.nzind].astype(np.float64) @ x.nzval, 5e-3, rng=23)
+omp_case("omp_f32_64x256_k8", A32, y32, 8, EPS32)
+gomp_case("gomp_f32_64x256_k7_l3", A32, y32, 3, 7, EPS32)  # 2 full steps + remainder 1 (:134-137)
+sp_case("sp_f64_64x256_k8", A, y, 8, 1e-12)
+mp_case("mp_f32_64x256_k40", A32, y32, 40)
+
+# 5: ragged shape (M not a multiple of any vector width), f32
+A, x, b = cs.sparse_data(n=37, m=101, k=4, rng=31, dtype=np.float32)
+y = cs.perturb(b, 5e-3, rng=32)
+omp_case("omp_f32_ragged_37x101", A, y, 4, EPS32)
+gomp_case("gomp_f32_ragged_37x101", A, y, 3, 5, EPS32)
+
+# 6: duplicated columns -> exact tie, the lower index must win (argmax = first max, :184)
+A, x, b = cs.sparse_data(n=32, m=40, k=3, rng=41)
+A = np.asfortranarray(np.concatenate([A, A[:, x.nzind]], axis=1))  # copies at 40, 41, 42
+y = cs.perturb(b, 5e-3, rng=42)
+# (the numpy twin is not consulted here: BLAS gemv may round the two copies of a column
+#  differently depending on their position, which breaks the exact tie -- the C oracle and the
+#  GPU kernel both compute every column with one fixed summation order, so the tie is exact)
+omp_case("omp_dupcols", A, y, 3, EPS64, twin=False)
+assert np.all(out["omp_dupcols.idx"] < 40)
+t = on.omp(A, y, 3, EPS64)
+assert np.array_equal(np.sort(np.where(t[0] >= 40, x.nzind[np.clip(t[0] - 40, 0, 2)], t[0])), out["omp_dupcols.idx"])
+gomp_case("gomp_dupcols", A, y, 2, 4, EPS64, twin=False)
+
+# 7: eps-stop: noiseless 3-sparse signal, generous k, eps well above round-off
+A, x, b = cs.sparse_data(n=48, m=128, k=3, rng=51)
+omp_case("omp_eps_stop", A, b, 10, 1e-8)
+assert len(out["omp_eps_stop.idx"]) == 3
+gomp_case("gomp_eps_stop_remainder", A, b, 2, 9, 1e-8)  # eps-break, then the remainder step still runs
+
+# 8: stagnation: every atom already selected, eps = 0 never stops (:66)
+A, x, b = cs.sparse_data(n=16, m=3, k=2, rng=61)
+y = cs.perturb(b, 1e-2, rng=62)
+omp_case("omp_stagnation_N3", A, y, 6, 0.0)
+assert len(out["omp_stagnation_N3.idx"]) == 3
+
+# 9: support fills the whole row space: nnz(x) == size(A,1) guard (:63)
+A, x, b = cs.sparse_data(n=4, m=12, k=2, rng=71)
+y = cs.perturb(b, 1e-1, rng=72)
+omp_case("omp_full_M4", A, y, 8, 0.0)
+assert len(out["omp_full_M4.idx"]) == 4
+
+# 10: b = 0: the first update! still adds atom 0 with coefficient 0 before the eps check (:77-79)
+A, x, b = cs.sparse_data(n=16, m=24, k=2, rng=81)
+omp_case("omp_zero_b", A, np.zeros(16), 3, EPS64)
+assert out["omp_zero_b.idx"].tolist() == [0]
+
+# 11: the twostage test shape (test/twostage.jl:42-52)
+A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=91)
+y = cs.perturb(b, 5e-3, rng=92)
+sp_case("sp_ref_32x64", A, y, 3, 1e-2)
+sp_case("sp_ref_32x64_noiseless", A, b, 3, 1e-12)
+
+out["names"] = np.array(names)
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
+np.savez_compressed(path, **out)
+print("wrote", path, len(names), "cases", os.path.getsize(path), "bytes")

@@ -1,0 +1,52 @@
+"""CPU tests of the boundary: libcsmp.so loads, exports every symbol include/csmp.h declares, and
+refuses to run (loudly, no CPU fallback) when no GPU is visible."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "csmp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(csmp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(cs):
+    assert os.path.exists(cs.LIB_PATH), "build libcsmp.so first: python -c 'import __graft_entry__ as g; g.build()'"
+    L = ctypes.CDLL(cs.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/csmp.h but not exported"
+    L.csmp_version.restype = ctypes.c_int
+    assert L.csmp_version() >= 100
+
+
+def test_binding_table_matches_header(cs):
+    from csmp_pkg import load
+    lib = load()._lib
+    assert sorted(lib.SIGNATURES) == header_symbols()
+
+
+def test_product_does_not_link_the_oracle(cs):
+    import subprocess
+    out = subprocess.run(["ldd", cs.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    src = open(os.path.join(ROOT, "compressedsensing.jl_amd", "csrc", "csmp.hip")).read()
+    assert "oracle" not in src.lower()
+
+
+def test_no_cpu_fallback_without_gpu(cs):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(cs.CsmpError) as e:
+        cs.Context(0)
+    assert "no CPU fallback" in str(e.value)
+    A, x, b = cs.sparse_data(16, 24, 2, rng=0)
+    with pytest.raises(cs.CsmpError):
+        cs.omp(A, b, 2)

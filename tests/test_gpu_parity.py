@@ -1,0 +1,229 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C ABI (libcsmp.so via the
+ctypes host mirror), against the CPU oracle on the same seeded inputs and against the committed
+golden vectors.  Bar: identical supports / selection order (integer work: bit-exact), coefficients
+within 1e-6 relative in Float64 (north_star) -- in practice ~1e-13."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-6  # BASELINE.json north_star: "coefficients within 1e-6 relative Float64"
+EPS64 = float(np.finfo(np.float64).eps)
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def close(v, ref, tight=True):
+    tol = 1e-9 if tight else RTOL
+    return np.allclose(v, ref, rtol=tol, atol=tol * max(1e-300, float(np.max(np.abs(ref))) if len(ref) else 0.0))
+
+
+@pytest.fixture(scope="module")
+def D(cs):
+    made = []
+
+    def make(A):
+        d = cs.Dictionary(A)
+        made.append(d)
+        return d
+    yield make
+    for d in made:
+        d.close()
+
+
+def test_library_is_the_hip_one(cs):
+    d = cs.Context(0)
+    name, cus, mem = d.device_info()
+    assert "gfx950" in name and cus >= 200, name
+    d.close()
+
+
+def test_golden_vectors_through_the_abi(cs, golden, D):
+    ran = 0
+    for name, c in golden.items():
+        A, b, p = c["A"], c["b"], c["params"]
+        d = D(A)
+        if c["algo"] == "omp":
+            idx, val, order = d.ctx.omp(b, int(p[0]), float(p[1]))
+            assert np.array_equal(order, c["order"]), name
+        elif c["algo"] == "mp":
+            idx, val = d.ctx.mp(b, int(p[0]))
+        else:
+            continue
+        assert np.array_equal(idx, c["idx"]), (name, idx, c["idx"])
+        assert close(val, c["val"]), (name, val, c["val"])
+        ran += 1
+    assert ran >= 11
+
+
+@pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_omp_matches_oracle(cs, oracle, D, shape, dtype):
+    n, m, k = shape
+    eps = float(np.finfo(dtype).eps)
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n * 31 + m, dtype=dtype)
+    d = D(A)
+    for seed in range(3):
+        xs = cs.sparse_vector(m, k, rng=seed)
+        y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=seed + 100)
+        ref = oracle.omp(A, y, k, eps)
+        got = d.ctx.omp(y, k, eps)
+        assert np.array_equal(got[2], ref[2]), "selection order"
+        assert np.array_equal(got[0], ref[0])
+        assert close(got[1], ref[1])
+        # the public driver, same defaults as the reference: omp(A, b, k)
+        xv = cs.omp(d, y, k)
+        assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
+
+
+def test_omp_b_dtype_f32(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=64, m=256, k=6, rng=3, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=4).astype(np.float32)
+    d = D(A)
+    ref = oracle.omp(A, y.astype(np.float64), 6, EPS32)
+    got = d.ctx.omp(y, 6, EPS32)
+    assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+
+
+def test_omp_keyword_and_eps_forms(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=48, m=128, k=3, rng=51)
+    d = D(A)
+    ref = oracle.omp(A, b, 10, 1e-8)
+    for xv in (cs.omp(d, b, 1e-8, 10), cs.omp(d, b, max_residual=1e-8, sparsity=10)):
+        assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
+    assert len(ref[0]) == 3  # eps-stop after the planted atoms
+    xv = cs.omp(d, b, 1e-8)  # k defaults to size(A,1)
+    assert np.array_equal(xv.nzind, ref[0])
+    with pytest.raises(ValueError):
+        cs.omp(d, b, -1.0, 3)
+    with pytest.raises(cs.CsmpError):  # the ABI itself refuses too (CSMP_EINVAL)
+        d.ctx.omp(b, 3, -1.0)
+    with pytest.raises(cs.CsmpError):  # CSMP_EDIM
+        d.ctx.omp(b[:-1], 3, 0.0)
+
+
+def test_mp_matches_oracle(cs, oracle, D):
+    for (n, m, k, dtype) in [(32, 48, 30, np.float64), (64, 256, 50, np.float32), (37, 101, 25, np.float32)]:
+        A, x, b = cs.sparse_data(n=n, m=m, k=3, rng=n + m, dtype=dtype)
+        d = D(A)
+        ref = oracle.mp(A, b, k)
+        got = d.ctx.mp(b, k)
+        assert np.array_equal(got[0], ref[0])
+        assert close(got[1], ref[1])
+        # warm start: mp(A,b,k2,x) continues from x (src/matchingpursuit.jl:34)
+        x1 = cs.mp(d, b, 7)
+        x2 = cs.mp(d, b, k - 7, x1)
+        assert np.array_equal(x2.nzind, ref[0]) and close(x2.nzval, ref[1])
+
+
+def test_sweep_primitive(cs, oracle, D):
+    rng = np.random.default_rng(0)
+    for (n, m, dtype) in [(32, 48, np.float64), (256, 1024, np.float32), (37, 101, np.float32), (1024, 5000, np.float32), (129, 333, np.float64)]:
+        A = np.asfortranarray(rng.standard_normal((n, m)).astype(dtype))
+        r = rng.standard_normal(n)
+        d = D(A)
+        out, ti, tv = d.ctx.sweep(r, 1)
+        ref, best = oracle.sweep_abs(A, r)
+        np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-13)
+        assert int(ti[0]) == best
+        assert cs.argmaxinner(d, r) == best
+
+
+def test_duplicate_columns_tie_goes_to_lowest_index(cs, D):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((64, 300)).astype(np.float32)
+    A[:, 250] = A[:, 17]
+    A[:, 299] = A[:, 17]
+    A = np.asfortranarray(A)
+    r = A[:, 17].astype(np.float64) * 3.0  # makes atom 17 (and its copies) the arg-max
+    d = D(A)
+    out, ti, tv = d.ctx.sweep(r, 1)
+    assert out[17] == out[250] == out[299] and int(ti[0]) == 17
+
+
+def test_omp_batch_equals_single_signal_calls(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=64, m=256, k=5, rng=8, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(9)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(256, 5, rng=rng).to_dense(), 5e-3, rng=rng) for _ in range(6)], axis=1))
+    xs = cs.omp_batch(d, B, 5)
+    for s, xv in enumerate(xs):
+        ref = oracle.omp(A, B[:, s], 5, EPS32)
+        assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
+    # float32 signals, device-resident in/out (the bench path)
+    import torch
+    Bt = torch.from_numpy(np.ascontiguousarray(B.T.astype(np.float32))).cuda()
+    idx = torch.empty((6, 5), dtype=torch.int64, device="cuda")
+    val = torch.empty((6, 5), dtype=torch.float64, device="cuda")
+    nnz = torch.empty(6, dtype=torch.int64, device="cuda")
+    d.ctx.omp_batch_device(Bt, 5, EPS32, idx, val, nnz)
+    d.ctx.sync()
+    for s in range(6):
+        ref = oracle.omp(A, B[:, s].astype(np.float32).astype(np.float64), 5, EPS32)
+        n = int(nnz[s])
+        assert np.array_equal(idx[s, :n].cpu().numpy(), ref[0]) and close(val[s, :n].cpu().numpy(), ref[1])
+
+
+def test_step_level_omp_functor(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=64, m=256, k=6, rng=12)
+    y = cs.perturb(b, 5e-3, rng=13)
+    d = D(A)
+    P = cs.OMP(d, y, 6)
+    xv = cs.spzeros(256)
+    ref = oracle.omp(A, y, 6, 0.0)
+    for t in range(6):
+        P(xv)  # (U::Update)(x) = update!(U, x)
+        assert xv.nnz == t + 1 and np.array_equal(np.sort(ref[2][:t + 1]), xv.nzind)
+        step_ref = oracle.lstsq_cols(A, xv.nzind, y)  # update! leaves x = LS solution on the support
+        assert close(xv.nzval, step_ref)
+        rn = np.linalg.norm(oracle.residual(A, xv.nzind, xv.nzval, y))
+        assert abs(P.resnorm - rn) <= 1e-9 * max(rn, 1e-30)
+    assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
+
+
+def test_device_dictionary_is_borrowed_zero_copy(cs, oracle):
+    import torch
+    A, x, b = cs.sparse_data(n=64, m=256, k=5, rng=20, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=21)
+    At = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()  # (N, M): row j = atom j
+    d = cs.Dictionary(At)
+    ref = oracle.omp(A, y, 5, EPS32)
+    xv = cs.omp(d, y, 5)
+    assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
+    d.close()
+
+
+def test_full_size_config2_properties(cs, oracle):
+    """BASELINE config 2 shape (4096 x 65536 f32): first atoms against the oracle, and
+    size-independent properties over a full k=256 solve: support is k distinct atoms, the
+    coefficients are the LS solution on that support (normal equations ~ 0), re-running is
+    bit-identical, and sweep linearity."""
+    import torch
+    M, N, k = 4096, 65536, 256
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    At = torch.randn((N, M), generator=g, device="cuda", dtype=torch.float32)
+    At /= At.norm(dim=1, keepdim=True)
+    d = cs.Dictionary(At)
+    A = np.asfortranarray(At.cpu().numpy().T)
+    xs = cs.sparse_vector(N, k, rng=1)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=2)
+    # oracle on the first 12 atoms (a dozen 1-GiB sweeps on the host cores)
+    ref = oracle.omp(A, y, 12, EPS32)
+    got = d.ctx.omp(y, 12, EPS32)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+    full = d.ctx.omp(y, k, EPS32)
+    again = d.ctx.omp(y, k, EPS32)
+    assert np.array_equal(full[0], again[0]) and np.array_equal(full[1], again[1]) and np.array_equal(full[2], again[2])
+    assert len(full[0]) == k and len(np.unique(full[0])) == k and np.all(np.diff(full[0]) > 0)
+    assert np.array_equal(full[2][:12], ref[2])
+    AS = A[:, full[0]].astype(np.float64)
+    r = y - AS @ full[1]
+    assert np.abs(AS.T @ r).max() < 1e-10 * np.linalg.norm(y)
+    assert np.array_equal(full[0], xs.nzind)  # planted support recovered at this shape
+    # sweep linearity: A'(2 r1 - r2) == 2 A'r1 - A'r2 to rounding
+    rng = np.random.default_rng(3)
+    r1, r2 = rng.standard_normal(M), rng.standard_normal(M)
+    c1 = oracle.sweep_abs(A[:, :2048], r1)[0]
+    o1, t1, _ = d.ctx.sweep(r1, 1)
+    np.testing.assert_allclose(o1[:2048], c1, rtol=1e-11, atol=1e-12)
+    assert int(t1[0]) == int(np.argmax(o1))
+    d.close()

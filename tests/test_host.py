@@ -1,0 +1,69 @@
+"""CPU tests of the host-side mirror: SparseVector, the synthetic-data generators of
+src/util.jl, and the drivers' argument handling / error behaviour (no GPU compute)."""
+import numpy as np
+import pytest
+
+
+def test_sparsevector_semantics(cs):
+    x = cs.spzeros(16)
+    for i, v in enumerate((1.0, 2.0, 3.0)):  # test/util.jl:48-58
+        x[i] = v
+    assert x.nnz == 3 and x.nzind.tolist() == [0, 1, 2]
+    x[9] = float("nan")  # util.jl:120 placeholder is stored
+    x[5] = 0.0  # structural zero is not
+    assert x.nzind.tolist() == [0, 1, 2, 9]
+    x[1] = 0.0  # an existing entry keeps its slot
+    assert x.nnz == 4 and x[1] == 0.0
+    y = cs.SparseVector(8, [5, 1], [2.0, 3.0])
+    assert y.nzind.tolist() == [1, 5] and y.nzval.tolist() == [3.0, 2.0]
+    with pytest.raises(ValueError):
+        cs.SparseVector(8, [1, 1], [1.0, 2.0])
+    assert np.array_equal(y.to_dense(), [0, 3, 0, 0, 0, 2, 0, 0])
+
+
+def test_sparse_data_matches_reference_recipe(cs):
+    A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=0)
+    assert A.shape == (32, 64) and A.flags.f_contiguous and A.dtype == np.float64
+    np.testing.assert_allclose(np.linalg.norm(A, axis=0), 1.0, rtol=1e-12)  # util.jl:26
+    assert x.nnz == 3 and set(np.abs(x.nzval)) == {1.0}  # util.jl:17
+    np.testing.assert_allclose(A @ x.to_dense(), b, rtol=1e-12, atol=1e-15)
+    A32, x32, b32 = cs.sparse_data(n=32, m=64, k=3, rng=0, dtype=np.float32)
+    assert A32.dtype == np.float32 and b32.dtype == np.float64
+    np.testing.assert_array_equal(A32[:, x32.nzind].astype(np.float64) @ x32.nzval, b32)
+    with pytest.raises(ValueError):
+        cs.sparse_vector(3, 4)
+
+
+def test_perturb_norm_is_exact(cs):
+    b = np.ones(50)
+    y = cs.perturb(b, 5e-3, rng=1)
+    assert abs(np.linalg.norm(y - b) - 5e-3) < 1e-15  # util.jl:50-55
+
+
+def test_samesupport(cs):
+    x = cs.SparseVector(10, [1, 4], [1.0, -1.0])
+    assert cs.samesupport(x, cs.SparseVector(10, [4, 1], [3.0, 2.0]))
+    assert not cs.samesupport(x, cs.SparseVector(10, [1, 5], [1.0, 1.0]))
+    assert cs.samesupport(x, x.to_dense())
+
+
+def test_driver_argument_errors_come_before_any_gpu_work(cs):
+    A, x, b = cs.sparse_data(16, 24, 2, rng=0)
+    with pytest.raises(ValueError, match="non-negative"):
+        cs.omp(A, b, -1e-3, 2)  # src/matchingpursuit.jl:74
+    with pytest.raises(ValueError, match="non-negative"):
+        cs.gomp(A, b, 2, -1.0, 2)  # :127
+    with pytest.raises(ValueError, match="invalid for Subspace Pursuit"):
+        cs.sp(A, b, 9)  # src/twostage.jl:55
+    with pytest.raises(ValueError):
+        cs.omp_batch(A, np.zeros((16, 2)), 2, eps=-1.0)
+
+
+def test_shard_range_partitions(cs):
+    for nsig in (0, 1, 7, 8, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [cs.shard_range(nsig, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == nsig
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,184 @@
+"""CPU tests of the oracle (oracle/): the reference's own known-answer tests re-run on seeded
+data, the C restatement against its independent numpy twin and scikit-learn, the golden vectors,
+and the edge semantics the C-ABI path is later held to."""
+import numpy as np
+import pytest
+
+from oracle import oracle_np as on
+
+EPS64 = float(np.finfo(np.float64).eps)
+EPS32 = float(np.finfo(np.float32).eps)
+
+
+def run_case(oracle, c):
+    A, b, p = c["A"], c["b"], c["params"]
+    if c["algo"] == "omp":
+        return oracle.omp(A, b, int(p[0]), float(p[1]))
+    if c["algo"] == "gomp":
+        return oracle.gomp(A, b, int(p[0]), int(p[1]), float(p[2]))
+    if c["algo"] == "mp":
+        return oracle.mp(A, b, int(p[0]))
+    if c["algo"] == "sp":
+        return oracle.sp(A, b, int(p[0]), float(p[1]))
+    raise AssertionError(c["algo"])
+
+
+def test_golden_vectors(oracle, golden):
+    assert len(golden) >= 19
+    for name, c in golden.items():
+        r = run_case(oracle, c)
+        assert np.array_equal(r[0], c["idx"]), name
+        np.testing.assert_allclose(r[1], c["val"], rtol=1e-12, atol=1e-15, err_msg=name)
+        if c["algo"] in ("omp", "gomp"):
+            assert np.array_equal(r[2], c["order"]), name
+        if c["algo"] == "sp":
+            assert r[2] == int(c["params"][2]), name
+
+
+# ---- the reference's known-answer tests (planted recovery), on seeded instances
+def test_reference_mp_property(oracle, cs):
+    # test/matchingpursuit.jl:15-19: mp(A,b,10k): A*xmp ~ b and xmp ~ x with atol = 3e-2
+    ok = 0
+    for seed in range(30):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=1000 + seed)
+        idx, val = oracle.mp(A, b, 30)
+        xm = np.zeros(48)
+        xm[idx] = val
+        ok += np.allclose(A @ xm, b, atol=3e-2) and np.allclose(xm, x.to_dense(), atol=3e-2)
+    assert ok >= 24  # "these tests may rarely fail" (test/matchingpursuit.jl:7)
+
+
+def test_reference_omp_property(oracle, cs):
+    # test/matchingpursuit.jl:21-30
+    ok = okn = 0
+    for seed in range(40):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=2000 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        idx, val, _ = oracle.omp(A, b, 3, EPS64)
+        ok += np.array_equal(idx, x.nzind) and np.allclose(val, x.nzval, rtol=1.5e-8)
+        idx, val, _ = oracle.omp(A, y, 3, EPS64)
+        okn += np.array_equal(idx, x.nzind) and np.allclose(val, x.nzval, atol=2e-2)
+    assert ok >= 36 and okn >= 36
+
+
+def test_reference_gomp_property(oracle, cs):
+    # test/matchingpursuit.jl:32-45 (l = 2)
+    ok = 0
+    for seed in range(40):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=3000 + seed)
+        idx, val, _ = oracle.gomp(A, b, 2, 3, EPS64)
+        ok += np.array_equal(idx, x.nzind) and np.allclose(val, x.nzval, rtol=1.5e-8)
+    assert ok >= 34
+
+
+def test_reference_sp_property(oracle, cs):
+    # test/twostage.jl:42-52
+    ok = 0
+    for seed in range(40):
+        A, x, b = cs.gaussian_data(32, 64, 3, rng=4000 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        idx, val, _ = oracle.sp(A, b, 3)
+        good = np.array_equal(idx, x.nzind) and np.allclose(val, x.nzval, rtol=1.5e-8)
+        idx, val, _ = oracle.sp(A, y, 3, 1e-2)
+        good &= np.array_equal(idx, x.nzind) and np.allclose(val, x.nzval, atol=3e-2)
+        ok += good
+    assert ok >= 34
+
+
+def test_reference_qr_solve_pin(oracle, cs):
+    # test/forward.jl:23-28: AiQR \ y ~ A[:, nzind] \ y -- the only direct pin on the third-party QR
+    for seed in range(5):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=5000 + seed)
+        y = cs.perturb(b, 1e-2, rng=seed)
+        cols = np.array([0, 1, 2])
+        np.testing.assert_allclose(oracle.lstsq_cols(A, cols, y), np.linalg.lstsq(A[:, cols], y, rcond=None)[0], rtol=1e-11)
+    A, x, b = cs.sparse_data(n=128, m=64, k=3, rng=7)
+    cols = np.array([5, 60, 3, 17, 40, 41, 2])
+    np.testing.assert_allclose(oracle.lstsq_cols(A, cols, b), np.linalg.lstsq(A[:, cols], b, rcond=None)[0], rtol=1e-10, atol=1e-13)
+
+
+# ---- C restatement against the independent numpy twin
+@pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 16)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_c_vs_numpy_twin(oracle, cs, shape, dtype):
+    n, m, k = shape
+    eps = float(np.finfo(dtype).eps)
+    for seed in range(3):
+        A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=seed * 7 + n, dtype=dtype)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        a, t = oracle.omp(A, y, k, eps), on.omp(A, y, k, eps)
+        assert np.array_equal(a[0], t[0]) and np.array_equal(a[2], t[2])
+        np.testing.assert_allclose(a[1], t[1], rtol=1e-10)
+        a, t = oracle.gomp(A, y, 3, k + 1, eps), on.gomp(A, y, 3, k + 1, eps)
+        assert np.array_equal(a[0], t[0]) and np.array_equal(a[2], t[2])
+        np.testing.assert_allclose(a[1], t[1], rtol=1e-9, atol=1e-12)
+        a, t = oracle.mp(A, y, 2 * k), on.mp(A, y, 2 * k)
+        assert np.array_equal(a[0], t[0])
+        np.testing.assert_allclose(a[1], t[1], rtol=1e-10, atol=1e-13)
+        if 2 * k <= n:
+            a, t = oracle.sp(A, y, k), on.sp(A, y, k)
+            assert np.array_equal(a[0], t[0]) and a[2] == t[2]
+            np.testing.assert_allclose(a[1], t[1], rtol=1e-9, atol=1e-12)
+
+
+def test_c256x1024_k32_config1(oracle, cs):
+    # BASELINE config 1: omp(A,b,k) on Gaussian A 256x1024, k=32, Float64
+    A, x, b = cs.sparse_data(n=256, m=1024, k=32, rng=123)
+    y = cs.perturb(b, 5e-3, rng=124)
+    a, t = oracle.omp(A, y, 32, EPS64), on.omp(A, y, 32, EPS64)
+    assert np.array_equal(a[0], t[0]) and np.array_equal(a[2], t[2])
+    np.testing.assert_allclose(a[1], t[1], rtol=1e-10)
+    # LS optimality of the result on its own support: A_S' (b - A_S c) = 0
+    r = oracle.residual(A, a[0], a[1], y)
+    assert np.abs(A[:, a[0]].T @ r).max() < 1e-12
+
+
+def test_against_sklearn_omp(oracle, cs):
+    from sklearn.linear_model import orthogonal_mp
+    for seed in range(4):
+        A, x, b = cs.sparse_data(n=64, m=256, k=6, rng=600 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        idx, val, _ = oracle.omp(A, y, 6, 0.0)
+        w = orthogonal_mp(A, y, n_nonzero_coefs=6, precompute=False)
+        assert np.array_equal(np.flatnonzero(w), idx)
+        np.testing.assert_allclose(w[idx], val, rtol=1e-8)
+
+
+# ---- step primitives and edge semantics
+def test_sweep_and_topk_semantics(oracle):
+    rng = np.random.default_rng(0)
+    A = np.asfortranarray(rng.standard_normal((20, 30)))
+    r = rng.standard_normal(20)
+    out, best = oracle.sweep_abs(A, r)
+    np.testing.assert_allclose(out, np.abs(A.T @ r), rtol=1e-13)
+    assert best == int(np.argmax(out))
+    v = np.array([1.0, 3.0, 3.0, 0.5, 3.0, 2.0])
+    assert oracle.topk_desc(v, 4).tolist() == [1, 2, 4, 5]  # ties by ascending index
+    assert oracle.topk_desc(v, 1).tolist() == [1]
+
+
+def test_eps_negative_is_an_error(oracle, cs):
+    A, x, b = cs.sparse_data(n=16, m=24, k=2, rng=0)
+    with pytest.raises(ValueError):
+        oracle.omp(A, b, 2, -1.0)
+    with pytest.raises(ValueError):
+        oracle.gomp(A, b, 2, 2, -1e-3)
+    with pytest.raises(ValueError):
+        oracle.sp(A, b, 9)  # 2k > M
+
+
+def test_f32_dictionary_is_promoted_exactly(oracle, cs):
+    A, x, b = cs.sparse_data(n=64, m=256, k=8, rng=5, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=6)
+    a = oracle.omp(A, y, 8, EPS32)
+    t = oracle.omp(A.astype(np.float64), y, 8, EPS32)
+    assert np.array_equal(a[0], t[0]) and np.array_equal(a[1], t[1])
+
+
+def test_mp_warm_start(oracle, cs):
+    A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=9)
+    i1, v1 = oracle.mp(A, b, 5)
+    i2, v2 = oracle.mp(A, b, 7, x0=(i1, v1))
+    i3, v3 = oracle.mp(A, b, 12)
+    assert np.array_equal(i2, i3)
+    np.testing.assert_allclose(v2, v3, rtol=1e-12, atol=1e-15)
