@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- single-signal OMP on MI355X at BASELINE.json configs[1]:
+A 4096 x 65536 Float32 Gaussian dictionary (unit-norm atoms), k = 256.
+
+A "step" is one complete omp(A, b, k) solve of one synthetic signal = 256 atoms selected, each by
+one full sweep of the 1 GiB dictionary (K1 of SURVEY.md section 2.3) plus the on-device QR append.
+Inputs (dictionary and signals) are resident in HBM before the timed region starts; results stay
+on the device and, with N > 1 ranks, are exchanged by ONE all_gather (RCCL) inside the timed
+region.  Signals are independent: weak scaling, K signals per rank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+M, N, K_ATOMS = 4096, 65536, 256
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+NOISE = 5e-3  # ||e||_2, as test/matchingpursuit.jl:12-13 (perturb(b, delta/2), delta = 1e-2)
+SEED_A = 0xC0FFEE
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=16)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=15.0, help="target wall time of the CPU baseline sample")
+    return p.parse_args()
+
+
+def make_dictionary(torch, dev):
+    """src/util.jl:21-27 on the device: randn in Float64, subtract 1e-6 * column mean, unit 2-norm,
+    cast ONCE to Float32.  Stored as (N, M) row-major = column-major M x N; same on every rank."""
+    g = torch.Generator(device=dev).manual_seed(SEED_A)
+    At = torch.empty((N, M), dtype=torch.float32, device=dev)
+    blk = 8192
+    for lo in range(0, N, blk):
+        a = torch.randn((blk, M), generator=g, device=dev, dtype=torch.float64)
+        a -= 1e-6 * a.mean(dim=1, keepdim=True)
+        a /= a.norm(dim=1, keepdim=True)
+        At[lo:lo + blk] = a.to(torch.float32)
+    return At
+
+
+def make_signals(torch, dev, At, first_id, count):
+    """Planted k-sparse +-1 x0 (src/util.jl:13-19), b = A x0 + e with ||e||_2 = 5e-3
+    (src/util.jl:50-55), formed in Float64 from the CAST dictionary.  Seeded by global signal id."""
+    B = torch.empty((count, M), dtype=torch.float64, device=dev)
+    for s in range(count):
+        g = torch.Generator(device=dev).manual_seed(1_000_003 * (first_id + s) + 17)
+        idx = torch.randperm(N, generator=g, device=dev)[:K_ATOMS]
+        sign = torch.randint(0, 2, (K_ATOMS,), generator=g, device=dev).to(torch.float64) * 2 - 1
+        b = (At[idx].to(torch.float64) * sign[:, None]).sum(dim=0)
+        e = torch.randn(M, generator=g, device=dev, dtype=torch.float64)
+        B[s] = b + e * (NOISE / e.norm())
+    return B
+
+
+def usable_cores():
+    """Host cores this process may actually use: min(affinity, cgroup CPU quota).  (The GPU
+    pool's boxes show 256 logical CPUs but cap the container at a 16-CPU quota; oversubscribing
+    OpenMP beyond the quota makes the sweep 10-30x slower.)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
+
+
+def cpu_baseline(At, B0, gpu_order, seconds):
+    """The oracle (oracle/csmp_oracle.c: the reference algorithm restated, OpenMP over the host
+    cores) timed on a bounded sample of THE SAME workload: the first atoms of signal 0 on the same
+    dictionary.  Doubles as an in-bench parity check of the GPU's selection order."""
+    import numpy as np
+    from oracle import oracle_c
+    oracle_c.build()
+    A = At.cpu().numpy().T  # (M, N) Fortran-ordered view, no copy
+    b = B0.cpu().numpy()
+    cores = usable_cores()
+    eps = float(np.finfo(np.float32).eps)
+    t0 = time.perf_counter()
+    oracle_c.omp(A, b, 2, eps, nthreads=cores)
+    per_atom = (time.perf_counter() - t0) / 2
+    atoms = int(max(4, min(K_ATOMS, seconds / max(per_atom, 1e-6))))
+    t0 = time.perf_counter()
+    idx, val, order = oracle_c.omp(A, b, atoms, eps, nthreads=cores)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(order, gpu_order[:atoms]))
+    return {"value": atoms / dt, "unit": "atoms/s", "cores": cores, "kind": "port",
+            "sample": f"first {atoms} of {K_ATOMS} atoms of signal 0, same 4096x65536 f32 dictionary, "
+                      f"oracle/csmp_oracle.c with {cores} OpenMP threads, {dt:.1f} s",
+            "selection_order_matches_gpu": same}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # not under a launcher: start one (child processes; this process never touches the GPU)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from csmp_pkg import load
+    cs = load()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    At = make_dictionary(torch, dev)
+    D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
+    eps = D.eps  # eps(Float32): omp(A, b, k) default (src/matchingpursuit.jl:85)
+    K, W = args.steps, args.warmup
+    B = make_signals(torch, dev, At, rank * (K + W), K + W)
+    idx = torch.full((K + W, K_ATOMS), -1, dtype=torch.int64, device=dev)
+    val = torch.zeros((K + W, K_ATOMS), dtype=torch.float64, device=dev)
+    nnz = torch.zeros(K + W, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()  # inputs are resident before the library's stream touches them
+
+    def barrier():
+        D.ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if W > 0:
+        D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
+    if world > 1:  # warm the collective too
+        dist.all_gather([torch.empty(4, device=dev) for _ in range(world)], torch.zeros(4, device=dev))
+    D.ctx.profile_enable(True)
+    D.ctx.profile_read(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
+    D.ctx.sync()
+    if world > 1:  # the single collective of the path: every rank's (idx, val, nnz) shard
+        packed = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, None].to(torch.float64)], dim=1)
+        gathered = [torch.empty_like(packed) for _ in range(world)]
+        dist.all_gather(gathered, packed)
+    barrier()
+    dt = time.perf_counter() - t0
+    sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+    D.ctx.profile_enable(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    atoms = torch.tensor([float(nnz[W:].sum().item())], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(atoms, op=dist.ReduceOp.SUM)
+    tmax, atoms = tmax.item(), atoms.item()
+
+    if rank == 0:
+        alg_bytes = M * N * 4  # bytes/atom = M*N*sizeof(Float32), A streamed once
+        avg_sweep_s = sweep_ms / max(sweeps, 1) / 1e3
+        achieved = alg_bytes / avg_sweep_s / 1e9 if sweeps else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (see profiles/README.md)
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps)",
+            "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
+            "signals_per_sec": K * world / tmax,
+            "config": {"workload": "configs[1]: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, "
+                                   "k=256, planted +-1 256-sparse x0 + noise 5e-3, eps=eps(Float32)",
+                       "signals_per_gpu": K, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_sweep<float,double,U=2,NT>", "launches_timed": int(sweeps),
+                         "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
+            "atoms_selected": int(atoms),
+        }
+        if not args.no_cpu_baseline:
+            try:
+                order0 = None
+                # selection order of signal W (first timed signal) for the parity cross-check
+                i0, v0, o0 = D.ctx.omp(B[W].cpu().numpy(), K_ATOMS, eps)
+                order0 = o0
+                out["cpu_baseline"] = cpu_baseline(At, B[W], order0, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    D.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -22,7 +23,7 @@ struct Solver {
     int G = 0, Mpad = 0, jpad = 0;
     double *b = nullptr, *r = nullptr, *cvec = nullptr, *pval = nullptr;
     int* pidx = nullptr;
-    double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr;
+    double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr, *P1s = nullptr;
     double *avec = nullptr, *vvec = nullptr, *coef = nullptr, *scal = nullptr;
     int *sel = nullptr, *cands = nullptr, *ncands = nullptr;
     DevState* st = nullptr;
@@ -47,6 +48,7 @@ struct csmp_ctx {
     int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
     int sweep_grid = 0, sweep_U = 1;
     bool sweep_full = false, sweep_nt = false;
+    bool force_reorth = false;  // debug/test knob: always run the second Gram-Schmidt pass
     size_t sweep_lds = 0;
     Solver s;
     // profiling
@@ -118,13 +120,16 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
         delete ctx;
         return CSMP_EHIP;
     }
+    // test knob: CSMP_FORCE_REORTH=1 always runs the second Gram-Schmidt pass (k_qr3)
+    const char* fr = getenv("CSMP_FORCE_REORTH");
+    ctx->force_reorth = fr && fr[0] == '1';
     *out = ctx;
     return CSMP_OK;
 }
 
 static void solver_free(Solver& s) {
     dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
-    dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
+    dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val);
     s = Solver();
@@ -246,8 +251,10 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
     ctx->sweep_lds = sweep_lds_bytes(ctx->Mv, vec);
     if (ctx->sweep_lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "M too large: the residual must fit the 160 KiB LDS");
-    ctx->sweep_U = 4;
-    ctx->sweep_nt = false;
+    // measured on MI355X at 4096 x 65536 f32 (tools/probe_sweep.py, profiles/): U=2 with
+    // non-temporal loads and 4 workgroups/CU is the fastest variant (6.09 TB/s vs 5.6 plain)
+    ctx->sweep_U = 2;
+    ctx->sweep_nt = true;
     // resident workgroups: LDS- and wave-limited (<=128 VGPRs -> 4 waves/SIMD -> 4 workgroups/CU)
     int per_cu = (int)std::min<size_t>(4, (160 * 1024) / ctx->sweep_lds);
     if (per_cu < 1) per_cu = 1;
@@ -328,6 +335,7 @@ static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
     CHECK(dmalloc(ctx, &s.P1, (size_t)s.G * kcap));
     CHECK(dmalloc(ctx, &s.P2, (size_t)s.G * kcap));
     CHECK(dmalloc(ctx, &s.P2s, (size_t)2 * s.G));
+    CHECK(dmalloc(ctx, &s.P1s, (size_t)2 * s.G));
     CHECK(dmalloc(ctx, &s.scal, 8));
     CHECK(dmalloc(ctx, &s.sel, kcap));
     CHECK(dmalloc(ctx, &s.cands, kcap));
@@ -376,8 +384,10 @@ static int launch_select(csmp_ctx* ctx, int mode, int skipmask) {
     return CSMP_OK;
 }
 
-// add_column!(AiQR, A[:, cand]) + residual update for the candidate the control kernel accepted
-static int launch_append(csmp_ctx* ctx) {
+// One atom through the append chain.  mode 1: atom = arg-max of the last sweep + OMP guards
+// (src/matchingpursuit.jl:63,65-66); mode 2: atom = cands[which] + GOMP's duplicate skip
+// (src/util.jl:119,129-134).  Then add_column!(AiQR, A[:, atom]) and the residual update.
+static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask) {
     Solver& s = ctx->s;
     const size_t lds = qr_lds_bytes(s.kcap);
     if (lds > 64 * 1024) {
@@ -388,14 +398,18 @@ static int launch_append(csmp_ctx* ctx) {
     }
     if (ctx->dtype == CSMP_F32)
         hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)ctx->dA, ctx->ld,
-                           (int)ctx->M, (const double*)s.Q, s.ldq, (const DevState*)s.st, s.avec, s.P1, s.kcap, s.jpad);
+                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
+                           (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s);
     else
         hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)ctx->dA, ctx->ld,
-                           (int)ctx->M, (const double*)s.Q, s.ldq, (const DevState*)s.st, s.avec, s.P1, s.kcap, s.jpad);
+                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
+                           (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s);
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)s.Q, s.ldq,
-                       (const DevState*)s.st, (const double*)s.avec, (const double*)s.r, (const double*)s.P1, s.G, s.W1,
-                       s.vvec, s.P2, s.P2s, s.kcap, s.jpad);
+    hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
+                       (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
+                       s.jpad, ctx->force_reorth ? 1 : 0);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qr3, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.vvec, s.r,
                        (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, s.jpad);
@@ -418,8 +432,7 @@ static int launch_mp_update(csmp_ctx* ctx) {
 static int omp_step(csmp_ctx* ctx, double eps, int check_eps) {
     const int skip = STOP_EPS | STOP_STAG | STOP_FULL;
     CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skip));
-    CHECK(launch_select(ctx, 1, skip));
-    return launch_append(ctx);
+    return launch_append(ctx, 1, 0, skip);
 }
 
 // ldiv! + SparseVector assembly into device outputs
@@ -624,8 +637,7 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
         case CSMP_ALGO_OMP: {
             // update!(P::OMP, x) alone: no eps logic (that belongs to the omp driver)
             CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
-            CHECK(launch_select(ctx, 1, STOP_FULL));
-            return launch_append(ctx);
+            return launch_append(ctx, 1, 0, STOP_FULL);
         }
         default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL);
     }

@@ -28,8 +28,8 @@ constexpr int kQrThreads = 256;
 enum : int { STOP_EPS = 1, STOP_STAG = 2, STOP_FULL = 4 };
 
 // Control block of one solve, in device memory.  Written only by single-workgroup control
-// kernels (k_select / k_ctl / k_init) and by workgroup 0 of k_qr3 / k_mp_update at their very
-// end (fields no workgroup of the same launch reads), so no launch races with itself.
+// kernels (k_select / k_init) and by workgroup 0 of k_qr1 / k_qr3 / k_mp_update (fields no
+// workgroup of the same launch depends on), so no launch races with itself.
 struct DevState {
     int nsel;       // columns in the QR / atoms in the support (MP: steps taken)
     int j;          // nsel frozen for the current step's QR kernels
@@ -37,7 +37,8 @@ struct DevState {
     int go;         // 1: the current step's append kernels run
     int done;       // STOP_* bits
     int steps;      // update! calls that changed x
-    int pad0, pad1;
+    int go2;        // 1: k_qr2 asked for the re-orthogonalisation pass (k_qr3)
+    int pad1;
     double rnorm2;  // ||r||^2 seen by the last sweep prologue
     double cval;    // signed <a_cand, r> (MP coefficient, src/matchingpursuit.jl:29)
 };
@@ -293,152 +294,283 @@ __global__ __launch_bounds__(256) void k_select(const double* __restrict__ pval,
     }
 }
 
-// Control kernel for one entry of a candidate list (GOMP: src/util.jl:129-134 walks the l best
-// atoms and skips those already in the support, util.jl:119).
-__global__ __launch_bounds__(256) void k_ctl(const int* __restrict__ cands, int which, const int* __restrict__ ncands,
-                                             const int* __restrict__ sel, DevState* st, int M, int kcap, int skipmask) {
-    __shared__ int found;
-    const int tid = threadIdx.x;
-    if (st->done & skipmask) {
-        if (tid == 0) st->go = 0;
-        return;
-    }
-    const int nsel = st->nsel;
-    const int valid = which < *ncands;
-    const int cand = valid ? cands[which] : -1;
-    if (tid == 0) found = 0;
-    __syncthreads();
-    for (int q = tid; q < nsel; q += 256)
-        if (sel[q] == cand) found = 1;
-    __syncthreads();
-    if (tid == 0) {
-        int go = valid && !found;
-        if (nsel >= M || nsel >= kcap) {  // :117 guard / QR capacity
-            st->done |= STOP_FULL;
-            go = 0;
-        }
-        st->cand = cand;
-        st->j = nsel;
-        st->go = go;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // On-device QR append (classical Gram-Schmidt with one re-orthogonalisation, "CGS2", in its
 // two-reduction form): Q is M x kcap Float64 column-major, split into slabs of 64 rows, one
 // workgroup per slab.  A grid-wide sum is a kernel boundary (cheaper on MI355X than an in-kernel
 // grid barrier): partial sums are written per slab and re-summed in a fixed order by every
 // workgroup of the next kernel, so results are bitwise reproducible.
-//   k_qr1:  a = A[:,cand];                 P1[g] = Q_g' a_g
-//   k_qr2:  w1 = sum_g P1[g];  v = a - Q w1;  P2[g] = Q_g' v_g,  |v_g|^2,  v_g' r_g
-//   k_qr3:  w2 = sum_g P2[g];  rho^2 = |v|^2 - |w2|^2;  q = (v - Q w2)/rho;  z_j = v'r/rho;
+//   k_qr1:  pick the atom (arg-max partials or a candidate list) + the reference's guards;
+//           a = A[:,cand];                 P1[:,g] = Q_g' a_g
+//   k_qr2:  w1 = sum_g P1[:,g];  v = a - Q w1;  P2[:,g] = Q_g' v_g,  |v_g|^2,  v_g' r_g
+//   k_qr3:  w2 = sum_g P2[:,g];  rho^2 = |v|^2 - |w2|^2;  q = (v - Q w2)/rho;  z_j = v'r/rho;
 //           r -= q z_j;  R[:,j] = [w1 + w2; rho];  support += cand
 // (r is orthogonal to Q, so q'b == q'r up to rounding; z accumulates Q'b for the final solve.)
+// The kernels are latency-bound (a slab is 128 KiB at j = 256), so every phase issues all of its
+// loads before the first use: one L2 round trip per phase instead of one per column.
 
-// partial Q_g' x for this workgroup's slab: wave w covers rows 16w..16w+15, lane <-> column
-__device__ __forceinline__ void slab_qt_x(const double* __restrict__ Q, int64_t ldq, int g, int j,
+// partial Q_g' x for this workgroup's slab: wave w covers rows 16w..16w+15 (one 128-B line per
+// column), lane <-> column, four 64-column chunks (32 x 16-B loads) in flight per lane.
+// out is laid out [column][slab] so the consumer reads its G partials contiguously.
+__device__ __forceinline__ void slab_qt_x(const double* __restrict__ Q, int64_t ldq, int g, int G, int j,
                                           const double* xs /*LDS, 64*/, double* part /*LDS 4*jpad*/, int jpad,
-                                          double* __restrict__ out /*global, this slab's row of partials*/) {
+                                          double* __restrict__ out /*global [kcap][G]*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double xr[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) xr[i] = xs[wave * 16 + i];
-    for (int c = lane; c < j; c += kWave) {
-        const f64x2* q = reinterpret_cast<const f64x2*>(Q + (int64_t)c * ldq + g * kSlabRows + wave * 16);
-        double acc = 0.0;
+    const double* base = Q + g * kSlabRows + wave * 16;
+    for (int c0 = 0; c0 < j; c0 += 4 * kWave) {
+        f64x2 v[4][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f64x2 v = q[i];
-            acc = fma(v.x, xr[2 * i], acc);
-            acc = fma(v.y, xr[2 * i + 1], acc);
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * kWave + lane;
+            const f64x2* q = reinterpret_cast<const f64x2*>(base + (int64_t)(c < j ? c : 0) * ldq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = (c < j) ? q[i] : (f64x2)0.0;
         }
-        part[wave * jpad + c] = acc;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = c0 + u * kWave + lane;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a0 = fma(v[u][i].x, xr[2 * i], a0);
+                a1 = fma(v[u][i].y, xr[2 * i + 1], a1);
+            }
+            if (c < j) part[wave * jpad + c] = a0 + a1;
+        }
     }
     __syncthreads();
     for (int c = tid; c < j; c += kQrThreads)
-        out[c] = (part[c] + part[jpad + c]) + (part[2 * jpad + c] + part[3 * jpad + c]);
+        out[(int64_t)c * G + g] = (part[c] + part[jpad + c]) + (part[2 * jpad + c] + part[3 * jpad + c]);
     __syncthreads();
 }
 
-// x_g -= Q_g w for this slab: lane <-> row, wave w takes columns c = w (mod 4); result in xs (LDS)
+// ws[c] = sum_g P[c][g] (fixed order) for c < j; returns this thread's sum of squares
+__device__ __forceinline__ double sum_partials(const double* __restrict__ P, int G, int j, double* ws) {
+    double sq = 0.0;
+    for (int c = threadIdx.x; c < j; c += kQrThreads) {
+        const double* p = P + (int64_t)c * G;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int gg = 0;
+        for (; gg + 16 <= G; gg += 16) {  // 8 x 16-B loads in flight
+            f64x2 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = reinterpret_cast<const f64x2*>(p + gg)[i];
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                s0 += t[i].x;
+                s1 += t[i].y;
+                s2 += t[i + 1].x;
+                s3 += t[i + 1].y;
+            }
+        }
+        for (; gg < G; ++gg) s0 += p[gg];
+        const double s = (s0 + s1) + (s2 + s3);
+        ws[c] = s;
+        sq = fma(s, s, sq);
+    }
+    return sq;
+}
+
+// x_g -= Q_g w for this slab.  8 column streams (4 waves x 2 half-waves), each lane owns 2 rows
+// (16-B loads, 512 B contiguous per column), 16 loads in flight per lane; result in xs (LDS).
 __device__ __forceinline__ void slab_x_minus_qw(const double* __restrict__ Q, int64_t ldq, int g, int j,
                                                 const double* ws /*LDS, j*/, double* xs /*LDS 64, in/out*/,
-                                                double* tmp /*LDS 4*64*/) {
+                                                double* tmp /*LDS 8*64*/) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const double* q = Q + g * kSlabRows + lane;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int c = wave;
-    for (; c + 12 < j; c += 16) {
-        const double q0 = q[(int64_t)c * ldq], q1 = q[(int64_t)(c + 4) * ldq];
-        const double q2 = q[(int64_t)(c + 8) * ldq], q3 = q[(int64_t)(c + 12) * ldq];
-        a0 = fma(q0, ws[c], a0);
-        a1 = fma(q1, ws[c + 4], a1);
-        a2 = fma(q2, ws[c + 8], a2);
-        a3 = fma(q3, ws[c + 12], a3);
+    const int stream = wave * 2 + (lane >> 5), l32 = lane & 31;
+    const double* q = Q + g * kSlabRows + 2 * l32;
+    double ax0 = 0.0, ay0 = 0.0, ax1 = 0.0, ay1 = 0.0;
+    int c = stream;
+    for (; c + 8 * 15 < j; c += 8 * 16) {
+        f64x2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const f64x2*>(q + (int64_t)(c + 8 * i) * ldq);
+#pragma unroll
+        for (int i = 0; i < 16; i += 2) {
+            const double w0 = ws[c + 8 * i], w1 = ws[c + 8 * (i + 1)];
+            ax0 = fma(v[i].x, w0, ax0);
+            ay0 = fma(v[i].y, w0, ay0);
+            ax1 = fma(v[i + 1].x, w1, ax1);
+            ay1 = fma(v[i + 1].y, w1, ay1);
+        }
     }
-    for (; c < j; c += 4) a0 = fma(q[(int64_t)c * ldq], ws[c], a0);
-    tmp[wave * kSlabRows + lane] = (a0 + a1) + (a2 + a3);
+    for (; c < j; c += 8) {
+        const f64x2 v = *reinterpret_cast<const f64x2*>(q + (int64_t)c * ldq);
+        const double w0 = ws[c];
+        ax0 = fma(v.x, w0, ax0);
+        ay0 = fma(v.y, w0, ay0);
+    }
+    tmp[stream * kSlabRows + 2 * l32] = ax0 + ax1;
+    tmp[stream * kSlabRows + 2 * l32 + 1] = ay0 + ay1;
     __syncthreads();
-    if (tid < kSlabRows)
-        xs[tid] -= (tmp[tid] + tmp[kSlabRows + tid]) + (tmp[2 * kSlabRows + tid] + tmp[3 * kSlabRows + tid]);
+    if (tid < kSlabRows) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += tmp[t * kSlabRows + tid];
+        xs[tid] -= s;
+    }
     __syncthreads();
 }
 
-// LDS carve shared by the three QR kernels (dynamic): part[4*jpad] | ws[jpad] | xs[64] | tmp[256]
-__device__ __forceinline__ void qr_carve(double* base, int jpad, double*& part, double*& ws, double*& xs, double*& tmp) {
+// LDS carve shared by the QR kernels (dynamic): part[4*jpad] | ws[jpad] | xs[64] | tmp[512] | sc[8]
+__device__ __forceinline__ void qr_carve(double* base, int jpad, double*& part, double*& ws, double*& xs,
+                                         double*& tmp, double*& sc) {
     part = base;
     ws = part + 4 * jpad;
     xs = ws + jpad;
     tmp = xs + kSlabRows;
-}
-inline size_t qr_lds_bytes(int kcap) {
-    const int jpad = ((kcap + 63) / 64) * 64 + 2;
-    return (size_t)(5 * jpad + kSlabRows + 4 * kSlabRows + 8) * sizeof(double);
+    sc = tmp + 8 * kSlabRows;
 }
 inline int qr_jpad(int kcap) { return ((kcap + 63) / 64) * 64 + 2; }
-
-template <typename TA>
-__global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, int64_t ld, int M,
-                                                    const double* __restrict__ Q, int64_t ldq, const DevState* st,
-                                                    double* __restrict__ avec, double* __restrict__ P1, int kcap, int jpad) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (!st->go) return;
-    double *part, *ws, *xs, *tmp;
-    qr_carve(lds, jpad, part, ws, xs, tmp);
-    const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
-    if (tid < kSlabRows) {
-        const int row = g * kSlabRows + tid;
-        const double a = (row < M) ? (double)A[(int64_t)st->cand * ld + row] : 0.0;
-        xs[tid] = a;
-        avec[row] = a;
-    }
-    __syncthreads();
-    slab_qt_x(Q, ldq, g, j, xs, part, jpad, P1 + (int64_t)g * kcap);
+inline size_t qr_lds_bytes(int kcap) {
+    return (size_t)(5 * qr_jpad(kcap) + kSlabRows + 8 * kSlabRows + 8) * sizeof(double);
 }
 
-__global__ __launch_bounds__(kQrThreads) void k_qr2(const double* __restrict__ Q, int64_t ldq, const DevState* st,
-                                                    const double* __restrict__ avec, const double* __restrict__ r,
-                                                    const double* __restrict__ P1, int G, double* __restrict__ W1,
-                                                    double* __restrict__ vvec, double* __restrict__ P2,
-                                                    double* __restrict__ P2s, int kcap, int jpad) {
+// mode 1 (OMP): atom = arg-max over the sweep's workgroup partials; guards nnz < M (:63) and
+//   "i not in x.nzind" (:66) -- a failed guard makes every later update! the same no-op: done.
+// mode 2 (GOMP): atom = cands[which] (the l best of the sweep, src/util.jl:129-134), skipped if
+//   already in the support (util.jl:119); only a full support stops anything (:117).
+// Every workgroup derives the same decision from the same device data; workgroup 0 publishes it
+// (cand, j, go) for k_qr2 / k_qr3, which no workgroup of THIS launch reads.
+template <typename TA>
+__global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, int64_t ld, int M,
+                                                    const double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                    double* __restrict__ avec, double* __restrict__ P1, int G, int kcap,
+                                                    int jpad, int mode, const double* __restrict__ pval,
+                                                    const int* __restrict__ pidx, int nblk,
+                                                    const int* __restrict__ cands, const int* __restrict__ ncands,
+                                                    int which, const int* __restrict__ sel, int skipmask,
+                                                    const double* __restrict__ r, double* __restrict__ P1s) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *part, *ws, *xs, *tmp, *sc;
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
+    const int tid = threadIdx.x, g = blockIdx.x;
+    if (st->done & skipmask) {
+        if (g == 0 && tid == 0) st->go = 0;
+        return;
+    }
+    const int nsel = st->nsel;
+    int cand;
+    if (mode == 1) {
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int q = tid; q < nblk; q += kQrThreads)
+            if (better(pval[q], pidx[q], bv, bi)) {
+                bv = pval[q];
+                bi = pidx[q];
+            }
+        block_argmax(bv, bi, tmp, reinterpret_cast<int*>(tmp + kQrThreads));
+        cand = bi;
+    } else {
+        cand = (which < *ncands) ? cands[which] : -1;
+    }
+    int found = 0;
+    for (int q = tid; q < nsel; q += kQrThreads) found |= (sel[q] == cand);
+    found = __syncthreads_or(found);
+    const bool full = nsel >= M || nsel >= kcap;
+    const bool go = cand >= 0 && !found && !full;
+    if (g == 0 && tid == 0) {
+        st->cand = cand;
+        st->j = nsel;
+        st->go = go ? 1 : 0;
+        if (full)
+            st->done |= STOP_FULL;
+        else if (mode == 1 && found)
+            st->done |= STOP_STAG;
+    }
+    if (!go) return;
+    if (tid < kSlabRows) {
+        const int row = g * kSlabRows + tid;
+        const double a = (row < M) ? (double)A[(int64_t)cand * ld + row] : 0.0;
+        xs[tid] = a;
+        avec[row] = a;
+        double n2 = a * a, ar = a * r[row];
+        for (int s = 32; s >= 1; s >>= 1) {
+            n2 += shx(n2, s);
+            ar += shx(ar, s);
+        }
+        if (tid == 0) {
+            P1s[2 * g] = n2;      // |a_g|^2
+            P1s[2 * g + 1] = ar;  // a_g' r_g
+        }
+    }
+    __syncthreads();
+    slab_qt_x(Q, ldq, g, G, nsel, xs, part, jpad, P1);
+}
+
+// Publishes the new column (shared by the accept path of k_qr2 and by k_qr3).
+__device__ __forceinline__ void qr_commit(double* __restrict__ Q, int64_t ldq, DevState* st, double* __restrict__ r,
+                                          double* __restrict__ R, double* __restrict__ z, int* __restrict__ sel,
+                                          int kcap, int g, int j, const double* xs, double rr, double rho, double zj,
+                                          const double* W1 /*global or null*/, const double* ws /*LDS*/) {
+    const int tid = threadIdx.x;
+    if (tid < kSlabRows) {
+        const int row = g * kSlabRows + tid;
+        const double q = (rho > 0.0) ? xs[tid] / rho : 0.0;
+        Q[(int64_t)j * ldq + row] = q;
+        r[row] = fma(-q, zj, rr);
+    }
+    if (g == 0) {
+        for (int c = tid; c < j; c += kQrThreads) R[(int64_t)j * kcap + c] = W1 ? W1[c] + ws[c] : ws[c];
+        if (tid == 0) {
+            R[(int64_t)j * kcap + j] = (rho > 0.0) ? rho : 1.0;  // degenerate column: coefficient 0
+            z[j] = zj;
+            sel[j] = st->cand;
+            st->nsel = j + 1;
+            st->steps += 1;
+        }
+    }
+}
+
+// Second kernel of the append.  With rho^2 = |a|^2 - |w1|^2 (Pythagoras) the Daniel-Gragg-Kaufman-
+// Stewart test rho^2 >= |a|^2 / 2 says whether the first Gram-Schmidt pass lost accuracy to
+// cancellation.  If it did not (always, for incoherent dictionaries with k << M) the column is
+// committed here and k_qr3 returns at once; otherwise the second pass runs as before.
+__global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                    const double* __restrict__ avec, double* __restrict__ r,
+                                                    const double* __restrict__ P1, const double* __restrict__ P1s,
+                                                    int G, double* __restrict__ W1, double* __restrict__ vvec,
+                                                    double* __restrict__ P2, double* __restrict__ P2s,
+                                                    double* __restrict__ R, double* __restrict__ z,
+                                                    int* __restrict__ sel, int kcap, int jpad, int force_reorth) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     if (!st->go) return;
-    double *part, *ws, *xs, *tmp;
-    qr_carve(lds, jpad, part, ws, xs, tmp);
+    double *part, *ws, *xs, *tmp, *sc;
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
     const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
-    for (int c = tid; c < j; c += kQrThreads) {  // w1 = sum over slabs, fixed order
-        double s = 0.0;
-        for (int gg = 0; gg < G; ++gg) s += P1[(int64_t)gg * kcap + c];
-        ws[c] = s;
-        if (g == 0) W1[c] = s;
+    double rr = 0.0, na2 = 0.0, ar = 0.0;
+    if (tid < kSlabRows) {
+        xs[tid] = avec[g * kSlabRows + tid];
+        rr = r[g * kSlabRows + tid];
     }
-    if (tid < kSlabRows) xs[tid] = avec[g * kSlabRows + tid];
-    __syncthreads();
-    slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);  // v_g
+    for (int gg = tid; gg < G; gg += kQrThreads) {
+        na2 += P1s[2 * gg];
+        ar += P1s[2 * gg + 1];
+    }
+    double w1sq = sum_partials(P1, G, j, ws);  // w1
+    w1sq = block_sum256(w1sq, sc);
+    na2 = block_sum256(na2, sc);
+    ar = block_sum256(ar, sc);
+    const double rho2 = na2 - w1sq;
+    const bool accept = !force_reorth && rho2 >= 0.5 * na2 && rho2 > 0.0;
+    slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);  // v_g = a_g - Q_g w1
+    if (accept) {
+        const double rho = sqrt(rho2);
+        qr_commit(Q, ldq, st, r, R, z, sel, kcap, g, j, xs, rr, rho, ar / rho, nullptr, ws);
+        if (g == 0 && tid == 0) st->go2 = 0;
+        return;
+    }
+    if (g == 0) {
+        for (int c = tid; c < j; c += kQrThreads) W1[c] = ws[c];
+        if (tid == 0) st->go2 = 1;
+    }
     if (tid < kSlabRows) {
         const double v = xs[tid];
         vvec[g * kSlabRows + tid] = v;
-        double n2 = v * v, vr = v * r[g * kSlabRows + tid];
+        double n2 = v * v, vr = v * rr;
         for (int s = 32; s >= 1; s >>= 1) {
             n2 += shx(n2, s);
             vr += shx(vr, s);
@@ -448,7 +580,7 @@ __global__ __launch_bounds__(kQrThreads) void k_qr2(const double* __restrict__ Q
             P2s[2 * g + 1] = vr;
         }
     }
-    slab_qt_x(Q, ldq, g, j, xs, part, jpad, P2 + (int64_t)g * kcap);
+    slab_qt_x(Q, ldq, g, G, j, xs, part, jpad, P2);
 }
 
 __global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int64_t ldq, DevState* st,
@@ -457,53 +589,28 @@ __global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int6
                                                     int G, const double* __restrict__ W1, double* __restrict__ R,
                                                     double* __restrict__ z, int* __restrict__ sel, int kcap, int jpad) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (!st->go) return;
-    double *part, *ws, *xs, *tmp;
-    qr_carve(lds, jpad, part, ws, xs, tmp);
-    double* sc = tmp + 4 * kSlabRows;  // 8 spare doubles behind tmp
+    if (!st->go || !st->go2) return;
+    double *part, *ws, *xs, *tmp, *sc;
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
     const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
-    double w2sq = 0.0;
-    for (int c = tid; c < j; c += kQrThreads) {
-        double s = 0.0;
-        for (int gg = 0; gg < G; ++gg) s += P2[(int64_t)gg * kcap + c];
-        ws[c] = s;
-        w2sq = fma(s, s, w2sq);
+    double rr = 0.0, n2 = 0.0, vr = 0.0;
+    if (tid < kSlabRows) {
+        xs[tid] = vvec[g * kSlabRows + tid];
+        rr = r[g * kSlabRows + tid];
     }
-    if (tid < kSlabRows) xs[tid] = vvec[g * kSlabRows + tid];
-    w2sq = block_sum256(w2sq, sc);  // |w2|^2, fixed order
-    double n2 = 0.0, vr = 0.0;
     for (int gg = tid; gg < G; gg += kQrThreads) {
         n2 += P2s[2 * gg];
         vr += P2s[2 * gg + 1];
     }
+    double w2sq = sum_partials(P2, G, j, ws);  // w2
+    w2sq = block_sum256(w2sq, sc);             // |w2|^2, fixed order
     n2 = block_sum256(n2, sc);
     vr = block_sum256(vr, sc);
-    __syncthreads();
-    if (tid == 0) {
-        const double rho2 = n2 - w2sq;
-        const double rho_ = (rho2 > 0.0) ? sqrt(rho2) : 0.0;
-        sc[0] = rho_;
-        sc[1] = (rho_ > 0.0) ? vr / rho_ : 0.0;  // z_j = q_j' r
-    }
-    __syncthreads();
-    const double rho = sc[0], zj = sc[1];
-    slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);  // v_g - Q_g w2
-    if (tid < kSlabRows) {
-        const int row = g * kSlabRows + tid;
-        const double q = (rho > 0.0) ? xs[tid] / rho : 0.0;
-        Q[(int64_t)j * ldq + row] = q;
-        r[row] = fma(-q, zj, r[row]);
-    }
-    if (g == 0) {
-        for (int c = tid; c < j; c += kQrThreads) R[(int64_t)j * kcap + c] = W1[c] + ws[c];
-        if (tid == 0) {
-            R[(int64_t)j * kcap + j] = (rho > 0.0) ? rho : 1.0;  // degenerate column: coefficient 0
-            z[j] = zj;
-            sel[j] = st->cand;
-            st->nsel = j + 1;
-            st->steps += 1;
-        }
-    }
+    const double rho2 = n2 - w2sq;
+    const double rho = (rho2 > 0.0) ? sqrt(rho2) : 0.0;
+    const double zj = (rho > 0.0) ? vr / rho : 0.0;  // z_j = q_j' r
+    slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);      // v_g - Q_g w2
+    qr_commit(Q, ldq, st, r, R, z, sel, kcap, g, j, xs, rr, rho, zj, W1, ws);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -565,6 +672,7 @@ __global__ __launch_bounds__(256) void k_init(const TB* __restrict__ src, int M,
         st->go = 0;
         st->done = 0;
         st->steps = 0;
+        st->go2 = 0;
         st->rnorm2 = 0.0;
         st->cval = 0.0;
     }
