@@ -16,6 +16,7 @@
 using namespace csmp;
 
 static std::string g_create_err;
+static constexpr int kRsEqCap = 4096;
 
 struct Solver {
     int kcap = 0, outcap = 0;
@@ -26,6 +27,11 @@ struct Solver {
     double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr, *P1s = nullptr;
     double *avec = nullptr, *vvec = nullptr, *coef = nullptr, *scal = nullptr;
     int *sel = nullptr, *cands = nullptr, *ncands = nullptr;
+    // top-S selection scratch
+    double *top_lv = nullptr, *cvals = nullptr;
+    int *top_li = nullptr, *rs_gt = nullptr, *rs_eq = nullptr, *rs_work = nullptr;
+    RsState* rs = nullptr;
+    int top_nb = 0;
     DevState* st = nullptr;
     double* bstage = nullptr;  // Mpad doubles: host-uploaded b
     int64_t *out_idx = nullptr, *out_order = nullptr, *out_nnz = nullptr;
@@ -131,6 +137,7 @@ static void solver_free(Solver& s) {
     dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
+    dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val);
     s = Solver();
 }
@@ -341,6 +348,14 @@ static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
     CHECK(dmalloc(ctx, &s.cands, kcap));
     CHECK(dmalloc(ctx, &s.ncands, 4));
     CHECK(dmalloc(ctx, &s.st, 1));
+    s.top_nb = (int)((ctx->N + kTopChunk - 1) / kTopChunk);
+    CHECK(dmalloc(ctx, &s.top_lv, (size_t)s.top_nb * kTopSmall));
+    CHECK(dmalloc(ctx, &s.top_li, (size_t)s.top_nb * kTopSmall));
+    CHECK(dmalloc(ctx, &s.cvals, kcap));
+    CHECK(dmalloc(ctx, &s.rs_gt, kcap));
+    CHECK(dmalloc(ctx, &s.rs_eq, kRsEqCap));
+    CHECK(dmalloc(ctx, &s.rs_work, kcap));
+    CHECK(dmalloc(ctx, &s.rs, 1));
     CHECK(dmalloc(ctx, &s.out_idx, outcap));
     CHECK(dmalloc(ctx, &s.out_order, outcap));
     CHECK(dmalloc(ctx, &s.out_val, outcap));
@@ -668,16 +683,203 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
     return download_result(ctx, s.outcap, idx, val, nnz, order);
 }
 
-// ------------------------------------------------------------------------------------------ not yet built
-static int gomp_update(csmp_ctx* ctx, int64_t, double, int, int) { return fail(ctx, CSMP_ESTATE, "gomp: not built yet"); }
-extern "C" int csmp_gomp(csmp_ctx* ctx, const void*, int, int64_t, int64_t, double, int64_t*, double*, int64_t*, int64_t*) {
-    return fail(ctx, CSMP_ESTATE, "gomp: not built yet");
+// ------------------------------------------------------------------------------------------ top-S, GOMP, LS, SP
+// cands[0..S) <- the S atoms with the largest |c| (descending, ties by ascending index), on device
+static int launch_topS(csmp_ctx* ctx, int S) {
+    Solver& s = ctx->s;
+    if (S < 1 || S > s.kcap) return fail(ctx, CSMP_ERANGE, "top-S: S out of range");
+    if (S <= kTopSmall && (size_t)s.top_nb * S * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_top_local, dim3(s.top_nb), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, S, s.top_lv, s.top_li);
+        HIPCHECK(hipGetLastError());
+        const int n = s.top_nb * S;
+        hipLaunchKernelGGL(k_top_merge, dim3(1), dim3(256), (size_t)n * sizeof(double), ctx->stream, (const double*)s.top_lv,
+                           (const int*)s.top_li, n, S, s.cands, s.cvals, s.ncands);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
+    const int S_eff = (int)std::min<int64_t>(S, ctx->N);
+    const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->prop.multiProcessorCount * 4);
+    hipLaunchKernelGGL(k_rs_init, dim3(1), dim3(256), 0, ctx->stream, s.rs, S_eff);
+    for (int pass = 0; pass < 8; ++pass) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs);
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, ctx->stream, s.rs);
+    }
+    hipLaunchKernelGGL(k_rs_collect, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, s.rs_gt, s.rs_eq, kRsEqCap);
+    hipLaunchKernelGGL(k_rs_finish, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, (const int*)s.rs_gt,
+                       (const int*)s.rs_eq, kRsEqCap, s.rs_work, s.cands, s.cvals, s.ncands);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
 }
-extern "C" int csmp_sp(csmp_ctx* ctx, const void*, int, int64_t, double, int64_t, int64_t*, double*, int64_t*, int64_t*) {
-    return fail(ctx, CSMP_ESTATE, "sp: not built yet");
+
+// update!(P::GOMP, x, l): src/matchingpursuit.jl:116-123
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask) {
+    l = std::min<int64_t>(l, ctx->N);
+    CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skipmask));
+    CHECK(launch_topS(ctx, (int)l));
+    for (int64_t w = 0; w < l; ++w) CHECK(launch_append(ctx, 2, (int)w, skipmask));
+    return CSMP_OK;
 }
-extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t*, int64_t, const void*, int, double*) {
-    return fail(ctx, CSMP_ESTATE, "lstsq: not built yet");
+
+extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, int64_t k, double eps, int64_t* idx,
+                         double* val, int64_t* nnz, int64_t* order) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:127
+    if (!b || k < 0 || l < 1) return fail(ctx, CSMP_EINVAL, "gomp: b == NULL, k < 0 or l < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    // GOMP(A,b,l): QR capacity M (:108,:128); at most k atoms are ever added, and top-l needs l slots
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(k, l), std::max<int64_t>(ctx->M, l)));
+    CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k + l, 1)));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    const int main_skip = STOP_EPS | STOP_FULL;
+    for (int64_t it = 0; it < k / l; ++it) CHECK(gomp_update(ctx, l, eps, it > 0, main_skip));  // :130-133
+    const int64_t rem = k % l;                                                                      // :134
+    if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL));  // :135-137: runs even after an eps-break
+    CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+}
+
+// state reset + r = b for a fresh factorisation on the same b (SP re-factorises from scratch)
+static int solver_restart(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.b, (int)ctx->M, s.Mpad, s.bstage, s.r, s.st);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// factorize! + ldiv! (src/matchingpursuit.jl:219-227, src/twostage.jl:104-107) on the columns
+// `cols` (host list): QR by successive appends, residual r = b - A_S c as a by-product.
+static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
+    Solver& s = ctx->s;
+    if ((int)cols.size() > s.kcap) return fail(ctx, CSMP_ERANGE, "least squares: more columns than the QR capacity");
+    CHECK(solver_restart(ctx));
+    const int n = (int)cols.size();
+    HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (int w = 0; w < n; ++w) CHECK(launch_append(ctx, 2, w, 0));
+    return CSMP_OK;
+}
+
+extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t* cols, int64_t ncols, const void* b, int b_dtype, double* coef) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!cols || !b || !coef || ncols < 1) return fail(ctx, CSMP_EINVAL, "lstsq: bad arguments");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (ncols > ctx->M) return fail(ctx, CSMP_ERANGE, "lstsq: more columns than rows");
+    std::vector<int> c((size_t)ncols);
+    for (int64_t t = 0; t < ncols; ++t) {
+        if (cols[t] < 0 || cols[t] >= ctx->N) return fail(ctx, CSMP_ERANGE, "lstsq: column index out of range");
+        c[t] = (int)cols[t];
+    }
+    std::vector<int> srt = c;
+    std::sort(srt.begin(), srt.end());
+    if (std::adjacent_find(srt.begin(), srt.end()) != srt.end()) return fail(ctx, CSMP_EINVAL, "lstsq: duplicate column");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)ncols, (int)ncols));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    CHECK(ls_on_columns(ctx, c));
+    Solver& s = ctx->s;
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    HIPCHECK(hipMemcpyAsync(coef, s.coef, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));  // insertion order = cols order
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
+}
+
+static int residual_norm(csmp_ctx* ctx, double* out) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+    HIPCHECK(hipGetLastError());
+    double n2 = 0.0;
+    HIPCHECK(hipMemcpyAsync(&n2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    *out = std::sqrt(n2);
+    return CSMP_OK;
+}
+
+// current support + coefficients (sorted by index) to the host
+static int fetch_sorted(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val) {
+    Solver& s = ctx->s;
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    idx.assign((size_t)s.outcap, 0);
+    val.assign((size_t)s.outcap, 0.0);
+    int64_t n = 0;
+    CHECK(download_result(ctx, s.outcap, idx.data(), val.data(), &n, nullptr));
+    idx.resize((size_t)n);
+    val.resize((size_t)n);
+    return CSMP_OK;
+}
+
+// sp_acquisition!(P, x, k): src/twostage.jl:67-72 -- sweep on the current residual, union the k best
+// atoms into the support, least squares on the union
+static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val) {
+    Solver& s = ctx->s;
+    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+    CHECK(launch_topS(ctx, k));
+    std::vector<int> top((size_t)k);
+    int nt = 0;
+    HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(&nt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    std::vector<int> cols;
+    for (auto i : idx) cols.push_back((int)i);
+    for (int t = 0; t < nt; ++t) cols.push_back(top[t]);  // @. x[i] = NaN (:70)
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    CHECK(ls_on_columns(ctx, cols));  // solve! (:71)
+    return fetch_sorted(ctx, idx, val);
+}
+
+extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
+                       double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "sp: b == NULL or k < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
+    if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
+    if (maxiter < 0) maxiter = 16 * k;  // :87
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)(2 * k), (int)(2 * k)));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    CHECK(sp_acquire(ctx, (int)k, xi, xv));  // :90
+    double resnorm = 0.0;
+    CHECK(residual_norm(ctx, &resnorm));     // :91
+    int64_t it = 0;
+    while (it < maxiter) {                   // :92
+        const double oldnorm = resnorm;
+        // update!(P::SP, x): :75-83
+        CHECK(sp_acquire(ctx, (int)k, xi, xv));  // :77
+        const int64_t drop = (int64_t)xi.size() - k;
+        if (drop > 0) {  // :78-81: delete the (nnz-k) smallest |coef|, ties by position
+            std::vector<int> pos(xi.size());
+            for (size_t t = 0; t < pos.size(); ++t) pos[t] = (int)t;
+            std::stable_sort(pos.begin(), pos.end(), [&](int a, int c) { return std::fabs(xv[a]) < std::fabs(xv[c]); });
+            std::vector<char> kill(xi.size(), 0);
+            for (int64_t t = 0; t < drop; ++t) kill[pos[t]] = 1;
+            std::vector<int64_t> keep;
+            for (size_t t = 0; t < xi.size(); ++t)
+                if (!kill[t]) keep.push_back(xi[t]);
+            xi.swap(keep);
+        }
+        std::vector<int> cols;
+        for (auto i : xi) cols.push_back((int)i);
+        CHECK(ls_on_columns(ctx, cols));  // :82
+        CHECK(fetch_sorted(ctx, xi, xv));
+        ++it;
+        CHECK(residual_norm(ctx, &resnorm));                 // :95
+        if (resnorm <= delta || oldnorm <= resnorm) break;   // :96
+    }
+    for (size_t t = 0; t < xi.size(); ++t) {
+        if (idx) idx[t] = xi[t];
+        if (val) val[t] = xv[t];
+    }
+    if (nnz) *nnz = (int64_t)xi.size();
+    if (iters) *iters = it;
+    return CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ primitives
@@ -685,9 +887,10 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
     if (!ctx) return CSMP_EINVAL;
     if (!r || topk < 0) return fail(ctx, CSMP_EINVAL, "sweep: bad arguments");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
-    if (topk > 1) return fail(ctx, CSMP_ESTATE, "sweep: topk > 1 not built yet");
+    if (topk > ctx->N) topk = ctx->N;
+    if (topk > ctx->M) return fail(ctx, CSMP_ERANGE, "sweep: topk > size(A,1) is not supported (no caller of argmaxinner!(P,k) needs it)");
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(solver_ensure(ctx, 1, 1));
+    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(topk, 1), 1));
     ctx->s.begun = false;
     CHECK(upload_b(ctx, r, CSMP_F64));
     CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
@@ -703,6 +906,17 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         if (top_idx) top_idx[0] = hs.cand;
         if (top_val) top_val[0] = std::fabs(hs.cval);
+    } else if (topk > 1) {
+        CHECK(launch_topS(ctx, (int)topk));
+        std::vector<int> hc((size_t)topk);
+        std::vector<double> hv((size_t)topk);
+        HIPCHECK(hipMemcpyAsync(hc.data(), ctx->s.cands, (size_t)topk * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(hv.data(), ctx->s.cvals, (size_t)topk * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t t = 0; t < topk; ++t) {
+            if (top_idx) top_idx[t] = hc[t];
+            if (top_val) top_val[t] = hv[t];
+        }
     }
     return CSMP_OK;
 }

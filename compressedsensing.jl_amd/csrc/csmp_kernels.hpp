@@ -295,6 +295,210 @@ __global__ __launch_bounds__(256) void k_select(const double* __restrict__ pval,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Top-S selection over c = A'r: partialsortperm(abs(Ar), 1:S, rev=true) (src/matchingpursuit.jl:192)
+// -- descending by |c|, ties by ascending index.  Small S (GOMP's l): each workgroup takes the S
+// best of its chunk by S rounds of block arg-max in LDS, a single workgroup merges.  Large S (SP's
+// k): radix select on the IEEE bits of |c| (order-preserving for non-negative doubles), then a
+// rank sort of the survivors.
+constexpr int kTopChunk = 2048;  // |c| values per workgroup in the local stage
+constexpr int kTopSmall = 16;    // largest S served by the arg-max path
+
+__global__ __launch_bounds__(256) void k_top_local(const double* __restrict__ cvec, int64_t N, int S,
+                                                   double* __restrict__ lv, int* __restrict__ li) {
+    __shared__ double v[kTopChunk];
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kTopChunk;
+    for (int t = tid; t < kTopChunk; t += 256) v[t] = (base + t < N) ? fabs(cvec[base + t]) : -1.0;
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        double bv = -1.0;
+        int bi = 0x7fffffff;
+        for (int t = tid; t < kTopChunk; t += 256)
+            if (v[t] > bv) {  // ascending t per thread: '>' keeps the lowest index on ties
+                bv = v[t];
+                bi = t;
+            }
+        block_argmax(bv, bi, sv, si);
+        if (tid == 0) {
+            lv[(int64_t)blockIdx.x * S + s] = bv;
+            li[(int64_t)blockIdx.x * S + s] = (bv >= 0.0) ? (int)(base + bi) : -1;
+            if (bv >= 0.0) v[bi] = -1.0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_top_merge(const double* __restrict__ lv, const int* __restrict__ li, int n,
+                                                   int S, int* __restrict__ cands, double* __restrict__ cvals,
+                                                   int* __restrict__ ncands) {
+    extern __shared__ __attribute__((aligned(16))) double mv[];  // n values
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    for (int t = tid; t < n; t += 256) mv[t] = (li[t] >= 0) ? lv[t] : -1.0;
+    __syncthreads();
+    int cnt = 0;
+    for (int s = 0; s < S; ++s) {
+        double bv = -1.0;
+        int bi = 0x7fffffff, bp = -1;
+        for (int t = tid; t < n; t += 256)
+            if (better(mv[t], li[t], bv, bi) && mv[t] >= 0.0) {
+                bv = mv[t];
+                bi = li[t];
+                bp = t;
+            }
+        // arg-max on (value, atom index); carry the position through a second pass
+        double rv = bv;
+        int ri = bi;
+        block_argmax(rv, ri, sv, si);
+        if (rv >= 0.0 && bv == rv && bi == ri && bp >= 0) mv[bp] = -1.0;  // the unique owner retires it
+        if (tid == 0 && rv >= 0.0) {
+            cands[s] = ri;
+            cvals[s] = rv;
+        }
+        cnt += (rv >= 0.0);
+        __syncthreads();
+    }
+    if (tid == 0) *ncands = cnt;
+}
+
+// ---- radix select (large S)
+struct RsState {
+    unsigned long long prefix;  // bits fixed so far (high bits)
+    int pass;                   // next digit, 0 = most significant byte
+    int remaining;              // how many still to take among keys matching the prefix
+    int n_gt, n_eq;             // append counters of k_rs_collect
+    unsigned int hist[256];
+};
+
+__device__ __forceinline__ unsigned long long abs_key(double c) {
+    return (unsigned long long)__double_as_longlong(fabs(c));  // NaN sorts above inf; inputs are finite
+}
+
+__global__ __launch_bounds__(256) void k_rs_init(RsState* rs, int S) {
+    if (threadIdx.x == 0) {
+        rs->prefix = 0;
+        rs->pass = 0;
+        rs->remaining = S;
+        rs->n_gt = 0;
+        rs->n_eq = 0;
+    }
+    rs->hist[threadIdx.x] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec, int64_t N, RsState* rs) {
+    __shared__ unsigned int h[256];
+    const int tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const int pass = rs->pass;
+    const int shift = 56 - 8 * pass;
+    const unsigned long long prefix = rs->prefix;
+    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (64 - 8 * pass));
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < N; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = abs_key(cvec[i]);
+        if ((key & himask) == prefix) atomicAdd(&h[(key >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (h[tid]) atomicAdd(&rs->hist[tid], h[tid]);
+}
+
+__global__ __launch_bounds__(256) void k_rs_scan(RsState* rs) {
+    __shared__ unsigned int h[256];
+    const int tid = threadIdx.x;
+    h[tid] = rs->hist[tid];
+    __syncthreads();
+    if (tid == 0) {
+        int rem = rs->remaining;
+        int b = 255;
+        for (; b > 0; --b) {  // walk from the largest digit down
+            if ((int)h[b] >= rem) break;
+            rem -= (int)h[b];
+        }
+        rs->prefix |= (unsigned long long)b << (56 - 8 * rs->pass);
+        rs->remaining = rem;
+        rs->pass += 1;
+    }
+    __syncthreads();
+    rs->hist[tid] = 0;
+}
+
+// after 8 passes prefix == the S-th largest key T and `remaining` == how many keys equal to T to take
+__global__ __launch_bounds__(256) void k_rs_collect(const double* __restrict__ cvec, int64_t N, RsState* rs,
+                                                    int* __restrict__ gt_idx, int* __restrict__ eq_idx, int eq_cap) {
+    const unsigned long long T = rs->prefix;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const unsigned long long key = abs_key(cvec[i]);
+        if (key > T) {
+            gt_idx[atomicAdd(&rs->n_gt, 1)] = (int)i;
+        } else if (key == T) {
+            const int p = atomicAdd(&rs->n_eq, 1);
+            if (p < eq_cap) eq_idx[p] = (int)i;
+        }
+    }
+}
+
+// ONE workgroup: the keys above T plus the `remaining` lowest-index keys equal to T, rank-sorted by
+// (|c| descending, index ascending) into cands.  (The append order above is arbitrary; the sort
+// makes the output deterministic.)  If more keys tie at T than eq_idx holds (e.g. r = 0: every
+// |c| is 0), the ties are taken by an in-order scan of c instead.
+__global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cvec, int64_t N, RsState* rs,
+                                                   const int* __restrict__ gt_idx, const int* __restrict__ eq_idx,
+                                                   int eq_cap, int* __restrict__ work /*S ints*/,
+                                                   int* __restrict__ cands, double* __restrict__ cvals,
+                                                   int* __restrict__ ncands) {
+    __shared__ int wcnt[4];
+    __shared__ int taken;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ngt = rs->n_gt, neq = rs->n_eq, take = min(rs->remaining, neq);
+    const unsigned long long T = rs->prefix;
+    for (int t = tid; t < ngt; t += 256) work[t] = gt_idx[t];
+    if (neq <= eq_cap) {
+        for (int t = tid; t < neq; t += 256) {  // rank the ties by index, keep the `take` lowest
+            const int me = eq_idx[t];
+            int rank = 0;
+            for (int u = 0; u < neq; ++u) rank += (eq_idx[u] < me);
+            if (rank < take) work[ngt + rank] = me;
+        }
+    } else {
+        if (tid == 0) taken = 0;
+        __syncthreads();
+        for (int64_t base = 0; base < N; base += 256) {
+            const int64_t i = base + tid;
+            const bool hit = i < N && abs_key(cvec[i]) == T;
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int off = taken;
+            for (int w = 0; w < wave; ++w) off += wcnt[w];
+            off += __popcll(m & ((1ull << lane) - 1ull));
+            if (hit && off < take) work[ngt + off] = (int)i;
+            __syncthreads();
+            if (tid == 0) taken += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+            if (taken >= take) break;
+        }
+    }
+    __syncthreads();
+    const int n = ngt + take;
+    for (int t = tid; t < n; t += 256) {
+        const int me = work[t];
+        const double mv = fabs(cvec[me]);
+        int rank = 0;
+        for (int u = 0; u < n; ++u) {
+            const int o = work[u];
+            const double ov = fabs(cvec[o]);
+            rank += (ov > mv) || (ov == mv && o < me);
+        }
+        cands[rank] = me;
+        cvals[rank] = mv;
+    }
+    if (tid == 0) *ncands = n;
+}
+
+// ---------------------------------------------------------------------------------------------
 // On-device QR append (classical Gram-Schmidt with one re-orthogonalisation, "CGS2", in its
 // two-reduction form): Q is M x kcap Float64 column-major, split into slabs of 64 rows, one
 // workgroup per slab.  A grid-wide sum is a kernel boundary (cheaper on MI355X than an in-kernel

@@ -28,7 +28,8 @@ def test_golden_vectors(oracle, golden):
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
-        np.testing.assert_allclose(r[1], c["val"], rtol=1e-12, atol=1e-15, err_msg=name)
+        if np.all(np.isfinite(c["val"])):  # (gomp_dupcols is a singular LS problem: support only)
+            np.testing.assert_allclose(r[1], c["val"], rtol=1e-12, atol=1e-15, err_msg=name)
         if c["algo"] in ("omp", "gomp"):
             assert np.array_equal(r[2], c["order"]), name
         if c["algo"] == "sp":
