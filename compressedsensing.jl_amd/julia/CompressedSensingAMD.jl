@@ -1,0 +1,179 @@
+# CompressedSensingAMD.jl -- Julia host for libcsmp.so (MI355X / gfx950).
+#
+# Keeps CompressedSensing.jl's matching-pursuit API surface -- mp / omp / gomp / sp with the same
+# positional and keyword forms, the MP / OMP / GOMP update functors -- and forwards the work through
+# `ccall` to the C ABI declared in include/csmp.h.  Results are `SparseVector{Float64,Int}` with
+# sorted 1-based `nzind`, exactly what the reference returns (src/matchingpursuit.jl:76).
+#
+# NOTE: the build container has no `julia`, so this file has never been executed; it is the
+# reference-side binding a maintainer adds (see INTEGRATION.md).  The same ABI is exercised by the
+# Python/ctypes mirror (compressedsensing.jl_amd/_lib.py, api.py), which the test suite drives.
+module CompressedSensingAMD
+
+using LinearAlgebra
+using SparseArrays
+
+const libcsmp = get(ENV, "LIBCSMP", joinpath(@__DIR__, "..", "csrc", "libcsmp.so"))
+
+const CSMP_F32, CSMP_F64 = Cint(0), Cint(1)
+const CSMP_HOST = Cint(0)
+const ALGO_MP, ALGO_OMP, ALGO_GOMP = Cint(0), Cint(1), Cint(2)
+
+dtype_code(::Type{Float32}) = CSMP_F32
+dtype_code(::Type{Float64}) = CSMP_F64
+
+# ---------------------------------------------------------------------------------- context
+"""
+    Dictionary(A; device = 0)
+
+The measurement matrix resident in HBM (uploaded once).  Stands in for the `A` field of the
+reference's MP / OMP / GOMP / SP structs.
+"""
+mutable struct Dictionary{T<:Union{Float32,Float64}}
+    ctx::Ptr{Cvoid}
+    n::Int   # rows  (reference: n, m = size(A), src/matchingpursuit.jl:20)
+    m::Int   # atoms
+    function Dictionary(A::StridedMatrix{T}; device::Integer = 0) where {T<:Union{Float32,Float64}}
+        ref = Ref{Ptr{Cvoid}}(C_NULL)
+        rc = ccall((:csmp_create, libcsmp), Cint, (Ref{Ptr{Cvoid}}, Cint), ref, device)
+        rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), C_NULL)))
+        D = new{T}(ref[], size(A, 1), size(A, 2))
+        finalizer(d -> ccall((:csmp_destroy, libcsmp), Cint, (Ptr{Cvoid},), d.ctx), D)
+        GC.@preserve A check(D, ccall((:csmp_set_dictionary, libcsmp), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint),
+            D.ctx, pointer(A), size(A, 1), size(A, 2), stride(A, 2), dtype_code(T), CSMP_HOST))
+        return D
+    end
+end
+Base.size(D::Dictionary) = (D.n, D.m)
+Base.size(D::Dictionary, i::Int) = size(D)[i]
+Base.eltype(::Dictionary{T}) where {T} = T
+
+# the reference throws bare strings (src/matchingpursuit.jl:74; src/twostage.jl:76): so do we
+function check(D::Dictionary, rc::Integer)
+    rc == 0 && return
+    throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), D.ctx)))
+end
+
+const MatOrDict{T} = Union{StridedMatrix{T}, Dictionary{T}}
+dict(A::Dictionary) = A
+dict(A::StridedMatrix) = Dictionary(A)
+
+function to_sparse(m::Int, idx::Vector{Int64}, val::Vector{Float64}, nnz::Integer)
+    # 0-based sorted indices from the ABI -> SparseVector{Float64,Int} (src/matchingpursuit.jl:76)
+    SparseVector(m, idx[1:nnz] .+ 1, val[1:nnz])
+end
+
+bvec(b::AbstractVector{Float32}) = (convert(Vector{Float32}, b), CSMP_F32)
+bvec(b::AbstractVector) = (convert(Vector{Float64}, b), CSMP_F64)
+
+# ---------------------------------------------------------------------------------- omp
+# src/matchingpursuit.jl:73-91
+function omp(A::MatOrDict{T}, b::AbstractVector, ε::Real, k::Int = size(A, 1)) where {T}
+    ε ≥ 0 || throw("ε = $ε has to be non-negative")
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx, val, nnz = zeros(Int64, max(k, 1)), zeros(Float64, max(k, 1)), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_omp, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Int64}),
+        D.ctx, bb, bt, k, ε, idx, val, nnz, C_NULL))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+omp(A::MatOrDict{T}, b::AbstractVector, k::Int) where {T} = omp(A, b, eps(T), k)
+omp(A::MatOrDict{T}, b::AbstractVector; max_residual = eps(T), sparsity = min(size(A)...)) where {T} =
+    omp(A, b, max_residual, sparsity)
+
+# ---------------------------------------------------------------------------------- gomp
+# src/matchingpursuit.jl:126-148
+function gomp(A::MatOrDict{T}, b::AbstractVector, l::Int, ε::Real, k::Int = size(A, 1)) where {T}
+    ε ≥ 0 || throw("ε = $ε has to be non-negative")
+    D = dict(A)
+    bb, bt = bvec(b)
+    cap = max(k + l, 1)
+    idx, val, nnz = zeros(Int64, cap), zeros(Float64, cap), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_gomp, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Int64}),
+        D.ctx, bb, bt, l, k, ε, idx, val, nnz, C_NULL))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+gomp(A::MatOrDict{T}, b::AbstractVector, l::Int, k::Int) where {T} = gomp(A, b, l, eps(T), k)
+gomp(A::MatOrDict{T}, b::AbstractVector, l::Int; max_residual = eps(T), sparsity = size(A, 2)) where {T} =
+    gomp(A, b, l, max_residual, sparsity)
+
+# ---------------------------------------------------------------------------------- mp
+# src/matchingpursuit.jl:34-40 (x is a warm start and is updated in place)
+function mp(A::MatOrDict{T}, b::AbstractVector, k::Int, x::SparseVector = spzeros(size(A, 2))) where {T}
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx0, val0 = convert(Vector{Int64}, x.nzind .- 1), convert(Vector{Float64}, x.nzval)
+    cap = max(k + length(idx0), 1)
+    idx, val, nnz = zeros(Int64, cap), zeros(Float64, cap), Ref{Int64}(0)
+    GC.@preserve bb idx0 val0 idx val check(D, ccall((:csmp_mp, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, k, idx0, val0, length(idx0), idx, val, nnz))
+    y = to_sparse(size(D, 2), idx, val, nnz[])
+    resize!(x.nzind, nnz[]); resize!(x.nzval, nnz[])
+    copyto!(x.nzind, y.nzind); copyto!(x.nzval, y.nzval)
+    return x
+end
+
+# ---------------------------------------------------------------------------------- sp
+# src/twostage.jl:87-101
+function sp(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxiter = 16k) where {T}
+    2k > length(b) && error("2k = $(2k) > $(length(b)) = length(b) is invalid for Subspace Pursuit")
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx, val, nnz, iters = zeros(Int64, 2k), zeros(Float64, 2k), Ref{Int64}(0), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_sp, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}),
+        D.ctx, bb, bt, k, δ, maxiter, idx, val, nnz, iters))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+
+# ---------------------------------------------------------------------------------- functors
+# abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)
+abstract type Update{T} end
+(U::Update)(x) = update!(U, x)
+
+struct DevicePursuit{T} <: Update{T}
+    D::Dictionary{T}
+    algo::Cint
+    l::Int
+    kcap::Int
+end
+function begin_solver(A::MatOrDict{T}, b, algo, kcap, l = 1) where {T}
+    D = dict(A)
+    bb, bt = bvec(b)
+    GC.@preserve bb check(D, ccall((:csmp_solver_begin, libcsmp), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64),
+        D.ctx, algo, bb, bt, kcap, C_NULL, C_NULL, 0))
+    DevicePursuit{T}(D, algo, l, kcap)
+end
+MP(A, b) = begin_solver(A, b, ALGO_MP, 4096)                                        # :19-24
+OMP(A, b, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_OMP, min(k, size(A, 1)))      # :54-60
+GOMP(A, b, l::Int, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_GOMP, min(k, size(A, 1)), l)  # :108-114
+
+# update!(P, x): one greedy step on the device, then x <- the device's current solution
+function update!(P::DevicePursuit, x::SparseVector = spzeros(size(P.D, 2)), l::Int = P.l)
+    check(P.D, ccall((:csmp_solver_step, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.D.ctx, l))
+    idx, val, nnz = zeros(Int64, P.kcap), zeros(Float64, P.kcap), Ref{Int64}(0)
+    GC.@preserve idx val check(P.D, ccall((:csmp_solver_state, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Cint}),
+        P.D.ctx, idx, val, nnz, C_NULL, C_NULL, C_NULL))
+    y = to_sparse(size(P.D, 2), idx, val, nnz[])
+    resize!(x.nzind, nnz[]); resize!(x.nzval, nnz[])
+    copyto!(x.nzind, y.nzind); copyto!(x.nzval, y.nzval)
+    return x
+end
+
+# argmaxinner!(P) / argmaxinner!(P, k): src/matchingpursuit.jl:181-193
+function argmaxinner(D::Dictionary, r::AbstractVector, k::Int = 1)
+    rr = convert(Vector{Float64}, r)
+    ti, tv = zeros(Int64, k), zeros(Float64, k)
+    GC.@preserve rr ti tv check(D, ccall((:csmp_sweep, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int64, Ptr{Int64}, Ptr{Cdouble}),
+        D.ctx, rr, C_NULL, k, ti, tv))
+    k == 1 ? ti[1] + 1 : ti .+ 1
+end
+
+end # module

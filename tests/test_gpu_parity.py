@@ -362,3 +362,49 @@ def test_full_size_config2_properties(cs, oracle):
     np.testing.assert_allclose(o1[:2048], c1, rtol=1e-11, atol=1e-12)
     assert int(t1[0]) == int(np.argmax(o1))
     d.close()
+
+
+def test_full_size_config5_gomp_and_sp(cs, oracle):
+    """BASELINE config 5 shape (8192 x 131072 f32, 4 GiB): GOMP S=4 k=512 and Subspace Pursuit.
+    Oracle comparison on a prefix (a few 4-GiB host sweeps), size-independent properties on the
+    full solves: distinct sorted support of the right size, least-squares optimality on it
+    (A_S' r = 0), planted recovery, idempotent re-run."""
+    import torch
+    M, N, k, S = 8192, 131072, 512, 4
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    At = torch.empty((N, M), device="cuda", dtype=torch.float32)
+    for lo in range(0, N, 16384):
+        a = torch.randn((16384, M), generator=g, device="cuda", dtype=torch.float32)
+        At[lo:lo + 16384] = a / a.norm(dim=1, keepdim=True)
+    d = cs.Dictionary(At)
+    A = np.asfortranarray(At.cpu().numpy().T)
+    xs = cs.sparse_vector(N, k, rng=7)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=8)
+
+    ref = oracle.gomp(A, y, S, 16, EPS32)  # 4 sweeps on the host
+    got = d.ctx.gomp(y, S, 16, EPS32)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+
+    full = d.ctx.gomp(y, S, k, EPS32)
+    assert len(full[0]) == k and np.all(np.diff(full[0]) > 0)
+    assert np.array_equal(full[2][:16], ref[2])
+    AS = A[:, full[0]].astype(np.float64)
+    r = y - AS @ full[1]
+    assert np.abs(AS.T @ r).max() < 1e-10 * np.linalg.norm(y)
+    assert np.array_equal(full[0], xs.nzind)  # planted support recovered
+    again = d.ctx.gomp(y, S, k, EPS32)
+    assert np.array_equal(full[0], again[0]) and np.array_equal(full[1], again[1])
+
+    # Subspace Pursuit: oracle parity at k = 24 on the big dictionary, properties at k = 512
+    xs2 = cs.sparse_vector(N, 24, rng=9)
+    y2 = cs.perturb(A[:, xs2.nzind].astype(np.float64) @ xs2.nzval, 5e-3, rng=10)
+    rsp = oracle.sp(A, y2, 24, 1e-2)
+    gsp = d.ctx.sp(y2, 24, 1e-2)
+    assert gsp[2] == rsp[2] and np.array_equal(gsp[0], rsp[0]) and close(gsp[1], rsp[1])
+    big = d.ctx.sp(y, k, 1e-2)
+    assert len(big[0]) == k and np.all(np.diff(big[0]) > 0)
+    AS = A[:, big[0]].astype(np.float64)
+    r = y - AS @ big[1]
+    assert np.abs(AS.T @ r).max() < 1e-9 * np.linalg.norm(y)
+    assert np.array_equal(big[0], xs.nzind)
+    d.close()
