@@ -36,6 +36,9 @@ SIGNATURES = {
     "csmp_gomp": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_sp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
+                                   C.POINTER(C.c_double)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
     "csmp_solver_step": (C.c_int, [vp, i64]),
     "csmp_solver_state": (C.c_int, [vp, vp, vp, C.POINTER(i64), C.POINTER(C.c_double), vp, C.POINTER(C.c_int)]),
@@ -226,6 +229,39 @@ class Context:
         self.call("csmp_omp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
                   C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
         return idx, val, nnz
+
+    def omp_batch_mfma(self, B, k, eps):
+        """Batched (MFMA-screened) variant of omp_batch: same inputs and outputs."""
+        B = np.asfortranarray(B)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        M, nsig = B.shape
+        if M != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {M} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), nsig), np.int64, order="F")
+        val = np.zeros((int(k), nsig), np.float64, order="F")
+        nnz = np.zeros(nsig, np.int64)
+        self.call("csmp_omp_batch_mfma", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
+                  C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
+        return idx, val, nnz
+
+    def omp_batch_mfma_device(self, B, k, eps, idx, val, nnz):
+        """torch CUDA tensors as in omp_batch_device; synchronises once at the end."""
+        import torch
+        nsig, M = B.shape
+        assert B.is_cuda and B.is_contiguous() and M == self.M
+        assert idx.dtype == torch.int64 and val.dtype == torch.float64 and nnz.dtype == torch.int64
+        assert idx.is_contiguous() and val.is_contiguous() and idx.shape == (nsig, int(k)) and val.shape == (nsig, int(k))
+        code = F32 if B.dtype == torch.float32 else F64
+        self.call("csmp_omp_batch_mfma", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(k)), C.c_double(eps),
+                  vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
+
+    def batch_stats(self):
+        v = [i64(0) for _ in range(5)]
+        ms = C.c_double(0)
+        self.call("csmp_batch_stats", *[C.byref(x) for x in v], C.byref(ms))
+        return {"signals": v[0].value, "resolved_exactly": v[1].value, "uncertain": v[2].value, "illcond": v[3].value,
+                "screen_launches": v[4].value, "screen_ms": ms.value}
 
     def omp_batch_device(self, B, k, eps, idx, val, nnz):
         """torch CUDA tensors: B (nsig, M) rows = signals; outputs idx (nsig, k) int64,

@@ -4,6 +4,7 @@
 // synchronises inside a solve, only when results are copied back.
 #include "../../include/csmp.h"
 #include "csmp_kernels.hpp"
+#include "csmp_batched.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -40,6 +41,26 @@ struct Solver {
     bool begun = false;
 };
 
+// device state of the batched (MFMA-screened) path
+struct Batch {
+    __bf16* Ab = nullptr;  // dictionary as bf16 [Npad][Mk]
+    bool ab_valid = false;
+    int Mk = 0;
+    int64_t Npad = 0;
+    int n_atiles = 0;
+    float* amax = nullptr;  // max |A_ij| (device scalar) for the screening error bound
+    float amax_host = 0.f;
+    // per-batch buffers
+    int Bcap = 0, kcap = 0, Mr = 0;
+    __bf16* Rb = nullptr;
+    double *r = nullptr, *b = nullptr, *T = nullptr, *Tt = nullptr, *z = nullptr;
+    int* sel = nullptr;
+    BState* bs = nullptr;
+    float* cand_val = nullptr;
+    int* cand_idx = nullptr;
+    int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
+};
+
 struct csmp_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
@@ -57,12 +78,18 @@ struct csmp_ctx {
     bool force_reorth = false;  // debug/test knob: always run the second Gram-Schmidt pass
     size_t sweep_lds = 0;
     Solver s;
+    Batch bt;
     // profiling
     bool prof = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     int64_t prof_n = 0;
     double prof_ms = 0.0;
+    // second event pool: the batched path's screening GEMM
+    std::vector<hipEvent_t> ev2;
+    size_t ev2_used = 0;
+    int64_t prof2_n = 0;
+    double prof2_ms = 0.0;
 };
 
 #define HIPCHECK(expr)                                                                          \
@@ -133,6 +160,17 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
     return CSMP_OK;
 }
 
+static void batch_free(Batch& b, bool keep_dict) {
+    dfree(b.Rb); dfree(b.r); dfree(b.b); dfree(b.T); dfree(b.Tt); dfree(b.z); dfree(b.sel); dfree(b.bs);
+    dfree(b.cand_val); dfree(b.cand_idx);
+    b.Bcap = b.kcap = 0;
+    if (!keep_dict) {
+        dfree(b.Ab);
+        dfree(b.amax);
+        b.ab_valid = false;
+    }
+}
+
 static void solver_free(Solver& s) {
     dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
@@ -147,8 +185,10 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->stream);
     solver_free(ctx->s);
+    batch_free(ctx->bt, false);
     if (ctx->ownA) dfree(ctx->dA);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev2) (void)hipEventDestroy(e);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CSMP_OK;
@@ -282,6 +322,7 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     ctx->dA = nullptr;
     ctx->ownA = false;
     solver_free(ctx->s);
+    batch_free(ctx->bt, false);
     const size_t es = dtype == CSMP_F32 ? 4 : 8;
     const int vec = 16 / (int)es;
     const bool borrow = loc == CSMP_DEVICE && ((uintptr_t)A % 16 == 0) && (M % vec == 0) && (ldA % vec == 0);
@@ -918,6 +959,213 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
             if (top_val) top_val[t] = hv[t];
         }
     }
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ batched (MFMA-screened) OMP
+__global__ void k_absmax_f32(const float* __restrict__ A, int64_t n, float* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(A[i]));
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+__global__ void k_absmax_f64(const double* __restrict__ A, int64_t n, float* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, (float)fabs(A[i]));
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m * 1.0000002f));
+}
+
+static int batch_dict(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.ab_valid) return CSMP_OK;
+    b.Mk = (int)(((ctx->M + kBK - 1) / kBK) * kBK);
+    b.Npad = ((ctx->N + kBT - 1) / kBT) * kBT;
+    b.n_atiles = (int)(b.Npad / kBT);
+    HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
+    HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
+    HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+    const int64_t total = b.Npad * (b.Mk / 8);
+    const int grid = (int)((total + 255) / 256);
+    const int64_t nel = ctx->ld * ctx->N;
+    if (ctx->dtype == CSMP_F32) {
+        hipLaunchKernelGGL(k_b_convert<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+        hipLaunchKernelGGL(k_absmax_f32, dim3(2048), dim3(256), 0, ctx->stream, (const float*)ctx->dA, nel, b.amax);
+    } else {
+        hipLaunchKernelGGL(k_b_convert<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+        hipLaunchKernelGGL(k_absmax_f64, dim3(2048), dim3(256), 0, ctx->stream, (const double*)ctx->dA, nel, b.amax);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&b.amax_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.ab_valid = true;
+    return CSMP_OK;
+}
+
+static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
+    Batch& b = ctx->bt;
+    const int Bpad = ((nsig + kBT - 1) / kBT) * kBT;
+    if (b.Bcap >= Bpad && b.kcap >= kcap) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int nb = std::max(Bpad, b.Bcap), nk = std::max(kcap, b.kcap);
+    batch_free(b, true);
+    b.Bcap = nb;
+    b.kcap = nk;
+    b.Mr = (int)(((ctx->M + 3) / 4) * 4);
+    CHECK(dmalloc(ctx, &b.Rb, (size_t)nb * b.Mk));
+    CHECK(dmalloc(ctx, &b.r, (size_t)nb * b.Mr));
+    CHECK(dmalloc(ctx, &b.b, (size_t)nb * b.Mr));
+    CHECK(dmalloc(ctx, &b.T, (size_t)nb * nk * nk));
+    CHECK(dmalloc(ctx, &b.Tt, (size_t)nb * nk * nk));
+    CHECK(dmalloc(ctx, &b.z, (size_t)nb * nk));
+    CHECK(dmalloc(ctx, &b.sel, (size_t)nb * nk));
+    CHECK(dmalloc(ctx, &b.bs, (size_t)nb));
+    CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
+    CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
+    return CSMP_OK;
+}
+
+template <typename TA, int NI>
+static hipError_t b_step_launch(csmp_ctx* ctx, int nsig, double eps, int check_eps, double cert_coef) {
+    Batch& b = ctx->bt;
+    auto kern = k_b_step<TA, NI>;
+    const size_t lds = b_step_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+                       (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
+                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef);
+    return hipGetLastError();
+}
+
+template <typename TA>
+static hipError_t b_step_dispatch(csmp_ctx* ctx, int nsig, double eps, int check_eps, double cert_coef) {
+    const int groups = (ctx->Mv + 1023) / 1024;
+    if (groups <= 1) return b_step_launch<TA, 1>(ctx, nsig, eps, check_eps, cert_coef);
+    if (groups <= 2) return b_step_launch<TA, 2>(ctx, nsig, eps, check_eps, cert_coef);
+    if (groups <= 4) return b_step_launch<TA, 4>(ctx, nsig, eps, check_eps, cert_coef);
+    return b_step_launch<TA, 8>(ctx, nsig, eps, check_eps, cert_coef);
+}
+
+extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                                   double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (!B || nsig < 1 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch_mfma: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (ctx->Mv > 8192) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: M > 8192 not supported (use csmp_omp_batch)");
+    if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    CHECK(batch_dict(ctx));
+    CHECK(batch_ensure(ctx, (int)nsig, kc));
+    CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals
+    ctx->s.begun = false;
+    Batch& b = ctx->bt;
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    bool ownB = false;
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(hipMalloc(&dB, (size_t)ldB * (size_t)nsig * es));
+        ownB = true;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(hipMalloc((void**)&d_idx, (size_t)k * nsig * 8));
+        HIPCHECK(hipMalloc((void**)&d_val, (size_t)k * nsig * 8));
+        HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
+    }
+    const int Bpad = (int)(((nsig + kBT - 1) / kBT) * kBT);
+    const int n_stiles = Bpad / kBT;
+    if (b_dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+    else
+        hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipFuncSetAttribute((const void*)k_b_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds));
+    // screening error bound (8 sigma of the bf16 rounding model): delta = coef * ||r||
+    const double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+    for (int64_t t = 0; t < k; ++t) {
+        if (ctx->prof) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        hipLaunchKernelGGL(k_b_screen, dim3(b.n_atiles * n_stiles), dim3(256), kScreenLds, ctx->stream, (const __bf16*)b.Ab,
+                           (const __bf16*)b.Rb, b.Mk, b.n_atiles, n_stiles, ctx->N, b.cand_val, b.cand_idx);
+        HIPCHECK(hipGetLastError());
+        if (ctx->prof) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, (int)nsig, eps, t > 0, cert_coef)
+                                              : b_step_dispatch<double>(ctx, (int)nsig, eps, t > 0, cert_coef);
+        HIPCHECK(e);
+    }
+    hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
+                       (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);
+    HIPCHECK(hipGetLastError());
+    // signals whose screen could not be certified (or whose support turned ill-conditioned) are
+    // re-solved by the exact single-signal path
+    std::vector<BState> hs((size_t)nsig);
+    HIPCHECK(hipMemcpyAsync(hs.data(), b.bs, (size_t)nsig * sizeof(BState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.last_signals = nsig;
+    b.last_resolved = b.last_uncertain = b.last_illcond = 0;
+    int rc = CSMP_OK;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        if (!hs[sgn].uncertain && !hs[sgn].illcond) continue;
+        b.last_resolved += 1;
+        b.last_uncertain += hs[sgn].uncertain ? 1 : 0;
+        b.last_illcond += hs[sgn].illcond ? 1 : 0;
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
+                                 : init_from_device_t<double>(ctx, (const double*)col);
+        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0);
+        if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k);
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_idx);
+        (void)hipFree(d_val);
+        (void)hipFree(d_nnz);
+    }
+    if (ownB) {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dB);
+    }
+    return rc;
+}
+
+extern "C" int csmp_batch_stats(csmp_ctx* ctx, int64_t* signals, int64_t* resolved_exactly, int64_t* uncertain, int64_t* illcond,
+                                int64_t* screen_launches, double* screen_ms) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->ev2_used; i += 2) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev2[i], ctx->ev2[i + 1]));
+        ctx->prof2_ms += ms;
+        ctx->prof2_n += 1;
+    }
+    ctx->ev2_used = 0;
+    if (signals) *signals = ctx->bt.last_signals;
+    if (resolved_exactly) *resolved_exactly = ctx->bt.last_resolved;
+    if (uncertain) *uncertain = ctx->bt.last_uncertain;
+    if (illcond) *illcond = ctx->bt.last_illcond;
+    if (screen_launches) *screen_launches = ctx->prof2_n;
+    if (screen_ms) *screen_ms = ctx->prof2_ms;
+    ctx->prof2_n = 0;
+    ctx->prof2_ms = 0.0;
     return CSMP_OK;
 }
 

@@ -1,0 +1,640 @@
+// csmp_batched.hpp -- batched OMP: many signals sharing one dictionary (BASELINE configs 3/4).
+//
+// Not in the reference (it solves one b at a time, src/matchingpursuit.jl:73-82); this is the loop
+// `[omp(A, B[:,s], eps, k) for s in axes(B,2)]` restructured so that the dominant cost, the
+// residual-correlation sweep, becomes ONE dense GEMM  C = A' [r_1 ... r_B]  on the matrix cores:
+//
+//   k_b_screen  bf16 MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate) 128 atoms x 128 signals tiles
+//               with a fused epilogue that keeps the 4 largest |c| per (signal, atom tile): the
+//               N x B product (256 MiB at C3) is never written.
+//   k_b_step    one workgroup per signal: merges the tile candidates to the 16 best screened atoms,
+//               RESCORES them exactly (f32 master dictionary, Float64 products and sums against the
+//               Float64 residual), picks the arg-max by the exact value (first index on ties), then
+//               appends it to the signal's factorisation and updates the residual.
+//
+// The bf16 product only SCREENS; every value that decides or enters the result is Float64 on the
+// exactly promoted dictionary, so supports match the Float64 oracle.  A certificate (exact best
+// > 16th screened value + an error bound) guards the screen; a signal that ever fails it (or whose
+// support becomes ill-conditioned) is re-solved by the exact single-signal path.
+//
+// Per-signal factorisation: no Q is stored (it would be M x k Float64 per signal and read twice a
+// step).  With A_S = Q R:  w = Q'a = R^-T (A_S' a),  v = a - Q w = a - A_S (R^-1 w); the inverse
+// T = R^-1 is kept explicitly (and its transpose), so both "triangular solves" are coalesced
+// mat-vecs and the only large traffic is two streams over the support's f32 columns of A.
+#pragma once
+#include "csmp_kernels.hpp"
+
+namespace csmp {
+
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kBT = 128;         // tile edge: atoms x signals
+constexpr int kBK = 64;          // k elements staged per step
+constexpr int kBRow = 144;       // LDS bytes per staged row: 128 + 16 pad -> conflict-free ds_read_b128
+constexpr int kTileCand = 4;     // candidates kept per (signal, atom tile)
+constexpr int kKeep = 16;        // candidates rescored per signal and step
+constexpr size_t kScreenLds = 2 * 2 * kBT * kBRow;  // [buffer][A|R][row] = 73,728 B
+
+struct BState {
+    int nsel, done, uncertain, illcond;
+    double rnorm2;
+};
+
+// dictionary (f32/f64, column-major M x N) -> bf16 [Npad][Mk], zero padded (RNE: v_cvt_pk_bf16_f32)
+template <typename TA>
+__global__ __launch_bounds__(256) void k_b_convert(const TA* __restrict__ A, int64_t ld, int M, int64_t N,
+                                                   __bf16* __restrict__ out, int Mk, int64_t Npad) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kc = Mk / 8;
+    const int64_t n = idx / kc;
+    const int c = (int)(idx % kc);
+    if (n >= Npad) return;
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = c * 8 + e;
+        v[e] = (__bf16)((n < N && k < M) ? (float)A[n * ld + k] : 0.0f);
+    }
+    *reinterpret_cast<bf16x8*>(out + n * Mk + c * 8) = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Screening GEMM.  D[atom][signal] = sum_k A[atom][k] R[signal][k]; A-operand rows = atoms,
+// B-operand columns = signals, so a lane's 16 accumulator registers are 16 atoms of ONE signal
+// (C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5)).
+// 4 waves as 2 (atoms) x 2 (signals), each 64 x 64 = 2 x 2 MFMA tiles; BK = 64 staged through LDS
+// (register staging, padded rows), double buffered, one barrier per k-step.
+// Block map: the 8 XCDs each take whole atom tiles and walk all signal tiles of it back to back, so
+// an atom tile's 1 MiB of bf16 is fetched into one L2 once.
+struct top4 {
+    float v[4];
+    int i[4];
+};
+// insert (v, i) into the descending list (ties: lower atom index first)
+__device__ __forceinline__ void top4_push(top4& t, float v, int i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const bool up = (v > t.v[q]) || (v == t.v[q] && i < t.i[q]);
+        const float tv = up ? t.v[q] : v;
+        const int ti = up ? t.i[q] : i;
+        t.v[q] = up ? v : t.v[q];
+        t.i[q] = up ? i : t.i[q];
+        v = tv;
+        i = ti;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
+                                                  int n_atiles, int n_stiles, int64_t N,
+                                                  float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
+    int atile, stile;
+    {
+        const int bid = blockIdx.x;
+        if ((n_atiles & 7) == 0) {
+            const int xcd = bid & 7, local = bid >> 3;
+            stile = local % n_stiles;
+            atile = (local / n_stiles) * 8 + xcd;
+        } else {
+            stile = bid % n_stiles;
+            atile = bid / n_stiles;
+        }
+    }
+    const __bf16* gA = Ab + (int64_t)atile * kBT * Mk;
+    const __bf16* gR = Rb + (int64_t)stile * kBT * Mk;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x16)0.0f;
+
+    // staging map: 1024 16-B pieces per operand tile, 4 per thread
+    int srow[4], skc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = tid + 256 * i;
+        srow[i] = p >> 3;
+        skc[i] = p & 7;
+    }
+    bf16x8 ra[4], rr[4];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ra[i] = *reinterpret_cast<const bf16x8*>(gA + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
+            rr[i] = *reinterpret_cast<const bf16x8*>(gR + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow;
+        char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<bf16x8*>(la + srow[i] * kBRow + skc[i] * 16) = ra[i];
+            *reinterpret_cast<bf16x8*>(lr + srow[i] * kBRow + skc[i] * 16) = rr[i];
+        }
+    };
+    const int nkb = Mk / kBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) gload(kb + 1);
+        const char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow + (wr * 64 + r) * kBRow + h * 16;
+        const char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow + (wc * 64 + r) * kBRow + h * 16;
+#pragma unroll
+        for (int kk = 0; kk < kBK / 16; ++kk) {
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + kk * 32);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(la + 32 * kBRow + kk * 32);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lr + kk * 32);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lr + 32 * kBRow + kk * 32);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kb + 1 < nkb) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: the 4 largest |c| per signal over this tile's 128 atoms
+    top4* sc = reinterpret_cast<top4*>(smem);  // [2 (wr)][128 signals]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        top4 t;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            t.v[q] = -1.0f;
+            t.i[q] = 0x7fffffff;
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int atom = atile * kBT + wr * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+                const float v = (atom < N) ? fabsf(acc[m][n][q]) : -1.0f;
+                top4_push(t, v, atom);
+            }
+        // merge the two lane halves (same signal, interleaved atoms)
+        top4 o;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            o.v[q] = __shfl_xor(t.v[q], 32, kWave);
+            o.i[q] = __shfl_xor(t.i[q], 32, kWave);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) top4_push(t, o.v[q], o.i[q]);
+        if (h == 0) sc[wr * kBT + wc * 64 + n * 32 + r] = t;
+    }
+    __syncthreads();
+    if (tid < kBT) {
+        top4 t = sc[tid];
+        const top4 o = sc[kBT + tid];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) top4_push(t, o.v[q], o.i[q]);
+        const int64_t sig = (int64_t)stile * kBT + tid;
+        const int64_t base = (sig * n_atiles + atile) * kTileCand;
+        *reinterpret_cast<f32x4*>(cand_val + base) = f32x4{t.v[0], t.v[1], t.v[2], t.v[3]};
+        *reinterpret_cast<int4*>(cand_idx + base) = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers of the per-signal kernels: thread t owns the 4-row groups g = t + 256 i, i < NI
+template <typename TA>
+__device__ __forceinline__ void load4(const TA* p, int avail, double (&o)[4]) {
+    if constexpr (sizeof(TA) == 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    } else {
+        const f64x2 v0 = reinterpret_cast<const f64x2*>(p)[0];
+        const f64x2 v1 = (avail >= 4) ? reinterpret_cast<const f64x2*>(p)[1] : (f64x2)0.0;
+        o[0] = v0.x; o[1] = v0.y; o[2] = v1.x; o[3] = v1.y;
+    }
+}
+// 4 consecutive rows kept in the dictionary's own type (f32: one 16-B register quad) until used
+template <typename TA> struct Raw4;
+template <> struct Raw4<float> {
+    f32x4 v;
+    // avail = rows left in the column from p (a multiple of 4 for f32 storage)
+    __device__ __forceinline__ void load(const float* p, int avail) { (void)avail; v = *reinterpret_cast<const f32x4*>(p); }
+    __device__ __forceinline__ void zero() { v = (f32x4)0.0f; }
+    __device__ __forceinline__ double get(int e) const { return (double)v[e]; }
+};
+template <> struct Raw4<double> {
+    f64x2 v0, v1;
+    // f64 columns are padded to 2 rows only: the second pair may lie beyond the column
+    __device__ __forceinline__ void load(const double* p, int avail) {
+        v0 = reinterpret_cast<const f64x2*>(p)[0];
+        v1 = (avail >= 4) ? reinterpret_cast<const f64x2*>(p)[1] : (f64x2)0.0;
+    }
+    __device__ __forceinline__ void zero() { v0 = v1 = (f64x2)0.0; }
+    __device__ __forceinline__ double get(int e) const { return e < 2 ? v0[e] : v1[e - 2]; }
+};
+
+// b -> r (Float64) and its bf16 image; state reset.  One workgroup per signal (pad signals: zeros).
+template <typename TB>
+__global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int64_t ldB, int M, int nsig,
+                                                double* __restrict__ r_all, double* __restrict__ b_all, int Mr,
+                                                __bf16* __restrict__ rb_all, int Mk, BState* __restrict__ bs) {
+    const int s = blockIdx.x;
+    for (int m = threadIdx.x; m < Mk || m < Mr; m += 256) {
+        const double v = (s < nsig && m < M) ? (double)Bsig[(int64_t)s * ldB + m] : 0.0;
+        if (m < Mr) {
+            r_all[(int64_t)s * Mr + m] = v;
+            b_all[(int64_t)s * Mr + m] = v;
+        }
+        if (m < Mk) rb_all[(int64_t)s * Mk + m] = (__bf16)(float)v;
+    }
+    if (threadIdx.x == 0) {
+        bs[s].nsel = 0;
+        bs[s].done = (s < nsig) ? 0 : STOP_FULL;  // padding signals never run
+        bs[s].uncertain = 0;
+        bs[s].illcond = 0;
+        bs[s].rnorm2 = 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One OMP step of one signal (one workgroup per signal).  See the file header for the algebra.
+// LDS: a image (Float64, sweep layout) | vectors g,w,y (3 x kcap) | candidate scratch
+template <typename TA, int NI>
+__global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
+                                                const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
+                                                double* __restrict__ z_all, int* __restrict__ sel_all,
+                                                BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
+                                                __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
+                                                int check_eps, double cert_coef) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    BState& st = bs[s];
+    if (st.done) return;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    double* aimg = lds;                 // Mlds
+    double* gv = aimg + Mlds;           // kcap
+    double* wv = gv + kcap;             // kcap
+    double* yv = wv + kcap;             // kcap
+    double* sc = yv + kcap;             // 8
+    double* red = sc + 8;               // 4 x kKeep
+    float* cv = reinterpret_cast<float*>(red + 4 * kKeep);  // kKeep
+    int* ci = reinterpret_cast<int*>(cv + kKeep);           // kKeep
+    float* rv = reinterpret_cast<float*>(ci + kKeep);       // 256 (arg-max scratch)
+    int* ri = reinterpret_cast<int*>(rv + 256);             // 256
+
+    double* r = r_all + (int64_t)s * Mr;
+    const int j = st.nsel;
+    int* sel = sel_all + (int64_t)s * kcap;
+
+    // residual in registers (thread t: rows 4(t + 256 i) .. +3), ||r||^2, eps-stop of the last step
+    double rreg[NI][4];
+    double n2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = 4 * (tid + 256 * i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            rreg[i][e] = (row + e < Mrows) ? r[row + e] : 0.0;
+            n2 = fma(rreg[i][e], rreg[i][e], n2);
+        }
+    }
+    n2 = block_sum256(n2, sc);
+    if (tid == 0) st.rnorm2 = n2;
+    if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
+        if (tid == 0) st.done |= STOP_EPS;
+        return;
+    }
+    if (j >= Mrows || j >= kcap) {  // nnz(x) < size(A,1) guard (:63)
+        if (tid == 0) st.done |= STOP_FULL;
+        return;
+    }
+
+    // ---- merge the tile candidates: the kKeep largest screened |c| (ties: lower atom index).
+    // cert_thr bounds the screened value of every atom NOT in the list: the smallest kept value,
+    // or the last (4th) candidate of a tile whose candidates were all kept (atoms hidden behind it).
+    const float* cvs = cand_val + (int64_t)s * ncand;
+    const int* cis = cand_idx + (int64_t)s * ncand;
+    float thr_v = 3.0e38f, cert_thr = -1.0f;
+    int thr_i = -1;
+    for (int q = 0; q < kKeep; ++q) {
+        float bv = -1.0f;
+        int bi = 0x7fffffff, bslot = 0;
+        for (int t = tid; t < ncand; t += 256) {
+            const float v = cvs[t];
+            const int i = cis[t];
+            const bool below = (v < thr_v) || (v == thr_v && i > thr_i);  // strictly after the previous pick
+            if (below && v >= 0.0f && (v > bv || (v == bv && i < bi))) {
+                bv = v;
+                bi = i;
+                bslot = t & (kTileCand - 1);
+            }
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft, kWave);
+            const int oi = __shfl_xor(bi, sft, kWave);
+            const int os = __shfl_xor(bslot, sft, kWave);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+                bslot = os;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            rv[wave] = bv;
+            ri[wave] = bi;
+            ri[4 + wave] = bslot;
+        }
+        __syncthreads();
+        bv = rv[0];
+        bi = ri[0];
+        bslot = ri[4];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) {
+                bv = rv[w];
+                bi = ri[w];
+                bslot = ri[4 + w];
+            }
+        if (tid == 0) {
+            cv[q] = bv;
+            ci[q] = bi;
+        }
+        if (bv >= 0.0f && (bslot == kTileCand - 1 || q == kKeep - 1)) cert_thr = fmaxf(cert_thr, bv);
+        thr_v = bv;
+        thr_i = bi;
+    }
+    __syncthreads();
+
+    // ---- exact rescoring: <a_c, r> in Float64 for the kKeep candidates (all loads in flight)
+    double ex[kKeep];
+#pragma unroll
+    for (int half = 0; half < 4; ++half) {
+        Raw4<TA> av[kKeep / 4][NI];
+#pragma unroll
+        for (int q = 0; q < kKeep / 4; ++q) {
+            const int c = ci[half * (kKeep / 4) + q];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int row = 4 * (tid + 256 * i);
+                av[q][i].zero();
+                if (c >= 0 && c != 0x7fffffff && row < Mv) av[q][i].load(A + (int64_t)c * ld + row, Mv - row);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kKeep / 4; ++q) {
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = fma(av[q][i].get(e), rreg[i][e], acc);
+            for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+            if (lane == 0) red[wave * kKeep + half * (kKeep / 4) + q] = acc;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) ex[q] = (red[q] + red[kKeep + q]) + (red[2 * kKeep + q] + red[3 * kKeep + q]);
+    // arg-max by the exact value, first index on ties (Julia argmax)
+    int best = -1;
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+#pragma unroll
+    for (int q = 0; q < kKeep; ++q) {
+        const int c = ci[q];
+        if (c < 0 || c == 0x7fffffff) continue;
+        const double v = fabs(ex[q]);
+        if (v > bestv || (v == bestv && c < besti)) {
+            bestv = v;
+            besti = c;
+            best = q;
+        }
+    }
+    if (best < 0) {  // no candidate at all (N == 0): nothing to do
+        if (tid == 0) st.done |= STOP_FULL;
+        return;
+    }
+    // certificate: every atom outside the list has a screened value <= cert_thr, hence an exact
+    // value <= cert_thr + delta, delta = cert_coef * ||r|| (bf16 rounding model).
+    // cert_thr < 0 means fewer than kKeep atoms exist: everything was rescored.
+    if (cert_thr >= 0.0f && !(bestv > (double)cert_thr + cert_coef * sqrt(n2)))
+        if (tid == 0) st.uncertain += 1;
+    // "i not in x.nzind" (:66): a re-selected atom makes every later step the same no-op
+    int found = 0;
+    for (int t = tid; t < j; t += 256) found |= (sel[t] == besti);
+    found = __syncthreads_or(found);
+    if (found) {
+        if (tid == 0) st.done |= STOP_STAG;
+        return;
+    }
+    const double cexact = ex[best];
+
+    // ---- a = A[:, besti]: registers (row-owner form) and LDS image (sweep form); ||a||^2
+    double areg[NI][4];
+    double na2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int row = 4 * (tid + 256 * i);
+        if (row < Mv)
+            load4(A + (int64_t)besti * ld + row, Mv - row, areg[i]);
+        else
+            areg[i][0] = areg[i][1] = areg[i][2] = areg[i][3] = 0.0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            na2 = fma(areg[i][e], areg[i][e], na2);
+            if (row + e < Mlds) aimg[r_slot<VEC>(row + e)] = areg[i][e];
+        }
+    }
+    for (int m = 4 * 256 * NI + tid; m < Mlds; m += 256) aimg[r_slot<VEC>(m)] = 0.0;
+    na2 = block_sum256(na2, sc);  // (barrier inside: aimg is complete afterwards)
+
+    // ---- pass 1: g_i = <a_{s_i}, a>, one wave per 4 support columns (the sweep's inner loop)
+    {
+        const f64x2* as2 = reinterpret_cast<const f64x2*>(aimg);
+        for (int c0 = wave * 4; c0 < j; c0 += 16) {
+            const VT* p[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = sel[min(c0 + c, j - 1)];
+                p[c] = reinterpret_cast<const VT*>(A + (int64_t)col * ld) + lane;
+            }
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int t = 0; t < nchunk; ++t) {
+                VT a[4];
+                const int row = t * ROWS + lane * VEC;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a[c] = (VT)0;
+                    if (row < Mv) a[c] = p[c][t * kWave];
+                }
+                if constexpr (VEC == 4) {
+                    const f64x2 r01 = as2[(t * 2 + 0) * kWave + lane], r23 = as2[(t * 2 + 1) * kWave + lane];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c] = fma((double)a[c].x, r01.x, acc[c]);
+                        acc[c] = fma((double)a[c].y, r01.y, acc[c]);
+                        acc[c] = fma((double)a[c].z, r23.x, acc[c]);
+                        acc[c] = fma((double)a[c].w, r23.y, acc[c]);
+                    }
+                } else {
+                    const f64x2 r01 = as2[t * kWave + lane];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        acc[c] = fma((double)a[c].x, r01.x, acc[c]);
+                        acc[c] = fma((double)a[c].y, r01.y, acc[c]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                for (int sft = 32; sft >= 1; sft >>= 1) acc[c] += shx(acc[c], sft);
+                if (lane == 0 && c0 + c < j) gv[c0 + c] = acc[c];
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- w = T' g (w_i = sum_{t<=i} T[t,i] g_t): thread i walks column i of T (rows of Tt contiguous)
+    const double* T = T_all + (int64_t)s * kcap * kcap;    // column-major: T[t + i*kcap]
+    double* Tw = T_all + (int64_t)s * kcap * kcap;
+    const double* Tt = Tt_all + (int64_t)s * kcap * kcap;  // Tt[i + t*kcap] = T[t,i]
+    double* Ttw = Tt_all + (int64_t)s * kcap * kcap;
+    double w2 = 0.0;
+    for (int i = tid; i < j; i += 256) {
+        double acc = 0.0;
+        for (int t = 0; t <= i; ++t) acc = fma(Tt[i + (int64_t)t * kcap], gv[t], acc);
+        wv[i] = acc;
+        w2 = fma(acc, acc, w2);
+    }
+    w2 = block_sum256(w2, sc);
+    const double rho2 = na2 - w2;
+    // DGKS-style guard: a badly cancelling first pass means an ill-conditioned support; this
+    // light-weight factorisation is then not trusted and the signal goes to the exact path
+    if (!(rho2 >= 0.5 * na2) || !(rho2 > 0.0)) {
+        if (tid == 0) {
+            st.illcond += 1;
+            st.done |= STOP_FULL;
+        }
+        return;
+    }
+    const double rho = sqrt(rho2);
+    // ---- y = T w (y_t = sum_{i>=t} T[t,i] w_i): thread t walks row t of T (column-major: coalesced)
+    for (int t = tid; t < j; t += 256) {
+        double acc = 0.0;
+        for (int i = t; i < j; ++i) acc = fma(T[t + (int64_t)i * kcap], wv[i], acc);
+        yv[t] = acc;
+    }
+    __syncthreads();
+
+    // ---- pass 2: v = a - sum_i y_i a_{s_i}  (row-owner form, 4 columns x NI loads in flight)
+    {
+        int i = 0;
+        for (; i + 4 <= j; i += 4) {
+            Raw4<TA> cv4[4][NI];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int col = sel[i + c];
+#pragma unroll
+                for (int u = 0; u < NI; ++u) {
+                    const int row = 4 * (tid + 256 * u);
+                    cv4[c][u].zero();
+                    if (row < Mv) cv4[c][u].load(A + (int64_t)col * ld + row, Mv - row);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const double yc = yv[i + c];
+#pragma unroll
+                for (int u = 0; u < NI; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) areg[u][e] = fma(-yc, cv4[c][u].get(e), areg[u][e]);
+            }
+        }
+        for (; i < j; ++i) {
+            const int col = sel[i];
+            const double yc = yv[i];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int row = 4 * (tid + 256 * u);
+                double t4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (row < Mv) load4(A + (int64_t)col * ld + row, Mv - row, t4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) areg[u][e] = fma(-yc, t4[e], areg[u][e]);
+            }
+        }
+    }
+    // ---- q = v / rho, z_j = <a, r> / rho, r -= q z_j; new column of T = [-y / rho; 1 / rho]
+    const double zj = cexact / rho;
+    const double f = zj / rho;  // r -= v * (z_j / rho)
+    __bf16* rb = rb_all + (int64_t)s * Mk;
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int row = 4 * (tid + 256 * u);
+        bf16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const double nr = fma(-areg[u][e], f, rreg[u][e]);
+            if (row + e < Mrows) r[row + e] = nr;
+            o[e] = (__bf16)(float)((row + e < Mrows) ? nr : 0.0);
+        }
+        if (row < Mk) *reinterpret_cast<bf16x4*>(rb + row) = o;
+    }
+    for (int t = tid; t < j; t += 256) {
+        const double v = -yv[t] / rho;
+        Tw[t + (int64_t)j * kcap] = v;
+        Ttw[j + (int64_t)t * kcap] = v;
+    }
+    if (tid == 0) {
+        Tw[j + (int64_t)j * kcap] = 1.0 / rho;
+        Ttw[j + (int64_t)j * kcap] = 1.0 / rho;
+        z_all[(int64_t)s * kcap + j] = zj;
+        sel[j] = besti;
+        st.nsel = j + 1;
+    }
+}
+inline size_t b_step_lds_bytes(int Mv, int vec, int kcap) {
+    const int rows = kWave * vec;
+    const int nchunk = (Mv + rows - 1) / rows;
+    return (size_t)(nchunk * rows + 3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + 64;
+}
+
+// x = T z (ldiv!), sorted-index assembly; one workgroup per signal
+__global__ __launch_bounds__(256) void k_b_finish(const double* __restrict__ T_all, const double* __restrict__ z_all,
+                                                  const int* __restrict__ sel_all, const BState* __restrict__ bs, int kcap,
+                                                  int outk, int64_t* __restrict__ out_idx, double* __restrict__ out_val,
+                                                  int64_t* __restrict__ out_nnz) {
+    extern __shared__ __attribute__((aligned(16))) double x[];  // kcap
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const int j = bs[s].nsel;
+    const double* T = T_all + (int64_t)s * kcap * kcap;
+    const double* z = z_all + (int64_t)s * kcap;
+    const int* sel = sel_all + (int64_t)s * kcap;
+    for (int t = tid; t < j; t += 256) {
+        double acc = 0.0;
+        for (int i = t; i < j; ++i) acc = fma(T[t + (int64_t)i * kcap], z[i], acc);
+        x[t] = acc;
+    }
+    for (int t = tid; t < outk; t += 256) {
+        out_idx[(int64_t)s * outk + t] = -1;
+        out_val[(int64_t)s * outk + t] = 0.0;
+    }
+    __syncthreads();
+    for (int t = tid; t < j; t += 256) {
+        const int me = sel[t];
+        int rank = 0;
+        for (int u = 0; u < j; ++u) rank += (sel[u] < me);
+        out_idx[(int64_t)s * outk + rank] = me;
+        out_val[(int64_t)s * outk + rank] = x[t];
+    }
+    if (tid == 0) out_nnz[s] = j;
+}
+
+}  // namespace csmp

@@ -104,6 +104,20 @@ int csmp_sp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, 
 int csmp_omp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                    double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 
+/* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
+ * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
+ * SCREENS 16 candidates per signal; those are rescored in Float64 from the f32/f64 master
+ * dictionary, so selections and coefficients equal csmp_omp_batch's.  A signal whose screen cannot
+ * be certified against the bf16 error bound is re-solved by the exact path before returning.
+ * Requires M <= 8192.  With out_loc == CSMP_DEVICE this call still synchronises once (to read the
+ * per-signal certificates). */
+int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                        double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+/* statistics of the last csmp_omp_batch_mfma call: signals, how many were re-solved exactly (and
+ * why), and -- when profiling is enabled -- the number and total duration (ms) of screening GEMMs */
+int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly, int64_t *uncertain, int64_t *illcond,
+                     int64_t *screen_launches, double *screen_ms);
+
 /* ------------------------------------------------------------------ step-level API
  * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) then update!(P,x)
  * (src/CompressedSensing.jl:22-23; src/matchingpursuit.jl:26,62,116).  The solver state

@@ -408,3 +408,45 @@ def test_full_size_config5_gomp_and_sp(cs, oracle):
     assert np.abs(AS.T @ r).max() < 1e-9 * np.linalg.norm(y)
     assert np.array_equal(big[0], xs.nzind)
     d.close()
+
+
+@pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype):
+    """csmp_omp_batch_mfma: bf16 MFMA screening + Float64 rescoring must reproduce the oracle's
+    supports exactly and its coefficients to the north_star tolerance, signal by signal."""
+    n, m, k, nsig = shape
+    eps = float(np.finfo(dtype).eps)
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + 3 * m, dtype=dtype)
+    d = D(A)
+    rng = np.random.default_rng(nsig)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
+                                    for _ in range(nsig)], axis=1))
+    idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+    st = d.ctx.batch_stats()
+    assert st["signals"] == nsig and st["illcond"] == 0
+    check = range(nsig) if nsig <= 40 else list(range(0, nsig, max(1, nsig // 25)))
+    for s in check:
+        ref = oracle.omp(A, B[:, s], k, eps)
+        assert nnz[s] == len(ref[0]), (s, nnz[s], len(ref[0]))
+        assert np.array_equal(idx[:nnz[s], s], ref[0]), (s, idx[:nnz[s], s], ref[0])
+        assert close(val[:nnz[s], s], ref[1]), s
+    # and it agrees with the exact batch path on every signal
+    i2, v2, n2 = d.ctx.omp_batch(B, k, eps)
+    assert np.array_equal(nnz, n2) and np.array_equal(idx, i2)
+    assert np.allclose(val, v2, rtol=1e-9, atol=1e-12)
+
+
+def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
+    # noiseless 3-sparse signals, k = 8: every signal stops after 3 atoms (eps-stop inside k_b_step)
+    A, x, b = cs.sparse_data(n=96, m=400, k=3, rng=1, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(2)
+    B = np.asfortranarray(np.stack([A.astype(np.float64) @ cs.sparse_vector(400, 3, rng=rng).to_dense() for _ in range(7)], axis=1))
+    idx, val, nnz = d.ctx.omp_batch_mfma(B, 8, 1e-6)
+    for s in range(7):
+        ref = oracle.omp(A, B[:, s], 8, 1e-6)
+        assert nnz[s] == len(ref[0]) == 3 and np.array_equal(idx[:3, s], ref[0]) and close(val[:3, s], ref[1])
+        assert np.all(idx[3:, s] == -1)
+    with pytest.raises(cs.CsmpError):
+        d.ctx.omp_batch_mfma(B, 8, -1.0)
