@@ -228,9 +228,9 @@ extern "C" int csmp_device_info(csmp_ctx* ctx, char* name, int name_len, int* co
 }
 
 // ------------------------------------------------------------------------------------------ sweep launch
-template <typename TA, typename TACC, int U, bool FULL, bool NT>
+template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW = kCPW>
 static hipError_t sweep_launch_t(csmp_ctx* ctx, int grid, size_t lds, const double* r, double eps, int check_eps, int skipmask) {
-    auto kern = k_sweep<TA, TACC, U, FULL, NT>;
+    auto kern = k_sweep<TA, TACC, U, FULL, NT, CPW>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -251,6 +251,20 @@ static hipError_t sweep_dispatch(csmp_ctx* ctx, int U, bool full, bool nt, int g
                           : sweep_launch_t<TA, TACC, 2, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
     return nt ? sweep_launch_t<TA, TACC, 1, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
               : sweep_launch_t<TA, TACC, 1, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+}
+
+// product configuration: one column per wave at a time (CPW = 1), U chunks = U KiB in flight per lane-row
+template <typename TA>
+static hipError_t sweep_product(csmp_ctx* ctx, int U, bool full, int grid, size_t lds, const double* r, double eps,
+                                int check_eps, int skipmask) {
+    if (!full) return sweep_launch_t<TA, double, 1, false, false, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    switch (U) {
+        case 16: return sweep_launch_t<TA, double, 16, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+        case 8: return sweep_launch_t<TA, double, 8, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+        case 4: return sweep_launch_t<TA, double, 4, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+        case 2: return sweep_launch_t<TA, double, 2, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+        default: return sweep_launch_t<TA, double, 1, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    }
 }
 
 static int prof_mark(csmp_ctx* ctx) {
@@ -290,7 +304,13 @@ static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int chec
 }
 
 static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
-    return launch_sweep_cfg(ctx, r, eps, check_eps, skipmask, ctx->sweep_U, ctx->sweep_nt, false, ctx->sweep_grid);
+    if (ctx->prof) CHECK(prof_mark(ctx));
+    hipError_t e = ctx->dtype == CSMP_F32
+                       ? sweep_product<float>(ctx, ctx->sweep_U, ctx->sweep_full, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask)
+                       : sweep_product<double>(ctx, ctx->sweep_U, ctx->sweep_full, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
+    HIPCHECK(e);
+    if (ctx->prof) CHECK(prof_mark(ctx));
+    return CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ dictionary
@@ -298,14 +318,25 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
     ctx->sweep_lds = sweep_lds_bytes(ctx->Mv, vec);
     if (ctx->sweep_lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "M too large: the residual must fit the 160 KiB LDS");
-    // measured on MI355X at 4096 x 65536 f32 (tools/probe_sweep.py, profiles/): U=2 with
-    // non-temporal loads and 4 workgroups/CU is the fastest variant (6.09 TB/s vs 5.6 plain)
-    ctx->sweep_U = 2;
+    // Measured on MI355X at 4096 x 65536 f32 (tools/probe_sweep.py, tools/probe_sweep2.py, profiles/):
+    // ONE column per wave at a time with the whole column's loads in flight (U = 16 KiB-pieces),
+    // non-temporal, 3 workgroups/CU: 6.67 TB/s; four columns per wave (better amortised r reads and
+    // reductions) only reaches 6.1 TB/s -- fewer concurrent DRAM streams win.
+    const int rows = kWave * vec;
+    const int nchunk = (ctx->Mv + rows - 1) / rows;
+    ctx->sweep_full = (ctx->Mv % rows) == 0;
+    ctx->sweep_U = 1;
+    if (ctx->sweep_full)
+        for (int u : {16, 8, 4, 2})
+            if (nchunk % u == 0) {
+                ctx->sweep_U = u;
+                break;
+            }
     ctx->sweep_nt = true;
-    // resident workgroups: LDS- and wave-limited (<=128 VGPRs -> 4 waves/SIMD -> 4 workgroups/CU)
-    int per_cu = (int)std::min<size_t>(4, (160 * 1024) / ctx->sweep_lds);
+    int per_cu = ctx->sweep_U == 16 ? 3 : 4;
+    per_cu = (int)std::min<size_t>((size_t)per_cu, (160 * 1024) / ctx->sweep_lds);
     if (per_cu < 1) per_cu = 1;
-    const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kCPW - 1) / ((kSweepThreads / kWave) * kCPW);
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     int64_t grid = (int64_t)ctx->prop.multiProcessorCount * per_cu;
     ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
     return CSMP_OK;
@@ -1196,7 +1227,20 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
     return CSMP_OK;
 }
 
+// experimental column-per-wave variants (f32 dictionary, full chunks only): cpw in {1,2}, U in {4,8,16}
+static hipError_t sweep_launch_cpw(csmp_ctx* ctx, int cpw, int U, int grid, const double* r) {
+    const size_t lds = ctx->sweep_lds;
+    if (cpw == 1 && U == 4) return sweep_launch_t<float, double, 4, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
+    if (cpw == 1 && U == 8) return sweep_launch_t<float, double, 8, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
+    if (cpw == 1 && U == 16) return sweep_launch_t<float, double, 16, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
+    if (cpw == 2 && U == 2) return sweep_launch_t<float, double, 2, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
+    if (cpw == 2 && U == 4) return sweep_launch_t<float, double, 4, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
+    if (cpw == 2 && U == 8) return sweep_launch_t<float, double, 8, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
+    return hipErrorInvalidValue;
+}
+
 // variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (0 = product configuration)
+// variant >= 1<<20: experimental: (variant>>20) = cpw, bits 0-7 = U, bits 8-15 = workgroups per CU
 extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
     if (!ctx || reps < 1) return CSMP_EINVAL;
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
@@ -1212,6 +1256,30 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     CHECK(upload_b(ctx, r.data(), CSMP_F64));
     int U = ctx->sweep_U, grid = ctx->sweep_grid;
     bool nt = ctx->sweep_nt, f32acc = false;
+    const int cpwx = variant >> 20;
+    if (cpwx) {
+        if (ctx->dtype != CSMP_F32) return fail(ctx, CSMP_EINVAL, "bench_sweep: experimental variants are f32 only");
+        U = variant & 0xff;
+        const int per_cu = (variant >> 8) & 0xff;
+        const int64_t groups = (ctx->N + 4 * cpwx - 1) / (4 * cpwx);
+        grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * (per_cu ? per_cu : 4), groups));
+        if (grid > ctx->prop.multiProcessorCount * 8) grid = ctx->prop.multiProcessorCount * 8;
+        if (ctx->Mv % (256 * U)) return fail(ctx, CSMP_EINVAL, "bench_sweep: M must be a multiple of 256*U");
+        for (int i = 0; i < 3; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < reps; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
+        HIPCHECK(hipEventRecord(e1, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (avg_ms) *avg_ms = (double)ms / reps;
+        return CSMP_OK;
+    }
     if (variant != 0) {
         U = variant & 7;
         nt = (variant & 8) != 0;
@@ -1225,6 +1293,23 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     }
     const bool was = ctx->prof;
     ctx->prof = false;
+    if (variant == 0) {
+        for (int i = 0; i < 3; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+        hipEvent_t e0, e1;
+        HIPCHECK(hipEventCreate(&e0));
+        HIPCHECK(hipEventCreate(&e1));
+        HIPCHECK(hipEventRecord(e0, ctx->stream));
+        for (int i = 0; i < reps; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+        HIPCHECK(hipEventRecord(e1, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        float ms0 = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms0, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        ctx->prof = was;
+        if (avg_ms) *avg_ms = (double)ms0 / reps;
+        return CSMP_OK;
+    }
     for (int i = 0; i < 3; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));

@@ -87,7 +87,7 @@ __device__ __forceinline__ int r_slot(int m) {  // index in doubles
 //   NT    non-temporal dictionary loads (A is streamed once per sweep and exceeds every cache)
 //   TACC  double = product; float exists only as a bandwidth probe (csmp_bench_sweep)
 // dynamic LDS: r image (nchunk*64*VEC doubles) + 64 doubles of reduction scratch
-template <typename TA, typename TACC, int U, bool FULL, bool NT>
+template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW = kCPW>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
@@ -123,24 +123,24 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
     const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
     double bestv = -1.0;
     int besti = 0x7fffffff;
-    const int64_t stride = (int64_t)gridDim.x * NW * kCPW;
-    for (int64_t cg = ((int64_t)blockIdx.x * NW + wave) * kCPW; cg < N; cg += stride) {
-        const VT* p[kCPW];
+    const int64_t stride = (int64_t)gridDim.x * NW * CPW;
+    for (int64_t cg = ((int64_t)blockIdx.x * NW + wave) * CPW; cg < N; cg += stride) {
+        const VT* p[CPW];
 #pragma unroll
-        for (int c = 0; c < kCPW; ++c) {
+        for (int c = 0; c < CPW; ++c) {
             const int64_t col = (cg + c < N) ? cg + c : N - 1;
             p[c] = reinterpret_cast<const VT*>(A + col * ld) + lane;
         }
-        TACC acc[kCPW];
+        TACC acc[CPW];
 #pragma unroll
-        for (int c = 0; c < kCPW; ++c) acc[c] = (TACC)0;
+        for (int c = 0; c < CPW; ++c) acc[c] = (TACC)0;
 
         for (int t = 0; t < nchunk; t += U) {
-            VT a[U][kCPW];
+            VT a[U][CPW];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int c = 0; c < kCPW; ++c) {
+                for (int c = 0; c < CPW; ++c) {
                     if constexpr (FULL) {
                         if constexpr (NT)
                             a[u][c] = __builtin_nontemporal_load(p[c] + (t + u) * kWave);
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
                     const f64x2 r01 = rs[((t + u) * 2 + 0) * kWave + lane];
                     const f64x2 r23 = rs[((t + u) * 2 + 1) * kWave + lane];
 #pragma unroll
-                    for (int c = 0; c < kCPW; ++c) {
+                    for (int c = 0; c < CPW; ++c) {
                         acc[c] = fma((TACC)a[u][c].x, (TACC)r01.x, acc[c]);
                         acc[c] = fma((TACC)a[u][c].y, (TACC)r01.y, acc[c]);
                         acc[c] = fma((TACC)a[u][c].z, (TACC)r23.x, acc[c]);
@@ -168,34 +168,47 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
                 } else {
                     const f64x2 r01 = rs[(t + u) * kWave + lane];
 #pragma unroll
-                    for (int c = 0; c < kCPW; ++c) {
+                    for (int c = 0; c < CPW; ++c) {
                         acc[c] = fma((TACC)a[u][c].x, (TACC)r01.x, acc[c]);
                         acc[c] = fma((TACC)a[u][c].y, (TACC)r01.y, acc[c]);
                     }
                 }
             }
         }
-        // transposing butterfly: 4 accumulators x 64 lanes -> 16-lane group g holds column cg+g
-        double s0, s1;
-        {
+        // transposing butterfly: CPW accumulators x 64 lanes -> each (64/CPW)-lane group holds one column
+        double s0;
+        if constexpr (CPW == 4) {
+            double s1;
+            {
+                const bool hi = lane & 32;
+                const double k0 = hi ? (double)acc[2] : (double)acc[0], k1 = hi ? (double)acc[3] : (double)acc[1];
+                const double g0 = hi ? (double)acc[0] : (double)acc[2], g1 = hi ? (double)acc[1] : (double)acc[3];
+                s0 = k0 + shx(g0, 32);
+                s1 = k1 + shx(g1, 32);
+            }
+            {
+                const bool hi = lane & 16;
+                const double k = hi ? s1 : s0, g = hi ? s0 : s1;
+                s0 = k + shx(g, 16);
+            }
+        } else if constexpr (CPW == 2) {
             const bool hi = lane & 32;
-            const double k0 = hi ? (double)acc[2] : (double)acc[0], k1 = hi ? (double)acc[3] : (double)acc[1];
-            const double g0 = hi ? (double)acc[0] : (double)acc[2], g1 = hi ? (double)acc[1] : (double)acc[3];
-            s0 = k0 + shx(g0, 32);
-            s1 = k1 + shx(g1, 32);
-        }
-        {
-            const bool hi = lane & 16;
-            const double k = hi ? s1 : s0, g = hi ? s0 : s1;
-            s0 = k + shx(g, 16);
+            const double k = hi ? (double)acc[1] : (double)acc[0], g = hi ? (double)acc[0] : (double)acc[1];
+            s0 = k + shx(g, 32);
+            s0 += shx(s0, 16);
+        } else {
+            s0 = (double)acc[0];
+            s0 += shx(s0, 32);
+            s0 += shx(s0, 16);
         }
         s0 += shx(s0, 8);
         s0 += shx(s0, 4);
         s0 += shx(s0, 2);
         s0 += shx(s0, 1);
-        const int64_t col = cg + (lane >> 4);
+        constexpr int GL = kWave / CPW;  // lanes per column group
+        const int64_t col = cg + lane / GL;
         if (col < N) {
-            if ((lane & 15) == 0) cvec[col] = s0;
+            if ((lane & (GL - 1)) == 0) cvec[col] = s0;
             const double av = fabs(s0);
             if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
                 bestv = av;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
             }
         }
     }
-    if ((lane & 15) == 0) {
+    if ((lane & 15) == 0) {  // (with CPW < 4 several 16-lane groups carry the same pair: harmless)
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;
     }
