@@ -4,6 +4,9 @@ A 4096 x 65536 Float32 Gaussian dictionary (unit-norm atoms), k = 256.
 
 A "step" is one complete omp(A, b, k) solve of one synthetic signal = 256 atoms selected, each by
 one full sweep of the 1 GiB dictionary (K1 of SURVEY.md section 2.3) plus the on-device QR append.
+Every atom of every signal is selected by its own single-signal sweep (1 GiB streamed per atom);
+independent signals are pipelined three at a time so that the short append chain of two signals
+runs underneath the sweep of the third (csmp_omp_batch, DESIGN.md "tick kernel").
 Inputs (dictionary and signals) are resident in HBM before the timed region starts; results stay
 on the device and, with N > 1 ranks, are exchanged by ONE all_gather (RCCL) inside the timed
 region.  Signals are independent: weak scaling, K signals per rank.
@@ -33,9 +36,10 @@ SEED_A = 0xC0FFEE
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=16)
-    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--steps", type=int, default=18)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return p.parse_args()
 
@@ -151,7 +155,7 @@ def main():
         D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
     if world > 1:  # warm the collective too
         dist.all_gather([torch.empty(4, device=dev) for _ in range(world)], torch.zeros(4, device=dev))
-    D.ctx.profile_enable(True)
+    D.ctx.profile_enable(args.profile_every)  # HIP events around every n-th sweep launch of the timed region
     D.ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -192,7 +196,7 @@ def main():
                        "signals_per_gpu": K, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "csmp::k_sweep<float,double,16,true,true,1> (one column per wave, 16 x 1 KiB in flight, nt loads)", "launches_timed": int(sweeps),
+                         "kernel": "csmp::k_tick<float,16> = sweep of one signal (one column per wave, 16 x 1 KiB nt loads in flight) fused with the two short append stages of two other signals; csmp::k_sweep<float,double,16,true,true,1> when a signal runs alone", "launches_timed": int(sweeps),
                          "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
             "atoms_selected": int(atoms),
         }

@@ -317,7 +317,8 @@ class Context:
 
     # ---- measurement
     def profile_enable(self, on=True):
-        self.call("csmp_profile_enable", int(bool(on)))
+        """on=True: time every sweep launch with HIP events; on=n>1: every n-th; False: off."""
+        self.call("csmp_profile_enable", int(on))
 
     def profile_read(self, reset=True):
         n = i64(0)

@@ -39,6 +39,10 @@ struct Solver {
     double* out_val = nullptr;
     int algo = -1;
     bool begun = false;
+    int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
+    int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
+    int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
+    int sigcap = 0;
 };
 
 // device state of the batched (MFMA-screened) path
@@ -77,10 +81,16 @@ struct csmp_ctx {
     bool sweep_full = false, sweep_nt = false;
     bool force_reorth = false;  // debug/test knob: always run the second Gram-Schmidt pass
     size_t sweep_lds = 0;
-    Solver s;
+    Solver s;        // the ACTIVE solver slot (see activate_slot)
+    Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch
+    int active = 0;
+    bool pipeline = true;
+    int tick_wg_per_cu = 2;  // sweep workgroups per CU inside the tick kernel (CSMP_TICK_WGS)
     Batch bt;
     // profiling
     bool prof = false;
+    int prof_every = 1;       // time every n-th sweep launch only (an event pair costs a few us of stream time)
+    int64_t prof_count = 0;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     int64_t prof_n = 0;
@@ -153,6 +163,9 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
         delete ctx;
         return CSMP_EHIP;
     }
+    const char* pl = getenv("CSMP_PIPELINE");  // CSMP_PIPELINE=0: solve the signals of a batch strictly one after the other
+    ctx->pipeline = !(pl && pl[0] == '0');
+    if (const char* tw = getenv("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
     // test knob: CSMP_FORCE_REORTH=1 always runs the second Gram-Schmidt pass (k_qr3)
     const char* fr = getenv("CSMP_FORCE_REORTH");
     ctx->force_reorth = fr && fr[0] == '1';
@@ -171,20 +184,33 @@ static void batch_free(Batch& b, bool keep_dict) {
     }
 }
 
+// Make slot `slot` the active solver: every launch helper works on ctx->s / ctx->stream.
+static void activate_slot(csmp_ctx* ctx, int slot) {
+    if (ctx->active == slot) return;
+    ctx->park[ctx->active] = ctx->s;
+    ctx->s = ctx->park[slot];
+    ctx->park[slot] = Solver();
+    ctx->active = slot;
+}
+static hipError_t sync_all(csmp_ctx* ctx) { return hipStreamSynchronize(ctx->stream); }
+
 static void solver_free(Solver& s) {
     dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
-    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val);
+    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
     s = Solver();
 }
 
 extern "C" int csmp_destroy(csmp_ctx* ctx) {
     if (!ctx) return CSMP_OK;
     (void)hipSetDevice(ctx->dev);
-    (void)hipStreamSynchronize(ctx->stream);
-    solver_free(ctx->s);
+    (void)sync_all(ctx);
+    for (int q = 2; q >= 0; --q) {
+        activate_slot(ctx, q);
+        solver_free(ctx->s);
+    }
     batch_free(ctx->bt, false);
     if (ctx->ownA) dfree(ctx->dA);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
@@ -197,7 +223,8 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
 extern "C" int csmp_set_stream(csmp_ctx* ctx, void* hip_stream) {
     if (!ctx) return CSMP_EINVAL;
     HIPCHECK(hipSetDevice(ctx->dev));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
+    activate_slot(ctx, 0);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     if (hip_stream) {
         ctx->stream = (hipStream_t)hip_stream;
@@ -212,7 +239,7 @@ extern "C" int csmp_set_stream(csmp_ctx* ctx, void* hip_stream) {
 extern "C" int csmp_sync(csmp_ctx* ctx) {
     if (!ctx) return CSMP_EINVAL;
     HIPCHECK(hipSetDevice(ctx->dev));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     return CSMP_OK;
 }
 
@@ -267,6 +294,12 @@ static hipError_t sweep_product(csmp_ctx* ctx, int U, bool full, int grid, size_
     }
 }
 
+// true when this sweep launch is one of the sampled ones
+static bool prof_pick(csmp_ctx* ctx) {
+    if (!ctx->prof) return false;
+    return (ctx->prof_count++ % ctx->prof_every) == 0;
+}
+
 static int prof_mark(csmp_ctx* ctx) {
     if (ctx->ev_used == ctx->ev.size()) {
         hipEvent_t e;
@@ -304,12 +337,13 @@ static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int chec
 }
 
 static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
-    if (ctx->prof) CHECK(prof_mark(ctx));
+    const bool timed = prof_pick(ctx);
+    if (timed) CHECK(prof_mark(ctx));
     hipError_t e = ctx->dtype == CSMP_F32
                        ? sweep_product<float>(ctx, ctx->sweep_U, ctx->sweep_full, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask)
                        : sweep_product<double>(ctx, ctx->sweep_U, ctx->sweep_full, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
     HIPCHECK(e);
-    if (ctx->prof) CHECK(prof_mark(ctx));
+    if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;
 }
 
@@ -352,7 +386,11 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     if (ctx->ownA) dfree(ctx->dA);
     ctx->dA = nullptr;
     ctx->ownA = false;
-    solver_free(ctx->s);
+    HIPCHECK(sync_all(ctx));
+    for (int q = 2; q >= 0; --q) {
+        activate_slot(ctx, q);
+        solver_free(ctx->s);
+    }
     batch_free(ctx->bt, false);
     const size_t es = dtype == CSMP_F32 ? 4 : 8;
     const int vec = 16 / (int)es;
@@ -451,6 +489,7 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // hb goes out of scope
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
+    s.jh = 0;
     return CSMP_OK;
 }
 
@@ -459,6 +498,7 @@ static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
     Solver& s = ctx->s;
     hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
+    s.jh = 0;
     return CSMP_OK;
 }
 
@@ -474,9 +514,10 @@ static int launch_select(csmp_ctx* ctx, int mode, int skipmask) {
 // One atom through the append chain.  mode 1: atom = arg-max of the last sweep + OMP guards
 // (src/matchingpursuit.jl:63,65-66); mode 2: atom = cands[which] + GOMP's duplicate skip
 // (src/util.jl:119,129-134).  Then add_column!(AiQR, A[:, atom]) and the residual update.
-static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask) {
+static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool optimistic = false) {
     Solver& s = ctx->s;
     const size_t lds = qr_lds_bytes(s.kcap);
+    const int jh = std::min(s.jh, s.kcap);
     if (lds > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -487,17 +528,19 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask) {
         hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)ctx->dA, ctx->ld,
                            (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
                            (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
-                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s);
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh);
     else
         hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)ctx->dA, ctx->ld,
                            (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
                            (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
-                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s);
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
                        (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
-                       s.jpad, ctx->force_reorth ? 1 : 0);
+                       s.jpad, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0);
     HIPCHECK(hipGetLastError());
+    if (s.jh < s.kcap) s.jh += 1;
+    if (optimistic) return CSMP_OK;  // k_qr3 (second Gram-Schmidt pass) only in the safe chain
     hipLaunchKernelGGL(k_qr3, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.vvec, s.r,
                        (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, s.jpad);
     HIPCHECK(hipGetLastError());
@@ -516,18 +559,19 @@ static int launch_mp_update(csmp_ctx* ctx) {
 }
 
 // update!(P::OMP, x) + the driver's residual check of the PREVIOUS iteration (src/matchingpursuit.jl:62-70,79)
-static int omp_step(csmp_ctx* ctx, double eps, int check_eps) {
-    const int skip = STOP_EPS | STOP_STAG | STOP_FULL;
+static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
     CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skip));
-    return launch_append(ctx, 1, 0, skip);
+    return launch_append(ctx, 1, 0, skip, optimistic);
 }
 
 // ldiv! + SparseVector assembly into device outputs
-static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap) {
+static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
+                         int* d_flag = nullptr) {
     Solver& s = ctx->s;
     const size_t lds = (size_t)(s.kcap + 2) * sizeof(double);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
-                       (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap);
+                       (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -551,6 +595,93 @@ static int download_result(csmp_ctx* ctx, int outcap, int64_t* idx, double* val,
     return CSMP_OK;
 }
 
+// ------------------------------------------------------------------------------------------ tick kernel (3 signals in flight)
+template <typename TA>
+static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, const Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
+    TickSweep<TA> p;
+    p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
+    p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;
+    p.eps = eps; p.check_eps = check_eps; p.skipmask = skipmask; p.nblk = nblk; p.active = active;
+    return p;
+}
+template <typename TA>
+static TickQr1<TA> tick_qr1_params(csmp_ctx* ctx, const Solver& s, int skipmask, int nblk_sweep, int jh, int active) {
+    TickQr1<TA> p;
+    p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.M = (int)ctx->M;
+    p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.P1 = s.P1;
+    p.G = s.G; p.kcap = s.kcap; p.jpad = s.jpad; p.mode = 1;
+    p.pval = s.pval; p.pidx = s.pidx; p.nblk_sweep = nblk_sweep;
+    p.cands = s.cands; p.ncands = s.ncands; p.which = 0; p.sel = s.sel; p.skipmask = skipmask;
+    p.r = s.r; p.P1s = s.P1s; p.jh = jh; p.active = active;
+    return p;
+}
+static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optimistic, int active) {
+    TickQr2 p;
+    p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.r = s.r;
+    p.P1 = s.P1; p.P1s = s.P1s; p.G = s.G;
+    p.W1 = s.W1; p.vvec = s.vvec; p.P2 = s.P2; p.P2s = s.P2s; p.R = s.R; p.z = s.z; p.sel = s.sel;
+    p.kcap = s.kcap; p.jpad = s.jpad; p.force_reorth = ctx->force_reorth ? 1 : 0; p.jh = jh; p.optimistic = optimistic;
+    p.active = active;
+    return p;
+}
+
+template <typename TA, int U>
+static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
+    auto kern = k_tick<TA, U>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G);
+    return hipGetLastError();
+}
+template <typename TA>
+static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
+    switch (ctx->sweep_U) {
+        case 16: return tick_launch_t<TA, 16>(ctx, sw, q1, q2, G, lds);
+        case 8: return tick_launch_t<TA, 8>(ctx, sw, q1, q2, G, lds);
+        case 4: return tick_launch_t<TA, 4>(ctx, sw, q1, q2, G, lds);
+        case 2: return tick_launch_t<TA, 2>(ctx, sw, q1, q2, G, lds);
+        default: return tick_launch_t<TA, 1>(ctx, sw, q1, q2, G, lds);
+    }
+}
+
+// OMP for up to three signals (solver slots 0..2, already initialised with their b) advanced
+// together: at tick n slot n%3 sweeps, slot (n-1)%3 runs its k_qr1 stage, slot (n-2)%3 its k_qr2
+// stage.  k steps per signal = 3k+2 ticks.  present[q] == false leaves slot q idle.
+template <typename TA>
+static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    activate_slot(ctx, 0);
+    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
+    const int G = sl[0]->G;
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu, groups));
+    const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes(sl[0]->kcap));
+    for (int64_t n = 0; n < 3 * k + 2; ++n) {
+        const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
+        const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
+        const bool az = present[zs] && n >= zs && tz < k;
+        const bool ay = present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
+        const bool ax = present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
+        if (!az && !ay && !ax) continue;
+        int jh1 = 0;
+        if (ay) {
+            jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
+            sl[ys]->jh_last = jh1;
+            if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
+        }
+        const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, nblk, az ? 1 : 0);
+        const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
+        const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
+        const bool timed = az && ay && ax && prof_pick(ctx);  // steady-state ticks only
+        if (timed) CHECK(prof_mark(ctx));
+        HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, lds));
+        if (timed) CHECK(prof_mark(ctx));
+    }
+    return CSMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ drivers
 extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double eps, int64_t* idx, double* val,
                         int64_t* nnz, int64_t* order) {
@@ -562,9 +693,18 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // UpdatableQR(T, n, k): :58
     CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k, 1)));
     ctx->s.begun = false;
-    CHECK(upload_b(ctx, b, b_dtype));
-    for (int64_t t = 0; t < k; ++t) CHECK(omp_step(ctx, eps, t > 0));
-    CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+    // optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
+    // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool optimistic = pass == 0 && !ctx->force_reorth;
+        CHECK(upload_b(ctx, b, b_dtype));
+        for (int64_t t = 0; t < k; ++t) CHECK(omp_step(ctx, eps, t > 0, optimistic));
+        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) break;
+    }
     return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
 }
 
@@ -595,12 +735,66 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
     }
     int rc = CSMP_OK;
-    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+    activate_slot(ctx, 0);
+    if (ctx->s.sigcap < nsig) {
+        HIPCHECK(sync_all(ctx));
+        dfree(ctx->s.sigflags);
+        HIPCHECK(hipMalloc((void**)&ctx->s.sigflags, (size_t)nsig * sizeof(int)));
+        ctx->s.sigcap = (int)nsig;
+    }
+    int* const sigflags = ctx->s.sigflags;  // (a pointer VALUE: ctx->s itself is swapped by activate_slot)
+    auto solve_one = [&](int64_t sgn, bool optimistic) -> int {
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
-        rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
-                                 : init_from_device_t<double>(ctx, (const double*)col);
-        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0);
-        if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k);
+        int r2 = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
+                                     : init_from_device_t<double>(ctx, (const double*)col);
+        for (int64_t t = 0; t < k && r2 == CSMP_OK; ++t) r2 = omp_step(ctx, eps, t > 0, optimistic);
+        if (r2 == CSMP_OK) r2 = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k, sigflags + sgn);
+        return r2;
+    };
+    // optimistic two-kernel append chain for every signal, no host synchronisation.  Signals are
+    // taken three at a time through the tick kernel (k_tick): one launch per atom carries the sweep
+    // of one signal and the two short append stages of the other two, so the latency-bound chain
+    // is hidden underneath the HBM-bound sweep.  Bit-identical to the one-at-a-time path.
+    const bool opt = !ctx->force_reorth;
+    const bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full;
+    auto init_sig = [&](int64_t sgn) -> int {
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        return b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
+                                   : init_from_device_t<double>(ctx, (const double*)col);
+    };
+    int64_t sgn = 0;
+    if (pipe) {
+        for (int q = 1; q < 3 && rc == CSMP_OK; ++q) {
+            activate_slot(ctx, q);
+            rc = solver_ensure(ctx, kc, (int)k);
+        }
+        activate_slot(ctx, 0);
+        for (; sgn < nsig && rc == CSMP_OK; sgn += 3) {
+            bool present[3];
+            for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
+                present[q] = sgn + q < nsig;
+                if (!present[q]) continue;
+                activate_slot(ctx, q);
+                rc = init_sig(sgn + q);
+            }
+            if (rc == CSMP_OK) rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, present, k, eps, opt) : omp_ticks<double>(ctx, present, k, eps, opt);
+            for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
+                if (!present[q]) continue;
+                activate_slot(ctx, q);
+                rc = launch_finish(ctx, d_idx + (sgn + q) * k, d_val + (sgn + q) * k, d_nnz + sgn + q, nullptr, (int)k, sigflags + sgn + q);
+            }
+        }
+        activate_slot(ctx, 0);
+    }
+    for (; sgn < nsig && rc == CSMP_OK; ++sgn) rc = solve_one(sgn, opt);
+    // ... then ONE synchronisation: a signal whose support failed the DGKS test (flagged on the
+    // device, nothing committed for the failing column) is solved again with the full chain
+    if (rc == CSMP_OK) {
+        std::vector<int> hf((size_t)nsig);
+        HIPCHECK(hipMemcpyAsync(hf.data(), sigflags, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn)
+            if (hf[sgn] & STOP_REORTH) rc = solve_one(sgn, false);
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
@@ -817,6 +1011,7 @@ static int solver_restart(csmp_ctx* ctx) {
     Solver& s = ctx->s;
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.b, (int)ctx->M, s.Mpad, s.bstage, s.r, s.st);
     HIPCHECK(hipGetLastError());
+    s.jh = 0;
     return CSMP_OK;
 }
 
@@ -1156,7 +1351,7 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
                                  : init_from_device_t<double>(ctx, (const double*)col);
-        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0);
+        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0, false);
         if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k);
     }
     if (out_loc == CSMP_HOST) {
@@ -1204,13 +1399,15 @@ extern "C" int csmp_batch_stats(csmp_ctx* ctx, int64_t* signals, int64_t* resolv
 extern "C" int csmp_profile_enable(csmp_ctx* ctx, int on) {
     if (!ctx) return CSMP_EINVAL;
     ctx->prof = on != 0;
+    ctx->prof_every = on > 1 ? on : 1;  // on = n > 1: time every n-th sweep launch
+    ctx->prof_count = 0;
     return CSMP_OK;
 }
 
 extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double* sweep_ms, int reset) {
     if (!ctx) return CSMP_EINVAL;
     HIPCHECK(hipSetDevice(ctx->dev));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    HIPCHECK(sync_all(ctx));
     for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
         float ms = 0.f;
         HIPCHECK(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));

@@ -25,7 +25,7 @@ constexpr int kCPW = 4;             // dictionary columns a wave reduces togethe
 constexpr int kSlabRows = 64;       // rows of Q owned by one QR workgroup
 constexpr int kQrThreads = 256;
 
-enum : int { STOP_EPS = 1, STOP_STAG = 2, STOP_FULL = 4 };
+enum : int { STOP_EPS = 1, STOP_STAG = 2, STOP_FULL = 4, STOP_REORTH = 8 };  // REORTH: internal, see k_qr2
 
 // Control block of one solve, in device memory.  Written only by single-workgroup control
 // kernels (k_select / k_init) and by workgroup 0 of k_qr1 / k_qr3 / k_mp_update (fields no
@@ -87,17 +87,15 @@ __device__ __forceinline__ int r_slot(int m) {  // index in doubles
 //   NT    non-temporal dictionary loads (A is streamed once per sweep and exceeds every cache)
 //   TACC  double = product; float exists only as a bandwidth probe (csmp_bench_sweep)
 // dynamic LDS: r image (nchunk*64*VEC doubles) + 64 doubles of reduction scratch
-template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW = kCPW>
-__global__ __launch_bounds__(kSweepThreads) void k_sweep(
+template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW>
+__device__ __forceinline__ void sweep_body(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask) {
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, double* lds) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;  // rows per chunk
     constexpr int NW = kSweepThreads / kWave;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-
     if (st->done & skipmask) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nchunk = (Mv + ROWS - 1) / ROWS;
@@ -114,17 +112,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
         n2 = fma(v, v, n2);
     }
     n2 = block_sum256(n2, red);
-    if (blockIdx.x == 0 && tid == 0) st->rnorm2 = n2;
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
     if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
-        if (blockIdx.x == 0 && tid == 0) st->done |= STOP_EPS;
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
         return;
     }
 
     const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
     double bestv = -1.0;
     int besti = 0x7fffffff;
-    const int64_t stride = (int64_t)gridDim.x * NW * CPW;
-    for (int64_t cg = ((int64_t)blockIdx.x * NW + wave) * CPW; cg < N; cg += stride) {
+    const int64_t stride = (int64_t)nblk * NW * CPW;
+    for (int64_t cg = ((int64_t)bid * NW + wave) * CPW; cg < N; cg += stride) {
         const VT* p[CPW];
 #pragma unroll
         for (int c = 0; c < CPW; ++c) {
@@ -229,9 +227,18 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
                 bv = redv[q];
                 bi = redi[q];
             }
-        pval[blockIdx.x] = bv;
-        pidx[blockIdx.x] = bi;
+        pval[bid] = bv;
+        pidx[bid] = bi;
     }
+}
+template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW = kCPW>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body<TA, TACC, U, FULL, NT, CPW>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask,
+                                           (int)blockIdx.x, (int)gridDim.x, lds);
 }
 inline size_t sweep_lds_bytes(int Mv, int vec) {
     const int rows = kWave * vec;
@@ -564,6 +571,139 @@ __device__ __forceinline__ void slab_qt_x(const double* __restrict__ Q, int64_t 
     __syncthreads();
 }
 
+// ---- prefetched forms: the Q-slab operands of a phase are requested at kernel entry, before the
+// control block and the partial sums are known (jh >= j is the host's upper bound on the column
+// count), so the whole kernel is about one L2 round trip deep instead of one per phase.
+// W / NX set how many columns are requested up front: the stand-alone kernels use deep windows
+// (latency matters, registers do not); inside k_tick the stages run hidden under another signal's
+// sweep and must stay below 128 VGPRs so that the fused kernel keeps 4 waves per SIMD.
+template <int W>
+struct QtPre {
+    f64x2 v[W][8];  // columns c = u*64 + lane (u < W), rows 16w .. 16w+15 of the slab
+};
+template <int W>
+__device__ __forceinline__ void slab_qt_prefetch(QtPre<W>& P, const double* __restrict__ Q, int64_t ldq, int g, int jh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* base = Q + g * kSlabRows + wave * 16;
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const int c = u * kWave + lane;
+        const f64x2* q = reinterpret_cast<const f64x2*>(base + (int64_t)(c < jh ? c : 0) * ldq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) P.v[u][i] = (c < jh) ? q[i] : (f64x2)0.0;
+    }
+    asm volatile("" ::: "memory");  // keep the requests ahead of everything that follows
+}
+// partial Q_g' x with the first W*64 columns taken from the prefetch (see slab_qt_x)
+template <int W>
+__device__ __forceinline__ void slab_qt_x_pre(const QtPre<W>& P, const double* __restrict__ Q, int64_t ldq, int g, int G,
+                                              int j, const double* xs, double* part, int jpad,
+                                              double* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double xr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xr[i] = xs[wave * 16 + i];
+#pragma unroll
+    for (int u = 0; u < W; ++u) {
+        const int c = u * kWave + lane;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a0 = fma(P.v[u][i].x, xr[2 * i], a0);
+            a1 = fma(P.v[u][i].y, xr[2 * i + 1], a1);
+        }
+        if (c < j) part[wave * jpad + c] = a0 + a1;
+    }
+    const double* base = Q + g * kSlabRows + wave * 16;
+    for (int c0 = W * kWave; c0 < j; c0 += W * kWave) {  // columns beyond the prefetch window
+        f64x2 v[W][8];
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const int c = c0 + u * kWave + lane;
+            const f64x2* q = reinterpret_cast<const f64x2*>(base + (int64_t)(c < j ? c : 0) * ldq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[u][i] = (c < j) ? q[i] : (f64x2)0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const int c = c0 + u * kWave + lane;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                a0 = fma(v[u][i].x, xr[2 * i], a0);
+                a1 = fma(v[u][i].y, xr[2 * i + 1], a1);
+            }
+            if (c < j) part[wave * jpad + c] = a0 + a1;
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < j; c += kQrThreads)
+        out[(int64_t)c * G + g] = (part[c] + part[jpad + c]) + (part[2 * jpad + c] + part[3 * jpad + c]);
+    __syncthreads();
+}
+
+template <int NX>
+struct XmPre {
+    f64x2 v[NX];  // columns c = stream + 8 i (i < NX), rows 2*l32, 2*l32+1 of the slab
+};
+template <int NX>
+__device__ __forceinline__ void slab_xm_prefetch(XmPre<NX>& P, const double* __restrict__ Q, int64_t ldq, int g, int jh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int stream = wave * 2 + (lane >> 5), l32 = lane & 31;
+    const double* q = Q + g * kSlabRows + 2 * l32;
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int c = stream + 8 * i;
+        P.v[i] = (c < jh) ? *reinterpret_cast<const f64x2*>(q + (int64_t)c * ldq) : (f64x2)0.0;
+    }
+    asm volatile("" ::: "memory");
+}
+// x_g -= Q_g w with the first 8*NX columns taken from the prefetch (see slab_x_minus_qw)
+template <int NX>
+__device__ __forceinline__ void slab_x_minus_qw_pre(const XmPre<NX>& P, const double* __restrict__ Q, int64_t ldq, int g,
+                                                    int j, const double* ws, double* xs, double* tmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int stream = wave * 2 + (lane >> 5), l32 = lane & 31;
+    const double* q = Q + g * kSlabRows + 2 * l32;
+    double ax0 = 0.0, ay0 = 0.0, ax1 = 0.0, ay1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NX; i += 2) {
+        const int c0 = stream + 8 * i, c1 = stream + 8 * (i + 1);
+        const double w0 = (c0 < j) ? ws[c0] : 0.0, w1 = (c1 < j) ? ws[c1] : 0.0;
+        ax0 = fma(P.v[i].x, w0, ax0);
+        ay0 = fma(P.v[i].y, w0, ay0);
+        ax1 = fma(P.v[i + 1].x, w1, ax1);
+        ay1 = fma(P.v[i + 1].y, w1, ay1);
+    }
+    for (int cb = 8 * NX; cb < j; cb += 8 * NX) {  // columns beyond the prefetch window, NX loads in flight
+        f64x2 v[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int c = cb + stream + 8 * i;
+            v[i] = (c < j) ? *reinterpret_cast<const f64x2*>(q + (int64_t)c * ldq) : (f64x2)0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < NX; i += 2) {
+            const int c0 = cb + stream + 8 * i, c1 = cb + stream + 8 * (i + 1);
+            const double w0 = (c0 < j) ? ws[c0] : 0.0, w1 = (c1 < j) ? ws[c1] : 0.0;
+            ax0 = fma(v[i].x, w0, ax0);
+            ay0 = fma(v[i].y, w0, ay0);
+            ax1 = fma(v[i + 1].x, w1, ax1);
+            ay1 = fma(v[i + 1].y, w1, ay1);
+        }
+    }
+    tmp[stream * kSlabRows + 2 * l32] = ax0 + ax1;
+    tmp[stream * kSlabRows + 2 * l32 + 1] = ay0 + ay1;
+    __syncthreads();
+    if (tid < kSlabRows) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s += tmp[t * kSlabRows + tid];
+        xs[tid] -= s;
+    }
+    __syncthreads();
+}
+
 // ws[c] = sum_g P[c][g] (fixed order) for c < j; returns this thread's sum of squares
 __device__ __forceinline__ double sum_partials(const double* __restrict__ P, int G, int j, double* ws) {
     double sq = 0.0;
@@ -652,19 +792,20 @@ inline size_t qr_lds_bytes(int kcap) {
 //   already in the support (util.jl:119); only a full support stops anything (:117).
 // Every workgroup derives the same decision from the same device data; workgroup 0 publishes it
 // (cand, j, go) for k_qr2 / k_qr3, which no workgroup of THIS launch reads.
-template <typename TA>
-__global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, int64_t ld, int M,
+template <typename TA, int W>
+__device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, int M,
                                                     const double* __restrict__ Q, int64_t ldq, DevState* st,
                                                     double* __restrict__ avec, double* __restrict__ P1, int G, int kcap,
                                                     int jpad, int mode, const double* __restrict__ pval,
                                                     const int* __restrict__ pidx, int nblk,
                                                     const int* __restrict__ cands, const int* __restrict__ ncands,
                                                     int which, const int* __restrict__ sel, int skipmask,
-                                                    const double* __restrict__ r, double* __restrict__ P1s) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh, const int g, double* lds) {
     double *part, *ws, *xs, *tmp, *sc;
     qr_carve(lds, jpad, part, ws, xs, tmp, sc);
-    const int tid = threadIdx.x, g = blockIdx.x;
+    const int tid = threadIdx.x;
+    QtPre<W> pre;
+    slab_qt_prefetch<W>(pre, Q, ldq, g, jh);
     if (st->done & skipmask) {
         if (g == 0 && tid == 0) st->go = 0;
         return;
@@ -715,7 +856,20 @@ __global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, in
         }
     }
     __syncthreads();
-    slab_qt_x(Q, ldq, g, G, nsel, xs, part, jpad, P1);
+    slab_qt_x_pre<W>(pre, Q, ldq, g, G, nsel, xs, part, jpad, P1);
+}
+
+template <typename TA>
+__global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, int64_t ld, int M,
+                                                    const double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                    double* __restrict__ avec, double* __restrict__ P1, int G, int kcap,
+                                                    int jpad, int mode, const double* __restrict__ pval,
+                                                    const int* __restrict__ pidx, int nblk,
+                                                    const int* __restrict__ cands, const int* __restrict__ ncands,
+                                                    int which, const int* __restrict__ sel, int skipmask,
+                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr1_body<TA, 4>(A, ld, M, Q, ldq, st, avec, P1, G, kcap, jpad, mode, pval, pidx, nblk, cands, ncands, which, sel, skipmask, r, P1s, jh, (int)blockIdx.x, lds);
 }
 
 // Publishes the new column (shared by the accept path of k_qr2 and by k_qr3).
@@ -746,18 +900,21 @@ __device__ __forceinline__ void qr_commit(double* __restrict__ Q, int64_t ldq, D
 // Stewart test rho^2 >= |a|^2 / 2 says whether the first Gram-Schmidt pass lost accuracy to
 // cancellation.  If it did not (always, for incoherent dictionaries with k << M) the column is
 // committed here and k_qr3 returns at once; otherwise the second pass runs as before.
-__global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int64_t ldq, DevState* st,
+template <int NX>
+__device__ __forceinline__ void qr2_body(double* __restrict__ Q, int64_t ldq, DevState* st,
                                                     const double* __restrict__ avec, double* __restrict__ r,
                                                     const double* __restrict__ P1, const double* __restrict__ P1s,
                                                     int G, double* __restrict__ W1, double* __restrict__ vvec,
                                                     double* __restrict__ P2, double* __restrict__ P2s,
                                                     double* __restrict__ R, double* __restrict__ z,
-                                                    int* __restrict__ sel, int kcap, int jpad, int force_reorth) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+                                                    int* __restrict__ sel, int kcap, int jpad, int force_reorth,
+                                                    int jh, int optimistic, const int g, double* lds) {
+    XmPre<NX> pre;
+    slab_xm_prefetch<NX>(pre, Q, ldq, g, jh);
     if (!st->go) return;
     double *part, *ws, *xs, *tmp, *sc;
     qr_carve(lds, jpad, part, ws, xs, tmp, sc);
-    const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
+    const int tid = threadIdx.x, j = st->j;
     double rr = 0.0, na2 = 0.0, ar = 0.0;
     if (tid < kSlabRows) {
         xs[tid] = avec[g * kSlabRows + tid];
@@ -773,7 +930,16 @@ __global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int6
     ar = block_sum256(ar, sc);
     const double rho2 = na2 - w1sq;
     const bool accept = !force_reorth && rho2 >= 0.5 * na2 && rho2 > 0.0;
-    slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);  // v_g = a_g - Q_g w1
+    if (!accept && optimistic) {
+        // optimistic chain (k_qr3 is not launched): nothing is committed, the solve is flagged and the
+        // host repeats it with the full three-kernel chain
+        if (g == 0 && tid == 0) {
+            st->done |= STOP_REORTH;
+            st->go2 = 0;
+        }
+        return;
+    }
+    slab_x_minus_qw_pre<NX>(pre, Q, ldq, g, j, ws, xs, tmp);  // v_g = a_g - Q_g w1
     if (accept) {
         const double rho = sqrt(rho2);
         qr_commit(Q, ldq, st, r, R, z, sel, kcap, g, j, xs, rr, rho, ar / rho, nullptr, ws);
@@ -798,6 +964,18 @@ __global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int6
         }
     }
     slab_qt_x(Q, ldq, g, G, j, xs, part, jpad, P2);
+}
+
+__global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                    const double* __restrict__ avec, double* __restrict__ r,
+                                                    const double* __restrict__ P1, const double* __restrict__ P1s,
+                                                    int G, double* __restrict__ W1, double* __restrict__ vvec,
+                                                    double* __restrict__ P2, double* __restrict__ P2s,
+                                                    double* __restrict__ R, double* __restrict__ z,
+                                                    int* __restrict__ sel, int kcap, int jpad, int force_reorth,
+                                                    int jh, int optimistic) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr2_body<32>(Q, ldq, st, avec, r, P1, P1s, G, W1, vvec, P2, P2s, R, z, sel, kcap, jpad, force_reorth, jh, optimistic, (int)blockIdx.x, lds);
 }
 
 __global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int64_t ldq, DevState* st,
@@ -831,6 +1009,59 @@ __global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int6
 }
 
 // ---------------------------------------------------------------------------------------------
+// Tick kernel of the pipelined batch: THREE independent signals are in flight, one in each stage
+// of an OMP step, and one launch advances all of them:
+//     workgroups [0, G)        : k_qr2 stage of signal X   (commit the atom chosen two ticks ago)
+//     workgroups [G, 2G)       : k_qr1 stage of signal Y   (select + first projection)
+//     workgroups [2G, 2G + S)  : sweep of signal Z         (the HBM-bound part: S persistent workgroups)
+// The short latency-bound chain stages run on ~128 CU slots while the sweep streams the
+// dictionary, so a whole atom costs one sweep and one kernel boundary.  The stages of one signal
+// are separated by kernel boundaries exactly as in the stand-alone chain (sweep -> qr1 -> qr2 in
+// three consecutive ticks), so results are bit-identical to it.  A stage with active == 0 idles.
+template <typename TA>
+struct TickSweep {
+    const TA* A; int64_t ld; int Mv; int64_t N;
+    const double* r; double* cvec; double* pval; int* pidx; DevState* st;
+    double eps; int check_eps, skipmask, nblk, active;
+};
+template <typename TA>
+struct TickQr1 {
+    const TA* A; int64_t ld; int M;
+    const double* Q; int64_t ldq; DevState* st; double* avec; double* P1;
+    int G, kcap, jpad, mode;
+    const double* pval; const int* pidx; int nblk_sweep;
+    const int* cands; const int* ncands; int which; const int* sel; int skipmask;
+    const double* r; double* P1s; int jh, active;
+};
+struct TickQr2 {
+    double* Q; int64_t ldq; DevState* st; const double* avec; double* r;
+    const double* P1; const double* P1s; int G;
+    double* W1; double* vvec; double* P2; double* P2s; double* R; double* z; int* sel;
+    int kcap, jpad, force_reorth, jh, optimistic, active;
+};
+
+template <typename TA, int U>
+__global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
+                                                        const int G) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid < G) {
+        if (q2.active)
+            qr2_body<8>(q2.Q, q2.ldq, q2.st, q2.avec, q2.r, q2.P1, q2.P1s, q2.G, q2.W1, q2.vvec, q2.P2, q2.P2s, q2.R, q2.z,
+                     q2.sel, q2.kcap, q2.jpad, q2.force_reorth, q2.jh, q2.optimistic, bid, lds);
+    } else if (bid < 2 * G) {
+        if (q1.active)
+            qr1_body<TA, 2>(q1.A, q1.ld, q1.M, q1.Q, q1.ldq, q1.st, q1.avec, q1.P1, q1.G, q1.kcap, q1.jpad, q1.mode, q1.pval,
+                         q1.pidx, q1.nblk_sweep, q1.cands, q1.ncands, q1.which, q1.sel, q1.skipmask, q1.r, q1.P1s, q1.jh,
+                         bid - G, lds);
+    } else {
+        if (sw.active)
+            sweep_body<TA, double, U, true, true, 1>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st,
+                                                     sw.eps, sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Final solve + SparseVector assembly (ONE workgroup): c = R^{-1} z by column-oriented back
 // substitution, then (index, coefficient) pairs in ascending index order (rank sort), as
 // ldiv!(AiQR, r) returns them (src/matchingpursuit.jl:175; sorted insert, src/util.jl:122).
@@ -838,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ R, co
                                                 const int* __restrict__ sel, const DevState* st, int kcap,
                                                 double* __restrict__ coef /*kcap scratch*/, int64_t* __restrict__ out_idx,
                                                 double* __restrict__ out_val, int64_t* __restrict__ out_nnz,
-                                                int64_t* __restrict__ out_order, int outcap) {
+                                                int64_t* __restrict__ out_order, int outcap, int* __restrict__ flag_out) {
     extern __shared__ __attribute__((aligned(16))) double y[];  // kcap + 2
     double& ci = y[kcap];
     const int tid = threadIdx.x, j = st->nsel;
@@ -868,7 +1099,10 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ R, co
         out_idx[rank] = me;
         out_val[rank] = y[t];
     }
-    if (tid == 0) *out_nnz = j;
+    if (tid == 0) {
+        *out_nnz = j;
+        if (flag_out) *flag_out = st->done;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -99,8 +99,9 @@ int csmp_sp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, 
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);
  * outputs idx (k x nsig, int64, unused tail = -1), val (k x nsig, f64, unused tail = 0),
- * nnz (nsig) on host or device (out_loc).  With out_loc == CSMP_DEVICE the call only enqueues
- * work on the ctx stream (no host synchronisation): call csmp_sync() before reading. */
+ * nnz (nsig) on host or device (out_loc).  All signals are enqueued back to back without host
+ * synchronisation; the call then synchronises ONCE (to verify the per-signal factorisation flags,
+ * see DESIGN.md "optimistic chain") and returns with the results complete. */
 int csmp_omp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                    double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 
@@ -141,7 +142,8 @@ int csmp_sweep(csmp_ctx *ctx, const double *r, double *abs_corr, int64_t topk, i
 int csmp_lstsq(csmp_ctx *ctx, const int64_t *cols, int64_t ncols, const void *b, int b_dtype, double *coef);
 
 /* ------------------------------------------------------------------ measurement
- * When enabled, every sweep launch is bracketed by HIP events on the ctx stream. */
+ * on = 1: every sweep launch is bracketed by HIP events on the ctx stream; on = n > 1: every
+ * n-th launch only (an event pair costs a few microseconds of stream time); 0 = off. */
 int csmp_profile_enable(csmp_ctx *ctx, int on);
 /* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
 int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);

@@ -112,6 +112,14 @@ def test_omp_coherent_dictionary_triggers_dgks(cs, oracle, D):
     assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
     cond = np.linalg.cond(A[:, ref[0]])
     assert np.allclose(got[1], ref[1], rtol=1e-6, atol=1e-12 * cond * np.abs(ref[1]).max()), (cond, got[1], ref[1])
+    # the batch driver runs the optimistic two-kernel chain first, sees the device flag and repeats
+    # the flagged signals with the second Gram-Schmidt pass: same answers
+    B = np.asfortranarray(np.stack([y, cs.perturb(A @ cs.sparse_vector(m, k, rng=rng).to_dense(), 1e-3, rng=rng), y], axis=1))
+    idx, val, nnz = d.ctx.omp_batch(B, k, EPS64)
+    for s_ in range(3):
+        r_ = oracle.omp(A, B[:, s_], k, EPS64)
+        assert nnz[s_] == len(r_[0]) and np.array_equal(idx[:nnz[s_], s_], r_[0])
+        assert np.allclose(val[:nnz[s_], s_], r_[1], rtol=1e-6, atol=1e-10)
 
 
 def test_omp_b_dtype_f32(cs, oracle, D):
