@@ -130,7 +130,7 @@ def make_signals_fast(torch, dev, At, first_id, count, k):
     return B
 
 
-def run_batched(args, cs, torch, dist, dev, rank, world, At, D):
+def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
     """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128."""
     nsig, k = 1024, 128
     K, W = args.steps, args.warmup
@@ -146,7 +146,7 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D):
     D.ctx.profile_enable(True)
     D.ctx.batch_stats()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -160,18 +160,18 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D):
         screen_n += st["screen_launches"]
         screen_ms += st["screen_ms"]
     D.ctx.sync()
-    if world > 1:  # one gather of every rank's packed results
+    if use_dist:  # one gather of every rank's packed results
         packed = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, :, None].to(torch.float64)], dim=2)
         gathered = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(gathered, packed)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     atoms = torch.tensor([float(nnz[W:].sum().item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(atoms, op=dist.ReduceOp.SUM)
     tmax, atoms = tmax.item(), atoms.item()
@@ -218,7 +218,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
     At = make_dictionary(torch, dev)
@@ -226,9 +227,9 @@ def main():
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
-        run_batched(args, cs, torch, dist, dev, rank, world, At, D)
+        run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist)
         D.close()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -243,13 +244,13 @@ def main():
     def barrier():
         D.ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     if W > 0:
         D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
-    if world > 1:  # warm the collective too
+    if use_dist:  # warm the collective too
         dist.all_gather([torch.empty(4, device=dev) for _ in range(world)], torch.zeros(4, device=dev))
     D.ctx.profile_enable(args.profile_every)  # HIP events around every n-th sweep launch of the timed region
     D.ctx.profile_read(reset=True)
@@ -257,7 +258,7 @@ def main():
     t0 = time.perf_counter()
     D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
     D.ctx.sync()
-    if world > 1:  # the single collective of the path: every rank's (idx, val, nnz) shard
+    if use_dist:  # the single collective of the path: every rank's (idx, val, nnz) shard
         packed = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, None].to(torch.float64)], dim=1)
         gathered = [torch.empty_like(packed) for _ in range(world)]
         dist.all_gather(gathered, packed)
@@ -268,7 +269,7 @@ def main():
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     atoms = torch.tensor([float(nnz[W:].sum().item())], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(atoms, op=dist.ReduceOp.SUM)
     tmax, atoms = tmax.item(), atoms.item()
@@ -307,7 +308,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
     D.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -458,3 +458,22 @@ def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
         assert np.all(idx[3:, s] == -1)
     with pytest.raises(cs.CsmpError):
         d.ctx.omp_batch_mfma(B, 8, -1.0)
+
+
+def test_oblivious_and_acquisitions(cs, oracle, D):
+    # src/oblivious.jl:3-8: top-k of |A'b| then least squares on those columns
+    A, x, b = cs.sparse_data(n=64, m=300, k=5, rng=31, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=32)
+    d = D(A)
+    xo = cs.oblivious(d, y, 5)
+    top = oracle.topk_desc(oracle.sweep_abs(A, y)[0], 5)
+    assert np.array_equal(xo.nzind, np.sort(top))
+    ref = np.linalg.lstsq(A[:, np.sort(top)].astype(np.float64), y, rcond=None)[0]
+    assert close(xo.nzval, ref)
+    xa = cs.oblivious_acquisition(d, y, cs.spzeros(300), 5)  # src/matchingpursuit.jl:207-216 on an empty x
+    assert np.array_equal(xa.nzind, xo.nzind) and close(xa.nzval, ref)
+    xr = cs.random_acquisition(d, y, cs.spzeros(300), 6, rng=1)  # :195-204
+    assert xr.nnz == 6 and close(xr.nzval, np.linalg.lstsq(A[:, xr.nzind].astype(np.float64), y, rcond=None)[0])
+    xs = cs.omp_batch_mfma(d, np.stack([y, y], axis=1), 5)
+    r = oracle.omp(A, y, 5, EPS32)
+    assert np.array_equal(xs[0].nzind, r[0]) and close(xs[1].nzval, r[1])
