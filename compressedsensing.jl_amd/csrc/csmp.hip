@@ -86,6 +86,8 @@ struct csmp_ctx {
     int active = 0;
     bool pipeline = true;
     int tick_wg_per_cu = 2;  // sweep workgroups per CU inside the tick kernel (CSMP_TICK_WGS)
+    bool tick_pf = true;     // software-pipelined sweep inside the tick kernel (CSMP_TICK_PF)
+    int tick_nblk = 0;       // absolute override of the sweep workgroup count (CSMP_TICK_NBLK), 0 = per-CU rule
     Batch bt;
     // profiling
     bool prof = false;
@@ -166,6 +168,8 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
     const char* pl = getenv("CSMP_PIPELINE");  // CSMP_PIPELINE=0: solve the signals of a batch strictly one after the other
     ctx->pipeline = !(pl && pl[0] == '0');
     if (const char* tw = getenv("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
+    if (const char* tn = getenv("CSMP_TICK_NBLK")) ctx->tick_nblk = std::max(0, atoi(tn));
+    if (const char* tp = getenv("CSMP_TICK_PF")) ctx->tick_pf = tp[0] != '0';
     // test knob: CSMP_FORCE_REORTH=1 always runs the second Gram-Schmidt pass (k_qr3)
     const char* fr = getenv("CSMP_FORCE_REORTH");
     ctx->force_reorth = fr && fr[0] == '1';
@@ -285,9 +289,22 @@ template <typename TA>
 static hipError_t sweep_product(csmp_ctx* ctx, int U, bool full, int grid, size_t lds, const double* r, double eps,
                                 int check_eps, int skipmask) {
     if (!full) return sweep_launch_t<TA, double, 1, false, false, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
+    if (U >= 8) {  // software-pipelined kernel
+        Solver& s = ctx->s;
+        if (lds > 64 * 1024) {
+            hipError_t e = U == 16 ? hipFuncSetAttribute((const void*)k_sweep_pf<TA, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                   : hipFuncSetAttribute((const void*)k_sweep_pf<TA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        if (U == 16)
+            hipLaunchKernelGGL((k_sweep_pf<TA, 16, true>), dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld,
+                               ctx->Mv, ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask);
+        else
+            hipLaunchKernelGGL((k_sweep_pf<TA, 8, true>), dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld,
+                               ctx->Mv, ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask);
+        return hipGetLastError();
+    }
     switch (U) {
-        case 16: return sweep_launch_t<TA, double, 16, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
-        case 8: return sweep_launch_t<TA, double, 8, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
         case 4: return sweep_launch_t<TA, double, 4, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
         case 2: return sweep_launch_t<TA, double, 2, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
         default: return sweep_launch_t<TA, double, 1, true, true, 1>(ctx, grid, lds, r, eps, check_eps, skipmask);
@@ -352,10 +369,11 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
     ctx->sweep_lds = sweep_lds_bytes(ctx->Mv, vec);
     if (ctx->sweep_lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "M too large: the residual must fit the 160 KiB LDS");
-    // Measured on MI355X at 4096 x 65536 f32 (tools/probe_sweep.py, tools/probe_sweep2.py, profiles/):
-    // ONE column per wave at a time with the whole column's loads in flight (U = 16 KiB-pieces),
-    // non-temporal, 3 workgroups/CU: 6.67 TB/s; four columns per wave (better amortised r reads and
-    // reductions) only reaches 6.1 TB/s -- fewer concurrent DRAM streams win.
+    // Measured on MI355X at 4096 x 65536 f32 (tools/probe_sweep*.py, profiles/): ONE column per wave
+    // at a time, non-temporal loads, software-pipelined across columns (the next column's 16 KiB are
+    // requested before the current one is reduced), and only 192 workgroups (3/4 of the CUs):
+    // 154.5 us = 6.95 TB/s.  More workgroups, or several columns per wave, mean more concurrent DRAM
+    // streams and LESS bandwidth (768 workgroups: 6.6 TB/s; 4 columns per wave: 6.1 TB/s).
     const int rows = kWave * vec;
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     ctx->sweep_full = (ctx->Mv % rows) == 0;
@@ -372,6 +390,11 @@ static int configure_sweep(csmp_ctx* ctx) {
     if (per_cu < 1) per_cu = 1;
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     int64_t grid = (int64_t)ctx->prop.multiProcessorCount * per_cu;
+    if (ctx->sweep_full && ctx->sweep_U == 16) grid = (int64_t)ctx->prop.multiProcessorCount * 3 / 4;  // pipelined kernel
+    if (ctx->sweep_full && ctx->sweep_U == 8) grid = (int64_t)ctx->prop.multiProcessorCount;
+    if (const char* sn = getenv("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));  // tuning knob
+    if (const char* sp = getenv("CSMP_SWEEP_LDS"))  // tuning knob: request at least this much LDS per workgroup
+        ctx->sweep_lds = std::max(ctx->sweep_lds, (size_t)atoi(sp));
     ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
     return CSMP_OK;
 }
@@ -625,9 +648,9 @@ static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optim
     return p;
 }
 
-template <typename TA, int U>
+template <typename TA, int U, bool PF>
 static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
-    auto kern = k_tick<TA, U>;
+    auto kern = k_tick<TA, U, PF>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -638,11 +661,11 @@ static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const Ti
 template <typename TA>
 static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
     switch (ctx->sweep_U) {
-        case 16: return tick_launch_t<TA, 16>(ctx, sw, q1, q2, G, lds);
-        case 8: return tick_launch_t<TA, 8>(ctx, sw, q1, q2, G, lds);
-        case 4: return tick_launch_t<TA, 4>(ctx, sw, q1, q2, G, lds);
-        case 2: return tick_launch_t<TA, 2>(ctx, sw, q1, q2, G, lds);
-        default: return tick_launch_t<TA, 1>(ctx, sw, q1, q2, G, lds);
+        case 16: return ctx->tick_pf ? tick_launch_t<TA, 16, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 16, false>(ctx, sw, q1, q2, G, lds);
+        case 8: return ctx->tick_pf ? tick_launch_t<TA, 8, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 8, false>(ctx, sw, q1, q2, G, lds);
+        case 4: return tick_launch_t<TA, 4, false>(ctx, sw, q1, q2, G, lds);
+        case 2: return tick_launch_t<TA, 2, false>(ctx, sw, q1, q2, G, lds);
+        default: return tick_launch_t<TA, 1, false>(ctx, sw, q1, q2, G, lds);
     }
 }
 
@@ -656,7 +679,7 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
     Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
     const int G = sl[0]->G;
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu, groups));
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : (ctx->sweep_U >= 8 ? (int64_t)ctx->sweep_grid * 11 / 12 : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu), groups));
     const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes(sl[0]->kcap));
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
@@ -1425,8 +1448,20 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
 }
 
 // experimental column-per-wave variants (f32 dictionary, full chunks only): cpw in {1,2}, U in {4,8,16}
+template <int U>
+static hipError_t sweep_launch_pf(csmp_ctx* ctx, int grid, const double* r) {
+    auto kern = k_sweep_pf<float, U, true>;
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const float*)ctx->dA, ctx->ld, ctx->Mv,
+                       ctx->N, r, s.cvec, s.pval, s.pidx, s.st, 0.0, 0, 0);
+    return hipGetLastError();
+}
 static hipError_t sweep_launch_cpw(csmp_ctx* ctx, int cpw, int U, int grid, const double* r) {
     const size_t lds = ctx->sweep_lds;
+    if (cpw == 3 && U == 16) return sweep_launch_pf<16>(ctx, grid, r);
+    if (cpw == 3 && U == 8) return sweep_launch_pf<8>(ctx, grid, r);
+    if (cpw == 3 && U == 4) return sweep_launch_pf<4>(ctx, grid, r);
+    if (cpw == 3 && U == 2) return sweep_launch_pf<2>(ctx, grid, r);
     if (cpw == 1 && U == 4) return sweep_launch_t<float, double, 4, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
     if (cpw == 1 && U == 8) return sweep_launch_t<float, double, 8, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
     if (cpw == 1 && U == 16) return sweep_launch_t<float, double, 16, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
@@ -1458,9 +1493,10 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         if (ctx->dtype != CSMP_F32) return fail(ctx, CSMP_EINVAL, "bench_sweep: experimental variants are f32 only");
         U = variant & 0xff;
         const int per_cu = (variant >> 8) & 0xff;
-        const int64_t groups = (ctx->N + 4 * cpwx - 1) / (4 * cpwx);
+        const int64_t groups = (ctx->N + 4 * (cpwx == 3 ? 1 : cpwx) - 1) / (4 * (cpwx == 3 ? 1 : cpwx));
         grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * (per_cu ? per_cu : 4), groups));
         if (grid > ctx->prop.multiProcessorCount * 8) grid = ctx->prop.multiProcessorCount * 8;
+        if (const char* sn = getenv("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));
         if (ctx->Mv % (256 * U)) return fail(ctx, CSMP_EINVAL, "bench_sweep: M must be a multiple of 256*U");
         for (int i = 0; i < 3; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
         hipEvent_t e0, e1;

@@ -240,6 +240,124 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep(
     sweep_body<TA, TACC, U, FULL, NT, CPW>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask,
                                            (int)blockIdx.x, (int)gridDim.x, lds);
 }
+// Software-pipelined form of the product sweep (one column per wave, full chunks, Float64): the NEXT
+// column's U loads are issued before the current column is converted, multiplied and reduced, so a
+// wave always has U..2U KiB in flight instead of draining to zero once per column.  Fewer waves
+// then saturate HBM, and fewer concurrent DRAM streams reach a higher bandwidth.
+template <typename TA, int U, bool NT>
+__device__ __forceinline__ void sweep_body_pf(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, double* lds) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    constexpr int NW = kSweepThreads / kWave;
+    if (st->done & skipmask) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = Mv / ROWS;  // exact (FULL) and a multiple of U
+    const int Mlds = nchunk * ROWS;
+    double* red = lds + Mlds;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+
+    double n2 = 0.0;
+    for (int m = tid; m < Mlds; m += kSweepThreads) {
+        const double v = r[m];
+        lds[r_slot<VEC>(m)] = v;
+        n2 = fma(v, v, n2);
+    }
+    n2 = block_sum256(n2, red);
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
+    if (check_eps && !(sqrt(n2) >= eps)) {
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+    const int64_t stride = (int64_t)nblk * NW;
+    const int nblocks = nchunk / U;  // load blocks per column
+    auto ldv = [&](const VT* p) -> VT {
+        if constexpr (NT) return __builtin_nontemporal_load(p);
+        else return *p;
+    };
+    int64_t col = (int64_t)bid * NW + wave;
+    if (col >= N) col = -1;
+    VT cur[U], nxt[U];
+    if (col >= 0) {
+        const VT* p = reinterpret_cast<const VT*>(A + col * ld) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = ldv(p + u * kWave);
+    }
+    while (col >= 0) {
+        double acc = 0.0;
+        for (int blk = 0; blk < nblocks; ++blk) {
+            // request the following block: next block of this column, or the first of the next column
+            const bool last = blk + 1 == nblocks;
+            const int64_t ncol = last ? col + stride : col;
+            const bool have = !last || ncol < N;
+            if (have) {
+                const VT* p = reinterpret_cast<const VT*>(A + ncol * ld) + lane + (last ? 0 : (blk + 1) * U * kWave);
+#pragma unroll
+                for (int u = 0; u < U; ++u) nxt[u] = ldv(p + u * kWave);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = blk * U + u;
+                if constexpr (VEC == 4) {
+                    const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                    const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                    acc = fma((double)cur[u].x, r01.x, acc);
+                    acc = fma((double)cur[u].y, r01.y, acc);
+                    acc = fma((double)cur[u].z, r23.x, acc);
+                    acc = fma((double)cur[u].w, r23.y, acc);
+                } else {
+                    const f64x2 r01 = rs[t * kWave + lane];
+                    acc = fma((double)cur[u].x, r01.x, acc);
+                    acc = fma((double)cur[u].y, r01.y, acc);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+        if (lane == 0) cvec[col] = acc;
+        const double av = fabs(acc);
+        if (av > bestv) {
+            bestv = av;
+            besti = (int)col;
+        }
+        col += stride;
+        if (col >= N) col = -1;
+    }
+    if ((lane & 15) == 0) {
+        redv[wave * 4 + (lane >> 4)] = bestv;
+        redi[wave * 4 + (lane >> 4)] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int q = 1; q < 4 * NW; ++q)
+            if (better(redv[q], redi[q], bv, bi)) {
+                bv = redv[q];
+                bi = redi[q];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+template <typename TA, int U, bool NT>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_pf(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body_pf<TA, U, NT>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x,
+                             (int)gridDim.x, lds);
+}
+
 inline size_t sweep_lds_bytes(int Mv, int vec) {
     const int rows = kWave * vec;
     const int nchunk = (Mv + rows - 1) / rows;
@@ -1040,7 +1158,7 @@ struct TickQr2 {
     int kcap, jpad, force_reorth, jh, optimistic, active;
 };
 
-template <typename TA, int U>
+template <typename TA, int U, bool PF>
 __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
                                                         const int G) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1055,9 +1173,14 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, 
                          q1.pidx, q1.nblk_sweep, q1.cands, q1.ncands, q1.which, q1.sel, q1.skipmask, q1.r, q1.P1s, q1.jh,
                          bid - G, lds);
     } else {
-        if (sw.active)
-            sweep_body<TA, double, U, true, true, 1>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st,
-                                                     sw.eps, sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
+        if (sw.active) {
+            if constexpr (PF && U >= 8)
+                sweep_body_pf<TA, U, true>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
+                                           sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
+            else
+                sweep_body<TA, double, U, true, true, 1>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st,
+                                                         sw.eps, sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
+        }
     }
 }
 
