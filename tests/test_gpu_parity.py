@@ -477,3 +477,25 @@ def test_oblivious_and_acquisitions(cs, oracle, D):
     xs = cs.omp_batch_mfma(d, np.stack([y, y], axis=1), 5)
     r = oracle.omp(A, y, 5, EPS32)
     assert np.array_equal(xs[0].nzind, r[0]) and close(xs[1].nzval, r[1])
+
+
+@pytest.mark.parametrize("cfg", [(2048, 3000, 12, 7, np.float32), (4096, 2500, 10, 5, np.float32), (1024, 1500, 9, 4, np.float64),
+                                 (2048, 1000, 8, 8, np.float64), (512, 900, 6, 6, np.float32)])
+def test_pipelined_batch_matches_oracle(cs, oracle, D, cfg):
+    """csmp_omp_batch takes signals three at a time through k_tick (sweep of one signal fused with the
+    append stages of two others).  Shapes chosen so that the software-pipelined sweep body (U = 8 / 16)
+    and the plain one are both exercised; group sizes 3, 2 and 1 all occur."""
+    n, m, k, nsig, dtype = cfg
+    eps = float(np.finfo(dtype).eps)
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dtype)
+    d = D(A)
+    rng = np.random.default_rng(nsig)
+    B = np.asfortranarray(np.stack([cs.perturb(A[:, (xs := cs.sparse_vector(m, k, rng=rng)).nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=rng)
+                                    for _ in range(nsig)], axis=1))
+    idx, val, nnz = d.ctx.omp_batch(B, k, eps)
+    for s in range(nsig):
+        ref = oracle.omp(A, B[:, s], k, eps)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), s
+        assert close(val[:nnz[s], s], ref[1]), s
+        solo = d.ctx.omp(B[:, s], k, eps)  # the one-at-a-time chain gives bit-identical numbers
+        assert np.array_equal(solo[0], idx[:nnz[s], s]) and np.array_equal(solo[1], val[:nnz[s], s])
