@@ -38,9 +38,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=18)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", choices=["omp", "batched"], default="omp",
+    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
-                        "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch)")
+                        "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
+                        "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -200,6 +201,62 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
         }), flush=True)
 
 
+def run_config5(args, cs, torch, dev, rank):
+    """configs[4]: GOMP (S = 4 atoms per step) and Subspace Pursuit on A 8192 x 131072 Float32, k = 512."""
+    import numpy as np
+    M5, N5, k, S = 8192, 131072, 512, 4
+    g = torch.Generator(device=dev).manual_seed(SEED_A + 5)
+    At = torch.empty((N5, M5), dtype=torch.float32, device=dev)
+    for lo in range(0, N5, 8192):
+        a = torch.randn((8192, M5), generator=g, device=dev, dtype=torch.float64)
+        a -= 1e-6 * a.mean(dim=1, keepdim=True)
+        a /= a.norm(dim=1, keepdim=True)
+        At[lo:lo + 8192] = a.to(torch.float32)
+    D = cs.Dictionary(At, device=dev.index)
+    K, W = args.steps, args.warmup
+    sigs = []
+    for s_ in range(K + W):
+        gs = torch.Generator(device=dev).manual_seed(99 + s_)
+        idx = torch.randperm(N5, generator=gs, device=dev)[:k]
+        sign = torch.randint(0, 2, (k,), generator=gs, device=dev).to(torch.float64) * 2 - 1
+        e = torch.randn(M5, generator=gs, device=dev, dtype=torch.float64)
+        sigs.append(((At[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
+    torch.cuda.synchronize()
+    eps = D.eps
+
+    def solve(b):
+        if args.workload == "gomp":
+            i, v, o = D.ctx.gomp(b, S, k, eps)
+            return len(i), 0
+        i, v, it = D.ctx.sp(b, k, 1e-2)
+        return len(i), it
+    for w in range(W):
+        solve(sigs[w])
+    D.ctx.profile_enable(True)
+    D.ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    atoms, iters = 0, 0
+    for s_ in range(W, W + K):
+        n, it = solve(sigs[s_])
+        atoms += n
+        iters += it
+    dt = time.perf_counter() - t0
+    sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+    alg = M5 * N5 * 4
+    avg = sweep_ms / max(sweeps, 1) / 1e3
+    out = {"metric": ("GOMP (S=4) atoms selected/sec" if args.workload == "gomp" else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
+           "value": (atoms / dt) if args.workload == "gomp" else K / dt, "unit": "atoms/s" if args.workload == "gomp" else "solves/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
+           "config": {"workload": f"configs[4]: {args.workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if args.workload == "gomp" else ", delta=1e-2"),
+                      "sweeps": int(sweeps), "sp_update_calls": int(iters)},
+           "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
+                        "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
+    print(json.dumps(out), flush=True)
+    D.close()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,6 +279,15 @@ def main():
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload in ("gomp", "sp"):
+        if args.steps == 18 and args.warmup == 3:
+            args.steps, args.warmup = 3, 1
+        if rank == 0:
+            run_config5(args, cs, torch, dev, rank)
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
     if args.workload == "batched":

@@ -499,3 +499,44 @@ def test_pipelined_batch_matches_oracle(cs, oracle, D, cfg):
         assert close(val[:nnz[s], s], ref[1]), s
         solo = d.ctx.omp(B[:, s], k, eps)  # the one-at-a-time chain gives bit-identical numbers
         assert np.array_equal(solo[0], idx[:nnz[s], s]) and np.array_equal(solo[1], val[:nnz[s], s])
+
+
+def test_edge_cases_tiny_and_degenerate(cs, oracle, D):
+    """Sizes at the edges of every kernel's indexing: one row, one atom, k = 0, k > N, k > M."""
+    rng = np.random.default_rng(0)
+    # k = 0: nothing selected
+    A, x, b = cs.sparse_data(n=16, m=24, k=2, rng=1)
+    d = D(A)
+    i, v, o = d.ctx.omp(b, 0, 0.0)
+    assert len(i) == 0
+    assert len(d.ctx.mp(b, 0)[0]) == 0
+    # k larger than the number of atoms: every atom gets selected once, then stagnation (:66)
+    A3 = np.asfortranarray(rng.standard_normal((12, 3)))
+    A3 /= np.linalg.norm(A3, axis=0)
+    b3 = rng.standard_normal(12)
+    d3 = D(A3)
+    ref = oracle.omp(A3, b3, 7, 0.0)
+    got = d3.ctx.omp(b3, 7, 0.0)
+    assert np.array_equal(got[0], ref[0]) and len(got[0]) == 3 and close(got[1], ref[1])
+    # one atom, one row
+    A1 = np.asfortranarray(np.array([[2.0]]))
+    d1 = D(A1)
+    got = d1.ctx.omp(np.array([3.0]), 1, 0.0)
+    assert got[0].tolist() == [0] and abs(got[1][0] - 1.5) < 1e-15
+    # M = 2 rows, k > M: support fills the row space then stops (:63)
+    A2 = np.asfortranarray(rng.standard_normal((2, 9)).astype(np.float32))
+    b2 = rng.standard_normal(2)
+    d2 = D(A2)
+    ref = oracle.omp(A2, b2, 5, 0.0)
+    got = d2.ctx.omp(b2, 5, 0.0)
+    assert np.array_equal(got[0], ref[0]) and len(got[0]) == 2
+    # gomp with l > k and l > N
+    ref = oracle.gomp(A3, b3, 5, 2, 0.0)
+    got = d3.ctx.gomp(b3, 5, 2, 0.0)
+    assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+    # batch of one signal, batch with k = 1
+    idx, val, nnz = d.ctx.omp_batch(np.asfortranarray(b[:, None]), 1, 0.0)
+    assert nnz[0] == 1 and idx[0, 0] == oracle.omp(A, b, 1, 0.0)[0][0]
+    idx, val, nnz = d.ctx.omp_batch_mfma(np.asfortranarray(np.stack([b, 2 * b], axis=1)), 2, 0.0)
+    r2 = oracle.omp(A, b, 2, 0.0)
+    assert np.array_equal(idx[:, 0], r2[0]) and np.array_equal(idx[:, 1], r2[0]) and close(val[:, 1], 2 * r2[1])
