@@ -5,6 +5,7 @@
 #include "../../include/csmp.h"
 #include "csmp_kernels.hpp"
 #include "csmp_batched.hpp"
+#include "csmp_block.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -41,6 +42,10 @@ struct Solver {
     bool begun = false;
     int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
+    // multi-column append (csmp_block.hpp), allocated on first use
+    double *Apan = nullptr, *Vpan = nullptr, *PB1 = nullptr, *W1b = nullptr, *PG = nullptr, *Gsum = nullptr;
+    int* pan_atoms = nullptr;
+    int blk_kcap = 0;
     int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
     int sigcap = 0;
 };
@@ -204,6 +209,7 @@ static void solver_free(Solver& s) {
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
+    dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     s = Solver();
 }
 
@@ -930,7 +936,7 @@ extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_d
     return CSMP_OK;
 }
 
-static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask);
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block);
 
 extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
     if (!ctx) return CSMP_EINVAL;
@@ -943,7 +949,7 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
             CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
             return launch_append(ctx, 1, 0, STOP_FULL);
         }
-        default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL);
+        default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
 }
 
@@ -970,6 +976,73 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
     if (s.algo == CSMP_ALGO_MP) return mp_collect(ctx, nullptr, nullptr, 0, idx, val, nnz);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
     return download_result(ctx, s.outcap, idx, val, nnz, order);
+}
+
+// ------------------------------------------------------------------------------------------ multi-column append
+static int block_ensure(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.blk_kcap >= s.kcap && s.Apan) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
+    constexpr int nent = kPanelMax * kPanelMax + 2 * kPanelMax;
+    CHECK(dmalloc(ctx, &s.Apan, (size_t)kPanelMax * s.ldq));
+    CHECK(dmalloc(ctx, &s.Vpan, (size_t)kPanelMax * s.ldq));
+    CHECK(dmalloc(ctx, &s.PB1, (size_t)s.kcap * kPanelMax * s.G));
+    CHECK(dmalloc(ctx, &s.W1b, (size_t)s.kcap * kPanelMax));
+    CHECK(dmalloc(ctx, &s.PG, (size_t)nent * s.G));
+    CHECK(dmalloc(ctx, &s.Gsum, (size_t)nent));
+    CHECK(dmalloc(ctx, &s.pan_atoms, kPanelMax));
+    s.blk_kcap = s.kcap;
+    return CSMP_OK;
+}
+
+// add_column! for up to PB atoms cands[base .. base+want) at once (atoms already in the support are skipped)
+template <typename TA, int PB>
+static int launch_block_append_t(csmp_ctx* ctx, int base, int want, int skipmask) {
+    Solver& s = ctx->s;
+    const int jh = std::min(s.jh, s.kcap);
+    const size_t l1 = blk1_lds_bytes<PB>(), l2 = blk2_lds_bytes<PB>(), l3 = blk3_lds_bytes<PB>();
+    if (l1 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk1<TA, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+    if (l2 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk2<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+    if (l3 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk3<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+    hipLaunchKernelGGL((k_blk1<TA, PB>), dim3(s.G), dim3(kQrThreads), l1, ctx->stream, (const TA*)ctx->dA, ctx->ld, (int)ctx->M,
+                       (const double*)s.Q, s.ldq, s.st, (const int*)s.cands, (const int*)s.ncands, base, want, (const int*)s.sel,
+                       s.kcap, skipmask, s.Apan, s.PB1, s.G, s.pan_atoms);
+    HIPCHECK(hipGetLastError());
+    const int n1 = jh * PB;
+    if (n1 > 0) {
+        hipLaunchKernelGGL(k_red, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.PB1, s.W1b, n1, s.G, (int64_t)s.kcap * PB, (const DevState*)s.st, s.R, s.kcap, PB);
+        HIPCHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_blk2<PB>), dim3(s.G), dim3(kQrThreads), l2, ctx->stream, (const double*)s.Q, s.ldq, (const DevState*)s.st,
+                       (const double*)s.Apan, (const double*)s.W1b, (const double*)s.r, s.Vpan, s.PG, s.G);
+    HIPCHECK(hipGetLastError());
+    constexpr int nent = blk2_nent<PB>();
+    hipLaunchKernelGGL(k_red, dim3((nent + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.PG, s.Gsum, nent, s.G, (int64_t)nent, (const DevState*)s.st, (double*)nullptr, 0, PB);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_blk3<PB>), dim3(s.G), dim3(kQrThreads), l3, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.Vpan,
+                       (const double*)s.Gsum, (const double*)s.W1b, s.r, s.R, s.z, s.sel, (const int*)s.pan_atoms, s.kcap);
+    HIPCHECK(hipGetLastError());
+    s.jh = std::min(s.kcap, s.jh + std::min(want, PB));
+    return CSMP_OK;
+}
+
+// panels of <= 32 atoms over cands[0 .. n)
+static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask) {
+    CHECK(block_ensure(ctx));
+    for (int base = 0; base < n;) {
+        const int want = std::min(n - base, kPanelMax);
+        int rc;
+        if (want <= 4)
+            rc = ctx->dtype == CSMP_F32 ? launch_block_append_t<float, 4>(ctx, base, want, skipmask)
+                                        : launch_block_append_t<double, 4>(ctx, base, want, skipmask);
+        else
+            rc = ctx->dtype == CSMP_F32 ? launch_block_append_t<float, kPanelMax>(ctx, base, want, skipmask)
+                                        : launch_block_append_t<double, kPanelMax>(ctx, base, want, skipmask);
+        CHECK(rc);
+        base += want;
+    }
+    return CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ top-S, GOMP, LS, SP
@@ -1001,10 +1074,11 @@ static int launch_topS(csmp_ctx* ctx, int S) {
 }
 
 // update!(P::GOMP, x, l): src/matchingpursuit.jl:116-123
-static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask) {
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block = false) {
     l = std::min<int64_t>(l, ctx->N);
     CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skipmask));
     CHECK(launch_topS(ctx, (int)l));
+    if (block && l > 1) return launch_block_appends(ctx, (int)l, skipmask);  // the l atoms join the QR together
     for (int64_t w = 0; w < l; ++w) CHECK(launch_append(ctx, 2, (int)w, skipmask));
     return CSMP_OK;
 }
@@ -1020,12 +1094,21 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(k, l), std::max<int64_t>(ctx->M, l)));
     CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k + l, 1)));
     ctx->s.begun = false;
-    CHECK(upload_b(ctx, b, b_dtype));
-    const int main_skip = STOP_EPS | STOP_FULL;
-    for (int64_t it = 0; it < k / l; ++it) CHECK(gomp_update(ctx, l, eps, it > 0, main_skip));  // :130-133
-    const int64_t rem = k % l;                                                                      // :134
-    if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL));  // :135-137: runs even after an eps-break
-    CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+    // first with the multi-column append (the l atoms of a step join the QR in one panel); a panel
+    // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool block = pass == 0 && !ctx->force_reorth && l <= kPanelMax;
+        CHECK(upload_b(ctx, b, b_dtype));
+        const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
+        for (int64_t it = 0; it < k / l; ++it) CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));  // :130-133
+        const int64_t rem = k % l;                                                                             // :134
+        if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block));  // :135-137: runs even after an eps-break
+        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) break;
+    }
     return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
 }
 
@@ -1048,6 +1131,14 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (n > 1 && !ctx->force_reorth) {  // panels of 32 columns; verified through the device flag
+        CHECK(launch_block_appends(ctx, n, STOP_REORTH));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) return CSMP_OK;
+        CHECK(solver_restart(ctx));  // a panel failed its DGKS test: column-wise chain with re-orthogonalisation
+    }
     for (int w = 0; w < n; ++w) CHECK(launch_append(ctx, 2, w, 0));
     return CSMP_OK;
 }

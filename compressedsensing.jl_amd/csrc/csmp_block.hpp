@@ -1,0 +1,365 @@
+// csmp_block.hpp -- multi-column QR append (BASELINE config 5: "GOMP S=4 + Subspace Pursuit ...
+// multi-column QR append").  A panel of P <= PB atoms joins the factorisation in one chain of five
+// launches instead of 2-3 launches per atom:
+//
+//   k_blk1   guards (atoms already in the support are dropped: src/util.jl:119,129-134; capacity),
+//            A_p = A[:, panel] (Float64), per-slab partial W1_g = Q_g' A_p,g
+//   k_red    W1 = sum_g W1_g                      (fixed order: bitwise reproducible)
+//   k_blk2   V = A_p - Q W1 per slab; per-slab partials of V'V, V'r and |a_p|^2
+//   k_red    their sums
+//   k_blk3   Cholesky V'V = Rp' Rp (every workgroup, redundantly), DGKS test on its diagonal,
+//            Q_new = V Rp^-1, z_new = Rp^-T V'r, r -= Q_new z_new, R gets [W1; Rp], support += panel
+//
+// i.e. block classical Gram-Schmidt against Q followed by CholeskyQR inside the panel.  The DGKS test
+// (diag(Rp)^2 >= |a_p|^2 / 2) bounds the cancellation of both steps; a panel that fails it commits
+// nothing and raises STOP_REORTH, and the host repeats the solve with the column-wise safe chain.
+// SP re-factorises A[:, support] from scratch twice per iteration (src/twostage.jl:74,104-107):
+// with PB = 32 that is 32 + 16 panels instead of 1536 single-column appends.
+#pragma once
+#include "csmp_kernels.hpp"
+
+namespace csmp {
+
+constexpr int kPanelMax = 32;
+
+// dst[e] = sum_g src[g*stride + e], fixed order (threads <-> consecutive e: coalesced)
+// With Rdst != NULL (the W1 reduction, e = c*PB + p) the sum is also stored as R[c, j+p]: the new
+// columns of R are written by the whole grid instead of by one workgroup of k_blk3.
+__global__ __launch_bounds__(256) void k_red(const double* __restrict__ src, double* __restrict__ dst, int n, int G,
+                                             int64_t stride, const DevState* st, double* __restrict__ Rdst, int kcap,
+                                             int PB) {
+    if (st->pcount == 0) return;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int g = 0;
+    for (; g + 8 <= G; g += 8) {
+        double t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = src[(int64_t)(g + i) * stride + e];
+        s0 += t[0]; s1 += t[1]; s2 += t[2]; s3 += t[3];
+        s0 += t[4]; s1 += t[5]; s2 += t[6]; s3 += t[7];
+    }
+    for (; g < G; ++g) s0 += src[(int64_t)g * stride + e];
+    const double sum = (s0 + s1) + (s2 + s3);
+    dst[e] = sum;
+    if (Rdst) {
+        const int c = e / PB, p = e % PB, j = st->j;
+        if (c < j && p < st->pcount) Rdst[(int64_t)(j + p) * kcap + c] = sum;
+    }
+}
+
+// LDS of k_blk1: Aps[PB][64] | part[4][64][PB] | ints
+template <int PB>
+constexpr size_t blk1_lds_bytes() {
+    return (size_t)(PB * kSlabRows + 4 * kWave * PB) * sizeof(double) + 4 * PB * sizeof(int) + 64;
+}
+
+template <typename TA, int PB>
+__global__ __launch_bounds__(kQrThreads) void k_blk1(const TA* __restrict__ A, int64_t ld, int M,
+                                                     const double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                     const int* __restrict__ cands, const int* __restrict__ ncands, int base,
+                                                     int want, const int* __restrict__ sel, int kcap, int skipmask,
+                                                     double* __restrict__ Apan, double* __restrict__ PB1, int G,
+                                                     int* __restrict__ pan_atoms) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* Aps = lds;                              // [PB][64]
+    double* part = Aps + PB * kSlabRows;            // [4][64][PB]
+    int* found = reinterpret_cast<int*>(part + 4 * kWave * PB);  // [PB]
+    int* pan = found + PB;                          // [PB]
+    int* cnt = pan + PB;                            // [1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
+    if (st->done & skipmask) {
+        if (g == 0 && tid == 0) st->pcount = 0;
+        return;
+    }
+    const int nsel = st->nsel;
+    int nreq = min(want, *ncands - base);
+    if (nreq < 0) nreq = 0;
+    if (nreq > PB) nreq = PB;
+    if (tid < PB) found[tid] = 0;
+    __syncthreads();
+    for (int q = tid; q < nsel; q += kQrThreads) {
+        const int v = sel[q];
+        for (int p = 0; p < nreq; ++p)
+            if (cands[base + p] == v) found[p] = 1;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int room = min(kcap, M) - nsel;
+        int c = 0;
+        for (int p = 0; p < nreq && c < room; ++p)
+            if (!found[p]) pan[c++] = cands[base + p];
+        *cnt = c;
+        if (g == 0) {
+            st->j = nsel;
+            st->pcount = c;
+            if (room <= 0) st->done |= STOP_FULL;  // nnz(x) < size(A,1) guard (:117)
+            for (int p = 0; p < c; ++p) pan_atoms[p] = pan[p];
+        }
+    }
+    __syncthreads();
+    const int P = *cnt;
+    if (P == 0) return;
+    // A_p slab -> LDS (Float64) and the global panel buffer
+    for (int e = tid; e < PB * kSlabRows; e += kQrThreads) {
+        const int p = e / kSlabRows, row = g * kSlabRows + (e % kSlabRows);
+        const double a = (p < P && row < M) ? (double)A[(int64_t)pan[p] * ld + row] : 0.0;
+        Aps[e] = a;
+        if (p < P) Apan[(int64_t)p * ldq + row] = a;
+    }
+    __syncthreads();
+    // W1_g = Q_g' A_p,g : lane <-> column of Q, wave <-> 16-row quarter, PB accumulators per thread;
+    // the next 64-column chunk of Q is requested while the current one is multiplied
+    const double* qbase = Q + g * kSlabRows + wave * 16;
+    double* out = PB1 + (int64_t)g * kcap * PB;  // this slab's partials, [c][p]
+    f64x2 qv[8], qn[8];
+    {
+        const int c = lane;
+        const f64x2* q = reinterpret_cast<const f64x2*>(qbase + (int64_t)(c < nsel ? c : 0) * ldq);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = (c < nsel) ? q[i] : (f64x2)0.0;
+    }
+    for (int c0 = 0; c0 < nsel; c0 += kWave) {
+        {
+            const int c = c0 + kWave + lane;
+            const f64x2* q = reinterpret_cast<const f64x2*>(qbase + (int64_t)(c < nsel ? c : 0) * ldq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qn[i] = (c < nsel) ? q[i] : (f64x2)0.0;
+        }
+        double acc[PB];
+#pragma unroll
+        for (int p = 0; p < PB; ++p) acc[p] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int p = 0; p < PB; ++p) {
+                const f64x2 ap = *reinterpret_cast<const f64x2*>(Aps + p * kSlabRows + wave * 16 + 2 * i);  // broadcast
+                acc[p] = fma(qv[i].x, ap.x, acc[p]);
+                acc[p] = fma(qv[i].y, ap.y, acc[p]);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PB; ++p) part[(wave * PB + p) * kWave + lane] = acc[p];  // [wave][p][lane]: conflict-free
+        __syncthreads();
+        for (int e = tid; e < kWave * PB; e += kQrThreads) {
+            const int p = e / kWave, cl = e % kWave, cc = c0 + cl;
+            if (cc < nsel && p < P)
+                out[(int64_t)cc * PB + p] = (part[(0 * PB + p) * kWave + cl] + part[(1 * PB + p) * kWave + cl]) +
+                                            (part[(2 * PB + p) * kWave + cl] + part[(3 * PB + p) * kWave + cl]);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = qn[i];
+    }
+}
+
+// entries of the per-slab partial vector of k_blk2: V'V (PB*PB, row-major [p][q]) | V'r (PB) | |a_p|^2 (PB)
+template <int PB>
+constexpr int blk2_nent() { return PB * PB + 2 * PB; }
+template <int PB>
+constexpr size_t blk2_lds_bytes() {
+    return (size_t)(PB * kSlabRows + kWave * PB + kSlabRows + PB * kSlabRows + kWave * kSlabRows) * sizeof(double) + 64;
+}
+
+template <int PB>
+__global__ __launch_bounds__(kQrThreads) void k_blk2(const double* __restrict__ Q, int64_t ldq, const DevState* st,
+                                                     const double* __restrict__ Apan, const double* __restrict__ W1b,
+                                                     const double* __restrict__ r, double* __restrict__ Vpan,
+                                                     double* __restrict__ PG, int G) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* Vs = lds;                        // [PB][64]  (A_p slab, then V slab)
+    double* Wt = Vs + PB * kSlabRows;        // [64][PB]  tile of W1
+    double* rs = Wt + kWave * PB;            // [64]
+    double* As = rs + kSlabRows;             // [PB][64]  copy of the A_p slab (for |a_p|^2)
+    double* Qt = As + PB * kSlabRows;        // [64 cols][64 rows] tile of the Q slab
+    const int P = st->pcount;
+    if (P == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x, j = st->j;
+    for (int e = tid; e < PB * kSlabRows; e += kQrThreads) {
+        const int p = e / kSlabRows;
+        const double a = (p < P) ? Apan[(int64_t)p * ldq + g * kSlabRows + (e % kSlabRows)] : 0.0;
+        Vs[e] = a;
+        As[e] = a;
+    }
+    if (tid < kSlabRows) rs[tid] = r[g * kSlabRows + tid];
+    // V = A_p - Q_g W1.  Q is staged in 64x64 tiles: every thread fetches 8 x 16 B of the NEXT tile
+    // (thread <-> (column tid/32 + 8 i, row pair tid%32)) while the current tile is consumed from LDS with
+    // lane <-> row and wave <-> PB/4 panel columns; W1 tiles come through LDS as well.
+    constexpr int PW = PB / 4;
+    double acc[PW];
+#pragma unroll
+    for (int t = 0; t < PW; ++t) acc[t] = 0.0;
+    const int tc = tid >> 5, tr = (tid & 31) * 2;  // this thread's column offset (0..7) and row pair in a tile
+    const double* qsrc = Q + g * kSlabRows + tr;
+    f64x2 nx[8];
+    constexpr int WPT = kWave * PB / kQrThreads;  // W1-tile entries per thread
+    double nw[WPT];
+    auto fetch = [&](int c0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = c0 + tc + 8 * i;
+            nx[i] = (c < j) ? *reinterpret_cast<const f64x2*>(qsrc + (int64_t)c * ldq) : (f64x2)0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int e = tid + i * kQrThreads;
+            const int cc = c0 + e / PB;
+            nw[i] = (cc < j) ? W1b[(int64_t)cc * PB + (e % PB)] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int c0 = 0; c0 < j; c0 += kWave) {
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f64x2*>(Qt + (tc + 8 * i) * kSlabRows + tr) = nx[i];
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) Wt[tid + i * kQrThreads] = nw[i];
+        if (c0 + kWave < j) fetch(c0 + kWave);
+        __syncthreads();
+        const int nc = min(kWave, j - c0);
+        for (int cl = 0; cl < nc; ++cl) {
+            const double qv = Qt[cl * kSlabRows + lane];
+#pragma unroll
+            for (int t = 0; t < PW; ++t) acc[t] = fma(qv, Wt[cl * PB + wave * PW + t], acc[t]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < PW; ++t) {
+        const int p = wave * PW + t;
+        const double v = Vs[p * kSlabRows + lane] - acc[t];
+        Vs[p * kSlabRows + lane] = v;
+        if (p < P) Vpan[(int64_t)p * ldq + g * kSlabRows + lane] = v;
+    }
+    __syncthreads();
+    // per-slab partials: V'V (upper triangle is enough, the full square is written), V'r, |a_p|^2
+    double* out = PG + (int64_t)g * blk2_nent<PB>();
+    for (int e = tid; e < blk2_nent<PB>(); e += kQrThreads) {
+        double s = 0.0;
+        if (e < PB * PB) {
+            const int p = e / PB, q = e % PB;
+            if (p <= q && q < P)
+                for (int row = 0; row < kSlabRows; ++row) s = fma(Vs[p * kSlabRows + row], Vs[q * kSlabRows + row], s);
+        } else if (e < PB * PB + PB) {
+            const int p = e - PB * PB;
+            if (p < P)
+                for (int row = 0; row < kSlabRows; ++row) s = fma(Vs[p * kSlabRows + row], rs[row], s);
+        } else {
+            const int p = e - PB * PB - PB;
+            if (p < P)
+                for (int row = 0; row < kSlabRows; ++row) s = fma(As[p * kSlabRows + row], As[p * kSlabRows + row], s);
+        }
+        out[e] = s;
+    }
+}
+
+template <int PB>
+constexpr size_t blk3_lds_bytes() {
+    return (size_t)(blk2_nent<PB>() + PB * PB + PB + PB * kSlabRows) * sizeof(double) + 64;
+}
+
+template <int PB>
+__global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                     const double* __restrict__ Vpan, const double* __restrict__ Gsum,
+                                                     const double* __restrict__ W1b, double* __restrict__ r,
+                                                     double* __restrict__ R, double* __restrict__ z, int* __restrict__ sel,
+                                                     const int* __restrict__ pan_atoms, int kcap) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double* Gs = lds;                          // PB*PB + 2 PB
+    double* Rp = Gs + blk2_nent<PB>();         // [PB][PB] upper triangular, Rp[t*PB + p], t <= p
+    double* zp = Rp + PB * PB;                 // [PB]
+    double* Vs = zp + PB;                      // [PB][64]
+    int& bad = *reinterpret_cast<int*>(Vs + PB * kSlabRows);
+    const int P = st->pcount;
+    if (P == 0) return;
+    const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
+    for (int e = tid; e < blk2_nent<PB>(); e += kQrThreads) Gs[e] = Gsum[e];
+    for (int e = tid; e < PB * kSlabRows; e += kQrThreads) {
+        const int p = e / kSlabRows;
+        Vs[e] = (p < P) ? Vpan[(int64_t)p * ldq + g * kSlabRows + (e % kSlabRows)] : 0.0;
+    }
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    // Cholesky V'V = Rp' Rp and zp = Rp^-T (V'r) in the registers of ONE wave: lane q owns column q
+    // of the (padded to PB x PB, identity beyond P) Gram matrix; every dependent step is a register
+    // broadcast (shuffle) + fma, no LDS round trips and no barriers.  Identical in every workgroup.
+    if (tid < kWave) {
+        const int q = tid;
+        double gq[PB];
+#pragma unroll
+        for (int t = 0; t < PB; ++t)
+            gq[t] = (q < PB && t <= q) ? ((q < P) ? Gs[t * PB + q] : (t == q ? 1.0 : 0.0)) : 0.0;
+        double sv = (q < P) ? Gs[PB * PB + q] : 0.0;        // V'r
+        const double na2 = (q < P) ? Gs[PB * PB + PB + q] : 0.0;
+        double zmine = 0.0;
+        int mybad = 0;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const double d = __shfl(gq[p], p, kWave);  // current pivot (lane p holds G[p][p])
+            if (q == p && p < P && (!(d > 0.0) || !(d >= 0.5 * na2))) mybad = 1;  // DGKS: too much cancellation
+            const double rd = (d > 0.0) ? sqrt(d) : 1.0;
+            gq[p] = (q == p) ? rd : gq[p] / rd;  // row p of Rp (lanes q >= p)
+#pragma unroll
+            for (int s_ = p + 1; s_ < PB; ++s_) {
+                const double rps = __shfl(gq[p], s_, kWave);  // Rp[p][s]
+                if (q >= s_) gq[s_] = fma(-rps, gq[p], gq[s_]);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {  // forward substitution, column oriented
+            const double zb = __shfl(sv / gq[p], p, kWave);
+            if (q == p) zmine = zb;
+            if (q > p) sv = fma(-gq[p], zb, sv);
+        }
+        if (__any(mybad) && tid == 0) bad = 1;
+        if (q < PB) {
+#pragma unroll
+            for (int t = 0; t < PB; ++t)
+                if (t <= q) Rp[t * PB + q] = gq[t];
+            zp[q] = zmine;
+        }
+    }
+    __syncthreads();
+    if (bad) {
+        if (g == 0 && tid == 0) st->done |= STOP_REORTH;  // nothing committed; the host falls back
+        return;
+    }
+    // Q_new = V Rp^-1 row by row; r -= Q_new zp
+    if (tid < kSlabRows) {
+        const int row = g * kSlabRows + tid;
+        double q[PB];
+        double dr = 0.0;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            double s = Vs[p * kSlabRows + tid];
+#pragma unroll
+            for (int t = 0; t < PB; ++t)
+                if (t < p) s = fma(-q[t], Rp[t * PB + p], s);
+            q[p] = (p < P) ? s / Rp[p * PB + p] : 0.0;
+            if (p < P) {
+                Q[(int64_t)(j + p) * ldq + row] = q[p];
+                dr = fma(q[p], zp[p], dr);
+            }
+        }
+        r[row] -= dr;
+    }
+    if (g == 0) {
+        // (rows 0..j-1 of the new R columns = W1 were stored by the W1 reduction, k_red)
+        for (int e = tid; e < P * P; e += kQrThreads) {
+            const int t = e / P, p = e % P;
+            if (t <= p) R[(int64_t)(j + p) * kcap + (j + t)] = Rp[t * PB + p];
+        }
+        if (tid < P) {
+            z[j + tid] = zp[tid];
+            sel[j + tid] = pan_atoms[tid];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            st->nsel = j + P;
+            st->steps += 1;
+        }
+    }
+}
+
+}  // namespace csmp

@@ -38,7 +38,7 @@ struct DevState {
     int done;       // STOP_* bits
     int steps;      // update! calls that changed x
     int go2;        // 1: k_qr2 asked for the re-orthogonalisation pass (k_qr3)
-    int pad1;
+    int pcount;     // atoms accepted into the current panel (multi-column append, csmp_block.hpp)
     double rnorm2;  // ||r||^2 seen by the last sweep prologue
     double cval;    // signed <a_cand, r> (MP coefficient, src/matchingpursuit.jl:29)
 };
@@ -1198,15 +1198,43 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ R, co
     const int tid = threadIdx.x, j = st->nsel;
     for (int t = tid; t < j; t += 256) y[t] = z[t];
     __syncthreads();
+    // column-oriented back substitution; column i-1 of R is requested while column i is applied
+    // (threads cover rows t = tid + 256 u, u < 4: kcap <= 1024)
+    double rc[4], rn[4];
+    double dcur = 1.0, dnext = 1.0;
+    if (j > 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u;
+            rc[u] = (t < j - 1) ? R[(int64_t)(j - 1) * kcap + t] : 0.0;
+        }
+        dcur = R[(int64_t)(j - 1) * kcap + (j - 1)];
+    }
     for (int i = j - 1; i >= 0; --i) {
+        if (i > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = tid + 256 * u;
+                rn[u] = (t < i - 1) ? R[(int64_t)(i - 1) * kcap + t] : 0.0;
+            }
+            dnext = R[(int64_t)(i - 1) * kcap + (i - 1)];
+        }
         if (tid == 0) {
-            ci = y[i] / R[(int64_t)i * kcap + i];
+            ci = y[i] / dcur;
             y[i] = ci;
         }
         __syncthreads();
         const double c = ci;
-        for (int t = tid; t < i; t += 256) y[t] = fma(-R[(int64_t)i * kcap + t], c, y[t]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int t = tid + 256 * u;
+            if (t < i) y[t] = fma(-rc[u], c, y[t]);
+        }
+        for (int t = tid + 1024; t < i; t += 256) y[t] = fma(-R[(int64_t)i * kcap + t], c, y[t]);  // kcap > 1024
         __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rc[u] = rn[u];
+        dcur = dnext;
     }
     for (int t = tid; t < j; t += 256) coef[t] = y[t];
     for (int t = tid; t < outcap; t += 256) {
@@ -1247,6 +1275,7 @@ __global__ __launch_bounds__(256) void k_init(const TB* __restrict__ src, int M,
         st->done = 0;
         st->steps = 0;
         st->go2 = 0;
+        st->pcount = 0;
         st->rnorm2 = 0.0;
         st->cval = 0.0;
     }
