@@ -540,3 +540,35 @@ def test_edge_cases_tiny_and_degenerate(cs, oracle, D):
     idx, val, nnz = d.ctx.omp_batch_mfma(np.asfortranarray(np.stack([b, 2 * b], axis=1)), 2, 0.0)
     r2 = oracle.omp(A, b, 2, 0.0)
     assert np.array_equal(idx[:, 0], r2[0]) and np.array_equal(idx[:, 1], r2[0]) and close(val[:, 1], 2 * r2[1])
+
+
+def test_block_append_falls_back_on_coherent_panels(cs, oracle, D):
+    """Multi-column append (GOMP panels, SP / lstsq factorisations): on a highly coherent dictionary a
+    panel fails its DGKS test, nothing is committed and the host repeats the solve column-wise with
+    re-orthogonalisation.  Results must still match the oracle (tolerance scaled by conditioning)."""
+    rng = np.random.default_rng(8)
+    n, m = 96, 260
+    U, V = rng.standard_normal((n, n)), rng.standard_normal((n, m))
+    A = (U * (1.0 / np.arange(1, n + 1) ** 2)) @ V
+    A /= np.linalg.norm(A, axis=0)
+    A = np.asfortranarray(A)
+    d = D(A)
+    xs = cs.sparse_vector(m, 6, rng=rng)
+    y = cs.perturb(A @ xs.to_dense(), 1e-3, rng=rng)
+    ref = oracle.gomp(A, y, 3, 6, EPS64)
+    got = d.ctx.gomp(y, 3, 6, EPS64)
+    assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    cond = np.linalg.cond(A[:, ref[0]])
+    assert np.allclose(got[1], ref[1], rtol=1e-6, atol=1e-11 * cond * np.abs(ref[1]).max()), cond
+    cols = np.array([5, 6, 7, 8, 9, 100, 101, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52,
+                     53, 54, 55, 56, 57, 58, 59, 60, 61, 62])  # 40 columns: two panels
+    got = d.ctx.lstsq(cols, y)
+    want = np.linalg.lstsq(A[:, cols], y, rcond=None)[0]
+    cond = np.linalg.cond(A[:, cols])
+    r1, r2 = y - A[:, cols] @ got, y - A[:, cols] @ want
+    assert abs(np.linalg.norm(r1) - np.linalg.norm(r2)) <= 1e-9 * np.linalg.norm(y) * max(1.0, cond * 1e-6), (cond,)
+    # well-conditioned panels on the same context still take the fast path and agree tightly
+    A2, x2, b2 = cs.sparse_data(n=96, m=260, k=5, rng=3)
+    d2 = D(A2)
+    cols2 = np.arange(0, 70, 2)
+    np.testing.assert_allclose(d2.ctx.lstsq(cols2, b2), np.linalg.lstsq(A2[:, cols2], b2, rcond=None)[0], rtol=1e-9, atol=1e-12)
