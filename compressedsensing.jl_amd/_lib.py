@@ -35,6 +35,7 @@ SIGNATURES = {
     "csmp_omp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_gomp": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_sp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
@@ -211,6 +212,17 @@ class Context:
         nnz = i64(0)
         iters = i64(0)
         self.call("csmp_sp", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
+                  ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), iters.value
+
+    def ompr(self, b, k, delta, maxiter=-1):
+        b = self._b(b)
+        idx = np.zeros(max(int(k), 1), np.int64)
+        val = np.zeros(max(int(k), 1), np.float64)
+        nnz = i64(0)
+        iters = i64(0)
+        self.call("csmp_ompr", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
                   ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), iters.value

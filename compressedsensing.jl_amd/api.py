@@ -146,6 +146,17 @@ def sp(A, b, k, delta=1e-12, maxiter=None):
             D.close()
 
 
+def ompr(A, b, k, delta, maxiter=None):
+    """ompr(A,b,k,delta; maxiter=size(A,1)): OMP with replacement, src/twostage.jl:184-202 (x empty)."""
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.ompr(b, int(k), float(delta), -1 if maxiter is None else int(maxiter))
+        return SparseVector(D.shape[1], idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
 def omp_batch(A, B, k, eps=None):
     """[omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU; returns a list of SparseVectors."""
     eps = _meta(A)[2] if eps is None else eps

@@ -1302,6 +1302,107 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
     return CSMP_OK;
 }
 
+// ------------------------------------------------------------------------------------------ OMP with replacement
+// ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202, x starting empty.  The support is filled by
+// oblivious_acquisition! (src/matchingpursuit.jl:207-216); every update! (:134-180) is one sweep +
+// arg-max on the device, the tiny "which entry leaves" decision on k+1 numbers on the host, and --
+// when the support changes -- a fresh panel factorisation of the new support (the reference's
+// add_column!/remove_column! pair yields the same least-squares solution).
+extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
+                         double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "ompr: b == NULL or k < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
+    if (maxiter < 0) maxiter = ctx->M;  // :185
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)k, (int)k));
+    ctx->s.begun = false;
+    Solver& s = ctx->s;
+    CHECK(upload_b(ctx, b, b_dtype));
+    // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
+    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+    CHECK(launch_topS(ctx, (int)k));
+    std::vector<int> top((size_t)k);
+    HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    std::sort(top.begin(), top.end());
+    CHECK(ls_on_columns(ctx, top));
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    CHECK(fetch_sorted(ctx, xi, xv));
+    double resnorm = 0.0;
+    CHECK(residual_norm(ctx, &resnorm));  // :192
+    int64_t it = 0;
+    std::vector<double> cs((size_t)k), call;
+    while (it < maxiter) {  // :193
+        const double oldnorm = resnorm;
+        // update!(P, x): Ar = x + A'r (eta = 1), arg-max over atoms outside the support
+        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+        CHECK(launch_select(ctx, 0, 0));
+        std::vector<int> cur(xi.begin(), xi.end());
+        HIPCHECK(hipMemcpyAsync(s.cands, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
+        HIPCHECK(hipGetLastError());
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(cs.data(), s.coef, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        int64_t cand = hs.cand;
+        double ccand = hs.cval;
+        if (std::binary_search(xi.begin(), xi.end(), cand)) {
+            // degenerate: the overall arg-max lies inside the support; scan the correlations on the host
+            call.resize((size_t)ctx->N);
+            HIPCHECK(hipMemcpy(call.data(), s.cvec, (size_t)ctx->N * 8, hipMemcpyDeviceToHost));
+            cand = -1;
+            double m = 0.0;
+            for (int64_t j = 0; j < ctx->N; ++j) {
+                if (std::binary_search(xi.begin(), xi.end(), j)) continue;
+                const double f = std::fabs(call[j]);
+                if (f > m) {  // strict '>' from m = 0: first maximum, none if everything is zero (:139-155)
+                    m = f;
+                    cand = j;
+                }
+            }
+            if (cand >= 0) ccand = call[cand];
+        } else if (!(std::fabs(ccand) > 0.0)) {
+            cand = -1;
+        }
+        ++it;
+        if (cand >= 0) {
+            // x[i] = NaN; x.nzval = Ar[x.nzind]; drop the first entry of smallest magnitude (:158-169)
+            const size_t pos = (size_t)(std::lower_bound(xi.begin(), xi.end(), cand) - xi.begin());
+            size_t jmin = 0;
+            double vmin = 0.0;
+            for (size_t t = 0; t <= xi.size(); ++t) {
+                const double v = t == pos ? ccand : (t < pos ? xv[t] + cs[t] : xv[t - 1] + cs[t - 1]);
+                if (t == 0 || std::fabs(v) < vmin) {
+                    vmin = std::fabs(v);
+                    jmin = t;
+                }
+            }
+            if (jmin != pos) {  // qr_i != j (:171): the support really changes
+                std::vector<int> cols;
+                for (size_t t = 0; t <= xi.size(); ++t) {
+                    if (t == jmin) continue;
+                    cols.push_back(t == pos ? (int)cand : (int)(t < pos ? xi[t] : xi[t - 1]));
+                }
+                CHECK(ls_on_columns(ctx, cols));  // :178
+                CHECK(fetch_sorted(ctx, xi, xv));
+            }
+        }
+        CHECK(residual_norm(ctx, &resnorm));                 // :196
+        if (resnorm <= delta || oldnorm <= resnorm) break;   // :197
+    }
+    for (size_t t = 0; t < xi.size(); ++t) {
+        if (idx) idx[t] = xi[t];
+        if (val) val[t] = xv[t];
+    }
+    if (nnz) *nnz = (int64_t)xi.size();
+    if (iters) *iters = it;
+    return CSMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ batched (MFMA-screened) OMP
 __global__ void k_absmax_f32(const float* __restrict__ A, int64_t n, float* out) {
     float m = 0.f;

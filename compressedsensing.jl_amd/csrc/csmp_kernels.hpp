@@ -1314,6 +1314,13 @@ __global__ __launch_bounds__(256) void k_mp_update(const TA* __restrict__ A, int
     }
 }
 
+// out[t] = c[idx[t]] (OMPR reads the correlations of its support, src/twostage.jl:165)
+__global__ __launch_bounds__(256) void k_gather(const double* __restrict__ c, const int* __restrict__ idx, int n,
+                                                double* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < n) out[t] = c[idx[t]];
+}
+
 // ||r||_2^2 by one workgroup (step-level API / SP loop control)
 __global__ __launch_bounds__(256) void k_norm2(const double* __restrict__ r, int M, double* __restrict__ out) {
     __shared__ double s[256];

@@ -130,6 +130,18 @@ function sp(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxite
     to_sparse(size(D, 2), idx, val, nnz[])
 end
 
+# ---------------------------------------------------------------------------------- ompr
+# src/twostage.jl:184-202 (x starting empty: the support is filled by oblivious_acquisition!)
+function ompr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real; maxiter = size(A, 1)) where {T}
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx, val, nnz, iters = zeros(Int64, k), zeros(Float64, k), Ref{Int64}(0), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_ompr, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}),
+        D.ctx, bb, bt, k, δ, maxiter, idx, val, nnz, iters))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+
 # ---------------------------------------------------------------------------------- functors
 # abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)
 abstract type Update{T} end

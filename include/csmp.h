@@ -95,6 +95,12 @@ int csmp_gomp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t l, int64_t k, d
 int csmp_sp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t *idx,
             double *val, int64_t *nnz, int64_t *iters);
 
+/* ompr(A,b,k,delta;maxiter): OMP with replacement, src/twostage.jl:110-202, with x starting empty
+ * (the support is filled by oblivious_acquisition!, src/matchingpursuit.jl:207-216).  maxiter < 0
+ * selects the default size(A,1).  Capacity k.  *iters (may be NULL) = number of update! calls. */
+int csmp_ompr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t *idx,
+              double *val, int64_t *nnz, int64_t *iters);
+
 /* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);

@@ -508,3 +508,73 @@ int cso_sp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const dou
     sp_free(&x);
     return CSO_OK;
 }
+
+/* ---------------------------------------------------------------- ompr (OMP with replacement)
+ * OMPR ctor: src/twostage.jl:124-131;  update!(P::OMPR, x, eta=1): :134-180;  ompr: :184-202.
+ * The support is first filled by oblivious_acquisition! (src/matchingpursuit.jl:207-216: the k atoms
+ * best correlated with b, QR columns added in sorted order, one LS solve).  add_column! followed by
+ * remove_column! on the updatable QR (:171-175) is restated as a fresh least-squares solve on the new
+ * support: the LS solution on a full-rank support is unique. */
+int cso_ompr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+             double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
+             int nthreads) {
+    if (k < 1 || k > N || k > M) return CSO_ERANGE;
+    if (maxiter < 0) maxiter = M; /* :185 maxiter = size(A, 1) */
+    spvec_t x;
+    if (sp_init(&x, k + 1) != 0) return CSO_ENOMEM;
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *Ar = (double *)malloc((size_t)N * sizeof(double));
+    double *cs = (double *)malloc((size_t)N * sizeof(double));
+    int64_t *top = (int64_t *)malloc((size_t)k * sizeof(int64_t));
+    /* oblivious_acquisition!(P, x, k): :190 */
+    cso_residual(A, dtype, M, ld, x.idx, x.val, 0, b, r);
+    cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads);
+    cso_topk_desc(Ar, N, k, top);
+    for (int64_t t = 0; t < k; ++t) sp_set(&x, top[t], NAN);
+    cso_lstsq_cols(A, dtype, M, ld, x.idx, x.nnz, b, x.val);
+    cso_residual(A, dtype, M, ld, x.idx, x.val, x.nnz, b, r);
+    double resnorm = nrm2(r, M); /* :192 */
+    int64_t it = 0;
+    while (it < maxiter) { /* :193 */
+        const double oldnorm = resnorm;
+        /* update!(P, x): residual (r is current); Ar = x + eta * A'r with eta = 1 (:136-138) */
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+        for (int64_t j = 0; j < N; ++j) cs[j] = col_dot(A, dtype, M, ld, j, r);
+        for (int64_t t = 0; t < x.nnz; ++t) cs[x.idx[t]] += x.val[t];
+        /* arg-max of |Ar| over j not in the support, strict '>' from m = 0 (:139-151) */
+        double m = 0.0;
+        int64_t best = -1;
+        for (int64_t j = 0; j < N; ++j) {
+            if (sp_find(&x, j) >= 0) continue;
+            const double f = fabs(cs[j]);
+            if (f > m) {
+                m = f;
+                best = j;
+            }
+        }
+        ++it;
+        if (best >= 0) { /* :153-155: i == 0 -> return x */
+            const int64_t qr_i = sp_set(&x, best, NAN);                 /* :158-159 */
+            for (int64_t t = 0; t < x.nnz; ++t) x.val[t] = cs[x.idx[t]]; /* :165 */
+            int64_t jmin = 0;                                           /* :167 argmin(abs, nzval): first minimum */
+            for (int64_t t = 1; t < x.nnz; ++t)
+                if (fabs(x.val[t]) < fabs(x.val[jmin])) jmin = t;
+            memmove(x.idx + jmin, x.idx + jmin + 1, (size_t)(x.nnz - jmin - 1) * sizeof(int64_t)); /* :168-169 */
+            memmove(x.val + jmin, x.val + jmin + 1, (size_t)(x.nnz - jmin - 1) * sizeof(double));
+            x.nnz--;
+            (void)qr_i; /* :171-175 QR add/remove == re-solve on the new support */
+            cso_lstsq_cols(A, dtype, M, ld, x.idx, x.nnz, b, x.val); /* :178 */
+        }
+        cso_residual(A, dtype, M, ld, x.idx, x.val, x.nnz, b, r);
+        resnorm = nrm2(r, M);                              /* :196 */
+        if (resnorm <= delta || oldnorm <= resnorm) break; /* :197 */
+    }
+    emit(&x, idx, val, nnz);
+    if (iters) *iters = it;
+    free(r);
+    free(Ar);
+    free(cs);
+    free(top);
+    sp_free(&x);
+    return CSO_OK;
+}

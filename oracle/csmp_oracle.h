@@ -59,6 +59,12 @@ int cso_sp(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const dou
            double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
            int nthreads);
 
+/* ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202 (x starts empty -> oblivious_acquisition!).
+ * maxiter < 0 selects the default size(A,1). */
+int cso_ompr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+             double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
+             int nthreads);
+
 /* step primitives, exported so tests can pin them one by one */
 /* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
 int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,

@@ -120,6 +120,23 @@ def sp(A, b, k, delta=1e-12, maxiter=-1, nthreads=0):
     return idx[:n].copy(), val[:n].copy(), iters.value
 
 
+def ompr(A, b, k, delta, maxiter=-1, nthreads=0):
+    A, b, M, N, dtype = _prep(A, b)
+    idx = np.zeros(max(int(k), 1) + 1, np.int64)
+    val = np.zeros(max(int(k), 1) + 1, np.float64)
+    nnz = i64(0)
+    iters = i64(0)
+    if nthreads <= 0:
+        nthreads = min(16, os.cpu_count() or 1)  # (GPU-pool boxes: 256 logical CPUs, 16-CPU cgroup quota)
+    rc = lib().cso_ompr(_vp(A), dtype, i64(M), i64(N), i64(M), _vp(b), i64(int(k)), C.c_double(delta),
+                        i64(int(maxiter)), _vp(idx), _vp(val), C.byref(nnz), C.byref(iters), int(nthreads))
+    if rc == -3:
+        raise ValueError("k out of range")
+    assert rc == 0, rc
+    n = nnz.value
+    return idx[:n].copy(), val[:n].copy(), iters.value
+
+
 def sweep_abs(A, r, nthreads=0):
     A, r, M, N, dtype = _prep(A, r)
     out = np.zeros(N, np.float64)

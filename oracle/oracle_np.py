@@ -141,3 +141,35 @@ def sp(A, b, k, delta=1e-12, maxiter=None):
         if resnorm <= delta or oldnorm <= resnorm:  # :96
             break
     return idx, val, iters
+
+
+def ompr(A, b, k, delta, maxiter=None):
+    """OMP with replacement: src/twostage.jl:110-202 (x starts empty)."""
+    A, b = _f64(A, b)
+    M, N = A.shape
+    if maxiter is None:
+        maxiter = M  # :185
+    idx = np.sort(_topk(_abs_corr(A, b), k)).astype(np.int64)  # oblivious_acquisition! (matchingpursuit.jl:207-216)
+    val = _ls(A, idx, b)
+    resnorm = np.linalg.norm(_residual(A, b, idx, val))
+    iters = 0
+    for _ in range(maxiter):
+        oldnorm = resnorm
+        r = _residual(A, b, idx, val)
+        Ar = A.T @ r  # eta = 1
+        Ar[idx] += val  # copy!(P.Ar, x); mul!(P.Ar, A', r, eta, 1)
+        mask = np.ones(N, bool)
+        mask[idx] = False
+        cand = np.abs(Ar) * mask
+        iters += 1
+        if cand.max() > 0:
+            i = int(np.argmax(cand))  # first maximum among atoms outside the support
+            idx2 = np.sort(np.append(idx, i))
+            v2 = Ar[idx2]
+            j = int(np.argmin(np.abs(v2)))  # first minimum
+            idx = np.delete(idx2, j)
+            val = _ls(A, idx, b)
+        resnorm = np.linalg.norm(_residual(A, b, idx, val))
+        if resnorm <= delta or oldnorm <= resnorm:
+            break
+    return idx, val, iters

@@ -572,3 +572,19 @@ def test_block_append_falls_back_on_coherent_panels(cs, oracle, D):
     d2 = D(A2)
     cols2 = np.arange(0, 70, 2)
     np.testing.assert_allclose(d2.ctx.lstsq(cols2, b2), np.linalg.lstsq(A2[:, cols2], b2, rcond=None)[0], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 3, np.float64), (128, 512, 12, np.float32), (100, 333, 9, np.float64), (256, 2048, 40, np.float32)])
+def test_ompr_matches_oracle(cs, oracle, D, cfg):
+    """OMP with replacement (src/twostage.jl:110-202): same supports, coefficients and number of
+    update! calls as the oracle, noiseless and noisy; property of test/twostage.jl on the way."""
+    n, m, k, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m + 1, dtype=dtype)
+    d = D(A)
+    for y, delta in ((b, 1e-6), (cs.perturb(b, 5e-3, rng=2), 1e-2), (cs.perturb(b, 5e-2, rng=3), 1e-6)):
+        ref = oracle.ompr(A, y, k, delta)
+        got = d.ctx.ompr(y, k, delta)
+        assert got[2] == ref[2], ("update! calls", got[2], ref[2])
+        assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+    xo = cs.ompr(d, b, k, 1e-6)
+    assert np.array_equal(xo.nzind, oracle.ompr(A, b, k, 1e-6)[0])

@@ -183,3 +183,22 @@ def test_mp_warm_start(oracle, cs):
     i3, v3 = oracle.mp(A, b, 12)
     assert np.array_equal(i2, i3)
     np.testing.assert_allclose(v2, v3, rtol=1e-12, atol=1e-15)
+
+
+def test_reference_ompr_property_and_twin(oracle, cs):
+    # test/twostage.jl "OMP with replacement": ompr(A,b,k,1e-6) recovers the planted x; C vs numpy twin
+    ok = 0
+    for seed in range(30):
+        A, x, b = cs.gaussian_data(32, 64, 3, rng=7000 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        a, t = oracle.ompr(A, b, 3, 1e-6), on.ompr(A, b, 3, 1e-6)
+        assert np.array_equal(a[0], t[0]) and a[2] == t[2]
+        np.testing.assert_allclose(a[1], t[1], rtol=1e-9, atol=1e-12)
+        a2, t2 = oracle.ompr(A, y, 3, 1e-2), on.ompr(A, y, 3, 1e-2)
+        assert np.array_equal(a2[0], t2[0]) and a2[2] == t2[2]
+        ok += np.array_equal(a[0], x.nzind) and np.allclose(a[1], x.nzval, rtol=1.5e-8)
+    assert ok >= 26
+    A, x, b = cs.sparse_data(n=128, m=512, k=12, rng=5, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=6)
+    a, t = oracle.ompr(A, y, 12, 1e-6), on.ompr(A, y, 12, 1e-6)
+    assert np.array_equal(a[0], t[0]) and a[2] == t[2] and a[2] >= 2
