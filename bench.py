@@ -363,7 +363,7 @@ def main():
                          "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
             "atoms_selected": int(atoms),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
             try:
                 order0 = None
                 # selection order of signal W (first timed signal) for the parity cross-check

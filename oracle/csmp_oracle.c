@@ -527,7 +527,7 @@ int cso_ompr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const d
     double *cs = (double *)malloc((size_t)N * sizeof(double));
     int64_t *top = (int64_t *)malloc((size_t)k * sizeof(int64_t));
     /* oblivious_acquisition!(P, x, k): :190 */
-    cso_residual(A, dtype, M, ld, x.idx, x.val, 0, b, r);
+    memcpy(r, b, (size_t)M * sizeof(double)); /* residual of the empty x */
     cso_sweep_abs(A, dtype, M, N, ld, r, Ar, nthreads);
     cso_topk_desc(Ar, N, k, top);
     for (int64_t t = 0; t < k; ++t) sp_set(&x, top[t], NAN);
