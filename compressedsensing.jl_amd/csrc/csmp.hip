@@ -278,6 +278,7 @@ static hipError_t sweep_launch_t(csmp_ctx* ctx, int grid, size_t lds, const doub
     return hipGetLastError();
 }
 
+#ifdef CSMP_EXPERIMENTS  // kernel variants kept only for the tuning probes (tools/probe_sweep*.py, `make experiments`)
 template <typename TA, typename TACC>
 static hipError_t sweep_dispatch(csmp_ctx* ctx, int U, bool full, bool nt, int grid, size_t lds, const double* r,
                                  double eps, int check_eps, int skipmask) {
@@ -289,6 +290,8 @@ static hipError_t sweep_dispatch(csmp_ctx* ctx, int U, bool full, bool nt, int g
     return nt ? sweep_launch_t<TA, TACC, 1, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
               : sweep_launch_t<TA, TACC, 1, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
 }
+
+#endif
 
 // product configuration: one column per wave at a time (CPW = 1), U chunks = U KiB in flight per lane-row
 template <typename TA>
@@ -333,6 +336,7 @@ static int prof_mark(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
+#ifdef CSMP_EXPERIMENTS
 // one sweep with the product configuration (or an explicit experimental one)
 static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, int U, bool nt,
                             bool f32acc, int grid) {
@@ -358,6 +362,8 @@ static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int chec
     if (ctx->prof) CHECK(prof_mark(ctx));
     return CSMP_OK;
 }
+
+#endif
 
 static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
     const bool timed = prof_pick(ctx);
@@ -1640,6 +1646,7 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
 }
 
 // experimental column-per-wave variants (f32 dictionary, full chunks only): cpw in {1,2}, U in {4,8,16}
+#ifdef CSMP_EXPERIMENTS
 template <int U>
 static hipError_t sweep_launch_pf(csmp_ctx* ctx, int grid, const double* r) {
     auto kern = k_sweep_pf<float, U, true>;
@@ -1663,6 +1670,8 @@ static hipError_t sweep_launch_cpw(csmp_ctx* ctx, int cpw, int U, int grid, cons
     return hipErrorInvalidValue;
 }
 
+#endif
+
 // variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (0 = product configuration)
 // variant >= 1<<20: experimental: (variant>>20) = cpw, bits 0-7 = U, bits 8-15 = workgroups per CU
 extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
@@ -1680,6 +1689,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     CHECK(upload_b(ctx, r.data(), CSMP_F64));
     int U = ctx->sweep_U, grid = ctx->sweep_grid;
     bool nt = ctx->sweep_nt, f32acc = false;
+#ifdef CSMP_EXPERIMENTS
     const int cpwx = variant >> 20;
     if (cpwx) {
         if (ctx->dtype != CSMP_F32) return fail(ctx, CSMP_EINVAL, "bench_sweep: experimental variants are f32 only");
@@ -1705,6 +1715,10 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         if (avg_ms) *avg_ms = (double)ms / reps;
         return CSMP_OK;
     }
+#else
+    if (variant != 0) return fail(ctx, CSMP_ESTATE, "bench_sweep: experimental variants need a build with -DCSMP_EXPERIMENTS (make experiments)");
+#endif
+#ifdef CSMP_EXPERIMENTS
     if (variant != 0) {
         U = variant & 7;
         nt = (variant & 8) != 0;
@@ -1716,6 +1730,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         }
         if (U != 1 && U != 2 && U != 4) return fail(ctx, CSMP_EINVAL, "bench_sweep: U must be 1, 2 or 4");
     }
+#endif
     const bool was = ctx->prof;
     ctx->prof = false;
     if (variant == 0) {
@@ -1735,6 +1750,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         if (avg_ms) *avg_ms = (double)ms0 / reps;
         return CSMP_OK;
     }
+#ifdef CSMP_EXPERIMENTS
     for (int i = 0; i < 3; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0));
@@ -1750,4 +1766,8 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     ctx->prof = was;
     if (avg_ms) *avg_ms = (double)ms / reps;
     return CSMP_OK;
+#else
+    (void)U; (void)grid; (void)nt; (void)f32acc;
+    return CSMP_OK;
+#endif
 }

@@ -322,7 +322,86 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     // or the last (4th) candidate of a tile whose candidates were all kept (atoms hidden behind it).
     const float* cvs = cand_val + (int64_t)s * ncand;
     const int* cis = cand_idx + (int64_t)s * ncand;
-    float thr_v = 3.0e38f, cert_thr = -1.0f;
+    float cert_thr = -1.0f;
+    if (ncand <= 8 * 256) {
+        // fast path: the list lives in registers (<= 8 entries per lane).  Each wave extracts the 16 best
+        // of its quarter with wave-only shuffles (no workgroup barriers), then wave 0 merges the 4 x 16.
+        constexpr int EPL = 8;
+        const int Qn = (ncand + 3) / 4;  // entries per wave
+        float ev[EPL];
+        int ei[EPL], es[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int t = wave * Qn + lane + kWave * e;
+            const bool ok = (lane + kWave * e) < Qn && t < ncand;
+            ev[e] = ok ? cvs[t] : -1.0f;
+            ei[e] = ok ? cis[t] : 0x7fffffff;
+            es[e] = t & (kTileCand - 1);
+        }
+        float* wlv = rv;       // [4][16] per-wave lists (rv has 256 floats)
+        int* wli = ri;         // [4][16]
+        int* wls = ri + 64;    // [4][16]
+        for (int q = 0; q < kKeep; ++q) {
+            float bv = -1.0f;
+            int bi = 0x7fffffff, bs = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (ev[e] >= 0.0f && (ev[e] > bv || (ev[e] == bv && ei[e] < bi))) {
+                    bv = ev[e];
+                    bi = ei[e];
+                    bs = es[e];
+                }
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                const float ov = __shfl_xor(bv, sft, kWave);
+                const int oi = __shfl_xor(bi, sft, kWave);
+                const int os = __shfl_xor(bs, sft, kWave);
+                if (ov > bv || (ov == bv && oi < bi)) {
+                    bv = ov;
+                    bi = oi;
+                    bs = os;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < EPL; ++e)
+                if (ei[e] == bi) ev[e] = -1.0f;  // atoms are unique: exactly one owner retires it
+            if (lane == 0) {
+                wlv[wave * kKeep + q] = bv;
+                wli[wave * kKeep + q] = bi;
+                wls[wave * kKeep + q] = bs;
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float mv = wlv[lane];
+            int mi = wli[lane];
+            const int ms = wls[lane];
+            float thr = -1.0f;
+            for (int q = 0; q < kKeep; ++q) {
+                float bv = mv;
+                int bi = mi, bs = ms;
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    const float ov = __shfl_xor(bv, sft, kWave);
+                    const int oi = __shfl_xor(bi, sft, kWave);
+                    const int os = __shfl_xor(bs, sft, kWave);
+                    if (ov > bv || (ov == bv && oi < bi)) {
+                        bv = ov;
+                        bi = oi;
+                        bs = os;
+                    }
+                }
+                if (mi == bi) mv = -1.0f;
+                if (lane == 0) {
+                    cv[q] = bv;
+                    ci[q] = bi;
+                }
+                if (bv >= 0.0f && (bs == kTileCand - 1 || q == kKeep - 1)) thr = fmaxf(thr, bv);
+            }
+            if (lane == 0) sc[4] = (double)thr;
+        }
+        __syncthreads();
+        cert_thr = (float)sc[4];
+    } else {
+    float thr_v = 3.0e38f;
     int thr_i = -1;
     for (int q = 0; q < kKeep; ++q) {
         float bv = -1.0f;
@@ -371,6 +450,7 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
         if (bv >= 0.0f && (bslot == kTileCand - 1 || q == kKeep - 1)) cert_thr = fmaxf(cert_thr, bv);
         thr_v = bv;
         thr_i = bi;
+    }
     }
     __syncthreads();
 
@@ -467,29 +547,36 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
                 p[c] = reinterpret_cast<const VT*>(A + (int64_t)col * ld) + lane;
             }
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int t = 0; t < nchunk; ++t) {
-                VT a[4];
-                const int row = t * ROWS + lane * VEC;
+            for (int t0 = 0; t0 < nchunk; t0 += 4) {  // 4 chunks x 4 columns = 16 loads in flight per lane
+                VT a[4][4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    a[c] = (VT)0;
-                    if (row < Mv) a[c] = p[c][t * kWave];
-                }
-                if constexpr (VEC == 4) {
-                    const f64x2 r01 = as2[(t * 2 + 0) * kWave + lane], r23 = as2[(t * 2 + 1) * kWave + lane];
+                for (int u = 0; u < 4; ++u) {
+                    const int row = (t0 + u) * ROWS + lane * VEC;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        acc[c] = fma((double)a[c].x, r01.x, acc[c]);
-                        acc[c] = fma((double)a[c].y, r01.y, acc[c]);
-                        acc[c] = fma((double)a[c].z, r23.x, acc[c]);
-                        acc[c] = fma((double)a[c].w, r23.y, acc[c]);
+                        a[u][c] = (VT)0;
+                        if (t0 + u < nchunk && row < Mv) a[u][c] = p[c][(t0 + u) * kWave];
                     }
-                } else {
-                    const f64x2 r01 = as2[t * kWave + lane];
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        acc[c] = fma((double)a[c].x, r01.x, acc[c]);
-                        acc[c] = fma((double)a[c].y, r01.y, acc[c]);
+                for (int u = 0; u < 4; ++u) {
+                    const int t = (t0 + u < nchunk) ? t0 + u : 0;  // (padding chunks carry zeros)
+                    if constexpr (VEC == 4) {
+                        const f64x2 r01 = as2[(t * 2 + 0) * kWave + lane], r23 = as2[(t * 2 + 1) * kWave + lane];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[c] = fma((double)a[u][c].x, r01.x, acc[c]);
+                            acc[c] = fma((double)a[u][c].y, r01.y, acc[c]);
+                            acc[c] = fma((double)a[u][c].z, r23.x, acc[c]);
+                            acc[c] = fma((double)a[u][c].w, r23.y, acc[c]);
+                        }
+                    } else {
+                        const f64x2 r01 = as2[t * kWave + lane];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            acc[c] = fma((double)a[u][c].x, r01.x, acc[c]);
+                            acc[c] = fma((double)a[u][c].y, r01.y, acc[c]);
+                        }
                     }
                 }
             }
@@ -509,8 +596,20 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     double* Ttw = Tt_all + (int64_t)s * kcap * kcap;
     double w2 = 0.0;
     for (int i = tid; i < j; i += 256) {
-        double acc = 0.0;
-        for (int t = 0; t <= i; ++t) acc = fma(Tt[i + (int64_t)t * kcap], gv[t], acc);
+        double acc = 0.0, acc1 = 0.0;
+        int t = 0;
+        for (; t + 8 <= i + 1; t += 8) {
+            double tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tv[u] = Tt[i + (int64_t)(t + u) * kcap];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc = fma(tv[u], gv[t + u], acc);
+                acc1 = fma(tv[u + 1], gv[t + u + 1], acc1);
+            }
+        }
+        for (; t <= i; ++t) acc = fma(Tt[i + (int64_t)t * kcap], gv[t], acc);
+        acc += acc1;
         wv[i] = acc;
         w2 = fma(acc, acc, w2);
     }
@@ -528,9 +627,20 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     const double rho = sqrt(rho2);
     // ---- y = T w (y_t = sum_{i>=t} T[t,i] w_i): thread t walks row t of T (column-major: coalesced)
     for (int t = tid; t < j; t += 256) {
-        double acc = 0.0;
-        for (int i = t; i < j; ++i) acc = fma(T[t + (int64_t)i * kcap], wv[i], acc);
-        yv[t] = acc;
+        double acc = 0.0, acc1 = 0.0;
+        int i = t;
+        for (; i + 8 <= j; i += 8) {
+            double tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tv[u] = T[t + (int64_t)(i + u) * kcap];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc = fma(tv[u], wv[i + u], acc);
+                acc1 = fma(tv[u + 1], wv[i + u + 1], acc1);
+            }
+        }
+        for (; i < j; ++i) acc = fma(T[t + (int64_t)i * kcap], wv[i], acc);
+        yv[t] = acc + acc1;
     }
     __syncthreads();
 

@@ -1,4 +1,5 @@
-"""GPU probe: sweep-kernel variants at BASELINE config 2 (and 5) shapes -> GB/s per variant.
+"""(needs the experimental kernel variants: `make -C compressedsensing.jl_amd/csrc experiments`)
+GPU probe: sweep-kernel variants at BASELINE config 2 (and 5) shapes -> GB/s per variant.
 variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (csmp_bench_sweep)."""
 import os
 import sys

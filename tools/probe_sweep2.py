@@ -1,4 +1,5 @@
-"""GPU probe 2: column-per-wave variants of the sweep (experimental, via csmp_bench_sweep)."""
+"""(needs the experimental kernel variants: `make -C compressedsensing.jl_amd/csrc experiments`)
+GPU probe 2: column-per-wave variants of the sweep (experimental, via csmp_bench_sweep)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,4 +1,5 @@
-"""GPU probe 3: solo sweep (cpw=1, U=16) vs workgroups per CU, incl. 1."""
+"""(needs the experimental kernel variants: `make -C compressedsensing.jl_amd/csrc experiments`)
+GPU probe 3: solo sweep (cpw=1, U=16) vs workgroups per CU, incl. 1."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,3 +1,4 @@
+# needs the experimental kernel variants: make -C compressedsensing.jl_amd/csrc experiments
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
