@@ -120,15 +120,19 @@ __global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab,
         srow[i] = p >> 3;
         skc[i] = p & 7;
     }
-    bf16x8 ra[4], rr[4];
-    auto gload = [&](int kb) {
+    // Two register sets: the tile for k-step kb+1 is written to LDS while the loads for kb+2 and kb+3 are
+    // already in flight, so a global load has two full MFMA phases (and a barrier) to land.
+    bf16x8 ra0[4], rr0[4], ra1[4], rr1[4];
+    const int nkb = Mk / kBK;
+    auto gload = [&](bf16x8 (&ra)[4], bf16x8 (&rr)[4], int kb) {
+        if (kb >= nkb) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             ra[i] = *reinterpret_cast<const bf16x8*>(gA + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
             rr[i] = *reinterpret_cast<const bf16x8*>(gR + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
         }
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](const bf16x8 (&ra)[4], const bf16x8 (&rr)[4], int buf) {
         char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow;
         char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow;
 #pragma unroll
@@ -137,13 +141,7 @@ __global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab,
             *reinterpret_cast<bf16x8*>(lr + srow[i] * kBRow + skc[i] * 16) = rr[i];
         }
     };
-    const int nkb = Mk / kBK;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
-        const int buf = kb & 1;
-        if (kb + 1 < nkb) gload(kb + 1);
+    auto compute = [&](int buf) {
         const char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow + (wr * 64 + r) * kBRow + h * 16;
         const char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow + (wc * 64 + r) * kBRow + h * 16;
 #pragma unroll
@@ -157,8 +155,23 @@ __global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab,
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (kb + 1 < nkb) lstore(buf ^ 1);
+    };
+    gload(ra0, rr0, 0);
+    lstore(ra0, rr0, 0);
+    gload(ra0, rr0, 1);
+    gload(ra1, rr1, 2);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; kb += 2) {
+        compute(0);                                   // tile kb
+        if (kb + 1 < nkb) lstore(ra0, rr0, 1);        // tile kb+1
+        gload(ra0, rr0, kb + 3);
         __syncthreads();
+        if (kb + 1 < nkb) {
+            compute(1);                               // tile kb+1
+            if (kb + 2 < nkb) lstore(ra1, rr1, 0);    // tile kb+2
+            gload(ra1, rr1, kb + 4);
+            __syncthreads();
+        }
     }
 
     // epilogue: the 4 largest |c| per signal over this tile's 128 atoms
