@@ -588,3 +588,32 @@ def test_ompr_matches_oracle(cs, oracle, D, cfg):
         assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
     xo = cs.ompr(d, b, k, 1e-6)
     assert np.array_equal(xo.nzind, oracle.ompr(A, b, k, 1e-6)[0])
+
+
+def test_near_tie_below_f32_resolution_is_resolved_in_f64(cs, oracle, D):
+    """Two atoms whose correlations with r differ by ~1e-9 relative -- far below what an f32 (or
+    bf16) accumulation can resolve -- with the LARGER one at the HIGHER index, so that a low-precision
+    tie would be broken the wrong way (lowest index).  The Float64 sweep, and the batched path's
+    Float64 rescoring of the bf16-screened candidates, must both pick the oracle's atom."""
+    rng = np.random.default_rng(123)
+    M, N = 512, 3000
+    A = rng.standard_normal((M, N)).astype(np.float32)
+    A /= np.linalg.norm(A, axis=0).astype(np.float32)
+    lo, hi = 700, 2100
+    A[:, hi] = A[:, lo]
+    r = rng.standard_normal(M) + 40.0 * A[:, lo].astype(np.float64)  # makes both copies the clear arg-max pair
+    m = int(np.argmax(np.abs(r) * np.abs(A[:, lo])))  # a row where a one-ulp nudge is felt
+    c_lo = float(A[:, lo].astype(np.float64) @ r)
+    A[m, hi] = np.nextafter(A[m, hi], np.float32(np.inf if c_lo * r[m] > 0 else -np.inf))  # grows |<a_hi, r>|
+    A = np.asfortranarray(A)
+    c = A.astype(np.float64).T @ r
+    assert abs(c[hi]) > abs(c[lo]) and (abs(c[hi]) - abs(c[lo])) / abs(c[hi]) < 1e-7
+    d = D(A)
+    out, ti, tv = d.ctx.sweep(r, 2)
+    assert ti.tolist() == [hi, lo]
+    ref = oracle.omp(A, r, 3, 0.0)
+    got = d.ctx.omp(r, 3, 0.0)
+    assert got[2][0] == hi == ref[2][0] and np.array_equal(got[2], ref[2]) and close(got[1], ref[1])
+    idx, val, nnz = d.ctx.omp_batch_mfma(np.asfortranarray(np.stack([r, 0.5 * r], axis=1)), 3, 0.0)
+    assert np.array_equal(np.sort(idx[:, 0]), ref[0]) and np.array_equal(np.sort(idx[:, 1]), ref[0])
+    assert close(val[:, 0], ref[1])
