@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
 OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
-ALGO_MP, ALGO_OMP, ALGO_GOMP = 0, 1, 2
+ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
 
 i64 = C.c_int64
@@ -35,6 +35,8 @@ SIGNATURES = {
     "csmp_omp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_gomp": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_sp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_fr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, C.c_double, vp, vp, C.POINTER(i64), vp]),
+    "csmp_fr_scores": (C.c_int, [vp, vp]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
@@ -226,6 +228,23 @@ class Context:
                   ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), iters.value
+
+    def fr(self, b, k, max_eps=0.0, min_delta=0.0):
+        b = self._b(b)
+        cap = max(int(k), 1)
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        order = np.zeros(cap, np.int64)
+        nnz = i64(0)
+        self.call("csmp_fr", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(max_eps), C.c_double(min_delta),
+                  ptr(idx), ptr(val), C.byref(nnz), ptr(order))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), order[:n].copy()
+
+    def fr_scores(self):
+        d2 = np.zeros(self.N, np.float64)
+        self.call("csmp_fr_scores", ptr(d2))
+        return d2
 
     def omp_batch(self, B, k, eps):
         """Host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz) numpy arrays."""

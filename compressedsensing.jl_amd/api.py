@@ -6,6 +6,9 @@ Same names, argument meaning and error behaviour as the reference (paths relativ
     omp(A, b, k) / omp(A, b, eps, k) / omp(A, b; max_residual, sparsity)   :73-91
     gomp(A, b, l, k) / gomp(A, b, l, eps, k) / gomp(A, b, l; ...)          :126-148
     sp(A, b, k, delta=1e-12; maxiter=16k)    src/twostage.jl:87-101
+    fr(A, b, max_eps, min_delta, k) / fr(A, b; max_residual, min_decrease, sparsity) = ols = oomp = ormp
+                                             src/forward.jl:34-54
+    FR functor with update!                  src/forward.jl:88-95
     MP / OMP / GOMP functors with update!    src/matchingpursuit.jl:10-31,44-70,95-123
     argmaxinner!(P[, k])                     src/matchingpursuit.jl:181-193
 
@@ -157,6 +160,31 @@ def ompr(A, b, k, delta, maxiter=None):
             D.close()
 
 
+def fr(A, b, *args, max_residual=0.0, min_decrease=0.0, sparsity=None):
+    """fr(A,b,max_eps,min_delta,k=size(A,1)) and fr(A,b; max_residual=0, min_decrease=0, sparsity=size(A,2)):
+    forward regression / orthogonal least squares (src/forward.jl:34-54), x starting empty."""
+    M, N, _ = _meta(A)
+    if len(args) == 0:  # keyword form :34-37
+        max_eps, min_delta, k = max_residual, min_decrease, (N if sparsity is None else sparsity)
+    elif len(args) in (2, 3):
+        max_eps, min_delta = args[0], args[1]
+        k = args[2] if len(args) == 3 else M  # :45
+    else:
+        raise TypeError("fr(A, b, max_eps, min_delta[, k]) or fr(A, b; max_residual, min_decrease, sparsity)")
+    if np.shape(b)[0] != M:  # FR(A, b): DimensionMismatch (:22)
+        raise ValueError(f"DimensionMismatch: size(A, 1) = {M} != {np.shape(b)[0]} = length(b)")
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.fr(b, min(int(k), M), float(max_eps), float(min_delta))
+        return SparseVector(N, idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+ols = oomp = ormp = fr  # src/forward.jl:52-54
+
+
 def omp_batch(A, B, k, eps=None):
     """[omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU; returns a list of SparseVectors."""
     eps = _meta(A)[2] if eps is None else eps
@@ -253,6 +281,31 @@ class GOMP(_DevicePursuit):
             raise ValueError("update!(P::GOMP, x): x is not the support this GOMP object's QR was built for")
         self.D.ctx.solver_step(self.l if l is None else int(l))
         return self._sync_x(x)
+
+
+class FR(_DevicePursuit):
+    """FR(A, b) (= OLS = OOMP = ORMP = StepwiseRegression, src/forward.jl:14-19); update!(P, x): :88-95.
+    `delta2` is P.δ² of the last step (:11)."""
+    ALGO = _lib.ALGO_FR
+
+    def __init__(self, A, b, k=None):
+        M = A.shape[0]
+        if np.shape(b)[0] != M:
+            raise ValueError(f"DimensionMismatch: size(A, 1) = {M} != {np.shape(b)[0]} = length(b)")
+        super().__init__(A, b, M if k is None else min(int(k), M))
+
+    def update_(self, x=None):
+        if not self._same(x):
+            raise ValueError("update!(P::FR, x): x is not the support this FR object's QR was built for")
+        self.D.ctx.solver_step(1)
+        return self._sync_x(x)
+
+    @property
+    def delta2(self):
+        return self.D.ctx.fr_scores()
+
+
+OLS = OOMP = ORMP = StepwiseRegression = FR
 
 
 class MP(_DevicePursuit):

@@ -6,6 +6,7 @@
 #include "csmp_kernels.hpp"
 #include "csmp_batched.hpp"
 #include "csmp_block.hpp"
+#include "csmp_forward.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -47,6 +48,8 @@ struct Solver {
     int* pan_atoms = nullptr;
     int blk_kcap = 0;
     int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
+    double *rho2 = nullptr, *dvec = nullptr;  // forward regression: OLS rescaling and δ² scores (N each), allocated on first use
+    int fr_grid = 0;
     int sigcap = 0;
 };
 
@@ -210,6 +213,7 @@ static void solver_free(Solver& s) {
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
+    dfree(s.rho2); dfree(s.dvec);
     s = Solver();
 }
 
@@ -549,7 +553,7 @@ static int launch_select(csmp_ctx* ctx, int mode, int skipmask) {
 // One atom through the append chain.  mode 1: atom = arg-max of the last sweep + OMP guards
 // (src/matchingpursuit.jl:63,65-66); mode 2: atom = cands[which] + GOMP's duplicate skip
 // (src/util.jl:119,129-134).  Then add_column!(AiQR, A[:, atom]) and the residual update.
-static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool optimistic = false) {
+static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool optimistic = false, double min_d2 = 0.0, int nblk_sweep = 0) {
     Solver& s = ctx->s;
     const size_t lds = qr_lds_bytes(s.kcap);
     const int jh = std::min(s.jh, s.kcap);
@@ -562,13 +566,13 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
     if (ctx->dtype == CSMP_F32)
         hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)ctx->dA, ctx->ld,
                            (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
-                           (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
-                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh);
+                           (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2);
     else
         hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)ctx->dA, ctx->ld,
                            (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
-                           (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid, (const int*)s.cands,
-                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh);
+                           (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
+                           (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
                        (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
@@ -734,6 +738,112 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         const bool optimistic = pass == 0 && !ctx->force_reorth;
         CHECK(upload_b(ctx, b, b_dtype));
         for (int64_t t = 0; t < k; ++t) CHECK(omp_step(ctx, eps, t > 0, optimistic));
+        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) break;
+    }
+    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+}
+
+// ------------------------------------------------------------------------------------------ forward regression (OLS)
+template <typename TA, int U, bool FULL>
+static hipError_t fr_sweep_launch_t(csmp_ctx* ctx, bool first, int grid, size_t lds, double max_eps, int skipmask) {
+    Solver& s = ctx->s;
+    auto k1 = k_fr_sweep<TA, U, FULL, true>;
+    auto k0 = k_fr_sweep<TA, U, FULL, false>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)(first ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(first ? k1 : k0, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                       ctx->N, (const double*)s.r, (const double*)s.Q, s.ldq, s.rho2, s.dvec, s.pval, s.pidx, (const int*)s.sel,
+                       s.st, max_eps, skipmask);
+    return hipGetLastError();
+}
+
+// block size of the forward-regression sweep: the largest of 16/8/4 chunks that tiles M exactly, else
+// the predicated 4-chunk kernel
+static void fr_config(const csmp_ctx* ctx, int& U, bool& full, size_t& lds, int& grid) {
+    const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
+    const int rows = kWave * vec;
+    U = 4;
+    full = false;
+    if (ctx->Mv % rows == 0) {
+        const int nchunk = ctx->Mv / rows;
+        for (int u : {16, 8, 4})
+            if (nchunk % u == 0) {
+                U = u;
+                full = true;
+                break;
+            }
+    }
+    lds = fr_sweep_lds_bytes(ctx->Mv, vec, U);
+    const int cus = ctx->prop.multiProcessorCount;
+    int64_t g = U == 16 ? (int64_t)cus * 3 / 4 : (int64_t)cus;  // as the OMP sweep (configure_sweep)
+    if (const char* sn = getenv("CSMP_FR_NBLK")) g = std::max(1, atoi(sn));  // tuning knob
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
+    grid = (int)std::max<int64_t>(1, std::min<int64_t>(g, groups));
+}
+
+static int fr_ensure(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    int U; bool full; size_t lds;
+    fr_config(ctx, U, full, lds, s.fr_grid);
+    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "fr: M too large (r and q must both fit the 160 KiB LDS)");
+    if (!s.rho2) CHECK(dmalloc(ctx, &s.rho2, (size_t)ctx->N));
+    if (!s.dvec) CHECK(dmalloc(ctx, &s.dvec, (size_t)ctx->N));
+    return CSMP_OK;
+}
+
+// forward_δ! + the residual-norm guard of forward_step! (src/forward.jl:59-61,75-82)
+static int launch_fr_sweep(csmp_ctx* ctx, bool first, double max_eps, int skipmask) {
+    int U, grid; bool full; size_t lds;
+    fr_config(ctx, U, full, lds, grid);
+    const bool timed = prof_pick(ctx);
+    if (timed) CHECK(prof_mark(ctx));
+    hipError_t e;
+    if (ctx->dtype == CSMP_F32) {
+        if (!full) e = fr_sweep_launch_t<float, 4, false>(ctx, first, grid, lds, max_eps, skipmask);
+        else if (U == 16) e = fr_sweep_launch_t<float, 16, true>(ctx, first, grid, lds, max_eps, skipmask);
+        else if (U == 8) e = fr_sweep_launch_t<float, 8, true>(ctx, first, grid, lds, max_eps, skipmask);
+        else e = fr_sweep_launch_t<float, 4, true>(ctx, first, grid, lds, max_eps, skipmask);
+    } else {
+        if (!full) e = fr_sweep_launch_t<double, 4, false>(ctx, first, grid, lds, max_eps, skipmask);
+        else if (U == 16) e = fr_sweep_launch_t<double, 16, true>(ctx, first, grid, lds, max_eps, skipmask);
+        else if (U == 8) e = fr_sweep_launch_t<double, 8, true>(ctx, first, grid, lds, max_eps, skipmask);
+        else e = fr_sweep_launch_t<double, 4, true>(ctx, first, grid, lds, max_eps, skipmask);
+    }
+    HIPCHECK(e);
+    if (timed) CHECK(prof_mark(ctx));
+    return CSMP_OK;
+}
+
+// forward_step!(P, x, max_ε, min_δ): src/forward.jl:56-73
+static int fr_step(csmp_ctx* ctx, bool first, double max_eps, double min_d2, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    CHECK(launch_fr_sweep(ctx, first, max_eps, skip));
+    return launch_append(ctx, 3, 0, skip, optimistic, min_d2, ctx->s.fr_grid);
+}
+
+// fr(A, b, max_ε, min_δ, k) = ols = oomp = ormp, x starting empty: src/forward.jl:44-54
+extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t* idx,
+                       double* val, int64_t* nnz, int64_t* order) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 0) return fail(ctx, CSMP_EINVAL, "fr: b == NULL or k < 0");
+    if (max_eps != max_eps || min_delta != min_delta) return fail(ctx, CSMP_EINVAL, "fr: max_eps / min_delta is NaN");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k, 1)));
+    CHECK(fr_ensure(ctx));
+    ctx->s.begun = false;
+    const double min_d2 = min_delta * min_delta;  // :64
+    for (int pass = 0; pass < 2; ++pass) {  // optimistic append chain, repeated with re-orthogonalisation if flagged (see csmp_omp)
+        const bool optimistic = pass == 0 && !ctx->force_reorth;
+        CHECK(upload_b(ctx, b, b_dtype));
+        for (int64_t t = 0; t < k; ++t) CHECK(fr_step(ctx, t == 0, max_eps, min_d2, optimistic));
         CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -927,11 +1037,12 @@ extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_d
                                  const double* val0, int64_t nnz0) {
     if (!ctx) return CSMP_EINVAL;
     if (!b || kcap < 1) return fail(ctx, CSMP_EINVAL, "solver_begin: bad arguments");
-    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP) return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
+    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP && algo != CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = algo == CSMP_ALGO_MP ? (int)kcap : (int)std::min<int64_t>(kcap, ctx->M);
     CHECK(solver_ensure(ctx, kc, kc));
+    if (algo == CSMP_ALGO_FR) CHECK(fr_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
     if (nnz0 > 0) {
         if (algo != CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "warm start is only defined for MP (src/matchingpursuit.jl:34)");
@@ -955,8 +1066,23 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
             CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
             return launch_append(ctx, 1, 0, STOP_FULL);
         }
+        case CSMP_ALGO_FR: {
+            // update!(P::FR, x): nnz < n guard, acquisition_index! = argmax δ², addindex!, solve (src/forward.jl:88-95)
+            const int skip = STOP_FULL | STOP_STAG;  // (a step that found no finite score would otherwise downdate rho2 twice)
+            CHECK(launch_fr_sweep(ctx, ctx->s.jh == 0, -HUGE_VAL, skip));
+            return launch_append(ctx, 3, 0, skip, false, -1.0, ctx->s.fr_grid);
+        }
         default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
+}
+
+extern "C" int csmp_fr_scores(csmp_ctx* ctx, double* delta2) {
+    if (!ctx || !delta2) return CSMP_EINVAL;
+    if (!ctx->s.dvec) return fail(ctx, CSMP_ESTATE, "fr_scores: no forward-regression step has run");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipMemcpyAsync(delta2, ctx->s.dvec, (size_t)ctx->N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
 }
 
 extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64_t* nnz, double* resnorm, int64_t* order,

@@ -1,0 +1,185 @@
+// csmp_forward.hpp -- forward regression / orthogonal least squares (fr = ols = oomp = ormp) on gfx950.
+//
+// Reference primitives replaced (paths relative to the reference repository):
+//   k_fr_sweep   forward_δ!(P, x):   mul!(δ², A', r); ols_rescaling!; δ² = δ²^2 / rescaling;
+//                δ²[x.nzind] = 0                                   src/forward.jl:75-82
+//                ols_rescaling!:  mul!(QA, Q', A); rescaling_j = |a_j|^2 - |(Q'A)[1:nnz, j]|^2
+//                                                                  src/forward.jl:99-114
+//                + norm(residual!) > max_ε                         src/forward.jl:59-61
+//   (k_qr1 mode 3) findmax(δ²), min_δ^2 < max_δ² guard, addindex!   src/forward.jl:63-68
+//
+// The reference forms Q'A -- an (M x M) x (M x N) product, 2.2e12 flop at 4096 x 65536 -- at every
+// step.  |Q_S' a_j|^2 = sum_i (q_i' a_j)^2 runs over the columns of ANY orthonormal basis of
+// span(A_S), and this library's Q only ever grows by one column per step (csmp_kernels.hpp, k_qr2),
+// so the same sum is evaluated one term per step: the sweep that streams the dictionary for
+// c = A'r also forms g = A'q_new in the same pass and downdates rho2_j -= g_j^2.  A forward-regression
+// step therefore costs exactly what an OMP step costs in HBM traffic: M*N*sizeof(T) bytes.
+//
+// Numerics as everywhere else: Float64 products of the exactly promoted dictionary, fixed summation
+// order (no atomics), so equal columns score bit-identically and the first maximum is well defined.
+#pragma once
+#include "csmp_kernels.hpp"
+
+namespace csmp {
+
+// One column per wave at a time, software-pipelined across columns like sweep_body_pf.
+//   U      16-byte row chunks per load block (U KiB in flight per wave, U..2U while a block is reduced)
+//   FULL   Mv is a multiple of U*64*VEC rows; otherwise the tail chunks are predicated
+//   FIRST  first step of a solve: no Q column yet; the second accumulator forms |a_j|^2 instead
+//          (sum!(abs2, rescaling', A), src/forward.jl:108) and initialises rho2
+// dynamic LDS: r image | q image (each nblocks*U*64*VEC doubles) | 32 doubles of reduction scratch
+template <typename TA, int U, bool FULL, bool FIRST>
+__global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    const double* __restrict__ Q, int64_t ldq, double* __restrict__ rho2, double* __restrict__ dvec,
+    double* __restrict__ pval, int* __restrict__ pidx, const int* __restrict__ sel, DevState* st,
+    double max_eps, int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    constexpr int NW = kSweepThreads / kWave;
+    if (st->done & skipmask) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = blockIdx.x, nblk = gridDim.x;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int nblocks = (nchunk + U - 1) / U;
+    const int Mlds = nblocks * U * ROWS;
+    double* qim = lds + Mlds;
+    double* red = qim + Mlds;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+
+    const int nsel = st->nsel;
+    const int lastsel = (!FIRST && nsel > 0) ? sel[nsel - 1] : -1;
+    const double* qcol = (!FIRST && nsel > 0) ? Q + (int64_t)(nsel - 1) * ldq : nullptr;
+    double n2 = 0.0;
+    for (int m = tid; m < Mlds; m += kSweepThreads) {
+        const double v = (m < Mv) ? r[m] : 0.0;
+        lds[r_slot<VEC>(m)] = v;
+        n2 = fma(v, v, n2);
+        if constexpr (!FIRST) qim[r_slot<VEC>(m)] = (qcol && m < Mv) ? qcol[m] : 0.0;
+    }
+    n2 = block_sum256(n2, red);
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
+    if (!(sqrt(n2) > max_eps)) {  // normr > max_ε || return false   (src/forward.jl:60-61)
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    const f64x2* qs = reinterpret_cast<const f64x2*>(qim);
+    double bestv = -1.0;  // a NaN score never wins a comparison
+    int besti = 0x7fffffff;
+    const int64_t stride = (int64_t)nblk * NW;
+    auto load_block = [&](VT* dst, int64_t c, int blk) {
+        const VT* p = reinterpret_cast<const VT*>(A + c * ld) + lane + (int64_t)blk * U * kWave;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if constexpr (FULL) {
+                dst[u] = __builtin_nontemporal_load(p + u * kWave);
+            } else {
+                dst[u] = (VT)0;
+                if ((blk * U + u) * ROWS + lane * VEC < Mv) dst[u] = __builtin_nontemporal_load(p + u * kWave);
+            }
+        }
+    };
+    int64_t col = (int64_t)bid * NW + wave;
+    if (col >= N) col = -1;
+    VT cur[U], nxt[U];
+    if (col >= 0) load_block(cur, col, 0);
+    while (col >= 0) {
+        double rho_old = 0.0;
+        if constexpr (!FIRST) rho_old = rho2[col];  // requested before the column's loads are consumed
+        double acc = 0.0, acg = 0.0;
+        for (int blk = 0; blk < nblocks; ++blk) {
+            const bool last = blk + 1 == nblocks;
+            const int64_t ncol = last ? col + stride : col;
+            if (!last || ncol < N) load_block(nxt, ncol, last ? 0 : blk + 1);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = blk * U + u;
+                if constexpr (VEC == 4) {
+                    const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                    const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                    const double a0 = (double)cur[u].x, a1 = (double)cur[u].y, a2 = (double)cur[u].z, a3 = (double)cur[u].w;
+                    acc = fma(a0, r01.x, acc);
+                    acc = fma(a1, r01.y, acc);
+                    acc = fma(a2, r23.x, acc);
+                    acc = fma(a3, r23.y, acc);
+                    if constexpr (FIRST) {
+                        acg = fma(a0, a0, acg);
+                        acg = fma(a1, a1, acg);
+                        acg = fma(a2, a2, acg);
+                        acg = fma(a3, a3, acg);
+                    } else {
+                        const f64x2 q01 = qs[(t * 2 + 0) * kWave + lane];
+                        const f64x2 q23 = qs[(t * 2 + 1) * kWave + lane];
+                        acg = fma(a0, q01.x, acg);
+                        acg = fma(a1, q01.y, acg);
+                        acg = fma(a2, q23.x, acg);
+                        acg = fma(a3, q23.y, acg);
+                    }
+                } else {
+                    const f64x2 r01 = rs[t * kWave + lane];
+                    const double a0 = (double)cur[u].x, a1 = (double)cur[u].y;
+                    acc = fma(a0, r01.x, acc);
+                    acc = fma(a1, r01.y, acc);
+                    if constexpr (FIRST) {
+                        acg = fma(a0, a0, acg);
+                        acg = fma(a1, a1, acg);
+                    } else {
+                        const f64x2 q01 = qs[t * kWave + lane];
+                        acg = fma(a0, q01.x, acg);
+                        acg = fma(a1, q01.y, acg);
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            acc += shx(acc, sft);
+            acg += shx(acg, sft);
+        }
+        // rescaling_j (src/forward.jl:108-113), one more row of Q'A per step; atoms of the support get
+        // +Inf once, which makes their score c^2 / Inf = 0 for good (δ²[x.nzind] = 0, :80)
+        double rho = FIRST ? acg : fma(-acg, acg, rho_old);
+        if ((int)col == lastsel) rho = __builtin_inf();
+        const double d2 = acc * acc / rho;
+        if (lane == 0) {
+            rho2[col] = rho;
+            dvec[col] = d2;
+        }
+        if (d2 > bestv) {
+            bestv = d2;
+            besti = (int)col;
+        }
+        col += stride;
+        if (col >= N) col = -1;
+    }
+    if ((lane & 15) == 0) {
+        redv[wave * 4 + (lane >> 4)] = bestv;
+        redi[wave * 4 + (lane >> 4)] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int q = 1; q < 4 * NW; ++q)
+            if (better(redv[q], redi[q], bv, bi)) {
+                bv = redv[q];
+                bi = redi[q];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+
+inline size_t fr_sweep_lds_bytes(int Mv, int vec, int U) {
+    const int rows = kWave * vec;
+    const int nchunk = (Mv + rows - 1) / rows;
+    const int nblocks = (nchunk + U - 1) / U;
+    return ((size_t)2 * nblocks * U * rows + 8 + 16 + 8) * sizeof(double);
+}
+
+}  // namespace csmp

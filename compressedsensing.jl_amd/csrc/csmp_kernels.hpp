@@ -908,6 +908,8 @@ inline size_t qr_lds_bytes(int kcap) {
 //   "i not in x.nzind" (:66) -- a failed guard makes every later update! the same no-op: done.
 // mode 2 (GOMP): atom = cands[which] (the l best of the sweep, src/util.jl:129-134), skipped if
 //   already in the support (util.jl:119); only a full support stops anything (:117).
+// mode 3 (forward regression): atom = arg-max of the δ² scores of k_fr_sweep (findmax, src/forward.jl:63);
+//   the step fails -- and fr stops -- unless min_δ^2 < max δ² (:64); nnz < n guard (:58).
 // Every workgroup derives the same decision from the same device data; workgroup 0 publishes it
 // (cand, j, go) for k_qr2 / k_qr3, which no workgroup of THIS launch reads.
 template <typename TA, int W>
@@ -918,7 +920,8 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
                                                     const int* __restrict__ pidx, int nblk,
                                                     const int* __restrict__ cands, const int* __restrict__ ncands,
                                                     int which, const int* __restrict__ sel, int skipmask,
-                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh, const int g, double* lds) {
+                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh, const int g, double* lds,
+                                                    const double min_d2 = 0.0) {
     double *part, *ws, *xs, *tmp, *sc;
     qr_carve(lds, jpad, part, ws, xs, tmp, sc);
     const int tid = threadIdx.x;
@@ -930,7 +933,8 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
     }
     const int nsel = st->nsel;
     int cand;
-    if (mode == 1) {
+    bool low = false;  // mode 3: the best score does not exceed min_δ^2
+    if (mode == 1 || mode == 3) {
         double bv = -1.0;
         int bi = 0x7fffffff;
         for (int q = tid; q < nblk; q += kQrThreads)
@@ -940,6 +944,7 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
             }
         block_argmax(bv, bi, tmp, reinterpret_cast<int*>(tmp + kQrThreads));
         cand = bi;
+        low = mode == 3 && !(min_d2 < bv);
     } else {
         cand = (which < *ncands) ? cands[which] : -1;
     }
@@ -947,14 +952,14 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
     for (int q = tid; q < nsel; q += kQrThreads) found |= (sel[q] == cand);
     found = __syncthreads_or(found);
     const bool full = nsel >= M || nsel >= kcap;
-    const bool go = cand >= 0 && !found && !full;
+    const bool go = cand >= 0 && cand < 0x7fffffff && !found && !full && !low;
     if (g == 0 && tid == 0) {
         st->cand = cand;
         st->j = nsel;
         st->go = go ? 1 : 0;
         if (full)
             st->done |= STOP_FULL;
-        else if (mode == 1 && found)
+        else if ((mode == 1 || mode == 3) && (found || low || cand == 0x7fffffff))
             st->done |= STOP_STAG;
     }
     if (!go) return;
@@ -985,9 +990,10 @@ __global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, in
                                                     const int* __restrict__ pidx, int nblk,
                                                     const int* __restrict__ cands, const int* __restrict__ ncands,
                                                     int which, const int* __restrict__ sel, int skipmask,
-                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh) {
+                                                    const double* __restrict__ r, double* __restrict__ P1s, int jh,
+                                                    double min_d2) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    qr1_body<TA, 4>(A, ld, M, Q, ldq, st, avec, P1, G, kcap, jpad, mode, pval, pidx, nblk, cands, ncands, which, sel, skipmask, r, P1s, jh, (int)blockIdx.x, lds);
+    qr1_body<TA, 4>(A, ld, M, Q, ldq, st, avec, P1, G, kcap, jpad, mode, pval, pidx, nblk, cands, ncands, which, sel, skipmask, r, P1s, jh, (int)blockIdx.x, lds, min_d2);
 }
 
 // Publishes the new column (shared by the accept path of k_qr2 and by k_qr3).

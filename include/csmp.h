@@ -45,6 +45,7 @@ extern "C" {
 #define CSMP_ALGO_MP 0
 #define CSMP_ALGO_OMP 1
 #define CSMP_ALGO_GOMP 2
+#define CSMP_ALGO_FR 3 /* update!(P::FR, x): src/forward.jl:88-95 */
 
 /* why a solve stopped early (csmp_solver_state: *stop) */
 #define CSMP_STOP_NONE 0
@@ -101,6 +102,17 @@ int csmp_sp(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, 
 int csmp_ompr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t *idx,
               double *val, int64_t *nnz, int64_t *iters);
 
+/* fr(A,b,max_eps,min_delta,k) = ols = oomp = ormp: forward regression / orthogonal least squares,
+ * src/forward.jl:44-54 (forward_step! :56-73, forward_δ! :75-82, ols_rescaling! :99-114), with x
+ * starting empty.  Each step adds the atom maximising <a_j,r>^2 / (|a_j|^2 - |Q_S' a_j|^2); stops
+ * when norm(r) <= max_eps, when the best score does not exceed min_delta^2, or at k atoms / nnz = M.
+ * Capacity k.  Requires 16*M bytes of LDS (M <= ~10000). */
+int csmp_fr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t *idx,
+            double *val, int64_t *nnz, int64_t *order);
+/* P.δ² of the most recent forward-regression step (src/forward.jl:11,75-82; foba reads its maximum,
+ * src/stepwise.jl:52): delta2 receives N Float64 scores (host). */
+int csmp_fr_scores(csmp_ctx *ctx, double *delta2);
+
 /* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);
@@ -126,8 +138,8 @@ int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly,
                      int64_t *screen_launches, double *screen_ms);
 
 /* ------------------------------------------------------------------ step-level API
- * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) then update!(P,x)
- * (src/CompressedSensing.jl:22-23; src/matchingpursuit.jl:26,62,116).  The solver state
+ * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) / FR(A,b) then update!(P,x)
+ * (src/CompressedSensing.jl:22-23; src/matchingpursuit.jl:26,62,116; src/forward.jl:88-95).  The solver state
  * (residual, on-device QR, support) lives in the ctx. */
 int csmp_solver_begin(csmp_ctx *ctx, int algo, const void *b, int b_dtype, int64_t kcap,
                       const int64_t *idx0, const double *val0, int64_t nnz0);

@@ -578,3 +578,97 @@ int cso_ompr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const d
     sp_free(&x);
     return CSO_OK;
 }
+
+/* ---------------------------------------------------------------- forward regression (OLS)
+ * src/forward.jl:44-73 (fr / forward_step!), :75-82 (forward_δ!), :99-114 (ols_rescaling!).
+ *
+ * forward_step!: guard nnz(x) < n (:58); r = b - A x, stop unless norm(r) > max_ε (:59-61);
+ * δ²_j = <a_j, r>² / rescaling_j with rescaling_j = |a_j|² - |Q_S' a_j|² (:104-112) and
+ * δ²[x.nzind] = 0 (:80); (max, i) = findmax(δ²) = first maximum (:63); the atom is added only if
+ * min_δ² < max (:64), otherwise the step fails and fr stops (:52).
+ *
+ * The reference recomputes Q'A (an M x M x N product) at every step.  |Q_S' a_j|² = Σ_i (q_i' a_j)²
+ * is a sum over the columns of any orthonormal basis of span(A_S), so the restatement evaluates
+ * the SAME sum progressively: one new term (q_new' a_j)² per step, q_new being the explicit last
+ * column of this file's Householder Q.  (oracle_np.fr recomputes it from scratch with a fresh
+ * LAPACK QR at every step; tests/test_oracle.py diffs the two.)
+ *
+ * Not defined by the reference's tests ("parity unpinned"): NaN scores (0/0 on an atom that lies
+ * in span(A_S) with zero correlation) -- Julia's findmax would return the NaN; here, as on the
+ * GPU, a NaN never wins a comparison. */
+static void hqr_last_q(const hqr_t *F, double *q) { /* q = Q e_{j-1} = H_0 ... H_{j-1} e_{j-1} */
+    const int64_t M = F->M, j = F->j;
+    memset(q, 0, (size_t)M * sizeof(double));
+    q[j - 1] = 1.0;
+    for (int64_t i = j - 1; i >= 0; --i) {
+        const double *v = F->V + i * M;
+        double s = 0.0;
+        for (int64_t t = i; t < M; ++t) s += v[t] * q[t];
+        s *= F->beta[i];
+        for (int64_t t = i; t < M; ++t) q[t] -= s * v[t];
+    }
+}
+
+int cso_fr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+           double max_eps, double min_delta, int64_t *idx, double *val, int64_t *nnz, int64_t *order,
+           int nthreads) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    (void)nthreads;
+#endif
+    active_t S;
+    if (act_init(&S, M, k) != 0) return CSO_ENOMEM;
+    double *r = (double *)malloc((size_t)M * sizeof(double));
+    double *q = (double *)malloc((size_t)M * sizeof(double));
+    double *resc = (double *)malloc((size_t)N * sizeof(double)); /* P.rescaling */
+    double *d2 = (double *)malloc((size_t)N * sizeof(double));   /* P.δ² */
+    char *insupp = (char *)calloc((size_t)N, 1);
+    const double min_d2 = min_delta * min_delta; /* :64 */
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+    for (int64_t j = 0; j < N; ++j) { /* sum!(abs2, rescaling', A)  :108 */
+        double s = 0.0;
+        for (int64_t i = 0; i < M; ++i) {
+            const double a = a_at(A, dtype, ld, i, j);
+            s += a * a;
+        }
+        resc[j] = s;
+    }
+    for (int64_t it = 0; it < k; ++it) { /* :51 */
+        if (!(S.x.nnz < M)) break;       /* :58 */
+        cso_residual(A, dtype, M, ld, S.x.idx, S.x.val, S.x.nnz, b, r); /* :59 */
+        if (!(nrm2(r, M) > max_eps)) break;                             /* :60-61 */
+        const int have_q = it > 0; /* every successful step appended exactly one column */
+        if (have_q) hqr_last_q(&S.F, q);
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+        for (int64_t j = 0; j < N; ++j) {
+            if (have_q) {
+                const double g = col_dot(A, dtype, M, ld, j, q);
+                resc[j] -= g * g; /* :109-113, one more row of Q'A */
+            }
+            const double c = col_dot(A, dtype, M, ld, j, r); /* :77 */
+            d2[j] = insupp[j] ? 0.0 : c * c / resc[j];       /* :79-80 */
+        }
+        int64_t best = 0; /* findmax: first maximum (:63); NaN never wins, see header */
+        double bv = -1.0;
+        for (int64_t j = 0; j < N; ++j)
+            if (d2[j] > bv) {
+                bv = d2[j];
+                best = j;
+            }
+        if (!(min_d2 < bv)) break; /* :64,:69-71: the solve leaves x as it is */
+        if (!act_add(&S, A, dtype, M, ld, best)) break;
+        insupp[best] = 1;
+        act_solve(&S, b); /* :67 */
+    }
+    emit(&S.x, idx, val, nnz);
+    if (order)
+        for (int64_t t = 0; t < S.norder; ++t) order[t] = S.order[t];
+    free(r);
+    free(q);
+    free(resc);
+    free(d2);
+    free(insupp);
+    act_free(&S);
+    return CSO_OK;
+}

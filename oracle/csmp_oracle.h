@@ -65,6 +65,12 @@ int cso_ompr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const d
              double delta, int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int64_t *iters,
              int nthreads);
 
+/* fr(A,b,max_eps,min_delta,k) = ols = oomp = ormp: src/forward.jl:44-114 (x starts empty).
+ * idx/val/order sized >= k. */
+int cso_fr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+           double max_eps, double min_delta, int64_t *idx, double *val, int64_t *nnz, int64_t *order,
+           int nthreads);
+
 /* step primitives, exported so tests can pin them one by one */
 /* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
 int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,

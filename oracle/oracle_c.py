@@ -137,6 +137,21 @@ def ompr(A, b, k, delta, maxiter=-1, nthreads=0):
     return idx[:n].copy(), val[:n].copy(), iters.value
 
 
+def fr(A, b, k, max_eps=0.0, min_delta=0.0, nthreads=0):
+    """fr/ols/oomp/ormp (src/forward.jl:44-54) -> (idx sorted 0-based, val, order)."""
+    A, b, M, N, dtype = _prep(A, b)
+    cap = max(int(k), 1)
+    idx = np.zeros(cap, np.int64)
+    val = np.zeros(cap, np.float64)
+    order = np.zeros(cap, np.int64)
+    nnz = i64(0)
+    rc = lib().cso_fr(_vp(A), dtype, i64(M), i64(N), i64(M), _vp(b), i64(int(k)), C.c_double(max_eps),
+                      C.c_double(min_delta), _vp(idx), _vp(val), C.byref(nnz), _vp(order), int(nthreads))
+    assert rc == 0, rc
+    n = nnz.value
+    return idx[:n].copy(), val[:n].copy(), order[:n].copy()
+
+
 def sweep_abs(A, r, nthreads=0):
     A, r, M, N, dtype = _prep(A, r)
     out = np.zeros(N, np.float64)

@@ -9,6 +9,7 @@ Reference lines restated (paths relative to /root/reference):
   mp    src/matchingpursuit.jl:26-40      omp   src/matchingpursuit.jl:62-82
   gomp  src/matchingpursuit.jl:116-139    sp    src/twostage.jl:54-107
   helpers src/matchingpursuit.jl:152-193, src/util.jl:118-134
+  fr    src/forward.jl:44-114
 All arithmetic is Float64 on exactly promoted inputs; indices are 0-based.
 """
 import numpy as np
@@ -173,3 +174,35 @@ def ompr(A, b, k, delta, maxiter=None):
         if resnorm <= delta or oldnorm <= resnorm:
             break
     return idx, val, iters
+
+
+def fr(A, b, k, max_eps=0.0, min_delta=0.0):
+    """Forward regression / OLS: src/forward.jl:44-114, with the rescaling recomputed from scratch
+    at every step exactly as ols_rescaling! does (:99-114): |a_j|^2 - |Q' a_j|^2 with a fresh QR
+    of the active columns."""
+    A, b = _f64(A, b)
+    M, N = A.shape
+    idx = np.zeros(0, np.int64)
+    val = np.zeros(0)
+    order = []
+    for _ in range(k):  # :51
+        if not len(idx) < M:  # :58
+            break
+        r = _residual(A, b, idx, val)
+        if not np.linalg.norm(r) > max_eps:  # :60-61
+            break
+        resc = np.sum(A * A, axis=0)  # :108
+        if len(idx):
+            Q = np.linalg.qr(A[:, idx])[0]
+            resc = resc - np.sum((Q.T @ A) ** 2, axis=0)  # :104,:109-113
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d2 = (A.T @ r) ** 2 / resc  # :77-79
+        d2[idx] = 0.0  # :80
+        d2 = np.where(np.isnan(d2), -1.0, d2)  # a NaN never wins (see csmp_oracle.c)
+        i = int(np.argmax(d2))  # findmax: first maximum
+        if not min_delta ** 2 < d2[i]:  # :64
+            break
+        idx = np.sort(np.append(idx, i))
+        order.append(i)
+        val = _ls(A, idx, b)  # :67
+    return idx, val, np.array(order, np.int64)

@@ -617,3 +617,148 @@ def test_near_tie_below_f32_resolution_is_resolved_in_f64(cs, oracle, D):
     idx, val, nnz = d.ctx.omp_batch_mfma(np.asfortranarray(np.stack([r, 0.5 * r], axis=1)), 3, 0.0)
     assert np.array_equal(np.sort(idx[:, 0]), ref[0]) and np.array_equal(np.sort(idx[:, 1]), ref[0])
     assert close(val[:, 0], ref[1])
+
+
+# ------------------------------------------------------------------------------------------------
+# forward regression / orthogonal least squares (fr = ols = oomp = ormp; src/forward.jl)
+@pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40),
+                                   (1024, 2000, 24), (2048, 1500, 16), (4096, 1200, 12)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_fr_matches_oracle(cs, oracle, D, shape, dtype):
+    n, m, k = shape
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n * 17 + m, dtype=dtype)
+    d = D(A)
+    for seed in range(2):
+        xs = cs.sparse_vector(m, k, rng=seed)
+        y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=seed + 100)
+        ref = oracle.fr(A, y, k)
+        got = d.ctx.fr(y, k)
+        assert np.array_equal(got[2], ref[2]), "selection order"
+        assert np.array_equal(got[0], ref[0])
+        assert close(got[1], ref[1])
+    # the public driver: fr(A, b, sparsity = k) and the aliases (test/forward.jl:15-22)
+    xg = cs.fr(d, y, sparsity=k)
+    assert np.array_equal(xg.nzind, ref[0]) and close(xg.nzval, ref[1])
+    assert cs.ols is cs.fr and cs.oomp is cs.fr and cs.ormp is cs.fr
+
+
+def test_fr_reference_known_answer(cs, D):
+    """test/forward.jl:14-22 on seeded data: planted 3-sparse recovery, noiseless and perturbed."""
+    ok = 0
+    for seed in range(10):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=seed)
+        d = D(A)
+        xfr = cs.fr(d, b, sparsity=3)
+        y = cs.perturb(b, 1e-2, rng=seed)
+        yfr = cs.fr(d, y, sparsity=3)
+        ok += (np.array_equal(xfr.nzind, x.nzind) and np.allclose(xfr.nzval, x.nzval)
+               and np.array_equal(yfr.nzind, x.nzind) and np.allclose(yfr.nzval, x.nzval, atol=2e-2))
+    assert ok >= 9  # "may rarely fail" on random data (test/matchingpursuit.jl:7)
+
+
+def test_fr_stopping_rules(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=256, m=1024, k=24, rng=5, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=6)
+    d = D(A)
+    # residual tolerance: norm(r) > max_eps || return false (src/forward.jl:60-61)
+    for max_eps in (0.5, 0.05, 6e-3):
+        ref = oracle.fr(A, y, 100, max_eps=max_eps)
+        got = d.ctx.fr(y, 100, max_eps, 0.0)
+        assert np.array_equal(got[2], ref[2]) and close(got[1], ref[1]) and 0 < len(got[0]) < 100
+    # marginal decrease: the step fails unless min_delta^2 < max δ² (:64)
+    for min_delta in (0.9, 0.3, 0.01):
+        ref = oracle.fr(A, y, 100, min_delta=min_delta)
+        got = d.ctx.fr(y, 100, 0.0, min_delta)
+        assert np.array_equal(got[2], ref[2]) and close(got[1], ref[1]) and len(got[0]) < 100
+    assert len(d.ctx.fr(y, 100, 0.0, 1e3)[0]) == 0 and len(oracle.fr(A, y, 100, min_delta=1e3)[0]) == 0
+    assert len(d.ctx.fr(y, 100, 1e3, 0.0)[0]) == 0
+    assert len(d.ctx.fr(y, 0)[0]) == 0
+    # keyword form (:34-37) and positional form (:44-45, k defaults to size(A,1))
+    xk = cs.fr(d, y, max_residual=0.05, min_decrease=0.01, sparsity=50)
+    ref = oracle.fr(A, y, 50, max_eps=0.05, min_delta=0.01)
+    assert np.array_equal(xk.nzind, ref[0]) and close(xk.nzval, ref[1])
+    xp = cs.fr(d, y, 0.05, 0.01)
+    assert np.array_equal(xp.nzind, ref[0])
+    # nnz(x) < size(A,1) guard (:58): a square-ish system fills up and stops at M atoms
+    A2, _, b2 = cs.sparse_data(n=12, m=40, k=3, rng=9)
+    y2 = cs.perturb(b2, 1e-1, rng=1)
+    got = D(A2).ctx.fr(y2, 30)
+    ref = oracle.fr(A2, y2, 30)
+    assert len(ref[0]) <= 12 and np.array_equal(got[2][:8], ref[2][:8])
+    with pytest.raises(ValueError):
+        cs.fr(d, y[:-1], sparsity=3)
+
+
+def test_fr_scores_and_functor(cs, oracle, D):
+    """update!(P::FR, x) step by step (src/forward.jl:88-95) and P.δ² (:75-82) against the formula
+    evaluated from scratch in numpy: <a_j,r>^2 / (|a_j|^2 - |Q'a_j|^2), zero on the support."""
+    A, x, b = cs.sparse_data(n=96, m=400, k=6, rng=2)
+    y = cs.perturb(b, 1e-2, rng=3)
+    d = D(A)
+    P = cs.FR(d, y)
+    xg = cs.spzeros(400)
+    ref_order = oracle.fr(A, y, 6)[2]
+    supp = []
+    for t in range(6):
+        if supp:
+            S = np.array(sorted(supp))
+            coef = np.linalg.lstsq(A[:, S], y, rcond=None)[0]
+            r = y - A[:, S] @ coef
+            Q = np.linalg.qr(A[:, S])[0]
+            resc = np.sum(A * A, axis=0) - np.sum((Q.T @ A) ** 2, axis=0)
+        else:
+            r, resc = y.copy(), np.sum(A * A, axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            want = (A.T @ r) ** 2 / resc
+        want[supp] = 0.0
+        xg = P(xg)
+        got = P.delta2
+        assert np.allclose(got, want, rtol=1e-9, atol=1e-12 * want.max())
+        assert int(np.argmax(want)) == ref_order[t] == P.order[t]
+        supp.append(int(ref_order[t]))
+    assert np.array_equal(xg.nzind, np.sort(ref_order))
+    assert close(xg.nzval, np.linalg.lstsq(A[:, xg.nzind], y, rcond=None)[0])
+    assert cs.OLS is cs.FR
+
+
+def test_fr_differs_from_omp_on_coherent_dictionary(cs, oracle, D):
+    """OLS and OMP part ways when atoms are correlated with the selected ones: the parity check must
+    follow the OLS rule, not the OMP one.  Dictionary with a strong common component."""
+    rng = np.random.default_rng(11)
+    M, N, k = 48, 600, 16
+    A = rng.standard_normal((M, N)) + 1.5 * rng.standard_normal((M, 1))
+    A /= np.linalg.norm(A, axis=0)
+    b = A[:, rng.choice(N, k, replace=False)] @ rng.standard_normal(k) + 1e-3 * rng.standard_normal(M)
+    d = D(A)
+    ref = oracle.fr(A, b, k)
+    got = d.ctx.fr(b, k)
+    assert np.array_equal(got[2], ref[2]) and close(got[1], ref[1], tight=False)
+    assert not np.array_equal(oracle.omp(A, b, k, 0.0)[2], ref[2])
+
+
+def test_fr_duplicate_columns_tie_goes_to_lowest_index(cs, oracle, D):
+    A, x, b = cs.sparse_data(n=64, m=200, k=4, rng=3, dtype=np.float32)
+    A = np.asfortranarray(A)
+    first = int(oracle.fr(A, b, 1)[2][0])
+    dup = (first + 57) % 200
+    A[:, dup] = A[:, first]
+    lo = min(first, dup)
+    got = D(A).ctx.fr(b, 1)
+    assert got[2][0] == lo == oracle.fr(A, b, 1)[2][0]
+
+
+def test_full_size_config2_forward_regression(cs, oracle):
+    """C2 shape (4096 x 65536 f32): 48 OLS steps against the oracle (support, order, coefficients) and
+    the defining property of every OLS solution: the residual is orthogonal to the selected atoms."""
+    M, N, k = 4096, 65536, 48
+    A, x, b = cs.sparse_data(n=M, m=N, k=k, rng=77, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=78)
+    d = cs.Dictionary(A)
+    try:
+        got = d.ctx.fr(y, k)
+        ref = oracle.fr(A, y, k)
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+        r = y - A[:, got[0]].astype(np.float64) @ got[1]
+        assert np.max(np.abs(A[:, got[0]].astype(np.float64).T @ r)) < 1e-12
+    finally:
+        d.close()
