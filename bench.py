@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=18)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp"], default="omp",
+    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -257,6 +257,36 @@ def run_config5(args, cs, torch, dev, rank):
     D.close()
 
 
+def run_fr(args, cs, torch, dev, At, D):
+    """Forward regression / OLS (src/forward.jl) at the configs[1] shape: single signals, k = 256 atoms each.
+    One step = one complete fr(A, b, sparsity=256) solve; inputs host-resident vectors of 32 KiB."""
+    K, W = args.steps, args.warmup
+    Bsig = make_signals(torch, dev, At, 5000, K + W).cpu().numpy()
+    torch.cuda.synchronize()
+    for w in range(W):
+        D.ctx.fr(Bsig[w], K_ATOMS)
+    D.ctx.profile_enable(args.profile_every)
+    D.ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    atoms = 0
+    for s_ in range(W, W + K):
+        atoms += len(D.ctx.fr(Bsig[s_], K_ATOMS)[0])
+    dt = time.perf_counter() - t0
+    sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+    alg = M * N * 4
+    avg = sweep_ms / max(sweeps, 1) / 1e3
+    out = {"metric": "forward regression (OLS) atoms selected/sec at m=4096,n=65536,k=256", "value": atoms / dt, "unit": "atoms/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
+           "config": {"workload": "SURVEY 8(f)3: fr/ols on A 4096x65536 Float32 Gaussian unit-norm, k=256, one signal at a time",
+                      "sweeps": int(sweeps)},
+           "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
+                        "kernel": "csmp::k_fr_sweep<float,16,true,false>", "launches_timed": int(sweeps),
+                        "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +320,16 @@ def main():
         return
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
+    if args.workload == "fr":
+        if args.steps == 18 and args.warmup == 3:
+            args.steps, args.warmup = 6, 1
+        if rank == 0:
+            run_fr(args, cs, torch, dev, At, D)
+        D.close()
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1

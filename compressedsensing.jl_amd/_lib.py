@@ -44,6 +44,7 @@ SIGNATURES = {
                                    C.POINTER(C.c_double)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
     "csmp_solver_step": (C.c_int, [vp, i64]),
+    "csmp_solver_remove": (C.c_int, [vp, i64]),
     "csmp_solver_state": (C.c_int, [vp, vp, vp, C.POINTER(i64), C.POINTER(C.c_double), vp, C.POINTER(C.c_int)]),
     "csmp_sweep": (C.c_int, [vp, vp, vp, i64, vp, vp]),
     "csmp_lstsq": (C.c_int, [vp, vp, i64, vp, C.c_int, vp]),
@@ -316,6 +317,9 @@ class Context:
 
     def solver_step(self, l=1):
         self.call("csmp_solver_step", i64(int(l)))
+
+    def solver_remove(self, atom):
+        self.call("csmp_solver_remove", i64(int(atom)))
 
     def solver_state(self, cap):
         idx = np.zeros(cap, np.int64)

@@ -7,6 +7,7 @@
 #include "csmp_batched.hpp"
 #include "csmp_block.hpp"
 #include "csmp_forward.hpp"
+#include "csmp_downdate.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -50,6 +51,9 @@ struct Solver {
     int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
     double *rho2 = nullptr, *dvec = nullptr;  // forward regression: OLS rescaling and δ² scores (N each), allocated on first use
     int fr_grid = 0;
+    // column removal (csmp_downdate.hpp), allocated on first use
+    double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
+    int *delmeta = nullptr, *delpos = nullptr;
     int sigcap = 0;
 };
 
@@ -214,6 +218,7 @@ static void solver_free(Solver& s) {
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec);
+    dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     s = Solver();
 }
 
@@ -1074,6 +1079,54 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
         }
         default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
+}
+
+// ------------------------------------------------------------------------------------------ column removal
+static int del_ensure(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.kcap > kDelMaxCols) return fail(ctx, CSMP_ERANGE, "column removal supports at most 1023 columns");
+    if (s.R2) return CSMP_OK;
+    CHECK(dmalloc(ctx, &s.R2, (size_t)s.kcap * s.kcap));
+    CHECK(dmalloc(ctx, &s.Gdel, (size_t)2 * s.kcap + 2));
+    CHECK(dmalloc(ctx, &s.qdrop, s.Mpad));
+    CHECK(dmalloc(ctx, &s.bwd, s.kcap));
+    CHECK(dmalloc(ctx, &s.bwd_coef, s.kcap));
+    CHECK(dmalloc(ctx, &s.bwd_info, 2));
+    CHECK(dmalloc(ctx, &s.delmeta, 2));
+    CHECK(dmalloc(ctx, &s.delpos, 1));
+    return CSMP_OK;
+}
+
+// remove_column!(AiQR, *delpos) -- the insertion position is read from device memory (-1: nothing happens)
+static int launch_delete(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    const int threads = std::min(1024, ((s.kcap + 1 + 63) / 64) * 64);
+    hipLaunchKernelGGL(k_qrdel_r, dim3(1), dim3(threads), 0, ctx->stream, (const double*)s.R, s.R2, s.kcap, s.z, s.sel, s.st,
+                       (const int*)s.delpos, s.Gdel, s.scal, s.delmeta);
+    HIPCHECK(hipGetLastError());
+    std::swap(s.R, s.R2);
+    hipLaunchKernelGGL(k_qrdel_q, dim3(s.G), dim3(64), 0, ctx->stream, s.Q, s.ldq, (const double*)s.Gdel, (const double*)s.scal,
+                       (const int*)s.delmeta, s.r, s.qdrop);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+static int launch_delete_atom(csmp_ctx* ctx, int atom) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_find_pos, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, atom, s.delpos);
+    HIPCHECK(hipGetLastError());
+    return launch_delete(ctx);
+}
+
+// dropindex!(x, AiQR, i) on the step-level solver (src/util.jl:137-161): atom leaves the support
+extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_remove: no solver begun");
+    if (ctx->s.algo == CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "solver_remove: MP keeps no factorisation");
+    if (ctx->s.algo == CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_remove: use csmp_srr / the backward step for FR");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(del_ensure(ctx));
+    return launch_delete_atom(ctx, (int)atom);
 }
 
 extern "C" int csmp_fr_scores(csmp_ctx* ctx, double* delta2) {

@@ -145,6 +145,9 @@ int csmp_solver_begin(csmp_ctx *ctx, int algo, const void *b, int b_dtype, int64
                       const int64_t *idx0, const double *val0, int64_t nnz0);
 /* one update!: MP/OMP ignore l; GOMP adds the l best atoms */
 int csmp_solver_step(csmp_ctx *ctx, int64_t l);
+/* dropindex!(x, AiQR, i) (src/util.jl:137-161): atom leaves the support of an OMP/GOMP solver -- Givens
+ * down-date of the on-device QR (remove_column!), residual and coefficients follow.  No-op if absent. */
+int csmp_solver_remove(csmp_ctx *ctx, int64_t atom);
 /* current x (sorted), ||b - A x||_2, selection order, stop reason.  Any pointer may be NULL. */
 int csmp_solver_state(csmp_ctx *ctx, int64_t *idx, double *val, int64_t *nnz, double *resnorm,
                       int64_t *order, int *stop);

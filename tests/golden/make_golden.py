@@ -141,6 +141,43 @@ y = cs.perturb(b, 5e-3, rng=92)
 sp_case("sp_ref_32x64", A, y, 3, 1e-2)
 sp_case("sp_ref_32x64_noiseless", A, b, 3, 1e-12)
 
+
+
+# 12-: forward regression / OLS (src/forward.jl).  params = [k, max_eps, min_delta]
+def fr_case(name, A, b, k, max_eps=0.0, min_delta=0.0, twin=True):
+    r = oc.fr(A, b, k, max_eps, min_delta)
+    if twin:
+        agree(r, on.fr(A, b, k, max_eps, min_delta), name)
+    add(name, "fr", A, b, [k, max_eps, min_delta], r)
+
+
+A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=11)  # test/forward.jl:8-22
+y = cs.perturb(b, 1e-2, rng=12)
+fr_case("fr_ref_32x48", A, b, 3)
+fr_case("fr_ref_32x48_noisy", A, y, 3)
+assert np.array_equal(out["fr_ref_32x48.idx"], x.nzind) and np.array_equal(out["fr_ref_32x48_noisy.idx"], x.nzind)
+A, x, b = cs.sparse_data(n=64, m=256, k=8, rng=21)
+A32 = np.asfortranarray(A.astype(np.float32))
+y32 = cs.perturb(A32[:, x.nzind].astype(np.float64) @ x.nzval, 5e-3, rng=23)
+fr_case("fr_f32_64x256_k12", A32, y32, 12)
+fr_case("fr_f64_64x256_eps_stop", A, cs.perturb(b, 5e-3, rng=22), 40, max_eps=0.02)  # norm(r) > max_eps (:60)
+assert 0 < len(out["fr_f64_64x256_eps_stop.idx"]) < 40
+fr_case("fr_f64_64x256_delta_stop", A, cs.perturb(b, 5e-3, rng=22), 40, min_delta=0.05)  # min_delta^2 < max (:64)
+assert 0 < len(out["fr_f64_64x256_delta_stop.idx"]) < 40
+A, x, b = cs.sparse_data(n=37, m=101, k=4, rng=31, dtype=np.float32)
+fr_case("fr_f32_ragged_37x101", A, cs.perturb(b, 5e-3, rng=32), 6)
+A, x, b = cs.sparse_data(n=32, m=40, k=3, rng=41)
+A = np.asfortranarray(np.concatenate([A, A[:, x.nzind]], axis=1))
+fr_case("fr_dupcols", A, cs.perturb(b, 5e-3, rng=42), 3, twin=False)  # exact tie -> lower index (findmax)
+assert np.all(out["fr_dupcols.idx"] < 40)
+# a coherent dictionary, where the OLS rule and the OMP rule select different atoms
+rng = np.random.default_rng(11)
+A = rng.standard_normal((48, 600)) + 1.5 * rng.standard_normal((48, 1))
+A = np.asfortranarray(A / np.linalg.norm(A, axis=0))
+b = A[:, rng.choice(600, 16, replace=False)] @ rng.standard_normal(16) + 1e-3 * rng.standard_normal(48)
+fr_case("fr_coherent_48x600", A, b, 16)
+assert not np.array_equal(out["fr_coherent_48x600.order"], oc.omp(A, b, 16, 0.0)[2])
+
 out["names"] = np.array(names)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
 np.savez_compressed(path, **out)

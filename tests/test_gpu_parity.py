@@ -50,6 +50,9 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         elif c["algo"] == "gomp":
             idx, val, order = d.ctx.gomp(b, int(p[0]), int(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
+        elif c["algo"] == "fr":
+            idx, val, order = d.ctx.fr(b, int(p[0]), float(p[1]), float(p[2]))
+            assert np.array_equal(order, c["order"]), (name, order, c["order"])
         else:
             idx, val, iters = d.ctx.sp(b, int(p[0]), float(p[1]))
             assert iters == int(p[2]), name
@@ -59,7 +62,7 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         else:  # gomp_dupcols: an atom AND its exact copy are both selected -> singular least squares;
             pass  # the reference's own coefficients are NaN/Inf there, only the support is defined
         ran += 1
-    assert ran == len(golden) >= 19
+    assert ran == len(golden) >= 27
 
 
 @pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])
@@ -762,3 +765,55 @@ def test_full_size_config2_forward_regression(cs, oracle):
         assert np.max(np.abs(A[:, got[0]].astype(np.float64).T @ r)) < 1e-12
     finally:
         d.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# column removal from the on-device QR (remove_column! / dropindex!, src/util.jl:137-161)
+@pytest.mark.parametrize("cfg", [(100, 300, 12, np.float64), (256, 1000, 40, np.float32), (77, 200, 9, np.float32),
+                                 (1024, 3000, 150, np.float32)])
+def test_qr_column_removal(cs, D, cfg):
+    """Build a support with OMP steps, remove atoms at the first / a middle / the last insertion
+    position, and after every removal compare coefficients and residual with a dense least-squares
+    solve on what is left; then keep stepping (appends on top of a down-dated factorisation)."""
+    n, m, k, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + k, dtype=dtype)
+    y = cs.perturb(b, 5e-2, rng=1)
+    d = D(A)
+    A64 = A.astype(np.float64)
+    d.ctx.solver_begin(cs._lib.ALGO_OMP, y, k + 2)
+    for _ in range(k):
+        d.ctx.solver_step(1)
+    idx, val, res, order, stop = d.ctx.solver_state(k + 2)
+    assert len(idx) == k
+
+    def check(expect_support):
+        idx, val, res, order, stop = d.ctx.solver_state(k + 2)
+        S = np.array(sorted(expect_support))
+        assert np.array_equal(idx, S)
+        coef = np.linalg.lstsq(A64[:, S], y, rcond=None)[0]
+        assert close(val, coef, tight=False) and np.allclose(val, coef, rtol=1e-8, atol=1e-10)
+        assert np.isclose(res, np.linalg.norm(y - A64[:, S] @ coef), rtol=1e-8, atol=1e-12)
+        return order
+
+    supp = list(order)
+    for pos in (0, len(supp) // 2, -1, 1):
+        atom = supp[pos]
+        d.ctx.solver_remove(atom)
+        supp.remove(atom)
+        order = check(supp)
+        assert list(order) == supp  # insertion order is preserved among the survivors
+    d.ctx.solver_remove(10 ** 6)  # not in the support: no-op
+    check(supp)
+    for _ in range(3):  # appends after removals
+        d.ctx.solver_step(1)
+        idx, val, res, order, stop = d.ctx.solver_state(k + 2)
+        supp = list(order)
+        check(supp)
+    # remove everything, one by one
+    for atom in list(supp):
+        d.ctx.solver_remove(atom)
+        supp.remove(atom)
+        if supp:
+            check(supp)
+    idx, val, res, order, stop = d.ctx.solver_state(k + 2)
+    assert len(idx) == 0 and np.isclose(res, np.linalg.norm(y), rtol=1e-10)

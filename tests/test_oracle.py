@@ -20,17 +20,19 @@ def run_case(oracle, c):
         return oracle.mp(A, b, int(p[0]))
     if c["algo"] == "sp":
         return oracle.sp(A, b, int(p[0]), float(p[1]))
+    if c["algo"] == "fr":
+        return oracle.fr(A, b, int(p[0]), float(p[1]), float(p[2]))
     raise AssertionError(c["algo"])
 
 
 def test_golden_vectors(oracle, golden):
-    assert len(golden) >= 19
+    assert len(golden) >= 27
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
         if np.all(np.isfinite(c["val"])):  # (gomp_dupcols is a singular LS problem: support only)
             np.testing.assert_allclose(r[1], c["val"], rtol=1e-12, atol=1e-15, err_msg=name)
-        if c["algo"] in ("omp", "gomp"):
+        if c["algo"] in ("omp", "gomp", "fr"):
             assert np.array_equal(r[2], c["order"]), name
         if c["algo"] == "sp":
             assert r[2] == int(c["params"][2]), name
@@ -202,3 +204,32 @@ def test_reference_ompr_property_and_twin(oracle, cs):
     y = cs.perturb(b, 5e-3, rng=6)
     a, t = oracle.ompr(A, y, 12, 1e-6), on.ompr(A, y, 12, 1e-6)
     assert np.array_equal(a[0], t[0]) and a[2] == t[2] and a[2] >= 2
+
+
+def test_reference_fr_property_and_twin(oracle, cs):
+    """test/forward.jl:14-22 (planted 3-sparse recovery at 32 x 48, noiseless and perturbed by 1e-2) on
+    seeded data; and the C restatement (rescaling downdated one Q column per step) against the numpy
+    twin (rescaling recomputed from a fresh QR at every step, as ols_rescaling! does)."""
+    from oracle import oracle_np
+    ok = 0
+    for seed in range(40):
+        A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=3000 + seed)
+        y = cs.perturb(b, 1e-2, rng=seed)
+        i1, v1, o1 = oracle.fr(A, b, 3)
+        i2, v2, o2 = oracle.fr(A, y, 3)
+        t1, t2 = oracle_np.fr(A, b, 3), oracle_np.fr(A, y, 3)
+        assert np.array_equal(o1, t1[2]) and np.array_equal(o2, t2[2])
+        np.testing.assert_allclose(v2, t2[1], rtol=1e-10)
+        ok += (np.array_equal(i1, x.nzind) and np.allclose(v1, x.nzval) and np.array_equal(i2, x.nzind)
+               and np.allclose(v2, x.nzval, atol=2e-2))
+    assert ok >= 36  # "may rarely fail" (test/matchingpursuit.jl:7)
+    for (n, m, k, dt) in [(64, 256, 12, np.float64), (100, 333, 20, np.float32), (256, 1024, 40, np.float32)]:
+        A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dt)
+        y = cs.perturb(b, 5e-3, rng=1)
+        for kw in ({}, {"max_eps": 0.05}, {"min_delta": 0.05}):
+            a, t = oracle.fr(A, y, k + 5, **kw), oracle_np.fr(A, y, k + 5, **kw)
+            assert np.array_equal(a[2], t[2]), (n, m, kw)
+            np.testing.assert_allclose(a[1], t[1], rtol=1e-9, atol=1e-12)
+    # k >= M: the nnz(x) < size(A,1) guard ends the loop (src/forward.jl:58)
+    A, x, b = cs.sparse_data(n=6, m=20, k=2, rng=5)
+    assert len(oracle.fr(A, cs.perturb(b, 0.1, rng=2), 15)[0]) <= 6
