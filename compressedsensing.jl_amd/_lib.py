@@ -37,6 +37,7 @@ SIGNATURES = {
     "csmp_sp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_fr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_fr_scores": (C.c_int, [vp, vp]),
+    "csmp_srr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, C.c_int, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
@@ -241,6 +242,18 @@ class Context:
                   ptr(idx), ptr(val), C.byref(nnz), ptr(order))
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), order[:n].copy()
+
+    def srr(self, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1):
+        b = self._b(b)
+        cap = int(k) + int(l) + 1
+        idx = np.zeros(cap, np.int64)
+        val = np.zeros(cap, np.float64)
+        nnz = i64(0)
+        iters = i64(0)
+        self.call("csmp_srr", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
+                  int(initialization), i64(int(l)), ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), iters.value
 
     def fr_scores(self):
         d2 = np.zeros(self.N, np.float64)

@@ -9,6 +9,8 @@ Same names, argument meaning and error behaviour as the reference (paths relativ
     fr(A, b, max_eps, min_delta, k) / fr(A, b; max_residual, min_decrease, sparsity) = ols = oomp = ormp
                                              src/forward.jl:34-54
     FR functor with update!                  src/forward.jl:88-95
+    srr(A, b, k, delta=1e-12; maxiter=4k, initialization=1, l=1)          src/twostage.jl:3-33
+    ompr(A, b, k, delta; maxiter)            src/twostage.jl:184-202
     MP / OMP / GOMP functors with update!    src/matchingpursuit.jl:10-31,44-70,95-123
     argmaxinner!(P[, k])                     src/matchingpursuit.jl:181-193
 
@@ -183,6 +185,20 @@ def fr(A, b, *args, max_residual=0.0, min_decrease=0.0, sparsity=None):
 
 
 ols = oomp = ormp = fr  # src/forward.jl:52-54
+
+
+def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
+    """srr(A,b,k,delta=1e-12; maxiter=4k, initialization=1, l=1): stepwise regression with replacement,
+    src/twostage.jl:3-33 (x empty).  initialization 3 (random) is not offered: it draws from Julia's RNG."""
+    if initialization == 3:
+        raise ValueError("srr: initialization = 3 (random_acquisition!) is not reproducible outside Julia; use 1 or 2")
+    D, tmp = _dict(A)
+    try:
+        idx, val, _ = D.ctx.srr(b, int(k), float(delta), -1 if maxiter is None else int(maxiter), int(initialization), int(l))
+        return SparseVector(D.shape[1], idx, val)
+    finally:
+        if tmp:
+            D.close()
 
 
 def omp_batch(A, B, k, eps=None):

@@ -52,7 +52,7 @@ struct Solver {
     double *rho2 = nullptr, *dvec = nullptr;  // forward regression: OLS rescaling and δ² scores (N each), allocated on first use
     int fr_grid = 0;
     // column removal (csmp_downdate.hpp), allocated on first use
-    double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
+    double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *qsave = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
     int *delmeta = nullptr, *delpos = nullptr;
     int sigcap = 0;
 };
@@ -218,7 +218,7 @@ static void solver_free(Solver& s) {
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec);
-    dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
+    dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     s = Solver();
 }
 
@@ -753,38 +753,63 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
 }
 
 // ------------------------------------------------------------------------------------------ forward regression (OLS)
-template <typename TA, int U, bool FULL>
-static hipError_t fr_sweep_launch_t(csmp_ctx* ctx, bool first, int grid, size_t lds, double max_eps, int skipmask) {
+// one pass of k_fr_sweep (csmp_forward.hpp): nq = -1 first step (norms), 0 scores only, 1 / 2 directions
+struct FrPass {
+    int nq = 1;
+    const double* q1 = nullptr;  // null with nq >= 1: the last Q column, looked up on the device
+    double s1 = -1.0;
+    const double* q2 = nullptr;
+    double s2 = 1.0;
+    const int* unmark = nullptr;
+    int update_only = 0;
+};
+
+template <typename TA, int U, bool FULL, int NQ>
+static hipError_t fr_sweep_launch_t(csmp_ctx* ctx, const FrPass& ps, int grid, size_t lds, double max_eps, int skipmask) {
     Solver& s = ctx->s;
-    auto k1 = k_fr_sweep<TA, U, FULL, true>;
-    auto k0 = k_fr_sweep<TA, U, FULL, false>;
+    auto kern = k_fr_sweep<TA, U, FULL, NQ>;
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)(first ? k1 : k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(first ? k1 : k0, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, (const double*)s.r, (const double*)s.Q, s.ldq, s.rho2, s.dvec, s.pval, s.pidx, (const int*)s.sel,
-                       s.st, max_eps, skipmask);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+                       (const double*)s.r, (const double*)s.Q, s.ldq, ps.q1, ps.s1, ps.q2, ps.s2, ps.unmark, ps.update_only, s.rho2,
+                       s.dvec, s.pval, s.pidx, (const int*)s.sel, s.st, max_eps, skipmask);
     return hipGetLastError();
 }
+template <typename TA, int U, bool FULL>
+static hipError_t fr_sweep_launch_nq(csmp_ctx* ctx, const FrPass& ps, int grid, size_t lds, double max_eps, int skipmask) {
+    switch (ps.nq) {
+        case -1: return fr_sweep_launch_t<TA, U, FULL, -1>(ctx, ps, grid, lds, max_eps, skipmask);
+        case 0: return fr_sweep_launch_t<TA, U, FULL, 0>(ctx, ps, grid, lds, max_eps, skipmask);
+        case 1: return fr_sweep_launch_t<TA, U, FULL, 1>(ctx, ps, grid, lds, max_eps, skipmask);
+        default: return fr_sweep_launch_t<TA, U, FULL, 2>(ctx, ps, grid, lds, max_eps, skipmask);
+    }
+}
+template <typename TA>
+static hipError_t fr_sweep_launch(csmp_ctx* ctx, const FrPass& ps, int U, bool full, int grid, size_t lds, double max_eps, int skipmask) {
+    if (!full) return fr_sweep_launch_nq<TA, 4, false>(ctx, ps, grid, lds, max_eps, skipmask);
+    if (U == 16) return fr_sweep_launch_nq<TA, 16, true>(ctx, ps, grid, lds, max_eps, skipmask);
+    return fr_sweep_launch_nq<TA, 8, true>(ctx, ps, grid, lds, max_eps, skipmask);
+}
 
-// block size of the forward-regression sweep: the largest of 16/8/4 chunks that tiles M exactly, else
-// the predicated 4-chunk kernel
-static void fr_config(const csmp_ctx* ctx, int& U, bool& full, size_t& lds, int& grid) {
+// block size of the forward-regression sweep: 16 or 8 chunks when they tile M exactly, else the
+// predicated 4-chunk kernel
+static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& lds, int& grid) {
     const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
     const int rows = kWave * vec;
     U = 4;
     full = false;
     if (ctx->Mv % rows == 0) {
         const int nchunk = ctx->Mv / rows;
-        for (int u : {16, 8, 4})
+        for (int u : {16, 8})
             if (nchunk % u == 0) {
                 U = u;
                 full = true;
                 break;
             }
     }
-    lds = fr_sweep_lds_bytes(ctx->Mv, vec, U);
+    lds = fr_sweep_lds_bytes(ctx->Mv, vec, U, nq);
     const int cus = ctx->prop.multiProcessorCount;
     int64_t g = U == 16 ? (int64_t)cus * 3 / 4 : (int64_t)cus;  // as the OMP sweep (configure_sweep)
     if (const char* sn = getenv("CSMP_FR_NBLK")) g = std::max(1, atoi(sn));  // tuning knob
@@ -795,7 +820,7 @@ static void fr_config(const csmp_ctx* ctx, int& U, bool& full, size_t& lds, int&
 static int fr_ensure(csmp_ctx* ctx) {
     Solver& s = ctx->s;
     int U; bool full; size_t lds;
-    fr_config(ctx, U, full, lds, s.fr_grid);
+    fr_config(ctx, 1, U, full, lds, s.fr_grid);
     if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "fr: M too large (r and q must both fit the 160 KiB LDS)");
     if (!s.rho2) CHECK(dmalloc(ctx, &s.rho2, (size_t)ctx->N));
     if (!s.dvec) CHECK(dmalloc(ctx, &s.dvec, (size_t)ctx->N));
@@ -803,26 +828,22 @@ static int fr_ensure(csmp_ctx* ctx) {
 }
 
 // forward_δ! + the residual-norm guard of forward_step! (src/forward.jl:59-61,75-82)
-static int launch_fr_sweep(csmp_ctx* ctx, bool first, double max_eps, int skipmask) {
+static int launch_fr_pass(csmp_ctx* ctx, const FrPass& ps, double max_eps, int skipmask) {
     int U, grid; bool full; size_t lds;
-    fr_config(ctx, U, full, lds, grid);
-    const bool timed = prof_pick(ctx);
+    fr_config(ctx, ps.nq, U, full, lds, grid);
+    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "forward-regression sweep: M too large for the LDS images");
+    const bool timed = !ps.update_only && prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
-    hipError_t e;
-    if (ctx->dtype == CSMP_F32) {
-        if (!full) e = fr_sweep_launch_t<float, 4, false>(ctx, first, grid, lds, max_eps, skipmask);
-        else if (U == 16) e = fr_sweep_launch_t<float, 16, true>(ctx, first, grid, lds, max_eps, skipmask);
-        else if (U == 8) e = fr_sweep_launch_t<float, 8, true>(ctx, first, grid, lds, max_eps, skipmask);
-        else e = fr_sweep_launch_t<float, 4, true>(ctx, first, grid, lds, max_eps, skipmask);
-    } else {
-        if (!full) e = fr_sweep_launch_t<double, 4, false>(ctx, first, grid, lds, max_eps, skipmask);
-        else if (U == 16) e = fr_sweep_launch_t<double, 16, true>(ctx, first, grid, lds, max_eps, skipmask);
-        else if (U == 8) e = fr_sweep_launch_t<double, 8, true>(ctx, first, grid, lds, max_eps, skipmask);
-        else e = fr_sweep_launch_t<double, 4, true>(ctx, first, grid, lds, max_eps, skipmask);
-    }
+    hipError_t e = ctx->dtype == CSMP_F32 ? fr_sweep_launch<float>(ctx, ps, U, full, grid, lds, max_eps, skipmask)
+                                          : fr_sweep_launch<double>(ctx, ps, U, full, grid, lds, max_eps, skipmask);
     HIPCHECK(e);
     if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;
+}
+static int launch_fr_sweep(csmp_ctx* ctx, bool first, double max_eps, int skipmask) {
+    FrPass ps;
+    ps.nq = first ? -1 : 1;
+    return launch_fr_pass(ctx, ps, max_eps, skipmask);
 }
 
 // forward_step!(P, x, max_ε, min_δ): src/forward.jl:56-73
@@ -1092,7 +1113,8 @@ static int del_ensure(csmp_ctx* ctx) {
     CHECK(dmalloc(ctx, &s.bwd, s.kcap));
     CHECK(dmalloc(ctx, &s.bwd_coef, s.kcap));
     CHECK(dmalloc(ctx, &s.bwd_info, 2));
-    CHECK(dmalloc(ctx, &s.delmeta, 2));
+    CHECK(dmalloc(ctx, &s.delmeta, 4));
+    CHECK(dmalloc(ctx, &s.qsave, s.Mpad));
     CHECK(dmalloc(ctx, &s.delpos, 1));
     return CSMP_OK;
 }
@@ -1106,7 +1128,7 @@ static int launch_delete(csmp_ctx* ctx) {
     HIPCHECK(hipGetLastError());
     std::swap(s.R, s.R2);
     hipLaunchKernelGGL(k_qrdel_q, dim3(s.G), dim3(64), 0, ctx->stream, s.Q, s.ldq, (const double*)s.Gdel, (const double*)s.scal,
-                       (const int*)s.delmeta, s.r, s.qdrop);
+                       (const int*)s.delmeta, s.r, s.qdrop, s.qsave);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -1491,8 +1513,8 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
 // ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202, x starting empty.  The support is filled by
 // oblivious_acquisition! (src/matchingpursuit.jl:207-216); every update! (:134-180) is one sweep +
 // arg-max on the device, the tiny "which entry leaves" decision on k+1 numbers on the host, and --
-// when the support changes -- a fresh panel factorisation of the new support (the reference's
-// add_column!/remove_column! pair yields the same least-squares solution).
+// when the support changes -- remove_column! as a Givens down-date of the on-device QR
+// (csmp_downdate.hpp) followed by the usual append (k > 1023: a fresh panel factorisation instead).
 extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
                          double* val, int64_t* nnz, int64_t* iters) {
     if (!ctx) return CSMP_EINVAL;
@@ -1504,6 +1526,8 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     CHECK(solver_ensure(ctx, (int)k, (int)k));
     ctx->s.begun = false;
     Solver& s = ctx->s;
+    const bool use_downdate = k <= kDelMaxCols && !getenv("CSMP_OMPR_REFACTOR");  // (knob: refactorise instead)
+    if (use_downdate) CHECK(del_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
     // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
     CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
@@ -1567,18 +1591,178 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
                 }
             }
             if (jmin != pos) {  // qr_i != j (:171): the support really changes
-                std::vector<int> cols;
-                for (size_t t = 0; t <= xi.size(); ++t) {
-                    if (t == jmin) continue;
-                    cols.push_back(t == pos ? (int)cand : (int)(t < pos ? xi[t] : xi[t - 1]));
+                const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
+                if (use_downdate) {
+                    // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
+                    CHECK(launch_delete_atom(ctx, leaving));
+                    const int one = 1, ci = (int)cand;
+                    HIPCHECK(hipMemcpyAsync(s.cands, &ci, 4, hipMemcpyHostToDevice, ctx->stream));
+                    HIPCHECK(hipMemcpyAsync(s.ncands, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+                    CHECK(launch_append(ctx, 2, 0, 0));
+                } else {
+                    std::vector<int> cols;
+                    for (size_t t = 0; t <= xi.size(); ++t) {
+                        if (t == jmin) continue;
+                        cols.push_back(t == pos ? (int)cand : (int)(t < pos ? xi[t] : xi[t - 1]));
+                    }
+                    CHECK(ls_on_columns(ctx, cols));  // :178
                 }
-                CHECK(ls_on_columns(ctx, cols));  // :178
                 CHECK(fetch_sorted(ctx, xi, xv));
             }
         }
         CHECK(residual_norm(ctx, &resnorm));                 // :196
         if (resnorm <= delta || oldnorm <= resnorm) break;   // :197
     }
+    for (size_t t = 0; t < xi.size(); ++t) {
+        if (idx) idx[t] = xi[t];
+        if (val) val[t] = xv[t];
+    }
+    if (nnz) *nnz = (int64_t)xi.size();
+    if (iters) *iters = it;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stepwise regression with replacement
+// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty.  Every
+// iteration is l forward steps (forward_step!(P,x,0,0): one dictionary sweep + one append each) and
+// as many backward steps (backward_step!(P,x,Inf,Inf): scores from R, Givens down-date).  The OLS
+// rescaling rho2 follows the support through rank-one corrections folded into the NEXT sweep: -<a,q>^2
+// for the column a forward step appended, +<a,q_drop>^2 for the direction a backward step rotated out
+// (csmp_forward.hpp, NQ = 2) -- so an iteration with l = 1 streams the dictionary once.  The host
+// reads the 48-byte control block after every step (it must know which steps changed the support).
+extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1 || l < 1) return fail(ctx, CSMP_EINVAL, "srr: b == NULL, k < 1 or l < 1");
+    if (initialization != 1 && initialization != 2)
+        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression)");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
+    if (maxiter < 0) maxiter = 4 * k;  // :5
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kcap = (int)(k + l);
+    CHECK(solver_ensure(ctx, kcap, kcap));
+    CHECK(fr_ensure(ctx));
+    CHECK(del_ensure(ctx));
+    Solver& s = ctx->s;
+    s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    struct Pend { const double* q; double sgn; };
+    std::vector<Pend> pend;  // rank-one corrections rho2 still lacks; q == nullptr: the last Q column (device look-up)
+    bool unmark = false;     // delmeta[2] names an atom that left the support and needs its rho2 re-seeded
+    const int skipF = STOP_EPS | STOP_STAG | STOP_FULL;
+    static const int zero = 0;
+    DevState hs;
+    auto read_state = [&]() -> int {
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        return CSMP_OK;
+    };
+    auto pass_of = [&](int update_only) {
+        FrPass ps;
+        ps.nq = (int)pend.size();
+        ps.update_only = update_only;
+        if (pend.size() >= 1) { ps.q1 = pend[0].q; ps.s1 = pend[0].sgn; }
+        if (pend.size() >= 2) { ps.q2 = pend[1].q; ps.s2 = pend[1].sgn; }
+        ps.unmark = unmark ? s.delmeta + 2 : nullptr;  // (the direction that was rotated out is always the last one)
+        return ps;
+    };
+    if (initialization == 1) {
+        // oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216
+        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+        CHECK(launch_topS(ctx, (int)k));
+        std::vector<int> top((size_t)k);
+        HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        std::sort(top.begin(), top.end());
+        CHECK(ls_on_columns(ctx, top));
+        // rho2_j = |a_j|^2 - |Q'a_j|^2 for the k columns just factorised: the norms, then two columns per pass
+        FrPass p0;
+        p0.nq = -1;
+        p0.update_only = 1;
+        CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
+        for (int64_t t = 0; t < k; t += 2) {
+            FrPass ps;
+            ps.update_only = 1;
+            ps.q1 = s.Q + t * s.ldq;
+            ps.s1 = -1.0;
+            ps.nq = 1;
+            if (t + 1 < k) {
+                ps.nq = 2;
+                ps.q2 = s.Q + (t + 1) * s.ldq;
+                ps.s2 = -1.0;
+            }
+            CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
+        }
+        hipLaunchKernelGGL(k_mark_inf, dim3(1), dim3(256), 0, ctx->stream, s.rho2, (const int*)s.sel, (const DevState*)s.st);
+        HIPCHECK(hipGetLastError());
+    } else {
+        // k times update!(P::FR, x) (:12-15; src/forward.jl:88-95)
+        const int skip = STOP_FULL | STOP_STAG;
+        for (int64_t t = 0; t < k; ++t) {
+            CHECK(launch_fr_sweep(ctx, t == 0, -HUGE_VAL, skip));
+            CHECK(launch_append(ctx, 3, 0, skip, false, -1.0, s.fr_grid));
+        }
+        pend.push_back({nullptr, -1.0});
+    }
+    CHECK(read_state());
+    int n = hs.nsel;
+    if (hs.done) HIPCHECK(hipMemcpyAsync(&s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+    double resnorm = 0.0;
+    CHECK(residual_norm(ctx, &resnorm));  // :18
+    int64_t it = 0;
+    while (it < maxiter) {  // :19
+        const double oldnorm = resnorm;
+        for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
+            CHECK(launch_fr_pass(ctx, pass_of(0), 0.0, skipF));
+            CHECK(launch_append(ctx, 3, 0, skipF, false, 0.0, s.fr_grid));
+            CHECK(read_state());
+            if (hs.done & skipF) {
+                // the step failed.  A residual-norm stop returns before rho2 is touched; the other guards act
+                // after the sweep, which has then consumed the pending corrections.
+                if (!(hs.done & STOP_EPS)) {
+                    pend.clear();
+                    unmark = false;
+                }
+                HIPCHECK(hipMemcpyAsync(&s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+                break;
+            }
+            pend.clear();
+            unmark = false;
+            pend.push_back({nullptr, -1.0});
+            n = hs.nsel;
+        }
+        while (n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
+            bool has_drop = false;
+            for (const Pend& e : pend) has_drop |= e.q == s.qdrop;
+            if (has_drop) {  // the q_drop buffer is about to be reused: bring rho2 up to date first
+                CHECK(launch_fr_pass(ctx, pass_of(1), 0.0, 0));
+                pend.clear();
+                unmark = false;
+            }
+            hipLaunchKernelGGL(k_bwd_scores, dim3(n), dim3(64), (size_t)n * sizeof(double), ctx->stream, (const double*)s.R, s.kcap,
+                               (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
+            HIPCHECK(hipGetLastError());
+            hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
+                               (const DevState*)s.st, (const double*)s.r, (int)ctx->M, (double)HUGE_VAL, (double)HUGE_VAL, s.delpos,
+                               s.bwd_info);
+            HIPCHECK(hipGetLastError());
+            CHECK(launch_delete(ctx));
+            CHECK(read_state());
+            if (hs.nsel == n) break;  // nothing could be dropped (no finite score)
+            for (Pend& e : pend)
+                if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_qrdel_q kept a copy
+            pend.push_back({s.qdrop, 1.0});
+            unmark = true;
+            n = hs.nsel;
+        }
+        CHECK(residual_norm(ctx, &resnorm));  // :27
+        ++it;
+        if (resnorm <= delta || oldnorm <= resnorm) break;  // :28-30
+    }
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    CHECK(fetch_sorted(ctx, xi, xv));
     for (size_t t = 0; t < xi.size(); ++t) {
         if (idx) idx[t] = xi[t];
         if (val) val[t] = xv[t];

@@ -26,7 +26,7 @@ constexpr int kDelPre = 8;         // rows of look-ahead in the rotation chain
 // R side.  Thread c owns OLD column c (it becomes new column c-1 for c > p); thread n owns z.
 // Writes the new factor into Rnew (Rold is left intact: the host swaps the two buffers), z and sel
 // in place, the rotations into G[2i], G[2i+1] (i = p .. n-2), zeta into scal[0] and the (p, n)
-// pair the Q kernel needs into meta[0..1].  delpos < 0 or >= n: nothing is removed (Rnew = Rold).
+// pair the Q kernel needs into meta[0..1], the leaving atom into meta[2].  delpos < 0 or >= n: nothing is removed (Rnew = Rold).
 __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rold, double* __restrict__ Rnew, int kcap,
                                                   double* __restrict__ z, int* __restrict__ sel, DevState* st,
                                                   const int* __restrict__ delpos, double* __restrict__ G,
@@ -41,7 +41,10 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
     if (p < 0) {
         if (iscol)
             for (int t = 0; t <= c; ++t) Rnew[co + t] = Rold[co + t];
-        if (c == 0) meta[0] = -1;
+        if (c == 0) {
+            meta[0] = -1;
+            meta[2] = -1;
+        }
         return;
     }
     const int mysel = iscol ? sel[c] : -1;
@@ -101,6 +104,7 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
         scal[0] = carry;  // zeta = q_drop' b
         z[n - 1] = 0.0;
     }
+    if (c == p) meta[2] = mysel;  // the atom that leaves
     if (c == 0) {
         meta[0] = p;
         meta[1] = n;
@@ -115,11 +119,16 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
 constexpr int kQPre = 16;
 __global__ __launch_bounds__(64) void k_qrdel_q(double* __restrict__ Q, int64_t ldq, const double* __restrict__ G,
                                                 const double* __restrict__ scal, const int* __restrict__ meta,
-                                                double* __restrict__ r, double* __restrict__ qdrop) {
+                                                double* __restrict__ r, double* __restrict__ qdrop,
+                                                double* __restrict__ qsave) {
     const int p = meta[0], n = meta[1];
-    if (p < 0) return;
     const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (p < 0) {
+        qdrop[row] = 0.0;
+        return;
+    }
     double* q = Q + row;
+    qsave[row] = q[(int64_t)(n - 1) * ldq];  // the last column as it was before the rotations
     double carry = q[(int64_t)p * ldq];
     double pre[kQPre], nxt[kQPre];
     auto fetch = [&](double* dst, int i0) {

@@ -25,15 +25,26 @@ namespace csmp {
 // One column per wave at a time, software-pipelined across columns like sweep_body_pf.
 //   U      16-byte row chunks per load block (U KiB in flight per wave, U..2U while a block is reduced)
 //   FULL   Mv is a multiple of U*64*VEC rows; otherwise the tail chunks are predicated
-//   FIRST  first step of a solve: no Q column yet; the second accumulator forms |a_j|^2 instead
-//          (sum!(abs2, rescaling', A), src/forward.jl:108) and initialises rho2
-// dynamic LDS: r image | q image (each nblocks*U*64*VEC doubles) | 32 doubles of reduction scratch
-template <typename TA, int U, bool FULL, bool FIRST>
+//   NQ     directions whose squared projections correct rho2 in this pass:
+//          -1  first step of a solve: no factorisation yet; the second accumulator forms |a_j|^2
+//              (sum!(abs2, rescaling', A), src/forward.jl:108) and initialises rho2
+//           0  rho2 is current: scores only
+//           1  rho2_j += s1 * <a_j, q1>^2          (s1 = -1: q1 is the Q column appended last step)
+//           2  ... + s2 * <a_j, q2>^2 as well      (stepwise regression with replacement: the column
+//              appended by the forward step, s = -1, and the direction q_drop that the backward step
+//              rotated out, s = +1; csmp_downdate.hpp)
+//   q1 == nullptr with NQ >= 1: q1 = Q[:, nsel-1], looked up on the device
+//   unmark (may be null): atom that LEFT the support; its rho2 is re-seeded with <a, q_last>^2, q_last being
+//          the last direction of the pass (q_drop): the atom's squared distance from the new span.  The atom sel[nsel-1] is marked rho2 = +Inf (score 0 for good).
+//   update_only: rho2 maintenance pass, no residual test and no scores
+// dynamic LDS: r image | NQ direction images (each nblocks*U*64*VEC doubles) | 32 doubles of scratch
+template <typename TA, int U, bool FULL, int NQ>
 __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
-    const double* __restrict__ Q, int64_t ldq, double* __restrict__ rho2, double* __restrict__ dvec,
-    double* __restrict__ pval, int* __restrict__ pidx, const int* __restrict__ sel, DevState* st,
-    double max_eps, int skipmask) {
+    const double* __restrict__ Q, int64_t ldq, const double* __restrict__ q1in, double s1,
+    const double* __restrict__ q2in, double s2, const int* __restrict__ unmark, int update_only,
+    double* __restrict__ rho2, double* __restrict__ dvec, double* __restrict__ pval, int* __restrict__ pidx,
+    const int* __restrict__ sel, DevState* st, double max_eps, int skipmask) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
@@ -45,29 +56,36 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
     const int nchunk = (Mv + ROWS - 1) / ROWS;
     const int nblocks = (nchunk + U - 1) / U;
     const int Mlds = nblocks * U * ROWS;
+    constexpr bool FIRST = NQ < 0;
+    constexpr int NIM = NQ > 0 ? NQ : 0;
     double* qim = lds + Mlds;
-    double* red = qim + Mlds;
+    double* qim2 = qim + (NIM > 1 ? Mlds : 0);
+    double* red = lds + (size_t)(1 + NIM) * Mlds;
     double* redv = red + 8;
     int* redi = reinterpret_cast<int*>(redv + 4 * NW);
 
     const int nsel = st->nsel;
     const int lastsel = (!FIRST && nsel > 0) ? sel[nsel - 1] : -1;
-    const double* qcol = (!FIRST && nsel > 0) ? Q + (int64_t)(nsel - 1) * ldq : nullptr;
+    const int unsel = (NQ >= 1 && unmark) ? *unmark : -1;
+    const double* q1 = nullptr;
+    if constexpr (NQ >= 1) q1 = q1in ? q1in : (nsel > 0 ? Q + (int64_t)(nsel - 1) * ldq : nullptr);
     double n2 = 0.0;
     for (int m = tid; m < Mlds; m += kSweepThreads) {
         const double v = (m < Mv) ? r[m] : 0.0;
         lds[r_slot<VEC>(m)] = v;
         n2 = fma(v, v, n2);
-        if constexpr (!FIRST) qim[r_slot<VEC>(m)] = (qcol && m < Mv) ? qcol[m] : 0.0;
+        if constexpr (NQ >= 1) qim[r_slot<VEC>(m)] = (q1 && m < Mv) ? q1[m] : 0.0;
+        if constexpr (NQ == 2) qim2[r_slot<VEC>(m)] = (q2in && m < Mv) ? q2in[m] : 0.0;
     }
     n2 = block_sum256(n2, red);
     if (bid == 0 && tid == 0) st->rnorm2 = n2;
-    if (!(sqrt(n2) > max_eps)) {  // normr > max_ε || return false   (src/forward.jl:60-61)
+    if (!update_only && !(sqrt(n2) > max_eps)) {  // normr > max_ε || return false   (src/forward.jl:60-61)
         if (bid == 0 && tid == 0) st->done |= STOP_EPS;
         return;
     }
     const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
     const f64x2* qs = reinterpret_cast<const f64x2*>(qim);
+    const f64x2* qs2 = reinterpret_cast<const f64x2*>(qim2);
     double bestv = -1.0;  // a NaN score never wins a comparison
     int besti = 0x7fffffff;
     const int64_t stride = (int64_t)nblk * NW;
@@ -90,7 +108,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
     while (col >= 0) {
         double rho_old = 0.0;
         if constexpr (!FIRST) rho_old = rho2[col];  // requested before the column's loads are consumed
-        double acc = 0.0, acg = 0.0;
+        double acc = 0.0, acg = 0.0, acg2 = 0.0;
         for (int blk = 0; blk < nblocks; ++blk) {
             const bool last = blk + 1 == nblocks;
             const int64_t ncol = last ? col + stride : col;
@@ -111,13 +129,22 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
                         acg = fma(a1, a1, acg);
                         acg = fma(a2, a2, acg);
                         acg = fma(a3, a3, acg);
-                    } else {
+                    }
+                    if constexpr (NQ >= 1) {
                         const f64x2 q01 = qs[(t * 2 + 0) * kWave + lane];
                         const f64x2 q23 = qs[(t * 2 + 1) * kWave + lane];
                         acg = fma(a0, q01.x, acg);
                         acg = fma(a1, q01.y, acg);
                         acg = fma(a2, q23.x, acg);
                         acg = fma(a3, q23.y, acg);
+                    }
+                    if constexpr (NQ == 2) {
+                        const f64x2 q01 = qs2[(t * 2 + 0) * kWave + lane];
+                        const f64x2 q23 = qs2[(t * 2 + 1) * kWave + lane];
+                        acg2 = fma(a0, q01.x, acg2);
+                        acg2 = fma(a1, q01.y, acg2);
+                        acg2 = fma(a2, q23.x, acg2);
+                        acg2 = fma(a3, q23.y, acg2);
                     }
                 } else {
                     const f64x2 r01 = rs[t * kWave + lane];
@@ -127,10 +154,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
                     if constexpr (FIRST) {
                         acg = fma(a0, a0, acg);
                         acg = fma(a1, a1, acg);
-                    } else {
+                    }
+                    if constexpr (NQ >= 1) {
                         const f64x2 q01 = qs[t * kWave + lane];
                         acg = fma(a0, q01.x, acg);
                         acg = fma(a1, q01.y, acg);
+                    }
+                    if constexpr (NQ == 2) {
+                        const f64x2 q01 = qs2[t * kWave + lane];
+                        acg2 = fma(a0, q01.x, acg2);
+                        acg2 = fma(a1, q01.y, acg2);
                     }
                 }
             }
@@ -139,16 +172,23 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
         }
         for (int sft = 32; sft >= 1; sft >>= 1) {
             acc += shx(acc, sft);
-            acg += shx(acg, sft);
+            if constexpr (NQ != 0) acg += shx(acg, sft);
+            if constexpr (NQ == 2) acg2 += shx(acg2, sft);
         }
         // rescaling_j (src/forward.jl:108-113), one more row of Q'A per step; atoms of the support get
         // +Inf once, which makes their score c^2 / Inf = 0 for good (δ²[x.nzind] = 0, :80)
-        double rho = FIRST ? acg : fma(-acg, acg, rho_old);
+        double rho = rho_old;
+        if constexpr (FIRST) rho = acg;
+        if constexpr (NQ >= 1) rho = fma(s1 * acg, acg, rho);
+        if constexpr (NQ == 2) rho = fma(s2 * acg2, acg2, rho);
         if ((int)col == lastsel) rho = __builtin_inf();
+        if constexpr (NQ >= 1)
+            if ((int)col == unsel) rho = NQ == 2 ? acg2 * acg2 : acg * acg;
         const double d2 = acc * acc / rho;
         if (lane == 0) {
-            rho2[col] = rho;
-            dvec[col] = d2;
+            if constexpr (NQ != 0) rho2[col] = rho;
+            else if ((int)col == lastsel) rho2[col] = rho;
+            if (!update_only) dvec[col] = d2;
         }
         if (d2 > bestv) {
             bestv = d2;
@@ -175,11 +215,16 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
     }
 }
 
-inline size_t fr_sweep_lds_bytes(int Mv, int vec, int U) {
+inline size_t fr_sweep_lds_bytes(int Mv, int vec, int U, int nq) {
     const int rows = kWave * vec;
     const int nchunk = (Mv + rows - 1) / rows;
     const int nblocks = (nchunk + U - 1) / U;
-    return ((size_t)2 * nblocks * U * rows + 8 + 16 + 8) * sizeof(double);
+    return ((size_t)(1 + (nq > 0 ? nq : 0)) * nblocks * U * rows + 8 + 16 + 8) * sizeof(double);
+}
+
+// rho2 = +Inf for every atom of the support (bulk form of the per-step marking in k_fr_sweep)
+__global__ __launch_bounds__(256) void k_mark_inf(double* __restrict__ rho2, const int* __restrict__ sel, const DevState* st) {
+    for (int t = threadIdx.x; t < st->nsel; t += 256) rho2[sel[t]] = __builtin_inf();
 }
 
 }  // namespace csmp

@@ -113,6 +113,14 @@ int csmp_fr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double max_eps
  * src/stepwise.jl:52): delta2 receives N Float64 scores (host). */
 int csmp_fr_scores(csmp_ctx *ctx, double *delta2);
 
+/* srr(A,b,k,delta; maxiter,initialization,l): stepwise regression with replacement, src/twostage.jl:3-33,
+ * x starting empty.  initialization 1 = oblivious_acquisition! (src/matchingpursuit.jl:207-216),
+ * 2 = k forward-regression steps; each iteration takes l forward steps (src/forward.jl:56-73) and then
+ * backward steps (src/backward.jl:51-83) until k atoms remain.  maxiter < 0 selects the default 4k.
+ * Capacity k + l (at most 1023).  *iters (may be NULL) = iterations made. */
+int csmp_srr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+             int64_t l, int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
+
 /* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);

@@ -672,3 +672,185 @@ int cso_fr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const dou
     act_free(&S);
     return CSO_OK;
 }
+
+/* ---------------------------------------------------------------- stepwise regression with replacement
+ * srr(A,b,k,δ; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty.
+ *   initialization 1: oblivious_acquisition! (src/matchingpursuit.jl:207-216): the k atoms best
+ *                     correlated with b;   2: k forward-regression steps update!(P::FR, x) (:12-15)
+ *   each iteration: l forward steps forward_step!(P,x,0,0) (src/forward.jl:56-73), then
+ *   backward_step!(P,x,Inf,Inf) (src/backward.jl:51-67) until nnz(x) == k: the atom with the
+ *   smallest δ²_i = x_i² / γ_i, γ = diag((R'R)^-1) (backward_δ!/get_gamma :70-83) leaves; first
+ *   minimum in nzind order.  Stops when norm(r) <= δ or the residual did not decrease (:28-30).
+ * The factorisation is rebuilt from scratch (in nzind order) whenever the support changes, and the
+ * forward rescaling |a_j|² - |Q'a_j|² is recomputed from that fresh factorisation for every atom:
+ * O(M N k) per step, small problems only -- deliberately none of the product's incremental tricks. */
+typedef struct {
+    const void *A;
+    int dtype;
+    int64_t M, N, ld;
+    const double *b;
+    int64_t *S; /* sorted support */
+    int64_t n;
+    double *coef, *r, *norm2;
+    hqr_t F;
+    int nthreads;
+} srr_t;
+
+static void srr_refit(srr_t *P) { /* QR of A[:, S] in nzind order; coef = AiQR \ b; r = b - A x */
+    P->F.j = 0;
+    double *a = (double *)malloc((size_t)P->M * sizeof(double));
+    for (int64_t t = 0; t < P->n; ++t) {
+        col_to_f64(P->A, P->dtype, P->M, P->ld, P->S[t], a);
+        hqr_append(&P->F, a);
+    }
+    free(a);
+    if (P->n > 0) hqr_solve(&P->F, P->b, P->coef);
+    cso_residual(P->A, P->dtype, P->M, P->ld, P->S, P->coef, P->n, P->b, P->r);
+}
+static void srr_insert(srr_t *P, int64_t i) {
+    int64_t p = P->n;
+    while (p > 0 && P->S[p - 1] > i) {
+        P->S[p] = P->S[p - 1];
+        --p;
+    }
+    P->S[p] = i;
+    P->n += 1;
+}
+static int srr_in(const srr_t *P, int64_t i) {
+    for (int64_t t = 0; t < P->n; ++t)
+        if (P->S[t] == i) return 1;
+    return 0;
+}
+/* forward_step!(P, x, max_eps, min_delta) with the rescaling from scratch; returns 1 if an atom was added */
+static int srr_forward(srr_t *P, double max_eps, double min_d2, int guarded) {
+    if (!(P->n < P->M)) return 0;
+    if (guarded && !(nrm2(P->r, P->M) > max_eps)) return 0;
+    const int64_t M = P->M, N = P->N, n = P->n;
+    double *d2 = (double *)malloc((size_t)N * sizeof(double));
+#pragma omp parallel num_threads(P->nthreads)
+    {
+        double *w = (double *)malloc((size_t)M * sizeof(double));
+#pragma omp for schedule(static)
+        for (int64_t j = 0; j < N; ++j) {
+            col_to_f64(P->A, P->dtype, M, P->ld, j, w);
+            double c = 0.0;
+            for (int64_t t = 0; t < M; ++t) c += w[t] * P->r[t];
+            hqr_apply_qt(&P->F, w); /* first n entries = Q_S' a_j */
+            double resc = P->norm2[j];
+            for (int64_t t = 0; t < n; ++t) resc -= w[t] * w[t];
+            d2[j] = c * c / resc;
+        }
+        free(w);
+    }
+    for (int64_t t = 0; t < n; ++t) d2[P->S[t]] = 0.0;
+    int64_t best = 0;
+    double bv = -1.0;
+    for (int64_t j = 0; j < N; ++j)
+        if (d2[j] > bv) {
+            bv = d2[j];
+            best = j;
+        }
+    free(d2);
+    if (guarded && !(min_d2 < bv)) return 0;
+    if (srr_in(P, best)) return 0; /* addindex! is a no-op for an atom already in the support */
+    srr_insert(P, best);
+    srr_refit(P);
+    return 1;
+}
+/* backward_step!(P, x, Inf, Inf): drops the atom of least δ² = x_i²/γ_i; returns 1 if one was dropped */
+static int srr_backward(srr_t *P) {
+    const int64_t n = P->n;
+    if (!(n > 0)) return 0;
+    double *y = (double *)malloc((size_t)n * sizeof(double));
+    int64_t best = -1;
+    double bv = INFINITY;
+    for (int64_t p = 0; p < n; ++p) { /* γ_p = |R^-T e_p|² */
+        for (int64_t t = 0; t < n; ++t) y[t] = 0.0;
+        y[p] = 1.0 / P->F.R[p * P->F.cap + p];
+        double g = y[p] * y[p];
+        for (int64_t i = p + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int64_t t = p; t < i; ++t) s += P->F.R[i * P->F.cap + t] * y[t];
+            y[i] = -s / P->F.R[i * P->F.cap + i];
+            g += y[i] * y[i];
+        }
+        const double d = P->coef[p] * P->coef[p] / g;
+        if (d < bv) { /* findmin: first minimum */
+            bv = d;
+            best = p;
+        }
+    }
+    free(y);
+    if (best < 0) return 0; /* all NaN */
+    for (int64_t t = best; t + 1 < n; ++t) P->S[t] = P->S[t + 1];
+    P->n -= 1;
+    srr_refit(P);
+    return 1;
+}
+
+int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+            double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
+            int64_t *nnz, int64_t *iters, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    if (nthreads > 16) nthreads = 16;
+#else
+    nthreads = 1;
+#endif
+    if (k < 1 || k > N || k + l > M || l < 1) return CSO_ERANGE;
+    if (initialization != 1 && initialization != 2) return CSO_EINVAL;
+    if (maxiter < 0) maxiter = 4 * k; /* :5 */
+    srr_t P;
+    memset(&P, 0, sizeof P);
+    P.A = A; P.dtype = dtype; P.M = M; P.N = N; P.ld = ld; P.b = b; P.nthreads = nthreads;
+    P.S = (int64_t *)malloc((size_t)(k + l + 1) * sizeof(int64_t));
+    P.coef = (double *)calloc((size_t)(k + l + 1), sizeof(double));
+    P.r = (double *)malloc((size_t)M * sizeof(double));
+    P.norm2 = (double *)malloc((size_t)N * sizeof(double));
+    if (hqr_init(&P.F, M, k + l) != 0) return CSO_ENOMEM;
+    for (int64_t j = 0; j < N; ++j) {
+        double s = 0.0;
+        for (int64_t i = 0; i < M; ++i) {
+            const double a = a_at(A, dtype, ld, i, j);
+            s += a * a;
+        }
+        P.norm2[j] = s;
+    }
+    memcpy(P.r, b, (size_t)M * sizeof(double));
+    if (initialization == 1) { /* oblivious_acquisition!(P, x, k) */
+        double *Ar = (double *)malloc((size_t)N * sizeof(double));
+        int64_t *top = (int64_t *)malloc((size_t)k * sizeof(int64_t));
+        cso_sweep_abs(A, dtype, M, N, ld, P.r, Ar, nthreads);
+        cso_topk_desc(Ar, N, k, top);
+        for (int64_t t = 0; t < k; ++t) srr_insert(&P, top[t]);
+        srr_refit(&P);
+        free(Ar);
+        free(top);
+    } else { /* k times update!(P::FR, x): src/forward.jl:88-95 (no residual / decrease guards) */
+        for (int64_t t = 0; t < k; ++t) srr_forward(&P, 0.0, 0.0, 0);
+    }
+    double resnorm = nrm2(P.r, M); /* :18 */
+    int64_t it = 0;
+    while (it < maxiter) { /* :19 */
+        const double oldnorm = resnorm;
+        for (int64_t s = 0; s < l; ++s)
+            if (!srr_forward(&P, 0.0, 0.0, 1)) break; /* :21-23 */
+        while (P.n > k)
+            if (!srr_backward(&P)) break; /* :24-26 */
+        resnorm = nrm2(P.r, M);
+        ++it;
+        if (resnorm <= delta || oldnorm <= resnorm) break; /* :28-30 */
+    }
+    for (int64_t t = 0; t < P.n; ++t) {
+        idx[t] = P.S[t];
+        val[t] = P.coef[t];
+    }
+    *nnz = P.n;
+    if (iters) *iters = it;
+    free(P.S);
+    free(P.coef);
+    free(P.r);
+    free(P.norm2);
+    hqr_free(&P.F);
+    return CSO_OK;
+}

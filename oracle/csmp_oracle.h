@@ -71,6 +71,12 @@ int cso_fr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const dou
            double max_eps, double min_delta, int64_t *idx, double *val, int64_t *nnz, int64_t *order,
            int nthreads);
 
+/* srr(A,b,k,delta; maxiter,initialization,l): src/twostage.jl:3-33 (x starts empty; initialization
+ * 1 = oblivious, 2 = forward regression).  maxiter < 0 selects the default 4k.  idx/val sized >= k + l. */
+int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+            double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
+            int64_t *nnz, int64_t *iters, int nthreads);
+
 /* step primitives, exported so tests can pin them one by one */
 /* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
 int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,

@@ -206,3 +206,70 @@ def fr(A, b, k, max_eps=0.0, min_delta=0.0):
         order.append(i)
         val = _ls(A, idx, b)  # :67
     return idx, val, np.array(order, np.int64)
+
+
+def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
+    """Stepwise regression with replacement: src/twostage.jl:3-33 (x starts empty).  Forward scores as
+    in fr() above; backward scores x_i^2 / diag(inv(As'As))_i (src/backward.jl:70-83) from a dense
+    inverse -- independent of the C restatement's triangular solves."""
+    A, b = _f64(A, b)
+    M, N = A.shape
+    if maxiter is None:
+        maxiter = 4 * k
+    norm2 = np.sum(A * A, axis=0)
+
+    def fit(idx):
+        val = _ls(A, idx, b) if len(idx) else np.zeros(0)
+        return val, _residual(A, b, idx, val)
+
+    def forward(idx, val, r, guarded):
+        if not len(idx) < M:
+            return idx, val, r, False
+        if guarded and not np.linalg.norm(r) > 0:
+            return idx, val, r, False
+        resc = norm2.copy()
+        if len(idx):
+            Q = np.linalg.qr(A[:, idx])[0]
+            resc = resc - np.sum((Q.T @ A) ** 2, axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d2 = (A.T @ r) ** 2 / resc
+        d2[idx] = 0.0
+        d2 = np.where(np.isnan(d2), -1.0, d2)
+        i = int(np.argmax(d2))
+        if (guarded and not 0 < d2[i]) or i in idx:
+            return idx, val, r, False
+        idx = np.sort(np.append(idx, i))
+        val, r = fit(idx)
+        return idx, val, r, True
+
+    def backward(idx, val, r):
+        As = A[:, idx]
+        gamma = np.diag(np.linalg.inv(As.T @ As))
+        j = int(np.argmin(val ** 2 / gamma))  # first minimum in nzind order
+        idx = np.delete(idx, j)
+        val, r = fit(idx)
+        return idx, val, r
+
+    idx = np.zeros(0, np.int64)
+    val, r = fit(idx)
+    if initialization == 1:
+        idx = np.sort(_topk(_abs_corr(A, b), k)).astype(np.int64)
+        val, r = fit(idx)
+    else:
+        for _ in range(k):
+            idx, val, r, _ok = forward(idx, val, r, False)
+    resnorm = np.linalg.norm(r)
+    iters = 0
+    for _ in range(maxiter):
+        oldnorm = resnorm
+        for _s in range(l):
+            idx, val, r, ok = forward(idx, val, r, True)
+            if not ok:
+                break
+        while len(idx) > k:
+            idx, val, r = backward(idx, val, r)
+        resnorm = np.linalg.norm(r)
+        iters += 1
+        if resnorm <= delta or oldnorm <= resnorm:
+            break
+    return idx, val, iters

@@ -178,6 +178,26 @@ b = A[:, rng.choice(600, 16, replace=False)] @ rng.standard_normal(16) + 1e-3 * 
 fr_case("fr_coherent_48x600", A, b, 16)
 assert not np.array_equal(out["fr_coherent_48x600.order"], oc.omp(A, b, 16, 0.0)[2])
 
+
+
+# stepwise regression with replacement (src/twostage.jl:3-33).  params = [k, delta, initialization, l, iterations]
+def srr_case(name, A, b, k, init, l):
+    r = oc.srr(A, b, k, 1e-12, -1, init, l)
+    t = on.srr(A, b, k, 1e-12, None, init, l)
+    agree(r[:2], t[:2], name)
+    assert r[2] == t[2]
+    add(name, "srr", A, b, [k, 1e-12, init, l, r[2]], r[:2])
+
+
+A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=91)  # test/twostage.jl:6-9
+srr_case("srr_ref_32x64", A, cs.perturb(b, 5e-3, rng=92), 3, 1, 1)
+srr_case("srr_ref_32x64_l3", A, cs.perturb(b, 5e-3, rng=92), 3, 1, 3)
+A, x, b = cs.sparse_data(n=128, m=512, k=14, rng=93, dtype=np.float32)
+y = cs.perturb(b, 2e-1, rng=94)
+srr_case("srr_f32_128x512_k12", A, y, 12, 1, 1)  # two atoms fewer than planted, noisy: several replacements
+assert out["srr_f32_128x512_k12.params"][4] >= 3
+srr_case("srr_f32_128x512_k12_init2", A, y, 12, 2, 1)
+
 out["names"] = np.array(names)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
 np.savez_compressed(path, **out)

@@ -50,6 +50,9 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         elif c["algo"] == "gomp":
             idx, val, order = d.ctx.gomp(b, int(p[0]), int(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
+        elif c["algo"] == "srr":
+            idx, val, iters = d.ctx.srr(b, int(p[0]), float(p[1]), -1, int(p[2]), int(p[3]))
+            assert iters == int(p[4]), name
         elif c["algo"] == "fr":
             idx, val, order = d.ctx.fr(b, int(p[0]), float(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
@@ -62,7 +65,7 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         else:  # gomp_dupcols: an atom AND its exact copy are both selected -> singular least squares;
             pass  # the reference's own coefficients are NaN/Inf there, only the support is defined
         ran += 1
-    assert ran == len(golden) >= 27
+    assert ran == len(golden) >= 31
 
 
 @pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])
@@ -817,3 +820,45 @@ def test_qr_column_removal(cs, D, cfg):
             check(supp)
     idx, val, res, order, stop = d.ctx.solver_state(k + 2)
     assert len(idx) == 0 and np.isclose(res, np.linalg.norm(y), rtol=1e-10)
+
+
+# ------------------------------------------------------------------------------------------------
+# stepwise regression with replacement (srr, src/twostage.jl:3-33): forward steps + backward steps
+@pytest.mark.parametrize("cfg", [(32, 64, 3, 1, np.float64), (32, 64, 3, 3, np.float64), (128, 512, 12, 1, np.float32),
+                                 (128, 512, 8, 4, np.float32), (100, 333, 9, 2, np.float64), (256, 2048, 24, 1, np.float32),
+                                 (512, 4096, 40, 1, np.float32), (1024, 3000, 30, 5, np.float32)])
+@pytest.mark.parametrize("init", [1, 2])
+def test_srr_matches_oracle(cs, oracle, D, cfg, init):
+    n, m, k, l, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m + k, dtype=dtype)
+    d = D(A)
+    for seed, noise in ((0, 0.0), (1, 5e-3), (2, 2e-1)):  # the noisy cases make the replacement loop work
+        xs = cs.sparse_vector(m, k + 2, rng=seed)  # two atoms more than srr may keep
+        y = A[:, xs.nzind].astype(np.float64) @ xs.nzval
+        if noise:
+            y = cs.perturb(y, noise, rng=seed + 50)
+        ref = oracle.srr(A, y, k, 1e-12, -1, init, l)
+        got = d.ctx.srr(y, k, 1e-12, -1, init, l)
+        assert np.array_equal(got[0], ref[0]), (seed, got, ref)
+        assert close(got[1], ref[1], tight=False)
+        assert got[2] == ref[2], "iterations"
+    xg = cs.srr(d, y, k, initialization=init, l=l)
+    assert np.array_equal(xg.nzind, ref[0])
+
+
+def test_srr_reference_known_answer(cs, D):
+    """test/twostage.jl:11-39 on seeded data: planted recovery, noiseless / noisy, k = 1, and l = k."""
+    ok = 0
+    for seed in range(8):
+        A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=100 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        d = D(A)
+        good = True
+        for bb, l in ((b, 1), (y, 1), (b, 3), (y, 3)):
+            xs = cs.srr(d, bb, 3, l=l)
+            good &= np.array_equal(xs.nzind, x.nzind) and np.allclose(xs.nzval, x.nzval, atol=3e-2)
+        x1 = cs.sparse_vector(64, 1, rng=seed)
+        xs = cs.srr(d, A[:, x1.nzind] @ x1.nzval, 1)
+        good &= np.array_equal(xs.nzind, x1.nzind) and np.allclose(xs.nzval, x1.nzval)
+        ok += good
+    assert ok >= 7

@@ -20,13 +20,15 @@ def run_case(oracle, c):
         return oracle.mp(A, b, int(p[0]))
     if c["algo"] == "sp":
         return oracle.sp(A, b, int(p[0]), float(p[1]))
+    if c["algo"] == "srr":
+        return oracle.srr(A, b, int(p[0]), float(p[1]), -1, int(p[2]), int(p[3]))
     if c["algo"] == "fr":
         return oracle.fr(A, b, int(p[0]), float(p[1]), float(p[2]))
     raise AssertionError(c["algo"])
 
 
 def test_golden_vectors(oracle, golden):
-    assert len(golden) >= 27
+    assert len(golden) >= 31
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
@@ -36,6 +38,8 @@ def test_golden_vectors(oracle, golden):
             assert np.array_equal(r[2], c["order"]), name
         if c["algo"] == "sp":
             assert r[2] == int(c["params"][2]), name
+        if c["algo"] == "srr":
+            assert r[2] == int(c["params"][4]), name
 
 
 # ---- the reference's known-answer tests (planted recovery), on seeded instances
@@ -233,3 +237,31 @@ def test_reference_fr_property_and_twin(oracle, cs):
     # k >= M: the nnz(x) < size(A,1) guard ends the loop (src/forward.jl:58)
     A, x, b = cs.sparse_data(n=6, m=20, k=2, rng=5)
     assert len(oracle.fr(A, cs.perturb(b, 0.1, rng=2), 15)[0]) <= 6
+
+
+def test_reference_srr_property_and_twin(oracle, cs):
+    """test/twostage.jl:11-39 (planted recovery with srr, noiseless / noisy / k = 1 / l = k) on seeded data,
+    and the C restatement against the numpy twin (dense inverse for the backward scores)."""
+    from oracle import oracle_np
+    ok = 0
+    for seed in range(20):
+        A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=4000 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        good = True
+        for bb, l in ((b, 1), (y, 1), (b, 3), (y, 3)):
+            r = oracle.srr(A, bb, 3, l=l)
+            t = oracle_np.srr(A, bb, 3, l=l)
+            assert np.array_equal(r[0], t[0]) and r[2] == t[2]
+            np.testing.assert_allclose(r[1], t[1], rtol=1e-9, atol=1e-12)
+            good &= np.array_equal(r[0], x.nzind) and np.allclose(r[1], x.nzval, atol=3e-2)
+        x1 = cs.sparse_vector(64, 1, rng=seed)
+        r = oracle.srr(A, A[:, x1.nzind] @ x1.nzval, 1)
+        good &= np.array_equal(r[0], x1.nzind) and np.allclose(r[1], x1.nzval)
+        ok += good
+    assert ok >= 18
+    for (n, m, k, l, init) in [(128, 512, 12, 1, 1), (128, 512, 8, 4, 2), (100, 333, 9, 2, 1), (256, 1024, 20, 1, 2)]:
+        A, x, b = cs.sparse_data(n=n, m=m, k=k + 2, rng=n + k, dtype=np.float32)
+        y = cs.perturb(b, 1e-1, rng=3)
+        r, t = oracle.srr(A, y, k, 1e-12, -1, init, l), oracle_np.srr(A, y, k, 1e-12, None, init, l)
+        assert np.array_equal(r[0], t[0]) and r[2] == t[2], (n, m, k, l, init)
+        np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
