@@ -613,6 +613,20 @@ static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
 static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
                          int* d_flag = nullptr) {
     Solver& s = ctx->s;
+    if (s.kcap <= 1024) {  // single-wave form
+        const size_t lds = (size_t)s.kcap * sizeof(int);
+        if (s.kcap <= 256)
+            hipLaunchKernelGGL(k_finish_w<4>, dim3(1), dim3(64), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
+                               (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
+        else if (s.kcap <= 512)
+            hipLaunchKernelGGL(k_finish_w<8>, dim3(1), dim3(64), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
+                               (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
+        else
+            hipLaunchKernelGGL(k_finish_w<16>, dim3(1), dim3(64), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
+                               (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
     const size_t lds = (size_t)(s.kcap + 2) * sizeof(double);
     hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
                        (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
@@ -1740,8 +1754,12 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
                 pend.clear();
                 unmark = false;
             }
-            hipLaunchKernelGGL(k_bwd_scores, dim3(n), dim3(64), (size_t)n * sizeof(double), ctx->stream, (const double*)s.R, s.kcap,
-                               (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
+            if (n <= 257)
+                hipLaunchKernelGGL((k_bwd_scores<4, 4>), dim3(n), dim3(64), 0, ctx->stream, (const double*)s.R,
+                                   s.kcap, (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
+            else
+                hipLaunchKernelGGL((k_bwd_scores<16, 2>), dim3(n), dim3(64), 0, ctx->stream, (const double*)s.R,
+                                   s.kcap, (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
             HIPCHECK(hipGetLastError());
             hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
                                (const DevState*)s.st, (const double*)s.r, (int)ctx->M, (double)HUGE_VAL, (double)HUGE_VAL, s.delpos,

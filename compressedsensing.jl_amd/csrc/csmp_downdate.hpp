@@ -75,9 +75,17 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
             const int i = ib + u;
             if (i <= n - 2) {  // uniform
                 if (iscol && c == i + 1) {  // old column i+1 closes rotation i: rows (i, i+1) -> (rr, 0)
+                    // (cs, sn) = (carry, d) / sqrt(carry^2 + d^2) from v_rsq_f64 + two Newton steps: this is the
+                    // serial chain of the kernel, and hypot() + a division cost ~4x as much.  Entries of R
+                    // are O(1) for unit-norm atoms, so the squares neither overflow nor underflow.
                     const double d = pre[u];
-                    const double rr = hypot(carry, d);
-                    const double inv = rr > 0.0 ? 1.0 / rr : 0.0;
+                    const double ss = fma(carry, carry, d * d), hs = 0.5 * ss;
+                    double inv = __builtin_amdgcn_rsq(ss);
+                    inv = inv * fma(-hs * inv, inv, 1.5);
+                    inv = inv * fma(-hs * inv, inv, 1.5);
+                    const bool okr = ss > 0.0 && ss < 1e300;
+                    const double rr = okr ? ss * inv : hypot(carry, d);
+                    if (!okr) inv = rr > 0.0 ? 1.0 / rr : 0.0;
                     const double cs = rr > 0.0 ? carry * inv : 1.0, sn = d * inv;
                     gcs[i] = cs;
                     gsn[i] = sn;
@@ -85,7 +93,7 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
                     G[2 * i + 1] = sn;
                     Rnew[(int64_t)i * kcap + i] = rr;
                 }
-                __syncthreads();
+                lds_barrier();
                 if ((iscol && c > i + 1) || isz) {
                     const double cs = gcs[i], sn = gsn[i], x = pre[u];
                     const double top = fma(cs, carry, sn * x);
@@ -174,26 +182,71 @@ __global__ __launch_bounds__(256) void k_find_pos(const int* __restrict__ sel, c
 // block; then gamma_p = |y|^2 = ((R'R)^-1)_pp, x_p = y'z (the least-squares coefficient of atom
 // sel[p]) and delta2_p = x_p^2 / gamma_p: the growth of |r|^2 if that atom were removed
 // (src/backward.jl:77-83).  out[p] = delta2_p, coef[p] = x_p.
+// Right-looking, one wave, no LDS: lane l owns the columns i = p+1+l+64u of R (contiguous in memory)
+// with a partial sum each; at step t every lane adds R[t,i] y_t to its sums, the owner of column t+1
+// closes y_{t+1} and v_readlane broadcasts it.  R values are requested D steps ahead.
+template <int NU, int D>
 __global__ __launch_bounds__(64) void k_bwd_scores(const double* __restrict__ R, int kcap, const double* __restrict__ z,
                                                    const DevState* st, double* __restrict__ out,
                                                    double* __restrict__ coef) {
-    extern __shared__ __attribute__((aligned(16))) double y[];  // n
     const int n = st->nsel, p = blockIdx.x, lane = threadIdx.x;
     if (p >= n) return;
-    if (lane == 0) y[p] = 1.0 / R[(int64_t)p * kcap + p];
-    __syncthreads();
-    for (int i = p + 1; i < n; ++i) {
-        const double* col = R + (int64_t)i * kcap;
-        double s = 0.0;
-        for (int t = p + lane; t < i; t += 64) s = fma(col[t], y[t], s);
-        for (int sft = 32; sft >= 1; sft >>= 1) s += shx(s, sft);
-        if (lane == 0) y[i] = -s / col[i];
-        __syncthreads();
+    const double* colp[NU];
+    double acc[NU], rdg[NU], zr[NU];
+    bool own[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = p + 1 + lane + 64 * u;
+        own[u] = i < n;
+        colp[u] = R + (int64_t)(own[u] ? i : p) * kcap;
+        acc[u] = 0.0;
+        rdg[u] = own[u] ? 1.0 / colp[u][i] : 0.0;
+        zr[u] = own[u] ? z[i] : 0.0;
     }
+    double yt = 1.0 / R[(int64_t)p * kcap + p];
     double g = 0.0, x = 0.0;
-    for (int t = p + lane; t < n; t += 64) {
-        g = fma(y[t], y[t], g);
-        x = fma(y[t], z[t], x);
+    if (lane == 0) {
+        g = yt * yt;
+        x = yt * z[p];
+    }
+    double cur[D][NU], nxt[D][NU];
+    auto fetch = [&](double (*dst)[NU], int t0) {  // rows t0 .. t0+D-1 of the owned columns (row t < column index)
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int t = t0 + d, i = p + 1 + lane + 64 * u;
+                dst[d][u] = (own[u] && t < i) ? colp[u][t] : 0.0;
+            }
+    };
+    fetch(cur, p);
+    for (int tb = p; tb <= n - 2; tb += D) {
+        fetch(nxt, tb + D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tb + d;
+            if (t <= n - 2) {  // uniform
+                const int rel = t - p, su = rel >> 6, sl = rel & 63;  // column t+1: lane sl, slot su
+                double mine = 0.0, zs = 0.0;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    acc[u] = fma(cur[d][u], yt, acc[u]);
+                    if (u == su) {
+                        mine = -acc[u] * rdg[u];
+                        zs = zr[u];
+                    }
+                }
+                yt = readlane_f64(mine, sl);
+                if (lane == sl) {
+                    g = fma(yt, yt, g);
+                    x = fma(yt, zs, x);
+                }
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
     }
     for (int sft = 32; sft >= 1; sft >>= 1) {
         g += shx(g, sft);

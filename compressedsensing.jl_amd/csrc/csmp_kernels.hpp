@@ -59,6 +59,16 @@ __device__ __forceinline__ double block_sum256(double v, double* scratch4) {
 }
 
 __device__ __forceinline__ double shx(double v, int m) { return __shfl_xor(v, m, kWave); }
+// value of lane `src` (uniform) in every lane: two v_readlane_b32, no LDS round trip
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding
+// global load and store (s_waitcnt vmcnt(0)), which would serialise a latency chain with the
+// look-ahead loads it is supposed to overlap
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // lexicographic "better": larger value wins, ties go to the LOWER index (Julia argmax = first max)
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) {
@@ -1257,6 +1267,73 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ R, co
         out_val[rank] = y[t];
     }
     if (tid == 0) {
+        *out_nnz = j;
+        if (flag_out) *flag_out = st->done;
+    }
+}
+
+// The same for kcap <= 64*NU as ONE wave with y in registers (lane l owns rows l + 64u): no barrier and
+// no LDS in the chain -- the coefficient of column i is formed by its owner and broadcast with
+// v_readlane -- and reciprocal diagonals formed up front, so the division leaves the chain too.
+// ~0.05 us per column instead of ~0.5: this kernel closes every solve and every OMPR iteration.
+template <int NU>
+__global__ __launch_bounds__(64) void k_finish_w(const double* __restrict__ R, const double* __restrict__ z,
+                                                 const int* __restrict__ sel, const DevState* st, int kcap,
+                                                 double* __restrict__ coef, int64_t* __restrict__ out_idx,
+                                                 double* __restrict__ out_val, int64_t* __restrict__ out_nnz,
+                                                 int64_t* __restrict__ out_order, int outcap, int* __restrict__ flag_out) {
+    extern __shared__ __attribute__((aligned(16))) int ssel[];  // kcap
+    const int lane = threadIdx.x, j = st->nsel;
+    double yr[NU], rdr[NU], rc[NU], rn[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int t = lane + 64 * u;
+        yr[u] = t < j ? z[t] : 0.0;
+        rdr[u] = t < j ? 1.0 / R[(int64_t)t * kcap + t] : 0.0;
+    }
+    for (int t = lane; t < j; t += 64) ssel[t] = sel[t];
+    auto fetch = [&](double* dst, int i) {  // column i above the diagonal: rows lane + 64u < i (zero elsewhere)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int t = lane + 64 * u;
+            dst[u] = (i >= 0 && t < i) ? R[(int64_t)i * kcap + t] : 0.0;
+        }
+    };
+    fetch(rc, j - 1);
+    for (int i = j - 1; i >= 0; --i) {
+        fetch(rn, i - 1);
+        const int su = i >> 6, sl = i & 63;
+        double mine = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if (u == su) mine = yr[u] * rdr[u];
+        const double c = readlane_f64(mine, sl);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            yr[u] = fma(-rc[u], c, yr[u]);
+            if (u == su && lane == sl) yr[u] = c;
+            rc[u] = rn[u];
+        }
+    }
+    for (int t = lane; t < outcap; t += 64) {
+        out_idx[t] = -1;
+        out_val[t] = 0.0;
+        if (out_order) out_order[t] = (t < j) ? sel[t] : -1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int t = lane + 64 * u;
+        if (t < j) {
+            coef[t] = yr[u];
+            const int me = ssel[t];
+            int rank = 0;
+            for (int q = 0; q < j; ++q) rank += (ssel[q] < me);
+            out_idx[rank] = me;
+            out_val[rank] = yr[u];
+        }
+    }
+    if (lane == 0) {
         *out_nnz = j;
         if (flag_out) *flag_out = st->done;
     }
