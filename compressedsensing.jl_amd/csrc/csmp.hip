@@ -8,6 +8,7 @@
 #include "csmp_block.hpp"
 #include "csmp_forward.hpp"
 #include "csmp_downdate.hpp"
+#include "csmp_tinv.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -54,6 +55,9 @@ struct Solver {
     // column removal (csmp_downdate.hpp), allocated on first use
     double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *qsave = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
     int *delmeta = nullptr, *delpos = nullptr;
+    // explicit inverse factor of the two-stage solvers (csmp_tinv.hpp)
+    double *T = nullptr, *T2 = nullptr, *tpd = nullptr, *tpn = nullptr;
+    int* tmeta = nullptr;
     int sigcap = 0;
 };
 
@@ -219,6 +223,7 @@ static void solver_free(Solver& s) {
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
+    dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta);
     s = Solver();
 }
 
@@ -774,6 +779,7 @@ struct FrPass {
     double s1 = -1.0;
     const double* q2 = nullptr;
     double s2 = 1.0;
+    int64_t qstride = 0;  // nq == 4: the directions are q1 + d*qstride
     const int* unmark = nullptr;
     int update_only = 0;
 };
@@ -797,7 +803,17 @@ static hipError_t fr_sweep_launch_nq(csmp_ctx* ctx, const FrPass& ps, int grid, 
         case -1: return fr_sweep_launch_t<TA, U, FULL, -1>(ctx, ps, grid, lds, max_eps, skipmask);
         case 0: return fr_sweep_launch_t<TA, U, FULL, 0>(ctx, ps, grid, lds, max_eps, skipmask);
         case 1: return fr_sweep_launch_t<TA, U, FULL, 1>(ctx, ps, grid, lds, max_eps, skipmask);
-        default: return fr_sweep_launch_t<TA, U, FULL, 2>(ctx, ps, grid, lds, max_eps, skipmask);
+        case 2: return fr_sweep_launch_t<TA, U, FULL, 2>(ctx, ps, grid, lds, max_eps, skipmask);
+        default: {
+            auto kern = k_fr_update4<TA, U, FULL>;
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+                               ps.q1, ps.qstride, ps.s1, ctx->s.rho2);
+            return hipGetLastError();
+        }
     }
 }
 template <typename TA>
@@ -1152,6 +1168,89 @@ static int launch_delete_atom(csmp_ctx* ctx, int atom) {
     hipLaunchKernelGGL(k_find_pos, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, atom, s.delpos);
     HIPCHECK(hipGetLastError());
     return launch_delete(ctx);
+}
+
+// ---- explicit-inverse mode (csmp_tinv.hpp): T = R^-1 kept next to R by the two-stage solvers
+static int tinv_ensure(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    CHECK(del_ensure(ctx));
+    if (s.T) return CSMP_OK;
+    const size_t nch = (size_t)(s.kcap + kTChunk - 1) / kTChunk;
+    CHECK(dmalloc(ctx, &s.T, (size_t)s.kcap * s.kcap));
+    CHECK(dmalloc(ctx, &s.T2, (size_t)s.kcap * s.kcap));
+    CHECK(dmalloc(ctx, &s.tpd, nch * s.kcap));
+    CHECK(dmalloc(ctx, &s.tpn, nch * s.kcap));
+    CHECK(dmalloc(ctx, &s.tmeta, 2));
+    return CSMP_OK;
+}
+// T = R^-1 for the columns factorised so far
+static int launch_tinv_build(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.kcap <= 257)
+        hipLaunchKernelGGL((k_tinv_build<4, 4>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
+                           (const DevState*)s.st, s.T, s.tmeta);
+    else
+        hipLaunchKernelGGL((k_tinv_build<16, 2>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
+                           (const DevState*)s.st, s.T, s.tmeta);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+static int launch_tinv_mv(csmp_ctx* ctx, int mode) {
+    Solver& s = ctx->s;
+    const dim3 grid((s.kcap + 63) / 64, (s.kcap + kTChunk - 1) / kTChunk);
+    hipLaunchKernelGGL(k_tinv_matvec, grid, dim3(64), 0, ctx->stream, (const double*)s.T, s.kcap, (const DevState*)s.st,
+                       (const int*)s.tmeta, (const double*)s.z, (const double*)s.R, mode, s.tpd, s.tpn);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_tinv_fin, dim3(1), dim3(256), 0, ctx->stream, s.T, s.kcap, (const DevState*)s.st, s.tmeta,
+                       (const double*)s.R, mode, (const double*)s.tpd, (const double*)s.tpn, s.bwd_coef, s.bwd);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+// after launch_append: the column the append may have added enters T (no-op if it added none)
+static int launch_tinv_append(csmp_ctx* ctx) { return launch_tinv_mv(ctx, 1); }
+// x = T z (insertion order, s.bwd_coef) and the backward scores x^2 / gamma (s.bwd)
+static int launch_tinv_solve(csmp_ctx* ctx) { return launch_tinv_mv(ctx, 0); }
+// remove_column!(AiQR, *delpos) with the rotations taken from T
+static int launch_delete_t(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    const int threads = std::min(1024, ((s.kcap + 1 + 63) / 64) * 64);
+    hipLaunchKernelGGL(k_tdel_prep, dim3(1), dim3(threads), 0, ctx->stream, (const double*)s.T, s.kcap, (const double*)s.z, s.sel,
+                       s.st, (const int*)s.delpos, s.Gdel, s.scal, s.delmeta, s.tmeta);
+    HIPCHECK(hipGetLastError());
+    const int NB = (s.kcap + 63) / 64;
+    hipLaunchKernelGGL(k_tdel_apply, dim3(s.G + 2 * NB + 1), dim3(64), 0, ctx->stream, s.Q, s.ldq, s.G, (const double*)s.T, s.T2,
+                       (const double*)s.R, s.R2, s.kcap, NB, s.z, (const double*)s.Gdel, (const double*)s.scal,
+                       (const int*)s.delmeta, s.r, s.qdrop, s.qsave);
+    HIPCHECK(hipGetLastError());
+    std::swap(s.T, s.T2);
+    std::swap(s.R, s.R2);
+    return CSMP_OK;
+}
+static int launch_delete_atom_t(csmp_ctx* ctx, int atom) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_find_pos, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, atom, s.delpos);
+    HIPCHECK(hipGetLastError());
+    return launch_delete_t(ctx);
+}
+// fetch_sorted in explicit-inverse mode: coefficients from T z, emitted in index order
+static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val) {
+    Solver& s = ctx->s;
+    CHECK(launch_tinv_solve(ctx));
+    hipLaunchKernelGGL(k_emit_sorted, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd_coef, (const int*)s.sel,
+                       (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap);
+    HIPCHECK(hipGetLastError());
+    idx.assign((size_t)s.outcap, 0);
+    val.assign((size_t)s.outcap, 0.0);
+    std::vector<int64_t> hi((size_t)s.outcap);
+    std::vector<double> hv((size_t)s.outcap);
+    int64_t hn = 0;
+    HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(&hn, s.out_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    idx.assign(hi.begin(), hi.begin() + hn);
+    val.assign(hv.begin(), hv.begin() + hn);
+    return CSMP_OK;
 }
 
 // dropindex!(x, AiQR, i) on the step-level solver (src/util.jl:137-161): atom leaves the support
@@ -1541,7 +1640,9 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     ctx->s.begun = false;
     Solver& s = ctx->s;
     const bool use_downdate = k <= kDelMaxCols && !getenv("CSMP_OMPR_REFACTOR");  // (knob: refactorise instead)
+    const bool tmode = use_downdate && !getenv("CSMP_NO_TINV");  // explicit inverse next to R (csmp_tinv.hpp)
     if (use_downdate) CHECK(del_ensure(ctx));
+    if (tmode) CHECK(tinv_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
     // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
     CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
@@ -1553,7 +1654,12 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     CHECK(ls_on_columns(ctx, top));
     std::vector<int64_t> xi;
     std::vector<double> xv;
-    CHECK(fetch_sorted(ctx, xi, xv));
+    if (tmode) {
+        CHECK(launch_tinv_build(ctx));
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+    } else {
+        CHECK(fetch_sorted(ctx, xi, xv));
+    }
     double resnorm = 0.0;
     CHECK(residual_norm(ctx, &resnorm));  // :192
     int64_t it = 0;
@@ -1608,11 +1714,15 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
                 const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
                 if (use_downdate) {
                     // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
-                    CHECK(launch_delete_atom(ctx, leaving));
+                    if (tmode)
+                        CHECK(launch_delete_atom_t(ctx, leaving));
+                    else
+                        CHECK(launch_delete_atom(ctx, leaving));
                     const int one = 1, ci = (int)cand;
                     HIPCHECK(hipMemcpyAsync(s.cands, &ci, 4, hipMemcpyHostToDevice, ctx->stream));
                     HIPCHECK(hipMemcpyAsync(s.ncands, &one, 4, hipMemcpyHostToDevice, ctx->stream));
                     CHECK(launch_append(ctx, 2, 0, 0));
+                    if (tmode) CHECK(launch_tinv_append(ctx));
                 } else {
                     std::vector<int> cols;
                     for (size_t t = 0; t <= xi.size(); ++t) {
@@ -1621,7 +1731,10 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
                     }
                     CHECK(ls_on_columns(ctx, cols));  // :178
                 }
-                CHECK(fetch_sorted(ctx, xi, xv));
+                if (tmode)
+                    CHECK(fetch_sorted_t(ctx, xi, xv));
+                else
+                    CHECK(fetch_sorted(ctx, xi, xv));
             }
         }
         CHECK(residual_norm(ctx, &resnorm));                 // :196
@@ -1658,6 +1771,8 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     CHECK(solver_ensure(ctx, kcap, kcap));
     CHECK(fr_ensure(ctx));
     CHECK(del_ensure(ctx));
+    const bool tmode = !getenv("CSMP_NO_TINV");  // explicit inverse next to R (csmp_tinv.hpp)
+    if (tmode) CHECK(tinv_ensure(ctx));
     Solver& s = ctx->s;
     s.begun = false;
     CHECK(upload_b(ctx, b, b_dtype));
@@ -1695,16 +1810,26 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         p0.nq = -1;
         p0.update_only = 1;
         CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
-        for (int64_t t = 0; t < k; t += 2) {
+        int U4, g4; bool f4; size_t lds4;
+        fr_config(ctx, 4, U4, f4, lds4, g4);
+        const bool four = lds4 <= 160 * 1024 - 512;  // four direction images fit the LDS (M <= ~5000)
+        for (int64_t t = 0; t < k;) {
             FrPass ps;
             ps.update_only = 1;
             ps.q1 = s.Q + t * s.ldq;
             ps.s1 = -1.0;
-            ps.nq = 1;
-            if (t + 1 < k) {
+            if (four && t + 4 <= k) {
+                ps.nq = 4;
+                ps.qstride = s.ldq;
+                t += 4;
+            } else if (t + 2 <= k) {
                 ps.nq = 2;
                 ps.q2 = s.Q + (t + 1) * s.ldq;
                 ps.s2 = -1.0;
+                t += 2;
+            } else {
+                ps.nq = 1;
+                t += 1;
             }
             CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
         }
@@ -1719,6 +1844,7 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         }
         pend.push_back({nullptr, -1.0});
     }
+    if (tmode) CHECK(launch_tinv_build(ctx));
     CHECK(read_state());
     int n = hs.nsel;
     if (hs.done) HIPCHECK(hipMemcpyAsync(&s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1730,6 +1856,7 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
             CHECK(launch_fr_pass(ctx, pass_of(0), 0.0, skipF));
             CHECK(launch_append(ctx, 3, 0, skipF, false, 0.0, s.fr_grid));
+            if (tmode) CHECK(launch_tinv_append(ctx));
             CHECK(read_state());
             if (hs.done & skipF) {
                 // the step failed.  A residual-norm stop returns before rho2 is touched; the other guards act
@@ -1754,7 +1881,9 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
                 pend.clear();
                 unmark = false;
             }
-            if (n <= 257)
+            if (tmode)
+                CHECK(launch_tinv_solve(ctx));
+            else if (n <= 257)
                 hipLaunchKernelGGL((k_bwd_scores<4, 4>), dim3(n), dim3(64), 0, ctx->stream, (const double*)s.R,
                                    s.kcap, (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
             else
@@ -1765,7 +1894,10 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
                                (const DevState*)s.st, (const double*)s.r, (int)ctx->M, (double)HUGE_VAL, (double)HUGE_VAL, s.delpos,
                                s.bwd_info);
             HIPCHECK(hipGetLastError());
-            CHECK(launch_delete(ctx));
+            if (tmode)
+                CHECK(launch_delete_t(ctx));
+            else
+                CHECK(launch_delete(ctx));
             CHECK(read_state());
             if (hs.nsel == n) break;  // nothing could be dropped (no finite score)
             for (Pend& e : pend)
@@ -1780,7 +1912,10 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     }
     std::vector<int64_t> xi;
     std::vector<double> xv;
-    CHECK(fetch_sorted(ctx, xi, xv));
+    if (tmode)
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+    else
+        CHECK(fetch_sorted(ctx, xi, xv));
     for (size_t t = 0; t < xi.size(); ++t) {
         if (idx) idx[t] = xi[t];
         if (val) val[t] = xv[t];

@@ -1,0 +1,344 @@
+// csmp_tinv.hpp -- the two-stage solvers' factorisation with an explicit T = R^-1 (gfx950).
+//
+// OMPR and SRR alternate one column in, one column out, and need the coefficients (OMPR) or the
+// backward scores (SRR) after every exchange (src/twostage.jl:19-31,158-178; src/backward.jl:51-83).
+// With R alone each of those is a chain of n dependent steps -- back substitution, n forward
+// substitutions for gamma = diag((R'R)^-1), Givens elimination of a Hessenberg R -- and on a GPU a
+// chain costs a memory round trip per step (~0.4 us measured, 50-200 us per operation at n = 256).
+// Keeping T = R^-1 next to R turns every one of them into independent dot products:
+//     coefficients    x = T z                                  (ldiv!, src/matchingpursuit.jl:170-176)
+//     backward scores gamma_p = |T[p,:]|^2, delta2_p = x_p^2 / gamma_p     (src/backward.jl:70-83)
+//     append          T[:,j] = (-T w / rho, 1 / rho)           (add_column!)
+//     removal of p    u = T[p,:] is, in Q coordinates, the direction that leaves the column space.
+//                     The plane rotations (i, i+1), i = p..n-2, that take u to sigma e_{n-1} are the
+//                     Givens rotations of the down-date, and they follow from PREFIX SUMS of u^2:
+//                     sigma_i^2 = u_p^2 + ... + u_i^2, cs_i = u_{i+1}/sigma_{i+1}, sn_i = -sigma_i/sigma_{i+1}
+//                     -- no elimination chain.  Rows of Q and T, columns of R and z then take the
+//                     rotations independently of one another (one thread each, loads known ahead).
+//                     (remove_column!, src/util.jl:152-161)
+// Accuracy: T carries cond(R) eps like any explicit inverse; the supports these solvers visit are
+// those of compressed-sensing dictionaries (cond(R) ~ 1-10^2), and the C oracle, which refactorises
+// from scratch at every change, is the referee in tests/.
+#pragma once
+#include "csmp_downdate.hpp"
+
+namespace csmp {
+
+constexpr int kTChunk = 32;  // columns per partial dot product
+constexpr int kTMaxCols = 1023;
+
+// tmeta[0] = number of columns T currently holds
+
+// Builds all of T from R: workgroup p (one wave) solves R' y = e_p (y = row p of T) right-looking:
+// lane l owns columns i = p+1+l+64u with a partial sum each, the owner of column t+1 closes y_{t+1}
+// and v_readlane broadcasts it.  Run once per solve, after the initial support has been factorised.
+template <int NU, int D>
+__global__ __launch_bounds__(64) void k_tinv_build(const double* __restrict__ R, int kcap, const DevState* st,
+                                                   double* __restrict__ T, int* __restrict__ tmeta) {
+    const int n = st->nsel, p = blockIdx.x, lane = threadIdx.x;
+    if (p == 0 && lane == 0) tmeta[0] = n;
+    if (p >= n) return;
+    const double* colp[NU];
+    double acc[NU], rdg[NU];
+    bool own[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int i = p + 1 + lane + 64 * u;
+        own[u] = i < n;
+        colp[u] = R + (int64_t)(own[u] ? i : p) * kcap;
+        acc[u] = 0.0;
+        rdg[u] = own[u] ? 1.0 / colp[u][i] : 0.0;
+    }
+    double yt = 1.0 / R[(int64_t)p * kcap + p];
+    if (lane == 0) T[(int64_t)p * kcap + p] = yt;
+    double cur[D][NU], nxt[D][NU];
+    auto fetch = [&](double (*dst)[NU], int t0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int t = t0 + d, i = p + 1 + lane + 64 * u;
+                dst[d][u] = (own[u] && t < i) ? colp[u][t] : 0.0;
+            }
+    };
+    fetch(cur, p);
+    for (int tb = p; tb <= n - 2; tb += D) {
+        fetch(nxt, tb + D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = tb + d;
+            if (t <= n - 2) {
+                const int rel = t - p, su = rel >> 6, sl = rel & 63;
+                double mine = 0.0;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    acc[u] = fma(cur[d][u], yt, acc[u]);
+                    if (u == su) mine = -acc[u] * rdg[u];
+                }
+                yt = readlane_f64(mine, sl);
+                if (lane == sl) T[(int64_t)(t + 1) * kcap + p] = yt;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
+    }
+}
+
+// Partial products of T with a vector: workgroup (rb, cb) covers rows rb*64 + lane and the kTChunk
+// columns of chunk cb; all kTChunk loads of a lane are independent.  mode 0: vec = z over the nsel
+// columns (+ squared row norms); mode 1 (append): the new column j = tmeta[0] of R holds w above its
+// diagonal, columns 0..j-1 of T take part -- nothing happens unless nsel > j.
+__global__ __launch_bounds__(64) void k_tinv_matvec(const double* __restrict__ T, int kcap, const DevState* st,
+                                                    const int* __restrict__ tmeta, const double* __restrict__ z,
+                                                    const double* __restrict__ R, int mode,
+                                                    double* __restrict__ pd, double* __restrict__ pn) {
+    const int n = st->nsel, j = tmeta[0];
+    int ncols;
+    const double* vec;
+    if (mode == 0) {
+        ncols = n;
+        vec = z;
+    } else {
+        if (!(n > j)) return;
+        ncols = j;
+        vec = R + (int64_t)j * kcap;
+    }
+    const int r = blockIdx.x * 64 + threadIdx.x, c0 = blockIdx.y * kTChunk;
+    if (c0 >= ncols) return;
+    double v[kTChunk];
+#pragma unroll
+    for (int q = 0; q < kTChunk; ++q) {
+        const int i = c0 + q;
+        v[q] = (r < ncols && i >= r && i < ncols) ? T[(int64_t)i * kcap + r] : 0.0;
+    }
+    double d = 0.0, s = 0.0;
+#pragma unroll
+    for (int q = 0; q < kTChunk; ++q) {
+        const int i = c0 + q;
+        const double x = i < ncols ? vec[i] : 0.0;
+        d = fma(v[q], x, d);
+        s = fma(v[q], v[q], s);
+    }
+    if (r < kcap) {
+        pd[(int64_t)blockIdx.y * kcap + r] = d;
+        pn[(int64_t)blockIdx.y * kcap + r] = s;
+    }
+}
+
+// Closes k_tinv_matvec.  mode 0: x = T z, gamma, delta2 = x^2 / gamma (src/backward.jl:81).
+// mode 1: column j of T from the partials with w: T[0:j, j] = -(T w) / rho, T[j, j] = 1 / rho.
+__global__ __launch_bounds__(256) void k_tinv_fin(double* __restrict__ T, int kcap, const DevState* st,
+                                                  int* __restrict__ tmeta, const double* __restrict__ R, int mode,
+                                                  const double* __restrict__ pd, const double* __restrict__ pn,
+                                                  double* __restrict__ coef, double* __restrict__ d2) {
+    const int n = st->nsel, j = tmeta[0];
+    if (mode == 0) {
+        const int nch = (n + kTChunk - 1) / kTChunk;
+        for (int r = threadIdx.x; r < n; r += 256) {
+            double x = 0.0, g = 0.0;
+            for (int c = r / kTChunk; c < nch; ++c) {
+                x += pd[(int64_t)c * kcap + r];
+                g += pn[(int64_t)c * kcap + r];
+            }
+            coef[r] = x;
+            d2[r] = x * x / g;
+        }
+        return;
+    }
+    if (!(n > j)) return;
+    const double rho = R[(int64_t)j * kcap + j];
+    const int nch = (j + kTChunk - 1) / kTChunk;
+    for (int r = threadIdx.x; r <= j; r += 256) {
+        if (r == j) {
+            T[(int64_t)j * kcap + j] = 1.0 / rho;
+        } else {
+            double x = 0.0;
+            for (int c = r / kTChunk; c < nch; ++c) x += pd[(int64_t)c * kcap + r];
+            T[(int64_t)j * kcap + r] = -x / rho;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tmeta[0] = j + 1;
+}
+
+// (index, coefficient) pairs in ascending index order from coefficients in insertion order (the tail of k_finish)
+__global__ __launch_bounds__(256) void k_emit_sorted(const double* __restrict__ coef, const int* __restrict__ sel,
+                                                     const DevState* st, int64_t* __restrict__ out_idx,
+                                                     double* __restrict__ out_val, int64_t* __restrict__ out_nnz,
+                                                     int64_t* __restrict__ out_order, int outcap) {
+    const int tid = threadIdx.x, j = st->nsel;
+    for (int t = tid; t < outcap; t += 256) {
+        out_idx[t] = -1;
+        out_val[t] = 0.0;
+        if (out_order) out_order[t] = (t < j) ? sel[t] : -1;
+    }
+    __syncthreads();
+    for (int t = tid; t < j; t += 256) {
+        const int me = sel[t];
+        int rank = 0;
+        for (int u = 0; u < j; ++u) rank += (sel[u] < me);
+        out_idx[rank] = me;
+        out_val[rank] = coef[t];
+    }
+    if (tid == 0) *out_nnz = j;
+}
+
+// Removal, step 1 (one workgroup of 1024 threads, thread c <-> column c): the rotations from row p of T.
+// G[2i], G[2i+1] = (cs_i, sn_i), i = p..n-2; scal[0] = zeta = u'z / sigma_{n-1} (the component of b along
+// the direction that leaves); meta = (p, n, leaving atom); sel shifted; nsel, tmeta[0] decremented.
+__global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T, int kcap, const double* __restrict__ z,
+                                                    int* __restrict__ sel, DevState* st, const int* __restrict__ delpos,
+                                                    double* __restrict__ G, double* __restrict__ scal,
+                                                    int* __restrict__ meta, int* __restrict__ tmeta) {
+    __shared__ double sa[1024], sb[1024];
+    __shared__ double red[16];
+    const int c = threadIdx.x, n = st->nsel;
+    int p = *delpos;
+    if (p < 0 || p >= n) {
+        if (c == 0) {
+            meta[0] = -1;
+            meta[2] = -1;
+        }
+        return;
+    }
+    const bool in = c >= p && c < n;
+    const double u = in ? T[(int64_t)c * kcap + p] : 0.0;
+    const int mysel = c < n ? sel[c] : -1;
+    // inclusive scan of u^2 (Hillis-Steele, ping-pong in LDS)
+    double* a = sa;
+    double* b = sb;
+    a[c] = u * u;
+    __syncthreads();
+    for (int off = 1; off < (int)blockDim.x; off <<= 1) {
+        b[c] = a[c] + (c >= off ? a[c - off] : 0.0);
+        __syncthreads();
+        double* t = a;
+        a = b;
+        b = t;
+    }
+    const double S = a[c];
+    const double sig = c == p ? u : sqrt(S);  // sigma_p keeps the sign of u_p; positive from there on
+    __syncthreads();
+    b[c] = sig;
+    // zeta = u'z / sigma_{n-1}
+    double uz = in ? u * z[c] : 0.0;
+    for (int s = 32; s >= 1; s >>= 1) uz += shx(uz, s);
+    if ((c & 63) == 0) red[c >> 6] = uz;
+    __syncthreads();
+    if (c > p && c < n) {
+        const double inv = 1.0 / sig;
+        G[2 * (c - 1)] = u * inv;
+        G[2 * (c - 1) + 1] = -b[c - 1] * inv;
+        sel[c - 1] = mysel;  // (thread c-1 took its own value before the barriers above)
+    }
+    if (c == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
+        scal[0] = tot / b[n - 1];
+        meta[0] = p;
+        meta[1] = n;
+        st->nsel = n - 1;
+        st->done &= ~(STOP_FULL | STOP_STAG);
+        tmeta[0] = n - 1;
+    }
+    if (c == p) meta[2] = mysel;
+}
+
+// Removal, step 2: every row of Q and of T, every column of R, and z take the rotations -- one thread
+// per vector, kQPre elements requested ahead.  Workgroups (64 threads): [0, GQ) rows of Q (in place;
+// also q_drop, the pre-rotation last column, and r += zeta q_drop); then NB blocks of T rows (into
+// T2, row p dropped); NB blocks of R columns (into R2, column p dropped); one block for z.  With
+// meta[0] < 0 nothing is removed and T2 / R2 receive copies.
+template <typename LD, typename ST>
+__device__ __forceinline__ double rot_chain(int p, int last, const double* __restrict__ G, LD ld, ST stv) {
+    double carry = ld(p);
+    double pre[kQPre], nxt[kQPre];
+#pragma unroll
+    for (int u = 0; u < kQPre; ++u) pre[u] = ld(p + 1 + u);
+    for (int ib = p; ib <= last; ib += kQPre) {
+#pragma unroll
+        for (int u = 0; u < kQPre; ++u) nxt[u] = ld(ib + kQPre + 1 + u);
+#pragma unroll
+        for (int u = 0; u < kQPre; ++u) {
+            const int i = ib + u;
+            if (i <= last) {
+                const double cs = G[2 * i], sn = G[2 * i + 1], x = pre[u];
+                stv(i, fma(cs, carry, sn * x));
+                carry = fma(cs, x, -sn * carry);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kQPre; ++u) pre[u] = nxt[u];
+    }
+    return carry;
+}
+
+__global__ __launch_bounds__(64) void k_tdel_apply(double* __restrict__ Q, int64_t ldq, int GQ, const double* __restrict__ T,
+                                                   double* __restrict__ T2, const double* __restrict__ R,
+                                                   double* __restrict__ R2, int kcap, int NB, double* __restrict__ z,
+                                                   const double* __restrict__ G, const double* __restrict__ scal,
+                                                   const int* __restrict__ meta, double* __restrict__ r,
+                                                   double* __restrict__ qdrop, double* __restrict__ qsave) {
+    const int p = meta[0], n = meta[1];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b < GQ) {  // rows of Q
+        const int64_t row = (int64_t)b * 64 + lane;
+        if (p < 0) {
+            qdrop[row] = 0.0;
+            return;
+        }
+        double* q = Q + row;
+        qsave[row] = q[(int64_t)(n - 1) * ldq];
+        const double carry = rot_chain(
+            p, n - 2, G, [&](int i) { return i <= n - 1 ? q[(int64_t)i * ldq] : 0.0; },
+            [&](int i, double v) { q[(int64_t)i * ldq] = v; });
+        q[(int64_t)(n - 1) * ldq] = 0.0;
+        qdrop[row] = carry;
+        r[row] = fma(scal[0], carry, r[row]);
+        return;
+    }
+    if (b < GQ + NB) {  // rows of T
+        const int t = (b - GQ) * 64 + lane;
+        if (p < 0) {  // plain copy, row t of the upper triangle
+            for (int i = t; i < kcap; ++i) T2[(int64_t)i * kcap + t] = T[(int64_t)i * kcap + t];
+            return;
+        }
+        if (t >= n || t == p) return;
+        const int tn = t - (t > p ? 1 : 0);
+        for (int i = t; i < p; ++i) T2[(int64_t)i * kcap + tn] = T[(int64_t)i * kcap + t];  // columns left of p (t < p only)
+        rot_chain(
+            p, n - 2, G, [&](int i) { return (i >= t && i <= n - 1) ? T[(int64_t)i * kcap + t] : 0.0; },
+            [&](int i, double v) {
+                if (i >= tn) T2[(int64_t)i * kcap + tn] = v;
+            });
+        return;
+    }
+    if (b < GQ + 2 * NB) {  // columns of R
+        const int c = (b - GQ - NB) * 64 + lane;
+        if (p < 0) {
+            if (c < kcap)
+                for (int i = 0; i <= c; ++i) R2[(int64_t)c * kcap + i] = R[(int64_t)c * kcap + i];
+            return;
+        }
+        if (c >= n || c == p) return;
+        const double* src = R + (int64_t)c * kcap;
+        if (c < p) {
+            for (int i = 0; i <= c; ++i) R2[(int64_t)c * kcap + i] = src[i];
+            return;
+        }
+        double* dst = R2 + (int64_t)(c - 1) * kcap;
+        for (int i = 0; i < p; ++i) dst[i] = src[i];
+        rot_chain(
+            p, c - 1, G, [&](int i) { return i <= c ? src[i] : 0.0; }, [&](int i, double v) { dst[i] = v; });
+        return;
+    }
+    if (lane == 0 && p >= 0) {  // z
+        rot_chain(
+            p, n - 2, G, [&](int i) { return i <= n - 1 ? z[i] : 0.0; }, [&](int i, double v) { z[i] = v; });
+        z[n - 1] = 0.0;
+    }
+}
+
+}  // namespace csmp
