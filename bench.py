@@ -38,7 +38,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=18)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr"], default="omp",
+    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr", "ompr", "srr"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -257,6 +257,50 @@ def run_config5(args, cs, torch, dev, rank):
     D.close()
 
 
+def run_twostage(args, cs, torch, dev, At, D):
+    """ompr / srr (src/twostage.jl) at the configs[1] shape, k = 256.  The signals carry 8 planted atoms more
+    than the solvers may keep and noise 0.3, so that the replacement loops have work to do (tens of
+    iterations); one step = one complete solve."""
+    import numpy as np
+    K, W = args.steps, args.warmup
+    sigs = []
+    for s_ in range(K + W):
+        g = torch.Generator(device=dev).manual_seed(31_337 + s_)
+        idx = torch.randperm(N, generator=g, device=dev)[:K_ATOMS + 8]
+        sign = torch.randint(0, 2, (K_ATOMS + 8,), generator=g, device=dev).to(torch.float64) * 2 - 1
+        e = torch.randn(M, generator=g, device=dev, dtype=torch.float64)
+        sigs.append(((At[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (0.3 / e.norm())).cpu().numpy())
+    torch.cuda.synchronize()
+
+    def solve(b):
+        if args.workload == "ompr":
+            return D.ctx.ompr(b, K_ATOMS, 1e-6)[2]
+        return D.ctx.srr(b, K_ATOMS, 1e-12, -1, 1, 1)[2]
+    for w in range(W):
+        solve(sigs[w])
+    D.ctx.profile_enable(1)
+    D.ctx.profile_read(reset=True)
+    t0 = time.perf_counter()
+    iters = 0
+    for s_ in range(W, W + K):
+        iters += solve(sigs[s_])
+    dt = time.perf_counter() - t0
+    sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+    alg = M * N * 4
+    avg = sweep_ms / max(sweeps, 1) / 1e3
+    name = {"ompr": "OMP with replacement", "srr": "stepwise regression with replacement (oblivious start, l=1)"}[args.workload]
+    out = {"metric": f"{name} solves/sec at m=4096,n=65536,k=256", "value": K / dt, "unit": "solves/s",
+           "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
+           "config": {"workload": f"SURVEY 8(f)2: {args.workload} on A 4096x65536 Float32 Gaussian unit-norm, k=256, 264 planted atoms, noise 0.3",
+                      "iterations": int(iters), "iterations_per_s": iters / dt, "sweeps_timed": int(sweeps)},
+           "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
+                        "kernel": "csmp::k_sweep_pf<float,16,true>" if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
+                        "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
+    print(json.dumps(out), flush=True)
+
+
 def run_fr(args, cs, torch, dev, At, D):
     """Forward regression / OLS (src/forward.jl) at the configs[1] shape: single signals, k = 256 atoms each.
     One step = one complete fr(A, b, sparsity=256) solve; inputs host-resident vectors of 32 KiB."""
@@ -320,11 +364,11 @@ def main():
         return
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
-    if args.workload == "fr":
+    if args.workload in ("fr", "ompr", "srr"):
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 6, 1
         if rank == 0:
-            run_fr(args, cs, torch, dev, At, D)
+            (run_fr if args.workload == "fr" else run_twostage)(args, cs, torch, dev, At, D)
         D.close()
         if use_dist:
             dist.barrier()

@@ -142,6 +142,38 @@ function ompr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real; maxiter = si
     to_sparse(size(D, 2), idx, val, nnz[])
 end
 
+# ---------------------------------------------------------------------------------- fr = ols = oomp = ormp
+# src/forward.jl:34-54 (x starting empty)
+function fr(A::MatOrDict{T}, b::AbstractVector, max_ε::Real, min_δ::Real, k::Int = size(A, 1)) where {T}
+    size(A, 1) == length(b) || throw(DimensionMismatch("size(A, 1) = $(size(A, 1)) ≠ $(length(b)) = length(b)"))
+    D = dict(A)
+    bb, bt = bvec(b)
+    k = min(k, size(A, 1))
+    idx, val, nnz = zeros(Int64, max(k, 1)), zeros(Float64, max(k, 1)), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_fr, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Int64}),
+        D.ctx, bb, bt, k, max_ε, min_δ, idx, val, nnz, C_NULL))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+fr(A::MatOrDict, b::AbstractVector; max_residual::Real = 0., min_decrease::Real = 0., sparsity::Int = size(A, 2)) =
+    fr(A, b, max_residual, min_decrease, sparsity)
+const ols = fr
+const oomp = fr
+const ormp = fr
+
+# ---------------------------------------------------------------------------------- srr
+# src/twostage.jl:3-33 (x starting empty; initialization 1 = oblivious, 2 = forward regression)
+function srr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxiter = 4k,
+             initialization::Int = 1, l::Int = 1) where {T}
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx, val, nnz, iters = zeros(Int64, k + l + 1), zeros(Float64, k + l + 1), Ref{Int64}(0), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_srr, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Int64, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}),
+        D.ctx, bb, bt, k, δ, maxiter, initialization, l, idx, val, nnz, iters))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+
 # ---------------------------------------------------------------------------------- functors
 # abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)
 abstract type Update{T} end
