@@ -38,6 +38,9 @@ SIGNATURES = {
     "csmp_fr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_fr_scores": (C.c_int, [vp, vp]),
     "csmp_srr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, C.c_int, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_rmp_delta": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, i64, vp, vp, C.POINTER(i64)]),
+    "csmp_rmp_k": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp, C.POINTER(i64)]),
+    "csmp_foba": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, vp, vp, C.POINTER(i64)]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
@@ -254,6 +257,35 @@ class Context:
                   int(initialization), i64(int(l)), ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), iters.value
+
+    def _stepwise_cap(self, kmax):
+        lim = min(self.M, self.N, 1023)
+        return lim if kmax is None or kmax <= 0 else min(int(kmax), lim)
+
+    def rmp(self, b, delta_or_k, maxiter=1, kmax=None):
+        """rmp(A,b,δ,maxiter) for a float second argument, rmp(A,b,k) for an int."""
+        b = self._b(b)
+        cap = self._stepwise_cap(kmax)
+        idx = np.zeros(cap + 1, np.int64)
+        val = np.zeros(cap + 1, np.float64)
+        nnz = i64(0)
+        if isinstance(delta_or_k, (int, np.integer)):
+            self.call("csmp_rmp_k", ptr(b), dtype_code(b.dtype), i64(int(delta_or_k)), i64(cap), ptr(idx), ptr(val), C.byref(nnz))
+        else:
+            self.call("csmp_rmp_delta", ptr(b), dtype_code(b.dtype), C.c_double(float(delta_or_k)), i64(int(maxiter)), i64(cap),
+                      ptr(idx), ptr(val), C.byref(nnz))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy()
+
+    def foba(self, b, delta, kmax=None):
+        b = self._b(b)
+        cap = self._stepwise_cap(kmax)
+        idx = np.zeros(cap + 1, np.int64)
+        val = np.zeros(cap + 1, np.float64)
+        nnz = i64(0)
+        self.call("csmp_foba", ptr(b), dtype_code(b.dtype), C.c_double(float(delta)), i64(cap), ptr(idx), ptr(val), C.byref(nnz))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy()
 
     def fr_scores(self):
         d2 = np.zeros(self.N, np.float64)

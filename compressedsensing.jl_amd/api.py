@@ -10,6 +10,7 @@ Same names, argument meaning and error behaviour as the reference (paths relativ
                                              src/forward.jl:34-54
     FR functor with update!                  src/forward.jl:88-95
     srr(A, b, k, delta=1e-12; maxiter=4k, initialization=1, l=1)          src/twostage.jl:3-33
+    rmp(A, b, delta, maxiter=1) / rmp(A, b, k) / foba(A, b, delta)        src/stepwise.jl:5-56
     ompr(A, b, k, delta; maxiter)            src/twostage.jl:184-202
     MP / OMP / GOMP functors with update!    src/matchingpursuit.jl:10-31,44-70,95-123
     argmaxinner!(P[, k])                     src/matchingpursuit.jl:181-193
@@ -195,6 +196,29 @@ def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
     D, tmp = _dict(A)
     try:
         idx, val, _ = D.ctx.srr(b, int(k), float(delta), -1 if maxiter is None else int(maxiter), int(initialization), int(l))
+        return SparseVector(D.shape[1], idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def rmp(A, b, delta_or_k, maxiter=1, kmax=None):
+    """rmp(A, b, δ, maxiter=1) -- δ a float -- and rmp(A, b, k) -- k an int: relevance matching pursuit,
+    src/stepwise.jl:5-43 (x empty).  kmax bounds the support of the forward stage (default min(M, N, 1023))."""
+    D, tmp = _dict(A)
+    try:
+        idx, val = D.ctx.rmp(b, delta_or_k, maxiter, kmax)
+        return SparseVector(D.shape[1], idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def foba(A, b, delta, kmax=None):
+    """foba(A, b, δ): adaptive forward-backward greedy algorithm, src/stepwise.jl:47-56 (x empty)."""
+    D, tmp = _dict(A)
+    try:
+        idx, val = D.ctx.foba(b, float(delta), kmax)
         return SparseVector(D.shape[1], idx, val)
     finally:
         if tmp:

@@ -1749,53 +1749,163 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     return CSMP_OK;
 }
 
-// ------------------------------------------------------------------------------------------ stepwise regression with replacement
-// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty.  Every
-// iteration is l forward steps (forward_step!(P,x,0,0): one dictionary sweep + one append each) and
-// as many backward steps (backward_step!(P,x,Inf,Inf): scores from R, Givens down-date).  The OLS
-// rescaling rho2 follows the support through rank-one corrections folded into the NEXT sweep: -<a,q>^2
-// for the column a forward step appended, +<a,q_drop>^2 for the direction a backward step rotated out
-// (csmp_forward.hpp, NQ = 2) -- so an iteration with l = 1 streams the dictionary once.  The host
-// reads the 48-byte control block after every step (it must know which steps changed the support).
-extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
-                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
-    if (!ctx) return CSMP_EINVAL;
-    if (!b || k < 1 || l < 1) return fail(ctx, CSMP_EINVAL, "srr: b == NULL, k < 1 or l < 1");
-    if (initialization != 1 && initialization != 2)
-        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression)");
-    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
-    if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
-    if (maxiter < 0) maxiter = 4 * k;  // :5
-    HIPCHECK(hipSetDevice(ctx->dev));
-    const int kcap = (int)(k + l);
-    CHECK(solver_ensure(ctx, kcap, kcap));
-    CHECK(fr_ensure(ctx));
-    CHECK(del_ensure(ctx));
-    const bool tmode = !getenv("CSMP_NO_TINV");  // explicit inverse next to R (csmp_tinv.hpp)
-    if (tmode) CHECK(tinv_ensure(ctx));
-    Solver& s = ctx->s;
-    s.begun = false;
-    CHECK(upload_b(ctx, b, b_dtype));
+// ------------------------------------------------------------------------------------------ stepwise regression object
+// StepwiseRegression = ForwardRegression (src/forward.jl:14-32) kept on the device and driven from the
+// host: forward_step! (src/forward.jl:56-73) = one dictionary sweep + one append, backward_step!
+// (src/backward.jl:51-67) = scores from T = R^-1 + column removal.  The OLS rescaling rho2 follows the
+// support through rank-one corrections folded into the NEXT sweep: -<a,q>^2 for the column a forward
+// step appended, +<a,q_drop>^2 for the direction a backward step rotated out (csmp_forward.hpp,
+// NQ = 2), so a forward/backward pair streams the dictionary once.  The host reads the 48-byte control
+// block after every step (it must know which steps changed the support).
+struct Stepwise {
     struct Pend { const double* q; double sgn; };
-    std::vector<Pend> pend;  // rank-one corrections rho2 still lacks; q == nullptr: the last Q column (device look-up)
+    csmp_ctx* ctx = nullptr;
+    std::vector<Pend> pend;  // corrections rho2 still lacks; q == nullptr: the last Q column (device look-up)
     bool unmark = false;     // delmeta[2] names an atom that left the support and needs its rho2 re-seeded
-    const int skipF = STOP_EPS | STOP_STAG | STOP_FULL;
-    static const int zero = 0;
+    bool rho_ready = false;  // rho2 has been initialised (|a_j|^2 at least)
+    int n = 0;               // atoms in the support
+    double last_max_d2 = 0.0;  // maximum(P.δ²) of the last forward step
+    int last_added = -1, last_removed = -1;  // atoms moved by the last successful forward / backward step
     DevState hs;
-    auto read_state = [&]() -> int {
+
+    int read_state() {
+        Solver& s = ctx->s;
         HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         return CSMP_OK;
-    };
-    auto pass_of = [&](int update_only) {
+    }
+    int clear_flags() {
+        static const int zero = 0;
+        HIPCHECK(hipMemcpyAsync(&ctx->s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        return CSMP_OK;
+    }
+    FrPass pass_of(int update_only) const {
+        const Solver& s = ctx->s;
         FrPass ps;
-        ps.nq = (int)pend.size();
+        ps.nq = rho_ready ? (int)pend.size() : -1;
         ps.update_only = update_only;
         if (pend.size() >= 1) { ps.q1 = pend[0].q; ps.s1 = pend[0].sgn; }
         if (pend.size() >= 2) { ps.q2 = pend[1].q; ps.s2 = pend[1].sgn; }
         ps.unmark = unmark ? s.delmeta + 2 : nullptr;  // (the direction that was rotated out is always the last one)
         return ps;
-    };
+    }
+    // buffers for at most kcap atoms, b uploaded, empty support
+    int begin(csmp_ctx* c, const void* b, int b_dtype, int kcap) {
+        ctx = c;
+        CHECK(solver_ensure(ctx, kcap, kcap));
+        CHECK(fr_ensure(ctx));
+        CHECK(tinv_ensure(ctx));
+        Solver& s = ctx->s;
+        s.begun = false;
+        CHECK(upload_b(ctx, b, b_dtype));
+        HIPCHECK(hipMemsetAsync(s.tmeta, 0, 2 * sizeof(int), ctx->stream));
+        pend.clear();
+        unmark = false;
+        rho_ready = false;
+        n = 0;
+        return CSMP_OK;
+    }
+    // forward_step!(P, x, max_eps, min_delta); guarded == false: update!(P::FR, x) (src/forward.jl:88-95)
+    int forward(double max_eps, double min_d2, bool guarded, bool* ok) {
+        Solver& s = ctx->s;
+        const int skipF = STOP_EPS | STOP_STAG | STOP_FULL;
+        if (!guarded) {
+            max_eps = -HUGE_VAL;
+            min_d2 = -1.0;
+        }
+        CHECK(launch_fr_pass(ctx, pass_of(0), max_eps, skipF));
+        CHECK(launch_append(ctx, 3, 0, skipF, false, min_d2, s.fr_grid));
+        CHECK(launch_tinv_append(ctx));
+        CHECK(read_state());
+        if (hs.done & skipF) {
+            // the step failed.  A residual-norm stop returns before rho2 is touched; the other guards act
+            // after the sweep, which has then consumed the pending corrections.
+            if (!(hs.done & STOP_EPS)) {
+                pend.clear();
+                unmark = false;
+                rho_ready = true;
+                last_max_d2 = hs.cval;
+            }
+            CHECK(clear_flags());
+            *ok = false;
+            return CSMP_OK;
+        }
+        last_max_d2 = hs.cval;
+        last_added = hs.cand;
+        rho_ready = true;
+        pend.clear();
+        unmark = false;
+        pend.push_back({nullptr, -1.0});
+        n = hs.nsel;
+        *ok = true;
+        return CSMP_OK;
+    }
+    // applies the pending corrections now (needed before a second removal reuses the q_drop buffer)
+    int flush() {
+        if (pend.empty() && !unmark) return CSMP_OK;
+        CHECK(launch_fr_pass(ctx, pass_of(1), 0.0, 0));
+        pend.clear();
+        unmark = false;
+        return CSMP_OK;
+    }
+    // backward_step!(P, x, max_eps, max_delta)
+    int backward(double max_eps, double max_d2, bool* ok) {
+        Solver& s = ctx->s;
+        *ok = false;
+        if (n <= 0) return CSMP_OK;
+        bool has_drop = false;
+        for (const Pend& e : pend) has_drop |= e.q == s.qdrop;
+        if (has_drop) CHECK(flush());
+        CHECK(launch_tinv_solve(ctx));
+        hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
+                           (const DevState*)s.st, (const double*)s.r, (int)ctx->M, max_eps, max_d2, s.delpos, s.bwd_info);
+        HIPCHECK(hipGetLastError());
+        CHECK(launch_delete_t(ctx));
+        HIPCHECK(hipMemcpyAsync(&last_removed, s.delmeta + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        CHECK(read_state());
+        if (hs.nsel == n) return CSMP_OK;  // the thresholds (or the lack of a finite score) kept every atom
+        for (Pend& e : pend)
+            if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_tdel_apply kept a copy
+        pend.push_back({s.qdrop, 1.0});
+        unmark = true;
+        n = hs.nsel;
+        *ok = true;
+        return CSMP_OK;
+    }
+    int result(int64_t* idx, double* val, int64_t* nnz) {
+        std::vector<int64_t> xi;
+        std::vector<double> xv;
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        for (size_t t = 0; t < xi.size(); ++t) {
+            if (idx) idx[t] = xi[t];
+            if (val) val[t] = xv[t];
+        }
+        if (nnz) *nnz = (int64_t)xi.size();
+        return CSMP_OK;
+    }
+};
+
+static int stepwise_args(csmp_ctx* ctx, const void* b, const char* who) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b) return fail(ctx, CSMP_EINVAL, (std::string(who) + ": b == NULL").c_str());
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    return CSMP_OK;
+}
+
+// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty
+extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    CHECK(stepwise_args(ctx, b, "srr"));
+    if (k < 1 || l < 1) return fail(ctx, CSMP_EINVAL, "srr: k < 1 or l < 1");
+    if (initialization != 1 && initialization != 2)
+        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression)");
+    if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
+    if (k + l > kTMaxCols) return fail(ctx, CSMP_ERANGE, "srr: k + l exceeds 1023");
+    if (maxiter < 0) maxiter = 4 * k;  // :5
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, (int)(k + l)));
+    Solver& s = ctx->s;
     if (initialization == 1) {
         // oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216
         CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
@@ -1805,7 +1915,7 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         std::sort(top.begin(), top.end());
         CHECK(ls_on_columns(ctx, top));
-        // rho2_j = |a_j|^2 - |Q'a_j|^2 for the k columns just factorised: the norms, then two columns per pass
+        // rho2_j = |a_j|^2 - |Q'a_j|^2 for the k columns just factorised: the norms, then four columns per pass
         FrPass p0;
         p0.nq = -1;
         p0.update_only = 1;
@@ -1835,94 +1945,167 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         }
         hipLaunchKernelGGL(k_mark_inf, dim3(1), dim3(256), 0, ctx->stream, s.rho2, (const int*)s.sel, (const DevState*)s.st);
         HIPCHECK(hipGetLastError());
+        CHECK(launch_tinv_build(ctx));
+        CHECK(P.read_state());
+        P.n = P.hs.nsel;
+        P.rho_ready = true;
+        if (P.hs.done) CHECK(P.clear_flags());
     } else {
         // k times update!(P::FR, x) (:12-15; src/forward.jl:88-95)
-        const int skip = STOP_FULL | STOP_STAG;
         for (int64_t t = 0; t < k; ++t) {
-            CHECK(launch_fr_sweep(ctx, t == 0, -HUGE_VAL, skip));
-            CHECK(launch_append(ctx, 3, 0, skip, false, -1.0, s.fr_grid));
+            bool ok;
+            CHECK(P.forward(0.0, 0.0, false, &ok));
+            if (!ok) break;
         }
-        pend.push_back({nullptr, -1.0});
     }
-    if (tmode) CHECK(launch_tinv_build(ctx));
-    CHECK(read_state());
-    int n = hs.nsel;
-    if (hs.done) HIPCHECK(hipMemcpyAsync(&s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
     double resnorm = 0.0;
     CHECK(residual_norm(ctx, &resnorm));  // :18
     int64_t it = 0;
     while (it < maxiter) {  // :19
         const double oldnorm = resnorm;
+        std::vector<int> added, removed;
         for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
-            CHECK(launch_fr_pass(ctx, pass_of(0), 0.0, skipF));
-            CHECK(launch_append(ctx, 3, 0, skipF, false, 0.0, s.fr_grid));
-            if (tmode) CHECK(launch_tinv_append(ctx));
-            CHECK(read_state());
-            if (hs.done & skipF) {
-                // the step failed.  A residual-norm stop returns before rho2 is touched; the other guards act
-                // after the sweep, which has then consumed the pending corrections.
-                if (!(hs.done & STOP_EPS)) {
-                    pend.clear();
-                    unmark = false;
-                }
-                HIPCHECK(hipMemcpyAsync(&s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
-                break;
-            }
-            pend.clear();
-            unmark = false;
-            pend.push_back({nullptr, -1.0});
-            n = hs.nsel;
+            bool ok;
+            CHECK(P.forward(0.0, 0.0, true, &ok));
+            if (!ok) break;
+            added.push_back(P.last_added);
         }
-        while (n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
-            bool has_drop = false;
-            for (const Pend& e : pend) has_drop |= e.q == s.qdrop;
-            if (has_drop) {  // the q_drop buffer is about to be reused: bring rho2 up to date first
-                CHECK(launch_fr_pass(ctx, pass_of(1), 0.0, 0));
-                pend.clear();
-                unmark = false;
-            }
-            if (tmode)
-                CHECK(launch_tinv_solve(ctx));
-            else if (n <= 257)
-                hipLaunchKernelGGL((k_bwd_scores<4, 4>), dim3(n), dim3(64), 0, ctx->stream, (const double*)s.R,
-                                   s.kcap, (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
-            else
-                hipLaunchKernelGGL((k_bwd_scores<16, 2>), dim3(n), dim3(64), 0, ctx->stream, (const double*)s.R,
-                                   s.kcap, (const double*)s.z, (const DevState*)s.st, s.bwd, s.bwd_coef);
-            HIPCHECK(hipGetLastError());
-            hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
-                               (const DevState*)s.st, (const double*)s.r, (int)ctx->M, (double)HUGE_VAL, (double)HUGE_VAL, s.delpos,
-                               s.bwd_info);
-            HIPCHECK(hipGetLastError());
-            if (tmode)
-                CHECK(launch_delete_t(ctx));
-            else
-                CHECK(launch_delete(ctx));
-            CHECK(read_state());
-            if (hs.nsel == n) break;  // nothing could be dropped (no finite score)
-            for (Pend& e : pend)
-                if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_qrdel_q kept a copy
-            pend.push_back({s.qdrop, 1.0});
-            unmark = true;
-            n = hs.nsel;
+        while (P.n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
+            bool ok;
+            CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok));
+            if (!ok) break;
+            removed.push_back(P.last_removed);
         }
-        CHECK(residual_norm(ctx, &resnorm));  // :27
+        std::sort(added.begin(), added.end());
+        std::sort(removed.begin(), removed.end());
+        // An iteration that removed exactly the atoms it added left x where it was: the residual norm is the
+        // old one (:27-28 then stops).  Measuring it instead would compare two roundings of the same number.
+        if (added == removed)
+            resnorm = oldnorm;
+        else
+            CHECK(residual_norm(ctx, &resnorm));  // :27
         ++it;
         if (resnorm <= delta || oldnorm <= resnorm) break;  // :28-30
     }
-    std::vector<int64_t> xi;
-    std::vector<double> xv;
-    if (tmode)
-        CHECK(fetch_sorted_t(ctx, xi, xv));
-    else
-        CHECK(fetch_sorted(ctx, xi, xv));
-    for (size_t t = 0; t < xi.size(); ++t) {
-        if (idx) idx[t] = xi[t];
-        if (val) val[t] = xv[t];
-    }
-    if (nnz) *nnz = (int64_t)xi.size();
     if (iters) *iters = it;
+    return P.result(idx, val, nnz);
+}
+
+// ------------------------------------------------------------------------------------------ relevance matching pursuit, FoBa
+// src/stepwise.jl (x starting empty): loops over the two steps of the object above.  kmax bounds the
+// support the forward stage may build (at most 1023; the reference's only bound is size(A,1)): a
+// forward stage that needs more atoms than that ends with CSMP_ERANGE rather than a truncated answer.
+static int stepwise_cap(csmp_ctx* ctx, int64_t kmax, int* kcap) {
+    const int64_t lim = std::min<int64_t>(std::min<int64_t>(ctx->M, ctx->N), kTMaxCols);
+    if (kmax <= 0) kmax = lim;
+    *kcap = (int)std::min<int64_t>(kmax, lim);
     return CSMP_OK;
+}
+static int stepwise_full(csmp_ctx* ctx, const Stepwise& P, int kcap) {
+    if (P.n >= kcap && kcap < std::min<int64_t>(ctx->M, ctx->N))
+        return fail(ctx, CSMP_ERANGE, "stepwise regression: the forward stage filled the support capacity (kmax, at most 1023 atoms)");
+    return CSMP_OK;
+}
+// !(xt ≈ x): isapprox with Julia's default rtol = sqrt(eps) on the sparse vectors
+static bool x_changed(const std::vector<int64_t>& i0, const std::vector<double>& v0, const std::vector<int64_t>& i1,
+                      const std::vector<double>& v1) {
+    double d2 = 0.0, na = 0.0, nb = 0.0;
+    size_t i = 0, j = 0;
+    while (i < i0.size() || j < i1.size()) {
+        double a = 0.0, b = 0.0;
+        if (j >= i1.size() || (i < i0.size() && i0[i] < i1[j])) a = v0[i++];
+        else if (i >= i0.size() || i1[j] < i0[i]) b = v1[j++];
+        else { a = v0[i++]; b = v1[j++]; }
+        d2 += (a - b) * (a - b);
+        na += a * a;
+        nb += b * b;
+    }
+    return !(std::sqrt(d2) <= 1.4901161193847656e-08 * std::sqrt(std::max(na, nb)));
+}
+
+// rmp(A, b, delta, maxiter): src/stepwise.jl:5-26
+extern "C" int csmp_rmp_delta(csmp_ctx* ctx, const void* b, int b_dtype, double delta, int64_t maxiter, int64_t kmax, int64_t* idx,
+                              double* val, int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "rmp"));
+    if (maxiter < 0) maxiter = 1;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    const double d2 = delta * delta;
+    std::vector<int64_t> xi0, xi;
+    std::vector<double> xv0, xv;
+    for (int64_t it = 0; it < maxiter; ++it) {  // :10
+        for (int64_t f = 0; f < ctx->M; ++f) {  // :12-14
+            bool ok;
+            CHECK(P.forward(0.0, d2, true, &ok));
+            if (!ok) break;
+        }
+        CHECK(stepwise_full(ctx, P, kcap));
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        if (!x_changed(xi0, xv0, xi, xv)) break;  // :15
+        xi0 = xi;
+        xv0 = xv;
+        for (int t = P.n; t >= 1; --t) {  // :18-20
+            bool ok;
+            CHECK(P.backward((double)HUGE_VAL, d2, &ok));
+            if (!ok) break;
+        }
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        if (!x_changed(xi0, xv0, xi, xv)) break;  // :21
+        xi0 = xi;
+        xv0 = xv;
+    }
+    return P.result(idx, val, nnz);
+}
+
+// rmp(A, b, k): src/stepwise.jl:32-43
+extern "C" int csmp_rmp_k(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, int64_t kmax, int64_t* idx, double* val,
+                          int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "rmp"));
+    if (k < 0) return fail(ctx, CSMP_EINVAL, "rmp: k < 0");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    for (int64_t f = 0; f < ctx->M; ++f) {  // :36-38
+        bool ok;
+        CHECK(P.forward(0.0, 0.0, true, &ok));
+        if (!ok) break;
+    }
+    CHECK(stepwise_full(ctx, P, kcap));
+    for (int t = P.n; t >= k + 1; --t) {  // :39-41
+        bool ok;
+        CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok));
+        if (!ok) break;
+    }
+    return P.result(idx, val, nnz);
+}
+
+// foba(A, b, delta): src/stepwise.jl:47-56
+extern "C" int csmp_foba(csmp_ctx* ctx, const void* b, int b_dtype, double delta, int64_t kmax, int64_t* idx, double* val,
+                         int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "foba"));
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    const double d2 = delta * delta;
+    for (int64_t f = 0; f < ctx->M; ++f) {  // :50
+        bool ok;
+        CHECK(P.forward(0.0, d2, true, &ok));  // :51
+        if (!ok) break;
+        const double half = std::sqrt(P.last_max_d2) / 2.0;  // :52-53
+        for (;;) {
+            CHECK(P.backward((double)HUGE_VAL, half * half, &ok));
+            if (!ok) break;
+        }
+    }
+    CHECK(stepwise_full(ctx, P, kcap));
+    return P.result(idx, val, nnz);
 }
 
 // ------------------------------------------------------------------------------------------ batched (MFMA-screened) OMP

@@ -955,6 +955,7 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
         block_argmax(bv, bi, tmp, reinterpret_cast<int*>(tmp + kQrThreads));
         cand = bi;
         low = mode == 3 && !(min_d2 < bv);
+        if (mode == 3 && g == 0 && tid == 0) st->cval = bv;  // maximum(P.δ²) (foba reads it: src/stepwise.jl:52)
     } else {
         cand = (which < *ncands) ? cands[which] : -1;
     }

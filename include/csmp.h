@@ -121,6 +121,18 @@ int csmp_fr_scores(csmp_ctx *ctx, double *delta2);
 int csmp_srr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
              int64_t l, int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
 
+/* rmp(A,b,delta,maxiter) (src/stepwise.jl:5-26), rmp(A,b,k) (:32-43) and foba(A,b,delta) (:47-56), x
+ * starting empty: loops over forward_step! (src/forward.jl:56-73) and backward_step!
+ * (src/backward.jl:51-67) of the StepwiseRegression object.  kmax (<= 0: min(M, N, 1023)) is the largest
+ * support the forward stage may build; reaching it below min(M,N) is CSMP_ERANGE.  Capacity of idx/val:
+ * kmax.  maxiter < 0 selects the default 1. */
+int csmp_rmp_delta(csmp_ctx *ctx, const void *b, int b_dtype, double delta, int64_t maxiter, int64_t kmax,
+                   int64_t *idx, double *val, int64_t *nnz);
+int csmp_rmp_k(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, int64_t kmax, int64_t *idx, double *val,
+               int64_t *nnz);
+int csmp_foba(csmp_ctx *ctx, const void *b, int b_dtype, double delta, int64_t kmax, int64_t *idx, double *val,
+              int64_t *nnz);
+
 /* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);

@@ -694,6 +694,7 @@ typedef struct {
     double *coef, *r, *norm2;
     hqr_t F;
     int nthreads;
+    double last_max_d2;
 } srr_t;
 
 static void srr_refit(srr_t *P) { /* QR of A[:, S] in nzind order; coef = AiQR \ b; r = b - A x */
@@ -751,16 +752,19 @@ static int srr_forward(srr_t *P, double max_eps, double min_d2, int guarded) {
             best = j;
         }
     free(d2);
+    P->last_max_d2 = bv; /* maximum(P.δ²) after the step (foba, src/stepwise.jl:52) */
     if (guarded && !(min_d2 < bv)) return 0;
     if (srr_in(P, best)) return 0; /* addindex! is a no-op for an atom already in the support */
     srr_insert(P, best);
     srr_refit(P);
     return 1;
 }
-/* backward_step!(P, x, Inf, Inf): drops the atom of least δ² = x_i²/γ_i; returns 1 if one was dropped */
-static int srr_backward(srr_t *P) {
+/* backward_step!(P, x, max_eps, max_delta): drops the atom of least δ² = x_i²/γ_i if
+ * sqrt(min + |r|²) < max_eps and min < max_delta² (src/backward.jl:58); returns 1 if one was dropped */
+static int srr_backward_thr(srr_t *P, double max_eps, double max_d2) {
     const int64_t n = P->n;
     if (!(n > 0)) return 0;
+    const double normr = nrm2(P->r, P->M);
     double *y = (double *)malloc((size_t)n * sizeof(double));
     int64_t best = -1;
     double bv = INFINITY;
@@ -782,11 +786,14 @@ static int srr_backward(srr_t *P) {
     }
     free(y);
     if (best < 0) return 0; /* all NaN */
+    if (!(sqrt(bv + normr * normr) < max_eps && bv < max_d2)) return 0; /* :58 */
     for (int64_t t = best; t + 1 < n; ++t) P->S[t] = P->S[t + 1];
     P->n -= 1;
     srr_refit(P);
     return 1;
 }
+
+static int srr_backward(srr_t *P) { return srr_backward_thr(P, INFINITY, INFINITY); }
 
 int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
             double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
@@ -852,5 +859,119 @@ int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const do
     free(P.r);
     free(P.norm2);
     hqr_free(&P.F);
+    return CSO_OK;
+}
+
+
+/* ---------------------------------------------------------------- relevance matching pursuit, FoBa
+ * src/stepwise.jl: rmp(A,b,δ,maxiter) :5-26, rmp(A,b,k) :32-43, foba(A,b,δ) :47-56 (x starting empty).
+ * All three are loops over forward_step! / backward_step! of the StepwiseRegression object. */
+static int stepwise_init(srr_t *P, const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b,
+                         int nthreads) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+    if (nthreads > 16) nthreads = 16;
+#else
+    nthreads = 1;
+#endif
+    memset(P, 0, sizeof *P);
+    P->A = A; P->dtype = dtype; P->M = M; P->N = N; P->ld = ld; P->b = b; P->nthreads = nthreads;
+    const int64_t cap = (M < N ? M : N) + 1;
+    P->S = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    P->coef = (double *)calloc((size_t)cap, sizeof(double));
+    P->r = (double *)malloc((size_t)M * sizeof(double));
+    P->norm2 = (double *)malloc((size_t)N * sizeof(double));
+    if (hqr_init(&P->F, M, cap) != 0) return CSO_ENOMEM;
+    for (int64_t j = 0; j < N; ++j) {
+        double s = 0.0;
+        for (int64_t i = 0; i < M; ++i) {
+            const double a = a_at(A, dtype, ld, i, j);
+            s += a * a;
+        }
+        P->norm2[j] = s;
+    }
+    memcpy(P->r, b, (size_t)M * sizeof(double));
+    return CSO_OK;
+}
+static void stepwise_finish(srr_t *P, int64_t *idx, double *val, int64_t *nnz) {
+    for (int64_t t = 0; t < P->n; ++t) {
+        idx[t] = P->S[t];
+        val[t] = P->coef[t];
+    }
+    *nnz = P->n;
+    free(P->S);
+    free(P->coef);
+    free(P->r);
+    free(P->norm2);
+    hqr_free(&P->F);
+}
+/* !(xt ≈ x): isapprox on the dense images, rtol = sqrt(eps) (Julia default) */
+static int x_changed(const srr_t *P, const int64_t *S0, const double *c0, int64_t n0) {
+    double d2 = 0.0, na = 0.0, nb = 0.0;
+    int64_t i = 0, j = 0;
+    while (i < P->n || j < n0) {
+        double a = 0.0, b = 0.0;
+        if (j >= n0 || (i < P->n && P->S[i] < S0[j])) a = P->coef[i++];
+        else if (i >= P->n || S0[j] < P->S[i]) b = c0[j++];
+        else { a = P->coef[i++]; b = c0[j++]; }
+        d2 += (a - b) * (a - b); na += a * a; nb += b * b;
+    }
+    const double mx = sqrt(na > nb ? na : nb);
+    return !(sqrt(d2) <= 1.4901161193847656e-08 * mx);
+}
+
+int cso_rmp_delta(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double delta,
+                  int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int nthreads) {
+    srr_t P;
+    if (stepwise_init(&P, A, dtype, M, N, ld, b, nthreads) != 0) return CSO_ENOMEM;
+    const int64_t cap = (M < N ? M : N) + 1;
+    int64_t *S0 = (int64_t *)malloc((size_t)cap * sizeof(int64_t));
+    double *c0 = (double *)malloc((size_t)cap * sizeof(double));
+    int64_t n0 = 0;
+    const double d2 = delta * delta;
+    for (int64_t it = 0; it < maxiter; ++it) { /* :10 */
+        for (int64_t s = 0; s < M; ++s)        /* :12-14 */
+            if (!srr_forward(&P, 0.0, d2, 1)) break;
+        if (!x_changed(&P, S0, c0, n0)) break; /* :15 */
+        n0 = P.n;
+        memcpy(S0, P.S, (size_t)n0 * sizeof(int64_t));
+        memcpy(c0, P.coef, (size_t)n0 * sizeof(double));
+        for (int64_t s = P.n; s >= 1; --s) /* :18-20 */
+            if (!srr_backward_thr(&P, INFINITY, d2)) break;
+        if (!x_changed(&P, S0, c0, n0)) break; /* :21 */
+        n0 = P.n;
+        memcpy(S0, P.S, (size_t)n0 * sizeof(int64_t));
+        memcpy(c0, P.coef, (size_t)n0 * sizeof(double));
+    }
+    free(S0);
+    free(c0);
+    stepwise_finish(&P, idx, val, nnz);
+    return CSO_OK;
+}
+
+int cso_rmp_k(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+              int64_t *idx, double *val, int64_t *nnz, int nthreads) {
+    srr_t P;
+    if (stepwise_init(&P, A, dtype, M, N, ld, b, nthreads) != 0) return CSO_ENOMEM;
+    for (int64_t s = 0; s < M; ++s) /* :36-38 */
+        if (!srr_forward(&P, 0.0, 0.0, 1)) break;
+    for (int64_t s = P.n; s >= k + 1; --s) /* :39-41 */
+        if (!srr_backward_thr(&P, INFINITY, INFINITY)) break;
+    stepwise_finish(&P, idx, val, nnz);
+    return CSO_OK;
+}
+
+int cso_foba(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double delta,
+             int64_t *idx, double *val, int64_t *nnz, int nthreads) {
+    srr_t P;
+    if (stepwise_init(&P, A, dtype, M, N, ld, b, nthreads) != 0) return CSO_ENOMEM;
+    const double d2 = delta * delta;
+    for (int64_t s = 0; s < M; ++s) { /* :50 */
+        if (!srr_forward(&P, 0.0, d2, 1)) break;              /* :51 */
+        const double half = sqrt(P.last_max_d2) / 2.0;        /* :52-53 */
+        while (srr_backward_thr(&P, INFINITY, half * half)) { /* :53 */
+        }
+    }
+    stepwise_finish(&P, idx, val, nnz);
     return CSO_OK;
 }

@@ -77,6 +77,15 @@ int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const do
             double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
             int64_t *nnz, int64_t *iters, int nthreads);
 
+/* rmp(A,b,delta,maxiter), rmp(A,b,k), foba(A,b,delta): src/stepwise.jl:5-56 (x starts empty).
+ * idx/val sized >= min(M,N) + 1. */
+int cso_rmp_delta(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double delta,
+                  int64_t maxiter, int64_t *idx, double *val, int64_t *nnz, int nthreads);
+int cso_rmp_k(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+              int64_t *idx, double *val, int64_t *nnz, int nthreads);
+int cso_foba(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double delta,
+             int64_t *idx, double *val, int64_t *nnz, int nthreads);
+
 /* step primitives, exported so tests can pin them one by one */
 /* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
 int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,

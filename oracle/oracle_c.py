@@ -170,6 +170,29 @@ def srr(A, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1, nthreads=0):
     return idx[:n].copy(), val[:n].copy(), iters.value
 
 
+def _stepwise(fn, A, b, *args, nthreads=0):
+    A, b, M, N, dtype = _prep(A, b)
+    cap = min(M, N) + 1
+    idx = np.zeros(cap, np.int64)
+    val = np.zeros(cap, np.float64)
+    nnz = i64(0)
+    rc = fn(_vp(A), dtype, i64(M), i64(N), i64(M), _vp(b), *args, _vp(idx), _vp(val), C.byref(nnz), int(nthreads))
+    assert rc == 0, rc
+    n = nnz.value
+    return idx[:n].copy(), val[:n].copy()
+
+
+def rmp(A, b, delta_or_k, maxiter=1, nthreads=0):
+    """rmp(A,b,δ,maxiter) for a float second argument, rmp(A,b,k) for an int (src/stepwise.jl:5-43)."""
+    if isinstance(delta_or_k, (int, np.integer)):
+        return _stepwise(lib().cso_rmp_k, A, b, i64(int(delta_or_k)), nthreads=nthreads)
+    return _stepwise(lib().cso_rmp_delta, A, b, C.c_double(float(delta_or_k)), i64(int(maxiter)), nthreads=nthreads)
+
+
+def foba(A, b, delta, nthreads=0):
+    return _stepwise(lib().cso_foba, A, b, C.c_double(float(delta)), nthreads=nthreads)
+
+
 def sweep_abs(A, r, nthreads=0):
     A, r, M, N, dtype = _prep(A, r)
     out = np.zeros(N, np.float64)

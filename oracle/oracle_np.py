@@ -273,3 +273,100 @@ def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
         if resnorm <= delta or oldnorm <= resnorm:
             break
     return idx, val, iters
+
+
+class _Stepwise:
+    """StepwiseRegression object (src/forward.jl:14-32) with everything recomputed from scratch per step."""
+
+    def __init__(self, A, b):
+        self.A, self.b = _f64(A, b)
+        self.M, self.N = self.A.shape
+        self.norm2 = np.sum(self.A * self.A, axis=0)
+        self.idx = np.zeros(0, np.int64)
+        self.val = np.zeros(0)
+        self.r = self.b.copy()
+        self.last_max_d2 = 0.0
+
+    def _fit(self):
+        self.val = _ls(self.A, self.idx, self.b) if len(self.idx) else np.zeros(0)
+        self.r = _residual(self.A, self.b, self.idx, self.val)
+
+    def forward(self, max_eps, min_delta):  # forward_step!: src/forward.jl:56-73
+        A = self.A
+        if not len(self.idx) < self.M or not np.linalg.norm(self.r) > max_eps:
+            return False
+        resc = self.norm2.copy()
+        if len(self.idx):
+            Q = np.linalg.qr(A[:, self.idx])[0]
+            resc = resc - np.sum((Q.T @ A) ** 2, axis=0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d2 = (A.T @ self.r) ** 2 / resc
+        d2[self.idx] = 0.0
+        d2 = np.where(np.isnan(d2), -1.0, d2)
+        i = int(np.argmax(d2))
+        self.last_max_d2 = float(d2[i])
+        if not min_delta ** 2 < d2[i] or i in self.idx:
+            return False
+        self.idx = np.sort(np.append(self.idx, i))
+        self._fit()
+        return True
+
+    def backward(self, max_eps, max_delta):  # backward_step!: src/backward.jl:51-67
+        if not len(self.idx) > 0:
+            return False
+        As = self.A[:, self.idx]
+        gamma = np.diag(np.linalg.inv(As.T @ As))
+        d2 = self.val ** 2 / gamma
+        j = int(np.argmin(d2))
+        if not (np.sqrt(d2[j] + np.linalg.norm(self.r) ** 2) < max_eps and d2[j] < max_delta ** 2):
+            return False
+        self.idx = np.delete(self.idx, j)
+        self._fit()
+        return True
+
+    def dense(self):
+        x = np.zeros(self.N)
+        x[self.idx] = self.val
+        return x
+
+
+def rmp(A, b, delta_or_k, maxiter=1):
+    """src/stepwise.jl:5-43: rmp(A,b,δ,maxiter) for a float, rmp(A,b,k) for an int."""
+    P = _Stepwise(A, b)
+    if isinstance(delta_or_k, (int, np.integer)):
+        k = int(delta_or_k)
+        for _ in range(P.M):
+            if not P.forward(0.0, 0.0):
+                break
+        for _ in range(len(P.idx), k, -1):
+            if not P.backward(np.inf, np.inf):
+                break
+        return P.idx, P.val
+    delta = float(delta_or_k)
+    xt = P.dense()
+    for _ in range(maxiter):
+        for _ in range(P.M):
+            if not P.forward(0.0, delta):
+                break
+        if np.allclose(xt, P.dense(), rtol=np.sqrt(np.finfo(float).eps), atol=0) and np.linalg.norm(xt - P.dense()) <= np.sqrt(np.finfo(float).eps) * max(np.linalg.norm(xt), np.linalg.norm(P.dense())):
+            break
+        xt = P.dense()
+        for _ in range(len(P.idx), 0, -1):
+            if not P.backward(np.inf, delta):
+                break
+        if np.linalg.norm(xt - P.dense()) <= np.sqrt(np.finfo(float).eps) * max(np.linalg.norm(xt), np.linalg.norm(P.dense())):
+            break
+        xt = P.dense()
+    return P.idx, P.val
+
+
+def foba(A, b, delta):
+    """src/stepwise.jl:47-56."""
+    P = _Stepwise(A, b)
+    for _ in range(P.M):
+        if not P.forward(0.0, delta):
+            break
+        half = np.sqrt(P.last_max_d2) / 2
+        while P.backward(np.inf, half):
+            pass
+    return P.idx, P.val

@@ -198,6 +198,26 @@ srr_case("srr_f32_128x512_k12", A, y, 12, 1, 1)  # two atoms fewer than planted,
 assert out["srr_f32_128x512_k12.params"][4] >= 3
 srr_case("srr_f32_128x512_k12_init2", A, y, 12, 2, 1)
 
+
+
+# relevance matching pursuit and FoBa (src/stepwise.jl).  params: rmp_k [k]; rmp_delta [delta, maxiter]; foba [delta]
+def stepwise_case(name, algo, A, b, params, f):
+    r, t = f(oc), f(on)
+    agree(r, t, name)
+    add(name, algo, A, b, params, r)
+
+
+A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=95)  # test/stepwise.jl:6-9
+y = cs.perturb(b, 1e-2, rng=96)
+stepwise_case("rmp_k_ref_32x64", "rmp_k", A, y, [3], lambda o: o.rmp(A, y, 3))
+stepwise_case("rmp_delta_ref_32x64", "rmp_delta", A, y, [1e-2, 3], lambda o: o.rmp(A, y, 1e-2, 3))
+stepwise_case("foba_ref_32x64", "foba", A, y, [1e-2], lambda o: o.foba(A, y, 1e-2))
+A, x, b = cs.sparse_data(n=96, m=300, k=8, rng=97, dtype=np.float32)
+y = cs.perturb(b, 5e-2, rng=98)
+stepwise_case("foba_f32_96x300", "foba", A, y, [0.05], lambda o: o.foba(A, y, 0.05))
+for nm in ("rmp_k_ref_32x64", "rmp_delta_ref_32x64", "foba_ref_32x64"):
+    assert len(out[nm + ".idx"]) == 3
+
 out["names"] = np.array(names)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
 np.savez_compressed(path, **out)

@@ -50,6 +50,12 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         elif c["algo"] == "gomp":
             idx, val, order = d.ctx.gomp(b, int(p[0]), int(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
+        elif c["algo"] == "rmp_k":
+            idx, val = d.ctx.rmp(b, int(p[0]))
+        elif c["algo"] == "rmp_delta":
+            idx, val = d.ctx.rmp(b, float(p[0]), int(p[1]))
+        elif c["algo"] == "foba":
+            idx, val = d.ctx.foba(b, float(p[0]))
         elif c["algo"] == "srr":
             idx, val, iters = d.ctx.srr(b, int(p[0]), float(p[1]), -1, int(p[2]), int(p[3]))
             assert iters == int(p[4]), name
@@ -65,7 +71,7 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         else:  # gomp_dupcols: an atom AND its exact copy are both selected -> singular least squares;
             pass  # the reference's own coefficients are NaN/Inf there, only the support is defined
         ran += 1
-    assert ran == len(golden) >= 31
+    assert ran == len(golden) >= 35
 
 
 @pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])
@@ -860,5 +866,47 @@ def test_srr_reference_known_answer(cs, D):
         x1 = cs.sparse_vector(64, 1, rng=seed)
         xs = cs.srr(d, A[:, x1.nzind] @ x1.nzval, 1)
         good &= np.array_equal(xs.nzind, x1.nzind) and np.allclose(xs.nzval, x1.nzval)
+        ok += good
+    assert ok >= 7
+
+
+# ------------------------------------------------------------------------------------------------
+# relevance matching pursuit and FoBa (src/stepwise.jl): loops over forward_step! / backward_step!
+@pytest.mark.parametrize("cfg", [(32, 64, 3, 1e-2, np.float64), (128, 512, 10, 5e-2, np.float32), (96, 300, 8, 5e-2, np.float64),
+                                 (256, 1500, 20, 5e-2, np.float32), (200, 150, 12, 5e-2, np.float64)])
+def test_rmp_and_foba_match_oracle(cs, oracle, D, cfg):
+    n, m, k, noise, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dtype)
+    d = D(A)
+    for seed in range(2):
+        xs = cs.sparse_vector(m, k, rng=seed)
+        y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, noise, rng=seed + 7)
+        for name, fo, fg in (("rmp(delta)", lambda: oracle.rmp(A, y, noise), lambda: d.ctx.rmp(y, noise)),
+                             ("rmp(delta,3)", lambda: oracle.rmp(A, y, noise, 3), lambda: d.ctx.rmp(y, noise, 3)),
+                             ("foba", lambda: oracle.foba(A, y, noise), lambda: d.ctx.foba(y, noise)),
+                             ("rmp(k)", lambda: oracle.rmp(A, y, k), lambda: d.ctx.rmp(y, k, kmax=min(n, m, 3 * k)))):
+            if name == "rmp(k)" and min(n, m) > 3 * k:
+                # rmp(A,b,k) first runs forward until the residual vanishes -- min(M,N) atoms on noisy data; with a
+                # bounded support the library must refuse rather than truncate
+                with pytest.raises(cs.CsmpError):
+                    fg()
+                continue
+            ref, got = fo(), fg()
+            assert np.array_equal(got[0], ref[0]), (name, seed, got[0], ref[0])
+            assert close(got[1], ref[1], tight=False), name
+    xg = cs.foba(d, y, noise)
+    assert np.array_equal(xg.nzind, oracle.foba(A, y, noise)[0])
+
+
+def test_rmp_foba_reference_known_answer(cs, D):
+    """test/stepwise.jl:11-39 on seeded data (32 x 64, k = 3; rmp(A,b,k) fills all 32 rows before pruning)."""
+    ok = 0
+    for seed in range(8):
+        A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=300 + seed)
+        y = cs.perturb(b, 1e-2, rng=seed)
+        d = D(A)
+        good = True
+        for xs in (cs.rmp(d, y, 3), cs.rmp(d, y, 1e-2), cs.rmp(d, y, 1e-2, 3), cs.foba(d, b, 1e-2), cs.foba(d, y, 1e-2)):
+            good &= np.array_equal(xs.nzind, x.nzind) and np.allclose(xs.nzval, x.nzval, atol=2e-2)
         ok += good
     assert ok >= 7

@@ -20,6 +20,12 @@ def run_case(oracle, c):
         return oracle.mp(A, b, int(p[0]))
     if c["algo"] == "sp":
         return oracle.sp(A, b, int(p[0]), float(p[1]))
+    if c["algo"] == "rmp_k":
+        return oracle.rmp(A, b, int(p[0]))
+    if c["algo"] == "rmp_delta":
+        return oracle.rmp(A, b, float(p[0]), int(p[1]))
+    if c["algo"] == "foba":
+        return oracle.foba(A, b, float(p[0]))
     if c["algo"] == "srr":
         return oracle.srr(A, b, int(p[0]), float(p[1]), -1, int(p[2]), int(p[3]))
     if c["algo"] == "fr":
@@ -28,7 +34,7 @@ def run_case(oracle, c):
 
 
 def test_golden_vectors(oracle, golden):
-    assert len(golden) >= 31
+    assert len(golden) >= 35
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
@@ -264,4 +270,29 @@ def test_reference_srr_property_and_twin(oracle, cs):
         y = cs.perturb(b, 1e-1, rng=3)
         r, t = oracle.srr(A, y, k, 1e-12, -1, init, l), oracle_np.srr(A, y, k, 1e-12, None, init, l)
         assert np.array_equal(r[0], t[0]) and r[2] == t[2], (n, m, k, l, init)
+        np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
+
+
+def test_reference_rmp_foba_property_and_twin(oracle, cs):
+    """test/stepwise.jl:11-39 (planted recovery with rmp(A,b,k), rmp(A,y,δ), rmp(A,y,δ,3), foba(A,·,δ)) on seeded
+    data, and the C restatement against the numpy twin."""
+    from oracle import oracle_np
+    ok = 0
+    for seed in range(16):
+        A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=5000 + seed)
+        y = cs.perturb(b, 1e-2, rng=seed)
+        good = True
+        for f in (lambda o: o.rmp(A, y, 3), lambda o: o.rmp(A, y, 1e-2), lambda o: o.rmp(A, y, 1e-2, 3),
+                  lambda o: o.foba(A, b, 1e-2), lambda o: o.foba(A, y, 1e-2)):
+            r, t = f(oracle), f(oracle_np)
+            assert np.array_equal(r[0], t[0])
+            np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
+            good &= np.array_equal(r[0], x.nzind) and np.allclose(r[1], x.nzval, atol=2e-2)
+        ok += good
+    assert ok >= 14
+    A, x, b = cs.sparse_data(n=128, m=512, k=10, rng=3, dtype=np.float32)
+    y = cs.perturb(b, 5e-2, rng=4)
+    for f in (lambda o: o.rmp(A, y, 0.05), lambda o: o.rmp(A, y, 0.05, 3), lambda o: o.foba(A, y, 0.05), lambda o: o.rmp(A, y, 12)):
+        r, t = f(oracle), f(oracle_np)
+        assert np.array_equal(r[0], t[0])
         np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
