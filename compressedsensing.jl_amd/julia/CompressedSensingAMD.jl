@@ -174,6 +174,23 @@ function srr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxit
     to_sparse(size(D, 2), idx, val, nnz[])
 end
 
+# ---------------------------------------------------------------------------------- rmp, foba
+# src/stepwise.jl:5-56 (x starting empty).  kmax bounds the support the forward stage may build (<= 1023).
+function stepwise_call(sym::Symbol, A::MatOrDict, b::AbstractVector, args, argtypes, kmax::Int)
+    D = dict(A)
+    bb, bt = bvec(b)
+    cap = min(size(A, 1), size(A, 2), 1023, kmax > 0 ? kmax : typemax(Int))
+    idx, val, nnz = zeros(Int64, cap + 1), zeros(Float64, cap + 1), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((sym, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, argtypes..., Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, args..., cap, idx, val, nnz))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
+rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0) =
+    stepwise_call(:csmp_rmp_delta, A, b, (Float64(δ), Int64(maxiter)), (Cdouble, Int64), kmax)
+rmp(A::MatOrDict, b::AbstractVector, k::Int; kmax::Int = 0) = stepwise_call(:csmp_rmp_k, A, b, (Int64(k),), (Int64,), kmax)
+foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0) = stepwise_call(:csmp_foba, A, b, (Float64(δ),), (Cdouble,), kmax)
+
 # ---------------------------------------------------------------------------------- functors
 # abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)
 abstract type Update{T} end
