@@ -41,6 +41,7 @@ SIGNATURES = {
     "csmp_rmp_delta": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, i64, vp, vp, C.POINTER(i64)]),
     "csmp_rmp_k": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp, C.POINTER(i64)]),
     "csmp_foba": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, vp, vp, C.POINTER(i64)]),
+    "csmp_br": (C.c_int, [vp, vp, C.c_int, C.c_double, C.c_double, i64, C.c_int, vp, vp, C.POINTER(i64)]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
@@ -284,6 +285,16 @@ class Context:
         val = np.zeros(cap + 1, np.float64)
         nnz = i64(0)
         self.call("csmp_foba", ptr(b), dtype_code(b.dtype), C.c_double(float(delta)), i64(cap), ptr(idx), ptr(val), C.byref(nnz))
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy()
+
+    def br(self, b, max_eps=float("inf"), max_delta=float("inf"), k=0, lace=False):
+        b = self._b(b)
+        idx = np.zeros(self.N + 1, np.int64)
+        val = np.zeros(self.N + 1, np.float64)
+        nnz = i64(0)
+        self.call("csmp_br", ptr(b), dtype_code(b.dtype), C.c_double(float(max_eps)), C.c_double(float(max_delta)),
+                  i64(int(k)), int(bool(lace)), ptr(idx), ptr(val), C.byref(nnz))
         n = nnz.value
         return idx[:n].copy(), val[:n].copy()
 

@@ -11,6 +11,7 @@ Same names, argument meaning and error behaviour as the reference (paths relativ
     FR functor with update!                  src/forward.jl:88-95
     srr(A, b, k, delta=1e-12; maxiter=4k, initialization=1, l=1)          src/twostage.jl:3-33
     rmp(A, b, delta, maxiter=1) / rmp(A, b, k) / foba(A, b, delta)        src/stepwise.jl:5-56
+    br / fbr / lace (A, b, max_eps, max_delta, k) and keyword forms       src/backward.jl:27-41,148-162,226-242
     ompr(A, b, k, delta; maxiter)            src/twostage.jl:184-202
     MP / OMP / GOMP functors with update!    src/matchingpursuit.jl:10-31,44-70,95-123
     argmaxinner!(P[, k])                     src/matchingpursuit.jl:181-193
@@ -223,6 +224,41 @@ def foba(A, b, delta, kmax=None):
     finally:
         if tmp:
             D.close()
+
+
+def _backward(A, b, args, max_residual, max_increase, sparsity, lace, name):
+    if len(args) == 0:  # keyword form (src/backward.jl:38-41,150-153,228-231)
+        max_eps, max_delta, k = max_residual, max_increase, sparsity
+    elif len(args) == 3:
+        max_eps, max_delta, k = args
+    else:
+        raise TypeError(f"{name}(A, b, max_eps, max_delta, k) or {name}(A, b; max_residual, max_increase, sparsity)")
+    M, N, _ = _meta(A)
+    if N > M:
+        raise ValueError(f"A needs to be overdetermined but is of size ({M}, {N})")  # :218
+    D, tmp = _dict(A)
+    try:
+        idx, val = D.ctx.br(b, float(max_eps), float(max_delta), int(k), lace)
+        return SparseVector(N, idx, val)
+    finally:
+        if tmp:
+            D.close()
+
+
+def br(A, b, *args, max_residual=float("inf"), max_increase=float("inf"), sparsity=0):
+    """br(A,b,max_eps,max_delta,k) / br(A,b; max_residual=Inf, max_increase=Inf, sparsity=0): backward regression,
+    src/backward.jl:27-41 (the default isfast = true scores)."""
+    return _backward(A, b, args, max_residual, max_increase, sparsity, False, "br")
+
+
+def fbr(A, b, *args, max_residual=float("inf"), max_increase=float("inf"), sparsity=0):
+    """fbr: the same algorithm as br on the normal equations (src/backward.jl:148-162); here they share one path."""
+    return _backward(A, b, args, max_residual, max_increase, sparsity, False, "fbr")
+
+
+def lace(A, b, *args, max_residual=float("inf"), max_increase=float("inf"), sparsity=0):
+    """lace(A,b,eps,delta,k): least absolute coefficient elimination, src/backward.jl:226-270."""
+    return _backward(A, b, args, max_residual, max_increase, sparsity, True, "lace")
 
 
 def omp_batch(A, B, k, eps=None):

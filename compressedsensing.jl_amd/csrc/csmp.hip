@@ -1848,8 +1848,8 @@ struct Stepwise {
         unmark = false;
         return CSMP_OK;
     }
-    // backward_step!(P, x, max_eps, max_delta)
-    int backward(double max_eps, double max_d2, bool* ok) {
+    // backward_step!(P, x, max_eps, max_delta); lace: LACE's candidate rule (least |x_i|)
+    int backward(double max_eps, double max_d2, bool* ok, bool lace = false) {
         Solver& s = ctx->s;
         *ok = false;
         if (n <= 0) return CSMP_OK;
@@ -1858,7 +1858,8 @@ struct Stepwise {
         if (has_drop) CHECK(flush());
         CHECK(launch_tinv_solve(ctx));
         hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
-                           (const DevState*)s.st, (const double*)s.r, (int)ctx->M, max_eps, max_d2, s.delpos, s.bwd_info);
+                           (const DevState*)s.st, (const double*)s.r, (int)ctx->M, max_eps, max_d2, s.delpos, s.bwd_info,
+                           lace ? (const double*)s.bwd_coef : (const double*)nullptr);
         HIPCHECK(hipGetLastError());
         CHECK(launch_delete_t(ctx));
         HIPCHECK(hipMemcpyAsync(&last_removed, s.delmeta + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -2105,6 +2106,35 @@ extern "C" int csmp_foba(csmp_ctx* ctx, const void* b, int b_dtype, double delta
         }
     }
     CHECK(stepwise_full(ctx, P, kcap));
+    return P.result(idx, val, nnz);
+}
+
+// br(A,b,max_eps,max_delta,k) (src/backward.jl:27-35; fbr :154-162 is the same algorithm on the normal
+// equations) and, with lace != 0, lace(A,b,eps,delta,k) (:233-270): the least-squares solution on ALL
+// N <= M columns, then backward steps until k atoms are left or a threshold stops them.
+extern "C" int csmp_br(csmp_ctx* ctx, const void* b, int b_dtype, double max_eps, double max_delta, int64_t k, int lace,
+                       int64_t* idx, double* val, int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "br"));
+    if (k < 0) return fail(ctx, CSMP_EINVAL, "br: k < 0");
+    if (max_eps != max_eps || max_delta != max_delta) return fail(ctx, CSMP_EINVAL, "br: threshold is NaN");
+    if (ctx->N > ctx->M) return fail(ctx, CSMP_ERANGE, "br: A needs to be overdetermined (size(A,2) <= size(A,1))");  // :218
+    if (ctx->N > kTMaxCols) return fail(ctx, CSMP_ERANGE, "br: more than 1023 columns");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, (int)ctx->N));
+    std::vector<int> all((size_t)ctx->N);
+    for (int64_t j = 0; j < ctx->N; ++j) all[(size_t)j] = (int)j;
+    CHECK(ls_on_columns(ctx, all));  // UpdatableQR(A); x = AiQR \ b   (:11,:30)
+    CHECK(launch_tinv_build(ctx));
+    CHECK(P.read_state());
+    P.n = P.hs.nsel;
+    if (P.hs.done) CHECK(P.clear_flags());
+    const double d2 = max_delta * max_delta;
+    for (int t = P.n; t >= k + 1; --t) {  // :31-33
+        bool ok;
+        CHECK(P.backward(max_eps, d2, &ok, lace != 0));
+        if (!ok) break;
+    }
     return P.result(idx, val, nnz);
 }
 

@@ -262,10 +262,13 @@ __global__ __launch_bounds__(64) void k_bwd_scores(const double* __restrict__ R,
 // src/backward.jl:57): ties go to the smaller atom index.  One workgroup.  Decision of backward_step!
 // (:58-66): the atom is dropped iff sqrt(min + |r|^2) < max_eps and min < max_delta^2; delpos
 // receives its insertion position, or -1.  |r|^2 is taken from r itself.
+// coef != nullptr selects LACE's rule (src/backward.jl:247-270): the candidate is the atom of least |x_i|
+// (argmin(abs, x.nzval), first minimum) and ITS delta2 is what the two thresholds see.
 __global__ __launch_bounds__(256) void k_bwd_pick(const double* __restrict__ sc, const int* __restrict__ sel,
                                                   const DevState* st, const double* __restrict__ r, int M,
                                                   double max_eps, double max_d2, int* __restrict__ delpos,
-                                                  double* __restrict__ info /* [0]=min δ², [1]=|r|^2 */) {
+                                                  double* __restrict__ info /* [0]=min δ², [1]=|r|^2 */,
+                                                  const double* __restrict__ coef = nullptr) {
     __shared__ double sv[256];
     __shared__ int si[256], sp[256];
     __shared__ double red[4];
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void k_bwd_pick(const double* __restrict__ sc,
     double bv = __builtin_inf();
     int bi = 0x7fffffff, bp = -1;
     for (int t = tid; t < n; t += 256) {
-        const double v = sc[t];
+        const double v = coef ? fabs(coef[t]) : sc[t];
         const int a = sel[t];
         if (v < bv || (v == bv && a < bi)) {
             bv = v;
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void k_bwd_pick(const double* __restrict__ sc,
         __syncthreads();
     }
     if (tid == 0) {
-        const double mn = sv[0];
+        const double mn = (coef && sp[0] >= 0) ? sc[sp[0]] : sv[0];
         const bool drop = n > 0 && sp[0] >= 0 && sqrt(mn + n2) < max_eps && mn < max_d2;
         *delpos = drop ? sp[0] : -1;
         info[0] = mn;

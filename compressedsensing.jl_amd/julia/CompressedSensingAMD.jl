@@ -191,6 +191,27 @@ rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0) 
 rmp(A::MatOrDict, b::AbstractVector, k::Int; kmax::Int = 0) = stepwise_call(:csmp_rmp_k, A, b, (Int64(k),), (Int64,), kmax)
 foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0) = stepwise_call(:csmp_foba, A, b, (Float64(δ),), (Cdouble,), kmax)
 
+# ---------------------------------------------------------------------------------- br = fbr, lace
+# src/backward.jl:27-41,148-162,226-242
+function backward_call(A::MatOrDict, b::AbstractVector, max_ε::Real, max_δ::Real, k::Int, lace::Bool)
+    n, m = size(A)
+    n ≥ m || throw("A needs to be overdetermined but is of size ($n, $m)")
+    D = dict(A)
+    bb, bt = bvec(b)
+    idx, val, nnz = zeros(Int64, m + 1), zeros(Float64, m + 1), Ref{Int64}(0)
+    GC.@preserve bb idx val check(D, ccall((:csmp_br, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Cdouble, Int64, Cint, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, max_ε, max_δ, k, lace, idx, val, nnz))
+    to_sparse(m, idx, val, nnz[])
+end
+br(A::MatOrDict, b::AbstractVector, max_ε::Real, max_δ::Real, k::Int) = backward_call(A, b, max_ε, max_δ, k, false)
+br(A::MatOrDict, b::AbstractVector; max_residual::Real = Inf, max_increase::Real = Inf, sparsity::Int = 0) =
+    br(A, b, max_residual, max_increase, sparsity)
+const fbr = br
+lace(A::MatOrDict, b::AbstractVector, ε::Real, δ::Real, k::Int) = backward_call(A, b, ε, δ, k, true)
+lace(A::MatOrDict, b::AbstractVector; max_residual::Real = Inf, max_increase::Real = Inf, sparsity::Int = 0) =
+    lace(A, b, max_residual, max_increase, sparsity)
+
 # ---------------------------------------------------------------------------------- functors
 # abstract type Update; (U::Update)(x) = update!(U, x)   (src/CompressedSensing.jl:22-23)
 abstract type Update{T} end

@@ -133,6 +133,12 @@ int csmp_rmp_k(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, int64_t kma
 int csmp_foba(csmp_ctx *ctx, const void *b, int b_dtype, double delta, int64_t kmax, int64_t *idx, double *val,
               int64_t *nnz);
 
+/* br(A,b,max_eps,max_delta,k) = fbr (src/backward.jl:27-35,154-162) and, with lace != 0,
+ * lace(A,b,eps,delta,k) (:233-270): backward regression from the least-squares solution on all N <= M
+ * columns (N <= 1023).  Infinite thresholds are passed as HUGE_VAL.  Capacity of idx/val: N. */
+int csmp_br(csmp_ctx *ctx, const void *b, int b_dtype, double max_eps, double max_delta, int64_t k, int lace,
+            int64_t *idx, double *val, int64_t *nnz);
+
 /* Many independent signals sharing the resident dictionary: omp(A, B[:,s], eps, k) for
  * s = 0..nsig-1 (the loop a caller of the reference writes around omp; signals are independent,
  * SURVEY.md section 8e).  B: M x nsig column-major (ldB elements) on host or device (b_loc);

@@ -761,10 +761,14 @@ static int srr_forward(srr_t *P, double max_eps, double min_d2, int guarded) {
 }
 /* backward_step!(P, x, max_eps, max_delta): drops the atom of least δ² = x_i²/γ_i if
  * sqrt(min + |r|²) < max_eps and min < max_delta² (src/backward.jl:58); returns 1 if one was dropped */
-static int srr_backward_thr(srr_t *P, double max_eps, double max_d2) {
+static int srr_backward_sel(srr_t *P, double max_eps, double max_d2, int lace);
+static int srr_backward_thr(srr_t *P, double max_eps, double max_d2) { return srr_backward_sel(P, max_eps, max_d2, 0); }
+/* lace != 0: the atom of least |x_i| is the candidate (LACE, src/backward.jl:247-270) and its δ² decides */
+static int srr_backward_sel(srr_t *P, double max_eps, double max_d2, int lace) {
     const int64_t n = P->n;
     if (!(n > 0)) return 0;
     const double normr = nrm2(P->r, P->M);
+    double bkey = INFINITY;
     double *y = (double *)malloc((size_t)n * sizeof(double));
     int64_t best = -1;
     double bv = INFINITY;
@@ -779,7 +783,9 @@ static int srr_backward_thr(srr_t *P, double max_eps, double max_d2) {
             g += y[i] * y[i];
         }
         const double d = P->coef[p] * P->coef[p] / g;
-        if (d < bv) { /* findmin: first minimum */
+        const double key = lace ? fabs(P->coef[p]) : d;
+        if (key < bkey) { /* findmin / argmin(abs, ·): first minimum */
+            bkey = key;
             bv = d;
             best = p;
         }
@@ -972,6 +978,25 @@ int cso_foba(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const d
         while (srr_backward_thr(&P, INFINITY, half * half)) { /* :53 */
         }
     }
+    stepwise_finish(&P, idx, val, nnz);
+    return CSO_OK;
+}
+
+
+/* ---------------------------------------------------------------- backward regression, LACE
+ * br(A,b,max_eps,max_delta,k) src/backward.jl:27-35 (fbr :154-162 is the same algorithm on the normal
+ * equations) and lace(A,b,eps,delta,k) :233-242: start from the least-squares solution on ALL N <= M
+ * columns, then backward steps until k atoms are left or a threshold stops them. */
+int cso_br(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double max_eps,
+           double max_delta, int64_t k, int lace, int64_t *idx, double *val, int64_t *nnz, int nthreads) {
+    if (N > M) return CSO_ERANGE;
+    srr_t P;
+    if (stepwise_init(&P, A, dtype, M, N, ld, b, nthreads) != 0) return CSO_ENOMEM;
+    for (int64_t j = 0; j < N; ++j) P.S[j] = j;
+    P.n = N;
+    srr_refit(&P);
+    for (int64_t s = N; s >= k + 1; --s)
+        if (!srr_backward_sel(&P, max_eps, max_delta * max_delta, lace)) break;
     stepwise_finish(&P, idx, val, nnz);
     return CSO_OK;
 }

@@ -86,6 +86,11 @@ int cso_rmp_k(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const 
 int cso_foba(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double delta,
              int64_t *idx, double *val, int64_t *nnz, int nthreads);
 
+/* br(A,b,max_eps,max_delta,k) (= fbr) and, with lace != 0, lace(A,b,eps,delta,k): src/backward.jl:27-35,
+ * 154-162, 233-270.  Needs N <= M.  idx/val sized >= N + 1. */
+int cso_br(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, double max_eps,
+           double max_delta, int64_t k, int lace, int64_t *idx, double *val, int64_t *nnz, int nthreads);
+
 /* step primitives, exported so tests can pin them one by one */
 /* argmaxinner!: out[j] = |<A[:,j], r>| (src/matchingpursuit.jl:181-184); returns first argmax */
 int64_t cso_sweep_abs(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *r,

@@ -193,6 +193,12 @@ def foba(A, b, delta, nthreads=0):
     return _stepwise(lib().cso_foba, A, b, C.c_double(float(delta)), nthreads=nthreads)
 
 
+def br(A, b, max_eps=np.inf, max_delta=np.inf, k=0, lace=False, nthreads=0):
+    """br / fbr (lace=False) and lace (lace=True): src/backward.jl:27-35,154-162,233-270."""
+    return _stepwise(lib().cso_br, A, b, C.c_double(float(max_eps)), C.c_double(float(max_delta)), i64(int(k)),
+                     int(bool(lace)), nthreads=nthreads)
+
+
 def sweep_abs(A, r, nthreads=0):
     A, r, M, N, dtype = _prep(A, r)
     out = np.zeros(N, np.float64)

@@ -324,6 +324,20 @@ class _Stepwise:
         self._fit()
         return True
 
+    def backward_lace(self, max_eps, max_delta):  # backward_step!(P::LACE, ...): src/backward.jl:247-270
+        if not len(self.idx) > 0:
+            return False
+        normr = np.linalg.norm(self.r)
+        j = int(np.argmin(np.abs(self.val)))
+        keep_idx, keep_val, keep_r = self.idx, self.val, self.r
+        self.idx = np.delete(self.idx, j)
+        self._fit()
+        d2 = np.linalg.norm(self.r) ** 2 - normr ** 2  # measured, as the reference does
+        if np.sqrt(normr ** 2 + d2) < max_eps and d2 < max_delta ** 2:
+            return True
+        self.idx, self.val, self.r = keep_idx, keep_val, keep_r
+        return False
+
     def dense(self):
         x = np.zeros(self.N)
         x[self.idx] = self.val
@@ -369,4 +383,16 @@ def foba(A, b, delta):
         half = np.sqrt(P.last_max_d2) / 2
         while P.backward(np.inf, half):
             pass
+    return P.idx, P.val
+
+
+def br(A, b, max_eps=np.inf, max_delta=np.inf, k=0, lace=False):
+    """br / fbr / lace: src/backward.jl:27-35,154-162,233-242 (all N <= M columns, then backward steps)."""
+    P = _Stepwise(A, b)
+    assert P.N <= P.M
+    P.idx = np.arange(P.N, dtype=np.int64)
+    P._fit()
+    for _ in range(P.N, k, -1):
+        if not (P.backward_lace(max_eps, max_delta) if lace else P.backward(max_eps, max_delta)):
+            break
     return P.idx, P.val

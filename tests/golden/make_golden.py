@@ -218,6 +218,18 @@ stepwise_case("foba_f32_96x300", "foba", A, y, [0.05], lambda o: o.foba(A, y, 0.
 for nm in ("rmp_k_ref_32x64", "rmp_delta_ref_32x64", "foba_ref_32x64"):
     assert len(out[nm + ".idx"]) == 3
 
+
+
+# backward regression and LACE (src/backward.jl).  params = [max_eps, max_delta, k]
+A, x, b = cs.sparse_data(n=32, m=32, k=3, rng=101)  # test/backward.jl:10-14
+y = cs.perturb(b, 5e-3, rng=102)
+BIG = 1e300  # stands for Inf in the fixture
+stepwise_case("br_ref_32x32_k3", "br", A, y, [BIG, BIG, 3], lambda o: o.br(A, y, k=3))
+stepwise_case("br_ref_32x32_eps", "br", A, y, [1e-2, BIG, 0], lambda o: o.br(A, y, max_eps=1e-2))
+stepwise_case("lace_ref_32x32_delta", "lace", A, y, [BIG, 1e-2, 0], lambda o: o.br(A, y, max_delta=1e-2, lace=True))
+for nm in ("br_ref_32x32_k3", "br_ref_32x32_eps", "lace_ref_32x32_delta"):
+    assert np.array_equal(out[nm + ".idx"], x.nzind)
+
 out["names"] = np.array(names)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
 np.savez_compressed(path, **out)

@@ -50,6 +50,8 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         elif c["algo"] == "gomp":
             idx, val, order = d.ctx.gomp(b, int(p[0]), int(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
+        elif c["algo"] in ("br", "lace"):
+            idx, val = d.ctx.br(b, float(p[0]), float(p[1]), int(p[2]), lace=c["algo"] == "lace")
         elif c["algo"] == "rmp_k":
             idx, val = d.ctx.rmp(b, int(p[0]))
         elif c["algo"] == "rmp_delta":
@@ -71,7 +73,7 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         else:  # gomp_dupcols: an atom AND its exact copy are both selected -> singular least squares;
             pass  # the reference's own coefficients are NaN/Inf there, only the support is defined
         ran += 1
-    assert ran == len(golden) >= 35
+    assert ran == len(golden) >= 38
 
 
 @pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])
@@ -910,3 +912,28 @@ def test_rmp_foba_reference_known_answer(cs, D):
             good &= np.array_equal(xs.nzind, x.nzind) and np.allclose(xs.nzval, x.nzval, atol=2e-2)
         ok += good
     assert ok >= 7
+
+
+# ------------------------------------------------------------------------------------------------
+# backward regression / LACE (src/backward.jl): all N <= M columns, then backward steps
+@pytest.mark.parametrize("cfg", [(32, 32, 3, np.float64), (200, 150, 12, np.float32), (512, 300, 20, np.float32), (96, 96, 6, np.float64)])
+def test_br_and_lace_match_oracle(cs, oracle, D, cfg):
+    n, m, k, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + 3 * m, dtype=dtype)
+    y = cs.perturb(b, 2e-2, rng=9)
+    d = D(A)
+    for lace in (False, True):
+        for kw in (dict(k=k), dict(max_eps=0.03), dict(max_delta=0.01), dict(k=2 * k, max_eps=0.5)):
+            ref = oracle.br(A, y, lace=lace, **kw)
+            got = d.ctx.br(y, lace=lace, **kw)
+            assert np.array_equal(got[0], ref[0]), (lace, kw, got[0], ref[0])
+            assert close(got[1], ref[1], tight=False), (lace, kw)
+    # public drivers, keyword and positional forms (src/backward.jl:27-41,148-162,226-242)
+    ref = oracle.br(A, y, k=k)
+    for f in (cs.br, cs.fbr):
+        xg = f(d, y, sparsity=k)
+        assert np.array_equal(xg.nzind, ref[0]) and close(xg.nzval, ref[1], tight=False)
+    assert np.array_equal(cs.br(d, y, np.inf, np.inf, k).nzind, ref[0])
+    assert np.array_equal(cs.lace(d, y, sparsity=k).nzind, oracle.br(A, y, k=k, lace=True)[0])
+    with pytest.raises(ValueError):
+        cs.br(np.zeros((4, 8)), np.zeros(4), sparsity=1)

@@ -20,6 +20,8 @@ def run_case(oracle, c):
         return oracle.mp(A, b, int(p[0]))
     if c["algo"] == "sp":
         return oracle.sp(A, b, int(p[0]), float(p[1]))
+    if c["algo"] in ("br", "lace"):
+        return oracle.br(A, b, float(p[0]), float(p[1]), int(p[2]), lace=c["algo"] == "lace")
     if c["algo"] == "rmp_k":
         return oracle.rmp(A, b, int(p[0]))
     if c["algo"] == "rmp_delta":
@@ -34,7 +36,7 @@ def run_case(oracle, c):
 
 
 def test_golden_vectors(oracle, golden):
-    assert len(golden) >= 35
+    assert len(golden) >= 38
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
@@ -296,3 +298,27 @@ def test_reference_rmp_foba_property_and_twin(oracle, cs):
         r, t = f(oracle), f(oracle_np)
         assert np.array_equal(r[0], t[0])
         np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
+
+
+def test_reference_br_lace_property_and_twin(oracle, cs):
+    """test/backward.jl:17-41 (br / lace / fbr with sparsity = k, max_residual = δ, max_increase = δ on a square
+    32 x 32 system) on seeded data, and the C restatement against the numpy twin (whose LACE step measures
+    the residual increase by re-solving, as the reference does)."""
+    from oracle import oracle_np
+    ok = tot = 0
+    for seed in range(12):
+        A, x, b = cs.sparse_data(n=32, m=32, k=3, rng=6000 + seed)
+        y = cs.perturb(b, 5e-3, rng=seed)
+        for lace in (False, True):
+            for kw in (dict(k=3), dict(max_eps=1e-2), dict(max_delta=1e-2)):
+                r, t = oracle.br(A, y, lace=lace, **kw), oracle_np.br(A, y, lace=lace, **kw)
+                assert np.array_equal(r[0], t[0])
+                np.testing.assert_allclose(r[1], t[1], rtol=1e-7, atol=1e-10)
+                tot += 1
+                ok += np.array_equal(r[0], x.nzind) and np.allclose(r[1], x.nzval, atol=2e-2)
+    assert ok >= tot - 4
+    A, x, b = cs.sparse_data(n=200, m=150, k=12, rng=5, dtype=np.float32)
+    y = cs.perturb(b, 5e-2, rng=4)
+    for kw in (dict(k=12), dict(max_eps=0.06), dict(max_delta=0.02), dict(k=20, lace=True), dict(max_eps=0.06, lace=True)):
+        r, t = oracle.br(A, y, **kw), oracle_np.br(A, y, **kw)
+        assert np.array_equal(r[0], t[0]), kw
