@@ -937,3 +937,49 @@ def test_br_and_lace_match_oracle(cs, oracle, D, cfg):
     assert np.array_equal(cs.lace(d, y, sparsity=k).nzind, oracle.br(A, y, k=k, lace=True)[0])
     with pytest.raises(ValueError):
         cs.br(np.zeros((4, 8)), np.zeros(4), sparsity=1)
+
+
+def test_stepwise_family_edge_cases(cs, oracle, D):
+    """Degenerate inputs through every §8f driver: b = 0, k = 1, fewer atoms than a wave, two rows."""
+    rng = np.random.default_rng(5)
+    # b = 0: forward steps stop at once (norm(r) > max_eps fails), the bulk initialisers still fill their support
+    A, x, b = cs.sparse_data(n=40, m=30, k=3, rng=1)
+    d = D(A)
+    z = np.zeros(40)
+    assert len(d.ctx.fr(z, 5)[0]) == 0 and len(oracle.fr(A, z, 5)[0]) == 0
+    assert len(d.ctx.rmp(z, 1e-2)[0]) == 0 and len(d.ctx.foba(z, 1e-2)[0]) == 0 and len(d.ctx.rmp(z, 2)[0]) == 0
+    got, ref = d.ctx.srr(z, 4), oracle.srr(A, z, 4)
+    assert np.array_equal(got[0], ref[0]) and np.all(got[1] == 0.0) and got[2] == ref[2]
+    got, ref = d.ctx.br(z, k=3), oracle.br(A, z, k=3)
+    assert np.array_equal(got[0], ref[0]) and np.allclose(got[1], 0.0, atol=1e-300)
+    # k = 1 everywhere
+    y = cs.perturb(b, 1e-2, rng=2)
+    for fo, fg in ((lambda: oracle.fr(A, y, 1), lambda: d.ctx.fr(y, 1)),
+                   (lambda: oracle.srr(A, y, 1), lambda: d.ctx.srr(y, 1)),
+                   (lambda: oracle.srr(A, y, 1, 1e-12, -1, 2, 1), lambda: d.ctx.srr(y, 1, 1e-12, -1, 2, 1)),
+                   (lambda: oracle.rmp(A, y, 1), lambda: d.ctx.rmp(y, 1)),
+                   (lambda: oracle.br(A, y, k=1), lambda: d.ctx.br(y, k=1)),
+                   (lambda: oracle.ompr(A, y, 1, 1e-6), lambda: d.ctx.ompr(y, 1, 1e-6))):
+        r, g = fo(), fg()
+        assert np.array_equal(g[0], r[0]) and close(g[1], r[1], tight=False)
+    # two rows, a handful of atoms (f32): every kernel runs with almost all lanes idle
+    A2 = np.asfortranarray(rng.standard_normal((2, 7)).astype(np.float32))
+    A2 /= np.linalg.norm(A2, axis=0)
+    y2 = rng.standard_normal(2)
+    d2 = D(A2)
+    for fo, fg in ((lambda: oracle.fr(A2, y2, 2), lambda: d2.ctx.fr(y2, 2)),
+                   (lambda: oracle.omp(A2, y2, 2, 0.0), lambda: d2.ctx.omp(y2, 2, 0.0)),
+                   (lambda: oracle.srr(A2, y2, 1), lambda: d2.ctx.srr(y2, 1)),
+                   (lambda: oracle.foba(A2, y2, 1e-3), lambda: d2.ctx.foba(y2, 1e-3))):
+        r, g = fo(), fg()
+        assert np.array_equal(g[0], r[0]), (g, r)
+        assert close(g[1], r[1], tight=False)
+    # argument errors mirror the reference's / the header's
+    with pytest.raises(cs.CsmpError):
+        d.ctx.srr(y, 0)
+    with pytest.raises(cs.CsmpError):
+        d.ctx.srr(y, 39, 1e-12, -1, 1, 2)  # k + l > M
+    with pytest.raises(cs.CsmpError):
+        d.ctx.srr(y, 3, 1e-12, -1, 3, 1)  # initialization 3 is not offered
+    with pytest.raises(cs.CsmpError):
+        D(np.asfortranarray(rng.standard_normal((8, 20)))).ctx.br(np.zeros(8), k=1)  # underdetermined
