@@ -9,11 +9,11 @@ from .data import sparse_vector, sparse_data, gaussian_data, perturb, samesuppor
 from ._lib import CsmpError, Context, LIB_PATH
 from .api import (Dictionary, mp, omp, gomp, sp, ompr, srr, rmp, foba, br, fbr, lace, fr, ols, oomp, ormp, FR, OLS, omp_batch, omp_batch_mfma, MP, OMP, GOMP, update_, argmaxinner,
                   oblivious, oblivious_acquisition, random_acquisition)
-from .sharded import omp_sharded, shard_range
+from .sharded import omp_sharded, shard_range, sharded_solve, fr_sharded
 
 __all__ = [
     "SparseVector", "spzeros", "sparse_vector", "sparse_data", "gaussian_data", "perturb", "samesupport",
     "CsmpError", "Context", "Dictionary", "mp", "omp", "gomp", "sp", "ompr", "srr", "rmp", "foba", "br", "fbr", "lace", "fr", "ols", "oomp", "ormp", "FR", "OLS", "omp_batch", "omp_batch_mfma", "MP", "OMP", "GOMP",
     "oblivious", "oblivious_acquisition", "random_acquisition",
-    "update_", "argmaxinner", "omp_sharded", "shard_range",
+    "update_", "argmaxinner", "omp_sharded", "shard_range", "sharded_solve", "fr_sharded",
 ]

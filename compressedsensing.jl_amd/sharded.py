@@ -60,3 +60,25 @@ def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None):
         rlo, rhi = shard_range(nsig, r, world)
         bufs.append(out[r][:rhi - rlo].cpu().numpy())
     return unpack(np.concatenate(bufs, axis=0), k)
+
+
+def sharded_solve(B, cap, one, group=None, device=None):
+    """The same sharding for ANY single-signal solver of the package: `one(b) -> (idx, val[, ...])` is called
+    for the signals of this rank's block (e.g. `lambda b: D.ctx.fr(b, k)`, `lambda b: D.ctx.srr(b, k)`); `cap`
+    bounds nnz.  Every rank returns (idx cap x nsig padded with -1, val, nnz) after the single all_gather."""
+    def solver(Bl, kk, eps):
+        n = Bl.shape[1]
+        idx = -np.ones((kk, n), np.int64)
+        val = np.zeros((kk, n))
+        nnz = np.zeros(n, np.int64)
+        for s in range(n):
+            r = one(Bl[:, s])
+            i, v = r[0], r[1]
+            idx[:len(i), s], val[:len(i), s], nnz[s] = i, v, len(i)
+        return idx, val, nnz
+    return omp_sharded(None, B, cap, eps=0.0, group=group, solver=solver, device=device)
+
+
+def fr_sharded(D, B, k, max_eps=0.0, min_delta=0.0, group=None):
+    """fr (forward regression / OLS) for every column of B, signals sharded over the ranks."""
+    return sharded_solve(B, k, lambda b: D.ctx.fr(b, k, max_eps, min_delta), group=group)

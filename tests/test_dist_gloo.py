@@ -64,3 +64,37 @@ def test_omp_sharded_gloo_world2(nsig, oracle):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _worker_generic(rank, world, port, nsig, k, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from csmp_pkg import load
+    from oracle import oracle_c
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    A, x, b = cs.sparse_data(n=48, m=160, k=k, rng=6)
+    rng = np.random.default_rng(78)
+    B = np.asfortranarray(np.stack([cs.perturb(A @ cs.sparse_vector(160, k, rng=rng).to_dense(), 5e-3, rng=rng) for _ in range(nsig)], axis=1))
+    # forward regression with a residual stop: signals end with different nnz, the gather must keep them apart
+    idx, val, nnz = cs.sharded_solve(B, k + 2, lambda bb: oracle_c.fr(A, bb, k + 2, 0.02, 0.0, nthreads=1))
+    ok = idx.shape == (k + 2, nsig)
+    for s in range(nsig):
+        i, v, _ = oracle_c.fr(A, B[:, s], k + 2, 0.02, 0.0, nthreads=1)
+        ok &= nnz[s] == len(i) and np.array_equal(idx[:len(i), s], i) and np.array_equal(val[:len(i), s], v)
+        ok &= bool(np.all(idx[len(i):, s] == -1))
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_sharded_solve_generic_gloo_world2(oracle):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_generic, args=(r, 2, port, 7, 4, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]
