@@ -195,7 +195,7 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
             "config": {"workload": "configs[2]/[3]: batched OMP, 1024 signals per GPU sharing A 4096x65536 Float32, k=128",
                        "signals_per_gpu_per_step": nsig, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
             "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
-                         "kernel": "csmp::k_b_screen (v_mfma_f32_32x32x16_bf16, 128x128 tiles, fused top-4 epilogue)",
+                         "kernel": D.ctx.batch_screen_kernel(),
                          "launches_timed": int(screen_n), "flops_per_launch": flops},
             "signals_resolved_by_exact_path": int(resolved), "matches_exact_path_on_sample": same,
         }), flush=True)

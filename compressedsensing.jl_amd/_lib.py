@@ -45,6 +45,7 @@ SIGNATURES = {
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(C.c_double)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
@@ -343,6 +344,9 @@ class Context:
         code = F32 if B.dtype == torch.float32 else F64
         self.call("csmp_omp_batch_mfma", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(k)), C.c_double(eps),
                   vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
+
+    def batch_screen_kernel(self):
+        return lib().csmp_batch_screen_kernel(self._h).decode()
 
     def batch_stats(self):
         v = [i64(0) for _ in range(5)]

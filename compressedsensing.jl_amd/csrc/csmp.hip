@@ -79,6 +79,7 @@ struct Batch {
     float* cand_val = nullptr;
     int* cand_idx = nullptr;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
+    bool last_big = false;  // the last batch used the 256^2 screening kernel
 };
 
 struct csmp_ctx {
@@ -2156,7 +2157,7 @@ static int batch_dict(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
     if (b.ab_valid) return CSMP_OK;
     b.Mk = (int)(((ctx->M + kBK - 1) / kBK) * kBK);
-    b.Npad = ((ctx->N + kBT - 1) / kBT) * kBT;
+    b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles (k_b_screen256)
     b.n_atiles = (int)(b.Npad / kBT);
     HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
     HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
@@ -2180,7 +2181,7 @@ static int batch_dict(csmp_ctx* ctx) {
 
 static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     Batch& b = ctx->bt;
-    const int Bpad = ((nsig + kBT - 1) / kBT) * kBT;
+    const int Bpad = ((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);
     if (b.Bcap >= Bpad && b.kcap >= kcap) return CSMP_OK;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     const int nb = std::max(Bpad, b.Bcap), nk = std::max(kcap, b.kcap);
@@ -2256,14 +2257,16 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         HIPCHECK(hipMalloc((void**)&d_val, (size_t)k * nsig * 8));
         HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
     }
-    const int Bpad = (int)(((nsig + kBT - 1) / kBT) * kBT);
+    const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
     const int n_stiles = Bpad / kBT;
     if (b_dtype == CSMP_F32)
         hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
     else
         hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipFuncSetAttribute((const void*)k_b_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds));
+    // 256^2 tiles with LDS-DMA staging whenever both edges tile by 256 (knob CSMP_SCREEN_128: the 128^2 kernel)
+    const bool big = !getenv("CSMP_SCREEN_128") && (b.n_atiles % 2 == 0) && (n_stiles % 2 == 0);
+    b.last_big = big;
     // screening error bound (8 sigma of the bf16 rounding model): delta = coef * ||r||
     const double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
     for (int64_t t = 0; t < k; ++t) {
@@ -2271,9 +2274,8 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
             if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
             HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
         }
-        hipLaunchKernelGGL(k_b_screen, dim3(b.n_atiles * n_stiles), dim3(256), kScreenLds, ctx->stream, (const __bf16*)b.Ab,
-                           (const __bf16*)b.Rb, b.Mk, b.n_atiles, n_stiles, ctx->N, b.cand_val, b.cand_idx);
-        HIPCHECK(hipGetLastError());
+        HIPCHECK(launch_screen(ctx->stream, big, (const __bf16*)b.Ab, (const __bf16*)b.Rb, b.Mk, b.n_atiles, n_stiles, ctx->N,
+                               b.cand_val, b.cand_idx));
         if (ctx->prof) {
             if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
             HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
@@ -2321,6 +2323,9 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     }
     return rc;
 }
+
+// name of the screening kernel the last csmp_omp_batch_mfma call used (for the bench's roofline line)
+extern "C" const char* csmp_batch_screen_kernel(const csmp_ctx* ctx) { return ctx ? screen_kernel_name(ctx->bt.last_big) : ""; }
 
 extern "C" int csmp_batch_stats(csmp_ctx* ctx, int64_t* signals, int64_t* resolved_exactly, int64_t* uncertain, int64_t* illcond,
                                 int64_t* screen_launches, double* screen_ms) {

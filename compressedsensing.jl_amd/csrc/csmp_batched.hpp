@@ -23,19 +23,14 @@
 // mat-vecs and the only large traffic is two streams over the support's f32 columns of A.
 #pragma once
 #include "csmp_kernels.hpp"
+#include "csmp_screen.hpp"
 
 namespace csmp {
 
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kBT = 128;         // tile edge: atoms x signals
-constexpr int kBK = 64;          // k elements staged per step
-constexpr int kBRow = 144;       // LDS bytes per staged row: 128 + 16 pad -> conflict-free ds_read_b128
-constexpr int kTileCand = 4;     // candidates kept per (signal, atom tile)
 constexpr int kKeep = 16;        // candidates rescored per signal and step
-constexpr size_t kScreenLds = 2 * 2 * kBT * kBRow;  // [buffer][A|R][row] = 73,728 B
 
 struct BState {
     int nsel, done, uncertain, illcond;
@@ -58,162 +53,6 @@ __global__ __launch_bounds__(256) void k_b_convert(const TA* __restrict__ A, int
         v[e] = (__bf16)((n < N && k < M) ? (float)A[n * ld + k] : 0.0f);
     }
     *reinterpret_cast<bf16x8*>(out + n * Mk + c * 8) = v;
-}
-
-// ---------------------------------------------------------------------------------------------
-// Screening GEMM.  D[atom][signal] = sum_k A[atom][k] R[signal][k]; A-operand rows = atoms,
-// B-operand columns = signals, so a lane's 16 accumulator registers are 16 atoms of ONE signal
-// (C/D map of 32x32 MFMA: col = lane&31, row = (reg&3) + 8(reg>>2) + 4(lane>>5)).
-// 4 waves as 2 (atoms) x 2 (signals), each 64 x 64 = 2 x 2 MFMA tiles; BK = 64 staged through LDS
-// (register staging, padded rows), double buffered, one barrier per k-step.
-// Block map: the 8 XCDs each take whole atom tiles and walk all signal tiles of it back to back, so
-// an atom tile's 1 MiB of bf16 is fetched into one L2 once.
-struct top4 {
-    float v[4];
-    int i[4];
-};
-// insert (v, i) into the descending list (ties: lower atom index first)
-__device__ __forceinline__ void top4_push(top4& t, float v, int i) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const bool up = (v > t.v[q]) || (v == t.v[q] && i < t.i[q]);
-        const float tv = up ? t.v[q] : v;
-        const int ti = up ? t.i[q] : i;
-        t.v[q] = up ? v : t.v[q];
-        t.i[q] = up ? i : t.i[q];
-        v = tv;
-        i = ti;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
-                                                  int n_atiles, int n_stiles, int64_t N,
-                                                  float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1, r = lane & 31, h = lane >> 5;
-    int atile, stile;
-    {
-        const int bid = blockIdx.x;
-        if ((n_atiles & 7) == 0) {
-            const int xcd = bid & 7, local = bid >> 3;
-            stile = local % n_stiles;
-            atile = (local / n_stiles) * 8 + xcd;
-        } else {
-            stile = bid % n_stiles;
-            atile = bid / n_stiles;
-        }
-    }
-    const __bf16* gA = Ab + (int64_t)atile * kBT * Mk;
-    const __bf16* gR = Rb + (int64_t)stile * kBT * Mk;
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x16)0.0f;
-
-    // staging map: 1024 16-B pieces per operand tile, 4 per thread
-    int srow[4], skc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p = tid + 256 * i;
-        srow[i] = p >> 3;
-        skc[i] = p & 7;
-    }
-    // Two register sets: the tile for k-step kb+1 is written to LDS while the loads for kb+2 and kb+3 are
-    // already in flight, so a global load has two full MFMA phases (and a barrier) to land.
-    bf16x8 ra0[4], rr0[4], ra1[4], rr1[4];
-    const int nkb = Mk / kBK;
-    auto gload = [&](bf16x8 (&ra)[4], bf16x8 (&rr)[4], int kb) {
-        if (kb >= nkb) return;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            ra[i] = *reinterpret_cast<const bf16x8*>(gA + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
-            rr[i] = *reinterpret_cast<const bf16x8*>(gR + (int64_t)srow[i] * Mk + kb * kBK + skc[i] * 8);
-        }
-    };
-    auto lstore = [&](const bf16x8 (&ra)[4], const bf16x8 (&rr)[4], int buf) {
-        char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow;
-        char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<bf16x8*>(la + srow[i] * kBRow + skc[i] * 16) = ra[i];
-            *reinterpret_cast<bf16x8*>(lr + srow[i] * kBRow + skc[i] * 16) = rr[i];
-        }
-    };
-    auto compute = [&](int buf) {
-        const char* la = smem + (size_t)(buf * 2 + 0) * kBT * kBRow + (wr * 64 + r) * kBRow + h * 16;
-        const char* lr = smem + (size_t)(buf * 2 + 1) * kBT * kBRow + (wc * 64 + r) * kBRow + h * 16;
-#pragma unroll
-        for (int kk = 0; kk < kBK / 16; ++kk) {
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + kk * 32);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(la + 32 * kBRow + kk * 32);
-            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lr + kk * 32);
-            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lr + 32 * kBRow + kk * 32);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    };
-    gload(ra0, rr0, 0);
-    lstore(ra0, rr0, 0);
-    gload(ra0, rr0, 1);
-    gload(ra1, rr1, 2);
-    __syncthreads();
-    for (int kb = 0; kb < nkb; kb += 2) {
-        compute(0);                                   // tile kb
-        if (kb + 1 < nkb) lstore(ra0, rr0, 1);        // tile kb+1
-        gload(ra0, rr0, kb + 3);
-        __syncthreads();
-        if (kb + 1 < nkb) {
-            compute(1);                               // tile kb+1
-            if (kb + 2 < nkb) lstore(ra1, rr1, 0);    // tile kb+2
-            gload(ra1, rr1, kb + 4);
-            __syncthreads();
-        }
-    }
-
-    // epilogue: the 4 largest |c| per signal over this tile's 128 atoms
-    top4* sc = reinterpret_cast<top4*>(smem);  // [2 (wr)][128 signals]
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        top4 t;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            t.v[q] = -1.0f;
-            t.i[q] = 0x7fffffff;
-        }
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int atom = atile * kBT + wr * 64 + m * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-                const float v = (atom < N) ? fabsf(acc[m][n][q]) : -1.0f;
-                top4_push(t, v, atom);
-            }
-        // merge the two lane halves (same signal, interleaved atoms)
-        top4 o;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            o.v[q] = __shfl_xor(t.v[q], 32, kWave);
-            o.i[q] = __shfl_xor(t.i[q], 32, kWave);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) top4_push(t, o.v[q], o.i[q]);
-        if (h == 0) sc[wr * kBT + wc * 64 + n * 32 + r] = t;
-    }
-    __syncthreads();
-    if (tid < kBT) {
-        top4 t = sc[tid];
-        const top4 o = sc[kBT + tid];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) top4_push(t, o.v[q], o.i[q]);
-        const int64_t sig = (int64_t)stile * kBT + tid;
-        const int64_t base = (sig * n_atiles + atile) * kTileCand;
-        *reinterpret_cast<f32x4*>(cand_val + base) = f32x4{t.v[0], t.v[1], t.v[2], t.v[3]};
-        *reinterpret_cast<int4*>(cand_idx + base) = make_int4(t.i[0], t.i[1], t.i[2], t.i[3]);
-    }
 }
 
 // ---------------------------------------------------------------------------------------------

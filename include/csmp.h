@@ -162,6 +162,8 @@ int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, 
  * why), and -- when profiling is enabled -- the number and total duration (ms) of screening GEMMs */
 int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly, int64_t *uncertain, int64_t *illcond,
                      int64_t *screen_launches, double *screen_ms);
+/* name of the screening kernel the last csmp_omp_batch_mfma call ran (measurement only) */
+const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 
 /* ------------------------------------------------------------------ step-level API
  * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) / FR(A,b) then update!(P,x)
