@@ -228,12 +228,15 @@ __global__ __launch_bounds__(512) void k_b_screen256(const __bf16* __restrict__ 
             bf16x8 b[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const bf16x8*>(lr + t * 16 * 128 + co);
+            bf16x8 a[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(la + m * 16 * 128 + co);
+            for (int m = 0; m < 8; ++m) a[m] = *reinterpret_cast<const bf16x8*>(la + m * 16 * 128 + co);
+            __builtin_amdgcn_s_setprio(1);  // the MFMA cluster of this wave ahead of the other wave's address / DMA issue
 #pragma unroll
-                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[n], acc[m][n], 0, 0, 0);
-            }
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
     };
     issue(0, 0);
