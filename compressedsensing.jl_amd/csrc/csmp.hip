@@ -105,6 +105,7 @@ struct csmp_ctx {
     int tick_wg_per_cu = 2;  // sweep workgroups per CU inside the tick kernel (CSMP_TICK_WGS)
     bool tick_pf = true;     // software-pipelined sweep inside the tick kernel (CSMP_TICK_PF)
     int tick_nblk = 0;       // absolute override of the sweep workgroup count (CSMP_TICK_NBLK), 0 = per-CU rule
+    bool tick_sweep_first = false;  // dispatch the sweep workgroups ahead of the append stages (CSMP_TICK_ORDER=1)
     Batch bt;
     // profiling
     bool prof = false;
@@ -186,6 +187,7 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
     ctx->pipeline = !(pl && pl[0] == '0');
     if (const char* tw = getenv("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
     if (const char* tn = getenv("CSMP_TICK_NBLK")) ctx->tick_nblk = std::max(0, atoi(tn));
+    if (const char* to = getenv("CSMP_TICK_ORDER")) ctx->tick_sweep_first = atoi(to) != 0;
     if (const char* tp = getenv("CSMP_TICK_PF")) ctx->tick_pf = tp[0] != '0';
     // test knob: CSMP_FORCE_REORTH=1 always runs the second Gram-Schmidt pass (k_qr3)
     const char* fr = getenv("CSMP_FORCE_REORTH");
@@ -696,7 +698,7 @@ static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const Ti
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G);
+    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, ctx->tick_sweep_first ? 1 : 0);
     return hipGetLastError();
 }
 template <typename TA>

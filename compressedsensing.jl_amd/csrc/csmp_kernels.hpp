@@ -1177,9 +1177,13 @@ struct TickQr2 {
 
 template <typename TA, int U, bool PF>
 __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
-                                                        const int G) {
+                                                        const int G, const int sweep_first) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int bid = (int)blockIdx.x;
+    // Workgroups are dispatched in index order.  sweep_first (CSMP_TICK_ORDER): the persistent sweep
+    // workgroups take their CUs at t = 0 and the short append stages fill what is left, instead of the sweep
+    // tail starting only when the stages have drained.
+    int bid = (int)blockIdx.x;
+    if (sweep_first) bid = bid < sw.nblk ? bid + 2 * G : bid - sw.nblk;
     if (bid < G) {
         if (q2.active)
             qr2_body<8>(q2.Q, q2.ldq, q2.st, q2.avec, q2.r, q2.P1, q2.P1s, q2.G, q2.W1, q2.vvec, q2.P2, q2.P2s, q2.R, q2.z,
