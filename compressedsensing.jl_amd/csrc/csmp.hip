@@ -835,8 +835,13 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
     full = false;
     if (ctx->Mv % rows == 0) {
         const int nchunk = ctx->Mv / rows;
+        // Measured at 4096 x 65536 f32 (profiles/r01_bench_fr_line.json): 8-chunk blocks on one workgroup per CU
+        // 168 us, 16-chunk blocks on 3/4 of the CUs (the OMP sweep's optimum) 173 us -- with a second LDS image
+        // to read per chunk, the extra waves hide more than the extra DRAM streams cost.
+        const char* fu = getenv("CSMP_FR_U");  // tuning knob: cap the load-block size
+        const int umax = fu ? atoi(fu) : 8;
         for (int u : {16, 8})
-            if (nchunk % u == 0) {
+            if (u <= umax && nchunk % u == 0) {
                 U = u;
                 full = true;
                 break;
