@@ -983,3 +983,34 @@ def test_stepwise_family_edge_cases(cs, oracle, D):
         d.ctx.srr(y, 3, 1e-12, -1, 3, 1)  # initialization 3 is not offered
     with pytest.raises(cs.CsmpError):
         D(np.asfortranarray(rng.standard_normal((8, 20)))).ctx.br(np.zeros(8), k=1)  # underdetermined
+
+
+def test_context_reuse_across_dictionaries_and_solver_families(cs, oracle):
+    """One ctx, dictionaries of growing and shrinking size, every solver family in turn: the lazily
+    allocated buffers (OLS rescaling, T = R^-1, panels, batch state) must follow the dictionary."""
+    ctx = cs.Context(0)
+    try:
+        for (n, m, k, dtype, seed) in [(64, 200, 5, np.float64, 1), (256, 3000, 20, np.float32, 2), (48, 90, 4, np.float32, 3),
+                                       (300, 280, 12, np.float64, 4)]:
+            A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=seed, dtype=dtype)
+            y = cs.perturb(b, 2e-2, rng=seed)
+            ctx.set_dictionary(A)
+            for got, ref in ((ctx.omp(y, k, 0.0), oracle.omp(A, y, k, 0.0)),
+                             (ctx.fr(y, k), oracle.fr(A, y, k)),
+                             (ctx.srr(y, k), oracle.srr(A, y, k)),
+                             (ctx.ompr(y, k, 1e-9), oracle.ompr(A, y, k, 1e-9)),
+                             (ctx.gomp(y, 2, k, 0.0), oracle.gomp(A, y, 2, k, 0.0)),
+                             (ctx.foba(y, 2e-2), oracle.foba(A, y, 2e-2)),
+                             (ctx.sp(y, k, 1e-12), oracle.sp(A, y, k, 1e-12))):
+                assert np.array_equal(got[0], ref[0]), (n, m)
+                assert close(got[1], ref[1], tight=False)
+            if m <= n:
+                got, ref = ctx.br(y, k=k), oracle.br(A, y, k=k)
+                assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1], tight=False)
+            B = np.asfortranarray(np.stack([y, 0.5 * y, -y], axis=1))
+            idx, val, nnz = ctx.omp_batch_mfma(B, k, 0.0)
+            ref = oracle.omp(A, y, k, 0.0)
+            for s_ in range(3):
+                assert np.array_equal(np.sort(idx[:nnz[s_], s_]), ref[0])
+    finally:
+        ctx.close()
