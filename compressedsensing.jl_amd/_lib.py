@@ -42,6 +42,7 @@ SIGNATURES = {
     "csmp_rmp_k": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp, C.POINTER(i64)]),
     "csmp_foba": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, vp, vp, C.POINTER(i64)]),
     "csmp_br": (C.c_int, [vp, vp, C.c_int, C.c_double, C.c_double, i64, C.c_int, vp, vp, C.POINTER(i64)]),
+    "csmp_fr_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
@@ -318,6 +319,32 @@ class Context:
         self.call("csmp_omp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
                   C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
         return idx, val, nnz
+
+    def fr_batch(self, B, k, max_eps=0.0, min_delta=0.0):
+        """fr for every column of the host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz)."""
+        B = np.asfortranarray(B)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        M, nsig = B.shape
+        if M != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {M} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), nsig), np.int64, order="F")
+        val = np.zeros((int(k), nsig), np.float64, order="F")
+        nnz = np.zeros(nsig, np.int64)
+        self.call("csmp_fr_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
+                  C.c_double(max_eps), C.c_double(min_delta), ptr(idx), ptr(val), ptr(nnz), HOST)
+        return idx, val, nnz
+
+    def fr_batch_device(self, B, k, max_eps, min_delta, idx, val, nnz):
+        """torch CUDA tensors as in omp_batch_device.  Only enqueues work; call sync()."""
+        import torch
+        nsig, M = B.shape
+        assert B.is_cuda and B.is_contiguous() and M == self.M
+        assert idx.dtype == torch.int64 and val.dtype == torch.float64 and nnz.dtype == torch.int64
+        assert idx.is_contiguous() and val.is_contiguous() and idx.shape == (nsig, int(k)) and val.shape == (nsig, int(k))
+        code = F32 if B.dtype == torch.float32 else F64
+        self.call("csmp_fr_batch", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(k)), C.c_double(max_eps),
+                  C.c_double(min_delta), vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
 
     def omp_batch_mfma(self, B, k, eps):
         """Batched (MFMA-screened) variant of omp_batch: same inputs and outputs."""

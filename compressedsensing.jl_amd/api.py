@@ -274,6 +274,17 @@ def omp_batch(A, B, k, eps=None):
             D.close()
 
 
+def fr_batch(A, B, k, max_eps=0.0, min_delta=0.0):
+    """[fr(A, B[:, s], max_eps, min_delta, k) for s in axes(B, 2)]: list of SparseVectors (pipelined on the device)."""
+    D, tmp = _dict(A)
+    try:
+        idx, val, nnz = D.ctx.fr_batch(B, int(k), float(max_eps), float(min_delta))
+        return [SparseVector(D.shape[1], idx[:nnz[s], s].copy(), val[:nnz[s], s].copy()) for s in range(idx.shape[1])]
+    finally:
+        if tmp:
+            D.close()
+
+
 def omp_batch_mfma(A, B, k, eps=None):
     """omp_batch through the batched variant (BASELINE configs 3/4): one bf16 MFMA screening GEMM per
     step for all signals, Float64 rescoring -- identical results, ~150x the single-signal throughput."""

@@ -891,6 +891,64 @@ static int fr_step(csmp_ctx* ctx, bool first, double max_eps, double min_d2, boo
     return launch_append(ctx, 3, 0, skip, optimistic, min_d2, ctx->s.fr_grid);
 }
 
+// Forward regression for up to three signals advanced together (the omp_ticks schedule with the OLS sweep):
+// at tick n slot n%3 sweeps, slot (n-1)%3 runs its k_qr1 stage (mode 3), slot (n-2)%3 its k_qr2 stage.
+template <typename TA, int U, int NQ>
+static hipError_t tick_fr_launch_t(csmp_ctx* ctx, const TickFr<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds,
+                                   double min_d2) {
+    auto kern = k_tick_fr<TA, U, NQ>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, min_d2);
+    return hipGetLastError();
+}
+template <typename TA>
+static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_eps, double min_d2, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    activate_slot(ctx, 0);
+    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
+    const int G = sl[0]->G;
+    int U, grid; bool full; size_t flds;
+    fr_config(ctx, 1, U, full, flds, grid);
+    int nblk = grid;
+    if (const char* tn = getenv("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
+    const size_t lds = std::max(flds, qr_lds_bytes(sl[0]->kcap));
+    for (int64_t n = 0; n < 3 * k + 2; ++n) {
+        const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
+        const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
+        const bool az = present[zs] && n >= zs && tz < k;
+        const bool ay = present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
+        const bool ax = present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
+        if (!az && !ay && !ax) continue;
+        int jh1 = 0;
+        if (ay) {
+            jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
+            sl[ys]->jh_last = jh1;
+            if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
+        }
+        const Solver& z = *sl[zs];
+        TickFr<TA> sw;
+        sw.A = (const TA*)ctx->dA; sw.ld = ctx->ld; sw.Mv = ctx->Mv; sw.N = ctx->N;
+        sw.r = z.r; sw.Q = z.Q; sw.ldq = z.ldq; sw.rho2 = z.rho2; sw.dvec = z.dvec; sw.pval = z.pval; sw.pidx = z.pidx;
+        sw.sel = z.sel; sw.st = z.st; sw.max_eps = max_eps; sw.skipmask = skip; sw.nblk = nblk; sw.active = az ? 1 : 0;
+        auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
+        q1.mode = 3;
+        const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
+        const bool timed = az && ay && ax && prof_pick(ctx);
+        if (timed) CHECK(prof_mark(ctx));
+        hipError_t e;
+        if (U == 16)
+            e = tz == 0 ? tick_fr_launch_t<TA, 16, -1>(ctx, sw, q1, q2, G, lds, min_d2) : tick_fr_launch_t<TA, 16, 1>(ctx, sw, q1, q2, G, lds, min_d2);
+        else
+            e = tz == 0 ? tick_fr_launch_t<TA, 8, -1>(ctx, sw, q1, q2, G, lds, min_d2) : tick_fr_launch_t<TA, 8, 1>(ctx, sw, q1, q2, G, lds, min_d2);
+        HIPCHECK(e);
+        if (timed) CHECK(prof_mark(ctx));
+    }
+    return CSMP_OK;
+}
+
 // fr(A, b, max_ε, min_δ, k) = ols = oomp = ormp, x starting empty: src/forward.jl:44-54
 extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t* idx,
                        double* val, int64_t* nnz, int64_t* order) {
@@ -917,16 +975,19 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
 }
 
-extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
-                              double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+// omp (algo = CSMP_ALGO_OMP: p1 = eps) or fr (CSMP_ALGO_FR: p1 = max_eps, p2 = min_delta^2) for every column of B
+static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                      double eps, double p2, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    const bool isfr = algo == CSMP_ALGO_FR;
     if (!ctx) return CSMP_EINVAL;
-    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
-    if (!B || nsig < 0 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch: bad arguments");
+    if (!isfr && !(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (!B || nsig < 0 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "batch: bad arguments");
     if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
     CHECK(solver_ensure(ctx, kc, (int)k));
+    if (isfr) CHECK(fr_ensure(ctx));
     ctx->s.begun = false;
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     void* dB = const_cast<void*>(B);
@@ -956,7 +1017,8 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         int r2 = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
                                      : init_from_device_t<double>(ctx, (const double*)col);
-        for (int64_t t = 0; t < k && r2 == CSMP_OK; ++t) r2 = omp_step(ctx, eps, t > 0, optimistic);
+        for (int64_t t = 0; t < k && r2 == CSMP_OK; ++t)
+            r2 = isfr ? fr_step(ctx, t == 0, eps, p2, optimistic) : omp_step(ctx, eps, t > 0, optimistic);
         if (r2 == CSMP_OK) r2 = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k, sigflags + sgn);
         return r2;
     };
@@ -965,7 +1027,12 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     // of one signal and the two short append stages of the other two, so the latency-bound chain
     // is hidden underneath the HBM-bound sweep.  Bit-identical to the one-at-a-time path.
     const bool opt = !ctx->force_reorth;
-    const bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full;
+    bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full;
+    if (isfr) {  // the tick kernel exists for the exact-tiling FR sweeps only
+        int U, g; bool full; size_t l;
+        fr_config(ctx, 1, U, full, l, g);
+        pipe = pipe && full;
+    }
     auto init_sig = [&](int64_t sgn) -> int {
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         return b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
@@ -976,6 +1043,7 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         for (int q = 1; q < 3 && rc == CSMP_OK; ++q) {
             activate_slot(ctx, q);
             rc = solver_ensure(ctx, kc, (int)k);
+            if (rc == CSMP_OK && isfr) rc = fr_ensure(ctx);
         }
         activate_slot(ctx, 0);
         for (; sgn < nsig && rc == CSMP_OK; sgn += 3) {
@@ -986,7 +1054,10 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
                 activate_slot(ctx, q);
                 rc = init_sig(sgn + q);
             }
-            if (rc == CSMP_OK) rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, present, k, eps, opt) : omp_ticks<double>(ctx, present, k, eps, opt);
+            if (rc == CSMP_OK && isfr)
+                rc = ctx->dtype == CSMP_F32 ? fr_ticks<float>(ctx, present, k, eps, p2, opt) : fr_ticks<double>(ctx, present, k, eps, p2, opt);
+            else if (rc == CSMP_OK)
+                rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, present, k, eps, opt) : omp_ticks<double>(ctx, present, k, eps, opt);
             for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
                 if (!present[q]) continue;
                 activate_slot(ctx, q);
@@ -1021,6 +1092,21 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         (void)hipFree(dB);
     }
     return rc;
+}
+
+extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                              double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    return batch_impl(ctx, CSMP_ALGO_OMP, B, b_dtype, ldB, nsig, b_loc, k, eps, 0.0, idx, val, nnz, out_loc);
+}
+
+// fr(A, B[:,s], max_eps, min_delta, k) for every column of B: the forward-regression sweeps of three signals
+// at a time are pipelined against one another's append stages exactly like csmp_omp_batch's
+extern "C" int csmp_fr_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                             double max_eps, double min_delta, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (max_eps != max_eps || min_delta != min_delta) return fail(ctx, CSMP_EINVAL, "fr_batch: max_eps / min_delta is NaN");
+    return batch_impl(ctx, CSMP_ALGO_FR, B, b_dtype, ldB, nsig, b_loc, k, max_eps, min_delta * min_delta, idx, val, nnz, out_loc);
 }
 
 // warm start: support/values -> device lists, r = b - A x

@@ -39,20 +39,18 @@ namespace csmp {
 //   update_only: rho2 maintenance pass, no residual test and no scores
 // dynamic LDS: r image | NQ direction images (each nblocks*U*64*VEC doubles) | 32 doubles of scratch
 template <typename TA, int U, bool FULL, int NQ>
-__global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
+__device__ __forceinline__ void fr_sweep_body(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     const double* __restrict__ Q, int64_t ldq, const double* __restrict__ q1in, double s1,
     const double* __restrict__ q2in, double s2, const int* __restrict__ unmark, int update_only,
     double* __restrict__ rho2, double* __restrict__ dvec, double* __restrict__ pval, int* __restrict__ pidx,
-    const int* __restrict__ sel, DevState* st, double max_eps, int skipmask) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int* __restrict__ sel, DevState* st, double max_eps, int skipmask, const int bid, const int nblk, double* lds) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
     constexpr int NW = kSweepThreads / kWave;
     if (st->done & skipmask) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = blockIdx.x, nblk = gridDim.x;
     const int nchunk = (Mv + ROWS - 1) / ROWS;
     const int nblocks = (nchunk + U - 1) / U;
     const int Mlds = nblocks * U * ROWS;
@@ -221,6 +219,50 @@ inline size_t fr_sweep_lds_bytes(int Mv, int vec, int U, int nq) {
     const int nblocks = (nchunk + U - 1) / U;
     const int images = nq == 4 ? 4 : 1 + (nq > 0 ? nq : 0);
     return ((size_t)images * nblocks * U * rows + 8 + 16 + 8) * sizeof(double);
+}
+
+template <typename TA, int U, bool FULL, int NQ>
+__global__ __launch_bounds__(kSweepThreads) void k_fr_sweep(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    const double* __restrict__ Q, int64_t ldq, const double* __restrict__ q1in, double s1,
+    const double* __restrict__ q2in, double s2, const int* __restrict__ unmark, int update_only,
+    double* __restrict__ rho2, double* __restrict__ dvec, double* __restrict__ pval, int* __restrict__ pidx,
+    const int* __restrict__ sel, DevState* st, double max_eps, int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    fr_sweep_body<TA, U, FULL, NQ>(A, ld, Mv, N, r, Q, ldq, q1in, s1, q2in, s2, unmark, update_only, rho2, dvec, pval, pidx, sel, st,
+                                   max_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// Tick kernel of the pipelined forward-regression batch (the k_tick of csmp_kernels.hpp with the OLS sweep):
+// workgroups [0, G) run the k_qr2 stage of signal X, [G, 2G) the k_qr1 stage (mode 3) of signal Y,
+// [2G, 2G + nblk) the forward-regression sweep of signal Z -- NQ = -1 on a signal's first step, 1 after.
+template <typename TA>
+struct TickFr {
+    const TA* A; int64_t ld; int Mv; int64_t N;
+    const double* r; const double* Q; int64_t ldq;
+    double* rho2; double* dvec; double* pval; int* pidx; const int* sel; DevState* st;
+    double max_eps; int skipmask; int nblk; int active;
+};
+template <typename TA, int U, int NQ>
+__global__ __launch_bounds__(kSweepThreads) void k_tick_fr(const TickFr<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
+                                                           const int G, const double min_d2) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int bid = (int)blockIdx.x;
+    if (bid < G) {
+        if (q2.active)
+            qr2_body<8>(q2.Q, q2.ldq, q2.st, q2.avec, q2.r, q2.P1, q2.P1s, q2.G, q2.W1, q2.vvec, q2.P2, q2.P2s, q2.R, q2.z,
+                        q2.sel, q2.kcap, q2.jpad, q2.force_reorth, q2.jh, q2.optimistic, bid, lds);
+    } else if (bid < 2 * G) {
+        if (q1.active)
+            qr1_body<TA, 2>(q1.A, q1.ld, q1.M, q1.Q, q1.ldq, q1.st, q1.avec, q1.P1, q1.G, q1.kcap, q1.jpad, q1.mode, q1.pval,
+                            q1.pidx, q1.nblk_sweep, q1.cands, q1.ncands, q1.which, q1.sel, q1.skipmask, q1.r, q1.P1s, q1.jh,
+                            bid - G, lds, min_d2);
+    } else {
+        if (sw.active)
+            fr_sweep_body<TA, U, true, NQ>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.Q, sw.ldq, nullptr, -1.0, nullptr, 1.0, nullptr, 0,
+                                           sw.rho2, sw.dvec, sw.pval, sw.pidx, sw.sel, sw.st, sw.max_eps, sw.skipmask,
+                                           bid - 2 * G, sw.nblk, lds);
+    }
 }
 
 // Maintenance pass with FOUR directions and no residual image: rho2_j += sgn * sum_d <a_j, q0 + d*qstride>^2.

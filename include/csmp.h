@@ -149,6 +149,11 @@ int csmp_br(csmp_ctx *ctx, const void *b, int b_dtype, double max_eps, double ma
 int csmp_omp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                    double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 
+/* fr(A, B[:,s], max_eps, min_delta, k) for s = 0..nsig-1 (src/forward.jl:44-54 in the caller's loop): same
+ * conventions, pipelining and single synchronisation as csmp_omp_batch. */
+int csmp_fr_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                  double max_eps, double min_delta, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
  * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
  * SCREENS 16 candidates per signal; those are rescored in Float64 from the f32/f64 master

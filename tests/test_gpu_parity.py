@@ -1014,3 +1014,29 @@ def test_context_reuse_across_dictionaries_and_solver_families(cs, oracle):
                 assert np.array_equal(np.sort(idx[:nnz[s_], s_]), ref[0])
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("cfg", [(2048, 3000, 12, 7, np.float32), (4096, 2500, 10, 5, np.float32), (1024, 1500, 9, 4, np.float64),
+                                 (130, 700, 8, 6, np.float32), (2048, 2000, 6, 2, np.float32)])
+def test_fr_batch_matches_single_signal_calls(cs, oracle, D, cfg):
+    """csmp_fr_batch (three signals per tick kernel where the sweep tiles exactly, one at a time otherwise) against
+    the oracle and against csmp_fr, including per-signal stops at different steps."""
+    n, m, k, nsig, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + nsig, dtype=dtype)
+    d = D(A)
+    rng = np.random.default_rng(nsig)
+    cols = []
+    for s_ in range(nsig):
+        xs = cs.sparse_vector(m, max(1, k - (s_ % 3)), rng=rng)
+        cols.append(cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 1e-2, rng=rng))
+    B = np.asfortranarray(np.stack(cols, axis=1))
+    for max_eps, min_delta in ((0.0, 0.0), (0.02, 0.0), (0.0, 0.05)):
+        idx, val, nnz = d.ctx.fr_batch(B, k, max_eps, min_delta)
+        for s_ in range(nsig):
+            ref = oracle.fr(A, B[:, s_], k, max_eps, min_delta)
+            one = d.ctx.fr(B[:, s_], k, max_eps, min_delta)
+            assert nnz[s_] == len(ref[0]) and np.array_equal(idx[:nnz[s_], s_], ref[0]), (s_, max_eps, min_delta)
+            assert close(val[:nnz[s_], s_], ref[1]) and np.array_equal(val[:nnz[s_], s_], one[1])  # bit-identical to csmp_fr
+            assert np.all(idx[nnz[s_]:, s_] == -1)
+    xs = cs.fr_batch(d, B, k)
+    assert len(xs) == nsig and np.array_equal(xs[0].nzind, oracle.fr(A, B[:, 0], k)[0])
