@@ -95,6 +95,7 @@ struct csmp_ctx {
     int64_t M = 0, N = 0, ld = 0;
     int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
     int sweep_grid = 0, sweep_U = 1;
+    int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
     bool sweep_full = false, sweep_nt = false;
     bool force_reorth = false;  // debug/test knob: always run the second Gram-Schmidt pass
     size_t sweep_lds = 0;
@@ -407,12 +408,16 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     ctx->sweep_full = (ctx->Mv % rows) == 0;
     ctx->sweep_U = 1;
+    const char* su = getenv("CSMP_SWEEP_U");  // tuning knob: cap the load-block size
+    const int umax = su ? atoi(su) : 16;
     if (ctx->sweep_full)
         for (int u : {16, 8, 4, 2})
-            if (nchunk % u == 0) {
+            if (u <= umax && nchunk % u == 0) {
                 ctx->sweep_U = u;
                 break;
             }
+    ctx->tick_U = ctx->sweep_U;
+    if (ctx->sweep_full && ctx->sweep_U == 16 && !getenv("CSMP_TICK_U16")) ctx->tick_U = 8;  // (16 | nchunk implies 8 | nchunk)
     ctx->sweep_nt = true;
     int per_cu = ctx->sweep_U == 16 ? 3 : 4;
     per_cu = (int)std::min<size_t>((size_t)per_cu, (160 * 1024) / ctx->sweep_lds);
@@ -703,7 +708,7 @@ static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const Ti
 }
 template <typename TA>
 static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
-    switch (ctx->sweep_U) {
+    switch (ctx->tick_U) {
         case 16: return ctx->tick_pf ? tick_launch_t<TA, 16, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 16, false>(ctx, sw, q1, q2, G, lds);
         case 8: return ctx->tick_pf ? tick_launch_t<TA, 8, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 8, false>(ctx, sw, q1, q2, G, lds);
         case 4: return tick_launch_t<TA, 4, false>(ctx, sw, q1, q2, G, lds);
@@ -722,7 +727,13 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
     Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
     const int G = sl[0]->G;
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : (ctx->sweep_U >= 8 ? (int64_t)ctx->sweep_grid * 11 / 12 : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu), groups));
+    // Measured at 4096 x 65536 f32: 8-chunk load blocks on ONE workgroup per CU (the append stages of the other two
+    // signals share those CUs) 160.4 us per tick; 16-chunk blocks on 176 workgroups (11/12 of the stand-alone sweep's
+    // optimum of 192) 162.6 us.
+    const int64_t auto_nblk = ctx->tick_U == 8 ? (int64_t)ctx->prop.multiProcessorCount
+                              : ctx->tick_U == 16 ? (int64_t)ctx->sweep_grid * 11 / 12
+                                                  : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
     const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes(sl[0]->kcap));
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
