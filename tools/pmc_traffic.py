@@ -8,7 +8,8 @@ for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         acc = {}
         for row in csv.DictReader(open(f)):
-            if "k_sweep" not in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if "k_tick<" not in kn and "k_sweep" not in kn:
                 continue
             acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
         for name, vals in acc.items():
