@@ -449,7 +449,7 @@ def main():
                        "signals_per_gpu": K, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "csmp::k_tick<float,16,true> = software-pipelined sweep of one signal (one column per wave, 16-32 KiB of nt loads in flight) fused with the two short append stages of two other signals; csmp::k_sweep_pf<float,16,true> when a signal runs alone", "launches_timed": int(sweeps),
+                         "kernel": "csmp::k_tick<float,8,true> = software-pipelined sweep of one signal (one column per wave, 8-16 KiB of nt loads in flight per wave, one workgroup per CU) fused with the two short append stages of two other signals; csmp::k_sweep_pf<float,16,true> when a signal runs alone", "launches_timed": int(sweeps),
                          "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
             "atoms_selected": int(atoms),
         }
