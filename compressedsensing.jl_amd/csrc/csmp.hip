@@ -626,6 +626,14 @@ static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
 static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
                          int* d_flag = nullptr) {
     Solver& s = ctx->s;
+    if (s.kcap > 256 && !getenv("CSMP_FINISH_W")) {  // blocked form: one memory round trip per 64 columns
+        const size_t lds = (size_t)(s.kcap + 64) * sizeof(double) + (size_t)s.kcap * sizeof(int);
+        if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_finish_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_finish_b, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
+                           (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
     if (s.kcap <= 1024) {  // single-wave form
         const size_t lds = (size_t)s.kcap * sizeof(int);
         if (s.kcap <= 256)
