@@ -1438,7 +1438,8 @@ static int launch_block_append_t(csmp_ctx* ctx, int base, int want, int skipmask
     if (l1 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk1<TA, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
     if (l2 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk2<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
     if (l3 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk3<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
-    hipLaunchKernelGGL((k_blk1<TA, PB>), dim3(s.G), dim3(kQrThreads), l1, ctx->stream, (const TA*)ctx->dA, ctx->ld, (int)ctx->M,
+    const int csplit = std::max(1, std::min(std::min(4, ctx->prop.multiProcessorCount / std::max(1, s.G)), (jh + kWave - 1) / kWave));
+    hipLaunchKernelGGL((k_blk1<TA, PB>), dim3(s.G, csplit), dim3(kQrThreads), l1, ctx->stream, (const TA*)ctx->dA, ctx->ld, (int)ctx->M,
                        (const double*)s.Q, s.ldq, s.st, (const int*)s.cands, (const int*)s.ncands, base, want, (const int*)s.sel,
                        s.kcap, skipmask, s.Apan, s.PB1, s.G, s.pan_atoms);
     HIPCHECK(hipGetLastError());

@@ -113,16 +113,19 @@ __global__ __launch_bounds__(kQrThreads) void k_blk1(const TA* __restrict__ A, i
     // the next 64-column chunk of Q is requested while the current one is multiplied
     const double* qbase = Q + g * kSlabRows + wave * 16;
     double* out = PB1 + (int64_t)g * kcap * PB;  // this slab's partials, [c][p]
+    // (blockIdx.y splits the 64-column chunks of Q round-robin: the slabs alone are M/64 workgroups -- half
+    //  the CUs at M = 8192 -- and the chunks of one slab are independent)
+    const int cstep = kWave * (int)gridDim.y;
     f64x2 qv[8], qn[8];
     {
-        const int c = lane;
+        const int c = (int)blockIdx.y * kWave + lane;
         const f64x2* q = reinterpret_cast<const f64x2*>(qbase + (int64_t)(c < nsel ? c : 0) * ldq);
 #pragma unroll
         for (int i = 0; i < 8; ++i) qv[i] = (c < nsel) ? q[i] : (f64x2)0.0;
     }
-    for (int c0 = 0; c0 < nsel; c0 += kWave) {
+    for (int c0 = (int)blockIdx.y * kWave; c0 < nsel; c0 += cstep) {
         {
-            const int c = c0 + kWave + lane;
+            const int c = c0 + cstep + lane;
             const f64x2* q = reinterpret_cast<const f64x2*>(qbase + (int64_t)(c < nsel ? c : 0) * ldq);
 #pragma unroll
             for (int i = 0; i < 8; ++i) qn[i] = (c < nsel) ? q[i] : (f64x2)0.0;
@@ -183,56 +186,110 @@ __global__ __launch_bounds__(kQrThreads) void k_blk2(const double* __restrict__ 
         As[e] = a;
     }
     if (tid < kSlabRows) rs[tid] = r[g * kSlabRows + tid];
-    // V = A_p - Q_g W1.  Q is staged in 64x64 tiles: every thread fetches 8 x 16 B of the NEXT tile
-    // (thread <-> (column tid/32 + 8 i, row pair tid%32)) while the current tile is consumed from LDS with
-    // lane <-> row and wave <-> PB/4 panel columns; W1 tiles come through LDS as well.
-    constexpr int PW = PB / 4;
-    double acc[PW];
+    if constexpr (PB == 32) {
+        // V = A_p - Q_g W1 on the Float64 matrix cores (v_mfma_f64_16x16x4_f64): wave w owns rows 16 w .. 16 w + 15
+        // of the slab and all 32 panel columns (two 16 x 16 tiles).  Both operands come STRAIGHT from global
+        // memory in fragment layout -- A[l&15][k = l>>4] is 16 consecutive rows of Q column c + k, B[k][l&15] is
+        // 16 consecutive entries of W1 row c + k: 128-byte segments -- with 8 K-steps (32 columns of Q) of loads
+        // in flight ahead of their MFMAs.  The LDS-staged scalar loop this replaces spent 9 LDS reads per 8 FMAs.
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        d4 c0v = {0.0, 0.0, 0.0, 0.0}, c1v = {0.0, 0.0, 0.0, 0.0};
+        const int fr = lane & 15, fk = lane >> 4;
+        const double* qa = Q + g * kSlabRows + wave * 16 + fr;  // + (c + fk) * ldq
+        const double* wb = W1b + fr;                            // + (c + fk) * PB  (+ 16 for the second tile)
+        constexpr int KU = 8;
+        double av[KU], b0[KU], b1[KU], an[KU], n0[KU], n1[KU];
+        auto fetchk = [&](double* a_, double* x0, double* x1, int cbase) {
 #pragma unroll
-    for (int t = 0; t < PW; ++t) acc[t] = 0.0;
-    const int tc = tid >> 5, tr = (tid & 31) * 2;  // this thread's column offset (0..7) and row pair in a tile
-    const double* qsrc = Q + g * kSlabRows + tr;
-    f64x2 nx[8];
-    constexpr int WPT = kWave * PB / kQrThreads;  // W1-tile entries per thread
-    double nw[WPT];
-    auto fetch = [&](int c0) {
+            for (int u = 0; u < KU; ++u) {
+                const int c = cbase + 4 * u + fk;
+                const bool ok = c < j;
+                a_[u] = ok ? qa[(int64_t)c * ldq] : 0.0;
+                x0[u] = ok ? wb[(int64_t)c * PB] : 0.0;
+                x1[u] = ok ? wb[(int64_t)c * PB + 16] : 0.0;
+            }
+        };
+        fetchk(av, b0, b1, 0);
+        for (int cb = 0; cb < j; cb += 4 * KU) {
+            fetchk(an, n0, n1, cb + 4 * KU);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int c = c0 + tc + 8 * i;
-            nx[i] = (c < j) ? *reinterpret_cast<const f64x2*>(qsrc + (int64_t)c * ldq) : (f64x2)0.0;
+            for (int u = 0; u < KU; ++u) {
+                c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b0[u], c0v, 0, 0, 0);
+                c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], b1[u], c1v, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                av[u] = an[u];
+                b0[u] = n0[u];
+                b1[u] = n1[u];
+            }
         }
+        __syncthreads();  // Vs / As staged above are complete
+        // C/D layout: col = lane & 15 (panel column within the tile), row = (lane >> 4) + 4 reg
 #pragma unroll
-        for (int i = 0; i < WPT; ++i) {
-            const int e = tid + i * kQrThreads;
-            const int cc = c0 + e / PB;
-            nw[i] = (cc < j) ? W1b[(int64_t)cc * PB + (e % PB)] : 0.0;
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = wave * 16 + fk + 4 * reg;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int p = nt * 16 + fr;
+                const double v = Vs[p * kSlabRows + row] - (nt == 0 ? c0v[reg] : c1v[reg]);
+                Vs[p * kSlabRows + row] = v;
+                if (p < P) Vpan[(int64_t)p * ldq + g * kSlabRows + row] = v;
+            }
         }
-    };
-    fetch(0);
-    for (int c0 = 0; c0 < j; c0 += kWave) {
-        __syncthreads();  // previous tile fully consumed
-#pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<f64x2*>(Qt + (tc + 8 * i) * kSlabRows + tr) = nx[i];
-#pragma unroll
-        for (int i = 0; i < WPT; ++i) Wt[tid + i * kQrThreads] = nw[i];
-        if (c0 + kWave < j) fetch(c0 + kWave);
         __syncthreads();
-        const int nc = min(kWave, j - c0);
-        for (int cl = 0; cl < nc; ++cl) {
-            const double qv = Qt[cl * kSlabRows + lane];
+    } else {
+    // V = A_p - Q_g W1.  Q is staged in 64x64 tiles: every thread fetches 8 x 16 B of the NEXT tile
+        // (thread <-> (column tid/32 + 8 i, row pair tid%32)) while the current tile is consumed from LDS with
+        // lane <-> row and wave <-> PB/4 panel columns; W1 tiles come through LDS as well.
+        constexpr int PW = PB / 4;
+        double acc[PW];
 #pragma unroll
-            for (int t = 0; t < PW; ++t) acc[t] = fma(qv, Wt[cl * PB + wave * PW + t], acc[t]);
+        for (int t = 0; t < PW; ++t) acc[t] = 0.0;
+        const int tc = tid >> 5, tr = (tid & 31) * 2;  // this thread's column offset (0..7) and row pair in a tile
+        const double* qsrc = Q + g * kSlabRows + tr;
+        f64x2 nx[8];
+        constexpr int WPT = kWave * PB / kQrThreads;  // W1-tile entries per thread
+        double nw[WPT];
+        auto fetch = [&](int c0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = c0 + tc + 8 * i;
+                nx[i] = (c < j) ? *reinterpret_cast<const f64x2*>(qsrc + (int64_t)c * ldq) : (f64x2)0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) {
+                const int e = tid + i * kQrThreads;
+                const int cc = c0 + e / PB;
+                nw[i] = (cc < j) ? W1b[(int64_t)cc * PB + (e % PB)] : 0.0;
+            }
+        };
+        fetch(0);
+        for (int c0 = 0; c0 < j; c0 += kWave) {
+            __syncthreads();  // previous tile fully consumed
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<f64x2*>(Qt + (tc + 8 * i) * kSlabRows + tr) = nx[i];
+#pragma unroll
+            for (int i = 0; i < WPT; ++i) Wt[tid + i * kQrThreads] = nw[i];
+            if (c0 + kWave < j) fetch(c0 + kWave);
+            __syncthreads();
+            const int nc = min(kWave, j - c0);
+            for (int cl = 0; cl < nc; ++cl) {
+                const double qv = Qt[cl * kSlabRows + lane];
+#pragma unroll
+                for (int t = 0; t < PW; ++t) acc[t] = fma(qv, Wt[cl * PB + wave * PW + t], acc[t]);
+            }
         }
-    }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int t = 0; t < PW; ++t) {
-        const int p = wave * PW + t;
-        const double v = Vs[p * kSlabRows + lane] - acc[t];
-        Vs[p * kSlabRows + lane] = v;
-        if (p < P) Vpan[(int64_t)p * ldq + g * kSlabRows + lane] = v;
+        for (int t = 0; t < PW; ++t) {
+            const int p = wave * PW + t;
+            const double v = Vs[p * kSlabRows + lane] - acc[t];
+            Vs[p * kSlabRows + lane] = v;
+            if (p < P) Vpan[(int64_t)p * ldq + g * kSlabRows + lane] = v;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     // per-slab partials: V'V (upper triangle is enough, the full square is written), V'r, |a_p|^2
     double* out = PG + (int64_t)g * blk2_nent<PB>();
     for (int e = tid; e < blk2_nent<PB>(); e += kQrThreads) {
