@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk2(const double* __restrict__ 
 
 template <int PB>
 constexpr size_t blk3_lds_bytes() {
-    return (size_t)(blk2_nent<PB>() + PB * PB + PB + PB * kSlabRows) * sizeof(double) + 64;
+    return (size_t)(blk2_nent<PB>() + PB * PB + 2 * PB + PB * kSlabRows) * sizeof(double) + 64;
 }
 
 template <int PB>
@@ -326,7 +326,8 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
     double* Gs = lds;                          // PB*PB + 2 PB
     double* Rp = Gs + blk2_nent<PB>();         // [PB][PB] upper triangular, Rp[t*PB + p], t <= p
     double* zp = Rp + PB * PB;                 // [PB]
-    double* Vs = zp + PB;                      // [PB][64]
+    double* rinv = zp + PB;                    // [PB]  1 / Rp[p][p]
+    double* Vs = rinv + PB;                    // [PB][64]
     int& bad = *reinterpret_cast<int*>(Vs + PB * kSlabRows);
     const int P = st->pcount;
     if (P == 0) return;
@@ -351,12 +352,18 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
         const double na2 = (q < P) ? Gs[PB * PB + PB + q] : 0.0;
         double zmine = 0.0;
         int mybad = 0;
+        double ri[PB];  // 1 / Rp[p][p]: divisions and square roots leave the dependent chain (v_rsq_f64 + two Newton steps)
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const double d = __shfl(gq[p], p, kWave);  // current pivot (lane p holds G[p][p])
             if (q == p && p < P && (!(d > 0.0) || !(d >= 0.5 * na2))) mybad = 1;  // DGKS: too much cancellation
-            const double rd = (d > 0.0) ? sqrt(d) : 1.0;
-            gq[p] = (q == p) ? rd : gq[p] / rd;  // row p of Rp (lanes q >= p)
+            const bool okd = d > 0.0 && d < 1e300;
+            double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            ri[p] = okd ? rs_ : 1.0;
+            const double rd = okd ? d * rs_ : 1.0;
+            gq[p] = (q == p) ? rd : gq[p] * ri[p];  // row p of Rp (lanes q >= p)
 #pragma unroll
             for (int s_ = p + 1; s_ < PB; ++s_) {
                 const double rps = __shfl(gq[p], s_, kWave);  // Rp[p][s]
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {  // forward substitution, column oriented
-            const double zb = __shfl(sv / gq[p], p, kWave);
+            const double zb = __shfl(sv * ri[p], p, kWave);
             if (q == p) zmine = zb;
             if (q > p) sv = fma(-gq[p], zb, sv);
         }
@@ -375,6 +382,10 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
             for (int t = 0; t < PB; ++t)
                 if (t <= q) Rp[t * PB + q] = gq[t];
             zp[q] = zmine;
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < PB; ++t) rinv[t] = ri[t];
         }
     }
     __syncthreads();
@@ -393,7 +404,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
 #pragma unroll
             for (int t = 0; t < PB; ++t)
                 if (t < p) s = fma(-q[t], Rp[t * PB + p], s);
-            q[p] = (p < P) ? s / Rp[p * PB + p] : 0.0;
+            q[p] = (p < P) ? s * rinv[p] : 0.0;
             if (p < P) {
                 Q[(int64_t)(j + p) * ldq + row] = q[p];
                 dr = fma(q[p], zp[p], dr);
