@@ -147,7 +147,10 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
     D.ctx.profile_enable(True)
     D.ctx.batch_stats()
     torch.cuda.synchronize()
-    if use_dist:
+    if use_dist:  # warm the collective at the size and through the packing kernels of the timed one
+        pw = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, :, None].to(torch.float64)], dim=2)
+        dist.all_gather([torch.empty_like(pw) for _ in range(world)], pw)
+        del pw
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -406,8 +409,10 @@ def main():
 
     if W > 0:
         D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
-    if use_dist:  # warm the collective too
-        dist.all_gather([torch.empty(4, device=dev) for _ in range(world)], torch.zeros(4, device=dev))
+    if use_dist:  # warm the collective too, at the size and through the packing kernels of the timed one
+        pw = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, None].to(torch.float64)], dim=1)
+        dist.all_gather([torch.empty_like(pw) for _ in range(world)], pw)
+        del pw
     D.ctx.profile_enable(args.profile_every)  # HIP events around every n-th sweep launch of the timed region
     D.ctx.profile_read(reset=True)
     barrier()
