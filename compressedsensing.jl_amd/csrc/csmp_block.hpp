@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_red(const double* __restrict__ src, dou
 // LDS of k_blk1: Aps[PB][64] | part[4][64][PB] | ints
 template <int PB>
 constexpr size_t blk1_lds_bytes() {
-    return (size_t)(PB * kSlabRows + 4 * kWave * PB) * sizeof(double) + 4 * PB * sizeof(int) + 64;
+    return (size_t)(PB * kSlabRows + 4 * kWave * PB + kSlabRows * (PB + 1)) * sizeof(double) + 4 * PB * sizeof(int) + 64;
 }
 
 template <typename TA, int PB>
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(kQrThreads) void k_blk1(const TA* __restrict__ A, i
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Aps = lds;                              // [PB][64]
     double* part = Aps + PB * kSlabRows;            // [4][64][PB]
-    int* found = reinterpret_cast<int*>(part + 4 * kWave * PB);  // [PB]
+    double* ApT = part + 4 * kWave * PB;            // [64][PB + 1]: the slab transposed (B operand of the MFMA path)
+    int* found = reinterpret_cast<int*>(ApT + kSlabRows * (PB + 1));  // [PB]
     int* pan = found + PB;                          // [PB]
     int* cnt = pan + PB;                            // [1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = blockIdx.x;
@@ -106,9 +107,54 @@ __global__ __launch_bounds__(kQrThreads) void k_blk1(const TA* __restrict__ A, i
         const int p = e / kSlabRows, row = g * kSlabRows + (e % kSlabRows);
         const double a = (p < P && row < M) ? (double)A[(int64_t)pan[p] * ld + row] : 0.0;
         Aps[e] = a;
+        ApT[(e % kSlabRows) * (PB + 1) + p] = a;
         if (p < P) Apan[(int64_t)p * ldq + row] = a;
     }
     __syncthreads();
+    if constexpr (PB == 32) {
+        // W1_g = Q_g' A_p,g on the Float64 matrix cores.  Wave w owns the 16 columns c0 + 16 w .. of a 64-column
+        // chunk over ALL 64 rows of the slab: lane l holds 16 consecutive rows (16 (l >> 4) ..) of column l & 15 --
+        // one 128-byte line -- and K-step kk multiplies row 16 (l >> 4) + kk of every quarter, so the 16 K-steps
+        // consume exactly those registers.  B[k][p] comes from the transposed slab in LDS (row stride 33:
+        // conflict-free).  No cross-wave reduction, no barrier inside the chunk loop.
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        const int fr = lane & 15, fk = lane >> 4;
+        const int cstep = kWave * (int)gridDim.y;
+        double* out = PB1 + (int64_t)g * kcap * PB;
+        const double* qb = Q + g * kSlabRows + fk * 16;
+        const double* bt = ApT + (fk * 16) * (PB + 1) + fr;
+        f64x2 qv[8], qn[8];
+        auto loadq = [&](f64x2* dst, int cbase) {
+            const int c = cbase + wave * 16 + fr;
+            const f64x2* q = reinterpret_cast<const f64x2*>(qb + (int64_t)(c < nsel ? c : 0) * ldq);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dst[i] = (c < nsel) ? q[i] : (f64x2)0.0;
+        };
+        loadq(qv, (int)blockIdx.y * kWave);
+        for (int c0 = (int)blockIdx.y * kWave; c0 < nsel; c0 += cstep) {
+            loadq(qn, c0 + cstep);
+            d4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                const double av = (kk & 1) ? qv[kk >> 1].y : qv[kk >> 1].x;
+                const double b0 = bt[kk * (PB + 1)], b1 = bt[kk * (PB + 1) + 16];
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
+            }
+            // C/D layout: col = lane & 15 (panel column), row = (lane >> 4) + 4 reg (Q column within the tile)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int cc = c0 + wave * 16 + fk + 4 * reg;
+                if (cc < nsel) {
+                    if (fr < P) out[(int64_t)cc * PB + fr] = a0[reg];
+                    if (fr + 16 < P) out[(int64_t)cc * PB + fr + 16] = a1[reg];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) qv[i] = qn[i];
+        }
+        return;
+    }
     // W1_g = Q_g' A_p,g : lane <-> column of Q, wave <-> 16-row quarter, PB accumulators per thread;
     // the next 64-column chunk of Q is requested while the current one is multiplied
     const double* qbase = Q + g * kSlabRows + wave * 16;
