@@ -280,6 +280,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk2(const double* __restrict__ 
                 const int p = nt * 16 + fr;
                 const double v = Vs[p * kSlabRows + row] - (nt == 0 ? c0v[reg] : c1v[reg]);
                 Vs[p * kSlabRows + row] = v;
+                Qt[row * (PB + 1) + p] = v;  // transposed copy [row][33] for the Gram product below (Qt is free here)
                 if (p < P) Vpan[(int64_t)p * ldq + g * kSlabRows + row] = v;
             }
         }
@@ -338,6 +339,34 @@ __global__ __launch_bounds__(kQrThreads) void k_blk2(const double* __restrict__ 
     }
     // per-slab partials: V'V (upper triangle is enough, the full square is written), V'r, |a_p|^2
     double* out = PG + (int64_t)g * blk2_nent<PB>();
+    if constexpr (PB == 32) {
+        // V'V on the matrix cores as well: wave w owns the 16 x 16 tile (w >> 1, w & 1); both operands are read from
+        // the transposed slab (row stride 33: conflict-free), K = the 64 rows in 16 steps
+        typedef double d4 __attribute__((ext_vector_type(4)));
+        const int fr = lane & 15, fk = lane >> 4, pt = wave >> 1, qt = wave & 1;
+        const double* vt = Qt + (fk * 16) * (PB + 1);
+        d4 gacc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(vt[kk * (PB + 1) + pt * 16 + fr], vt[kk * (PB + 1) + qt * 16 + fr], gacc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int pp = pt * 16 + fk + 4 * reg, qq = qt * 16 + fr;
+            out[pp * PB + qq] = (pp <= qq && qq < P) ? gacc[reg] : 0.0;
+        }
+        if (tid < 2 * PB) {
+            const int pp = tid & (PB - 1);
+            double sacc = 0.0;
+            if (pp < P) {
+                if (tid < PB)
+                    for (int row = 0; row < kSlabRows; ++row) sacc = fma(Qt[row * (PB + 1) + pp], rs[row], sacc);
+                else
+                    for (int row = 0; row < kSlabRows; ++row) sacc = fma(As[pp * kSlabRows + row], As[pp * kSlabRows + row], sacc);
+            }
+            out[PB * PB + tid] = sacc;
+        }
+        return;
+    }
     for (int e = tid; e < blk2_nent<PB>(); e += kQrThreads) {
         double s = 0.0;
         if (e < PB * PB) {
