@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
                                                      const double* __restrict__ Vpan, const double* __restrict__ Gsum,
                                                      const double* __restrict__ W1b, double* __restrict__ r,
                                                      double* __restrict__ R, double* __restrict__ z, int* __restrict__ sel,
-                                                     const int* __restrict__ pan_atoms, int kcap) {
+                                                     const int* __restrict__ pan_atoms, int kcap, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Gs = lds;                          // PB*PB + 2 PB
     double* Rp = Gs + blk2_nent<PB>();         // [PB][PB] upper triangular, Rp[t*PB + p], t <= p
@@ -414,6 +414,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
     }
     if (tid == 0) bad = 0;
     __syncthreads();
+    if (dbg == 1) return;
     // Cholesky V'V = Rp' Rp and zp = Rp^-T (V'r) in the registers of ONE wave: lane q owns column q
     // of the (padded to PB x PB, identity beyond P) Gram matrix; every dependent step is a register
     // broadcast (shuffle) + fma, no LDS round trips and no barriers.  Identical in every workgroup.
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
         double ri[PB];  // 1 / Rp[p][p]: divisions and square roots leave the dependent chain (v_rsq_f64 + two Newton steps)
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
-            const double d = __shfl(gq[p], p, kWave);  // current pivot (lane p holds G[p][p])
+            const double d = readlane_f64(gq[p], p);  // current pivot (lane p holds G[p][p]); p, s_ are unrolled constants: v_readlane, no LDS crossbar
             if (q == p && p < P && (!(d > 0.0) || !(d >= 0.5 * na2))) mybad = 1;  // DGKS: too much cancellation
             const bool okd = d > 0.0 && d < 1e300;
             double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
@@ -441,13 +442,13 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
             gq[p] = (q == p) ? rd : gq[p] * ri[p];  // row p of Rp (lanes q >= p)
 #pragma unroll
             for (int s_ = p + 1; s_ < PB; ++s_) {
-                const double rps = __shfl(gq[p], s_, kWave);  // Rp[p][s]
+                const double rps = readlane_f64(gq[p], s_);  // Rp[p][s]
                 if (q >= s_) gq[s_] = fma(-rps, gq[p], gq[s_]);
             }
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {  // forward substitution, column oriented
-            const double zb = __shfl(sv * ri[p], p, kWave);
+            const double zb = readlane_f64(sv * ri[p], p);
             if (q == p) zmine = zb;
             if (q > p) sv = fma(-gq[p], zb, sv);
         }
@@ -464,6 +465,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
         }
     }
     __syncthreads();
+    if (dbg == 2) return;
     if (bad) {
         if (g == 0 && tid == 0) st->done |= STOP_REORTH;  // nothing committed; the host falls back
         return;
