@@ -1455,8 +1455,7 @@ static int launch_block_append_t(csmp_ctx* ctx, int base, int want, int skipmask
     hipLaunchKernelGGL(k_red, dim3((nent + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.PG, s.Gsum, nent, s.G, (int64_t)nent, (const DevState*)s.st, (double*)nullptr, 0, PB);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL((k_blk3<PB>), dim3(s.G), dim3(kQrThreads), l3, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.Vpan,
-                       (const double*)s.Gsum, (const double*)s.W1b, s.r, s.R, s.z, s.sel, (const int*)s.pan_atoms, s.kcap,
-                       getenv("CSMP_BLK3_DBG") ? atoi(getenv("CSMP_BLK3_DBG")) : 0);
+                       (const double*)s.Gsum, (const double*)s.W1b, s.r, s.R, s.z, s.sel, (const int*)s.pan_atoms, s.kcap);
     HIPCHECK(hipGetLastError());
     s.jh = std::min(s.kcap, s.jh + std::min(want, PB));
     return CSMP_OK;

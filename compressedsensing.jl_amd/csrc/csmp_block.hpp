@@ -396,7 +396,7 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
                                                      const double* __restrict__ Vpan, const double* __restrict__ Gsum,
                                                      const double* __restrict__ W1b, double* __restrict__ r,
                                                      double* __restrict__ R, double* __restrict__ z, int* __restrict__ sel,
-                                                     const int* __restrict__ pan_atoms, int kcap, int dbg) {
+                                                     const int* __restrict__ pan_atoms, int kcap) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double* Gs = lds;                          // PB*PB + 2 PB
     double* Rp = Gs + blk2_nent<PB>();         // [PB][PB] upper triangular, Rp[t*PB + p], t <= p
@@ -414,7 +414,6 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
     }
     if (tid == 0) bad = 0;
     __syncthreads();
-    if (dbg == 1) return;
     // Cholesky V'V = Rp' Rp and zp = Rp^-T (V'r) in the registers of ONE wave: lane q owns column q
     // of the (padded to PB x PB, identity beyond P) Gram matrix; every dependent step is a register
     // broadcast (shuffle) + fma, no LDS round trips and no barriers.  Identical in every workgroup.
@@ -465,7 +464,6 @@ __global__ __launch_bounds__(kQrThreads) void k_blk3(double* __restrict__ Q, int
         }
     }
     __syncthreads();
-    if (dbg == 2) return;
     if (bad) {
         if (g == 0 && tid == 0) st->done |= STOP_REORTH;  // nothing committed; the host falls back
         return;
