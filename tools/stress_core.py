@@ -1,0 +1,71 @@
+"""Randomised GPU-vs-oracle comparison of the core path (omp, gomp, sp, mp-free, the two batch drivers, lstsq).
+    python tools/stress_core.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from csmp_pkg import load  # noqa: E402
+from oracle import oracle_c as oc  # noqa: E402
+
+cs = load()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+t0 = time.time()
+runs = bad = 0
+tally = {}
+
+
+def cmp(name, got, ref, cfg):
+    global runs, bad
+    runs += 1
+    tally[name] = tally.get(name, 0) + 1
+    ok = np.array_equal(got[0], ref[0])
+    if ok and len(ref[1]) and np.all(np.isfinite(ref[1])):
+        ok = np.allclose(got[1], ref[1], rtol=1e-6, atol=1e-6 * float(np.max(np.abs(ref[1]))))
+    if not ok:
+        bad += 1
+        print("MISMATCH", name, cfg, got[0][:10], ref[0][:10], flush=True)
+
+
+while time.time() - t0 < budget:
+    M = int(rng.choice([37, 64, 130, 256, 512, 1024, 2048, 4096, 1500]))
+    N = int(rng.choice([300, 1000, 3000, 8000]))
+    dtype = rng.choice([np.float32, np.float64])
+    k = int(rng.integers(2, max(3, min(M // 6, 48))))
+    A = rng.standard_normal((M, N))
+    A /= np.linalg.norm(A, axis=0)
+    A = np.asfortranarray(A.astype(dtype))
+    nsig = int(rng.choice([1, 2, 3, 5, 7]))
+    B = []
+    for _ in range(nsig):
+        supp = rng.choice(N, k, replace=False)
+        b = A[:, supp].astype(np.float64) @ rng.choice([-1.0, 1.0], k)
+        e = rng.standard_normal(M)
+        B.append(b + 5e-3 * e / np.linalg.norm(e))
+    B = np.asfortranarray(np.stack(B, axis=1))
+    cfg = (M, N, k, str(np.dtype(dtype)), nsig)
+    eps = float(np.finfo(dtype).eps)
+    D = cs.Dictionary(A)
+    try:
+        refs = [oc.omp(A, B[:, s], k, eps) for s in range(nsig)]
+        cmp("omp", D.ctx.omp(B[:, 0], k, eps), refs[0], cfg)
+        idx, val, nnz = D.ctx.omp_batch(B, k, eps)
+        for s in range(nsig):
+            cmp("omp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
+        idx, val, nnz = D.ctx.omp_batch_mfma(B, k, eps)
+        for s in range(nsig):
+            cmp("omp_mfma", (np.sort(idx[:nnz[s], s]), val[:nnz[s], s][np.argsort(idx[:nnz[s], s])]), refs[s], cfg)
+        l = int(rng.choice([2, 3, 4]))
+        cmp("gomp", D.ctx.gomp(B[:, 0], l, k, eps), oc.gomp(A, B[:, 0], l, k, eps), cfg + (l,))
+        if 2 * k <= M:
+            cmp("sp", D.ctx.sp(B[:, 0], k, 1e-12), oc.sp(A, B[:, 0], k, 1e-12), cfg)
+        cols = np.sort(rng.choice(N, min(3 * k, M // 2), replace=False))
+        got = D.ctx.lstsq(cols, B[:, 0])
+        ref = oc.lstsq_cols(A, cols, B[:, 0])
+        cmp("lstsq", (cols, got), (cols, ref), cfg)
+    finally:
+        D.close()
+print(f"runs {runs}  mismatches {bad}  {tally}  {time.time() - t0:.0f} s")
