@@ -10,6 +10,10 @@
 //   k_blk3   Cholesky V'V = Rp' Rp (every workgroup, redundantly), DGKS test on its diagonal,
 //            Q_new = V Rp^-1, z_new = Rp^-T V'r, r -= Q_new z_new, R gets [W1; Rp], support += panel
 //
+// For panels of 32 the three products -- Q'A_p, A_p - Q W1, V'V -- run on the Float64 matrix cores
+// (v_mfma_f64_16x16x4_f64, same peak as the vector FMA but without its LDS-operand bottleneck), and the
+// 32 x 32 Cholesky lives in the registers of one wave with v_readlane broadcasts.
+//
 // i.e. block classical Gram-Schmidt against Q followed by CholeskyQR inside the panel.  The DGKS test
 // (diag(Rp)^2 >= |a_p|^2 / 2) bounds the cancellation of both steps; a panel that fails it commits
 // nothing and raises STOP_REORTH, and the host repeats the solve with the column-wise safe chain.
