@@ -1346,8 +1346,13 @@ static int launch_delete_atom_t(csmp_ctx* ctx, int atom) {
     return launch_delete_t(ctx);
 }
 // fetch_sorted in explicit-inverse mode: coefficients from T z, emitted in index order
-static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val) {
+// (resnorm != NULL: the residual norm travels in the same synchronisation)
+static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
     Solver& s = ctx->s;
+    if (resnorm) {
+        hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal + 1);
+        HIPCHECK(hipGetLastError());
+    }
     CHECK(launch_tinv_solve(ctx));
     hipLaunchKernelGGL(k_emit_sorted, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd_coef, (const int*)s.sel,
                        (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap);
@@ -1360,9 +1365,12 @@ static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<
     HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipMemcpyAsync(&hn, s.out_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
+    double n2 = 0.0;
+    if (resnorm) HIPCHECK(hipMemcpyAsync(&n2, s.scal + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     idx.assign(hi.begin(), hi.begin() + hn);
     val.assign(hv.begin(), hv.begin() + hn);
+    if (resnorm) *resnorm = std::sqrt(n2);
     return CSMP_OK;
 }
 
@@ -1780,6 +1788,7 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     std::vector<double> cs((size_t)k), call;
     while (it < maxiter) {  // :193
         const double oldnorm = resnorm;
+        bool have_norm = false;
         // update!(P, x): Ar = x + A'r (eta = 1), arg-max over atoms outside the support
         CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
         CHECK(launch_select(ctx, 0, 0));
@@ -1845,13 +1854,15 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
                     }
                     CHECK(ls_on_columns(ctx, cols));  // :178
                 }
-                if (tmode)
-                    CHECK(fetch_sorted_t(ctx, xi, xv));
-                else
+                if (tmode) {
+                    CHECK(fetch_sorted_t(ctx, xi, xv, &resnorm));  // :178 and :196 in one synchronisation
+                    have_norm = true;
+                } else {
                     CHECK(fetch_sorted(ctx, xi, xv));
+                }
             }
         }
-        CHECK(residual_norm(ctx, &resnorm));                 // :196
+        if (!have_norm) CHECK(residual_norm(ctx, &resnorm));  // :196
         if (resnorm <= delta || oldnorm <= resnorm) break;   // :197
     }
     for (size_t t = 0; t < xi.size(); ++t) {
