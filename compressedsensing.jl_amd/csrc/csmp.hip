@@ -2046,28 +2046,43 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         p0.nq = -1;
         p0.update_only = 1;
         CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
-        int U4, g4; bool f4; size_t lds4;
-        fr_config(ctx, 4, U4, f4, lds4, g4);
-        const bool four = lds4 <= 160 * 1024 - 512;  // four direction images fit the LDS (M <= ~5000)
-        for (int64_t t = 0; t < k;) {
-            FrPass ps;
-            ps.update_only = 1;
-            ps.q1 = s.Q + t * s.ldq;
-            ps.s1 = -1.0;
-            if (four && t + 4 <= k) {
-                ps.nq = 4;
-                ps.qstride = s.ldq;
-                t += 4;
-            } else if (t + 2 <= k) {
-                ps.nq = 2;
-                ps.q2 = s.Q + (t + 1) * s.ldq;
-                ps.s2 = -1.0;
-                t += 2;
-            } else {
-                ps.nq = 1;
-                t += 1;
+        if (!getenv("CSMP_FR_REBUILD_SWEEPS")) {
+            // Q'A on the Float64 matrix cores, 256 directions per pass (csmp_forward.hpp, k_fr_rebuild)
+            const int grid = (int)((ctx->N + 63) / 64);
+            for (int64_t t = 0; t < k; t += 256) {
+                const int nd = (int)std::min<int64_t>(256, k - t);
+                if (ctx->dtype == CSMP_F32)
+                    hipLaunchKernelGGL(k_fr_rebuild<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld,
+                                       (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);
+                else
+                    hipLaunchKernelGGL(k_fr_rebuild<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld,
+                                       (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);
+                HIPCHECK(hipGetLastError());
             }
-            CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
+        } else {
+        int U4, g4; bool f4; size_t lds4;
+            fr_config(ctx, 4, U4, f4, lds4, g4);
+            const bool four = lds4 <= 160 * 1024 - 512;  // four direction images fit the LDS (M <= ~5000)
+            for (int64_t t = 0; t < k;) {
+                FrPass ps;
+                ps.update_only = 1;
+                ps.q1 = s.Q + t * s.ldq;
+                ps.s1 = -1.0;
+                if (four && t + 4 <= k) {
+                    ps.nq = 4;
+                    ps.qstride = s.ldq;
+                    t += 4;
+                } else if (t + 2 <= k) {
+                    ps.nq = 2;
+                    ps.q2 = s.Q + (t + 1) * s.ldq;
+                    ps.s2 = -1.0;
+                    t += 2;
+                } else {
+                    ps.nq = 1;
+                    t += 1;
+                }
+                CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
+            }
         }
         hipLaunchKernelGGL(k_mark_inf, dim3(1), dim3(256), 0, ctx->stream, s.rho2, (const int*)s.sel, (const DevState*)s.st);
         HIPCHECK(hipGetLastError());
