@@ -2047,10 +2047,10 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         p0.update_only = 1;
         CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
         if (!getenv("CSMP_FR_REBUILD_SWEEPS")) {
-            // Q'A on the Float64 matrix cores, 256 directions per pass (csmp_forward.hpp, k_fr_rebuild)
-            const int grid = (int)((ctx->N + 63) / 64);
-            for (int64_t t = 0; t < k; t += 256) {
-                const int nd = (int)std::min<int64_t>(256, k - t);
+            // Q'A on the Float64 matrix cores, 128 directions per pass (csmp_forward.hpp, k_fr_rebuild)
+            const int grid = (int)((ctx->N + 127) / 128);  // 4 waves x 32 atoms
+            for (int64_t t = 0; t < k; t += 128) {
+                const int nd = (int)std::min<int64_t>(128, k - t);
                 if (ctx->dtype == CSMP_F32)
                     hipLaunchKernelGGL(k_fr_rebuild<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld,
                                        (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);

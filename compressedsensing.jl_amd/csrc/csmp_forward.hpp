@@ -366,9 +366,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_update4(
 }
 
 // Bulk form of the same maintenance on the Float64 matrix cores: rho2_j -= sum_{d < nd} <a_j, q_{d0+d}>^2 for up to
-// 256 directions in ONE pass over the dictionary (k_fr_update4 needs nd/4 passes).  G = Q'A is a genuine GEMM here
-// (directions x atoms, K = rows); it is never written: wave w of a workgroup owns 16 atoms and keeps one 16 x 16
-// accumulator tile per 16 directions (up to 16 tiles = 128 VGPRs).  Operands are loaded straight from global
+// 128 directions in ONE pass over the dictionary (k_fr_update4 needs nd/4 passes).  G = Q'A is a genuine GEMM here
+// (directions x atoms, K = rows); it is never written: wave w of a workgroup owns 32 atoms and keeps one 16 x 16
+// accumulator tile per 16 atoms x 16 directions (2 x 8 tiles = 128 VGPRs).  Operands are loaded straight from global
 // memory with the K index permuted so that every lane walks CONTIGUOUS rows: within a 64-row block lane l holds
 // rows 16 (l >> 4) .. + 16 of atom / direction l & 15 (64 B of an f32 column, 128 B of a Q column), and K-step kk
 // multiplies row 16 (l >> 4) + kk of every quarter.  Q (nd x M doubles) is re-read by every atom tile from L2.
@@ -377,23 +377,32 @@ __global__ __launch_bounds__(256) void k_fr_rebuild(const TA* __restrict__ A, in
                                                     const double* __restrict__ Q, int64_t ldq, int d0, int nd,
                                                     double* __restrict__ rho2) {
     typedef double d4 __attribute__((ext_vector_type(4)));
-    constexpr int MAXT = 16;
+    constexpr int NA = 2;    // 16-atom tiles per wave: every Q fragment feeds NA MFMAs (Q is re-read from L2 by every wave)
+    constexpr int MAXT = 8;  // 16-direction tiles per pass: NA * MAXT accumulator tiles = 128 VGPRs
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int64_t a0 = ((int64_t)blockIdx.x * 4 + wave) * 16;
+    const int64_t a0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NA);
     if (a0 >= N) return;
-    const int64_t atom = a0 + fr < N ? a0 + fr : N - 1;
-    const TA* acol = A + atom * ld + fq * 16;
-    const int nt = (nd + 15) / 16;
-    d4 acc[MAXT];
+    const TA* acol[NA];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int h = 0; h < NA; ++h) {
+        const int64_t atom = a0 + h * 16 + fr < N ? a0 + h * 16 + fr : N - 1;
+        acol[h] = A + atom * ld + fq * 16;
+    }
+    const int nt = (nd + 15) / 16;
+    d4 acc[NA][MAXT];
+#pragma unroll
+    for (int h = 0; h < NA; ++h)
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) acc[h][t] = d4{0.0, 0.0, 0.0, 0.0};
     const int nrb = (M + 63) / 64;
     for (int rb = 0; rb < nrb; ++rb) {
-        double bv[16];
+        double bv[NA][16];
         const int r0 = rb * 64 + fq * 16;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) bv[e] = (r0 + e < M) ? (double)acol[(int64_t)rb * 64 + e] : 0.0;
+        for (int h = 0; h < NA; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[h][e] = (r0 + e < M) ? (double)acol[h][(int64_t)rb * 64 + e] : 0.0;
 #pragma unroll
         for (int t = 0; t < MAXT; ++t) {
             if (t < nt) {  // uniform
@@ -403,19 +412,24 @@ __global__ __launch_bounds__(256) void k_fr_rebuild(const TA* __restrict__ A, in
 #pragma unroll
                 for (int e = 0; e < 16; ++e) qv[e] = (dir < d0 + nd) ? qc[e] : 0.0;  // (rows beyond M are zero in Q)
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[kk], bv[kk], acc[t], 0, 0, 0);
+                for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                    for (int h = 0; h < NA; ++h) acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[kk], bv[h][kk], acc[h][t], 0, 0, 0);
             }
         }
     }
     // C/D layout: col = lane & 15 (atom), row = (lane >> 4) + 4 reg (direction within the tile)
-    double ssum = 0.0;
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t)
+    for (int h = 0; h < NA; ++h) {
+        double ssum = 0.0;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) ssum = fma(acc[t][reg], acc[t][reg], ssum);
-    ssum += shx(ssum, 16);
-    ssum += shx(ssum, 32);
-    if (fq == 0 && a0 + fr < N) rho2[a0 + fr] -= ssum;
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ssum = fma(acc[h][t][reg], acc[h][t][reg], ssum);
+        ssum += shx(ssum, 16);
+        ssum += shx(ssum, 32);
+        if (fq == 0 && a0 + h * 16 + fr < N) rho2[a0 + h * 16 + fr] -= ssum;
+    }
 }
 
 // rho2 = +Inf for every atom of the support (bulk form of the per-step marking in k_fr_sweep)
