@@ -2092,12 +2092,18 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         P.rho_ready = true;
         if (P.hs.done) CHECK(P.clear_flags());
     } else {
-        // k times update!(P::FR, x) (:12-15; src/forward.jl:88-95)
+        // k times update!(P::FR, x) (:12-15; src/forward.jl:88-95): enqueued back to back, no host round trips
+        const int skip = STOP_FULL | STOP_STAG;
         for (int64_t t = 0; t < k; ++t) {
-            bool ok;
-            CHECK(P.forward(0.0, 0.0, false, &ok));
-            if (!ok) break;
+            CHECK(launch_fr_sweep(ctx, t == 0, -HUGE_VAL, skip));
+            CHECK(launch_append(ctx, 3, 0, skip, false, -1.0, s.fr_grid));
         }
+        CHECK(launch_tinv_build(ctx));
+        CHECK(P.read_state());
+        P.n = P.hs.nsel;
+        P.rho_ready = true;
+        if (P.n > 0) P.pend.push_back({nullptr, -1.0});  // the last appended column has not reached rho2 yet
+        if (P.hs.done) CHECK(P.clear_flags());
     }
     double resnorm = 0.0;
     CHECK(residual_norm(ctx, &resnorm));  // :18
