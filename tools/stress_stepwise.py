@@ -48,7 +48,9 @@ while time.time() - t0 < budget:
     A = np.asfortranarray(A.astype(dtype))
     kk = min(N, k + int(rng.integers(0, 3)))
     supp = rng.choice(N, kk, replace=False)
-    b = A[:, supp].astype(np.float64) @ rng.choice([-1.0, 1.0], kk) * rng.uniform(0.5, 2.0)
+    # distinct magnitudes: with equal +-1 coefficients and k < #planted, two planted atoms tie EXACTLY in exact
+    # arithmetic (|<a_i, b>| = |1 + s g| for both) and rounding picks the winner -- the undefined-parity regime
+    b = A[:, supp].astype(np.float64) @ (rng.choice([-1.0, 1.0], kk) * rng.uniform(0.5, 2.0, kk))
     if noise:
         e = rng.standard_normal(M)
         b = b + noise * e / np.linalg.norm(e)
