@@ -14,7 +14,11 @@ region.  Signals are independent: weak scaling, K signals
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).  At N = 1 the line also
+carries, under "secondary", the results of the other single-GPU configurations of BASELINE.json measured
+by the same process right after the headline: configs[2] (batched, bf16 MFMA screen) and configs[4] (GOMP
+S = 4 and Subspace Pursuit on 8192 x 131072, k = 512) -- each with its own roofline block.  The headline
+stays configs[1]; --no-secondary skips them.
 """
 import argparse
 import json
@@ -33,6 +37,45 @@ NOISE = 5e-3  # ||e||_2, as test/matchingpursuit.jl:12-13 (perturb(b, delta/2), 
 SEED_A = 0xC0FFEE
 
 
+def free_port():
+    """A free TCP port on 127.0.0.1 for the launcher's rendezvous (no fixed port: two benches may share a box)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def exchange_results(idx, val, nnz, group=None):
+    """The ONE collective of the signal-sharded path: every rank's (idx, val, nnz) block,
+    packed on the device the tensors live on into rows of 2k+1 Float64 (csmp_pack_results' layout) and moved by a
+    single all_gather (RCCL over xGMI under the "nccl" backend; the gloo CPU test drives this very function).
+    idx, val: (n, k); nnz: (n,), the same n on every rank.  Returns the (world * n, 2k+1) tensor in rank order."""
+    import torch.distributed as dist
+    from csmp_pkg import load
+    cs = load()
+    packed = cs.pack_t(idx, val, nnz)
+    return cs.gather_packed(packed, packed.shape[0] * dist.get_world_size(group), group)
+
+
+def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
+    """AverageNs of the newest committed rocprofv3 --kernel-trace --stats row whose kernel name contains
+    `kernel_substr` (profiles/, named per round): lets the line state the profiler's figure beside the HIP-event one."""
+    import csv
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
+        try:
+            for row in csv.DictReader(open(f)):
+                if kernel_substr in row.get("Name", ""):
+                    best = {"file": os.path.relpath(f, ROOT), "kernel": row["Name"].split("(")[0], "calls": int(row["Calls"]),
+                            "avg_launch_us": float(row["AverageNs"]) / 1e3}
+        except Exception:  # noqa: BLE001
+            pass
+    return best
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -43,6 +86,7 @@ def parse():
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     return p.parse_args()
@@ -131,10 +175,13 @@ def make_signals_fast(torch, dev, At, first_id, count, k):
     return B
 
 
-def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
-    """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128."""
+MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparse figure is not used)
+
+
+def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
+    """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128.
+    A step = one batch of 1024 complete solves.  Returns the result dict on rank 0, None elsewhere."""
     nsig, k = 1024, 128
-    K, W = args.steps, args.warmup
     eps = D.eps
     B = make_signals_fast(torch, dev, At, rank * (K + W), (K + W) * nsig, k).reshape(K + W, nsig, M)
     idx = torch.full((K + W, nsig, k), -1, dtype=torch.int64, device=dev)
@@ -148,95 +195,93 @@ def run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist):
     D.ctx.batch_stats()
     torch.cuda.synchronize()
     if use_dist:  # warm the collective at the size and through the packing kernels of the timed one
-        pw = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, :, None].to(torch.float64)], dim=2)
-        dist.all_gather([torch.empty_like(pw) for _ in range(world)], pw)
-        del pw
+        exchange_results(idx[W:].reshape(-1, k), val[W:].reshape(-1, k), nnz[W:].reshape(-1))
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
-    resolved = 0
+    resolved = uncertain = illcond = 0
+    screen_n, screen_ms = 0, 0.0
     for s in range(W, W + K):
         D.ctx.omp_batch_mfma_device(B[s], k, eps, idx[s], val[s], nnz[s])
         st = D.ctx.batch_stats()
         resolved += st["resolved_exactly"]
-        if s == W:
-            screen_n, screen_ms = 0, 0.0
+        uncertain += st["uncertain"]
+        illcond += st["illcond"]
         screen_n += st["screen_launches"]
         screen_ms += st["screen_ms"]
     D.ctx.sync()
     if use_dist:  # one gather of every rank's packed results
-        packed = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, :, None].to(torch.float64)], dim=2)
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed)
+        exchange_results(idx[W:].reshape(-1, k), val[W:].reshape(-1, k), nnz[W:].reshape(-1))
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    D.ctx.profile_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     atoms = torch.tensor([float(nnz[W:].sum().item())], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(atoms, op=dist.ReduceOp.SUM)
     tmax, atoms = tmax.item(), atoms.item()
-    if rank == 0:
-        flops = 2.0 * M * N * nsig  # per screening GEMM (nsig is a multiple of the 128-signal tile)
-        tf = flops / (screen_ms / max(screen_n, 1) / 1e3) / 1e12 if screen_n else 0.0
-        # parity spot check against the exact single-signal path (first 4 signals of the first timed batch)
-        i2 = torch.full((4, k), -1, dtype=torch.int64, device=dev)
-        v2 = torch.zeros((4, k), dtype=torch.float64, device=dev)
-        n2 = torch.zeros(4, dtype=torch.int64, device=dev)
-        D.ctx.omp_batch_device(B[W][:4].contiguous(), k, eps, i2, v2, n2)
-        D.ctx.sync()
-        same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
-        print(json.dumps({
-            "metric": "batched OMP atoms selected/sec, 1024 signals per GPU sharing A 4096x65536, k=128 (bf16 MFMA screen + f64 rescoring)",
-            "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 MFMA screen (f32 accumulate) + f64 rescoring/append", "data": "synthetic",
-            "signals_per_sec": K * nsig * world / tmax,
-            "config": {"workload": "configs[2]/[3]: batched OMP, 1024 signals per GPU sharing A 4096x65536 Float32, k=128",
-                       "signals_per_gpu_per_step": nsig, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
-            "roofline": {"bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
-                         "kernel": D.ctx.batch_screen_kernel(),
-                         "launches_timed": int(screen_n), "flops_per_launch": flops},
-            "signals_resolved_by_exact_path": int(resolved), "matches_exact_path_on_sample": same,
-        }), flush=True)
+    if rank != 0:
+        return None
+    flops = 2.0 * M * N * nsig  # per screening GEMM = per OMP step of the batch
+    tf = flops / (screen_ms / max(screen_n, 1) / 1e3) / 1e12 if screen_n else 0.0
+    ms_per_omp_step = tmax / K / k * 1e3
+    # parity spot check against the exact single-signal path (first 4 signals of the first timed batch)
+    i2 = torch.full((4, k), -1, dtype=torch.int64, device=dev)
+    v2 = torch.zeros((4, k), dtype=torch.float64, device=dev)
+    n2 = torch.zeros(4, dtype=torch.int64, device=dev)
+    D.ctx.omp_batch_device(B[W][:4].contiguous(), k, eps, i2, v2, n2)
+    D.ctx.sync()
+    same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
+    return {
+        "metric": "batched OMP atoms selected/sec, 1024 signals per GPU sharing A 4096x65536, k=128 (bf16 MFMA screen + f64 rescoring)",
+        "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 MFMA screen (f32 accumulate) + f64 rescoring/append", "data": "synthetic",
+        "signals_per_sec": K * nsig * world / tmax,
+        "config": {"workload": "configs[2]/[3]: batched OMP, 1024 signals per GPU sharing A 4096x65536 Float32, k=128",
+                   "signals_per_gpu_per_step": nsig, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
+        "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF, "traffic": None,
+                     "kernel": D.ctx.batch_screen_kernel(),
+                     "launches_timed": int(screen_n), "flops_per_launch": flops,
+                     # the whole OMP step of the batch (screen + rescoring/append of every signal) against the same ceiling
+                     "whole_step": {"ms_per_omp_step": ms_per_omp_step, "achieved": flops / (ms_per_omp_step / 1e3) / 1e12,
+                                    "frac": flops / (ms_per_omp_step / 1e3) / 1e12 / MFMA_PEAK_TF}},
+        "batch_stats": {"resolved_by_exact_path": int(resolved), "uncertain": int(uncertain), "illcond": int(illcond)},
+        "matches_exact_path_on_sample": same,
+    }
 
 
-def run_config5(args, cs, torch, dev, rank):
-    """configs[4]: GOMP (S = 4 atoms per step) and Subspace Pursuit on A 8192 x 131072 Float32, k = 512."""
-    import numpy as np
+def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None):
+    """configs[4]: GOMP (S = 4 atoms per step) or Subspace Pursuit on A 8192 x 131072 Float32, k = 512.
+    A step = one complete solve."""
     M5, N5, k, S = 8192, 131072, 512, 4
-    g = torch.Generator(device=dev).manual_seed(SEED_A + 5)
-    At = torch.empty((N5, M5), dtype=torch.float32, device=dev)
-    for lo in range(0, N5, 8192):
-        a = torch.randn((8192, M5), generator=g, device=dev, dtype=torch.float64)
-        a -= 1e-6 * a.mean(dim=1, keepdim=True)
-        a /= a.norm(dim=1, keepdim=True)
-        At[lo:lo + 8192] = a.to(torch.float32)
-    D = cs.Dictionary(At, device=dev.index)
-    K, W = args.steps, args.warmup
+    own = D5 is None
+    if own:
+        At5, D5 = make_dictionary5(cs, torch, dev)
     sigs = []
     for s_ in range(K + W):
         gs = torch.Generator(device=dev).manual_seed(99 + s_)
         idx = torch.randperm(N5, generator=gs, device=dev)[:k]
         sign = torch.randint(0, 2, (k,), generator=gs, device=dev).to(torch.float64) * 2 - 1
         e = torch.randn(M5, generator=gs, device=dev, dtype=torch.float64)
-        sigs.append(((At[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
+        sigs.append(((At5[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
     torch.cuda.synchronize()
-    eps = D.eps
+    eps = D5.eps
 
     def solve(b):
-        if args.workload == "gomp":
-            i, v, o = D.ctx.gomp(b, S, k, eps)
+        if workload == "gomp":
+            i, v, o = D5.ctx.gomp(b, S, k, eps)
             return len(i), 0
-        i, v, it = D.ctx.sp(b, k, 1e-2)
+        i, v, it = D5.ctx.sp(b, k, 1e-2)
         return len(i), it
     for w in range(W):
         solve(sigs[w])
-    D.ctx.profile_enable(True)
-    D.ctx.profile_read(reset=True)
+    D5.ctx.profile_enable(True)
+    D5.ctx.profile_read(reset=True)
     t0 = time.perf_counter()
     atoms, iters = 0, 0
     for s_ in range(W, W + K):
@@ -244,20 +289,41 @@ def run_config5(args, cs, torch, dev, rank):
         atoms += n
         iters += it
     dt = time.perf_counter() - t0
-    sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+    sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
+    D5.ctx.profile_enable(False)
     alg = M5 * N5 * 4
     avg = sweep_ms / max(sweeps, 1) / 1e3
-    out = {"metric": ("GOMP (S=4) atoms selected/sec" if args.workload == "gomp" else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
-           "value": (atoms / dt) if args.workload == "gomp" else K / dt, "unit": "atoms/s" if args.workload == "gomp" else "solves/s",
+    out = {"metric": ("GOMP (S=4) atoms selected/sec" if workload == "gomp" else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
+           "value": (atoms / dt) if workload == "gomp" else K / dt, "unit": "atoms/s" if workload == "gomp" else "solves/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
-           "config": {"workload": f"configs[4]: {args.workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if args.workload == "gomp" else ", delta=1e-2"),
+           "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if workload == "gomp" else ", delta=1e-2"),
                       "sweeps": int(sweeps), "sp_update_calls": int(iters)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
-    print(json.dumps(out), flush=True)
-    D.close()
+    if workload == "sp":
+        # the factorisations beside the sweeps: the first acquisition factorises k columns, every update! 2k and then k
+        # (src/twostage.jl:74-83,104-107); thin QR of n columns = 2 M n^2 flop.  Time = the solves minus their sweeps.
+        flop = 2.0 * M5 * (K * k * k + iters * ((2 * k) ** 2 + k * k))
+        rest = max(dt - sweep_ms / 1e3, 1e-9)
+        out["factorisation"] = {"flop": flop, "seconds_outside_sweeps": rest, "achieved_tflops_f64": flop / rest / 1e12,
+                                "note": "everything of a solve that is not a dictionary sweep: panel appends, top-k selection, back substitutions, host loop"}
+    if own:
+        D5.close()
+    return out
+
+
+def make_dictionary5(cs, torch, dev):
+    M5, N5 = 8192, 131072
+    g = torch.Generator(device=dev).manual_seed(SEED_A + 5)
+    At5 = torch.empty((N5, M5), dtype=torch.float32, device=dev)
+    for lo in range(0, N5, 8192):
+        a = torch.randn((8192, M5), generator=g, device=dev, dtype=torch.float64)
+        a -= 1e-6 * a.mean(dim=1, keepdim=True)
+        a /= a.norm(dim=1, keepdim=True)
+        At5[lo:lo + 8192] = a.to(torch.float32)
+    return At5, cs.Dictionary(At5, device=dev.index)
 
 
 def run_twostage(args, cs, torch, dev, At, D):
@@ -340,13 +406,23 @@ def run_fr(args, cs, torch, dev, At, D):
     print(json.dumps(out), flush=True)
 
 
+def rank_census(torch, dist, dev, use_dist, world):
+    """ranks_seen = the process group's own world size; devices = every rank's GPU as IT names it, gathered."""
+    name = torch.cuda.get_device_name(dev) + f" (cuda:{dev.index})"
+    if not use_dist:
+        return 1, [name]
+    names = [None] * world
+    dist.all_gather_object(names, name)
+    return dist.get_world_size(), names
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:
         # not under a launcher: start one (child processes; this process never touches the GPU)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.abspath(__file__)] + sys.argv[1:]
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
     import numpy as np
     import torch
@@ -361,16 +437,19 @@ def main():
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
     if use_dist:
         dist.init_process_group("nccl", device_id=dev)
+    ranks_seen, devices = rank_census(torch, dist, dev, use_dist, world)
+
+    def finish():
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
 
     if args.workload in ("gomp", "sp"):
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
         if rank == 0:
-            run_config5(args, cs, torch, dev, rank)
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev)), flush=True)
+        return finish()
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
     if args.workload in ("fr", "ompr", "srr"):
@@ -379,19 +458,16 @@ def main():
         if rank == 0:
             (run_fr if args.workload == "fr" else run_twostage)(args, cs, torch, dev, At, D)
         D.close()
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish()
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
-        run_batched(args, cs, torch, dist, dev, rank, world, At, D, use_dist)
+        out = measure_batched(args.steps, args.warmup, cs, torch, dist, dev, rank, world, At, D, use_dist)
+        if rank == 0:
+            out["ranks_seen"], out["devices"] = ranks_seen, devices
+            print(json.dumps(out), flush=True)
         D.close()
-        if use_dist:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish()
     eps = D.eps  # eps(Float32): omp(A, b, k) default (src/matchingpursuit.jl:85)
     K, W = args.steps, args.warmup
     B = make_signals(torch, dev, At, rank * (K + W), K + W)
@@ -410,19 +486,15 @@ def main():
     if W > 0:
         D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
     if use_dist:  # warm the collective too, at the size and through the packing kernels of the timed one
-        pw = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, None].to(torch.float64)], dim=1)
-        dist.all_gather([torch.empty_like(pw) for _ in range(world)], pw)
-        del pw
+        exchange_results(idx[W:], val[W:], nnz[W:])
     D.ctx.profile_enable(args.profile_every)  # HIP events around every n-th sweep launch of the timed region
     D.ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
     D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
     D.ctx.sync()
-    if use_dist:  # the single collective of the path: every rank's (idx, val, nnz) shard
-        packed = torch.cat([idx[W:].to(torch.float64), val[W:], nnz[W:, None].to(torch.float64)], dim=1)
-        gathered = [torch.empty_like(packed) for _ in range(world)]
-        dist.all_gather(gathered, packed)
+    if use_dist:  # the single collective of the path: every rank's (idx, val, nnz) shard, device buffers over RCCL
+        gathered = exchange_results(idx[W:], val[W:], nnz[W:])
     barrier()
     dt = time.perf_counter() - t0
     sweeps, sweep_ms = D.ctx.profile_read(reset=True)
@@ -443,35 +515,62 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes (see profiles/README.md)
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "csmp::k_tick<float,8,true,true> = the steady-state tick of the pipelined batch: software-pipelined sweep of one "
+                          "signal (one column per wave, 8-16 KiB of nt loads in flight per wave, one workgroup per CU) fused with the two "
+                          "short append stages of two other signals; csmp::k_sweep_pf<float,16,true> when a signal runs alone",
+                "launches_timed": int(sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                "timer": "HIP events on the library's stream around every %d-th steady-state tick of the timed region" % args.profile_every}
+        rp = rocprof_row("k_tick<float, 8, true, true>")
+        if rp:  # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command
+            rp["frac"] = alg_bytes / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
+            roof["rocprofv3"] = rp
         out = {
-            "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps)",
+            "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps, 3 signals pipelined)",
             "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
             "signals_per_sec": K * world / tmax,
             "config": {"workload": "configs[1]: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, "
                                    "k=256, planted +-1 256-sparse x0 + noise 5e-3, eps=eps(Float32)",
-                       "signals_per_gpu": K, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "csmp::k_tick<float,8,true> = software-pipelined sweep of one signal (one column per wave, 8-16 KiB of nt loads in flight per wave, one workgroup per CU) fused with the two short append stages of two other signals; csmp::k_sweep_pf<float,16,true> when a signal runs alone", "launches_timed": int(sweeps),
-                         "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes},
+                       "signals_per_gpu": K, "signals_in_flight": 3,
+                       "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
+            "ranks_seen": ranks_seen, "devices": devices,
+            "roofline": roof,
             "atoms_selected": int(atoms),
         }
+        if use_dist:
+            out["gathered_rows"] = int(gathered.shape[0])
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
             try:
-                order0 = None
                 # selection order of signal W (first timed signal) for the parity cross-check
                 i0, v0, o0 = D.ctx.omp(B[W].cpu().numpy(), K_ATOMS, eps)
-                order0 = o0
-                out["cpu_baseline"] = cpu_baseline(At, B[W:], order0, args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(At, B[W:], o0, args.cpu_seconds)
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        if not args.no_secondary and world == 1:
+            # the other single-GPU configurations of BASELINE.json, measured by this same process (builder-run lines
+            # of them also sit under profiles/; these are the driver-run ones)
+            sec = {}
+            try:
+                sec["batched_c3"] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False)
+            except Exception as e:  # noqa: BLE001
+                sec["batched_c3"] = {"error": repr(e)}
+            D.close()
+            del B, idx, val, nnz, At
+            torch.cuda.empty_cache()
+            try:
+                At5, D5 = make_dictionary5(cs, torch, dev)
+                sec["gomp_c5"] = measure_config5("gomp", 3, 1, cs, torch, dev, D5, At5)
+                sec["sp_c5"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5)
+                D5.close()
+            except Exception as e:  # noqa: BLE001
+                sec["config5"] = {"error": repr(e)}
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
     D.close()
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -31,6 +31,14 @@ SIGNATURES = {
     "csmp_sync": (C.c_int, [vp]),
     "csmp_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
     "csmp_set_dictionary": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int]),
+    "csmp_clone": (C.c_int, [vp, C.POINTER(vp)]),
+    "csmp_shard_config": (C.c_int, [vp, i64]),
+    "csmp_shard_record_bytes": (i64, [vp]),
+    "csmp_shard_sweep": (C.c_int, [vp, C.c_double, C.c_int, vp]),
+    "csmp_shard_append": (C.c_int, [vp, vp, C.c_int]),
+    "csmp_shard_range": (C.c_int, [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_pack_results": (C.c_int, [vp, vp, vp, i64, i64, vp]),
+    "csmp_unpack_results": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "csmp_mp": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
     "csmp_omp": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_gomp": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_double, vp, vp, C.POINTER(i64), vp]),
@@ -118,6 +126,20 @@ class Context:
         if getattr(self, "_h", None):
             lib().csmp_destroy(self._h)
             self._h = None
+        self._parent = None
+
+    def clone(self):
+        """A second context on the same GPU borrowing this one's resident dictionary (csmp_clone): what every
+        step-level functor works on, so that two of them never share solver state."""
+        c = Context.__new__(Context)
+        c._h = vp()
+        c.M, c.N, c.dtype, c._keep = self.M, self.N, self.dtype, self._keep
+        c._parent = self  # the borrowed dictionary must outlive the clone
+        rc = lib().csmp_clone(self._h, C.byref(c._h))
+        if rc != OK:
+            c._h = None
+            self.check(rc)
+        return c
 
     def __del__(self):
         try:
@@ -419,6 +441,25 @@ class Context:
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), res.value, order[:n].copy(), stop.value
 
+    # ---- one signal, columns sharded (csmp_shard_*): torch CUDA byte tensors for the records
+    def set_stream(self, hip_stream):
+        """Borrow a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 / None: the library's own."""
+        self.call("csmp_set_stream", vp(hip_stream or 0))
+
+    def shard_config(self, col_offset):
+        self.call("csmp_shard_config", i64(int(col_offset)))
+
+    def shard_record_bytes(self):
+        return int(lib().csmp_shard_record_bytes(self._h))
+
+    def shard_sweep(self, eps, check_eps, rec):
+        assert rec.is_cuda and rec.is_contiguous() and rec.numel() * rec.element_size() >= self.shard_record_bytes()
+        self.call("csmp_shard_sweep", C.c_double(eps), int(bool(check_eps)), vp(rec.data_ptr()))
+
+    def shard_append(self, recs, nrec):
+        assert recs.is_cuda and recs.is_contiguous() and recs.numel() * recs.element_size() >= nrec * self.shard_record_bytes()
+        self.call("csmp_shard_append", vp(recs.data_ptr()), int(nrec))
+
     # ---- primitives
     def sweep(self, r, topk=1, want_abs=True):
         r = np.ascontiguousarray(r, dtype=np.float64)
@@ -452,3 +493,37 @@ class Context:
         ms = C.c_double(0)
         self.call("csmp_bench_sweep", int(variant), int(reps), C.byref(ms))
         return ms.value
+
+
+# ---- signal sharding: the wire layout of the ONE exchange (host memory, no ctx)
+def shard_range(nsig, rank, world):
+    lo, hi = i64(0), i64(0)
+    rc = lib().csmp_shard_range(i64(int(nsig)), int(rank), int(world), C.byref(lo), C.byref(hi))
+    if rc != OK:
+        raise CsmpError(rc, "csmp_shard_range: bad arguments")
+    return lo.value, hi.value
+
+
+def pack_results(idx, val, nnz):
+    """idx, val: (nsig, k) C-contiguous int64 / float64; nnz: (nsig,) int64 -> (nsig, 2k+1) float64 rows."""
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    nnz = np.ascontiguousarray(nnz, dtype=np.int64)
+    nsig, k = idx.shape
+    out = np.empty((nsig, 2 * k + 1), np.float64)
+    rc = lib().csmp_pack_results(ptr(idx), ptr(val), ptr(nnz), i64(k), i64(nsig), ptr(out))
+    if rc != OK:
+        raise CsmpError(rc, "csmp_pack_results: bad arguments")
+    return out
+
+
+def unpack_results(packed, k):
+    packed = np.ascontiguousarray(packed, dtype=np.float64)
+    nsig = packed.shape[0]
+    idx = np.empty((nsig, k), np.int64)
+    val = np.empty((nsig, k), np.float64)
+    nnz = np.empty(nsig, np.int64)
+    rc = lib().csmp_unpack_results(ptr(packed), i64(int(k)), i64(nsig), ptr(idx), ptr(val), ptr(nnz))
+    if rc != OK:
+        raise CsmpError(rc, "csmp_unpack_results: bad arguments")
+    return idx, val, nnz

@@ -316,11 +316,14 @@ class _DevicePursuit(_Update):
         self.l = int(l)
         M, N = self.D.shape
         self.kcap = int(kcap)
-        self.D.ctx.solver_begin(self.ALGO, b, self.kcap)
+        # a context of its own that borrows the resident dictionary: like the reference's P objects, two functors on
+        # one Dictionary (or a functor and a driver call) share A and nothing else
+        self.ctx = self.D.ctx.clone()
+        self.ctx.solver_begin(self.ALGO, b, self.kcap)
         self._x = spzeros(N)  # the x this object has been evolving
 
     def _sync_x(self, x):
-        idx, val, res, order, stop = self.D.ctx.solver_state(max(self.kcap, 1))
+        idx, val, res, order, stop = self.ctx.solver_state(max(self.kcap, 1))
         self._x = SparseVector(self.D.shape[1], idx, val)
         self.resnorm, self.order, self.stop = res, order, stop
         if x is None:
@@ -332,9 +335,10 @@ class _DevicePursuit(_Update):
         return x is None or (x.nnz == self._x.nnz and np.array_equal(x.nzind, self._x.nzind))
 
     def residual_norm(self):
-        return self.D.ctx.solver_state(max(self.kcap, 1))[2]
+        return self.ctx.solver_state(max(self.kcap, 1))[2]
 
     def close(self):
+        self.ctx.close()
         if self._tmp:
             self.D.close()
 
@@ -351,7 +355,7 @@ class OMP(_DevicePursuit):
     def update_(self, x=None):
         if not self._same(x):
             raise ValueError("update!(P::OMP, x): x is not the support this OMP object's QR was built for")
-        self.D.ctx.solver_step(1)
+        self.ctx.solver_step(1)
         return self._sync_x(x)
 
 
@@ -366,7 +370,7 @@ class GOMP(_DevicePursuit):
     def update_(self, x=None, l=None):
         if not self._same(x):
             raise ValueError("update!(P::GOMP, x): x is not the support this GOMP object's QR was built for")
-        self.D.ctx.solver_step(self.l if l is None else int(l))
+        self.ctx.solver_step(self.l if l is None else int(l))
         return self._sync_x(x)
 
 
@@ -384,12 +388,12 @@ class FR(_DevicePursuit):
     def update_(self, x=None):
         if not self._same(x):
             raise ValueError("update!(P::FR, x): x is not the support this FR object's QR was built for")
-        self.D.ctx.solver_step(1)
+        self.ctx.solver_step(1)
         return self._sync_x(x)
 
     @property
     def delta2(self):
-        return self.D.ctx.fr_scores()
+        return self.ctx.fr_scores()
 
 
 OLS = OOMP = ORMP = StepwiseRegression = FR
@@ -401,14 +405,16 @@ class MP(_DevicePursuit):
     ALGO = _lib.ALGO_MP
 
     def __init__(self, A, b, steps=4096):
+        """steps: how many update! calls this object can record (MP keeps no factorisation, so this is only the
+        length of its (atom, coefficient) log on the device)."""
         super().__init__(A, b, steps)
 
     def update_(self, x=None):
         if x is not None and not (self._same(x) and np.array_equal(x.nzval, self._x.nzval)):
-            self.D.ctx.solver_begin(self.ALGO, self.b, self.kcap, x.nzind, x.nzval)
+            self.ctx.solver_begin(self.ALGO, self.b, self.kcap, x.nzind, x.nzval)
             self._base = x.copy()
-        self.D.ctx.solver_step(1)
-        idx, val, res, order, stop = self.D.ctx.solver_state(max(self.kcap, 1))
+        self.ctx.solver_step(1)
+        idx, val, res, order, stop = self.ctx.solver_state(max(self.kcap, 1))
         base = getattr(self, "_base", None)
         out = base.copy() if base is not None else spzeros(self.D.shape[1])
         for i, v in zip(idx, val):  # steps since the (re)start, merged per atom by the library

@@ -9,6 +9,7 @@
 #include "csmp_forward.hpp"
 #include "csmp_downdate.hpp"
 #include "csmp_tinv.hpp"
+#include "csmp_shard.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -25,8 +26,9 @@ static constexpr int kRsEqCap = 4096;
 
 struct Solver {
     int kcap = 0, outcap = 0;
+    int qcap = 0;  // capacity of the QR arrays: kcap, or 1 for a slot that so far served MP / sweep-only calls
     int64_t ldq = 0;
-    int G = 0, Mpad = 0, jpad = 0;
+    int G = 0, Mpad = 0;
     double *b = nullptr, *r = nullptr, *cvec = nullptr, *pval = nullptr;
     int* pidx = nullptr;
     double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr, *P1s = nullptr;
@@ -59,6 +61,7 @@ struct Solver {
     double *T = nullptr, *T2 = nullptr, *tpd = nullptr, *tpn = nullptr;
     int* tmeta = nullptr;
     int sigcap = 0;
+    void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
 };
 
 // device state of the batched (MFMA-screened) path
@@ -93,6 +96,7 @@ struct csmp_ctx {
     bool ownA = false;
     int dtype = CSMP_F32;
     int64_t M = 0, N = 0, ld = 0;
+    int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
     int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
     int sweep_grid = 0, sweep_U = 1;
     int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
@@ -156,6 +160,15 @@ static void dfree(T*& p) {
     if (p) (void)hipFree(p);
     p = nullptr;
 }
+// device temporary of one call: released on every return path (hipFree waits for the work that uses it)
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 1)); }
+};
 
 // ------------------------------------------------------------------------------------------ lifetime
 extern "C" int csmp_version(void) { return 100; }
@@ -227,7 +240,7 @@ static void solver_free(Solver& s) {
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
-    dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta);
+    dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
     s = Solver();
 }
 
@@ -455,6 +468,7 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     ctx->dtype = dtype;
     ctx->M = M;
     ctx->N = N;
+    ctx->col_offset = 0;
     if (borrow) {
         ctx->dA = const_cast<void*>(A);
         ctx->ld = ldA;
@@ -476,22 +490,18 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
 }
 
 // ------------------------------------------------------------------------------------------ solver buffers
-static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
-    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
-    Solver& s = ctx->s;
-    if (s.kcap >= kcap && s.outcap >= outcap) return CSMP_OK;
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    kcap = std::max(kcap, s.kcap);
-    outcap = std::max(outcap, s.outcap);
-    solver_free(s);
+// Largest support the on-device QR append can serve: its workgroups keep five support-length vectors in LDS.
+static int qr_max_cols() {
+    int k = 64;
+    while (qr_lds_bytes(k + 64) <= 160 * 1024 - 512) k += 64;
+    return k;
+}
+
+static int solver_alloc(csmp_ctx* ctx, Solver& s, int kcap, int outcap, int qcap) {
     const int M = (int)ctx->M;
-    s.kcap = kcap;
-    s.outcap = outcap;
     s.ldq = ((M + kSlabRows - 1) / kSlabRows) * kSlabRows;
     s.G = (int)(s.ldq / kSlabRows);
     s.Mpad = ((M + 255) / 256) * 256;
-    s.jpad = qr_jpad(kcap);
-    if (qr_lds_bytes(kcap) > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "sparsity too large for the on-device QR (LDS)");
     const int maxgrid = ctx->prop.multiProcessorCount * 8 + 8;
     CHECK(dmalloc(ctx, &s.b, s.Mpad));
     CHECK(dmalloc(ctx, &s.r, s.Mpad));
@@ -501,13 +511,13 @@ static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
     CHECK(dmalloc(ctx, &s.cvec, (size_t)ctx->N));
     CHECK(dmalloc(ctx, &s.pval, maxgrid));
     CHECK(dmalloc(ctx, &s.pidx, maxgrid));
-    CHECK(dmalloc(ctx, &s.Q, (size_t)s.ldq * kcap));
-    CHECK(dmalloc(ctx, &s.R, (size_t)kcap * kcap));
+    CHECK(dmalloc(ctx, &s.Q, (size_t)s.ldq * qcap));
+    CHECK(dmalloc(ctx, &s.R, (size_t)qcap * qcap));
     CHECK(dmalloc(ctx, &s.z, kcap));
-    CHECK(dmalloc(ctx, &s.W1, kcap));
+    CHECK(dmalloc(ctx, &s.W1, qcap));
     CHECK(dmalloc(ctx, &s.coef, kcap));
-    CHECK(dmalloc(ctx, &s.P1, (size_t)s.G * kcap));
-    CHECK(dmalloc(ctx, &s.P2, (size_t)s.G * kcap));
+    CHECK(dmalloc(ctx, &s.P1, (size_t)s.G * qcap));
+    CHECK(dmalloc(ctx, &s.P2, (size_t)s.G * qcap));
     CHECK(dmalloc(ctx, &s.P2s, (size_t)2 * s.G));
     CHECK(dmalloc(ctx, &s.P1s, (size_t)2 * s.G));
     CHECK(dmalloc(ctx, &s.scal, 8));
@@ -528,6 +538,43 @@ static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap) {
     CHECK(dmalloc(ctx, &s.out_val, outcap));
     CHECK(dmalloc(ctx, &s.out_nnz, 1));
     HIPCHECK(hipMemsetAsync(s.st, 0, sizeof(DevState), ctx->stream));
+    return CSMP_OK;
+}
+
+// Buffers of the active solver slot for supports of up to kcap atoms and outcap output entries.  qr = false
+// (MP, the sweep primitive): the QR arrays are not needed and stay at whatever size they have.  The slot only
+// grows; a request is either served completely or leaves an EMPTY slot (kcap = 0) behind, never a half-built one.
+static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap, bool qr = true) {
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    Solver& s = ctx->s;
+    if (s.kcap >= kcap && s.outcap >= outcap && (!qr || s.qcap == s.kcap)) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    kcap = std::max(kcap, s.kcap);
+    outcap = std::max(outcap, s.outcap);
+    const int qcap = qr ? kcap : 1;
+    solver_free(s);
+    Solver n;
+    const int rc = solver_alloc(ctx, n, kcap, outcap, qcap);
+    if (rc != CSMP_OK) {
+        solver_free(n);
+        return rc;
+    }
+    n.kcap = kcap;
+    n.outcap = outcap;
+    n.qcap = qcap;
+    s = n;
+    return CSMP_OK;
+}
+
+// The column-removal kernels (csmp_downdate.hpp, csmp_tinv.hpp) address R and T with the slot's capacity as
+// leading dimension and scan one support in one workgroup: at most kDelMaxCols columns.  A slot that an earlier
+// call grew beyond that is rebuilt at the size this call needs.
+static int solver_fit_for_removal(csmp_ctx* ctx, int kcap) {
+    Solver& s = ctx->s;
+    if (s.kcap > kDelMaxCols && kcap <= kDelMaxCols) {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        solver_free(s);
+    }
     return CSMP_OK;
 }
 
@@ -571,10 +618,17 @@ static int launch_select(csmp_ctx* ctx, int mode, int skipmask) {
 // One atom through the append chain.  mode 1: atom = arg-max of the last sweep + OMP guards
 // (src/matchingpursuit.jl:63,65-66); mode 2: atom = cands[which] + GOMP's duplicate skip
 // (src/util.jl:119,129-134).  Then add_column!(AiQR, A[:, atom]) and the residual update.
-static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool optimistic = false, double min_d2 = 0.0, int nblk_sweep = 0) {
+static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool optimistic = false, double min_d2 = 0.0, int nblk_sweep = 0,
+                         const void* onecol = nullptr) {
     Solver& s = ctx->s;
-    const size_t lds = qr_lds_bytes(s.kcap);
+    // onecol (mode 4): the atom's column is handed over as a one-column dictionary (ld = 0: every index reads it)
+    const void* dA = onecol ? onecol : ctx->dA;
+    const int64_t ldA = onecol ? 0 : ctx->ld;
     const int jh = std::min(s.jh, s.kcap);
+    // the LDS vectors of the append kernels are sized by the support they can meet (jh bounds it), not by the capacity
+    const int jpad = qr_jpad(jh);
+    const size_t lds = qr_lds_bytes(jh);
+    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     if (lds > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -582,24 +636,24 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     if (ctx->dtype == CSMP_F32)
-        hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)ctx->dA, ctx->ld,
-                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
+        hipLaunchKernelGGL(k_qr1<float>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const float*)dA, ldA,
+                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, jpad, mode,
                            (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
                            (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2);
     else
-        hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)ctx->dA, ctx->ld,
-                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, s.jpad, mode,
+        hipLaunchKernelGGL(k_qr1<double>, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, (const double*)dA, ldA,
+                           (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, jpad, mode,
                            (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
                            (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2);
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
                        (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
-                       s.jpad, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0);
+                       jpad, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0);
     HIPCHECK(hipGetLastError());
     if (s.jh < s.kcap) s.jh += 1;
     if (optimistic) return CSMP_OK;  // k_qr3 (second Gram-Schmidt pass) only in the safe chain
     hipLaunchKernelGGL(k_qr3, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.vvec, s.r,
-                       (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, s.jpad);
+                       (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, jpad);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -688,7 +742,7 @@ static TickQr1<TA> tick_qr1_params(csmp_ctx* ctx, const Solver& s, int skipmask,
     TickQr1<TA> p;
     p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.M = (int)ctx->M;
     p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.P1 = s.P1;
-    p.G = s.G; p.kcap = s.kcap; p.jpad = s.jpad; p.mode = 1;
+    p.G = s.G; p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.mode = 1;
     p.pval = s.pval; p.pidx = s.pidx; p.nblk_sweep = nblk_sweep;
     p.cands = s.cands; p.ncands = s.ncands; p.which = 0; p.sel = s.sel; p.skipmask = skipmask;
     p.r = s.r; p.P1s = s.P1s; p.jh = jh; p.active = active;
@@ -699,14 +753,14 @@ static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optim
     p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.r = s.r;
     p.P1 = s.P1; p.P1s = s.P1s; p.G = s.G;
     p.W1 = s.W1; p.vvec = s.vvec; p.P2 = s.P2; p.P2s = s.P2s; p.R = s.R; p.z = s.z; p.sel = s.sel;
-    p.kcap = s.kcap; p.jpad = s.jpad; p.force_reorth = ctx->force_reorth ? 1 : 0; p.jh = jh; p.optimistic = optimistic;
+    p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.force_reorth = ctx->force_reorth ? 1 : 0; p.jh = jh; p.optimistic = optimistic;
     p.active = active;
     return p;
 }
 
-template <typename TA, int U, bool PF>
+template <typename TA, int U, bool PF, bool STEADY = false>
 static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
-    auto kern = k_tick<TA, U, PF>;
+    auto kern = k_tick<TA, U, PF, STEADY>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -714,11 +768,16 @@ static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const Ti
     hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, ctx->tick_sweep_first ? 1 : 0);
     return hipGetLastError();
 }
+// steady: all three stages of this tick are live (the launches the bench's roofline is quoted on)
 template <typename TA>
-static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
+static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
     switch (ctx->tick_U) {
-        case 16: return ctx->tick_pf ? tick_launch_t<TA, 16, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 16, false>(ctx, sw, q1, q2, G, lds);
-        case 8: return ctx->tick_pf ? tick_launch_t<TA, 8, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 8, false>(ctx, sw, q1, q2, G, lds);
+        case 16:
+            if (!ctx->tick_pf) return tick_launch_t<TA, 16, false>(ctx, sw, q1, q2, G, lds);
+            return steady ? tick_launch_t<TA, 16, true, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 16, true, false>(ctx, sw, q1, q2, G, lds);
+        case 8:
+            if (!ctx->tick_pf) return tick_launch_t<TA, 8, false>(ctx, sw, q1, q2, G, lds);
+            return steady ? tick_launch_t<TA, 8, true, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 8, true, false>(ctx, sw, q1, q2, G, lds);
         case 4: return tick_launch_t<TA, 4, false>(ctx, sw, q1, q2, G, lds);
         case 2: return tick_launch_t<TA, 2, false>(ctx, sw, q1, q2, G, lds);
         default: return tick_launch_t<TA, 1, false>(ctx, sw, q1, q2, G, lds);
@@ -742,7 +801,8 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
                               : ctx->tick_U == 16 ? (int64_t)ctx->sweep_grid * 11 / 12
                                                   : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
-    const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes(sl[0]->kcap));
+    const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
+    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
         const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
@@ -759,9 +819,10 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
         const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, nblk, az ? 1 : 0);
         const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
         const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
-        const bool timed = az && ay && ax && prof_pick(ctx);  // steady-state ticks only
+        const bool steady = az && ay && ax;
+        const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
         if (timed) CHECK(prof_mark(ctx));
-        HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, lds));
+        HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, lds, steady));
         if (timed) CHECK(prof_mark(ctx));
     }
     return CSMP_OK;
@@ -933,7 +994,8 @@ static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_
     fr_config(ctx, 1, U, full, flds, grid);
     int nblk = grid;
     if (const char* tn = getenv("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
-    const size_t lds = std::max(flds, qr_lds_bytes(sl[0]->kcap));
+    const size_t lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));
+    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
         const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
@@ -1010,18 +1072,21 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     ctx->s.begun = false;
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     void* dB = const_cast<void*>(B);
-    bool ownB = false;
+    DevTmp tB, tIdx, tVal, tNnz;  // freed on every return path
     if (b_loc == CSMP_HOST) {
-        HIPCHECK(hipMalloc(&dB, (size_t)ldB * (size_t)nsig * es));
-        ownB = true;
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
         HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
     }
     int64_t *d_idx = idx, *d_nnz = nnz;
     double* d_val = val;
     if (out_loc == CSMP_HOST) {
-        HIPCHECK(hipMalloc((void**)&d_idx, (size_t)k * nsig * 8));
-        HIPCHECK(hipMalloc((void**)&d_val, (size_t)k * nsig * 8));
-        HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
     }
     int rc = CSMP_OK;
     activate_slot(ctx, 0);
@@ -1102,13 +1167,6 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_idx);
-        (void)hipFree(d_val);
-        (void)hipFree(d_nnz);
-    }
-    if (ownB) {
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(dB);
     }
     return rc;
 }
@@ -1182,6 +1240,9 @@ static int mp_collect(csmp_ctx* ctx, const int64_t* idx0, const double* val0, in
 }
 
 static int mp_step(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.jh >= s.kcap) return fail(ctx, CSMP_ERANGE, "mp: more steps than the capacity this solver was begun with");
+    s.jh += 1;  // (MP: steps taken; the log of (atom, coefficient) pairs holds kcap of them)
     CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
     CHECK(launch_select(ctx, 0, 0));
     return launch_mp_update(ctx);
@@ -1193,7 +1254,7 @@ extern "C" int csmp_mp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, con
     if (!b || k < 0 || nnz0 < 0 || (nnz0 > 0 && (!idx0 || !val0))) return fail(ctx, CSMP_EINVAL, "mp: bad arguments");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(std::max(k, nnz0), 1), 1));
+    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(std::max(k, nnz0), 1), 1, false));  // MP keeps no factorisation
     ctx->s.begun = false;
     CHECK(upload_b(ctx, b, b_dtype));
     if (nnz0 > 0) CHECK(upload_support(ctx, idx0, val0, nnz0));
@@ -1210,7 +1271,7 @@ extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_d
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = algo == CSMP_ALGO_MP ? (int)kcap : (int)std::min<int64_t>(kcap, ctx->M);
-    CHECK(solver_ensure(ctx, kc, kc));
+    CHECK(solver_ensure(ctx, kc, kc, algo != CSMP_ALGO_MP));
     if (algo == CSMP_ALGO_FR) CHECK(fr_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
     if (nnz0 > 0) {
@@ -1243,6 +1304,139 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
         }
         default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
+}
+
+// ------------------------------------------------------------------------------------------ shared dictionary
+// A second context on the same GPU that BORROWS the resident dictionary of `src` (no copy): the independent
+// P objects of the reference -- P1 = OMP(A, b1); P2 = OMP(A, b2) share A and nothing else
+// (src/matchingpursuit.jl:44-60).  `src` must outlive the clone and keep its dictionary.
+extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
+    if (!src || !out) return CSMP_EINVAL;
+    *out = nullptr;
+    if (!src->dA) return fail(src, CSMP_ESTATE, "clone: no dictionary set (csmp_set_dictionary)");
+    csmp_ctx* c = nullptr;
+    const int rc = csmp_create(&c, src->dev);
+    if (rc != CSMP_OK) {
+        src->err = g_create_err;
+        return rc;
+    }
+    c->dA = src->dA;
+    c->ownA = false;
+    c->dtype = src->dtype;
+    c->M = src->M;
+    c->N = src->N;
+    c->ld = src->ld;
+    c->Mv = src->Mv;
+    c->col_offset = src->col_offset;
+    const int rc2 = configure_sweep(c);
+    if (rc2 != CSMP_OK) {
+        src->err = c->err;
+        csmp_destroy(c);
+        return rc2;
+    }
+    *out = c;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ column-sharded OMP
+// See csmp_shard.hpp.  The ctx holds columns [col_offset, col_offset + N) of the global dictionary; a solve is
+// csmp_solver_begin(CSMP_ALGO_OMP) on every rank, then per step csmp_shard_sweep -> the caller's all_gather of
+// one record per rank -> csmp_shard_append, and csmp_solver_state at the end (identical on every rank).
+extern "C" int csmp_shard_config(csmp_ctx* ctx, int64_t col_offset) {
+    if (!ctx) return CSMP_EINVAL;
+    if (col_offset < 0 || col_offset + ctx->N > 0x7fffffff) return fail(ctx, CSMP_ERANGE, "shard_config: global column indices must fit 31 bits");
+    ctx->col_offset = col_offset;
+    return CSMP_OK;
+}
+
+extern "C" int64_t csmp_shard_record_bytes(const csmp_ctx* ctx) {
+    if (!ctx || !ctx->dA) return 0;
+    return (int64_t)shard_record_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 8);
+}
+
+static int shard_ready(csmp_ctx* ctx, const char* who) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun || ctx->s.algo != CSMP_ALGO_OMP)
+        return fail(ctx, CSMP_ESTATE, (std::string(who) + ": begin the solve with csmp_solver_begin(CSMP_ALGO_OMP)").c_str());
+    return CSMP_OK;
+}
+
+// steps 1-2: argmaxinner!(P) over the local columns (+ the driver's residual test of the previous iteration,
+// src/matchingpursuit.jl:79, when check_eps != 0) and the rank's record, written to DEVICE memory at rec_dev
+extern "C" int csmp_shard_sweep(csmp_ctx* ctx, double eps, int check_eps, void* rec_dev) {
+    CHECK(shard_ready(ctx, "shard_sweep"));
+    if (!rec_dev || !(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "shard_sweep: rec_dev == NULL or eps < 0");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Solver& s = ctx->s;
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL;
+    CHECK(launch_sweep(ctx, s.r, eps, check_eps, skip));
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_shard_pack<float>, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx,
+                           ctx->sweep_grid, (const double*)s.cvec, (const float*)ctx->dA, ctx->ld, ctx->Mv, ctx->col_offset,
+                           (const DevState*)s.st, skip, (char*)rec_dev);
+    else
+        hipLaunchKernelGGL(k_shard_pack<double>, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx,
+                           ctx->sweep_grid, (const double*)s.cvec, (const double*)ctx->dA, ctx->ld, ctx->Mv, ctx->col_offset,
+                           (const DevState*)s.st, skip, (char*)rec_dev);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// steps 4-5: global arg-max over the nrec gathered records (DEVICE memory, csmp_shard_record_bytes apart),
+// then update!(P::OMP, x)'s guards, add_column! and the residual update on the winning column
+extern "C" int csmp_shard_append(csmp_ctx* ctx, const void* recs_dev, int nrec) {
+    CHECK(shard_ready(ctx, "shard_append"));
+    if (!recs_dev || nrec < 1) return fail(ctx, CSMP_EINVAL, "shard_append: recs_dev == NULL or nrec < 1");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Solver& s = ctx->s;
+    const size_t es = ctx->dtype == CSMP_F32 ? 4 : 8;
+    if (!s.extcol) HIPCHECK(hipMalloc(&s.extcol, (size_t)ctx->Mv * es));
+    const int64_t rb = (int64_t)shard_record_bytes(ctx->Mv, es);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_shard_pick<float>, dim3(1), dim3(256), 0, ctx->stream, (const char*)recs_dev, nrec, rb, ctx->Mv,
+                           (float*)s.extcol, s.cands, s.ncands, s.st);
+    else
+        hipLaunchKernelGGL(k_shard_pick<double>, dim3(1), dim3(256), 0, ctx->stream, (const char*)recs_dev, nrec, rb, ctx->Mv,
+                           (double*)s.extcol, s.cands, s.ncands, s.st);
+    HIPCHECK(hipGetLastError());
+    return launch_append(ctx, 4, 0, STOP_EPS | STOP_STAG | STOP_FULL, false, 0.0, 0, s.extcol);
+}
+
+// ------------------------------------------------------------------------------------------ signal sharding helpers
+// The data path of the signal-sharded batch has ONE exchange: every rank's results.  These
+// three host-side helpers fix its layout so that any host language can run it over its own collective
+// (torch.distributed / RCCL here, MPI.jl from Julia): contiguous blocks of signals per rank, and per signal one row
+// of 2k + 1 Float64 = [idx_0 .. idx_{k-1} | val_0 .. val_{k-1} | nnz] (indices are exact in Float64 below 2^53).
+extern "C" int csmp_shard_range(int64_t nsig, int rank, int world, int64_t* lo, int64_t* hi) {
+    if (nsig < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return CSMP_EINVAL;
+    const int64_t base = nsig / world, extra = nsig % world;  // block sizes differ by at most one
+    *lo = rank * base + std::min<int64_t>(rank, extra);
+    *hi = *lo + base + (rank < extra ? 1 : 0);
+    return CSMP_OK;
+}
+extern "C" int csmp_pack_results(const int64_t* idx, const double* val, const int64_t* nnz, int64_t k, int64_t nsig, double* packed) {
+    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
+    const int64_t w = 2 * k + 1;
+    for (int64_t s = 0; s < nsig; ++s) {
+        for (int64_t t = 0; t < k; ++t) {
+            packed[s * w + t] = (double)idx[s * k + t];
+            packed[s * w + k + t] = val[s * k + t];
+        }
+        packed[s * w + 2 * k] = (double)nnz[s];
+    }
+    return CSMP_OK;
+}
+extern "C" int csmp_unpack_results(const double* packed, int64_t k, int64_t nsig, int64_t* idx, double* val, int64_t* nnz) {
+    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
+    const int64_t w = 2 * k + 1;
+    for (int64_t s = 0; s < nsig; ++s) {
+        for (int64_t t = 0; t < k; ++t) {
+            idx[s * k + t] = (int64_t)packed[s * w + t];
+            val[s * k + t] = packed[s * w + k + t];
+        }
+        nnz[s] = (int64_t)packed[s * w + 2 * k];
+    }
+    return CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ column removal
@@ -1713,7 +1907,7 @@ extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int6
     if (topk > ctx->N) topk = ctx->N;
     if (topk > ctx->M) return fail(ctx, CSMP_ERANGE, "sweep: topk > size(A,1) is not supported (no caller of argmaxinner!(P,k) needs it)");
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(topk, 1), 1));
+    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(topk, 1), 1, false));
     ctx->s.begun = false;
     CHECK(upload_b(ctx, r, CSMP_F64));
     CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
@@ -1758,6 +1952,8 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
     if (maxiter < 0) maxiter = ctx->M;  // :185
     HIPCHECK(hipSetDevice(ctx->dev));
+    const bool want_downdate = k <= kDelMaxCols && !getenv("CSMP_OMPR_REFACTOR");
+    if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
     CHECK(solver_ensure(ctx, (int)k, (int)k));
     ctx->s.begun = false;
     Solver& s = ctx->s;
@@ -1917,6 +2113,7 @@ struct Stepwise {
     // buffers for at most kcap atoms, b uploaded, empty support
     int begin(csmp_ctx* c, const void* b, int b_dtype, int kcap) {
         ctx = c;
+        CHECK(solver_fit_for_removal(ctx, kcap));
         CHECK(solver_ensure(ctx, kcap, kcap));
         CHECK(fr_ensure(ctx));
         CHECK(tinv_ensure(ctx));
@@ -2389,18 +2586,21 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     Batch& b = ctx->bt;
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     void* dB = const_cast<void*>(B);
-    bool ownB = false;
+    DevTmp tB, tIdx, tVal, tNnz;  // freed on every return path
     if (b_loc == CSMP_HOST) {
-        HIPCHECK(hipMalloc(&dB, (size_t)ldB * (size_t)nsig * es));
-        ownB = true;
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
         HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
     }
     int64_t *d_idx = idx, *d_nnz = nnz;
     double* d_val = val;
     if (out_loc == CSMP_HOST) {
-        HIPCHECK(hipMalloc((void**)&d_idx, (size_t)k * nsig * 8));
-        HIPCHECK(hipMalloc((void**)&d_val, (size_t)k * nsig * 8));
-        HIPCHECK(hipMalloc((void**)&d_nnz, (size_t)nsig * 8));
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
     }
     const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
     const int n_stiles = Bpad / kBT;
@@ -2458,13 +2658,6 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
             HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(d_idx);
-        (void)hipFree(d_val);
-        (void)hipFree(d_nnz);
-    }
-    if (ownB) {
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        (void)hipFree(dB);
     }
     return rc;
 }
@@ -2557,7 +2750,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     if (!ctx || reps < 1) return CSMP_EINVAL;
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(solver_ensure(ctx, 1, 1));
+    CHECK(solver_ensure(ctx, 1, 1, false));
     ctx->s.begun = false;
     std::vector<double> r((size_t)ctx->M);
     uint64_t sd = 0x9E3779B97F4A7C15ull;

@@ -920,6 +920,8 @@ inline size_t qr_lds_bytes(int kcap) {
 //   already in the support (util.jl:119); only a full support stops anything (:117).
 // mode 3 (forward regression): atom = arg-max of the δ² scores of k_fr_sweep (findmax, src/forward.jl:63);
 //   the step fails -- and fr stops -- unless min_δ^2 < max δ² (:64); nnz < n guard (:58).
+// mode 4 (column-sharded OMP, csmp_shard_append): atom = cands[0], a LABEL (global column index) whose column
+//   the caller supplies as a one-column dictionary (ld = 0); guards as mode 1.
 // Every workgroup derives the same decision from the same device data; workgroup 0 publishes it
 // (cand, j, go) for k_qr2 / k_qr3, which no workgroup of THIS launch reads.
 template <typename TA, int W>
@@ -970,7 +972,7 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
         st->go = go ? 1 : 0;
         if (full)
             st->done |= STOP_FULL;
-        else if ((mode == 1 || mode == 3) && (found || low || cand == 0x7fffffff))
+        else if ((mode == 1 || mode == 3 || mode == 4) && (found || low || cand < 0 || cand == 0x7fffffff))
             st->done |= STOP_STAG;
     }
     if (!go) return;
@@ -1175,7 +1177,10 @@ struct TickQr2 {
     int kcap, jpad, force_reorth, jh, optimistic, active;
 };
 
-template <typename TA, int U, bool PF>
+// STEADY only names the kernel: the launches in which all three stages are live (every tick of a batch except the
+// 2 + 2 that fill and drain the pipeline of a signal triple) get a symbol of their own, so that a kernel trace
+// (rocprofv3 --kernel-trace --stats) reports the sweep-carrying ticks as one clean row.
+template <typename TA, int U, bool PF, bool STEADY = false>
 __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
                                                         const int G, const int sweep_first) {
     extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -1,14 +1,24 @@
-"""Signals sharded across the GPUs of one node: one process per GPU (torch.distributed, backend
-"nccl" = RCCL over xGMI), the dictionary replicated, signal s owned by the rank whose contiguous
-block holds it, NO communication during the solves and ONE gather of the packed results at the
-end.  The reference has no distributed code; this is the loop
-`[omp(A, B[:, s], eps, k) for s in 1:nsig]` a caller of the reference writes, spread over ranks.
+"""Multi-GPU drivers: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+Two shardings, neither of which exists in the reference (it has no distributed code):
+
+* SIGNALS sharded, dictionary replicated (BASELINE configs[3]): the loop
+  `[omp(A, B[:, s], eps, k) for s in 1:nsig]` a caller of the reference writes, spread over ranks.  Signal s
+  is owned by the rank whose contiguous block holds it, NO communication during the solves and ONE
+  all_gather of the packed results at the end (`omp_sharded`, `sharded_solve`, `fr_sharded`).  The wire layout
+  -- per signal a row of 2k+1 Float64 [idx | val | nnz] -- is the C ABI's (`csmp_pack_results`).
+
+* COLUMNS sharded, one signal: `omp_colsharded` -- every rank sweeps its slice
+  of the dictionary, ONE all_gather of a 16-KiB record per rank and step carries (|c|, global index, the
+  column itself), and every rank appends the winner to its replica of the factorisation
+  (csrc/csmp_shard.hpp).  Results are identical to `omp(A, b, eps, k)` on the whole dictionary
+  (src/matchingpursuit.jl:73-82), ties across shards going to the lower global index.
 """
 import numpy as np
 
 
 def shard_range(nsig, rank, world):
-    """Contiguous block of signals owned by `rank`: sizes differ by at most one."""
+    """Contiguous block of signals owned by `rank`: sizes differ by at most one (= csmp_shard_range)."""
     base, extra = divmod(int(nsig), int(world))
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
@@ -32,34 +42,77 @@ def unpack(buf, k):
     return idx, val, nnz
 
 
-def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None):
+# ---------------------------------------------------------------------------------- the one exchange, on tensors
+def pack_t(idx, val, nnz):
+    """torch tensors idx (n, k) int64, val (n, k) float64, nnz (n,) int64 (device or CPU) -> (n, 2k+1) float64,
+    the same rows as `pack` / csmp_pack_results.  Stays on the tensors' device: no host round trip."""
+    import torch
+    return torch.cat([idx.to(torch.float64), val, nnz[:, None].to(torch.float64)], dim=1).contiguous()
+
+
+def gather_packed(packed, nsig, group=None):
+    """ONE all_gather of every rank's packed block (padded to the largest block, ceil(nsig / world) rows);
+    returns the (nsig, 2k+1) tensor of all signals in global order, on `packed`'s device."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    maxn = -(-int(nsig) // world)
+    mine = packed
+    if packed.shape[0] != maxn:
+        mine = torch.zeros((maxn, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        mine[:packed.shape[0]] = packed
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)  # the single collective of the path
+    parts = []
+    for r in range(world):
+        rlo, rhi = shard_range(nsig, r, world)
+        parts.append(out[r][:rhi - rlo])
+    return torch.cat(parts, dim=0)
+
+
+def unpack_t(full, k):
+    """(nsig, 2k+1) float64 tensor -> numpy (idx k x nsig, val k x nsig, nnz) like the batch drivers return."""
+    return unpack(full.cpu().numpy(), k)
+
+
+def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None, method="exact"):
     """Solve omp for every column of B (M x nsig, identical on all ranks) with the ranks of the
     default (or given) process group; every rank returns the full (idx, val, nnz) arrays.
 
-    `solver(B_local, k, eps) -> (idx, val, nnz)` defaults to the HIP path `D.ctx.omp_batch`;
-    the gloo CPU tests inject a stand-in there to exercise the sharding/gather logic only."""
+    method: "exact" = csmp_omp_batch (single-signal sweeps, three signals pipelined), "mfma" = csmp_omp_batch_mfma
+    (the batched variant BASELINE configs[3] names: bf16 MFMA screening GEMM + Float64 rescoring; same results).
+    With the "nccl" backend the local results stay on the GPU: they are packed there and gathered by RCCL straight
+    from device memory.  `solver(B_local, k, eps) -> (idx, val, nnz)` replaces the HIP path; the gloo CPU tests
+    inject a stand-in there to exercise the sharding/gather logic only."""
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     nsig = B.shape[1]
     lo, hi = shard_range(nsig, rank, world)
-    if solver is None:
-        eps = D.eps if eps is None else eps
-        solver = D.ctx.omp_batch
-    idx, val, nnz = solver(np.asfortranarray(B[:, lo:hi]), k, eps)
-    maxn = -(-nsig // world)
-    mine = np.zeros((maxn, 2 * k + 1), np.float64)
-    mine[:hi - lo] = pack(idx, val, nnz)
     backend = dist.get_backend(group)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
-    t = torch.from_numpy(mine).to(dev)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t, group=group)  # the single collective of the path
-    bufs = []
-    for r in range(world):
-        rlo, rhi = shard_range(nsig, r, world)
-        bufs.append(out[r][:rhi - rlo].cpu().numpy())
-    return unpack(np.concatenate(bufs, axis=0), k)
+    if method not in ("exact", "mfma"):
+        raise ValueError('omp_sharded: method must be "exact" or "mfma"')
+    if solver is None and dev.type == "cuda":
+        # device-resident path: signals uploaded once, results packed on the GPU, RCCL gathers device buffers
+        eps = D.eps if eps is None else eps
+        Bl = torch.from_numpy(np.ascontiguousarray(np.asarray(B)[:, lo:hi].T)).to(dev)  # (n, M): rows = signals
+        n = hi - lo
+        idx = torch.full((n, k), -1, dtype=torch.int64, device=dev)
+        val = torch.zeros((n, k), dtype=torch.float64, device=dev)
+        nnz = torch.zeros(n, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        if n:
+            (D.ctx.omp_batch_mfma_device if method == "mfma" else D.ctx.omp_batch_device)(Bl, k, eps, idx, val, nnz)
+        D.ctx.sync()
+        packed = pack_t(idx, val, nnz)
+    else:
+        if solver is None:
+            eps = D.eps if eps is None else eps
+            solver = D.ctx.omp_batch_mfma if method == "mfma" else D.ctx.omp_batch
+        idx, val, nnz = solver(np.asfortranarray(B[:, lo:hi]), k, eps)
+        packed = torch.from_numpy(pack(idx, val, nnz)).to(dev)
+    return unpack_t(gather_packed(packed, nsig, group), k)
 
 
 def sharded_solve(B, cap, one, group=None, device=None):
@@ -82,3 +135,93 @@ def sharded_solve(B, cap, one, group=None, device=None):
 def fr_sharded(D, B, k, max_eps=0.0, min_delta=0.0, group=None):
     """fr (forward regression / OLS) for every column of B, signals sharded over the ranks."""
     return sharded_solve(B, k, lambda b: D.ctx.fr(b, k, max_eps, min_delta), group=group)
+
+
+# ---------------------------------------------------------------------------------- one signal, columns sharded
+def column_range(N, rank, world):
+    """Contiguous block of dictionary columns held by `rank` (sizes differ by at most one)."""
+    return shard_range(N, rank, world)
+
+
+class HipColumnShard:
+    """One rank's side of the column-sharded solve on the GPU: a Context holding columns
+    [col_offset, col_offset + N_local) of the dictionary (csmp_shard_* of include/csmp.h)."""
+
+    def __init__(self, ctx, col_offset, device=None):
+        import torch
+        self.ctx = ctx
+        self.dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        ctx.shard_config(col_offset)
+        self.record_bytes = ctx.shard_record_bytes()
+        self._rec = torch.zeros(self.record_bytes, dtype=torch.uint8, device=self.dev)
+
+    def use_stream(self, handle):
+        """Run this shard's kernels on the given hipStream_t (None: the library's own stream again)."""
+        self.ctx.set_stream(handle)
+
+    def begin(self, b, k):
+        from . import _lib
+        self.k = int(k)
+        self.ctx.solver_begin(_lib.ALGO_OMP, b, max(int(k), 1))
+
+    def sweep(self, eps, check_eps):
+        self.ctx.shard_sweep(eps, check_eps, self._rec)
+        return self._rec
+
+    def append(self, recs, nrec):
+        self.ctx.shard_append(recs, nrec)
+
+    def state(self):
+        idx, val, res, order, stop = self.ctx.solver_state(max(self.k, 1))
+        return idx, val, order
+
+
+def omp_colsharded(shards, b, k, eps, group=None):
+    """omp(A, b, eps, k) (src/matchingpursuit.jl:73-82) with the dictionary's columns sharded.
+
+    `shards`: ONE shard object (this process is a rank of `group`: one all_gather of one record per rank and
+    step) or a LIST of shard objects living in this process ("virtual ranks", e.g. two contexts on one GPU: the
+    records are concatenated instead of gathered).  A shard offers begin / sweep / append / state
+    (`HipColumnShard`; the gloo CPU test supplies a numpy one).  Returns (idx sorted, val, selection order)."""
+    import torch
+    virtual = isinstance(shards, (list, tuple))
+    mine = list(shards) if virtual else [shards]
+    if not virtual:
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+    # On the GPU the sweeps, the record exchange and the appends are ordered by ONE stream: the library's kernels are
+    # enqueued on the torch stream the collective (or the concatenation) runs on; the host never waits inside the loop.
+    gpu = all(hasattr(sh, "use_stream") for sh in mine)
+    stream = torch.cuda.Stream(mine[0].dev) if gpu else None
+    if gpu:
+        for sh in mine:
+            sh.use_stream(stream.cuda_stream)
+    try:
+        ctxmgr = torch.cuda.stream(stream) if gpu else _Null()
+        with ctxmgr:
+            for sh in mine:
+                sh.begin(b, k)
+            for t in range(int(k)):
+                recs = [sh.sweep(float(eps), t > 0) for sh in mine]
+                if virtual:
+                    allrec, nrec = torch.cat([r.reshape(-1) for r in recs]), len(mine)
+                else:
+                    allrec = torch.empty(world * recs[0].numel(), dtype=recs[0].dtype, device=recs[0].device)
+                    dist.all_gather_into_tensor(allrec, recs[0].reshape(-1), group=group)  # the ONE collective of a step
+                    nrec = world
+                for sh in mine:
+                    sh.append(allrec, nrec)
+            out = mine[0].state()
+    finally:
+        if gpu:
+            for sh in mine:
+                sh.use_stream(None)
+    return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

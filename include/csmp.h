@@ -71,6 +71,11 @@ int csmp_device_info(csmp_ctx *ctx, char *name, int name_len, int *compute_units
  * src/twostage.jl:42-61).  Uploaded once, stays resident in HBM.  A CSMP_DEVICE pointer that is
  * 16-byte aligned with M and ldA multiples of 16 bytes is borrowed without a copy. */
 int csmp_set_dictionary(csmp_ctx *ctx, const void *A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc);
+/* A second context on the same GPU that borrows (does not copy) src's resident dictionary: the reference's P
+ * objects are independent of one another and share only A -- P1 = OMP(A, b1); P2 = OMP(A, b2)
+ * (src/matchingpursuit.jl:44-60) -- so every step-level solver (csmp_solver_begin) that must live beside
+ * another one gets a clone.  src must outlive the clone and keep its dictionary. */
+int csmp_clone(csmp_ctx *src, csmp_ctx **out);
 
 /* ------------------------------------------------------------------ drivers (synchronous)
  * b: length M, element type b_dtype, host memory.  idx/val/order: caller arrays of capacity
@@ -184,6 +189,32 @@ int csmp_solver_remove(csmp_ctx *ctx, int64_t atom);
 /* current x (sorted), ||b - A x||_2, selection order, stop reason.  Any pointer may be NULL. */
 int csmp_solver_state(csmp_ctx *ctx, int64_t *idx, double *val, int64_t *nnz, double *resnorm,
                       int64_t *order, int *stop);
+
+/* ------------------------------------------------------------------ one signal, columns sharded over GPUs
+ * SURVEY.md section 8e/8f-4 (not in the reference: its omp takes one b and one A, src/matchingpursuit.jl:73-82).
+ * Each rank's ctx holds columns [col_offset, col_offset + N) of the global dictionary and a full replica of
+ * the solver state.  A solve: csmp_solver_begin(ctx, CSMP_ALGO_OMP, b, ...) on every rank; then k times
+ *     csmp_shard_sweep (argmaxinner!(P), :181-185, over the local columns; t > 0: the driver's residual test :79)
+ *     -> the caller's all_gather of ONE record per rank (csmp_shard_record_bytes each, device memory)
+ *     -> csmp_shard_append (global arg-max, ties to the lower global index; update!'s guards :63,66;
+ *        add_column! and the residual update on the winner's column, which travels inside its record);
+ * then csmp_solver_state (indices are global; identical on every rank).  Nothing synchronises with the host
+ * between those calls: with csmp_set_stream they are stream-ordered with the collective. */
+int csmp_shard_config(csmp_ctx *ctx, int64_t col_offset);
+int64_t csmp_shard_record_bytes(const csmp_ctx *ctx);
+int csmp_shard_sweep(csmp_ctx *ctx, double eps, int check_eps, void *rec_dev);
+int csmp_shard_append(csmp_ctx *ctx, const void *recs_dev, int nrec);
+
+/* ------------------------------------------------------------------ many signals sharded over GPUs (host helpers)
+ * signals are independent given A, so rank r solves the contiguous block
+ * [lo, hi) = csmp_shard_range(nsig, r, world) with csmp_omp_batch / csmp_omp_batch_mfma on its own GPU (A
+ * replicated) and ONE exchange moves the results: per signal a row of 2k + 1 Float64
+ * [idx_0..idx_{k-1} | val_0..val_{k-1} | nnz] (csmp_pack_results), gathered by the host's collective
+ * (torch.distributed all_gather over RCCL; MPI.Allgather! from Julia -- INTEGRATION.md) and split again by
+ * csmp_unpack_results.  Host memory, no ctx: these fix the wire layout for every host language. */
+int csmp_shard_range(int64_t nsig, int rank, int world, int64_t *lo, int64_t *hi);
+int csmp_pack_results(const int64_t *idx, const double *val, const int64_t *nnz, int64_t k, int64_t nsig, double *packed);
+int csmp_unpack_results(const double *packed, int64_t k, int64_t nsig, int64_t *idx, double *val, int64_t *nnz);
 
 /* ------------------------------------------------------------------ primitives
  * argmaxinner!(P) / argmaxinner!(P,k): src/matchingpursuit.jl:181-193.  r: length-M Float64

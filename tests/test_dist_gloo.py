@@ -98,3 +98,144 @@ def test_sharded_solve_generic_gloo_world2(oracle):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------ round 2
+def _spawn2(target, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port) + tuple(args) + (q,)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    return res
+
+
+def _worker_bench_exchange(rank, world, port, n, k, q):
+    """bench.py's OWN pack -> all_gather -> unpack path (bench.exchange_results), under gloo on CPU tensors, with the C
+    oracle standing in for the per-rank HIP solver."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from csmp_pkg import load
+    from oracle import oracle_c
+    import bench
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    A, x, b = cs.sparse_data(n=40, m=120, k=k, rng=3)
+
+    def signals(r):  # weak scaling: every rank makes its own n signals, seeded by rank like bench.make_signals
+        rng = np.random.default_rng(1000 + r)
+        return [cs.perturb(A @ cs.sparse_vector(120, k, rng=rng).to_dense(), 5e-3, rng=rng) for _ in range(n)]
+
+    def solve(sigs):
+        idx = -np.ones((n, k), np.int64)
+        val = np.zeros((n, k))
+        nnz = np.zeros(n, np.int64)
+        for s, y in enumerate(sigs):
+            i, v, _ = oracle_c.omp(A, y, k, 0.02, nthreads=1)  # a residual stop: nnz differs between signals
+            idx[s, :len(i)], val[s, :len(i)], nnz[s] = i, v, len(i)
+        return idx, val, nnz
+    idx, val, nnz = solve(signals(rank))
+    full = bench.exchange_results(torch.from_numpy(idx), torch.from_numpy(val), torch.from_numpy(nnz))
+    ok = tuple(full.shape) == (world * n, 2 * k + 1) and full.dtype == torch.float64
+    gi, gv, gn = cs.unpack_t(full, k)  # (k x world*n) like the batch drivers
+    for r in range(world):
+        ri, rv, rn = solve(signals(r))
+        sl = slice(r * n, (r + 1) * n)
+        ok &= np.array_equal(gi[:, sl].T, ri) and np.array_equal(gv[:, sl].T, rv) and np.array_equal(gn[sl], rn)
+    # the C ABI's host helpers speak the same wire layout
+    ok &= np.array_equal(cs._lib.pack_results(idx, val, nnz), cs.pack_t(torch.from_numpy(idx), torch.from_numpy(val), torch.from_numpy(nnz)).numpy())
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bench_exchange_path_gloo_world2(oracle):
+    assert _spawn2(_worker_bench_exchange, (3, 5)) == [(0, True), (1, True)]
+
+
+class _NumpyColumnShard:
+    """CPU stand-in for HipColumnShard (same protocol, same record layout as csrc/csmp_shard.hpp): numpy sweeps over
+    this rank's columns, least squares from scratch after every append."""
+
+    def __init__(self, A_local, offset):
+        self.A, self.off = np.asarray(A_local, dtype=np.float64), int(offset)
+        self.M = self.A.shape[0]
+        self.rec_bytes = (32 + 8 * self.M + 15) // 16 * 16
+
+    def begin(self, b, k):
+        self.b = np.asarray(b, dtype=np.float64)
+        self.r = self.b.copy()
+        self.cols, self.labels, self.done = [], [], False
+
+    def sweep(self, eps, check_eps):
+        import torch
+        rec = np.zeros(self.rec_bytes, np.uint8)
+        hd = rec[:32].view(np.float64)
+        lab = rec[8:16].view(np.int64)
+        if check_eps and not (np.linalg.norm(self.r) >= eps):
+            self.done = True
+        if self.done:
+            hd[0], lab[0] = -1.0, -1
+        else:
+            c = self.A.T @ self.r
+            j = int(np.argmax(np.abs(c)))  # first maximum
+            hd[0], lab[0], hd[2] = abs(c[j]), self.off + j, c[j]
+            rec[32:32 + 8 * self.M].view(np.float64)[:] = self.A[:, j]
+        return torch.from_numpy(rec)
+
+    def append(self, allrec, nrec):
+        raw = allrec.numpy()
+        best = None
+        for q in range(nrec):
+            r = raw[q * self.rec_bytes:(q + 1) * self.rec_bytes]
+            av, lab = float(r[:8].view(np.float64)[0]), int(r[8:16].view(np.int64)[0])
+            if lab >= 0 and (best is None or av > best[0] or (av == best[0] and lab < best[1])):
+                best = (av, lab, r[32:32 + 8 * self.M].view(np.float64).copy())
+        if self.done or best is None or best[1] in self.labels:
+            self.done = True  # eps stop / nothing offered / 'i not in x.nzind' (src/matchingpursuit.jl:66)
+            return
+        self.labels.append(best[1])
+        self.cols.append(best[2])
+        AS = np.stack(self.cols, axis=1)
+        self.x = np.linalg.lstsq(AS, self.b, rcond=None)[0]
+        self.r = self.b - AS @ self.x
+
+    def state(self):
+        order = np.asarray(self.labels, np.int64)
+        p = np.argsort(order)
+        return order[p], np.asarray(self.x)[p], order
+
+
+def _worker_colsharded(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from csmp_pkg import load
+    from oracle import oracle_c
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ok = True
+    for seed, n, m, k, eps in [(1, 48, 161, 6, 0.0), (2, 64, 200, 5, 1e-9)]:
+        A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=seed)
+        A = A.copy()
+        j0 = int(x.nzind[0])
+        lo0, hi0 = cs.column_range(m, 0, world)
+        dup = (hi0 + 3) if j0 < hi0 else 2  # the same atom in the OTHER shard: the tie must go to the lower global index
+        if dup not in x.nzind:
+            A[:, dup] = A[:, j0]
+        y = A @ x.to_dense() if eps > 0 else cs.perturb(A @ x.to_dense(), 5e-3, rng=seed + 10)
+        lo, hi = cs.column_range(m, rank, world)
+        got = cs.omp_colsharded(_NumpyColumnShard(A[:, lo:hi], lo), y, k + (3 if eps > 0 else 0), eps)
+        ref = oracle_c.omp(A, y, k + (3 if eps > 0 else 0), eps, nthreads=1)
+        ok &= np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0]) and np.allclose(got[1], ref[1], rtol=1e-9, atol=1e-12)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_column_sharded_omp_gloo_world2(oracle):
+    """SURVEY section 8f-4 on CPU: the per-step record exchange (one all_gather), the cross-shard arg-max with its
+    lower-global-index tie rule and the replicated append, driven by sharded.omp_colsharded under gloo."""
+    assert _spawn2(_worker_colsharded, ()) == [(0, True), (1, True)]

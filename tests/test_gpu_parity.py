@@ -1040,3 +1040,202 @@ def test_fr_batch_matches_single_signal_calls(cs, oracle, D, cfg):
             assert np.all(idx[nnz[s_]:, s_] == -1)
     xs = cs.fr_batch(d, B, k)
     assert len(xs) == nsig and np.array_equal(xs[0].nzind, oracle.fr(A, B[:, 0], k)[0])
+
+
+# ------------------------------------------------------------------------------------------ round 2
+def test_full_size_config3_batched(cs, oracle):
+    """BASELINE configs[2] at its real workload: 1024 signals sharing A 4096 x 65536 f32, k = 128, through
+    csmp_omp_batch_mfma.  (i) oracle comparison on a sample: 8 signals x their first 16 atoms (OMP is greedy, so a
+    k = 16 solve IS the first 16 steps): supports exact, coefficients 1e-6; (ii) every one of the 1024 supports and
+    nnz equal to the exact single-signal path csmp_omp_batch, coefficients to 1e-9; (iii) the batch statistics."""
+    import torch
+    M, N, k, nsig = 4096, 65536, 128, 1024
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(0xC0FFEE)
+    At = torch.empty((N, M), dtype=torch.float32, device=dev)
+    for lo in range(0, N, 8192):  # src/util.jl:21-27 recipe, cast once to Float32
+        a = torch.randn((8192, M), generator=g, device=dev, dtype=torch.float64)
+        a -= 1e-6 * a.mean(dim=1, keepdim=True)
+        a /= a.norm(dim=1, keepdim=True)
+        At[lo:lo + 8192] = a.to(torch.float32)
+    d = cs.Dictionary(At)
+    g2 = torch.Generator(device=dev).manual_seed(4242)
+    B = torch.empty((nsig, M), dtype=torch.float64, device=dev)
+    for lo in range(0, nsig, 64):  # planted +-1 k-sparse x0 + noise ||e|| = 5e-3 (src/util.jl:13-19,50-55)
+        sel = torch.stack([torch.randperm(N, generator=g2, device=dev)[:k] for _ in range(64)])
+        sign = torch.randint(0, 2, (64, k), generator=g2, device=dev).to(torch.float64) * 2 - 1
+        b = torch.einsum("skm,sk->sm", At[sel].to(torch.float64), sign)
+        e = torch.randn((64, M), generator=g2, device=dev, dtype=torch.float64)
+        B[lo:lo + 64] = b + e * (5e-3 / e.norm(dim=1, keepdim=True))
+    torch.cuda.synchronize()
+
+    def run(fn, Bm, kk):
+        n = Bm.shape[0]
+        idx = torch.full((n, kk), -1, dtype=torch.int64, device=dev)
+        val = torch.zeros((n, kk), dtype=torch.float64, device=dev)
+        nnz = torch.zeros(n, dtype=torch.int64, device=dev)
+        fn(Bm, kk, EPS32, idx, val, nnz)
+        d.ctx.sync()
+        return idx.cpu().numpy(), val.cpu().numpy(), nnz.cpu().numpy()
+
+    # (i) oracle sample
+    A = np.asfortranarray(At.cpu().numpy().T)
+    sample = [0, 1, 127, 128, 511, 512, 777, 1023]
+    i16, v16, n16 = run(d.ctx.omp_batch_mfma_device, B[sample].contiguous(), 16)
+    for row, sgn in enumerate(sample):
+        ref = oracle.omp(A, B[sgn].cpu().numpy(), 16, EPS32)
+        assert n16[row] == len(ref[0]) == 16
+        assert np.array_equal(i16[row, :16], ref[0]), (sgn, i16[row], ref[0])
+        assert close(v16[row, :16], ref[1], tight=False), sgn
+    # (ii) the whole batch against the exact path
+    idx, val, nnz = run(d.ctx.omp_batch_mfma_device, B, k)
+    st = d.ctx.batch_stats()
+    print("C3 batch_stats:", st)
+    i2, v2, n2 = run(d.ctx.omp_batch_device, B, k)
+    assert np.array_equal(nnz, n2) and np.all(nnz == k)
+    assert np.array_equal(idx, i2)
+    assert np.allclose(val, v2, rtol=1e-9, atol=1e-12)
+    # (iii) statistics: every signal accounted for, nothing ill-conditioned on a Gaussian dictionary, and the
+    # certificate sends at most a handful of signals to the exact path
+    assert st["signals"] == nsig and st["illcond"] == 0
+    assert st["resolved_exactly"] == st["uncertain"] and st["uncertain"] <= 8, st
+    d.close()
+
+
+def test_step_level_mp_functor(cs, oracle, D):
+    """MP(A, b) + update!(P, x) (src/matchingpursuit.jl:19-31) with the functor's DEFAULT capacity, at M = 4096: every
+    step adds <a_i, r> to x[i] for the arg-max atom; the running x equals the oracle's mp after the same number of steps."""
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((4096, 6000)).astype(np.float32)
+    A /= np.linalg.norm(A.astype(np.float64), axis=0).astype(np.float32)
+    xs = cs.sparse_vector(6000, 6, rng=6)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=7)
+    d = D(A)
+    P = cs.MP(d, y)  # default steps = 4096: needs no factorisation (and no LDS for one)
+    x = cs.spzeros(6000)
+    for t in range(1, 10):
+        P(x)
+        ref = oracle.mp(A, y, t)
+        assert np.array_equal(x.nzind, ref[0]), (t, x.nzind, ref[0])
+        assert np.allclose(x.nzval, ref[1], rtol=1e-6, atol=1e-12)
+    P.close()
+
+
+def test_functors_on_one_dictionary_are_independent(cs, oracle, D):
+    """P1 = OMP(A, b1); P2 = OMP(A, b2) share A and nothing else (src/matchingpursuit.jl:44-60): interleaved updates, and a
+    driver call on the same Dictionary in between, leave each object's factorisation alone."""
+    A, x, b = cs.sparse_data(n=96, m=384, k=5, rng=31)
+    y1 = cs.perturb(b, 5e-3, rng=32)
+    y2 = cs.perturb(A @ cs.sparse_vector(384, 5, rng=33).to_dense(), 5e-3, rng=34)
+    d = D(A)
+    P1, P2 = cs.OMP(d, y1, 5), cs.OMP(d, y2, 5)
+    x1, x2 = cs.spzeros(384), cs.spzeros(384)
+    for t in range(5):
+        P1(x1)
+        if t == 2:
+            cs.omp(d, y2, 3)  # a driver call on the shared Dictionary
+            cs.sp(d, y1, 4)
+        P2(x2)
+    r1, r2 = oracle.omp(A, y1, 5, 0.0), oracle.omp(A, y2, 5, 0.0)
+    assert np.array_equal(x1.nzind, r1[0]) and close(x1.nzval, r1[1])
+    assert np.array_equal(x2.nzind, r2[0]) and close(x2.nzval, r2[1])
+    P1.close()
+    P2.close()
+
+
+def test_reference_default_capacities_at_m4096(cs, oracle, D):
+    """The reference's defaults size the QR by size(A,1): omp(A, b, eps) (k = M, src/matchingpursuit.jl:73), OMP(A, b)
+    (:54) and GOMP(A, b, l) (:108) must work at the headline M = 4096 -- the append kernels' LDS follows the support
+    actually built, not the capacity."""
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((4096, 5000)).astype(np.float32)
+    A /= np.linalg.norm(A.astype(np.float64), axis=0).astype(np.float32)
+    xs = cs.sparse_vector(5000, 5, rng=12)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 1e-3, rng=13)
+    d = D(A)
+    got = cs.omp(d, y, 2e-3)  # k = size(A,1) = 4096; the residual test stops it
+    ref = oracle.omp(A, y, 4096, 2e-3)
+    assert np.array_equal(got.nzind, ref[0]) and close(got.nzval, ref[1]) and got.nnz == 5
+    P = cs.OMP(d, y)
+    xv = cs.spzeros(5000)
+    for _ in range(5):
+        P(xv)
+    assert np.array_equal(xv.nzind, xs.nzind)
+    P.close()
+    G = cs.GOMP(d, y, 2)
+    xg = cs.spzeros(5000)
+    G(xg)
+    assert xg.nnz == 2
+    G.close()
+
+
+def test_capacity_growth_does_not_disable_the_removal_solvers(cs, oracle, D):
+    """A call that grows the solver slot past 1023 columns (sp with 2k = 1024) must not make every later
+    srr / ompr / rmp / foba / solver_remove on the same Dictionary fail: the slot is rebuilt at the size they need."""
+    A, x, b = cs.sparse_data(n=1100, m=3000, k=6, rng=41, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=42)
+    d = D(A)
+    big = cs.sp(d, y, 512)  # capacity 1024
+    assert big.nnz == 512
+    for name, call, ref in [("srr", lambda: cs.srr(d, y, 6), lambda: oracle.srr(A, y, 6)),
+                            ("ompr", lambda: cs.ompr(d, y, 6, 1e-6), lambda: oracle.ompr(A, y, 6, 1e-6)),
+                            ("rmp", lambda: cs.rmp(d, y, 6, kmax=40), None)]:
+        got = call()
+        if ref is not None:
+            r = ref()
+            assert np.array_equal(got.nzind, r[0]), name
+            assert close(got.nzval, r[1], tight=False), name
+        else:
+            assert got.nnz == 6, name
+
+
+def _colsharded(cs, A, y, k, eps, cuts):
+    """omp_colsharded over virtual ranks: one context per column block [cuts[i], cuts[i+1])."""
+    import torch
+    ctxs, shards = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        c = cs.Context(0)
+        c.set_dictionary(np.asfortranarray(A[:, lo:hi]))
+        ctxs.append(c)
+        shards.append(cs.HipColumnShard(c, lo, torch.device("cuda", 0)))
+    try:
+        return cs.omp_colsharded(shards, y, k, eps)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+@pytest.mark.parametrize("cfg", [(256, 1024, 24, np.float32, (0, 512, 1024)), (130, 701, 12, np.float64, (0, 233, 467, 701)),
+                                 (4096, 3000, 20, np.float32, (0, 1000, 3000))])
+def test_column_sharded_omp_equals_omp(cs, oracle, D, cfg):
+    """one signal, columns sharded over (virtual) ranks -- per step every rank sweeps its slice, one
+    record per rank is exchanged, every rank appends the winner.  Selection order, support and coefficients must be
+    those of csmp_omp on the whole dictionary (bitwise: the same kernels see the same numbers) and of the oracle."""
+    n, m, k, dtype, cuts = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dtype)
+    y = cs.perturb(b, 5e-3, rng=3)
+    eps = float(np.finfo(dtype).eps)
+    idx, val, order = _colsharded(cs, A, y, k, eps, cuts)
+    d = D(A)
+    full = d.ctx.omp(y, k, eps)
+    assert np.array_equal(order, full[2]) and np.array_equal(idx, full[0]) and np.array_equal(val, full[1])
+    ref = oracle.omp(A, y, k, eps)
+    assert np.array_equal(order, ref[2]) and np.array_equal(idx, ref[0]) and close(val, ref[1])
+
+
+def test_column_sharded_omp_ties_and_stops(cs, oracle):
+    """Ties across shards go to the LOWER global index (Julia argmax over the whole dictionary, src/matchingpursuit.jl:184):
+    one planted atom exists in both shards.  The driver's residual test (:79) stops every rank at the same step."""
+    A, x, b = cs.sparse_data(n=64, m=200, k=4, rng=9)
+    A = A.copy()
+    j0 = int(x.nzind[0])
+    dup = 150 if j0 < 100 else 20
+    assert dup not in x.nzind
+    A[:, dup] = A[:, j0]  # the same atom in the other shard
+    y = A @ x.to_dense()
+    for k, eps in [(4, 0.0), (8, 1e-9)]:
+        got = _colsharded(cs, A, y, k, eps, (0, 100, 200))
+        ref = oracle.omp(A, y, k, eps)
+        assert np.array_equal(got[2], ref[2]), (got[2], ref[2])
+        assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+        assert max(j0, dup) not in got[0] and min(j0, dup) in got[0]

@@ -67,3 +67,26 @@ def test_shard_range_partitions(cs):
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_signal_sharding_wire_layout_helpers(cs):
+    """csmp_shard_range / csmp_pack_results / csmp_unpack_results (host helpers of the C ABI, no GPU involved) agree with
+    the Python mirror's shard_range / pack / unpack: any host language shards and gathers the same way."""
+    L = cs._lib
+    for nsig, world in [(8192, 8), (5, 2), (7, 3), (3, 8), (0, 4)]:
+        blocks = [L.shard_range(nsig, r, world) for r in range(world)]
+        assert blocks == [cs.shard_range(nsig, r, world) for r in range(world)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == nsig and all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
+        assert max(h - l for l, h in blocks) - min(h - l for l, h in blocks) <= 1
+    rng = np.random.default_rng(0)
+    k, n = 6, 11
+    idx = rng.integers(0, 1 << 40, size=(n, k)).astype(np.int64)
+    val = rng.standard_normal((n, k))
+    nnz = rng.integers(0, k + 1, size=n).astype(np.int64)
+    packed = L.pack_results(idx, val, nnz)
+    assert packed.shape == (n, 2 * k + 1)
+    from csmp_pkg import load
+    sh = load().sharded
+    assert np.array_equal(packed, sh.pack(idx.T, val.T, nnz))
+    i2, v2, n2 = L.unpack_results(packed, k)
+    assert np.array_equal(i2, idx) and np.array_equal(v2, val) and np.array_equal(n2, nnz)
