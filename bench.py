@@ -226,8 +226,10 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
     tmax, atoms = tmax.item(), atoms.item()
     if rank != 0:
         return None
-    flops = 2.0 * M * N * nsig  # per screening GEMM = per OMP step of the batch
-    tf = flops / (screen_ms / max(screen_n, 1) / 1e3) / 1e12 if screen_n else 0.0
+    flops = 2.0 * M * N * nsig  # per OMP step of the batch
+    lay = D.ctx.batch_layout()  # the batch runs as two half-batches on two streams: a timed screening launch covers one half
+    flops_launch = 2.0 * M * N * lay["screen_signals"]
+    tf = flops_launch / (screen_ms / max(screen_n, 1) / 1e3) / 1e12 if screen_n else 0.0
     ms_per_omp_step = tmax / K / k * 1e3
     # parity spot check against the exact single-signal path (first 4 signals of the first timed batch)
     i2 = torch.full((4, k), -1, dtype=torch.int64, device=dev)
@@ -246,7 +248,8 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
                    "signals_per_gpu_per_step": nsig, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
         "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TF, "traffic": None,
                      "kernel": D.ctx.batch_screen_kernel(),
-                     "launches_timed": int(screen_n), "flops_per_launch": flops,
+                     "launches_timed": int(screen_n), "flops_per_launch": flops_launch, "avg_launch_us": screen_ms / max(screen_n, 1) * 1e3,
+                     "signals_per_launch": lay["screen_signals"], "streams": lay["streams"],
                      # the whole OMP step of the batch (screen + rescoring/append of every signal) against the same ceiling
                      "whole_step": {"ms_per_omp_step": ms_per_omp_step, "achieved": flops / (ms_per_omp_step / 1e3) / 1e12,
                                     "frac": flops / (ms_per_omp_step / 1e3) / 1e12 / MFMA_PEAK_TF}},

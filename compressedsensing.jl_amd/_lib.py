@@ -55,6 +55,7 @@ SIGNATURES = {
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
+    "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(C.c_double)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
@@ -396,6 +397,11 @@ class Context:
 
     def batch_screen_kernel(self):
         return lib().csmp_batch_screen_kernel(self._h).decode()
+
+    def batch_layout(self):
+        n, st = i64(0), C.c_int(0)
+        self.call("csmp_batch_layout", C.byref(n), C.byref(st))
+        return {"screen_signals": n.value, "streams": st.value}
 
     def batch_stats(self):
         v = [i64(0) for _ in range(5)]

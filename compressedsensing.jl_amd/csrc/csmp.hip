@@ -83,12 +83,16 @@ struct Batch {
     int* cand_idx = nullptr;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
     bool last_big = false;  // the last batch used the 256^2 screening kernel
+    int64_t last_screen_signals = 0;  // signal columns of one (timed) screening launch of the last batch
+    int last_streams = 1;
 };
 
 struct csmp_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
+    hipStream_t stream2 = nullptr;  // second stream of the batched path (half-batches alternate between screen and step)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop{};
     std::string err;
     // dictionary
@@ -256,6 +260,9 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
     if (ctx->ownA) dfree(ctx->dA);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev2) (void)hipEventDestroy(e);
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return CSMP_OK;
@@ -728,6 +735,21 @@ static int download_result(csmp_ctx* ctx, int outcap, int64_t* idx, double* val,
     return CSMP_OK;
 }
 
+// Every kPollSteps steps of a long single-signal driver loop the host looks at the control block once: a solve that
+// has stopped (residual test, stagnation, full support) is not followed by thousands of no-op launches -- the
+// reference's defaults ask for k = size(A,1) steps (src/matchingpursuit.jl:73,126) -- and the host's bound on the
+// support (jh, which sizes the append kernels' LDS vectors) snaps back to the true column count.
+static constexpr int64_t kPollSteps = 256;
+static int solver_poll(csmp_ctx* ctx, bool* stopped) {
+    Solver& s = ctx->s;
+    DevState hs;
+    HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    s.jh = std::min(s.kcap, hs.nsel);
+    *stopped = hs.done != 0;
+    return CSMP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ tick kernel (3 signals in flight)
 template <typename TA>
 static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, const Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
@@ -844,7 +866,14 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     for (int pass = 0; pass < 2; ++pass) {
         const bool optimistic = pass == 0 && !ctx->force_reorth;
         CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k; ++t) CHECK(omp_step(ctx, eps, t > 0, optimistic));
+        for (int64_t t = 0; t < k; ++t) {
+            CHECK(omp_step(ctx, eps, t > 0, optimistic));
+            if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
+                bool stopped = false;
+                CHECK(solver_poll(ctx, &stopped));
+                if (stopped) break;
+            }
+        }
         CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -1046,7 +1075,14 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     for (int pass = 0; pass < 2; ++pass) {  // optimistic append chain, repeated with re-orthogonalisation if flagged (see csmp_omp)
         const bool optimistic = pass == 0 && !ctx->force_reorth;
         CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k; ++t) CHECK(fr_step(ctx, t == 0, max_eps, min_d2, optimistic));
+        for (int64_t t = 0; t < k; ++t) {
+            CHECK(fr_step(ctx, t == 0, max_eps, min_d2, optimistic));
+            if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
+                bool stopped = false;
+                CHECK(solver_poll(ctx, &stopped));
+                if (stopped) break;
+            }
+        }
         CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -1602,11 +1638,12 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         *resnorm = std::sqrt(n2);
     }
-    if (stop) {
+    {
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        *stop = hs.done;
+        if (stop) *stop = hs.done;
+        if (s.algo != CSMP_ALGO_MP) s.jh = std::min(s.kcap, hs.nsel);  // the host's support bound snaps to the true count
     }
     if (s.algo == CSMP_ALGO_MP) return mp_collect(ctx, nullptr, nullptr, 0, idx, val, nnz);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
@@ -1736,7 +1773,14 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
         const bool block = pass == 0 && !ctx->force_reorth && l <= kPanelMax;
         CHECK(upload_b(ctx, b, b_dtype));
         const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
-        for (int64_t it = 0; it < k / l; ++it) CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));  // :130-133
+        for (int64_t it = 0; it < k / l; ++it) {  // :130-133
+            CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));
+            if ((it + 1) % kPollSteps == 0 && it + 1 < k / l) {
+                bool stopped = false;
+                CHECK(solver_poll(ctx, &stopped));
+                if (stopped) break;  // (the remainder step below still runs, as in the reference)
+            }
+        }
         const int64_t rem = k % l;                                                                             // :134
         if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block));  // :135-137: runs even after an eps-break
         CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
@@ -2545,7 +2589,7 @@ static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
 }
 
 template <typename TA, int NI>
-static hipError_t b_step_launch(csmp_ctx* ctx, int nsig, double eps, int check_eps, double cert_coef) {
+static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef) {
     Batch& b = ctx->bt;
     auto kern = k_b_step<TA, NI>;
     const size_t lds = b_step_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
@@ -2553,19 +2597,19 @@ static hipError_t b_step_launch(csmp_ctx* ctx, int nsig, double eps, int check_e
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
                        (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
-                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef);
+                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0);
     return hipGetLastError();
 }
 
 template <typename TA>
-static hipError_t b_step_dispatch(csmp_ctx* ctx, int nsig, double eps, int check_eps, double cert_coef) {
+static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef) {
     const int groups = (ctx->Mv + 1023) / 1024;
-    if (groups <= 1) return b_step_launch<TA, 1>(ctx, nsig, eps, check_eps, cert_coef);
-    if (groups <= 2) return b_step_launch<TA, 2>(ctx, nsig, eps, check_eps, cert_coef);
-    if (groups <= 4) return b_step_launch<TA, 4>(ctx, nsig, eps, check_eps, cert_coef);
-    return b_step_launch<TA, 8>(ctx, nsig, eps, check_eps, cert_coef);
+    if (groups <= 1) return b_step_launch<TA, 1>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
+    if (groups <= 2) return b_step_launch<TA, 2>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
+    if (groups <= 4) return b_step_launch<TA, 4>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
+    return b_step_launch<TA, 8>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
 }
 
 extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
@@ -2614,20 +2658,52 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     b.last_big = big;
     // screening error bound (8 sigma of the bf16 rounding model): delta = coef * ||r||
     const double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+    // Two half-batches on two streams: the screening GEMM of one half (matrix cores) runs beside the rescoring /
+    // append kernel of the other (HBM gathers).  The halves never touch each other's data; each stream is the plain
+    // chain screen -> step -> screen -> ... of its own signals.  Kernels of the SAME kind cannot share a CU (two
+    // screening workgroups exceed its LDS), so the two chains fall out of phase by themselves.
+    const int tile = 2 * kBT;  // halves are whole 256-signal tiles
+    const bool split = !getenv("CSMP_BATCH_ONE_STREAM") && Bpad >= 2 * tile;
+    const int nh = split ? 2 : 1;
+    int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
+    if (split) {
+        hpad[0] = ((Bpad / 2 + tile - 1) / tile) * tile;
+        hpad[1] = Bpad - hpad[0];
+        h0[1] = hpad[0];
+        hn[0] = (int)std::min<int64_t>(nsig, hpad[0]);
+        hn[1] = (int)(nsig - hn[0]);
+        if (!ctx->stream2) HIPCHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+        if (!ctx->ev_fork) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        if (!ctx->ev_join) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        HIPCHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHECK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    }
+    b.last_streams = nh;
+    b.last_screen_signals = hpad[0];
+    hipStream_t hs_[2] = {ctx->stream, ctx->stream2};
     for (int64_t t = 0; t < k; ++t) {
-        if (ctx->prof) {
-            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        for (int h = 0; h < nh; ++h) {
+            if (hn[h] <= 0) continue;
+            const bool timed = ctx->prof && h == 0;  // (events on the first half's stream: its screening launches)
+            if (timed) {
+                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
+            }
+            HIPCHECK(launch_screen(hs_[h], big, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles,
+                                   hpad[h] / kBT, ctx->N, b.cand_val + (size_t)h0[h] * b.n_atiles * kTileCand,
+                                   b.cand_idx + (size_t)h0[h] * b.n_atiles * kTileCand));
+            if (timed) {
+                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
+            }
+            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef)
+                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef);
+            HIPCHECK(e);
         }
-        HIPCHECK(launch_screen(ctx->stream, big, (const __bf16*)b.Ab, (const __bf16*)b.Rb, b.Mk, b.n_atiles, n_stiles, ctx->N,
-                               b.cand_val, b.cand_idx));
-        if (ctx->prof) {
-            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
-        }
-        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, (int)nsig, eps, t > 0, cert_coef)
-                                              : b_step_dispatch<double>(ctx, (int)nsig, eps, t > 0, cert_coef);
-        HIPCHECK(e);
+    }
+    if (split) {
+        HIPCHECK(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
                        (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);
@@ -2664,6 +2740,14 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
 
 // name of the screening kernel the last csmp_omp_batch_mfma call used (for the bench's roofline line)
 extern "C" const char* csmp_batch_screen_kernel(const csmp_ctx* ctx) { return ctx ? screen_kernel_name(ctx->bt.last_big) : ""; }
+
+// how the last csmp_omp_batch_mfma call was laid out: signal columns per screening launch, streams used
+extern "C" int csmp_batch_layout(const csmp_ctx* ctx, int64_t* screen_signals, int* streams) {
+    if (!ctx) return CSMP_EINVAL;
+    if (screen_signals) *screen_signals = ctx->bt.last_screen_signals;
+    if (streams) *streams = ctx->bt.last_streams;
+    return CSMP_OK;
+}
 
 extern "C" int csmp_batch_stats(csmp_ctx* ctx, int64_t* signals, int64_t* resolved_exactly, int64_t* uncertain, int64_t* illcond,
                                 int64_t* screen_launches, double* screen_ms) {

@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
                                                 double* __restrict__ z_all, int* __restrict__ sel_all,
                                                 BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
                                                 __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
-                                                int check_eps, double cert_coef) {
+                                                int check_eps, double cert_coef, int sig0) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = blockIdx.x + sig0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (sig0: first signal of this half-batch)
     BState& st = bs[s];
     if (st.done) return;
     const int nchunk = (Mv + ROWS - 1) / ROWS;

@@ -172,6 +172,10 @@ int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, 
  * why), and -- when profiling is enabled -- the number and total duration (ms) of screening GEMMs */
 int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly, int64_t *uncertain, int64_t *illcond,
                      int64_t *screen_launches, double *screen_ms);
+/* layout of the last csmp_omp_batch_mfma call (measurement only): signal columns of one timed screening launch
+ * (the batch is split into two half-batches on two HIP streams, so that the screening GEMM of one half runs
+ * beside the rescoring/append kernel of the other) and the number of streams used */
+int csmp_batch_layout(const csmp_ctx *ctx, int64_t *screen_signals, int *streams);
 /* name of the screening kernel the last csmp_omp_batch_mfma call ran (measurement only) */
 const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 
