@@ -82,7 +82,7 @@ struct Batch {
     float* cand_val = nullptr;
     int* cand_idx = nullptr;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
-    bool last_big = false;  // the last batch used the 256^2 screening kernel
+    int last_mode = 0;  // screening kernel of the last batch (kScreen128 / kScreen256 / kScreenCo)
     int64_t last_screen_signals = 0;  // signal columns of one (timed) screening launch of the last batch
     int last_streams = 1;
 };
@@ -2588,28 +2588,42 @@ static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     return CSMP_OK;
 }
 
+// co: the 168-register persistent form (one workgroup per CU), which shares CUs with the screening kernel of the other half-batch
 template <typename TA, int NI>
-static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef) {
+static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef, bool co) {
     Batch& b = ctx->bt;
-    auto kern = k_b_step<TA, NI>;
     const size_t lds = b_step_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
+    if constexpr (NI <= 4) {
+        if (co) {
+            auto kern = k_b_step_co<TA, NI, 2>;
+            if (lds > 64 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e != hipSuccess) return e;
+            }
+            hipLaunchKernelGGL(kern, dim3(std::min(nsig, ctx->prop.multiProcessorCount)), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+                               (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
+                               b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0, nsig);
+            return hipGetLastError();
+        }
+    }
+    auto kern = k_b_step<TA, NI, (NI >= 4 ? 2 : 4)>;  // (loads issued together: 8 columns' worth per lane either way)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
                        (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
-                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0);
+                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0, nsig);
     return hipGetLastError();
 }
 
 template <typename TA>
-static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef) {
+static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef, bool co) {
     const int groups = (ctx->Mv + 1023) / 1024;
-    if (groups <= 1) return b_step_launch<TA, 1>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
-    if (groups <= 2) return b_step_launch<TA, 2>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
-    if (groups <= 4) return b_step_launch<TA, 4>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
-    return b_step_launch<TA, 8>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef);
+    if (groups <= 1) return b_step_launch<TA, 1>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
+    if (groups <= 2) return b_step_launch<TA, 2>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
+    if (groups <= 4) return b_step_launch<TA, 4>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
+    return b_step_launch<TA, 8>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, false);
 }
 
 extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
@@ -2655,7 +2669,6 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     HIPCHECK(hipGetLastError());
     // 256^2 tiles with LDS-DMA staging whenever both edges tile by 256 (knob CSMP_SCREEN_128: the 128^2 kernel)
     const bool big = !getenv("CSMP_SCREEN_128") && (b.n_atiles % 2 == 0) && (n_stiles % 2 == 0);
-    b.last_big = big;
     // screening error bound (8 sigma of the bf16 rounding model): delta = coef * ||r||
     const double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
     // Two half-batches on two streams: the screening GEMM of one half (matrix cores) runs beside the rescoring /
@@ -2665,6 +2678,13 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     const int tile = 2 * kBT;  // halves are whole 256-signal tiles
     const bool split = !getenv("CSMP_BATCH_ONE_STREAM") && Bpad >= 2 * tile;
     const int nh = split ? 2 : 1;
+    // The co-resident kernel pair (k_b_screen256c + k_b_step_co: 168 registers each, < 160 KiB of LDS together, persistent
+    // grids of one workgroup per CU) is what makes the two streams actually overlap: the plain kernels each fill a CU
+    // alone.  It needs 256^2 tiling, at most 4096 rows and the step kernel's LDS below the 32 KiB the screen leaves.
+    const size_t step_lds = b_step_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, b.kcap);
+    const bool co = split && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256 && !getenv("CSMP_BATCH_NO_CO");
+    const int mode = co ? kScreenCo : big ? kScreen256 : kScreen128;
+    b.last_mode = mode;
     int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
     if (split) {
         hpad[0] = ((Bpad / 2 + tile - 1) / tile) * tile;
@@ -2689,15 +2709,15 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
                 if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
                 HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
             }
-            HIPCHECK(launch_screen(hs_[h], big, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles,
+            HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles,
                                    hpad[h] / kBT, ctx->N, b.cand_val + (size_t)h0[h] * b.n_atiles * kTileCand,
-                                   b.cand_idx + (size_t)h0[h] * b.n_atiles * kTileCand));
+                                   b.cand_idx + (size_t)h0[h] * b.n_atiles * kTileCand, ctx->prop.multiProcessorCount));
             if (timed) {
                 if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
                 HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
             }
-            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef)
-                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef);
+            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef, co)
+                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef, co);
             HIPCHECK(e);
         }
     }
@@ -2739,7 +2759,7 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
 }
 
 // name of the screening kernel the last csmp_omp_batch_mfma call used (for the bench's roofline line)
-extern "C" const char* csmp_batch_screen_kernel(const csmp_ctx* ctx) { return ctx ? screen_kernel_name(ctx->bt.last_big) : ""; }
+extern "C" const char* csmp_batch_screen_kernel(const csmp_ctx* ctx) { return ctx ? screen_kernel_name(ctx->bt.last_mode) : ""; }
 
 // how the last csmp_omp_batch_mfma call was laid out: signal columns per screening launch, streams used
 extern "C" int csmp_batch_layout(const csmp_ctx* ctx, int64_t* screen_signals, int* streams) {

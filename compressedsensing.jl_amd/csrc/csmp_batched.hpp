@@ -112,27 +112,28 @@ __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// One OMP step of one signal (one workgroup per signal).  See the file header for the algebra.
-// LDS: a image (Float64, sweep layout) | vectors g,w,y (3 x kcap) | candidate scratch
-template <typename TA, int NI>
-__global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
-                                                const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
-                                                double* __restrict__ z_all, int* __restrict__ sel_all,
-                                                BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
-                                                __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
-                                                int check_eps, double cert_coef, int sig0) {
+// One OMP step of one signal, by one workgroup.  See the file header for the algebra.
+// LDS: vectors g,w,y (3 x kcap Float64) | reduction and candidate scratch | the new atom's column in the
+// dictionary's own type (f32: 16 KiB at M = 4096 -- the whole footprint stays below 32 KiB, which is what lets one
+// of these workgroups share a CU with a 128-KiB screening workgroup of the OTHER half-batch).
+// DEPTH: columns (rescoring, pass 2) / row chunks (pass 1) whose loads are issued together.
+template <typename TA, int NI, int DEPTH>
+__device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
+                                           const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                           int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
+                                           double* __restrict__ z_all, int* __restrict__ sel_all,
+                                           BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
+                                           __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
+                                           int check_eps, double cert_coef, double* lds) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int s = blockIdx.x + sig0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;  // (sig0: first signal of this half-batch)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     BState& st = bs[s];
     if (st.done) return;
     const int nchunk = (Mv + ROWS - 1) / ROWS;
     const int Mlds = nchunk * ROWS;
-    double* aimg = lds;                 // Mlds
-    double* gv = aimg + Mlds;           // kcap
+    double* gv = lds;                   // kcap
     double* wv = gv + kcap;             // kcap
     double* yv = wv + kcap;             // kcap
     double* sc = yv + kcap;             // 8
@@ -141,6 +142,8 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     int* ci = reinterpret_cast<int*>(cv + kKeep);           // kKeep
     float* rv = reinterpret_cast<float*>(ci + kKeep);       // 256 (arg-max scratch)
     int* ri = reinterpret_cast<int*>(rv + 256);             // 256
+    TA* aimg = reinterpret_cast<TA*>((reinterpret_cast<uintptr_t>(ri + 256) + 15) & ~(uintptr_t)15);  // Mlds entries in natural row order: lane l of chunk t reads its
+                                                            // 16 bytes at (t * 64 + l) * 16 -- consecutive lanes, conflict-free
 
     double* r = r_all + (int64_t)s * Mr;
     const int j = st.nsel;
@@ -307,13 +310,12 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     __syncthreads();
 
     // ---- exact rescoring: <a_c, r> in Float64 for the kKeep candidates (all loads in flight)
-    double ex[kKeep];
+#pragma unroll 1
+    for (int grp = 0; grp < kKeep / DEPTH; ++grp) {
+        Raw4<TA> av[DEPTH][NI];
 #pragma unroll
-    for (int half = 0; half < 4; ++half) {
-        Raw4<TA> av[kKeep / 4][NI];
-#pragma unroll
-        for (int q = 0; q < kKeep / 4; ++q) {
-            const int c = ci[half * (kKeep / 4) + q];
+        for (int q = 0; q < DEPTH; ++q) {
+            const int c = ci[grp * DEPTH + q];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = 4 * (tid + 256 * i);
@@ -322,32 +324,32 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
             }
         }
 #pragma unroll
-        for (int q = 0; q < kKeep / 4; ++q) {
+        for (int q = 0; q < DEPTH; ++q) {
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = fma(av[q][i].get(e), rreg[i][e], acc);
             for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
-            if (lane == 0) red[wave * kKeep + half * (kKeep / 4) + q] = acc;
+            if (lane == 0) red[wave * kKeep + grp * DEPTH + q] = acc;
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kKeep; ++q) ex[q] = (red[q] + red[kKeep + q]) + (red[2 * kKeep + q] + red[3 * kKeep + q]);
     // arg-max by the exact value, first index on ties (Julia argmax)
     int best = -1;
-    double bestv = -1.0;
+    double bestv = -1.0, cexact = 0.0;
     int besti = 0x7fffffff;
-#pragma unroll
+#pragma unroll 1
     for (int q = 0; q < kKeep; ++q) {
         const int c = ci[q];
         if (c < 0 || c == 0x7fffffff) continue;
-        const double v = fabs(ex[q]);
+        const double exq = (red[q] + red[kKeep + q]) + (red[2 * kKeep + q] + red[3 * kKeep + q]);
+        const double v = fabs(exq);
         if (v > bestv || (v == bestv && c < besti)) {
             bestv = v;
             besti = c;
             best = q;
+            cexact = exq;
         }
     }
     if (best < 0) {  // no candidate at all (N == 0): nothing to do
@@ -367,30 +369,27 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
         if (tid == 0) st.done |= STOP_STAG;
         return;
     }
-    const double cexact = ex[best];
 
-    // ---- a = A[:, besti]: registers (row-owner form) and LDS image (sweep form); ||a||^2
-    double areg[NI][4];
+    // ---- a = A[:, besti] -> LDS image (natural row order, the dictionary's own type: exact); ||a||^2.  Nothing of a stays
+    // in registers across pass 1 and the T mat-vecs: pass 2 takes it from the image again.
     double na2 = 0.0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = 4 * (tid + 256 * i);
-        if (row < Mv)
-            load4(A + (int64_t)besti * ld + row, Mv - row, areg[i]);
-        else
-            areg[i][0] = areg[i][1] = areg[i][2] = areg[i][3] = 0.0;
+        double a0[4] = {0.0, 0.0, 0.0, 0.0};
+        if (row < Mv) load4(A + (int64_t)besti * ld + row, Mv - row, a0);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            na2 = fma(areg[i][e], areg[i][e], na2);
-            if (row + e < Mlds) aimg[r_slot<VEC>(row + e)] = areg[i][e];
+            na2 = fma(a0[e], a0[e], na2);
+            if (row + e < Mlds) aimg[row + e] = (TA)a0[e];
         }
     }
-    for (int m = 4 * 256 * NI + tid; m < Mlds; m += 256) aimg[r_slot<VEC>(m)] = 0.0;
+    for (int m = 4 * 256 * NI + tid; m < Mlds; m += 256) aimg[m] = (TA)0;
     na2 = block_sum256(na2, sc);  // (barrier inside: aimg is complete afterwards)
 
     // ---- pass 1: g_i = <a_{s_i}, a>, one wave per 4 support columns (the sweep's inner loop)
     {
-        const f64x2* as2 = reinterpret_cast<const f64x2*>(aimg);
+        const VT* as = reinterpret_cast<const VT*>(aimg);
         for (int c0 = wave * 4; c0 < j; c0 += 16) {
             const VT* p[4];
 #pragma unroll
@@ -399,10 +398,10 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
                 p[c] = reinterpret_cast<const VT*>(A + (int64_t)col * ld) + lane;
             }
             double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < nchunk; t0 += 4) {  // 4 chunks x 4 columns = 16 loads in flight per lane
-                VT a[4][4];
+            for (int t0 = 0; t0 < nchunk; t0 += DEPTH) {  // DEPTH chunks x 4 columns of loads in flight per lane
+                VT a[DEPTH][4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < DEPTH; ++u) {
                     const int row = (t0 + u) * ROWS + lane * VEC;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -411,23 +410,22 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < DEPTH; ++u) {
                     const int t = (t0 + u < nchunk) ? t0 + u : 0;  // (padding chunks carry zeros)
+                    const VT av = as[t * kWave + lane];
                     if constexpr (VEC == 4) {
-                        const f64x2 r01 = as2[(t * 2 + 0) * kWave + lane], r23 = as2[(t * 2 + 1) * kWave + lane];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            acc[c] = fma((double)a[u][c].x, r01.x, acc[c]);
-                            acc[c] = fma((double)a[u][c].y, r01.y, acc[c]);
-                            acc[c] = fma((double)a[u][c].z, r23.x, acc[c]);
-                            acc[c] = fma((double)a[u][c].w, r23.y, acc[c]);
+                            acc[c] = fma((double)a[u][c].x, (double)av.x, acc[c]);
+                            acc[c] = fma((double)a[u][c].y, (double)av.y, acc[c]);
+                            acc[c] = fma((double)a[u][c].z, (double)av.z, acc[c]);
+                            acc[c] = fma((double)a[u][c].w, (double)av.w, acc[c]);
                         }
                     } else {
-                        const f64x2 r01 = as2[t * kWave + lane];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
-                            acc[c] = fma((double)a[u][c].x, r01.x, acc[c]);
-                            acc[c] = fma((double)a[u][c].y, r01.y, acc[c]);
+                            acc[c] = fma((double)a[u][c].x, (double)av.x, acc[c]);
+                            acc[c] = fma((double)a[u][c].y, (double)av.y, acc[c]);
                         }
                     }
                 }
@@ -496,13 +494,20 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
     }
     __syncthreads();
 
-    // ---- pass 2: v = a - sum_i y_i a_{s_i}  (row-owner form, 4 columns x NI loads in flight)
+    // ---- pass 2: v = a - sum_i y_i a_{s_i}  (row-owner form, DEPTH columns x NI loads in flight)
+    double areg[NI][4];
+#pragma unroll
+    for (int u = 0; u < NI; ++u) {
+        const int row = 4 * (tid + 256 * u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) areg[u][e] = (row + e < Mlds) ? (double)aimg[row + e] : 0.0;
+    }
     {
         int i = 0;
-        for (; i + 4 <= j; i += 4) {
-            Raw4<TA> cv4[4][NI];
+        for (; i + DEPTH <= j; i += DEPTH) {
+            Raw4<TA> cv4[DEPTH][NI];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < DEPTH; ++c) {
                 const int col = sel[i + c];
 #pragma unroll
                 for (int u = 0; u < NI; ++u) {
@@ -512,7 +517,7 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
                 }
             }
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < DEPTH; ++c) {
                 const double yc = yv[i + c];
 #pragma unroll
                 for (int u = 0; u < NI; ++u)
@@ -543,7 +548,8 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const double nr = fma(-areg[u][e], f, rreg[u][e]);
+            const double rold = (row + e < Mrows) ? r[row + e] : 0.0;  // (reloaded: the residual is not held in registers across the step)
+            const double nr = fma(-areg[u][e], f, rold);
             if (row + e < Mrows) r[row + e] = nr;
             o[e] = (__bf16)(float)((row + e < Mrows) ? nr : 0.0);
         }
@@ -565,7 +571,45 @@ __global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_
 inline size_t b_step_lds_bytes(int Mv, int vec, int kcap) {
     const int rows = kWave * vec;
     const int nchunk = (Mv + rows - 1) / rows;
-    return (size_t)(nchunk * rows + 3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + 64;
+    return (size_t)(3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + (size_t)nchunk * rows * (16 / vec) + 64;
+}
+
+// Persistent form: workgroup w serves the signals sig0 + w, sig0 + w + gridDim.x, ... of its half-batch.  With one
+// workgroup per CU (grid = number of CUs) and at most 168 registers per lane (NI <= 4), one of these workgroups and one
+// 512-thread screening workgroup of the other half-batch fit a CU together: 3 x 168 registers per SIMD lane, < 160 KiB LDS.
+template <typename TA, int NI, int DEPTH>
+__global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
+                                                const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                                                int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
+                                                double* __restrict__ z_all, int* __restrict__ sel_all,
+                                                BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
+                                                __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
+                                                int check_eps, double cert_coef, int sig0, int nsig) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    for (int s = sig0 + (int)blockIdx.x; s < sig0 + nsig; s += (int)gridDim.x) {
+        b_step_one<TA, NI, DEPTH>(s, A, ld, Mv, N, cand_val, cand_idx, ncand, T_all, Tt_all, z_all, sel_all, bs, r_all, Mr, rb_all, Mk,
+                                  kcap, Mrows, eps, check_eps, cert_coef, lds);
+        __syncthreads();  // the LDS scratch is reused by the next signal
+    }
+}
+
+// The same kernel held to 168 registers per lane (three waves per SIMD): the form that shares a CU with a screening
+// workgroup.  Rows beyond 4096 (NI = 8) do not fit that budget and use k_b_step.
+template <typename TA, int NI, int DEPTH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_b_step_co(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
+                 const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
+                 int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
+                 double* __restrict__ z_all, int* __restrict__ sel_all,
+                 BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
+                 __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
+                 int check_eps, double cert_coef, int sig0, int nsig) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    for (int s = sig0 + (int)blockIdx.x; s < sig0 + nsig; s += (int)gridDim.x) {
+        b_step_one<TA, NI, DEPTH>(s, A, ld, Mv, N, cand_val, cand_idx, ncand, T_all, Tt_all, z_all, sel_all, bs, r_all, Mr, rb_all, Mk,
+                                  kcap, Mrows, eps, check_eps, cert_coef, lds);
+        __syncthreads();
+    }
 }
 
 // x = T z (ldiv!), sorted-index assembly; one workgroup per signal

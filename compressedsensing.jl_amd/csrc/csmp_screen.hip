@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256) void k_b_screen(const __bf16* __restrict__ Ab,
 // barrier that ends it.  Each (wave row, signal) pair lives in ONE wave, so the top-4 epilogue needs
 // no LDS: it is written per 128-atom half tile, the granularity k_b_step expects.
 constexpr int kBT2 = 256;
-constexpr size_t kScreenLds256 = 2 * 2 * kBT2 * 128;  // 131,072 B
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void glb_void_t;
 __global__ __launch_bounds__(512) void k_b_screen256(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
@@ -321,17 +320,164 @@ __global__ __launch_bounds__(512) void k_b_screen256(const __bf16* __restrict__ 
     }
 }
 
-hipError_t launch_screen(hipStream_t stream, bool big, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
-                         int64_t N, float* cand_val, int* cand_idx) {
+// ---------------------------------------------------------------------------------------------
+// k_b_screen256c: the 256 x 256 kernel in the form that SHARES a CU with a rescoring / append workgroup (k_b_step_co)
+// of the other half-batch: at most 168 registers per lane (three waves per SIMD: two of this kernel, one of the other),
+// 128 KiB of LDS, and a PERSISTENT grid (one workgroup per CU walks the tiles), so that a CU never holds more than one
+// of these.  Same tiles, same staging (LDS-DMA with the source-side XOR swizzle), same packed-key epilogue result as
+// k_b_screen256; the differences are in how registers are spent:
+//   * operand fragments are streamed: per 32-deep k-step the four signal fragments stay (16 registers), the eight atom
+//     fragments pass through a two-deep window (8 registers) -- 24 instead of 48;
+//   * the epilogue never materialises its 32 keys per signal: each of the four max passes recomputes them from the
+//     accumulators (3 VALU per key) and keeps only a running maximum.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_b_screen256c(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
+                    int n_at2, int n_st2, int64_t N, int n_atiles128,
+                    float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
+    const int nkb = Mk / kBK;
+    const int key = (fr >> 1) & 7;
+    // DMA map (as k_b_screen256): lane offsets within an operand tile, 32-bit
+    int goff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * (4 * wave + i) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        goff[i] = row * Mk + chunk * 8;
+    }
+    const int ntiles = n_at2 * n_st2;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // consecutive workgroups (= the CUs of one XCD, round-robin over XCDs) share an atom tile across the signal tiles
+        int atile, stile;
+        if ((n_at2 & 7) == 0) {
+            const int xcd = tile & 7, local = tile >> 3;
+            stile = local % n_st2;
+            atile = (local / n_st2) * 8 + xcd;
+        } else {
+            stile = tile % n_st2;
+            atile = tile / n_st2;
+        }
+        const __bf16* gA = Ab + (int64_t)atile * kBT2 * Mk;
+        const __bf16* gR = Rb + (int64_t)stile * kBT2 * Mk;
+        f32x4s acc[8][4];
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = (f32x4s)0.0f;
+        auto issue = [&](int buf, int kb) {
+            char* la = smem + (size_t)(buf * 2 + 0) * kBT2 * 128 + (size_t)(4 * wave) * 1024;
+            char* lr = smem + (size_t)(buf * 2 + 1) * kBT2 * 128 + (size_t)(4 * wave) * 1024;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gA + goff[i] + kb * kBK), (lds_void_t*)(la + i * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_void_t*)(gR + goff[i] + kb * kBK), (lds_void_t*)(lr + i * 1024), 16, 0, 0);
+            }
+        };
+        __syncthreads();  // (the previous tile's last reads of buffer 0 are done)
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int buf = kb & 1;
+            if (kb + 1 < nkb) issue(buf ^ 1, kb + 1);
+            const char* la = smem + (size_t)(buf * 2 + 0) * kBT2 * 128 + (wr * 128 + fr) * 128;
+            const char* lr = smem + (size_t)(buf * 2 + 1) * kBT2 * 128 + (wc * 64 + fr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < kBK / 32; ++kk) {
+                const int co = ((kk * 4 + fq) ^ key) << 4;
+                bf16x8 b[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) b[t] = *reinterpret_cast<const bf16x8*>(lr + t * 16 * 128 + co);
+                bf16x8 a0 = *reinterpret_cast<const bf16x8*>(la + co);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    bf16x8 a1 = a0;
+                    if (m + 1 < 8) a1 = *reinterpret_cast<const bf16x8*>(la + (m + 1) * 16 * 128 + co);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the window two deep: the next fragment's read stays here
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, b[n], acc[m][n], 0, 0, 0);
+                    a0 = a1;
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        // epilogue: per signal the 4 largest |c| over this wave's 128 atoms on packed keys (see k_b_screen256)
+        const int at128 = atile * 2 + wr;
+        const bool ragged = (int64_t)(at128 + 1) * 128 > N;
+        unsigned lo0 = 128u - (unsigned)(fq * 4);  // low key byte of this lane's first atom; the others follow by constants
+        asm volatile("" : "+v"(lo0));              // (opaque per tile: 32 precomputed low bytes per lane would cost 32 registers)
+        const int nleft = (int)(N - (int64_t)at128 * 128) - fq * 4;  // atoms of this tile from this lane's first one on (ragged tile only)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            unsigned w[4];
+            unsigned prev = 0xffffffffu;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                unsigned best = 0u;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned kv = (__float_as_uint(acc[m][n][j]) & 0x7fffff00u) | (lo0 - (unsigned)(m * 16 + j));
+                        if (ragged && m * 16 + j >= nleft) kv = 0u;
+                        kv = kv < prev ? kv : 0u;
+                        best = best > kv ? best : kv;
+                    }
+                w[p] = best;
+                prev = best;  // (0 stays 0: nothing is left below)
+            }
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                unsigned o[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] = (unsigned)__shfl_xor((int)w[q], sh, kSWave);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w[q] = w[q] > o[3 - q] ? w[q] : o[3 - q];
+                auto cx = [&](int x, int y) {
+                    const unsigned hi = w[x] > w[y] ? w[x] : w[y], lo = w[x] > w[y] ? w[y] : w[x];
+                    w[x] = hi;
+                    w[y] = lo;
+                };
+                cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
+            }
+            if (fq == 0) {
+                float ov[4];
+                int oi[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool ok = w[q] != 0u;
+                    ov[q] = ok ? __uint_as_float(w[q] | 0xffu) : -1.0f;
+                    oi[q] = ok ? at128 * 128 + (128 - (int)(w[q] & 0xffu)) : 0x7fffffff;
+                }
+                const int64_t sig = (int64_t)stile * kBT2 + wc * 64 + n * 16 + fr;
+                const int64_t base = (sig * n_atiles128 + at128) * kTileCand;
+                *reinterpret_cast<f32x4s*>(cand_val + base) = f32x4s{ov[0], ov[1], ov[2], ov[3]};
+                *reinterpret_cast<int4*>(cand_idx + base) = make_int4(oi[0], oi[1], oi[2], oi[3]);
+            }
+        }
+    }
+}
+
+hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
+                         int64_t N, float* cand_val, int* cand_idx, int ncu) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute((const void*)k_b_screen, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)k_b_screen256, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_b_screen256c, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
+        if (e != hipSuccess) return e;
         attr_done = true;
     }
-    if (big)
+    if (mode == kScreenCo) {
+        const int ntiles = (n_atiles / 2) * (n_stiles / 2);
+        hipLaunchKernelGGL(k_b_screen256c, dim3(ntiles < ncu ? ntiles : ncu), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
+                           n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx);
+    } else if (mode == kScreen256)
         hipLaunchKernelGGL(k_b_screen256, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
                            n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx);
     else
@@ -339,9 +485,11 @@ hipError_t launch_screen(hipStream_t stream, bool big, const __bf16* Ab, const _
                            cand_val, cand_idx);
     return hipGetLastError();
 }
-const char* screen_kernel_name(bool big) {
-    return big ? "csmp::k_b_screen256 (v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging, fused top-4 epilogue)"
-               : "csmp::k_b_screen (v_mfma_f32_32x32x16_bf16, 128x128 tiles, fused top-4 epilogue)";
+const char* screen_kernel_name(int mode) {
+    return mode == kScreenCo ? "csmp::k_b_screen256c (v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging, fused top-4 epilogue; persistent, "
+                               "168 registers: shares each CU with a k_b_step_co workgroup of the other half-batch)"
+           : mode == kScreen256 ? "csmp::k_b_screen256 (v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging, fused top-4 epilogue)"
+                                : "csmp::k_b_screen (v_mfma_f32_32x32x16_bf16, 128x128 tiles, fused top-4 epilogue)";
 }
 
 }  // namespace csmp

@@ -16,11 +16,14 @@ constexpr int kBK = 64;          // k elements staged per step
 constexpr int kBRow = 144;       // LDS bytes per staged row: 128 + 16 pad -> conflict-free ds_read_b128
 constexpr int kTileCand = 4;     // candidates kept per (signal, atom tile)
 constexpr size_t kScreenLds = 2 * 2 * kBT * kBRow;  // [buffer][A|R][row] = 73,728 B
+constexpr size_t kScreenLds256 = 2 * 2 * 256 * 128;  // the 256^2 kernels: 2 buffers x (A 32 KiB + R 32 KiB) = 131,072 B
 
 // one screening launch: D = Ab Rb' tile by tile with the fused top-4-per-(signal, 128-atom tile) epilogue.
-// big: 256^2 tiles with LDS-DMA staging (needs n_atiles and n_stiles even), else the 128^2 kernel.
-hipError_t launch_screen(hipStream_t stream, bool big, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
-                         int64_t N, float* cand_val, int* cand_idx);
-const char* screen_kernel_name(bool big);
+// mode: kScreen128 = the 128^2 kernel; kScreen256 = 256^2 tiles with LDS-DMA staging (needs n_atiles and n_stiles even);
+// kScreenCo = the same tiles by the persistent, 168-register kernel that shares CUs with k_b_step_co (ncu workgroups).
+enum : int { kScreen128 = 0, kScreen256 = 1, kScreenCo = 2 };
+hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
+                         int64_t N, float* cand_val, int* cand_idx, int ncu);
+const char* screen_kernel_name(int mode);
 
 }  // namespace csmp
