@@ -2678,11 +2678,14 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     const int tile = 2 * kBT;  // halves are whole 256-signal tiles
     const bool split = !getenv("CSMP_BATCH_ONE_STREAM") && Bpad >= 2 * tile;
     const int nh = split ? 2 : 1;
-    // The co-resident kernel pair (k_b_screen256c + k_b_step_co: 168 registers each, < 160 KiB of LDS together, persistent
-    // grids of one workgroup per CU) is what makes the two streams actually overlap: the plain kernels each fill a CU
-    // alone.  It needs 256^2 tiling, at most 4096 rows and the step kernel's LDS below the 32 KiB the screen leaves.
+    // CSMP_BATCH_CO=1 selects the co-resident kernel pair (k_b_screen256c + k_b_step_co: 168 registers each, < 160 KiB of
+    // LDS together, persistent grids of one workgroup per CU).  Only that pair can share a CU -- the plain kernels each
+    // fill one alone, and two streams of them merely interleave -- but the register diet costs more than the overlap
+    // returns (measured, DESIGN.md "Batched variant": screen 448 -> 812 us, step 430 -> 670 us per full batch; 139 ms per
+    // C3 batch against 114 ms), so it is off by default and kept as the documented experiment.
     const size_t step_lds = b_step_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, b.kcap);
-    const bool co = split && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256 && !getenv("CSMP_BATCH_NO_CO");
+    const char* coenv = getenv("CSMP_BATCH_CO");
+    const bool co = coenv && coenv[0] == '1' && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256;
     const int mode = co ? kScreenCo : big ? kScreen256 : kScreen128;
     b.last_mode = mode;
     int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};

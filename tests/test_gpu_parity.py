@@ -1178,15 +1178,14 @@ def test_capacity_growth_does_not_disable_the_removal_solvers(cs, oracle, D):
     big = cs.sp(d, y, 512)  # capacity 1024
     assert big.nnz == 512
     for name, call, ref in [("srr", lambda: cs.srr(d, y, 6), lambda: oracle.srr(A, y, 6)),
-                            ("ompr", lambda: cs.ompr(d, y, 6, 1e-6), lambda: oracle.ompr(A, y, 6, 1e-6)),
-                            ("rmp", lambda: cs.rmp(d, y, 6, kmax=40), None)]:
+                            ("ompr", lambda: cs.ompr(d, y, 6, 1e-6), lambda: oracle.ompr(A, y, 6, 1e-6))]:
         got = call()
-        if ref is not None:
-            r = ref()
-            assert np.array_equal(got.nzind, r[0]), name
-            assert close(got.nzval, r[1], tight=False), name
-        else:
-            assert got.nnz == 6, name
+        r = ref()
+        assert np.array_equal(got.nzind, r[0]), name
+        assert close(got.nzval, r[1], tight=False), name
+    # ... and the other way round: the small slot grows again for the next large request
+    again = cs.sp(d, y, 512)
+    assert np.array_equal(again.nzind, big.nzind) and np.array_equal(again.nzval, big.nzval)
 
 
 def _colsharded(cs, A, y, k, eps, cuts):

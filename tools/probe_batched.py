@@ -16,9 +16,15 @@ B = bench.make_signals_fast(torch, dev, At, 0, 2 * nsig, k).reshape(2, nsig, ben
 torch.cuda.synchronize()
 configs = [("two-stream", {}), ("one-stream", {"CSMP_BATCH_ONE_STREAM": "1"}),
            ("two-stream-128", {"CSMP_SCREEN_128": "1"}), ("one-stream-128", {"CSMP_SCREEN_128": "1", "CSMP_BATCH_ONE_STREAM": "1"})]
+only = None
 for a in sys.argv[1:]:
+    if a.startswith("only="):
+        only = a[5:].split(",")
+        continue
     name, _, kv = a.partition("=")
     configs.append((name, dict(x.split(":") for x in kv.split(",") if x)))
+if only:
+    configs = [c for c in configs if c[0] in only]
 ref = None
 for name, env in configs:
     for kk, vv in env.items():
