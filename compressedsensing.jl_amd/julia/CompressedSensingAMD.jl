@@ -217,35 +217,96 @@ lace(A::MatOrDict, b::AbstractVector; max_residual::Real = Inf, max_increase::Re
 abstract type Update{T} end
 (U::Update)(x) = update!(U, x)
 
-struct DevicePursuit{T} <: Update{T}
-    D::Dictionary{T}
+# Every functor works on a context of its OWN that borrows the Dictionary's device memory (csmp_clone): like the
+# reference's P objects, two functors on one A -- or a functor and a driver call -- share A and nothing else.
+mutable struct DevicePursuit{T} <: Update{T}
+    D::Dictionary{T}     # keeps the borrowed dictionary alive
+    ctx::Ptr{Cvoid}      # the clone
     algo::Cint
     l::Int
     kcap::Int
 end
 function begin_solver(A::MatOrDict{T}, b, algo, kcap, l = 1) where {T}
     D = dict(A)
+    ref = Ref{Ptr{Cvoid}}(C_NULL)
+    check(D, ccall((:csmp_clone, libcsmp), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), D.ctx, ref))
+    P = DevicePursuit{T}(D, ref[], algo, l, kcap)
+    finalizer(p -> ccall((:csmp_destroy, libcsmp), Cint, (Ptr{Cvoid},), p.ctx), P)
     bb, bt = bvec(b)
-    GC.@preserve bb check(D, ccall((:csmp_solver_begin, libcsmp), Cint,
+    GC.@preserve bb pcheck(P, ccall((:csmp_solver_begin, libcsmp), Cint,
         (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64),
-        D.ctx, algo, bb, bt, kcap, C_NULL, C_NULL, 0))
-    DevicePursuit{T}(D, algo, l, kcap)
+        P.ctx, algo, bb, bt, kcap, C_NULL, C_NULL, 0))
+    P
 end
-MP(A, b) = begin_solver(A, b, ALGO_MP, 4096)                                        # :19-24
+pcheck(P::DevicePursuit, rc::Integer) =
+    rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), P.ctx)))
+MP(A, b; steps::Integer = 4096) = begin_solver(A, b, ALGO_MP, steps)                       # :19-24 (steps: length of the device's step log)
 OMP(A, b, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_OMP, min(k, size(A, 1)))      # :54-60
 GOMP(A, b, l::Int, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_GOMP, min(k, size(A, 1)), l)  # :108-114
 
 # update!(P, x): one greedy step on the device, then x <- the device's current solution
 function update!(P::DevicePursuit, x::SparseVector = spzeros(size(P.D, 2)), l::Int = P.l)
-    check(P.D, ccall((:csmp_solver_step, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.D.ctx, l))
+    pcheck(P, ccall((:csmp_solver_step, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.ctx, l))
     idx, val, nnz = zeros(Int64, P.kcap), zeros(Float64, P.kcap), Ref{Int64}(0)
-    GC.@preserve idx val check(P.D, ccall((:csmp_solver_state, libcsmp), Cint,
+    GC.@preserve idx val pcheck(P, ccall((:csmp_solver_state, libcsmp), Cint,
         (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Cint}),
-        P.D.ctx, idx, val, nnz, C_NULL, C_NULL, C_NULL))
+        P.ctx, idx, val, nnz, C_NULL, C_NULL, C_NULL))
     y = to_sparse(size(P.D, 2), idx, val, nnz[])
     resize!(x.nzind, nnz[]); resize!(x.nzval, nnz[])
     copyto!(x.nzind, y.nzind); copyto!(x.nzval, y.nzval)
     return x
+end
+
+# ---------------------------------------------------------------------------------- many signals
+# [omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU.  method = :exact: single-signal sweeps, three signals
+# pipelined (csmp_omp_batch); :mfma: one bf16 screening GEMM per step + Float64 rescoring (csmp_omp_batch_mfma).
+# Returns (idx k x nsig 0-based, -1 padded; val; nnz) as the C ABI does -- the layout csmp_pack_results packs.
+function omp_batch_raw(A::MatOrDict{T}, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact) where {T}
+    D = dict(A)
+    BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
+    nsig = size(BB, 2)
+    idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)
+    f = method === :mfma ? :csmp_omp_batch_mfma : :csmp_omp_batch
+    GC.@preserve BB idx val nnz check(D, ccall((f, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
+        D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, k, ε, idx, val, nnz, CSMP_HOST))
+    idx, val, nnz
+end
+omp_batch(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact) = begin
+    idx, val, nnz = omp_batch_raw(A, B, ε, k; method = method)
+    [to_sparse(size(A, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:size(B, 2)]
+end
+
+# Signals sharded over ranks (SURVEY section 8e): rank r solves csmp_shard_range's block on its own GPU and ONE
+# gather moves the results.  `allgather(v::Vector{Float64}) -> Vector{Float64}` is the host's collective, e.g.
+#     allgather = v -> MPI.Allgather(v, comm)        # MPI.jl; every rank passes a block of the same length
+# (blocks are padded to the longest one: ceil(nsig / world) signals).
+function omp_sharded(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int, rank::Int, world::Int, allgather;
+                     method::Symbol = :exact)
+    nsig = size(B, 2)
+    lo, hi = Ref{Int64}(0), Ref{Int64}(0)
+    ccall((:csmp_shard_range, libcsmp), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), nsig, rank, world, lo, hi)
+    n = hi[] - lo[]
+    idx, val, nnz = omp_batch_raw(A, B[:, lo[]+1:hi[]], ε, k; method = method)
+    maxn = cld(nsig, world)
+    w = 2k + 1
+    packed = zeros(Float64, w * maxn)                     # row-major rows of 2k+1: [idx | val | nnz] per signal
+    ccall((:csmp_pack_results, libcsmp), Cint, (Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Int64, Int64, Ptr{Cdouble}),
+          idx, val, nnz, k, n, packed)                    # (idx/val are k x n column-major = n rows of k, as the ABI wants)
+    all = allgather(packed)
+    out = Vector{SparseVector{Float64,Int}}(undef, nsig)
+    for r in 0:world-1
+        ccall((:csmp_shard_range, libcsmp), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), nsig, r, world, lo, hi)
+        m = hi[] - lo[]
+        ri, rv, rn = zeros(Int64, k, m), zeros(Float64, k, m), zeros(Int64, m)
+        block = all[r*w*maxn+1:r*w*maxn+w*m]
+        ccall((:csmp_unpack_results, libcsmp), Cint, (Ptr{Cdouble}, Int64, Int64, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}),
+              block, k, m, ri, rv, rn)
+        for s in 1:m
+            out[lo[]+s] = to_sparse(size(A, 2), ri[:, s], rv[:, s], rn[s])
+        end
+    end
+    out
 end
 
 # argmaxinner!(P) / argmaxinner!(P, k): src/matchingpursuit.jl:181-193
