@@ -10,6 +10,7 @@
 #include "csmp_downdate.hpp"
 #include "csmp_tinv.hpp"
 #include "csmp_shard.hpp"
+#include "csmp_gram.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -61,6 +62,9 @@ struct Solver {
     double *T = nullptr, *T2 = nullptr, *tpd = nullptr, *tpn = nullptr;
     int* tmeta = nullptr;
     int sigcap = 0;
+    // whole-set least squares (csmp_gram.hpp), allocated on first use
+    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
+    int gram_np = 0, gram_split = 0;
     void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
 };
 
@@ -245,6 +249,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart);
     s = Solver();
 }
 
@@ -1823,6 +1828,89 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
     return CSMP_OK;
 }
 
+// ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
+static int gram_split_for(const csmp_ctx* ctx, int np) {
+    const int T = np / kGramTile, pairs = T * (T + 1) / 2;
+    const int blk = ctx->dtype == CSMP_F32 ? 64 : 32;  // rows per k_gram block
+    int nsplit = std::max(1, (3 * ctx->prop.multiProcessorCount + pairs - 1) / pairs);  // about three workgroups per CU
+    nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / (4 * blk))));       // at least four blocks of rows each
+    return std::min(nsplit, 32);
+}
+static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
+    Solver& s = ctx->s;
+    if (s.gram_np >= np && s.gram_split >= nsplit) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    np = std::max(np, s.gram_np);
+    nsplit = std::max(nsplit, s.gram_split);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart);
+    s.gram_np = s.gram_split = 0;
+    CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
+    CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
+    CHECK(dmalloc(ctx, &s.rpart, (size_t)((np + kResChunk - 1) / kResChunk) * s.Mpad));
+    s.gram_np = np;
+    s.gram_split = nsplit;
+    return CSMP_OK;
+}
+
+// factorize! + ldiv! on the columns `cols` taken together: enqueues the Gram matrix, its Cholesky factorisation, the
+// export of (R, z, support), the back substitution + sorted emission into the slot's out arrays and the residual
+// r = b - A_S x.  No host synchronisation; a set that fails the DGKS test leaves STOP_REORTH in the control block (and
+// nothing exported): the caller checks it with the results and falls back to ls_on_columns.
+template <typename TA>
+static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
+    Solver& s = ctx->s;
+    const int n = (int)cols.size(), M = (int)ctx->M;
+    const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
+    const int nsplit = gram_split_for(ctx, np);
+    CHECK(gram_ensure(ctx, np, nsplit));
+    CHECK(solver_restart(ctx));
+    HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
+    const int T = np / kGramTile, pairs = T * (T + 1) / 2;
+    const int blk = sizeof(TA) == 4 ? 64 : 32;
+    const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
+    hipLaunchKernelGGL(k_gram<TA>, dim3(pairs, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands, n,
+                       np, pairs, rps, s.Gpart);
+    HIPCHECK(hipGetLastError());
+    const int64_t nel = (int64_t)np * np;
+    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
+                       s.Gm, s.gdiag);
+    hipLaunchKernelGGL(k_gram_rhs<TA>, dim3((n + 1 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands,
+                       n, np, (const double*)s.b, s.Gm);
+    HIPCHECK(hipGetLastError());
+    for (int kb = 0; kb < np / kCholNB; ++kb) {
+        const int left = np - (kb + 1) * kCholNB;  // columns to the right of this step's block
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left + 255) / 256)), dim3(256), 0, ctx->stream, s.Gm, np, n, kb,
+                           (const double*)s.gdiag, s.st);
+        if (left > 0) {
+            const int Tt = (left + kGramTile - 1) / kGramTile;
+            hipLaunchKernelGGL(k_chol_trail, dim3(Tt * (Tt + 1) / 2), dim3(256), 0, ctx->stream, s.Gm, np, kb);
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np, n,
+                       (const int*)s.cands, s.R, s.kcap, s.z, s.sel, s.st);
+    HIPCHECK(hipGetLastError());
+    s.jh = std::min(s.kcap, n);
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
+    const int nch = (n + kResChunk - 1) / kResChunk;
+    hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                       (const int*)s.cands, (const double*)s.coef, n, s.rpart);
+    hipLaunchKernelGGL(k_residual_sum, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.rpart, nch, M, (const double*)s.b,
+                       s.r, (const DevState*)s.st);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+static bool gram_applicable(const csmp_ctx* ctx, size_t n) {
+    // worth it from a few panels on; needs QR capacity for R and distinct columns (the callers guarantee those)
+    return n >= 64 && !ctx->force_reorth && !getenv("CSMP_NO_GRAM");
+}
+static int ls_gram(csmp_ctx* ctx, const std::vector<int>& cols) {
+    return ctx->dtype == CSMP_F32 ? ls_gram_t<float>(ctx, cols) : ls_gram_t<double>(ctx, cols);
+}
+
 extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t* cols, int64_t ncols, const void* b, int b_dtype, double* coef) {
     if (!ctx) return CSMP_EINVAL;
     if (!cols || !b || !coef || ncols < 1) return fail(ctx, CSMP_EINVAL, "lstsq: bad arguments");
@@ -1840,8 +1928,16 @@ extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t* cols, int64_t ncols, con
     CHECK(solver_ensure(ctx, (int)ncols, (int)ncols));
     ctx->s.begun = false;
     CHECK(upload_b(ctx, b, b_dtype));
-    CHECK(ls_on_columns(ctx, c));
     Solver& s = ctx->s;
+    if (gram_applicable(ctx, c.size())) {
+        CHECK(ls_gram(ctx, c));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(coef, s.coef, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));  // the order of cols
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH) && hs.nsel == (int)ncols) return CSMP_OK;
+    }
+    CHECK(ls_on_columns(ctx, c));
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
     HIPCHECK(hipMemcpyAsync(coef, s.coef, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));  // insertion order = cols order
     HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -1872,9 +1968,42 @@ static int fetch_sorted(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<do
     return CSMP_OK;
 }
 
+// Least squares on `cols` + the sorted solution on the host (+ ||r|| when asked) in ONE synchronisation.  Large sets go
+// through the whole-set path (csmp_gram.hpp); if their DGKS test fails, or for small sets, the append chain does it.
+static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm) {
+    Solver& s = ctx->s;
+    if (gram_applicable(ctx, cols.size())) {
+        CHECK(ls_gram(ctx, cols));
+        if (resnorm) {
+            hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+            HIPCHECK(hipGetLastError());
+        }
+        const size_t n = cols.size();
+        std::vector<int64_t> hi(n);
+        std::vector<double> hv(n);
+        DevState hs;
+        double n2 = 0.0;
+        HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        if (resnorm) HIPCHECK(hipMemcpyAsync(&n2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
+            idx.swap(hi);
+            val.swap(hv);
+            if (resnorm) *resnorm = std::sqrt(n2);
+            return CSMP_OK;
+        }
+    }
+    CHECK(ls_on_columns(ctx, cols));
+    CHECK(fetch_sorted(ctx, idx, val));
+    if (resnorm) CHECK(residual_norm(ctx, resnorm));
+    return CSMP_OK;
+}
+
 // sp_acquisition!(P, x, k): src/twostage.jl:67-72 -- sweep on the current residual, union the k best
 // atoms into the support, least squares on the union
-static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val) {
+static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
     Solver& s = ctx->s;
     CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
     CHECK(launch_topS(ctx, k));
@@ -1888,8 +2017,7 @@ static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vect
     for (int t = 0; t < nt; ++t) cols.push_back(top[t]);  // @. x[i] = NaN (:70)
     std::sort(cols.begin(), cols.end());
     cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    CHECK(ls_on_columns(ctx, cols));  // solve! (:71)
-    return fetch_sorted(ctx, idx, val);
+    return ls_fetch(ctx, cols, idx, val, resnorm);  // solve! (:71)
 }
 
 extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
@@ -1906,9 +2034,8 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     CHECK(upload_b(ctx, b, b_dtype));
     std::vector<int64_t> xi;
     std::vector<double> xv;
-    CHECK(sp_acquire(ctx, (int)k, xi, xv));  // :90
     double resnorm = 0.0;
-    CHECK(residual_norm(ctx, &resnorm));     // :91
+    CHECK(sp_acquire(ctx, (int)k, xi, xv, &resnorm));  // :90-91
     int64_t it = 0;
     while (it < maxiter) {                   // :92
         const double oldnorm = resnorm;
@@ -1928,10 +2055,8 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
         }
         std::vector<int> cols;
         for (auto i : xi) cols.push_back((int)i);
-        CHECK(ls_on_columns(ctx, cols));  // :82
-        CHECK(fetch_sorted(ctx, xi, xv));
+        CHECK(ls_fetch(ctx, cols, xi, xv, &resnorm));       // :82, :95
         ++it;
-        CHECK(residual_norm(ctx, &resnorm));                 // :95
         if (resnorm <= delta || oldnorm <= resnorm) break;   // :96
     }
     for (size_t t = 0; t < xi.size(); ++t) {

@@ -1,0 +1,304 @@
+// csmp_gram.hpp -- least squares on a whole column set at once, for the FROM-SCRATCH factorisations of Subspace
+// Pursuit (factorize! + ldiv!, src/matchingpursuit.jl:219-227; solve!, src/twostage.jl:104-107: SP re-factorises
+// A[:, support] twice per iteration, 2k and k columns) and for the lstsq primitive.
+//
+// The panel appends of csmp_block.hpp build Q column block by column block: 64 panels x 5 launches per SP solve at
+// config 5, each a few microseconds of work.  Here the n columns are taken together:
+//
+//   k_gram        G = A_S' A_S (n x n, Float64 products of the exactly promoted dictionary values) on the Float64 matrix
+//                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
+//   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
+//   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
+//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 32 columns per step: the 32 x 32 diagonal
+//                 block in the registers of one wave (the v_readlane scheme of k_blk3), the row panel by substitution (one
+//                 thread per column), the trailing update on the matrix cores.  The bordered column comes out as
+//                 z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
+//   k_gram_export R, z, support and count into the solver slot: from there on k_finish* (back substitution + sorted
+//                 emission) and k_residual work as after any append chain.
+//
+// R is the triangular factor the appends would have produced (the Cholesky factor of A_S'A_S IS the R of A_S = QR), so
+// the same DGKS-type test applies, column by column: R_jj^2 >= |a_j|^2 / 2.  A set that fails it anywhere (coherent
+// atoms) raises STOP_REORTH, nothing is exported, and the host repeats the factorisation with the panel appends
+// (which orthogonalise explicitly and fall back further to the column-wise chain).  For the supports SP meets on
+// incoherent dictionaries cond(A_S) is a small constant and the normal-equation error cond^2 * eps stays at 1e-15.
+// No Q is formed: callers that go on appending or removing columns (ompr, srr, br) keep using the panel appends.
+#pragma once
+#include "csmp_kernels.hpp"
+
+namespace csmp {
+
+using d4g = __attribute__((ext_vector_type(4))) double;
+constexpr int kGramTile = 64;   // G tile edge per workgroup
+constexpr int kCholNB = 32;     // columns per Cholesky step
+
+// rows of a column a lane holds per 64-row (f32) / 32-row (f64) block: 16 consecutive f32 = 8 consecutive f64 = 64 bytes
+template <typename TA> struct GramRows { static constexpr int n = 16; };
+template <> struct GramRows<double> { static constexpr int n = 8; };
+
+// One (I <= J) tile pair x one slice of the rows.  4 waves: wave w owns the 16 columns J*64 + 16 w .. of the J block and all
+// 64 of the I block.  Lane (fr = l & 15, fq = l >> 4) loads RPL consecutive rows (block base + fq * RPL) of column fr of each
+// 16-column group; MFMA step kk multiplies row (base + fq * RPL + kk) of both operands -- a permutation of the summation
+// index, the same on both sides.
+template <typename TA>
+__global__ __launch_bounds__(256) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
+                                              int np, int ntile, int rows_per_split, double* __restrict__ Gpart) {
+    constexpr int RPL = GramRows<TA>::n;
+    constexpr int BLK = 4 * RPL;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    // tile pair index -> (I, J), I <= J, enumerated column by column: p = J (J + 1) / 2 + I
+    int J = 0;
+    {
+        const int p = blockIdx.x;
+        while ((J + 1) * (J + 2) / 2 <= p) ++J;
+        const int I = p - J * (J + 1) / 2;
+        const int ks = blockIdx.y;
+        const int k0 = ks * rows_per_split, k1 = min(M, k0 + rows_per_split);
+        const TA* ci[4];
+        bool vi[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = I * kGramTile + t * 16 + fr;
+            vi[t] = c < n;
+            ci[t] = A + (int64_t)(vi[t] ? cols[c] : 0) * ld;
+        }
+        const int cj = J * kGramTile + wave * 16 + fr;
+        const bool vj = cj < n;
+        const TA* cjp = A + (int64_t)(vj ? cols[cj] : 0) * ld;
+        d4g acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = d4g{0.0, 0.0, 0.0, 0.0};
+        for (int rb = k0; rb < k1; rb += BLK) {
+            const int r0 = rb + fq * RPL;
+            TA bj[RPL], ai[4][RPL];
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) bj[e] = (vj && r0 + e < k1) ? cjp[r0 + e] : (TA)0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < RPL; ++e) ai[t][e] = (vi[t] && r0 + e < k1) ? ci[t][r0 + e] : (TA)0;
+#pragma unroll
+            for (int kk = 0; kk < RPL; ++kk) {
+                const double b = (double)bj[kk];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[t][kk], b, acc[t], 0, 0, 0);
+            }
+        }
+        // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
+        double* out = Gpart + (int64_t)ks * np * np;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = I * kGramTile + t * 16 + fq + 4 * reg, col = J * kGramTile + wave * 16 + fr;
+                out[row + (int64_t)col * np] = acc[t][reg];
+            }
+    }
+    (void)ntile;
+}
+
+// G = sum of the row-slice partials (fixed order) on the upper tiles; identity on the padding diagonal (columns beyond the
+// bordered one), zeros elsewhere in the padding; the original diagonal goes to gdiag (DGKS reference, |a_j|^2)
+__global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ Gpart, int nsplit, int n, int np,
+                                                     double* __restrict__ G, double* __restrict__ gdiag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)np * np) return;
+    const int row = (int)(e % np), col = (int)(e / np);
+    if ((row / kGramTile) > (col / kGramTile)) return;  // lower tiles are never read
+    double s = 0.0;
+    if (row < n && col < n) {
+        for (int k = 0; k < nsplit; ++k) s += Gpart[(int64_t)k * np * np + e];
+    } else if (row == col && row > n) {
+        s = 1.0;
+    }
+    if (!(row < n && col == n)) G[e] = s;  // (column n, rows < n, belongs to k_gram_rhs)
+    if (row == col && row < n) gdiag[row] = s;
+}
+
+// column n of the bordered matrix: c_j = <a_{s_j}, b> (one wave per column, Float64), and the corner b'b
+template <typename TA>
+__global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
+                                                  int np, const double* __restrict__ b, double* __restrict__ G) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = blockIdx.x * 4 + wave;
+    if (j > n) return;
+    double acc = 0.0, acc1 = 0.0;
+    if (j < n) {
+        const TA* a = A + (int64_t)cols[j] * ld;
+        int m = lane;
+        for (; m + 64 < M; m += 128) {
+            acc = fma((double)a[m], b[m], acc);
+            acc1 = fma((double)a[m + 64], b[m + 64], acc1);
+        }
+        for (; m < M; m += 64) acc = fma((double)a[m], b[m], acc);
+    } else {
+        for (int m = lane; m < M; m += 64) acc = fma(b[m], b[m], acc);
+    }
+    acc += acc1;
+    for (int s = 32; s >= 1; s >>= 1) acc += shx(acc, s);
+    if (lane == 0) G[j + (int64_t)n * np] = acc;
+}
+
+// Cholesky step kb, first half: the 32 x 32 diagonal block (every workgroup, redundantly, in the registers of wave 0),
+// then the row panel R[c0 .. c0+31, c] = U^-T G[c0 .. c0+31, c] for this workgroup's 256 columns c >= c0 + 32.
+__global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
+                                                  DevState* st) {
+    constexpr int NB = kCholNB;
+    __shared__ double Rp[NB * NB];
+    __shared__ double rinv[NB];
+    const int tid = threadIdx.x, c0 = kb * NB;
+    if (tid < kWave) {
+        const int q = tid;
+        double gq[NB];
+        const double* gc = G + c0 + (int64_t)(c0 + (q < NB ? q : 0)) * np;
+#pragma unroll
+        for (int t = 0; t < NB; ++t) gq[t] = (q < NB && t <= q) ? gc[t] : 0.0;
+        const double ref = (q < NB && c0 + q < n) ? gdiag[c0 + q] : 0.0;
+        int mybad = 0;
+        double ri[NB];
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            const double d = readlane_f64(gq[p], p);
+            if (q == p && c0 + p < n && (!(d > 0.0) || !(d >= 0.5 * ref))) mybad = 1;  // DGKS: too much cancellation
+            const bool okd = d > 0.0 && d < 1e300;
+            double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            ri[p] = okd ? rs_ : 1.0;
+            const double rd = okd ? d * rs_ : 1.0;
+            gq[p] = (q == p) ? rd : gq[p] * ri[p];
+#pragma unroll
+            for (int s_ = p + 1; s_ < NB; ++s_) {
+                const double rps = readlane_f64(gq[p], s_);
+                if (q >= s_) gq[s_] = fma(-rps, gq[p], gq[s_]);
+            }
+        }
+        if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
+        if (q < NB) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                if (t <= q) Rp[t * NB + q] = gq[t];
+            if (blockIdx.x == 0) {  // the factored diagonal block, in place
+                double* go = G + c0 + (int64_t)(c0 + q) * np;
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+                    if (t <= q) go[t] = gq[t];
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) rinv[t] = ri[t];
+        }
+    }
+    __syncthreads();
+    const int c = c0 + NB + blockIdx.x * 256 + tid;
+    if (c >= np) return;
+    double* gc = G + c0 + (int64_t)c * np;
+    double x[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) x[p] = gc[p];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) {
+        double s = x[p];
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+            if (t < p) s = fma(-x[t], Rp[t * NB + p], s);
+        x[p] = s * rinv[p];
+    }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) gc[p] = x[p];
+}
+
+// Cholesky step kb, second half: G[i][j] -= sum_p X[p][i] X[p][j] over the 32 rows X = G[c0 .. c0+31, :] just finished, for
+// the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + 32).  Matrix cores; lane fq takes rows 8 fq .. 8 fq + 7 of X.
+__global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int np, int kb) {
+    constexpr int NB = kCholNB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const int c0 = kb * NB, t0 = c0 + NB;  // trailing matrix starts at column t0
+    int J = 0, p = blockIdx.x;
+    while ((J + 1) * (J + 2) / 2 <= p) ++J;
+    const int I = p - J * (J + 1) / 2;
+    const int cj = t0 + J * kGramTile + wave * 16 + fr;
+    const double* X = G + c0 + fq * 8;
+    double bj[8], ai[4][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bj[e] = (cj < np) ? X[e + (int64_t)cj * np] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int ci = t0 + I * kGramTile + t * 16 + fr;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? X[e + (int64_t)ci * np] : 0.0;
+    }
+    d4g acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = d4g{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[t][kk], bj[kk], acc[t], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg, col = t0 + J * kGramTile + wave * 16 + fr;
+            if (row < np && col < np && row <= col) G[row + (int64_t)col * np] -= acc[t][reg];
+        }
+}
+
+// R (n x n upper, leading dimension kcap), z = column n, support = cols, count = n -> the solver slot.  Nothing is
+// exported when the DGKS test failed anywhere (the host sees STOP_REORTH and falls back).
+__global__ __launch_bounds__(256) void k_gram_export(const double* __restrict__ G, int np, int n, const int* __restrict__ cols,
+                                                     double* __restrict__ R, int kcap, double* __restrict__ z,
+                                                     int* __restrict__ sel, DevState* st) {
+    if (st->done & STOP_REORTH) return;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (int64_t)n * n) {
+        const int row = (int)(e % n), col = (int)(e / n);
+        if (row <= col) R[row + (int64_t)col * kcap] = G[row + (int64_t)col * np];
+    }
+    if (e < n) {
+        z[e] = G[e + (int64_t)n * np];
+        sel[e] = cols[e];
+    }
+    if (e == 0) {
+        st->nsel = n;
+        st->j = n;
+        st->steps += 1;
+    }
+}
+
+// r = b - A[:, cols] x for a LARGE support (residual!, src/matchingpursuit.jl:158-161): the columns are cut into chunks of
+// 64, workgroup (row block, chunk) sums its chunk for 256 rows (8 columns of loads in flight), and k_residual_sum
+// subtracts the chunk sums from b in a fixed order.
+constexpr int kResChunk = 64;
+template <typename TA>
+__global__ __launch_bounds__(256) void k_residual_part(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ idx,
+                                                       const double* __restrict__ val, int n, double* __restrict__ part) {
+    const int row = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+    if (row >= M) return;
+    const int t0 = ch * kResChunk, t1 = min(n, t0 + kResChunk);
+    double a0 = 0.0, a1 = 0.0;
+    int t = t0;
+    for (; t + 8 <= t1; t += 8) {
+        TA v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = A[(int64_t)idx[t + u] * ld + row];
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) {
+            a0 = fma((double)v[u], val[t + u], a0);
+            a1 = fma((double)v[u + 1], val[t + u + 1], a1);
+        }
+    }
+    for (; t < t1; ++t) a0 = fma((double)A[(int64_t)idx[t] * ld + row], val[t], a0);
+    part[(int64_t)ch * M + row] = a0 + a1;
+}
+__global__ __launch_bounds__(256) void k_residual_sum(const double* __restrict__ part, int nch, int M, const double* __restrict__ b,
+                                                      double* __restrict__ r, const DevState* st) {
+    if (st->done & STOP_REORTH) return;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= M) return;
+    double s = 0.0;
+    for (int c = 0; c < nch; ++c) s += part[(int64_t)c * M + row];
+    r[row] = b[row] - s;
+}
+
+}  // namespace csmp
