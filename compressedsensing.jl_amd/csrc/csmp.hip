@@ -1745,8 +1745,9 @@ static int launch_topS(csmp_ctx* ctx, int S) {
         hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, ctx->stream, s.rs);
     }
     hipLaunchKernelGGL(k_rs_collect, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, s.rs_gt, s.rs_eq, kRsEqCap);
-    hipLaunchKernelGGL(k_rs_finish, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, (const int*)s.rs_gt,
-                       (const int*)s.rs_eq, kRsEqCap, s.rs_work, s.cands, s.cvals, s.ncands);
+    const int pairs = S_eff <= 4096 ? S_eff : 0;  // (value, index) pairs of the final rank sort staged in LDS
+    hipLaunchKernelGGL(k_rs_finish, dim3(1), dim3(256), (size_t)pairs * 12 + 16, ctx->stream, (const double*)s.cvec, ctx->N, s.rs,
+                       (const int*)s.rs_gt, (const int*)s.rs_eq, kRsEqCap, s.rs_work, s.cands, s.cvals, s.ncands, pairs);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -1830,8 +1831,8 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
 
 // ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
 static int gram_split_for(const csmp_ctx* ctx, int np) {
-    const int T = np / kGramTile, pairs = T * (T + 1) / 2;
-    const int blk = ctx->dtype == CSMP_F32 ? 64 : 32;  // rows per k_gram block
+    const int T = (np + kGramWg - 1) / kGramWg, pairs = T * (T + 1) / 2;
+    const int blk = 16;  // rows per k_gram block
     int nsplit = std::max(1, (3 * ctx->prop.multiProcessorCount + pairs - 1) / pairs);  // about three workgroups per CU
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / (4 * blk))));       // at least four blocks of rows each
     return std::min(nsplit, 32);
@@ -1868,11 +1869,11 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
-    const int T = np / kGramTile, pairs = T * (T + 1) / 2;
-    const int blk = sizeof(TA) == 4 ? 64 : 32;
+    const int T = (np + kGramWg - 1) / kGramWg, pairs = T * (T + 1) / 2;
+    const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
     hipLaunchKernelGGL(k_gram<TA>, dim3(pairs, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands, n,
-                       np, pairs, rps, s.Gpart);
+                       np, rps, s.Gpart);
     HIPCHECK(hipGetLastError());
     const int64_t nel = (int64_t)np * np;
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,

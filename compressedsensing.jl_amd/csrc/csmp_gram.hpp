@@ -31,69 +31,77 @@ using d4g = __attribute__((ext_vector_type(4))) double;
 constexpr int kGramTile = 64;   // G tile edge per workgroup
 constexpr int kCholNB = 32;     // columns per Cholesky step
 
-// rows of a column a lane holds per 64-row (f32) / 32-row (f64) block: 16 consecutive f32 = 8 consecutive f64 = 64 bytes
-template <typename TA> struct GramRows { static constexpr int n = 16; };
-template <> struct GramRows<double> { static constexpr int n = 8; };
+// rows of a column a lane holds per block of rows (4: the 32 operand values of a block, promoted to Float64, take 64
+// registers beside the 128 accumulators, which keeps two waves per SIMD)
+template <typename TA> struct GramRows { static constexpr int n = 4; };
+constexpr int kGramWg = 128;  // G tile edge per workgroup (k_gram): 2 x 2 waves of 64 x 64
 
-// One (I <= J) tile pair x one slice of the rows.  4 waves: wave w owns the 16 columns J*64 + 16 w .. of the J block and all
-// 64 of the I block.  Lane (fr = l & 15, fq = l >> 4) loads RPL consecutive rows (block base + fq * RPL) of column fr of each
-// 16-column group; MFMA step kk multiplies row (base + fq * RPL + kk) of both operands -- a permutation of the summation
-// index, the same on both sides.
+// One (I <= J) pair of 128-column blocks x one slice of the rows.  4 waves as 2 x 2, each a 64 x 64 piece = 4 x 4 MFMA
+// tiles (128 accumulator registers): every operand fragment feeds four MFMAs, and a workgroup fetches each of its 256
+// columns twice (not four times as with 64 x 64 tiles per workgroup) -- the kernel lives on L2 bandwidth.
+// Lane (fr = l & 15, fq = l >> 4) loads RPL consecutive rows (block base + fq * RPL) of column fr of each 16-column group;
+// MFMA step kk multiplies row (base + fq * RPL + kk) of both operands: a permutation of the summation index, the same
+// on both sides.
 template <typename TA>
-__global__ __launch_bounds__(256) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
-                                              int np, int ntile, int rows_per_split, double* __restrict__ Gpart) {
+__global__ __launch_bounds__(256, 2) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
+                                              int np, int rows_per_split, double* __restrict__ Gpart) {
     constexpr int RPL = GramRows<TA>::n;
     constexpr int BLK = 4 * RPL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const int wi = wave >> 1, wj = wave & 1;
     // tile pair index -> (I, J), I <= J, enumerated column by column: p = J (J + 1) / 2 + I
     int J = 0;
-    {
-        const int p = blockIdx.x;
-        while ((J + 1) * (J + 2) / 2 <= p) ++J;
-        const int I = p - J * (J + 1) / 2;
-        const int ks = blockIdx.y;
-        const int k0 = ks * rows_per_split, k1 = min(M, k0 + rows_per_split);
-        const TA* ci[4];
-        bool vi[4];
+    const int p = blockIdx.x;
+    while ((J + 1) * (J + 2) / 2 <= p) ++J;
+    const int I = p - J * (J + 1) / 2;
+    const int ks = blockIdx.y;
+    const int k0 = ks * rows_per_split, k1 = min(M, k0 + rows_per_split);
+    const int i0 = I * kGramWg + wi * 64, j0 = J * kGramWg + wj * 64;
+    const TA *ci[4], *cj[4];
+    bool vi[4], vj[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int c = I * kGramTile + t * 16 + fr;
-            vi[t] = c < n;
-            ci[t] = A + (int64_t)(vi[t] ? cols[c] : 0) * ld;
-        }
-        const int cj = J * kGramTile + wave * 16 + fr;
-        const bool vj = cj < n;
-        const TA* cjp = A + (int64_t)(vj ? cols[cj] : 0) * ld;
-        d4g acc[4];
+    for (int t = 0; t < 4; ++t) {
+        const int a = i0 + t * 16 + fr, b = j0 + t * 16 + fr;
+        vi[t] = a < n;
+        vj[t] = b < n;
+        ci[t] = A + (int64_t)(vi[t] ? cols[a] : 0) * ld;
+        cj[t] = A + (int64_t)(vj[t] ? cols[b] : 0) * ld;
+    }
+    d4g acc[4][4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = d4g{0.0, 0.0, 0.0, 0.0};
-        for (int rb = k0; rb < k1; rb += BLK) {
-            const int r0 = rb + fq * RPL;
-            TA bj[RPL], ai[4][RPL];
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) bj[e] = (vj && r0 + e < k1) ? cjp[r0 + e] : (TA)0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < RPL; ++e) ai[t][e] = (vi[t] && r0 + e < k1) ? ci[t][r0 + e] : (TA)0;
-#pragma unroll
-            for (int kk = 0; kk < RPL; ++kk) {
-                const double b = (double)bj[kk];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[t][kk], b, acc[t], 0, 0, 0);
-            }
-        }
-        // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
-        double* out = Gpart + (int64_t)ks * np * np;
+        for (int u = 0; u < 4; ++u) acc[t][u] = d4g{0.0, 0.0, 0.0, 0.0};
+    for (int rb = k0; rb < k1; rb += BLK) {
+        const int r0 = rb + fq * RPL;
+        TA ai[4][RPL], bj[4][RPL];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = I * kGramTile + t * 16 + fq + 4 * reg, col = J * kGramTile + wave * 16 + fr;
-                out[row + (int64_t)col * np] = acc[t][reg];
+            for (int e = 0; e < RPL; ++e) {
+                ai[t][e] = (vi[t] && r0 + e < k1) ? ci[t][r0 + e] : (TA)0;
+                bj[t][e] = (vj[t] && r0 + e < k1) ? cj[t][r0 + e] : (TA)0;
+            }
+#pragma unroll
+        for (int kk = 0; kk < RPL; ++kk)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double b = (double)bj[u][kk];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[t][kk], b, acc[t][u], 0, 0, 0);
             }
     }
-    (void)ntile;
+    // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
+    double* out = Gpart + (int64_t)ks * np * np;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = i0 + t * 16 + fq + 4 * reg, col = j0 + u * 16 + fr;
+                if (row < np && col < np) out[row + (int64_t)col * np] = acc[t][u][reg];
+            }
 }
 
 // G = sum of the row-slice partials (fixed order) on the upper tiles; identity on the padding diagonal (columns beyond the
@@ -146,6 +154,12 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
     __shared__ double Rp[NB * NB];
     __shared__ double rinv[NB];
     const int tid = threadIdx.x, c0 = kb * NB;
+    // this thread's column of the row panel: requested before the diagonal block is factorised (its latency hides there)
+    const int c = c0 + NB + blockIdx.x * 256 + tid;
+    double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;
+    double x[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gcol[p] : 0.0;
     if (tid < kWave) {
         const int q = tid;
         double gq[NB];
@@ -190,12 +204,8 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
         }
     }
     __syncthreads();
-    const int c = c0 + NB + blockIdx.x * 256 + tid;
     if (c >= np) return;
-    double* gc = G + c0 + (int64_t)c * np;
-    double x[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = gc[p];
+    double* gc = gcol;
 #pragma unroll
     for (int p = 0; p < NB; ++p) {
         double s = x[p];
@@ -209,28 +219,33 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
 }
 
 // Cholesky step kb, second half: G[i][j] -= sum_p X[p][i] X[p][j] over the 32 rows X = G[c0 .. c0+31, :] just finished, for
-// the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + 32).  Matrix cores; lane fq takes rows 8 fq .. 8 fq + 7 of X.
+// the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + 32).  Matrix cores; lane fq takes rows 8 fq .. 8 fq + 7 of
+// X; the accumulators start from G itself and one operand enters negated, so every load is issued before the first MFMA.
 __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int np, int kb) {
     constexpr int NB = kCholNB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int c0 = kb * NB, t0 = c0 + NB;  // trailing matrix starts at column t0
-    int J = 0, p = blockIdx.x;
+    int J = 0;
+    const int p = blockIdx.x;
     while ((J + 1) * (J + 2) / 2 <= p) ++J;
     const int I = p - J * (J + 1) / 2;
     const int cj = t0 + J * kGramTile + wave * 16 + fr;
     const double* X = G + c0 + fq * 8;
     double bj[8], ai[4][8];
+    d4g acc[4];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bj[e] = (cj < np) ? X[e + (int64_t)cj * np] : 0.0;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int ci = t0 + I * kGramTile + t * 16 + fr;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? X[e + (int64_t)ci * np] : 0.0;
-    }
-    d4g acc[4];
+        for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? -X[e + (int64_t)ci * np] : 0.0;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = d4g{0.0, 0.0, 0.0, 0.0};
+        for (int reg = 0; reg < 4; ++reg) {
+            const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg;
+            acc[t][reg] = (row < np && cj < np && row <= cj) ? G[row + (int64_t)cj * np] : 0.0;
+        }
+    }
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk)
 #pragma unroll
@@ -239,8 +254,8 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int 
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg, col = t0 + J * kGramTile + wave * 16 + fr;
-            if (row < np && col < np && row <= col) G[row + (int64_t)col * np] -= acc[t][reg];
+            const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg;
+            if (row < np && cj < np && row <= cj) G[row + (int64_t)cj * np] = acc[t][reg];
         }
 }
 
