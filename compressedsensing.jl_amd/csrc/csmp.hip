@@ -1831,7 +1831,7 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
 
 // ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
 static int gram_split_for(const csmp_ctx* ctx, int np) {
-    const int T = (np + kGramWg - 1) / kGramWg, pairs = T * (T + 1) / 2;
+    const int TJ = np / kGramWgJ, TI = (np + kGramWgI - 1) / kGramWgI, pairs = std::max(1, TJ * TI * 5 / 8);  // (pieces on or above the diagonal)
     const int blk = 16;  // rows per k_gram block
     int nsplit = std::max(1, (3 * ctx->prop.multiProcessorCount + pairs - 1) / pairs);  // about three workgroups per CU
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / (4 * blk))));       // at least four blocks of rows each
@@ -1869,10 +1869,9 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
-    const int T = (np + kGramWg - 1) / kGramWg, pairs = T * (T + 1) / 2;
     const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
-    hipLaunchKernelGGL(k_gram<TA>, dim3(pairs, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands, n,
+    hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands, n,
                        np, rps, s.Gpart);
     HIPCHECK(hipGetLastError());
     const int64_t nel = (int64_t)np * np;
@@ -1883,7 +1882,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipGetLastError());
     for (int kb = 0; kb < np / kCholNB; ++kb) {
         const int left = np - (kb + 1) * kCholNB;  // columns to the right of this step's block
-        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left + 255) / 256)), dim3(256), 0, ctx->stream, s.Gm, np, n, kb,
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left + kCholRowCols - 1) / kCholRowCols)), dim3(256), 0, ctx->stream, s.Gm, np, n, kb,
                            (const double*)s.gdiag, s.st);
         if (left > 0) {
             const int Tt = (left + kGramTile - 1) / kGramTile;

@@ -9,7 +9,7 @@
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
 //   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
-//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 32 columns per step: the 32 x 32 diagonal
+//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 64 columns per step: the 64 x 64 diagonal
 //                 block in the registers of one wave (the v_readlane scheme of k_blk3), the row panel by substitution (one
 //                 thread per column), the trailing update on the matrix cores.  The bordered column comes out as
 //                 z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
@@ -29,74 +29,85 @@ namespace csmp {
 
 using d4g = __attribute__((ext_vector_type(4))) double;
 constexpr int kGramTile = 64;   // G tile edge per workgroup
-constexpr int kCholNB = 32;     // columns per Cholesky step
+constexpr int kCholNB = 64;     // columns per Cholesky step
 
-// rows of a column a lane holds per block of rows (4: the 32 operand values of a block, promoted to Float64, take 64
-// registers beside the 128 accumulators, which keeps two waves per SIMD)
-template <typename TA> struct GramRows { static constexpr int n = 4; };
-constexpr int kGramWg = 128;  // G tile edge per workgroup (k_gram): 2 x 2 waves of 64 x 64
+constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
+constexpr int kGramWgI = 128;  // G rows per workgroup (k_gram): 2 x 2 waves, each 64 rows x 32 columns
+constexpr int kGramWgJ = 64;   // G columns per workgroup
 
-// One (I <= J) pair of 128-column blocks x one slice of the rows.  4 waves as 2 x 2, each a 64 x 64 piece = 4 x 4 MFMA
-// tiles (128 accumulator registers): every operand fragment feeds four MFMAs, and a workgroup fetches each of its 256
-// columns twice (not four times as with 64 x 64 tiles per workgroup) -- the kernel lives on L2 bandwidth.
-// Lane (fr = l & 15, fq = l >> 4) loads RPL consecutive rows (block base + fq * RPL) of column fr of each 16-column group;
-// MFMA step kk multiplies row (base + fq * RPL + kk) of both operands: a permutation of the summation index, the same
-// on both sides.
+// One (128-row block I, 64-column block J) piece of the upper triangle x one slice of the dictionary rows.  4 waves as
+// 2 x 2, each a 64 x 32 piece = 4 x 2 MFMA tiles (64 accumulator registers).  Lane (fr = l & 15, fq = l >> 4) loads 4
+// consecutive rows (block base + 4 fq) of column fr of each 16-column group; MFMA step kk multiplies row (base + 4 fq + kk)
+// of both operands: a permutation of the summation index, the same on both sides.  The fragments of the NEXT block of
+// rows are requested before the current block's 32 MFMAs are issued (two register sets), so the matrix cores do not wait
+// for L2: operands come straight from global memory, no LDS, no barriers.
 template <typename TA>
-__global__ __launch_bounds__(256, 2) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
+__global__ __launch_bounds__(256) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
                                               int np, int rows_per_split, double* __restrict__ Gpart) {
-    constexpr int RPL = GramRows<TA>::n;
-    constexpr int BLK = 4 * RPL;
+    constexpr int RPL = kGramRpl, BLK = 4 * RPL;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
-    // tile pair index -> (I, J), I <= J, enumerated column by column: p = J (J + 1) / 2 + I
-    int J = 0;
-    const int p = blockIdx.x;
-    while ((J + 1) * (J + 2) / 2 <= p) ++J;
-    const int I = p - J * (J + 1) / 2;
-    const int ks = blockIdx.y;
+    const int I = blockIdx.y, J = blockIdx.x, ks = blockIdx.z;
+    if (I * kGramWgI > J * kGramWgJ + kGramWgJ - 1) return;  // entirely below the diagonal
     const int k0 = ks * rows_per_split, k1 = min(M, k0 + rows_per_split);
-    const int i0 = I * kGramWg + wi * 64, j0 = J * kGramWg + wj * 64;
-    const TA *ci[4], *cj[4];
-    bool vi[4], vj[4];
+    const int i0 = I * kGramWgI + wi * 64, j0 = J * kGramWgJ + wj * 32;
+    const TA *ci[4], *cj[2];
+    bool vi[4], vj[2];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const int a = i0 + t * 16 + fr, b = j0 + t * 16 + fr;
+        const int a = i0 + t * 16 + fr;
         vi[t] = a < n;
-        vj[t] = b < n;
-        ci[t] = A + (int64_t)(vi[t] ? cols[a] : 0) * ld;
-        cj[t] = A + (int64_t)(vj[t] ? cols[b] : 0) * ld;
+        ci[t] = A + (int64_t)(vi[t] ? cols[a] : 0) * ld + fq * RPL;
     }
-    d4g acc[4][4];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int b = j0 + u * 16 + fr;
+        vj[u] = b < n;
+        cj[u] = A + (int64_t)(vj[u] ? cols[b] : 0) * ld + fq * RPL;
+    }
+    d4g acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) acc[t][u] = d4g{0.0, 0.0, 0.0, 0.0};
-    for (int rb = k0; rb < k1; rb += BLK) {
-        const int r0 = rb + fq * RPL;
-        TA ai[4][RPL], bj[4][RPL];
+        for (int u = 0; u < 2; ++u) acc[t][u] = d4g{0.0, 0.0, 0.0, 0.0};
+    TA ca[4][RPL], cb[2][RPL], na[4][RPL], nb[2][RPL];
+    auto fetch = [&](TA (&fa)[4][RPL], TA (&fb)[2][RPL], int rb) {
+        const int lim = k1 - fq * RPL;  // rows rb + e < lim are inside this slice
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) {
-                ai[t][e] = (vi[t] && r0 + e < k1) ? ci[t][r0 + e] : (TA)0;
-                bj[t][e] = (vj[t] && r0 + e < k1) ? cj[t][r0 + e] : (TA)0;
-            }
+            for (int e = 0; e < RPL; ++e) fa[t][e] = (vi[t] && rb + e < lim) ? ci[t][rb + e] : (TA)0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) fb[u][e] = (vj[u] && rb + e < lim) ? cj[u][rb + e] : (TA)0;
+    };
+    if (k0 < k1) fetch(ca, cb, k0);
+    for (int rb = k0; rb < k1; rb += BLK) {
+        if (rb + BLK < k1) fetch(na, nb, rb + BLK);
 #pragma unroll
         for (int kk = 0; kk < RPL; ++kk)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const double b = (double)bj[u][kk];
+            for (int u = 0; u < 2; ++u) {
+                const double b = (double)cb[u][kk];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ai[t][kk], b, acc[t][u], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ca[t][kk], b, acc[t][u], 0, 0, 0);
             }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) ca[t][e] = na[t][e];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int e = 0; e < RPL; ++e) cb[u][e] = nb[u][e];
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
     double* out = Gpart + (int64_t)ks * np * np;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = i0 + t * 16 + fq + 4 * reg, col = j0 + u * 16 + fr;
@@ -146,29 +157,25 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
     if (lane == 0) G[j + (int64_t)n * np] = acc;
 }
 
-// Cholesky step kb, first half: the 32 x 32 diagonal block (every workgroup, redundantly, in the registers of wave 0),
-// then the row panel R[c0 .. c0+31, c] = U^-T G[c0 .. c0+31, c] for this workgroup's 256 columns c >= c0 + 32.
+// Cholesky step kb, first half: the NB x NB diagonal block (every workgroup, redundantly, in the registers of wave 0: lane q
+// owns column q, every dependent step is a v_readlane broadcast + fma), then the row panel
+// R[c0 .. c0+NB-1, c] = U^-T G[c0 .. c0+NB-1, c] by substitution, one thread of waves 1-3 per column c >= c0 + NB.  The
+// panel columns are requested before the diagonal block is factorised: their latency hides behind it.
+constexpr int kCholRowCols = 192;  // panel columns per workgroup (waves 1-3)
 __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
                                                   DevState* st) {
     constexpr int NB = kCholNB;
     __shared__ double Rp[NB * NB];
     __shared__ double rinv[NB];
     const int tid = threadIdx.x, c0 = kb * NB;
-    // this thread's column of the row panel: requested before the diagonal block is factorised (its latency hides there)
-    const int c = c0 + NB + blockIdx.x * 256 + tid;
-    double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;
-    double x[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gcol[p] : 0.0;
     if (tid < kWave) {
         const int q = tid;
         double gq[NB];
-        const double* gc = G + c0 + (int64_t)(c0 + (q < NB ? q : 0)) * np;
+        const double* gc = G + c0 + (int64_t)(c0 + q) * np;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) gq[t] = (q < NB && t <= q) ? gc[t] : 0.0;
-        const double ref = (q < NB && c0 + q < n) ? gdiag[c0 + q] : 0.0;
+        for (int t = 0; t < NB; ++t) gq[t] = (t <= q) ? gc[t] : 0.0;
+        const double ref = (c0 + q < n) ? gdiag[c0 + q] : 0.0;
         int mybad = 0;
-        double ri[NB];
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
             const double d = readlane_f64(gq[p], p);
@@ -177,9 +184,10 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
             double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
             rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
             rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
-            ri[p] = okd ? rs_ : 1.0;
+            const double rip = okd ? rs_ : 1.0;
+            if (q == 0) rinv[p] = rip;
             const double rd = okd ? d * rs_ : 1.0;
-            gq[p] = (q == p) ? rd : gq[p] * ri[p];
+            gq[p] = (q == p) ? rd : gq[p] * rip;
 #pragma unroll
             for (int s_ = p + 1; s_ < NB; ++s_) {
                 const double rps = readlane_f64(gq[p], s_);
@@ -187,40 +195,55 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
             }
         }
         if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
-        if (q < NB) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                if (t <= q) Rp[t * NB + q] = gq[t];
-            if (blockIdx.x == 0) {  // the factored diagonal block, in place
-                double* go = G + c0 + (int64_t)(c0 + q) * np;
-#pragma unroll
-                for (int t = 0; t < NB; ++t)
-                    if (t <= q) go[t] = gq[t];
-            }
-        }
-        if (q == 0) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) rinv[t] = ri[t];
-        }
-    }
-    __syncthreads();
-    if (c >= np) return;
-    double* gc = gcol;
-#pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        double s = x[p];
 #pragma unroll
         for (int t = 0; t < NB; ++t)
-            if (t < p) s = fma(-x[t], Rp[t * NB + p], s);
-        x[p] = s * rinv[p];
+            if (t <= q) Rp[t * NB + q] = gq[t];
+        if (blockIdx.x == 0) {  // the factored diagonal block, in place
+            double* go = G + c0 + (int64_t)(c0 + q) * np;
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                if (t <= q) go[t] = gq[t];
+        }
+        __syncthreads();
+        return;
+    }
+    const int c = c0 + NB + blockIdx.x * kCholRowCols + (tid - kWave);
+    double* gc = G + c0 + (int64_t)(c < np ? c : c0) * np;
+    double x[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gc[p] : 0.0;
+    __syncthreads();
+    if (c >= np) return;
+    // blocked by 16 so that every loop has a small constant trip count (a 64 x 64 triangle is beyond the full-unroll
+    // budget: x[] would become an indexed scratch array)
+#pragma unroll
+    for (int pb = 0; pb < NB; pb += 16) {
+#pragma unroll
+        for (int tb = 0; tb < pb; tb += 16)
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                double s = x[pb + p];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) s = fma(-x[tb + t], Rp[(tb + t) * NB + pb + p], s);
+                x[pb + p] = s;
+            }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            double s = x[pb + p];
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                if (t < p) s = fma(-x[pb + t], Rp[(pb + t) * NB + pb + p], s);
+            x[pb + p] = s * rinv[pb + p];
+        }
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) gc[p] = x[p];
 }
 
-// Cholesky step kb, second half: G[i][j] -= sum_p X[p][i] X[p][j] over the 32 rows X = G[c0 .. c0+31, :] just finished, for
-// the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + 32).  Matrix cores; lane fq takes rows 8 fq .. 8 fq + 7 of
-// X; the accumulators start from G itself and one operand enters negated, so every load is issued before the first MFMA.
+// Cholesky step kb, second half: G[i][j] -= sum_p X[p][i] X[p][j] over the NB rows X = G[c0 .. c0+NB-1, :] just finished,
+// for the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + NB).  Matrix cores; lane fq takes 8 consecutive rows
+// of X per pass (NB / 32 passes); the accumulators start from G itself and one operand enters negated, so the loads of a
+// pass are all issued before its first MFMA.
 __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int np, int kb) {
     constexpr int NB = kCholNB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
@@ -230,26 +253,31 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int 
     while ((J + 1) * (J + 2) / 2 <= p) ++J;
     const int I = p - J * (J + 1) / 2;
     const int cj = t0 + J * kGramTile + wave * 16 + fr;
-    const double* X = G + c0 + fq * 8;
-    double bj[8], ai[4][8];
     d4g acc[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bj[e] = (cj < np) ? X[e + (int64_t)cj * np] : 0.0;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int ci = t0 + I * kGramTile + t * 16 + fr;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? -X[e + (int64_t)ci * np] : 0.0;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg;
             acc[t][reg] = (row < np && cj < np && row <= cj) ? G[row + (int64_t)cj * np] : 0.0;
         }
+#pragma unroll
+    for (int pass = 0; pass < NB / 32; ++pass) {
+        const double* X = G + c0 + pass * 32 + fq * 8;
+        double bj[8], ai[4][8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bj[e] = (cj < np) ? X[e + (int64_t)cj * np] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int ci = t0 + I * kGramTile + t * 16 + fr;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? -X[e + (int64_t)ci * np] : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[t][kk], bj[kk], acc[t], 0, 0, 0);
     }
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk)
-#pragma unroll
-        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ai[t][kk], bj[kk], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
