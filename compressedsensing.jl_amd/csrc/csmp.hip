@@ -1831,10 +1831,14 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
 
 // ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
 static int gram_split_for(const csmp_ctx* ctx, int np) {
-    const int TJ = np / kGramWgJ, TI = (np + kGramWgI - 1) / kGramWgI, pairs = std::max(1, TJ * TI * 5 / 8);  // (pieces on or above the diagonal)
-    const int blk = 16;  // rows per k_gram block
-    int nsplit = std::max(1, (3 * ctx->prop.multiProcessorCount + pairs - 1) / pairs);  // about three workgroups per CU
-    nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / (4 * blk))));       // at least four blocks of rows each
+    // pieces of k_gram on or above the diagonal; the rows are split so that ONE round of workgroups (two per CU) covers them:
+    // a second, partly filled round would cost as much as a full one
+    const int TJ = np / kGramWgJ;
+    int pieces = 0;
+    for (int J = 0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
+    const int slots = 2 * ctx->prop.multiProcessorCount;
+    int nsplit = std::max(1, slots / std::max(1, pieces));
+    nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
     return std::min(nsplit, 32);
 }
 static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {

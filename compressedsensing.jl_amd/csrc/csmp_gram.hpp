@@ -9,7 +9,7 @@
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
 //   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
-//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 64 columns per step: the 64 x 64 diagonal
+//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 32 columns per step: the 32 x 32 diagonal
 //                 block in the registers of one wave (the v_readlane scheme of k_blk3), the row panel by substitution (one
 //                 thread per column), the trailing update on the matrix cores.  The bordered column comes out as
 //                 z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
@@ -29,7 +29,7 @@ namespace csmp {
 
 using d4g = __attribute__((ext_vector_type(4))) double;
 constexpr int kGramTile = 64;   // G tile edge per workgroup
-constexpr int kCholNB = 64;     // columns per Cholesky step
+constexpr int kCholNB = 32;     // columns per Cholesky step (64: the unrolled in-register factorisation outgrows the instruction cache -- 203 us per step against 19)
 
 constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
 constexpr int kGramWgI = 128;  // G rows per workgroup (k_gram): 2 x 2 waves, each 64 rows x 32 columns
