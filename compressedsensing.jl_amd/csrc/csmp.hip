@@ -1839,6 +1839,7 @@ static int gram_split_for(const csmp_ctx* ctx, int np) {
     const int slots = 2 * ctx->prop.multiProcessorCount;
     int nsplit = std::max(1, slots / std::max(1, pieces));
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
+    if (const char* e = getenv("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
     return std::min(nsplit, 32);
 }
 static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
@@ -1868,6 +1869,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     const int n = (int)cols.size(), M = (int)ctx->M;
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int nsplit = gram_split_for(ctx, np);
+    if (getenv("CSMP_GRAM_DEBUG")) fprintf(stderr, "ls_gram: n %d np %d nsplit %d M %d\n", n, np, nsplit, M);
     CHECK(gram_ensure(ctx, np, nsplit));
     CHECK(solver_restart(ctx));
     HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));

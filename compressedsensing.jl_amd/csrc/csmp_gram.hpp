@@ -168,13 +168,21 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
     __shared__ double Rp[NB * NB];
     __shared__ double rinv[NB];
     const int tid = threadIdx.x, c0 = kb * NB;
+    // waves 1-3: this thread's column of the row panel, requested before the barrier (its latency hides behind the
+    // factorisation of the diagonal block in wave 0)
+    const int c = c0 + NB + blockIdx.x * kCholRowCols + (tid - kWave);
+    const bool mine = tid >= kWave && c < np;
+    double* gc = G + c0 + (int64_t)(mine ? c : c0) * np;
+    double x[NB];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) x[p] = mine ? gc[p] : 0.0;
     if (tid < kWave) {
         const int q = tid;
         double gq[NB];
-        const double* gc = G + c0 + (int64_t)(c0 + q) * np;
+        const double* gd = G + c0 + (int64_t)(c0 + (q < NB ? q : 0)) * np;  // (lanes beyond the block idle along)
 #pragma unroll
-        for (int t = 0; t < NB; ++t) gq[t] = (t <= q) ? gc[t] : 0.0;
-        const double ref = (c0 + q < n) ? gdiag[c0 + q] : 0.0;
+        for (int t = 0; t < NB; ++t) gq[t] = (q < NB && t <= q) ? gd[t] : 0.0;
+        const double ref = (q < NB && c0 + q < n) ? gdiag[c0 + q] : 0.0;
         int mybad = 0;
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
@@ -197,23 +205,16 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
         if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
 #pragma unroll
         for (int t = 0; t < NB; ++t)
-            if (t <= q) Rp[t * NB + q] = gq[t];
-        if (blockIdx.x == 0) {  // the factored diagonal block, in place
+            if (q < NB && t <= q) Rp[t * NB + q] = gq[t];
+        if (blockIdx.x == 0 && q < NB) {  // the factored diagonal block, in place
             double* go = G + c0 + (int64_t)(c0 + q) * np;
 #pragma unroll
             for (int t = 0; t < NB; ++t)
                 if (t <= q) go[t] = gq[t];
         }
-        __syncthreads();
-        return;
     }
-    const int c = c0 + NB + blockIdx.x * kCholRowCols + (tid - kWave);
-    double* gc = G + c0 + (int64_t)(c < np ? c : c0) * np;
-    double x[NB];
-#pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gc[p] : 0.0;
-    __syncthreads();
-    if (c >= np) return;
+    __syncthreads();  // (one call site for the whole workgroup)
+    if (!mine) return;
     // blocked by 16 so that every loop has a small constant trip count (a 64 x 64 triangle is beyond the full-unroll
     // budget: x[] would become an indexed scratch array)
 #pragma unroll
