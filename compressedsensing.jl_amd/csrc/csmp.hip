@@ -77,6 +77,7 @@ struct Batch {
     int n_atiles = 0;
     float* amax = nullptr;  // max |A_ij| (device scalar) for the screening error bound
     float amax_host = 0.f;
+    float anorm_host = -1.f;  // max column 2-norm (the deterministic bound, CSMP_CERT=rigorous), computed on first use
     // per-batch buffers
     int Bcap = 0, kcap = 0, Mr = 0;
     __bf16* Rb = nullptr;
@@ -226,6 +227,7 @@ static void batch_free(Batch& b, bool keep_dict) {
         dfree(b.Ab);
         dfree(b.amax);
         b.ab_valid = false;
+        b.anorm_host = -1.f;
     }
 }
 
@@ -2670,6 +2672,21 @@ __global__ void k_absmax_f64(const double* __restrict__ A, int64_t n, float* out
     if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m * 1.0000002f));
 }
 
+// max_j |a_j|_2 (rounded up), one wave per column
+template <typename TA>
+__global__ __launch_bounds__(256) void k_colnorm_max(const TA* __restrict__ A, int64_t ld, int M, int64_t N, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    double acc = 0.0;
+    for (int m = lane; m < M; m += 64) {
+        const double v = (double)A[col * ld + m];
+        acc = fma(v, v, acc);
+    }
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint((float)sqrt(acc) * 1.0000002f));
+}
+
 static int batch_dict(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
     if (b.ab_valid) return CSMP_OK;
@@ -2800,8 +2817,28 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     HIPCHECK(hipGetLastError());
     // 256^2 tiles with LDS-DMA staging whenever both edges tile by 256 (knob CSMP_SCREEN_128: the 128^2 kernel)
     const bool big = !getenv("CSMP_SCREEN_128") && (b.n_atiles % 2 == 0) && (n_stiles % 2 == 0);
-    // screening error bound (8 sigma of the bf16 rounding model): delta = coef * ||r||
-    const double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+    // Screening error bound delta = coef * ||r||.  Default: 8 sigma of the bf16 rounding model (independent roundings of
+    // the M products) -- a PROBABILISTIC certificate; structured dictionaries whose rounding errors add
+    // coherently are outside that model.  CSMP_CERT=rigorous: the deterministic bound
+    // |<a,r> - screened| <= (2^-7 (1 + 2^-9) + M 2^-24) |a|_2 |r|_2 (bf16 unit roundoff 2^-8 on both operands, Float32
+    // accumulation), eight times wider: more signals go to the exact path.
+    double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+    if (const char* ce = getenv("CSMP_CERT")) {
+        if (ce[0] == 'r') {
+            if (b.anorm_host < 0.f) {
+                HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+                const unsigned grid = (unsigned)((ctx->N + 3) / 4);
+                if (ctx->dtype == CSMP_F32)
+                    hipLaunchKernelGGL(k_colnorm_max<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+                else
+                    hipLaunchKernelGGL(k_colnorm_max<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+                HIPCHECK(hipGetLastError());
+                HIPCHECK(hipMemcpyAsync(&b.anorm_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHECK(hipStreamSynchronize(ctx->stream));
+            }
+            cert_coef = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+        }
+    }
     // Two half-batches on two streams: the screening GEMM of one half (matrix cores) runs beside the rescoring /
     // append kernel of the other (HBM gathers).  The halves never touch each other's data; each stream is the plain
     // chain screen -> step -> screen -> ... of its own signals.  Kernels of the SAME kind cannot share a CU (two

@@ -162,10 +162,14 @@ int csmp_fr_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
  * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
  * SCREENS 16 candidates per signal; those are rescored in Float64 from the f32/f64 master
- * dictionary, so selections and coefficients equal csmp_omp_batch's.  A signal whose screen cannot
- * be certified against the bf16 error bound is re-solved by the exact path before returning.
- * Requires M <= 8192.  With out_loc == CSMP_DEVICE this call still synchronises once (to read the
- * per-signal certificates). */
+ * dictionary, and a certificate (exact best > best screened value outside the list + an error bound)
+ * guards every step: a signal that fails it once is re-solved by the exact path before returning, so a
+ * certified result equals csmp_omp_batch's.  The DEFAULT error bound is statistical -- 8 standard deviations
+ * of independent bf16 roundings -- which holds for generic (e.g. Gaussian) dictionaries but is not a proof for
+ * structured ones whose rounding errors add coherently; the environment variable CSMP_CERT=rigorous selects
+ * the deterministic bound (2^-7 + M 2^-24) max|a_j| |r| instead (about 8x wider: more signals take the exact
+ * path, none can slip through).  Requires M <= 8192.  With out_loc == CSMP_DEVICE this call still
+ * synchronises once (to read the per-signal certificates). */
 int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                         double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 /* statistics of the last csmp_omp_batch_mfma call: signals, how many were re-solved exactly (and
