@@ -1838,7 +1838,7 @@ static int gram_split_for(const csmp_ctx* ctx, int np) {
     const int TJ = np / kGramWgJ;
     int pieces = 0;
     for (int J = 0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
-    const int slots = 2 * ctx->prop.multiProcessorCount;
+    const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
     int nsplit = std::max(1, slots / std::max(1, pieces));
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
     if (const char* e = getenv("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
