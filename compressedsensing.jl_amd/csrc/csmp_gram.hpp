@@ -203,10 +203,11 @@ __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np
     const int c = c0 + NB + blockIdx.x * kCholRowCols + (tid - kWave);
     const bool mine = tid >= kWave && c < np;
     double* gc = G + c0 + (int64_t)(mine ? c : c0) * np;
-    double x[NB];
+    double x[NB];  // (defined in waves 1-3 only: in wave 0 its registers are free for the factorisation)
+    if (tid >= kWave) {
 #pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = mine ? gc[p] : 0.0;
-    if (tid < kWave) {
+        for (int p = 0; p < NB; ++p) x[p] = mine ? gc[p] : 0.0;
+    } else {
         const int q = tid, fr = q & 15, fq = q >> 4;
         double gt[32], gb[32];
         const double* gd = G + c0 + (int64_t)(c0 + q) * np;
