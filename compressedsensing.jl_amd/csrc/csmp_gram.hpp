@@ -9,7 +9,7 @@
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
 //   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
-//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 64 columns per step: the 64 x 64 diagonal
+//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 32 columns per step: the 32 x 32 diagonal
 //                 block in the registers of one wave (the v_readlane scheme of k_blk3), the row panel by substitution (one
 //                 thread per column), the trailing update on the matrix cores.  The bordered column comes out as
 //                 z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
@@ -29,7 +29,9 @@ namespace csmp {
 
 using d4g = __attribute__((ext_vector_type(4))) double;
 constexpr int kGramTile = 64;   // G tile edge per workgroup
-constexpr int kCholNB = 64;     // columns per Cholesky step
+constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twice: a straight 64-step elimination in one wave is 110 KiB of
+                                // unrolled code, 203 us per step; two levels of 32 with an MFMA update in between, 63 us -- against 19 + 11 us
+                                // for two steps of 32: the unrolled substitution and factorisation together outgrow the instruction cache.)
 
 constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
 constexpr int kGramWgI = 128;  // G rows per workgroup (k_gram): 2 x 2 waves, each 64 rows x 32 columns
@@ -158,137 +160,74 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
     if (lane == 0) G[j + (int64_t)n * np] = acc;
 }
 
-// Right-looking elimination of 32 rows of a column block held one column per lane: g[t] = row t of this lane's column
-// (lanes LANE0 .. 63 take part; lane LANE0 + p owns the pivot of step p).  Every dependent step is a v_readlane broadcast
-// (unrolled, constant lane numbers) + fma: no LDS round trips, no barriers.  Leaves rows of U in g; 1/U[p][p] -> rinv_out[p].
-template <int LANE0>
-__device__ __forceinline__ void chol_rows32(double (&g)[32], const int q, const int col0, const int n, const double ref, int& mybad,
-                                            double* rinv_out) {
-#pragma unroll
-    for (int p = 0; p < 32; ++p) {
-        const double d = readlane_f64(g[p], LANE0 + p);
-        if (q == LANE0 + p && col0 + p < n && (!(d > 0.0) || !(d >= 0.5 * ref))) mybad = 1;  // DGKS: too much cancellation
-        const bool okd = d > 0.0 && d < 1e300;
-        double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
-        rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
-        rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
-        const double rip = okd ? rs_ : 1.0;
-        if (q == 0) rinv_out[p] = rip;
-        const double rd = okd ? d * rs_ : 1.0;
-        g[p] = (q == LANE0 + p) ? rd : g[p] * rip;
-#pragma unroll
-        for (int s_ = p + 1; s_ < 32; ++s_) {
-            const double rps = readlane_f64(g[p], LANE0 + s_);
-            if (q >= LANE0 + s_) g[s_] = fma(-rps, g[p], g[s_]);
-        }
-    }
-}
-
-// Cholesky step kb, first half: the 64 x 64 diagonal block D = [D11 D12; . D22] (every workgroup, redundantly, in wave 0:
-// lane q owns column q), in two levels -- a straight 64-step elimination would be 110 KiB of unrolled code and ran ten
-// times slower than two of 32 --: (1) 32 elimination steps on the top 32 rows of all 64 columns give U11 (lanes 0-31) and
-// U12 (lanes 32-63); (2) D22 -= U12' U12 on the matrix cores (operands and result cross the lanes through LDS);
-// (3) 32 elimination steps on D22 in lanes 32-63.  Then the row panel R[c0 .. c0+63, c] = U^-T G[c0 .. c0+63, c] by
-// substitution, one thread of waves 1-3 per column c >= c0 + 64; the panel columns are requested before the barrier.
-constexpr int kCholRowCols = 192;  // panel columns per workgroup (waves 1-3)
+// Cholesky step kb, first half: the 32 x 32 diagonal block (every workgroup, redundantly, in the registers of wave 0),
+// then the row panel R[c0 .. c0+31, c] = U^-T G[c0 .. c0+31, c] for this workgroup's 256 columns c >= c0 + 32.
+constexpr int kCholRowCols = 256;  // panel columns per workgroup
 __global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
                                                   DevState* st) {
     constexpr int NB = kCholNB;
-    static_assert(NB == 64, "two levels of 32");
     __shared__ double Rp[NB * NB];
     __shared__ double rinv[NB];
-    __shared__ double Us[32 * 33];  // U12 [row p][column j] (stride 33: conflict-free both ways)
-    __shared__ double Cs[32 * 33];  // U12' U12 [i][j]
     const int tid = threadIdx.x, c0 = kb * NB;
-    const int c = c0 + NB + blockIdx.x * kCholRowCols + (tid - kWave);
-    const bool mine = tid >= kWave && c < np;
-    double* gc = G + c0 + (int64_t)(mine ? c : c0) * np;
-    double x[NB];  // (defined in waves 1-3 only: in wave 0 its registers are free for the factorisation)
-    if (tid >= kWave) {
+    // this thread's column of the row panel: requested before the diagonal block is factorised (its latency hides there)
+    const int c = c0 + NB + blockIdx.x * 256 + tid;
+    double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;
+    double x[NB];
 #pragma unroll
-        for (int p = 0; p < NB; ++p) x[p] = mine ? gc[p] : 0.0;
-    } else {
-        const int q = tid, fr = q & 15, fq = q >> 4;
-        double gt[32], gb[32];
-        const double* gd = G + c0 + (int64_t)(c0 + q) * np;
+    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gcol[p] : 0.0;
+    if (tid < kWave) {
+        const int q = tid;
+        double gq[NB];
+        const double* gc = G + c0 + (int64_t)(c0 + (q < NB ? q : 0)) * np;
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            gt[t] = (t <= q) ? gd[t] : 0.0;
-            gb[t] = (32 + t <= q) ? gd[32 + t] : 0.0;
-        }
-        const double ref = (c0 + q < n) ? gdiag[c0 + q] : 0.0;
+        for (int t = 0; t < NB; ++t) gq[t] = (q < NB && t <= q) ? gc[t] : 0.0;
+        const double ref = (q < NB && c0 + q < n) ? gdiag[c0 + q] : 0.0;
         int mybad = 0;
-        chol_rows32<0>(gt, q, c0, n, ref, mybad, rinv);  // (1)
-        // (2) U12 -> LDS, C = U12' U12 (two 16-column tiles each way, K = 32), C -> LDS, D22 -= C
-        if (q >= 32) {
+        double ri[NB];
 #pragma unroll
-            for (int p = 0; p < 32; ++p) Us[p * 33 + (q - 32)] = gt[p];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (one wave: program order is enough, no barrier)
-        d4g acc[2][2];
+        for (int p = 0; p < NB; ++p) {
+            const double d = readlane_f64(gq[p], p);
+            if (q == p && c0 + p < n && (!(d > 0.0) || !(d >= 0.5 * ref))) mybad = 1;  // DGKS: too much cancellation
+            const bool okd = d > 0.0 && d < 1e300;
+            double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            ri[p] = okd ? rs_ : 1.0;
+            const double rd = okd ? d * rs_ : 1.0;
+            gq[p] = (q == p) ? rd : gq[p] * ri[p];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = d4g{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const double u0 = Us[(4 * kk + fq) * 33 + fr], u1 = Us[(4 * kk + fq) * 33 + fr + 16];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u0, u1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(u1, u1, acc[1][1], 0, 0, 0);
-        }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) Cs[(16 * a + fq + 4 * reg) * 33 + 16 * b2 + fr] = acc[a][b2][reg];  // C[i][j]
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (q >= 32) {
-#pragma unroll
-            for (int t = 0; t < 32; ++t)
-                if (32 + t <= q) gb[t] -= Cs[t * 33 + (q - 32)];
-        }
-        chol_rows32<32>(gb, q, c0 + 32, n, ref, mybad, rinv + 32);  // (3)
-        if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
-#pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            if (t <= q) Rp[t * NB + q] = gt[t];
-            if (32 + t <= q) Rp[(32 + t) * NB + q] = gb[t];
-        }
-        if (blockIdx.x == 0) {  // the factored diagonal block, in place
-            double* go = G + c0 + (int64_t)(c0 + q) * np;
-#pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                if (t <= q) go[t] = gt[t];
-                if (32 + t <= q) go[32 + t] = gb[t];
+            for (int s_ = p + 1; s_ < NB; ++s_) {
+                const double rps = readlane_f64(gq[p], s_);
+                gq[s_] = fma(-rps, gq[p], gq[s_]);  // (every lane: what lands below the diagonal, q < s_, is never read)
             }
+        }
+        if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
+        if (q < NB) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                if (t <= q) Rp[t * NB + q] = gq[t];
+            if (blockIdx.x == 0) {  // the factored diagonal block, in place
+                double* go = G + c0 + (int64_t)(c0 + q) * np;
+#pragma unroll
+                for (int t = 0; t < NB; ++t)
+                    if (t <= q) go[t] = gq[t];
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) rinv[t] = ri[t];
         }
     }
-    __syncthreads();  // (one call site for the whole workgroup)
-    if (!mine) return;
-    // blocked by 16 so that every loop has a small constant trip count (a 64 x 64 triangle is beyond the full-unroll
-    // budget: x[] would become an indexed scratch array)
+    __syncthreads();
+    if (c >= np) return;
+    double* gc = gcol;
 #pragma unroll
-    for (int pb = 0; pb < NB; pb += 16) {
+    for (int p = 0; p < NB; ++p) {
+        double s = x[p];
 #pragma unroll
-        for (int tb = 0; tb < pb; tb += 16)
-#pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                double s = x[pb + p];
-#pragma unroll
-                for (int t = 0; t < 16; ++t) s = fma(-x[tb + t], Rp[(tb + t) * NB + pb + p], s);
-                x[pb + p] = s;
-            }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            double s = x[pb + p];
-#pragma unroll
-            for (int t = 0; t < 16; ++t)
-                if (t < p) s = fma(-x[pb + t], Rp[(pb + t) * NB + pb + p], s);
-            x[pb + p] = s * rinv[pb + p];
-        }
+        for (int t = 0; t < NB; ++t)
+            if (t < p) s = fma(-x[t], Rp[t * NB + p], s);
+        x[p] = s * rinv[p];
     }
 #pragma unroll
     for (int p = 0; p < NB; ++p) gc[p] = x[p];
