@@ -64,6 +64,7 @@ struct Solver {
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
+    void* Acomp = nullptr;  // the set's columns, contiguous (np columns of Mv elements of the dictionary's type)
     int gram_np = 0, gram_split = 0;
     void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
 };
@@ -251,7 +252,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp);
     s = Solver();
 }
 
@@ -1850,12 +1851,13 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp);
     s.gram_np = s.gram_split = 0;
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
     CHECK(dmalloc(ctx, &s.rpart, (size_t)((np + kResChunk - 1) / kResChunk) * s.Mpad));
+    HIPCHECK(hipMalloc(&s.Acomp, (size_t)np * (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8)));
     s.gram_np = np;
     s.gram_split = nsplit;
     return CSMP_OK;
@@ -1879,8 +1881,17 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
     const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
-    hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands, n,
-                       np, rps, s.Gpart);
+    const bool compact = !getenv("CSMP_GRAM_NO_COMPACT");
+    if (compact) {
+        constexpr int VEC = 16 / sizeof(TA);
+        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((ctx->Mv / VEC + 255) / 256, n), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                           (const int*)s.cands, (TA*)s.Acomp, (int64_t)ctx->Mv);
+        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp,
+                           (int64_t)ctx->Mv, M, (const int*)nullptr, n, np, rps, s.Gpart);
+    } else {
+        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                           (const int*)s.cands, n, np, rps, s.Gpart);
+    }
     HIPCHECK(hipGetLastError());
     const int64_t nel = (int64_t)np * np;
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,

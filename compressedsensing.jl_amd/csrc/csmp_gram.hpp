@@ -33,6 +33,22 @@ constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twi
                                 // unrolled code, 203 us per step; two levels of 32 with an MFMA update in between, 63 us -- against 19 + 11 us
                                 // for two steps of 32: the unrolled substitution and factorisation together outgrow the instruction cache.)
 
+// The n columns of the set, copied into one contiguous M x n block (column j at j * ldo): k_gram touches 96 columns per
+// wave and block of rows, 16 bytes of each -- out of the dictionary itself (4 GiB at config 5, every column on pages of
+// its own) that is an address-translation miss per access; out of a compact 32 MiB copy it is not.
+template <typename TA>
+__global__ __launch_bounds__(256) void k_gather_cols(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols,
+                                                     TA* __restrict__ out, int64_t ldo) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    const int j = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;  // vector index within the column
+    if (v * VEC >= M) return;
+    const VT* src = reinterpret_cast<const VT*>(A + (int64_t)cols[j] * ld);
+    VT* dst = reinterpret_cast<VT*>(out + (int64_t)j * ldo);
+    dst[v] = src[v];
+}
+
 constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
 constexpr int kGramWgI = 128;  // G rows per workgroup (k_gram): 2 x 2 waves, each 64 rows x 32 columns
 constexpr int kGramWgJ = 64;   // G columns per workgroup
@@ -60,13 +76,13 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
     for (int t = 0; t < 4; ++t) {
         const int a = i0 + t * 16 + fr;
         vi[t] = a < n;
-        ci[t] = A + (int64_t)(vi[t] ? cols[a] : 0) * ld + fq * RPL;
+        ci[t] = A + (int64_t)(vi[t] ? (cols ? cols[a] : a) : 0) * ld + fq * RPL;
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int b = j0 + u * 16 + fr;
         vj[u] = b < n;
-        cj[u] = A + (int64_t)(vj[u] ? cols[b] : 0) * ld + fq * RPL;
+        cj[u] = A + (int64_t)(vj[u] ? (cols ? cols[b] : b) : 0) * ld + fq * RPL;
     }
     d4g acc[4][2];
 #pragma unroll
