@@ -1857,7 +1857,7 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
     CHECK(dmalloc(ctx, &s.rpart, (size_t)((np + kResChunk - 1) / kResChunk) * s.Mpad));
-    HIPCHECK(hipMalloc(&s.Acomp, (size_t)np * (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8)));
+    HIPCHECK(hipMalloc(&s.Acomp, (size_t)np * (size_t)((ctx->M + 15) / 16 * 16) * (ctx->dtype == CSMP_F32 ? 4 : 8)));
     s.gram_np = np;
     s.gram_split = nsplit;
     return CSMP_OK;
@@ -1881,17 +1881,11 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
     const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
-    const bool compact = !getenv("CSMP_GRAM_NO_COMPACT");
-    if (compact) {
-        constexpr int VEC = 16 / sizeof(TA);
-        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((ctx->Mv / VEC + 255) / 256, n), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                           (const int*)s.cands, (TA*)s.Acomp, (int64_t)ctx->Mv);
-        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp,
-                           (int64_t)ctx->Mv, M, (const int*)nullptr, n, np, rps, s.Gpart);
-    } else {
-        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
-                           (const int*)s.cands, n, np, rps, s.Gpart);
-    }
+    const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
+    hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)((ldo + 255) / 256), np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                       (const int*)s.cands, n, (TA*)s.Acomp, ldo);
+    hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
+                       rps, s.Gpart);
     HIPCHECK(hipGetLastError());
     const int64_t nel = (int64_t)np * np;
     hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,

@@ -33,73 +33,57 @@ constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twi
                                 // unrolled code, 203 us per step; two levels of 32 with an MFMA update in between, 63 us -- against 19 + 11 us
                                 // for two steps of 32: the unrolled substitution and factorisation together outgrow the instruction cache.)
 
-// The n columns of the set, copied into one contiguous M x n block (column j at j * ldo): k_gram touches 96 columns per
-// wave and block of rows, 16 bytes of each -- out of the dictionary itself (4 GiB at config 5, every column on pages of
-// its own) that is an address-translation miss per access; out of a compact 32 MiB copy it is not.
+// The n columns of the set, copied into one contiguous block: column j at j * ldo, ldo = M rounded up to 16 rows, zero rows
+// beyond M and zero columns from n to np.  k_gram touches 96 columns per wave and block of rows, 16 bytes of each: from the
+// compact copy every one of those is an unconditional, aligned 16-byte load (no bounds logic in the loop), and the 32 MiB
+// of a 1024-column set at config 5 sit on a handful of pages instead of one page per access.
 template <typename TA>
-__global__ __launch_bounds__(256) void k_gather_cols(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols,
+__global__ __launch_bounds__(256) void k_gather_cols(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
                                                      TA* __restrict__ out, int64_t ldo) {
-    using VT = typename Vec<TA>::type;
-    constexpr int VEC = Vec<TA>::n;
     const int j = blockIdx.y;
-    const int v = blockIdx.x * 256 + threadIdx.x;  // vector index within the column
-    if (v * VEC >= M) return;
-    const VT* src = reinterpret_cast<const VT*>(A + (int64_t)cols[j] * ld);
-    VT* dst = reinterpret_cast<VT*>(out + (int64_t)j * ldo);
-    dst[v] = src[v];
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= ldo) return;
+    out[(int64_t)j * ldo + r] = (j < n && r < M) ? A[(int64_t)cols[j] * ld + r] : (TA)0;
 }
 
 constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
 constexpr int kGramWgI = 128;  // G rows per workgroup (k_gram): 2 x 2 waves, each 64 rows x 32 columns
 constexpr int kGramWgJ = 64;   // G columns per workgroup
 
-// One (128-row block I, 64-column block J) piece of the upper triangle x one slice of the dictionary rows.  4 waves as
-// 2 x 2, each a 64 x 32 piece = 4 x 2 MFMA tiles (64 accumulator registers).  Lane (fr = l & 15, fq = l >> 4) loads 4
-// consecutive rows (block base + 4 fq) of column fr of each 16-column group; MFMA step kk multiplies row (base + 4 fq + kk)
-// of both operands: a permutation of the summation index, the same on both sides.  The fragments of the NEXT block of
-// rows are requested before the current block's 32 MFMAs are issued (two register sets), so the matrix cores do not wait
-// for L2: operands come straight from global memory, no LDS, no barriers.  Three workgroups per CU (f32: 140 registers):
+// One (128-row block I, 64-column block J) piece of the upper triangle x one slice of the rows, on the compact copy Ac.
+// 4 waves as 2 x 2, each a 64 x 32 piece = 4 x 2 MFMA tiles (64 accumulator registers).  Lane (fr = l & 15, fq = l >> 4)
+// loads 4 consecutive rows (block base + 4 fq) of column fr of each 16-column group; MFMA step kk multiplies row
+// (base + 4 fq + kk) of both operands: a permutation of the summation index, the same on both sides.  The fragments of the
+// NEXT block of rows are requested before the current block's 32 MFMAs are issued (two register sets), so the matrix
+// cores do not wait for L2: operands come straight from global memory, no LDS, no barriers.  Three workgroups per CU (f32):
 // one wave per SIMD cannot issue Float64 MFMAs back to back (measured: 35 TFLOP/s with one, 47 with two waves per SIMD).
 template <typename TA>
-__global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
-                                              int np, int rows_per_split, double* __restrict__ Gpart) {
+__global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const TA* __restrict__ Ac, int64_t ldo, int np,
+                                                                         int rows_per_split, double* __restrict__ Gpart) {
     constexpr int RPL = kGramRpl, BLK = 4 * RPL;
+    struct alignas(sizeof(TA) * RPL) Frag { TA v[RPL]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
     const int I = blockIdx.y, J = blockIdx.x, ks = blockIdx.z;
     if (I * kGramWgI > J * kGramWgJ + kGramWgJ - 1) return;  // entirely below the diagonal
-    const int k0 = ks * rows_per_split, k1 = min(M, k0 + rows_per_split);
+    const int k0 = ks * rows_per_split, k1 = (int)min((int64_t)ldo, (int64_t)k0 + rows_per_split);
     const int i0 = I * kGramWgI + wi * 64, j0 = J * kGramWgJ + wj * 32;
     const TA *ci[4], *cj[2];
-    bool vi[4], vj[2];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int a = i0 + t * 16 + fr;
-        vi[t] = a < n;
-        ci[t] = A + (int64_t)(vi[t] ? (cols ? cols[a] : a) : 0) * ld + fq * RPL;
-    }
+    for (int t = 0; t < 4; ++t) ci[t] = Ac + (int64_t)min(i0 + t * 16 + fr, np - 1) * ldo + fq * RPL;  // (rows >= np: clamped, never stored)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int b = j0 + u * 16 + fr;
-        vj[u] = b < n;
-        cj[u] = A + (int64_t)(vj[u] ? (cols ? cols[b] : b) : 0) * ld + fq * RPL;
-    }
+    for (int u = 0; u < 2; ++u) cj[u] = Ac + (int64_t)min(j0 + u * 16 + fr, np - 1) * ldo + fq * RPL;
     d4g acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u) acc[t][u] = d4g{0.0, 0.0, 0.0, 0.0};
-    TA ca[4][RPL], cb[2][RPL], na[4][RPL], nb[2][RPL];
-    auto fetch = [&](TA (&fa)[4][RPL], TA (&fb)[2][RPL], int rb) {
-        const int lim = k1 - fq * RPL;  // rows rb + e < lim are inside this slice
+    Frag ca[4], cb[2], na[4], nb[2];
+    auto fetch = [&](Frag (&fa)[4], Frag (&fb)[2], int rb) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) fa[t] = *reinterpret_cast<const Frag*>(ci[t] + rb);
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) fa[t][e] = (vi[t] && rb + e < lim) ? ci[t][rb + e] : (TA)0;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) fb[u][e] = (vj[u] && rb + e < lim) ? cj[u][rb + e] : (TA)0;
+        for (int u = 0; u < 2; ++u) fb[u] = *reinterpret_cast<const Frag*>(cj[u] + rb);
     };
     if (k0 < k1) fetch(ca, cb, k0);
     for (int rb = k0; rb < k1; rb += BLK) {
@@ -108,18 +92,14 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
         for (int kk = 0; kk < RPL; ++kk)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const double b = (double)cb[u][kk];
+                const double b = (double)cb[u].v[kk];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ca[t][kk], b, acc[t][u], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) acc[t][u] = __builtin_amdgcn_mfma_f64_16x16x4f64((double)ca[t].v[kk], b, acc[t][u], 0, 0, 0);
             }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) ca[t] = na[t];
 #pragma unroll
-            for (int e = 0; e < RPL; ++e) ca[t][e] = na[t][e];
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int e = 0; e < RPL; ++e) cb[u][e] = nb[u][e];
+        for (int u = 0; u < 2; ++u) cb[u] = nb[u];
     }
     // C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg
     double* out = Gpart + (int64_t)ks * np * np;
