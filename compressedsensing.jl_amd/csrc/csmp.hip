@@ -64,6 +64,7 @@ struct Solver {
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
+    std::vector<int> hcols;  // host copy of the column list an asynchronous upload reads from (kept until the next one)
     void* Acomp = nullptr;  // the set's columns, contiguous (np columns of Mv elements of the dictionary's type)
     int gram_np = 0, gram_split = 0;
     void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
@@ -1876,9 +1877,10 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     if (getenv("CSMP_GRAM_DEBUG")) fprintf(stderr, "ls_gram: n %d np %d nsplit %d M %d\n", n, np, nsplit, M);
     CHECK(gram_ensure(ctx, np, nsplit));
     CHECK(solver_restart(ctx));
-    HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (cols may be a temporary of the caller)
+    s.hcols.assign(cols.begin(), cols.end());  // (cols may be a temporary of the caller; this copy lives until the next call)
+    s.hcols.push_back(n);
+    HIPCHECK(hipMemcpyAsync(s.cands, s.hcols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, s.hcols.data() + n, 4, hipMemcpyHostToDevice, ctx->stream));
     const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
     const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
