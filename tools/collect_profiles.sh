@@ -29,7 +29,7 @@ d1=$(pmc fetch FETCH_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 d2=$(pmc write WRITE_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 python3 $R/tools/pmc_traffic.py $d1 $d2 > $OUT/sweep_traffic.json
 # matrix-core counters of the screening kernel
-d3=$(pmc mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVES" --workload batched --steps 1 --warmup 0)
+d3=$(pmc mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload batched --steps 1 --warmup 0)
 python3 - "$d3" > $OUT/batched_mfma_pmc.json <<'PY'
 import csv, glob, json, os, sys
 acc = {}
@@ -39,9 +39,10 @@ for f in glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), r
             continue
         acc.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 out = {k: {"dispatches": len(v), "avg": sum(v) / len(v)} for k, v in acc.items()}
-if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "SQ_BUSY_CYCLES" in out:
-    # SQ_BUSY_CYCLES is summed over the 32 SQ instances (8 XCDs x 4 shader engines); MFMA busy over the 256 CUs' 4 SIMDs
-    out["note"] = "utilisation = MFMA_BUSY / (kernel cycles x 1024 SIMDs); see profiles/README.md"
+if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 256 CUs x 4 SIMDs
+    out["mfma_util"] = out["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (out["GRBM_GUI_ACTIVE"]["avg"] / 8.0 * 1024.0)
+    out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (a launch covers one half-batch)"
 print(json.dumps(out, indent=1))
 PY
 ls -la $OUT
