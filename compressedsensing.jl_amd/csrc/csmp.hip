@@ -2846,12 +2846,15 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
             cert_coef = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
         }
     }
-    // Two half-batches on two streams: the screening GEMM of one half (matrix cores) runs beside the rescoring /
-    // append kernel of the other (HBM gathers).  The halves never touch each other's data; each stream is the plain
-    // chain screen -> step -> screen -> ... of its own signals.  Kernels of the SAME kind cannot share a CU (two
-    // screening workgroups exceed its LDS), so the two chains fall out of phase by themselves.
+    // CSMP_BATCH_STREAMS=2: two half-batches on two streams, so that the screening GEMM of one half (matrix cores) could
+    // run beside the rescoring / append kernel of the other (HBM gathers); each stream is the plain chain
+    // screen -> step -> screen -> ... of its own signals.  Measured at config 3: the plain kernels each fill
+    // a CU alone (LDS, registers), the two chains merely interleave and the batch gains 1.4 % -- while the per-launch
+    // timing of the screening kernel (HIP events on its stream) then also counts the time it queues behind the other
+    // stream's kernel.  Off by default; the pair that CAN share a CU is CSMP_BATCH_CO=1 (below).
     const int tile = 2 * kBT;  // halves are whole 256-signal tiles
-    const bool split = !getenv("CSMP_BATCH_ONE_STREAM") && Bpad >= 2 * tile;
+    const char* nstr = getenv("CSMP_BATCH_STREAMS");
+    const bool split = nstr && nstr[0] == '2' && Bpad >= 2 * tile;
     const int nh = split ? 2 : 1;
     // CSMP_BATCH_CO=1 selects the co-resident kernel pair (k_b_screen256c + k_b_step_co: 168 registers each, < 160 KiB of
     // LDS together, persistent grids of one workgroup per CU).  Only that pair can share a CU -- the plain kernels each
@@ -2860,7 +2863,7 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     // C3 batch against 114 ms), so it is off by default and kept as the documented experiment.
     const size_t step_lds = b_step_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, b.kcap);
     const char* coenv = getenv("CSMP_BATCH_CO");
-    const bool co = coenv && coenv[0] == '1' && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256;
+    const bool co = coenv && coenv[0] == '1' && split && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256;
     const int mode = co ? kScreenCo : big ? kScreen256 : kScreen128;
     b.last_mode = mode;
     int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};

@@ -14,8 +14,8 @@ D = cs.Dictionary(At, device=0)
 nsig, k = 1024, 128
 B = bench.make_signals_fast(torch, dev, At, 0, 2 * nsig, k).reshape(2, nsig, bench.M)
 torch.cuda.synchronize()
-configs = [("two-stream", {}), ("one-stream", {"CSMP_BATCH_ONE_STREAM": "1"}),
-           ("two-stream-128", {"CSMP_SCREEN_128": "1"}), ("one-stream-128", {"CSMP_SCREEN_128": "1", "CSMP_BATCH_ONE_STREAM": "1"})]
+configs = [("one-stream", {}), ("two-stream", {"CSMP_BATCH_STREAMS": "2"}), ("two-stream-co", {"CSMP_BATCH_STREAMS": "2", "CSMP_BATCH_CO": "1"}),
+           ("one-stream-128", {"CSMP_SCREEN_128": "1"}), ("two-stream-128", {"CSMP_SCREEN_128": "1", "CSMP_BATCH_STREAMS": "2"})]
 only = None
 for a in sys.argv[1:]:
     if a.startswith("only="):
