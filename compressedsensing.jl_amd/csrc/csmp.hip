@@ -2864,7 +2864,10 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     const size_t step_lds = b_step_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, b.kcap);
     const char* coenv = getenv("CSMP_BATCH_CO");
     const bool co = coenv && coenv[0] == '1' && split && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256;
-    const int mode = co ? kScreenCo : big ? kScreen256 : kScreen128;
+    // the eight-phase kernel needs an even number of 64-deep K-tiles; CSMP_SCREEN_8PHASE=0 falls back to the two-phase 256^2 kernel
+    const char* ph = getenv("CSMP_SCREEN_8PHASE");
+    const bool phased = big && (b.Mk % 128 == 0) && b.Mk >= 256 && !(ph && ph[0] == '0');
+    const int mode = co ? kScreenCo : phased ? kScreen256p : big ? kScreen256 : kScreen128;
     b.last_mode = mode;
     int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
     if (split) {

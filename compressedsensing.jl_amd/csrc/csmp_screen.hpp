@@ -21,7 +21,7 @@ constexpr size_t kScreenLds256 = 2 * 2 * 256 * 128;  // the 256^2 kernels: 2 buf
 // one screening launch: D = Ab Rb' tile by tile with the fused top-4-per-(signal, 128-atom tile) epilogue.
 // mode: kScreen128 = the 128^2 kernel; kScreen256 = 256^2 tiles with LDS-DMA staging (needs n_atiles and n_stiles even);
 // kScreenCo = the same tiles by the persistent, 168-register kernel that shares CUs with k_b_step_co (ncu workgroups).
-enum : int { kScreen128 = 0, kScreen256 = 1, kScreenCo = 2 };
+enum : int { kScreen128 = 0, kScreen256 = 1, kScreenCo = 2, kScreen256p = 3 };  // 256p: the eight-phase schedule (needs Mk % 128 == 0)
 hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
                          int64_t N, float* cand_val, int* cand_idx, int ncu);
 const char* screen_kernel_name(int mode);
