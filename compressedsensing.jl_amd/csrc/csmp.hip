@@ -2761,7 +2761,7 @@ static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int
             return hipGetLastError();
         }
     }
-    auto kern = k_b_step<TA, NI, (NI >= 4 ? 2 : 4)>;  // (loads issued together: 8 columns' worth per lane either way)
+    auto kern = k_b_step<TA, NI, ((NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : 4)>;  // (columns / row chunks whose loads are issued together)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;

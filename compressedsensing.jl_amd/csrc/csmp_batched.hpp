@@ -578,7 +578,7 @@ inline size_t b_step_lds_bytes(int Mv, int vec, int kcap) {
 // workgroup per CU (grid = number of CUs) and at most 168 registers per lane (NI <= 4), one of these workgroups and one
 // 512-thread screening workgroup of the other half-batch fit a CU together: 3 x 168 registers per SIMD lane, < 160 KiB LDS.
 template <typename TA, int NI, int DEPTH>
-__global__ __launch_bounds__(256) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
+__global__ __launch_bounds__(256, (NI <= 4 ? 2 : 1)) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
                                                 const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
                                                 int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
                                                 double* __restrict__ z_all, int* __restrict__ sel_all,
