@@ -2817,6 +2817,13 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     }
     const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
     const int n_stiles = Bpad / kBT;
+#ifdef CSMP_EXPERIMENTS
+    {
+        const char* ab = getenv("CSMP_STEP_ABLATE");
+        const int v = ab ? atoi(ab) : 0;
+        HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_step_ablate), &v, sizeof(int)));
+    }
+#endif
     if (b_dtype == CSMP_F32)
         hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
     else

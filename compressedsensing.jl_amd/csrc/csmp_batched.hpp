@@ -31,6 +31,9 @@ using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kKeep = 16;        // candidates rescored per signal and step
+#ifdef CSMP_EXPERIMENTS
+__device__ int g_step_ablate = 0;  // timing probe (tools/probe_batched.py): 1 skip the rescoring loads, 2 skip pass 1, 4 skip pass 2
+#endif
 
 struct BState {
     int nsel, done, uncertain, illcond;
@@ -309,17 +312,29 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     }
     __syncthreads();
 
-    // ---- exact rescoring: <a_c, r> in Float64 for the kKeep candidates (all loads in flight)
+    // ---- exact rescoring: <a_c, r> in Float64 -- for the WINDOW only.  The list is sorted by screened value; an atom whose
+    // screened value lies more than 2 delta below the largest one (delta = the screening error bound, cert_coef * ||r||)
+    // cannot be the exact arg-max: its exact value is at most s + delta < s_1 - delta, which the top atom exceeds.  So only the
+    // prefix within 2 delta of s_1 is rescored (one or two atoms as a rule, instead of 16 column reads per signal and step);
+    // everything else -- the rest of the list AND the atoms outside it -- is covered by the certificate below.
+    const double delta = cert_coef * sqrt(n2);
+    int nw = 0;
 #pragma unroll 1
-    for (int grp = 0; grp < kKeep / DEPTH; ++grp) {
+    for (int q = 0; q < kKeep; ++q) nw += (cv[q] >= 0.0f && (double)cv[q] >= (double)cv[0] - 2.0 * delta) ? 1 : 0;
+    if (nw < kKeep && cv[nw] >= 0.0f) cert_thr = fmaxf(cert_thr, cv[nw]);  // the best screened value that is NOT rescored
+#pragma unroll 1
+    for (int grp = 0; grp * DEPTH < nw; ++grp) {
         Raw4<TA> av[DEPTH][NI];
 #pragma unroll
         for (int q = 0; q < DEPTH; ++q) {
-            const int c = ci[grp * DEPTH + q];
+            const int c = (grp * DEPTH + q < nw) ? ci[grp * DEPTH + q] : 0x7fffffff;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = 4 * (tid + 256 * i);
                 av[q][i].zero();
+#ifdef CSMP_EXPERIMENTS
+                if (g_step_ablate & 1) continue;
+#endif
                 if (c >= 0 && c != 0x7fffffff && row < Mv) av[q][i].load(A + (int64_t)c * ld + row, Mv - row);
             }
         }
@@ -340,7 +355,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     double bestv = -1.0, cexact = 0.0;
     int besti = 0x7fffffff;
 #pragma unroll 1
-    for (int q = 0; q < kKeep; ++q) {
+    for (int q = 0; q < nw; ++q) {
         const int c = ci[q];
         if (c < 0 || c == 0x7fffffff) continue;
         const double exq = (red[q] + red[kKeep + q]) + (red[2 * kKeep + q] + red[3 * kKeep + q]);
@@ -356,10 +371,10 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         if (tid == 0) st.done |= STOP_FULL;
         return;
     }
-    // certificate: every atom outside the list has a screened value <= cert_thr, hence an exact
-    // value <= cert_thr + delta, delta = cert_coef * ||r|| (bf16 rounding model).
-    // cert_thr < 0 means fewer than kKeep atoms exist: everything was rescored.
-    if (cert_thr >= 0.0f && !(bestv > (double)cert_thr + cert_coef * sqrt(n2)))
+    // certificate: every atom that was not rescored -- outside the list, or in it below the window -- has a screened
+    // value <= cert_thr, hence an exact value <= cert_thr + delta (bf16 rounding model); the exact best must
+    // exceed that.  cert_thr < 0 means every existing atom was rescored.
+    if (cert_thr >= 0.0f && !(bestv > (double)cert_thr + delta))
         if (tid == 0) st.uncertain += 1;
     // "i not in x.nzind" (:66): a re-selected atom makes every later step the same no-op
     int found = 0;
@@ -390,7 +405,12 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     // ---- pass 1: g_i = <a_{s_i}, a>, one wave per 4 support columns (the sweep's inner loop)
     {
         const VT* as = reinterpret_cast<const VT*>(aimg);
-        for (int c0 = wave * 4; c0 < j; c0 += 16) {
+#ifdef CSMP_EXPERIMENTS
+        const int jp1 = (g_step_ablate & 2) ? 0 : j;
+#else
+        const int jp1 = j;
+#endif
+        for (int c0 = wave * 4; c0 < jp1; c0 += 16) {
             const VT* p[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -504,6 +524,9 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     }
     {
         int i = 0;
+#ifdef CSMP_EXPERIMENTS
+        if (g_step_ablate & 4) i = j;
+#endif
         for (; i + DEPTH <= j; i += DEPTH) {
             Raw4<TA> cv4[DEPTH][NI];
 #pragma unroll
