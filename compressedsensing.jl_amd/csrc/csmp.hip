@@ -1895,7 +1895,8 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     hipLaunchKernelGGL(k_gram_rhs<TA>, dim3((n + 1 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands,
                        n, np, (const double*)s.b, s.Gm);
     HIPCHECK(hipGetLastError());
-    for (int kb = 0; kb < np / kCholNB; ++kb) {
+    const int nsteps = (n + 1 + kCholNB - 1) / kCholNB;  // (the identity padding beyond the bordered column needs no elimination)
+    for (int kb = 0; kb < nsteps; ++kb) {
         const int left = np - (kb + 1) * kCholNB;  // columns to the right of this step's block
         hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left + kCholRowCols - 1) / kCholRowCols)), dim3(256), 0, ctx->stream, s.Gm, np, n, kb,
                            (const double*)s.gdiag, s.st);
