@@ -42,7 +42,7 @@ out = {k: {"dispatches": len(v), "avg": sum(v) / len(v)} for k, v in acc.items()
 if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 256 CUs x 4 SIMDs
     out["mfma_util"] = out["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (out["GRBM_GUI_ACTIVE"]["avg"] / 8.0 * 1024.0)
-    out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (a launch covers one half-batch)"
+    out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (k_b_screen256p, all 1024 signals of the batch)"
 print(json.dumps(out, indent=1))
 PY
 ls -la $OUT
