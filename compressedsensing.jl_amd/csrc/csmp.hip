@@ -23,7 +23,8 @@
 using namespace csmp;
 
 static std::string g_create_err;
-static constexpr int kRsEqCap = 4096;
+static constexpr int kRsEqCap = 4096;   // entries of the bucket list (exact ties beyond it: in-order scan)
+static constexpr int kRsSettle = 256;   // a bucket this small ends the passes (k_rs_finish ranks it in LDS)
 
 struct Solver {
     int kcap = 0, outcap = 0;
@@ -1744,13 +1745,16 @@ static int launch_topS(csmp_ctx* ctx, int S) {
     const int S_eff = (int)std::min<int64_t>(S, ctx->N);
     const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->prop.multiProcessorCount * 4);
     hipLaunchKernelGGL(k_rs_init, dim3(1), dim3(256), 0, ctx->stream, s.rs, S_eff);
-    for (int pass = 0; pass < 8; ++pass) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs);
-        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(256), 0, ctx->stream, s.rs);
-    }
+    // (few, fat workgroups: every workgroup flushes its non-empty bins with global atomics, and pass 0 -- the exponent -- puts
+    // all keys into a dozen bins)
+    const int hgrid = (int)std::min<int64_t>((ctx->N + 2047) / 2048, (int64_t)ctx->prop.multiProcessorCount);
+    for (int pass = 0; pass < kRsPasses; ++pass)  // (a settled selection turns the remaining launches into no-ops)
+        hipLaunchKernelGGL(k_rs_hist, dim3(hgrid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, kRsSettle);
     hipLaunchKernelGGL(k_rs_collect, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, s.rs_gt, s.rs_eq, kRsEqCap);
     const int pairs = S_eff <= 4096 ? S_eff : 0;  // (value, index) pairs of the final rank sort staged in LDS
-    hipLaunchKernelGGL(k_rs_finish, dim3(1), dim3(256), (size_t)pairs * 12 + 16, ctx->stream, (const double*)s.cvec, ctx->N, s.rs,
+    const size_t lds = (size_t)pairs * 12 + 16 + (size_t)kRsEqCap * 12 + 16;
+    HIPCHECK(hipFuncSetAttribute((const void*)k_rs_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_rs_finish, dim3((S_eff + 255) / 256), dim3(256), lds, ctx->stream, (const double*)s.cvec, ctx->N, s.rs,
                        (const int*)s.rs_gt, (const int*)s.rs_eq, kRsEqCap, s.rs_work, s.cands, s.cvals, s.ncands, pairs);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
@@ -1896,14 +1900,19 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
                        n, np, (const double*)s.b, s.Gm);
     HIPCHECK(hipGetLastError());
     const int nsteps = (n + 1 + kCholNB - 1) / kCholNB;  // (the identity padding beyond the bordered column needs no elimination)
-    for (int kb = 0; kb < nsteps; ++kb) {
-        const int left = np - (kb + 1) * kCholNB;  // columns to the right of this step's block
-        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left + kCholRowCols - 1) / kCholRowCols)), dim3(256), 0, ctx->stream, s.Gm, np, n, kb,
-                           (const double*)s.gdiag, s.st);
-        if (left > 0) {
-            const int Tt = (left + kGramTile - 1) / kGramTile;
-            hipLaunchKernelGGL(k_chol_trail, dim3(Tt * (Tt + 1) / 2), dim3(256), 0, ctx->stream, s.Gm, np, kb);
-        }
+    {
+        const int left0 = np - kCholNB;
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n,
+                           0, (const double*)s.gdiag, s.st);
+    }
+    for (int kb = 0; kb + 1 < nsteps; ++kb) {  // one launch per step: trailing update of panel kb + block row kb + 1
+        const int left = np - (kb + 1) * kCholNB;   // columns from the next block row on
+        const int left2 = left - kCholNB;           // columns to the right of the next diagonal block
+        const int Tt = (left + kGramTile - 1) / kGramTile;
+        const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
+        const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
+        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n, kb, (const double*)s.gdiag, s.st,
+                           nrow);
     }
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np, n,
@@ -2767,7 +2776,9 @@ static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
+    int grid = nsig;
+    if (const char* g = getenv("CSMP_STEP_GRID")) grid = std::max(1, std::min(nsig, atoi(g)));  // (fewer resident signals: smaller cache footprint)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
                        (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
                        b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0, nsig);
     return hipGetLastError();

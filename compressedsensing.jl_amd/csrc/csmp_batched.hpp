@@ -145,7 +145,8 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     int* ci = reinterpret_cast<int*>(cv + kKeep);           // kKeep
     float* rv = reinterpret_cast<float*>(ci + kKeep);       // 256 (arg-max scratch)
     int* ri = reinterpret_cast<int*>(rv + 256);             // 256
-    TA* aimg = reinterpret_cast<TA*>((reinterpret_cast<uintptr_t>(ri + 256) + 15) & ~(uintptr_t)15);  // Mlds entries in natural row order: lane l of chunk t reads its
+    int* selL = ri + 256;                                   // kcap: the support, staged once (the passes index it per column)
+    TA* aimg = reinterpret_cast<TA*>((reinterpret_cast<uintptr_t>(selL + kcap) + 15) & ~(uintptr_t)15);  // Mlds entries in natural row order: lane l of chunk t reads its
                                                             // 16 bytes at (t * 64 + l) * 16 -- consecutive lanes, conflict-free
 
     double* r = r_all + (int64_t)s * Mr;
@@ -174,6 +175,8 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         if (tid == 0) st.done |= STOP_FULL;
         return;
     }
+
+    for (int t = tid; t < j; t += 256) selL[t] = sel[t];  // (visible after the merge's barriers)
 
     // ---- merge the tile candidates: the kKeep largest screened |c| (ties: lower atom index).
     // cert_thr bounds the screened value of every atom NOT in the list: the smallest kept value,
@@ -378,7 +381,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         if (tid == 0) st.uncertain += 1;
     // "i not in x.nzind" (:66): a re-selected atom makes every later step the same no-op
     int found = 0;
-    for (int t = tid; t < j; t += 256) found |= (sel[t] == besti);
+    for (int t = tid; t < j; t += 256) found |= (selL[t] == besti);
     found = __syncthreads_or(found);
     if (found) {
         if (tid == 0) st.done |= STOP_STAG;
@@ -410,29 +413,42 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
 #else
         const int jp1 = j;
 #endif
-        for (int c0 = wave * 4; c0 < jp1; c0 += 16) {
-            const VT* p[4];
+        // Software-pipelined: the wave's work is the flat list of (4-column group, row chunk) items; DEPTH items (4 loads
+        // each) are always in flight -- an item's registers are refilled for item q + DEPTH right after item q is consumed,
+        // across group boundaries too, so the memory pipe never drains between the groups.
+        const int ngrp = (jp1 > wave * 4) ? (jp1 - wave * 4 + 15) / 16 : 0;
+        const int total = ngrp * nchunk;
+        VT a[DEPTH][4];
+        const VT* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        int ql = 0, tl = 0, c0l = wave * 4;
+        auto issue = [&](VT(&dst)[4]) {
+            if (ql < total) {
+                if (tl == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int col = sel[min(c0 + c, j - 1)];
-                p[c] = reinterpret_cast<const VT*>(A + (int64_t)col * ld) + lane;
-            }
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < nchunk; t0 += DEPTH) {  // DEPTH chunks x 4 columns of loads in flight per lane
-                VT a[DEPTH][4];
-#pragma unroll
-                for (int u = 0; u < DEPTH; ++u) {
-                    const int row = (t0 + u) * ROWS + lane * VEC;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        a[u][c] = (VT)0;
-                        if (t0 + u < nchunk && row < Mv) a[u][c] = p[c][(t0 + u) * kWave];
-                    }
+                    for (int c = 0; c < 4; ++c) p[c] = reinterpret_cast<const VT*>(A + (int64_t)selL[min(c0l + c, j - 1)] * ld) + lane;
                 }
+                const bool ok = tl * ROWS + lane * VEC < Mv;
 #pragma unroll
-                for (int u = 0; u < DEPTH; ++u) {
-                    const int t = (t0 + u < nchunk) ? t0 + u : 0;  // (padding chunks carry zeros)
-                    const VT av = as[t * kWave + lane];
+                for (int c = 0; c < 4; ++c) {
+                    dst[c] = (VT)0;
+                    if (ok) dst[c] = p[c][tl * kWave];
+                }
+                if (++tl == nchunk) {
+                    tl = 0;
+                    c0l += 16;
+                }
+            }
+            ++ql;
+        };
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) issue(a[u]);
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int tc = 0, c0c = wave * 4;
+        for (int q0 = 0; q0 < total; q0 += DEPTH) {
+#pragma unroll
+            for (int u = 0; u < DEPTH; ++u) {
+                if (q0 + u < total) {
+                    const VT av = as[tc * kWave + lane];
                     if constexpr (VEC == 4) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
@@ -448,12 +464,18 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
                             acc[c] = fma((double)a[u][c].y, (double)av.y, acc[c]);
                         }
                     }
-                }
-            }
+                    if (++tc == nchunk) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                for (int sft = 32; sft >= 1; sft >>= 1) acc[c] += shx(acc[c], sft);
-                if (lane == 0 && c0 + c < j) gv[c0 + c] = acc[c];
+                        for (int c = 0; c < 4; ++c) {
+                            for (int sft = 32; sft >= 1; sft >>= 1) acc[c] += shx(acc[c], sft);
+                            if (lane == 0 && c0c + c < j) gv[c0c + c] = acc[c];
+                            acc[c] = 0.0;
+                        }
+                        tc = 0;
+                        c0c += 16;
+                    }
+                }
+                issue(a[u]);
             }
         }
     }
@@ -464,7 +486,45 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     double* Tw = T_all + (int64_t)s * kcap * kcap;
     const double* Tt = Tt_all + (int64_t)s * kcap * kcap;  // Tt[i + t*kcap] = T[t,i]
     double* Ttw = Tt_all + (int64_t)s * kcap * kcap;
+    // Both mat-vecs are split over ALL 256 threads: thread (i, grp) of nI x G sums the terms t = grp, grp + G, ... of its
+    // output, 16 loads in flight, and the G partial sums meet in LDS -- a fraction of the dependent round trips of
+    // "one thread per output" (j / 8 of them at G = 1), which is what these two short phases consist of.
+    int nI = 16;
+    while (nI < j) nI <<= 1;
+    const int G = nI <= 256 ? 256 / nI : 1;
+    double* part = reinterpret_cast<double*>(rv);  // 256 Float64 (rv | ri: the arg-max scratch is free by now)
     double w2 = 0.0;
+    if (nI <= 256) {
+        const int i = tid & (nI - 1), grp = tid / nI;
+        double acc = 0.0, acc1 = 0.0;
+        if (i < j) {
+            int t = grp;
+            for (; t + 15 * G <= i; t += 16 * G) {
+                double tv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tv[u] = Tt[i + (int64_t)(t + u * G) * kcap];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    acc = fma(tv[u], gv[t + u * G], acc);
+                    acc1 = fma(tv[u + 1], gv[t + (u + 1) * G], acc1);
+                }
+            }
+            double tv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tv[u] = (t + u * G <= i) ? Tt[i + (int64_t)(t + u * G) * kcap] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (t + u * G <= i) acc = fma(tv[u], gv[t + u * G], acc);
+        }
+        part[tid] = acc + acc1;
+        __syncthreads();
+        if (tid < j) {
+            double sum = part[tid];
+            for (int g2 = 1; g2 < G; ++g2) sum += part[g2 * nI + tid];
+            wv[tid] = sum;
+            w2 = sum * sum;
+        }
+    } else {
     for (int i = tid; i < j; i += 256) {
         double acc = 0.0, acc1 = 0.0;
         int t = 0;
@@ -483,6 +543,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         wv[i] = acc;
         w2 = fma(acc, acc, w2);
     }
+    }
     w2 = block_sum256(w2, sc);
     const double rho2 = na2 - w2;
     // DGKS-style guard: a badly cancelling first pass means an ill-conditioned support; this
@@ -495,7 +556,37 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         return;
     }
     const double rho = sqrt(rho2);
-    // ---- y = T w (y_t = sum_{i>=t} T[t,i] w_i): thread t walks row t of T (column-major: coalesced)
+    // ---- y = T w (y_t = sum_{i>=t} T[t,i] w_i): thread (t, grp) walks row t of T (column-major: coalesced over t)
+    if (nI <= 256) {
+        const int t = tid & (nI - 1), grp = tid / nI;
+        double acc = 0.0, acc1 = 0.0;
+        if (t < j) {
+            int i = t + grp;
+            for (; i + 15 * G < j; i += 16 * G) {
+                double tv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) tv[u] = T[t + (int64_t)(i + u * G) * kcap];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    acc = fma(tv[u], wv[i + u * G], acc);
+                    acc1 = fma(tv[u + 1], wv[i + (u + 1) * G], acc1);
+                }
+            }
+            double tv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) tv[u] = (i + u * G < j) ? T[t + (int64_t)(i + u * G) * kcap] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (i + u * G < j) acc = fma(tv[u], wv[i + u * G], acc);
+        }
+        part[tid] = acc + acc1;  // (the partial sums of w were consumed before the barriers of block_sum256)
+        __syncthreads();
+        if (tid < j) {
+            double sum = part[tid];
+            for (int g2 = 1; g2 < G; ++g2) sum += part[g2 * nI + tid];
+            yv[tid] = sum;
+        }
+    } else {
     for (int t = tid; t < j; t += 256) {
         double acc = 0.0, acc1 = 0.0;
         int i = t;
@@ -512,6 +603,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         for (; i < j; ++i) acc = fma(T[t + (int64_t)i * kcap], wv[i], acc);
         yv[t] = acc + acc1;
     }
+    }
     __syncthreads();
 
     // ---- pass 2: v = a - sum_i y_i a_{s_i}  (row-owner form, DEPTH columns x NI loads in flight)
@@ -522,42 +614,40 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
 #pragma unroll
         for (int e = 0; e < 4; ++e) areg[u][e] = (row + e < Mlds) ? (double)aimg[row + e] : 0.0;
     }
+    // Columns are visited LAST TO FIRST: pass 1 has just streamed them first to last, and the other resident workgroups have
+    // pushed this signal's early columns out of the L2 / Infinity Cache in the meantime -- the late ones are still there.
+    // A ring of DEPTH columns: column i - DEPTH is requested into the registers column i has just been consumed from.
     {
-        int i = 0;
+        int jtop = j;
 #ifdef CSMP_EXPERIMENTS
-        if (g_step_ablate & 4) i = j;
+        if (g_step_ablate & 4) jtop = 0;
 #endif
-        for (; i + DEPTH <= j; i += DEPTH) {
-            Raw4<TA> cv4[DEPTH][NI];
-#pragma unroll
-            for (int c = 0; c < DEPTH; ++c) {
-                const int col = sel[i + c];
+        Raw4<TA> cv4[DEPTH][NI];
+        auto issue = [&](Raw4<TA>(&dst)[NI], int i) {
+            if (i >= 0) {
+                const int col = selL[i];
 #pragma unroll
                 for (int u = 0; u < NI; ++u) {
                     const int row = 4 * (tid + 256 * u);
-                    cv4[c][u].zero();
-                    if (row < Mv) cv4[c][u].load(A + (int64_t)col * ld + row, Mv - row);
+                    dst[u].zero();
+                    if (row < Mv) dst[u].load(A + (int64_t)col * ld + row, Mv - row);
                 }
             }
+        };
+#pragma unroll
+        for (int c = 0; c < DEPTH; ++c) issue(cv4[c], jtop - 1 - c);
+        for (int i0 = jtop - 1; i0 >= 0; i0 -= DEPTH) {
 #pragma unroll
             for (int c = 0; c < DEPTH; ++c) {
-                const double yc = yv[i + c];
+                const int i = i0 - c;
+                if (i >= 0) {
+                    const double yc = yv[i];
 #pragma unroll
-                for (int u = 0; u < NI; ++u)
+                    for (int u = 0; u < NI; ++u)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) areg[u][e] = fma(-yc, cv4[c][u].get(e), areg[u][e]);
-            }
-        }
-        for (; i < j; ++i) {
-            const int col = sel[i];
-            const double yc = yv[i];
-#pragma unroll
-            for (int u = 0; u < NI; ++u) {
-                const int row = 4 * (tid + 256 * u);
-                double t4[4] = {0.0, 0.0, 0.0, 0.0};
-                if (row < Mv) load4(A + (int64_t)col * ld + row, Mv - row, t4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) areg[u][e] = fma(-yc, t4[e], areg[u][e]);
+                        for (int e = 0; e < 4; ++e) areg[u][e] = fma(-yc, cv4[c][u].get(e), areg[u][e]);
+                }
+                issue(cv4[c], i - DEPTH);
             }
         }
     }
@@ -594,7 +684,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
 inline size_t b_step_lds_bytes(int Mv, int vec, int kcap) {
     const int rows = kWave * vec;
     const int nchunk = (Mv + rows - 1) / rows;
-    return (size_t)(3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + (size_t)nchunk * rows * (16 / vec) + 64;
+    return (size_t)(3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + (size_t)kcap * 4 + (size_t)nchunk * rows * (16 / vec) + 64;
 }
 
 // Persistent form: workgroup w serves the signals sig0 + w, sig0 + w + gridDim.x, ... of its half-batch.  With one

@@ -9,10 +9,10 @@
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
 //   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
-//   k_chol_row / k_chol_trail   right-looking blocked Cholesky G = R'R in place, 32 columns per step: the 32 x 32 diagonal
-//                 block in the registers of one wave (the v_readlane scheme of k_blk3), the row panel by substitution (one
-//                 thread per column), the trailing update on the matrix cores.  The bordered column comes out as
-//                 z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
+//   k_chol_row / k_chol_step   right-looking blocked Cholesky G = R'R in place, 32 columns per step and ONE launch per step:
+//                 the 32 x 32 diagonal block in the registers of one wave, the row panel by substitution (one thread per
+//                 column), the trailing update of the previous panel on the matrix cores beside it.  The bordered column comes
+//                 out as z = R^-T c = Q'b -- exactly what the append chain accumulates step by step;
 //   k_gram_export R, z, support and count into the solver slot: from there on k_finish* (back substitution + sorted
 //                 emission) and k_residual work as after any append chain.
 //
@@ -29,9 +29,9 @@ namespace csmp {
 
 using d4g = __attribute__((ext_vector_type(4))) double;
 constexpr int kGramTile = 64;   // G tile edge per workgroup
-constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twice: a straight 64-step elimination in one wave is 110 KiB of
-                                // unrolled code, 203 us per step; two levels of 32 with an MFMA update in between, 63 us -- against 19 + 11 us
-                                // for two steps of 32: the unrolled substitution and factorisation together outgrow the instruction cache.)
+constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twice: a straight 64-step elimination in one wave, 203 us per
+                                // step; two levels of 32 with an MFMA update in between, 63 us -- against 2 x 24 us for two steps of 32:
+                                // the per-thread work of a step grows with NB^2 and Float64 FMAs are what a step consists of.)
 
 // The n columns of the set, copied into one contiguous block: column j at j * ldo, ldo = M rounded up to 16 rows, zero rows
 // beyond M and zero columns from n to np.  k_gram touches 96 columns per wave and block of rows, 16 bytes of each: from the
@@ -156,91 +156,135 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
     if (lane == 0) G[j + (int64_t)n * np] = acc;
 }
 
-// Cholesky step kb, first half: the 32 x 32 diagonal block (every workgroup, redundantly, in the registers of wave 0),
-// then the row panel R[c0 .. c0+31, c] = U^-T G[c0 .. c0+31, c] for this workgroup's 256 columns c >= c0 + 32.
-constexpr int kCholRowCols = 256;  // panel columns per workgroup
-__global__ __launch_bounds__(256) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
-                                                  DevState* st) {
+// Block row kb of the factor, by workgroups of 5 waves: wave 0 factorises the 32 x 32 diagonal block in its registers (every
+// workgroup, redundantly; lane q holds column q, lanes 32..63 mirror 0..31); waves 1..4 own one column c >= c0 + 32 of the row
+// panel each, R[c0 .. c0+31, c] = U^-T G[c0 .. c0+31, c] (kCholRowCols of them per workgroup).  UPD: the trailing update of the
+// PREVIOUS panel (rows c0-32 .. c0-1, already final) has not been applied to this block row yet -- every thread applies it to its
+// own column first (k_chol_step below).
+//   * The row of the factor an elimination step produces goes from lane to lanes through LDS (one 8-byte write per lane, then
+//     wave-uniform 16-byte reads: the LDS serves a wave's instructions in order, so the reads see the row) -- not through 62
+//     v_readlane_b32 per step.
+//   * UPD: the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: they come through the SCALAR unit (s_load of
+//     64 B from the finished panel in global memory, constant address space) and enter the FMAs as scalar operands.
+// What a step costs (tools/probes/chol_probe.hip, n = 1024): 24.1 us, of which 2.6 us launch, 4.4 us the dependent trip
+// through memory between two launches, 5 us the update, 3 + 2 us elimination and its rsqrt chain, 3.4 us substitution; the
+// trailing update runs beside it for free.  Tried and slower: rolled loops on a shifting register window (38 us: twice the
+// FMAs -- code size was NOT the limit), the update over LDS operands (24.7 us).
+constexpr int kCholRowCols = 256;   // panel columns per workgroup
+constexpr int kCholThreads = 320;   // + the wave of the diagonal block
+
+template <bool UPD>
+__device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
+                                              DevState* st, int wg) {
     constexpr int NB = kCholNB;
-    __shared__ double Rp[NB * NB];
+    __shared__ __attribute__((aligned(16))) double U[NB * NB];  // U[t * NB + q]: row t of the factored diagonal block
     __shared__ double rinv[NB];
     const int tid = threadIdx.x, c0 = kb * NB;
-    // this thread's column of the row panel: requested before the diagonal block is factorised (its latency hides there)
-    const int c = c0 + NB + blockIdx.x * 256 + tid;
-    double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;
+    const bool diag = tid < kWave;
+    const int q = tid & (NB - 1);
+    const int c = diag ? c0 + q : c0 + NB + wg * kCholRowCols + (tid - kWave);
+    const bool have = diag ? tid < NB : c < np;
+    double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;  // (np is a multiple of 64: 16-byte aligned)
     double x[NB];
+    {
+        const f64x2* g2 = reinterpret_cast<const f64x2*>(gcol);
 #pragma unroll
-    for (int p = 0; p < NB; ++p) x[p] = (c < np) ? gcol[p] : 0.0;
-    if (tid < kWave) {
-        const int q = tid;
-        double gq[NB];
-        const double* gc = G + c0 + (int64_t)(c0 + (q < NB ? q : 0)) * np;
+        for (int p = 0; p < NB; p += 2) {
+            const f64x2 v = g2[p / 2];
+            x[p] = v.x;
+            x[p + 1] = v.y;
+        }
+    }
+    if (diag) {
 #pragma unroll
-        for (int t = 0; t < NB; ++t) gq[t] = (q < NB && t <= q) ? gc[t] : 0.0;
-        const double ref = (q < NB && c0 + q < n) ? gdiag[c0 + q] : 0.0;
+        for (int p = 0; p < NB; ++p) x[p] = (p <= q) ? x[p] : 0.0;  // (below the diagonal: not part of the stored triangle)
+    }
+    if constexpr (UPD) {
+        const f64x2* pc = reinterpret_cast<const f64x2*>(gcol - NB);  // the previous panel's rows in this thread's column
+        double xc[NB];
+#pragma unroll
+        for (int e = 0; e < NB; e += 2) {
+            const f64x2 v = pc[e / 2];
+            xc[e] = v.x;
+            xc[e + 1] = v.y;
+        }
+        typedef const double __attribute__((address_space(4))) sdouble;  // (constant address space + uniform address = s_load)
+        sdouble* xg = (sdouble*)(G + (c0 - NB) + (int64_t)c0 * np);
+#pragma unroll
+        for (int p = 0; p < NB; ++p) {
+            double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < NB; e += 2) {
+                acc0 = fma(xc[e], xg[e + (int64_t)p * np], acc0);
+                acc1 = fma(xc[e + 1], xg[e + 1 + (int64_t)p * np], acc1);
+            }
+            x[p] -= acc0 + acc1;
+        }
+    }
+    if (diag) {
+        const double ref = (c0 + q < n) ? gdiag[c0 + q] : 0.0;
         int mybad = 0;
         double ri[NB];
 #pragma unroll
         for (int p = 0; p < NB; ++p) {
-            const double d = readlane_f64(gq[p], p);
+            const double d = readlane_f64(x[p], p);
             if (q == p && c0 + p < n && (!(d > 0.0) || !(d >= 0.5 * ref))) mybad = 1;  // DGKS: too much cancellation
             const bool okd = d > 0.0 && d < 1e300;
-            double rs_ = __builtin_amdgcn_rsq(okd ? d : 1.0);
-            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
-            rs_ = rs_ * fma(-0.5 * (okd ? d : 1.0) * rs_, rs_, 1.5);
+            const double dd = okd ? d : 1.0;
+            double rs_ = __builtin_amdgcn_rsq(dd);
+            rs_ = rs_ * fma(-0.5 * dd * rs_, rs_, 1.5);
+            rs_ = rs_ * fma(-0.5 * dd * rs_, rs_, 1.5);
             ri[p] = okd ? rs_ : 1.0;
-            const double rd = okd ? d * rs_ : 1.0;
-            gq[p] = (q == p) ? rd : gq[p] * ri[p];
+            const double top = (q == p) ? (okd ? d * rs_ : 1.0) : x[p] * ri[p];  // R[p][q] (q >= p; lanes q < p: dead values)
+            x[p] = top;
+            U[p * NB + q] = top;
+            asm volatile("" ::: "memory");  // (the reads below follow the write in program order: same wave, in-order LDS)
 #pragma unroll
-            for (int s_ = p + 1; s_ < NB; ++s_) {
-                const double rps = readlane_f64(gq[p], s_);
-                gq[s_] = fma(-rps, gq[p], gq[s_]);  // (every lane: what lands below the diagonal, q < s_, is never read)
-            }
+            for (int s_ = p + 1; s_ < NB; ++s_) x[s_] = fma(-U[p * NB + s_], top, x[s_]);
         }
-        if (__any(mybad) && blockIdx.x == 0 && tid == 0) st->done |= STOP_REORTH;
-        if (q < NB) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t)
-                if (t <= q) Rp[t * NB + q] = gq[t];
-            if (blockIdx.x == 0) {  // the factored diagonal block, in place
-                double* go = G + c0 + (int64_t)(c0 + q) * np;
-#pragma unroll
-                for (int t = 0; t < NB; ++t)
-                    if (t <= q) go[t] = gq[t];
-            }
-        }
+        if (__any(mybad) && wg == 0 && tid == 0) st->done |= STOP_REORTH;
         if (q == 0) {
 #pragma unroll
             for (int t = 0; t < NB; ++t) rinv[t] = ri[t];
         }
+        if (wg == 0 && tid < NB) {  // the factored diagonal block, in place
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+                if (t <= q) gcol[t] = x[t];
+        }
     }
     __syncthreads();
-    if (c >= np) return;
-    double* gc = gcol;
+    if (diag || !have) return;
 #pragma unroll
-    for (int p = 0; p < NB; ++p) {
-        double s = x[p];
+    for (int t = 0; t < NB; ++t) {
+        const double xt = x[t] * rinv[t];
+        x[t] = xt;
 #pragma unroll
-        for (int t = 0; t < NB; ++t)
-            if (t < p) s = fma(-x[t], Rp[t * NB + p], s);
-        x[p] = s * rinv[p];
+        for (int p = t + 1; p < NB; ++p) x[p] = fma(-U[t * NB + p], xt, x[p]);
     }
+    f64x2* o2 = reinterpret_cast<f64x2*>(gcol);
 #pragma unroll
-    for (int p = 0; p < NB; ++p) gc[p] = x[p];
+    for (int p = 0; p < NB; p += 2) o2[p / 2] = f64x2{x[p], x[p + 1]};
 }
 
-// Cholesky step kb, second half: G[i][j] -= sum_p X[p][i] X[p][j] over the NB rows X = G[c0 .. c0+NB-1, :] just finished,
-// for the upper 64 x 64 tiles of the trailing matrix (columns >= c0 + NB).  Matrix cores; lane fq takes 8 consecutive rows
-// of X per pass (NB / 32 passes); the accumulators start from G itself and one operand enters negated, so the loads of a
-// pass are all issued before its first MFMA.
-__global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int np, int kb) {
+// The first block row (nothing to apply before it).
+__global__ __launch_bounds__(kCholThreads) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
+                                                           DevState* st) {
+    chol_row_body<false>(G, np, n, kb, gdiag, st, (int)blockIdx.x);
+}
+
+// The trailing update of step kb: G[i][j] -= sum_p X[p][i] X[p][j] over the NB rows X = G[c0 .. c0+NB-1, :] just finished, for
+// the upper 64 x 64 tile `p` of the trailing matrix (columns >= c0 + NB).  Matrix cores; lane fq takes 8 consecutive rows of X
+// per pass (NB / 32 passes); the accumulators start from G itself and one operand enters negated, so the loads of a pass are
+// all issued before its first MFMA.  skip_first: rows c0+NB .. c0+2NB-1 (the next block row) are left to chol_row_body<true>.
+__device__ __forceinline__ void chol_trail_body(double* __restrict__ G, int np, int kb, int p, bool skip_first) {
     constexpr int NB = kCholNB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int c0 = kb * NB, t0 = c0 + NB;  // trailing matrix starts at column t0
     int J = 0;
-    const int p = blockIdx.x;
     while ((J + 1) * (J + 2) / 2 <= p) ++J;
     const int I = p - J * (J + 1) / 2;
+    const int tlo = (skip_first && I == 0) ? NB / 16 : 0;  // 16-row sub-tiles of the tile that belong to the next block row
     const int cj = t0 + J * kGramTile + wave * 16 + fr;
     d4g acc[4];
 #pragma unroll
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg;
-            acc[t][reg] = (row < np && cj < np && row <= cj) ? G[row + (int64_t)cj * np] : 0.0;
+            acc[t][reg] = (t >= tlo && row < np && cj < np && row <= cj) ? G[row + (int64_t)cj * np] : 0.0;
         }
 #pragma unroll
     for (int pass = 0; pass < NB / 32; ++pass) {
@@ -260,7 +304,7 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int 
         for (int t = 0; t < 4; ++t) {
             const int ci = t0 + I * kGramTile + t * 16 + fr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) ai[t][e] = (ci < np) ? -X[e + (int64_t)ci * np] : 0.0;
+            for (int e = 0; e < 8; ++e) ai[t][e] = (t >= tlo && ci < np) ? -X[e + (int64_t)ci * np] : 0.0;
         }
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk)
@@ -272,8 +316,22 @@ __global__ __launch_bounds__(256) void k_chol_trail(double* __restrict__ G, int 
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
             const int row = t0 + I * kGramTile + t * 16 + fq + 4 * reg;
-            if (row < np && cj < np && row <= cj) G[row + (int64_t)cj * np] = acc[t][reg];
+            if (t >= tlo && row < np && cj < np && row <= cj) G[row + (int64_t)cj * np] = acc[t][reg];
         }
+}
+
+// Cholesky step kb -> kb + 1 in ONE launch (the factorisation is a chain of ~n/32 dependent steps, a few microseconds of work
+// each: what it costs is the number of launches on that chain).  Workgroups [0, nrow) produce block row kb + 1: they apply
+// panel kb to their own 32 x 256 part of it, factorise its diagonal block, solve.  Workgroups [nrow, ..) apply panel kb to the
+// rest of the trailing matrix meanwhile.  The two groups touch disjoint rows; panel kb itself is only read.
+__global__ __launch_bounds__(kCholThreads) void k_chol_step(double* __restrict__ G, int np, int n, int kb,
+                                                            const double* __restrict__ gdiag, DevState* st, int nrow) {
+    if ((int)blockIdx.x < nrow) {
+        chol_row_body<true>(G, np, n, kb + 1, gdiag, st, (int)blockIdx.x);
+    } else {
+        if (threadIdx.x >= 256) return;
+        chol_trail_body(G, np, kb, (int)blockIdx.x - nrow, true);
+    }
 }
 
 // R (n x n upper, leading dimension kcap), z = column n, support = cols, count = n -> the solver slot.  Nothing is

@@ -512,18 +512,32 @@ __global__ __launch_bounds__(256) void k_top_merge(const double* __restrict__ lv
     if (tid == 0) *ncands = cnt;
 }
 
-// ---- radix select (large S)
+// ---- radix select (large S): the S largest |c| of N, S up to the support capacity.
+// Keys are the bit patterns of |c| (monotone for finite values).  The digits are 11 bits wide (the last one 8): pass 0 fixes
+// the exponent, pass 1 the leading 11 mantissa bits -- after which the bucket that holds the S-th largest key carries a
+// handful of entries for anything but massively tied data.  As soon as that bucket holds at most `settle` keys the selection is
+// SETTLED: the later histogram launches (enqueued blindly by the host, which never reads anything back) return at once,
+// k_rs_collect gathers the keys above the bucket and the bucket itself, and k_rs_finish picks the `remaining` best of the
+// bucket exactly.  The scan of a pass is done by the LAST workgroup of its histogram launch (ticket counter): one launch per
+// pass.  Typical cost at N = 131072, S = 1024: 2 live passes + 4 empty launches + collect + finish, ~60 us (it was 19
+// launches, ~200 us, with 8-bit digits and a single-workgroup rank sort).
+constexpr int kRsDigit = 11, kRsBins = 1 << kRsDigit, kRsPasses = 6;
 struct RsState {
     unsigned long long prefix;  // bits fixed so far (high bits)
-    int pass;                   // next digit, 0 = most significant byte
+    int pass;                   // next digit, 0 = most significant
     int remaining;              // how many still to take among keys matching the prefix
     int n_gt, n_eq;             // append counters of k_rs_collect
-    unsigned int hist[256];
+    int settled;                // the prefix bucket is small enough: no further passes
+    unsigned int ticket;        // workgroups of the current histogram launch that are done
+    unsigned int hist[kRsBins];
 };
 
 __device__ __forceinline__ unsigned long long abs_key(double c) {
     return (unsigned long long)__double_as_longlong(fabs(c));  // NaN sorts above inf; inputs are finite
 }
+// bits fixed after `pass` passes (the sign bit counts as fixed: it is 0), and the mask of those bits
+__device__ __forceinline__ int rs_fixed_bits(int pass) { return pass >= kRsPasses ? 64 : 1 + kRsDigit * pass; }
+__device__ __forceinline__ unsigned long long rs_himask(int fixed) { return fixed >= 64 ? ~0ull : ~(~0ull >> fixed); }
 
 __global__ __launch_bounds__(256) void k_rs_init(RsState* rs, int S) {
     if (threadIdx.x == 0) {
@@ -532,66 +546,110 @@ __global__ __launch_bounds__(256) void k_rs_init(RsState* rs, int S) {
         rs->remaining = S;
         rs->n_gt = 0;
         rs->n_eq = 0;
+        rs->settled = 0;
+        rs->ticket = 0;
     }
-    rs->hist[threadIdx.x] = 0;
+    for (int b = threadIdx.x; b < kRsBins; b += 256) rs->hist[b] = 0;
 }
 
-__global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec, int64_t N, RsState* rs) {
-    __shared__ unsigned int h[256];
+// One pass: histogram of the current digit over the keys that match the prefix; the last workgroup to finish walks the
+// histogram from the largest digit down, extends the prefix and decides whether the selection is settled.
+__global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec, int64_t N, RsState* rs, int settle) {
+    __shared__ unsigned int h[kRsBins];
+    __shared__ unsigned int part[256];
+    __shared__ unsigned int last;
     const int tid = threadIdx.x;
-    h[tid] = 0;
-    __syncthreads();
+    if (rs->settled || rs->pass >= kRsPasses) return;
     const int pass = rs->pass;
-    const int shift = 56 - 8 * pass;
-    const unsigned long long prefix = rs->prefix;
-    const unsigned long long himask = pass == 0 ? 0ull : (~0ull << (64 - 8 * pass));
+    const int fixed = rs_fixed_bits(pass), width = (pass + 1 < kRsPasses) ? kRsDigit : 64 - fixed, shift = 64 - fixed - width;
+    const unsigned long long prefix = rs->prefix, himask = rs_himask(fixed);
+    const unsigned int dmask = (1u << width) - 1u;
+    for (int b = tid; b < kRsBins; b += 256) h[b] = 0;
+    __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < N; i += (int64_t)gridDim.x * 256) {
         const unsigned long long key = abs_key(cvec[i]);
-        if ((key & himask) == prefix) atomicAdd(&h[(key >> shift) & 0xff], 1u);
+        if ((key & himask) == prefix) atomicAdd(&h[(unsigned int)(key >> shift) & dmask], 1u);
     }
     __syncthreads();
-    if (h[tid]) atomicAdd(&rs->hist[tid], h[tid]);
-}
-
-__global__ __launch_bounds__(256) void k_rs_scan(RsState* rs) {
-    __shared__ unsigned int h[256];
-    const int tid = threadIdx.x;
-    h[tid] = rs->hist[tid];
+    for (int b = tid; b < kRsBins; b += 256)
+        if (h[b]) atomicAdd(&rs->hist[b], h[b]);
+    __threadfence();
     __syncthreads();
-    if (tid == 0) {
-        int rem = rs->remaining;
-        int b = 255;
-        for (; b > 0; --b) {  // walk from the largest digit down
-            if ((int)h[b] >= rem) break;
-            rem -= (int)h[b];
+    if (tid == 0) last = (atomicAdd(&rs->ticket, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    // thread t owns the 8 digits 2047 - 8t .. 2040 - 8t (descending); prefix sums over the threads, then the owner of the
+    // crossing walks its 8 bins
+    constexpr int PER = kRsBins / 256;
+    unsigned int mine[PER], sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        mine[u] = __hip_atomic_load(&rs->hist[kRsBins - 1 - (tid * PER + u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sum += mine[u];
+    }
+    part[tid] = sum;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int t = 0; t < tid; ++t) before += part[t];  // (256 LDS reads per thread at most: a microsecond, once per pass)
+    const unsigned int rem = (unsigned int)rs->remaining;
+    __syncthreads();
+    if (before < rem && before + sum >= rem) {  // exactly one thread, unless fewer than `remaining` keys exist at all
+        unsigned int acc = before;
+        int u = 0;
+        for (; u < PER - 1; ++u) {
+            if (acc + mine[u] >= rem) break;
+            acc += mine[u];
         }
-        rs->prefix |= (unsigned long long)b << (56 - 8 * rs->pass);
-        rs->remaining = rem;
-        rs->pass += 1;
+        const int b = kRsBins - 1 - (tid * PER + u);
+        rs->prefix = prefix | ((unsigned long long)b << shift);
+        rs->remaining = (int)(rem - acc);
+        rs->pass = pass + 1;
+        if ((int)mine[u] <= settle) rs->settled = 1;
     }
-    __syncthreads();
-    rs->hist[tid] = 0;
+    if (tid == 255 && before + sum < rem) {  // N < S cannot happen (S is clamped to N); keep the state consistent anyway
+        rs->pass = pass + 1;
+        rs->remaining = (int)(rem - (before + sum)) < 0 ? 0 : (int)(rem - (before + sum));
+    }
+    for (int b = tid; b < kRsBins; b += 256) rs->hist[b] = 0;
+    if (tid == 0) rs->ticket = 0;
 }
 
-// after 8 passes prefix == the S-th largest key T and `remaining` == how many keys equal to T to take
+// keys above the prefix bucket -> gt_idx, keys inside it -> eq_idx (at most eq_cap are kept; more than that only when the
+// selection never settled, i.e. after all passes: then the bucket is one exact key and k_rs_finish scans for the ties)
 __global__ __launch_bounds__(256) void k_rs_collect(const double* __restrict__ cvec, int64_t N, RsState* rs,
                                                     int* __restrict__ gt_idx, int* __restrict__ eq_idx, int eq_cap) {
-    const unsigned long long T = rs->prefix;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
-        const unsigned long long key = abs_key(cvec[i]);
-        if (key > T) {
-            gt_idx[atomicAdd(&rs->n_gt, 1)] = (int)i;
-        } else if (key == T) {
-            const int p = atomicAdd(&rs->n_eq, 1);
-            if (p < eq_cap) eq_idx[p] = (int)i;
+    const unsigned long long T = rs->prefix, himask = rs_himask(rs_fixed_bits(rs->pass));
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < N; i0 += stride) {  // (whole waves stay in the loop: ballots below)
+        const int64_t i = i0 + threadIdx.x;
+        const unsigned long long kh = i < N ? abs_key(cvec[i]) & himask : 0ull;
+        const bool gt = i < N && kh > T, eq = i < N && kh == T;
+        // one counter update per wave and list: the lanes that append take consecutive slots
+        const unsigned long long mg = __ballot(gt), me = __ballot(eq);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (mg) {
+            int base = 0;
+            if (lane == __ffsll((long long)mg) - 1) base = atomicAdd(&rs->n_gt, __popcll(mg));
+            base = __shfl(base, __ffsll((long long)mg) - 1, kWave);
+            if (gt) gt_idx[base + __popcll(mg & below)] = (int)i;
+        }
+        if (me) {
+            int base = 0;
+            if (lane == __ffsll((long long)me) - 1) base = atomicAdd(&rs->n_eq, __popcll(me));
+            base = __shfl(base, __ffsll((long long)me) - 1, kWave);
+            const int p = base + __popcll(me & below);
+            if (eq && p < eq_cap) eq_idx[p] = (int)i;
         }
     }
 }
 
-// ONE workgroup: the keys above T plus the `remaining` lowest-index keys equal to T, rank-sorted by
-// (|c| descending, index ascending) into cands.  (The append order above is arbitrary; the sort
-// makes the output deterministic.)  If more keys tie at T than eq_idx holds (e.g. r = 0: every
-// |c| is 0), the ties are taken by an in-order scan of c instead.
+// The keys above the bucket plus the `remaining` best of the bucket -- (|c| descending, index ascending) -- rank-sorted by
+// the same order into cands.  (The append order above is arbitrary; the sort makes the output deterministic.)  Every
+// workgroup builds the whole survivor list (in LDS when lds_pairs of (value, index) fit, else in `work`, which every workgroup
+// fills with the same values) and ranks 256 of its entries.  If more keys tie at T than eq_idx holds (e.g. r = 0: every |c|
+// is 0), the ties are taken by an in-order scan of c instead.
 __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cvec, int64_t N, RsState* rs,
                                                    const int* __restrict__ gt_idx, const int* __restrict__ eq_idx,
                                                    int eq_cap, int* __restrict__ work /*S ints*/,
@@ -599,16 +657,32 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
                                                    int* __restrict__ ncands, int lds_pairs) {
     __shared__ int wcnt[4];
     __shared__ int taken;
+    extern __shared__ __attribute__((aligned(16))) double rs_lds[];  // lds_pairs x (value, index) | eq_cap x (value, index)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ngt = rs->n_gt, neq = rs->n_eq, take = min(rs->remaining, neq);
     const unsigned long long T = rs->prefix;
-    for (int t = tid; t < ngt; t += 256) work[t] = gt_idx[t];
+    const int n = ngt + take;
+    const bool in_lds = n <= lds_pairs;
+    double* sv = rs_lds;
+    int* si = reinterpret_cast<int*>(rs_lds + lds_pairs);
+    int* list = in_lds ? si : work;
+    for (int t = tid; t < ngt; t += 256) list[t] = gt_idx[t];
     if (neq <= eq_cap) {
-        for (int t = tid; t < neq; t += 256) {  // rank the ties by index, keep the `take` lowest
-            const int me = eq_idx[t];
+        // the bucket, staged with its values; rank by (|c| descending, index ascending), keep the `take` first
+        double* ev = reinterpret_cast<double*>(si + lds_pairs + (lds_pairs & 1));
+        int* ei = reinterpret_cast<int*>(ev + eq_cap);
+        for (int t = tid; t < neq; t += 256) {
+            const int o = eq_idx[t];
+            ei[t] = o;
+            ev[t] = fabs(cvec[o]);
+        }
+        __syncthreads();
+        for (int t = tid; t < neq; t += 256) {
+            const int me = ei[t];
+            const double mv = ev[t];
             int rank = 0;
-            for (int u = 0; u < neq; ++u) rank += (eq_idx[u] < me);
-            if (rank < take) work[ngt + rank] = me;
+            for (int u = 0; u < neq; ++u) rank += (ev[u] > mv) || (ev[u] == mv && ei[u] < me);
+            if (rank < take) list[ngt + rank] = me;
         }
     } else {
         if (tid == 0) taken = 0;
@@ -622,7 +696,7 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
             int off = taken;
             for (int w = 0; w < wave; ++w) off += wcnt[w];
             off += __popcll(m & ((1ull << lane) - 1ull));
-            if (hit && off < take) work[ngt + off] = (int)i;
+            if (hit && off < take) list[ngt + off] = (int)i;
             __syncthreads();
             if (tid == 0) taken += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
             __syncthreads();
@@ -630,20 +704,12 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
         }
     }
     __syncthreads();
-    const int n = ngt + take;
-    // rank sort of the n survivors: (|c| descending, index ascending).  The (value, index) pairs are staged in LDS when
-    // they fit (lds_pairs of them: the launcher's dynamic allocation) -- n^2 comparisons on global gathers cost 200 us at n = 512
-    extern __shared__ __attribute__((aligned(16))) double rs_lds[];
-    if (n <= lds_pairs) {
-        double* sv = rs_lds;
-        int* si = reinterpret_cast<int*>(rs_lds + lds_pairs);
-        for (int t = tid; t < n; t += 256) {
-            const int o = work[t];
-            si[t] = o;
-            sv[t] = fabs(cvec[o]);
-        }
+    // rank sort of the n survivors, 256 per workgroup: n^2 comparisons on global gathers cost 200 us at n = 512 in one
+    // workgroup, hence the LDS staging and the split
+    if (in_lds) {
+        for (int t = tid; t < n; t += 256) sv[t] = fabs(cvec[si[t]]);
         __syncthreads();
-        for (int t = tid; t < n; t += 256) {
+        for (int t = blockIdx.x * 256 + tid; t < n; t += gridDim.x * 256) {
             const int me = si[t];
             const double mv = sv[t];
             int rank = 0;
@@ -652,7 +718,7 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
             cvals[rank] = mv;
         }
     } else {
-        for (int t = tid; t < n; t += 256) {
+        for (int t = blockIdx.x * 256 + tid; t < n; t += gridDim.x * 256) {
             const int me = work[t];
             const double mv = fabs(cvec[me]);
             int rank = 0;
@@ -665,7 +731,7 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
             cvals[rank] = mv;
         }
     }
-    if (tid == 0) *ncands = n;
+    if (tid == 0 && blockIdx.x == 0) *ncands = n;
 }
 
 // ---------------------------------------------------------------------------------------------

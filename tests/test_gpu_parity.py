@@ -224,6 +224,36 @@ def test_topk_sweep_semantics(cs, oracle, D):
     assert np.array_equal(cs.argmaxinner(d, r, 5), oracle.topk_desc(d.ctx.sweep(r, 1)[0], 5))
 
 
+def test_topk_radix_select_buckets_and_ties(cs, oracle, D):
+    """The radix select (large k) on data built to stress its bucket logic: |c| taken from a few exact levels (every bucket is
+    one massive tie: more ties than the bucket list holds -> in-order scan; fewer -> ranked by index), values that share their
+    leading 22 bits (the selection does not settle after two passes), and plain Gaussian data of reference size."""
+    rng = np.random.default_rng(3)
+
+    def check(levels, ks):
+        n = levels.size
+        A = np.zeros((1024, n), np.float32, order="F")  # (k <= size(A,1) is the ABI's bound)
+        A[0] = levels
+        d = D(A)
+        r = np.zeros(1024)
+        r[0] = 1.0
+        for k in ks:
+            out, ti, tv = d.ctx.sweep(r, k)
+            np.testing.assert_array_equal(out, np.abs(levels.astype(np.float64)))
+            want = oracle.topk_desc(out, k)
+            assert np.array_equal(ti, want), (k, ti[:8], want[:8])
+            np.testing.assert_array_equal(tv, out[ti])
+
+    # 3 levels, 20000 atoms: the bucket of the k-th key is a tie of ~6700 (> 4096 kept) or, for k small, the top level
+    check(rng.choice(np.array([0.25, 0.5, 1.0], np.float32), 20000) * rng.choice(np.array([-1, 1], np.float32), 20000), (40, 300, 1000))
+    # 60 levels, 6000 atoms: ties of ~100 inside the bucket
+    check(rng.choice(np.linspace(0.1, 0.9, 60).astype(np.float32), 6000), (33, 500, 1023))
+    # distinct values that agree in sign, exponent and 11 leading mantissa bits: 1 + j * 2^-20, j < 9000
+    check((1.0 + np.arange(9000) * 2.0 ** -20).astype(np.float32)[rng.permutation(9000)], (64, 700))
+    # Gaussian, N = 131072 (configs[4]'s N), k = 512 and 1023
+    check(rng.standard_normal(131072).astype(np.float32), (512, 1023))
+
+
 def test_lstsq_pin(cs, oracle, D):
     # test/forward.jl:23-28: "P.AiQR \\ y ~ A[:, nzind] \\ y" -- the reference's one direct pin of the QR
     A, x, b = cs.sparse_data(n=32, m=48, k=3, rng=5)
