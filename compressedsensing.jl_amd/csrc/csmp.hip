@@ -65,6 +65,13 @@ struct Solver {
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
+    // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
+    // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
+    double *Gkeep = nullptr, *gdkeep = nullptr;
+    int* kpos = nullptr;
+    std::vector<int> keep_cols, hpos;
+    int keep_n = 0, keep_np = 0;
+    bool keep_valid = false;
     std::vector<int> hcols;  // host copy of the column list an asynchronous upload reads from (kept until the next one)
     void* Acomp = nullptr;  // the set's columns, contiguous (np columns of Mv elements of the dictionary's type)
     int gram_np = 0, gram_split = 0;
@@ -254,7 +261,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos);
     s = Solver();
 }
 
@@ -608,6 +615,7 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
         return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
     HIPCHECK(hipMemcpyAsync(s.bstage, hb.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // hb goes out of scope
+    s.keep_valid = false;  // (the kept Gram matrix carries A_S'b of the previous b)
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
@@ -617,6 +625,7 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
 template <typename TB>
 static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
     Solver& s = ctx->s;
+    s.keep_valid = false;
     hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
@@ -1856,8 +1865,12 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos);
     s.gram_np = s.gram_split = 0;
+    s.keep_valid = false;
+    CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
+    CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
@@ -1885,20 +1898,47 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     s.hcols.push_back(n);
     HIPCHECK(hipMemcpyAsync(s.cands, s.hcols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, s.hcols.data() + n, 4, hipMemcpyHostToDevice, ctx->stream));
-    const int blk = 16;
-    const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
-    const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
-    hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)((ldo + 255) / 256), np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
-                       (const int*)s.cands, n, (TA*)s.Acomp, ldo);
-    hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
-                       rps, s.Gpart);
-    HIPCHECK(hipGetLastError());
-    const int64_t nel = (int64_t)np * np;
-    hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
-                       s.Gm, s.gdiag);
-    hipLaunchKernelGGL(k_gram_rhs<TA>, dim3((n + 1 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands,
-                       n, np, (const double*)s.b, s.Gm);
-    HIPCHECK(hipGetLastError());
+    // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
+    bool subset = s.keep_valid && n <= s.keep_n && !getenv("CSMP_NO_GRAM_REUSE");
+    if (subset) {
+        std::vector<std::pair<int, int>> where((size_t)s.keep_n);
+        for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
+        std::sort(where.begin(), where.end());
+        s.hpos.assign((size_t)n, 0);
+        for (int t = 0; t < n && subset; ++t) {
+            auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(cols[t], 0));
+            if (it == where.end() || it->first != cols[t]) subset = false;
+            else s.hpos[t] = it->second;
+        }
+    }
+    if (subset) {
+        HIPCHECK(hipMemcpyAsync(s.kpos, s.hpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        const int64_t nel = (int64_t)np * np;
+        hipLaunchKernelGGL(k_gram_subset, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep, s.keep_np, s.keep_n,
+                           (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag);
+        HIPCHECK(hipGetLastError());
+    } else {
+        const int blk = 16;
+        const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
+        const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
+        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)((ldo + 255) / 256), np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                           (const int*)s.cands, n, (TA*)s.Acomp, ldo);
+        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
+                           rps, s.Gpart);
+        HIPCHECK(hipGetLastError());
+        const int64_t nel = (int64_t)np * np;
+        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
+                           s.Gm, s.gdiag);
+        hipLaunchKernelGGL(k_gram_rhs<TA>, dim3((n + 1 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands,
+                           n, np, (const double*)s.b, s.Gm);
+        HIPCHECK(hipGetLastError());
+        HIPCHECK(hipMemcpyAsync(s.Gkeep, s.Gm, (size_t)np * np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(s.gdkeep, s.gdiag, (size_t)np * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        s.keep_cols.assign(cols.begin(), cols.end());
+        s.keep_n = n;
+        s.keep_np = np;
+        s.keep_valid = true;
+    }
     const int nsteps = (n + 1 + kCholNB - 1) / kCholNB;  // (the identity padding beyond the bordered column needs no elimination)
     {
         const int left0 = np - kCholNB;

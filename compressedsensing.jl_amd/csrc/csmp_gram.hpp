@@ -132,6 +132,31 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     if (row == col && row < n) gdiag[row] = s;
 }
 
+// The bordered Gram matrix of a set that lies inside the set of the kept matrix K (kn columns, leading dimension knp): entry
+// (i, j) is K's entry (pos[i], pos[j]) -- K holds the upper tiles, so the pair is ordered first -- the right-hand side and
+// the corner come from K's bordered column, the diagonal reference from K's.  Same layout rules as k_gram_reduce.
+__global__ __launch_bounds__(256) void k_gram_subset(const double* __restrict__ K, int knp, int kn, const double* __restrict__ kdiag,
+                                                     const int* __restrict__ pos, int n, int np, double* __restrict__ G,
+                                                     double* __restrict__ gdiag) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)np * np) return;
+    const int row = (int)(e % np), col = (int)(e / np);
+    if ((row / kGramTile) > (col / kGramTile)) return;  // lower tiles are never read
+    double s = 0.0;
+    if (row < n && col < n) {
+        const int a = pos[row], b = pos[col];
+        s = K[min(a, b) + (int64_t)max(a, b) * knp];
+    } else if (row < n && col == n) {
+        s = K[pos[row] + (int64_t)kn * knp];
+    } else if (row == n && col == n) {
+        s = K[kn + (int64_t)kn * knp];
+    } else if (row == col && row > n) {
+        s = 1.0;
+    }
+    G[e] = s;
+    if (row == col && row < n) gdiag[row] = kdiag[pos[row]];
+}
+
 // column n of the bordered matrix: c_j = <a_{s_j}, b> (one wave per column, Float64), and the corner b'b
 template <typename TA>
 __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
