@@ -46,6 +46,7 @@ SIGNATURES = {
     "csmp_fr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, C.c_double, vp, vp, C.POINTER(i64), vp]),
     "csmp_fr_scores": (C.c_int, [vp, vp]),
     "csmp_srr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, C.c_int, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_srr_from": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_rmp_delta": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, i64, vp, vp, C.POINTER(i64)]),
     "csmp_rmp_k": (C.c_int, [vp, vp, C.c_int, i64, i64, vp, vp, C.POINTER(i64)]),
     "csmp_foba": (C.c_int, [vp, vp, C.c_int, C.c_double, i64, vp, vp, C.POINTER(i64)]),
@@ -272,13 +273,21 @@ class Context:
         n = nnz.value
         return idx[:n].copy(), val[:n].copy(), order[:n].copy()
 
-    def srr(self, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1):
+    def srr(self, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1, init=None):
         b = self._b(b)
         cap = int(k) + int(l) + 1
         idx = np.zeros(cap, np.int64)
         val = np.zeros(cap, np.float64)
         nnz = i64(0)
         iters = i64(0)
+        if int(initialization) == 3:
+            init = np.ascontiguousarray(init, np.int64)
+            if init.size != int(k):
+                raise ValueError("srr: initialization = 3 needs k initial atoms")
+            self.call("csmp_srr_from", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
+                      ptr(init), i64(int(l)), ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
+            n = nnz.value
+            return idx[:n].copy(), val[:n].copy(), iters.value
         self.call("csmp_srr", ptr(b), dtype_code(b.dtype), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
                   int(initialization), i64(int(l)), ptr(idx), ptr(val), C.byref(nnz), C.byref(iters))
         n = nnz.value

@@ -189,14 +189,16 @@ def fr(A, b, *args, max_residual=0.0, min_decrease=0.0, sparsity=None):
 ols = oomp = ormp = fr  # src/forward.jl:52-54
 
 
-def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
+def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1, rng=None, init=None):
     """srr(A,b,k,delta=1e-12; maxiter=4k, initialization=1, l=1): stepwise regression with replacement,
-    src/twostage.jl:3-33 (x empty).  initialization 3 (random) is not offered: it draws from Julia's RNG."""
-    if initialization == 3:
-        raise ValueError("srr: initialization = 3 (random_acquisition!) is not reproducible outside Julia; use 1 or 2")
+    src/twostage.jl:3-33 (x empty).  initialization 3 = random_acquisition! (src/matchingpursuit.jl:195-204): the k initial
+    atoms are drawn HERE, without replacement, from `rng` (a numpy Generator or a seed) -- the reference draws them from Julia's
+    global RNG, so only the distribution matches, not the draw; pass `init` (k atom indices) to fix the draw itself."""
     D, tmp = _dict(A)
     try:
-        idx, val, _ = D.ctx.srr(b, int(k), float(delta), -1 if maxiter is None else int(maxiter), int(initialization), int(l))
+        if int(initialization) == 3 and init is None:
+            init = np.random.default_rng(rng).choice(D.shape[1], size=int(k), replace=False)
+        idx, val, _ = D.ctx.srr(b, int(k), float(delta), -1 if maxiter is None else int(maxiter), int(initialization), int(l), init)
         return SparseVector(D.shape[1], idx, val)
     finally:
         if tmp:

@@ -2449,13 +2449,15 @@ static int stepwise_args(csmp_ctx* ctx, const void* b, const char* who) {
     return CSMP_OK;
 }
 
-// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty
-extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
-                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty.  initialization 3
+// (random_acquisition!, src/matchingpursuit.jl:195-204) takes its k atoms from `init` (sorted, distinct): the draw is the
+// caller's -- the reference takes it from the host language's RNG.
+static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                    const std::vector<int>* init, int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
     CHECK(stepwise_args(ctx, b, "srr"));
     if (k < 1 || l < 1) return fail(ctx, CSMP_EINVAL, "srr: k < 1 or l < 1");
-    if (initialization != 1 && initialization != 2)
-        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression)");
+    if (initialization != 1 && initialization != 2 && !(initialization == 3 && init))
+        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression); 3 (random) through csmp_srr_from");
     if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
     if (k + l > kTMaxCols) return fail(ctx, CSMP_ERANGE, "srr: k + l exceeds 1023");
     if (maxiter < 0) maxiter = 4 * k;  // :5
@@ -2463,14 +2465,18 @@ extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     Stepwise P;
     CHECK(P.begin(ctx, b, b_dtype, (int)(k + l)));
     Solver& s = ctx->s;
-    if (initialization == 1) {
-        // oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216
-        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-        CHECK(launch_topS(ctx, (int)k));
+    if (initialization == 1 || initialization == 3) {
         std::vector<int> top((size_t)k);
-        HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        std::sort(top.begin(), top.end());
+        if (initialization == 1) {
+            // oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216
+            CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+            CHECK(launch_topS(ctx, (int)k));
+            HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            std::sort(top.begin(), top.end());
+        } else {
+            top = *init;  // random_acquisition!(P, x, k): :195-204 -- the caller's draw, sorted
+        }
         CHECK(ls_on_columns(ctx, top));
         // rho2_j = |a_j|^2 - |Q'a_j|^2 for the k columns just factorised: the norms, then four columns per pass
         FrPass p0;
@@ -2602,6 +2608,28 @@ static bool x_changed(const std::vector<int64_t>& i0, const std::vector<double>&
 }
 
 // rmp(A, b, delta, maxiter): src/stepwise.jl:5-26
+
+extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (initialization == 3) return fail(ctx, CSMP_EINVAL, "srr: initialization 3 (random) needs the drawn atoms: csmp_srr_from");
+    return srr_impl(ctx, b, b_dtype, k, delta, maxiter, initialization, nullptr, l, idx, val, nnz, iters);
+}
+
+// srr with initialization = 3: init[0..k) are the k distinct atoms random_acquisition! would have drawn (any order)
+extern "C" int csmp_srr_from(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, const int64_t* init,
+                             int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!init || k < 1) return fail(ctx, CSMP_EINVAL, "srr_from: init == NULL or k < 1");
+    std::vector<int> top((size_t)k);
+    for (int64_t t = 0; t < k; ++t) {
+        if (init[t] < 0 || init[t] >= ctx->N) return fail(ctx, CSMP_ERANGE, "srr_from: atom index out of range");
+        top[t] = (int)init[t];
+    }
+    std::sort(top.begin(), top.end());  // sort!(ind) (:197)
+    if (std::adjacent_find(top.begin(), top.end()) != top.end()) return fail(ctx, CSMP_EINVAL, "srr_from: duplicate atom");
+    return srr_impl(ctx, b, b_dtype, k, delta, maxiter, 3, &top, l, idx, val, nnz, iters);
+}
 extern "C" int csmp_rmp_delta(csmp_ctx* ctx, const void* b, int b_dtype, double delta, int64_t maxiter, int64_t kmax, int64_t* idx,
                               double* val, int64_t* nnz) {
     CHECK(stepwise_args(ctx, b, "rmp"));

@@ -12,6 +12,7 @@ module CompressedSensingAMD
 
 using LinearAlgebra
 using SparseArrays
+using Random
 
 const libcsmp = get(ENV, "LIBCSMP", joinpath(@__DIR__, "..", "csrc", "libcsmp.so"))
 
@@ -162,12 +163,22 @@ const oomp = fr
 const ormp = fr
 
 # ---------------------------------------------------------------------------------- srr
-# src/twostage.jl:3-33 (x starting empty; initialization 1 = oblivious, 2 = forward regression)
+# src/twostage.jl:3-33 (x starting empty; initialization 1 = oblivious, 2 = forward regression, 3 = random: the k atoms are
+# drawn here without replacement (randperm; the reference: sample(1:n, k, replace = false), src/matchingpursuit.jl:196) or taken
+# from `init` (1-based), and handed to csmp_srr_from)
 function srr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxiter = 4k,
-             initialization::Int = 1, l::Int = 1) where {T}
+             initialization::Int = 1, l::Int = 1, init = nothing) where {T}
     D = dict(A)
     bb, bt = bvec(b)
     idx, val, nnz, iters = zeros(Int64, k + l + 1), zeros(Float64, k + l + 1), Ref{Int64}(0), Ref{Int64}(0)
+    if initialization == 3
+        ind = init === nothing ? randperm(size(D, 2))[1:k] : collect(init)
+        ind0 = Int64.(ind) .- 1
+        GC.@preserve bb idx val ind0 check(D, ccall((:csmp_srr_from, libcsmp), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Int64, Ptr{Int64}, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}),
+            D.ctx, bb, bt, k, δ, maxiter, ind0, l, idx, val, nnz, iters))
+        return to_sparse(size(D, 2), idx, val, nnz[])
+    end
     GC.@preserve bb idx val check(D, ccall((:csmp_srr, libcsmp), Cint,
         (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cdouble, Int64, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ref{Int64}),
         D.ctx, bb, bt, k, δ, maxiter, initialization, l, idx, val, nnz, iters))

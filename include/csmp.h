@@ -125,6 +125,13 @@ int csmp_fr_scores(csmp_ctx *ctx, double *delta2);
  * Capacity k + l (at most 1023).  *iters (may be NULL) = iterations made. */
 int csmp_srr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
              int64_t l, int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
+/* srr with initialization = 3 (random_acquisition!, src/matchingpursuit.jl:195-204; src/twostage.jl:14-16): init[0..k) are the k
+ * distinct atoms of the initial support (0-based, any order).  The reference draws them with sample(1:n, k, replace = false) from
+ * the host language's RNG; here the host draws and passes them, everything after the draw is the reference's.  The same call is
+ * the warm start srr(A, b, k, delta, x) of a full support, nnz(x) == k (src/twostage.jl:7-9: P is built on x.nzind and the
+ * acquisition of k - nnz(x) = 0 further atoms changes nothing). */
+int csmp_srr_from(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, const int64_t *init,
+                  int64_t l, int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
 
 /* rmp(A,b,delta,maxiter) (src/stepwise.jl:5-26), rmp(A,b,k) (:32-43) and foba(A,b,delta) (:47-56), x
  * starting empty: loops over forward_step! (src/forward.jl:56-73) and backward_step!

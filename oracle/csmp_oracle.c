@@ -801,9 +801,9 @@ static int srr_backward_sel(srr_t *P, double max_eps, double max_d2, int lace) {
 
 static int srr_backward(srr_t *P) { return srr_backward_thr(P, INFINITY, INFINITY); }
 
-int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
-            double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
-            int64_t *nnz, int64_t *iters, int nthreads) {
+static int srr_core(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+                    double delta, int64_t maxiter, int initialization, const int64_t *init, int64_t l, int64_t *idx,
+                    double *val, int64_t *nnz, int64_t *iters, int nthreads) {
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
     if (nthreads > 16) nthreads = 16;
@@ -811,7 +811,7 @@ int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const do
     nthreads = 1;
 #endif
     if (k < 1 || k > N || k + l > M || l < 1) return CSO_ERANGE;
-    if (initialization != 1 && initialization != 2) return CSO_EINVAL;
+    if (initialization != 1 && initialization != 2 && !(initialization == 3 && init)) return CSO_EINVAL;
     if (maxiter < 0) maxiter = 4 * k; /* :5 */
     srr_t P;
     memset(&P, 0, sizeof P);
@@ -839,6 +839,10 @@ int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const do
         srr_refit(&P);
         free(Ar);
         free(top);
+    } else if (initialization == 3) { /* random_acquisition!(P, x, k), src/matchingpursuit.jl:195-204: the k indices are the
+                                       * caller's draw (the reference takes them from Julia's RNG), sorted, appended in order */
+        for (int64_t t = 0; t < k; ++t) srr_insert(&P, init[t]);
+        srr_refit(&P);
     } else { /* k times update!(P::FR, x): src/forward.jl:88-95 (no residual / decrease guards) */
         for (int64_t t = 0; t < k; ++t) srr_forward(&P, 0.0, 0.0, 0);
     }
@@ -866,6 +870,32 @@ int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const do
     free(P.norm2);
     hqr_free(&P.F);
     return CSO_OK;
+}
+int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+            double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
+            int64_t *nnz, int64_t *iters, int nthreads) {
+    if (initialization == 3) return CSO_EINVAL; /* the draw is the caller's: cso_srr_from */
+    return srr_core(A, dtype, M, N, ld, b, k, delta, maxiter, initialization, NULL, l, idx, val, nnz, iters, nthreads);
+}
+/* srr with initialization = 3: `init` holds the k distinct atoms random_acquisition! would have drawn (any order) */
+int cso_srr_from(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+                 double delta, int64_t maxiter, const int64_t *init, int64_t l, int64_t *idx, double *val,
+                 int64_t *nnz, int64_t *iters, int nthreads) {
+    if (!init || k < 1) return CSO_EINVAL;
+    int64_t *srt = (int64_t *)malloc((size_t)k * sizeof(int64_t));
+    memcpy(srt, init, (size_t)k * sizeof(int64_t));
+    for (int64_t a = 1; a < k; ++a) { /* sort!(ind) */
+        const int64_t v = srt[a];
+        int64_t c = a - 1;
+        for (; c >= 0 && srt[c] > v; --c) srt[c + 1] = srt[c];
+        srt[c + 1] = v;
+    }
+    int bad = srt[0] < 0 || srt[k - 1] >= N;
+    for (int64_t a = 1; a < k; ++a) bad |= srt[a] == srt[a - 1];
+    const int rc = bad ? CSO_EINVAL
+                       : srr_core(A, dtype, M, N, ld, b, k, delta, maxiter, 3, srt, l, idx, val, nnz, iters, nthreads);
+    free(srt);
+    return rc;
 }
 
 

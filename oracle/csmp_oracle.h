@@ -76,6 +76,10 @@ int cso_fr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const dou
 int cso_srr(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
             double delta, int64_t maxiter, int initialization, int64_t l, int64_t *idx, double *val,
             int64_t *nnz, int64_t *iters, int nthreads);
+/* srr with initialization = 3: `init` = the k distinct atoms random_acquisition! (src/matchingpursuit.jl:195-204) would draw */
+int cso_srr_from(const void *A, int dtype, int64_t M, int64_t N, int64_t ld, const double *b, int64_t k,
+                 double delta, int64_t maxiter, const int64_t *init, int64_t l, int64_t *idx, double *val,
+                 int64_t *nnz, int64_t *iters, int nthreads);
 
 /* rmp(A,b,delta,maxiter), rmp(A,b,k), foba(A,b,delta): src/stepwise.jl:5-56 (x starts empty).
  * idx/val sized >= min(M,N) + 1. */

@@ -152,14 +152,26 @@ def fr(A, b, k, max_eps=0.0, min_delta=0.0, nthreads=0):
     return idx[:n].copy(), val[:n].copy(), order[:n].copy()
 
 
-def srr(A, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1, nthreads=0):
-    """srr (src/twostage.jl:3-33) -> (idx sorted 0-based, val, iters)."""
+def srr(A, b, k, delta=1e-12, maxiter=-1, initialization=1, l=1, nthreads=0, init=None):
+    """srr (src/twostage.jl:3-33) -> (idx sorted 0-based, val, iters).  initialization = 3 takes the k atoms of
+    random_acquisition! (src/matchingpursuit.jl:195-204) from `init`: the draw is the caller's."""
     A, b, M, N, dtype = _prep(A, b)
     cap = int(k) + int(l) + 1
     idx = np.zeros(cap, np.int64)
     val = np.zeros(cap, np.float64)
     nnz = i64(0)
     iters = i64(0)
+    if initialization == 3:
+        init = np.ascontiguousarray(init, np.int64)
+        assert init.size == int(k)
+        rc = lib().cso_srr_from(_vp(A), dtype, i64(M), i64(N), i64(M), _vp(b), i64(int(k)), C.c_double(delta),
+                                i64(int(maxiter)), _vp(init), i64(int(l)), _vp(idx), _vp(val), C.byref(nnz),
+                                C.byref(iters), int(nthreads))
+        if rc == -3:
+            raise ValueError("k / l out of range")
+        assert rc == 0, rc
+        n = nnz.value
+        return idx[:n].copy(), val[:n].copy(), iters.value
     rc = lib().cso_srr(_vp(A), dtype, i64(M), i64(N), i64(M), _vp(b), i64(int(k)), C.c_double(delta),
                        i64(int(maxiter)), int(initialization), i64(int(l)), _vp(idx), _vp(val), C.byref(nnz),
                        C.byref(iters), int(nthreads))

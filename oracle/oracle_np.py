@@ -208,7 +208,7 @@ def fr(A, b, k, max_eps=0.0, min_delta=0.0):
     return idx, val, np.array(order, np.int64)
 
 
-def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
+def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1, init=None):
     """Stepwise regression with replacement: src/twostage.jl:3-33 (x starts empty).  Forward scores as
     in fr() above; backward scores x_i^2 / diag(inv(As'As))_i (src/backward.jl:70-83) from a dense
     inverse -- independent of the C restatement's triangular solves."""
@@ -254,6 +254,9 @@ def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1):
     val, r = fit(idx)
     if initialization == 1:
         idx = np.sort(_topk(_abs_corr(A, b), k)).astype(np.int64)
+        val, r = fit(idx)
+    elif initialization == 3:  # random_acquisition! (src/matchingpursuit.jl:195-204) with the caller's draw
+        idx = np.sort(np.asarray(init, np.int64))
         val, r = fit(idx)
     else:
         for _ in range(k):

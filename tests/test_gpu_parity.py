@@ -884,6 +884,29 @@ def test_srr_matches_oracle(cs, oracle, D, cfg, init):
     assert np.array_equal(xg.nzind, ref[0])
 
 
+@pytest.mark.parametrize("cfg", [(32, 64, 3, 1, np.float64), (128, 512, 12, 2, np.float32), (256, 2048, 24, 1, np.float32)])
+def test_srr_random_initialization(cs, oracle, D, cfg):
+    """srr(initialization = 3), src/twostage.jl:14-16: random_acquisition! (src/matchingpursuit.jl:195-204) with the draw made by
+    the caller -- csmp_srr_from -- against the oracle on the same draw; the Python mirror draws from a seeded Generator."""
+    n, m, k, l, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m + k, dtype=dtype)
+    y = cs.perturb(b, 5e-3, rng=3)
+    d = D(A)
+    for seed in range(4):
+        init = np.random.default_rng(seed).choice(m, size=k, replace=False)
+        ref = oracle.srr(A, y, k, 1e-12, -1, 3, l, init=init)
+        got = d.ctx.srr(y, k, 1e-12, -1, 3, l, init)
+        assert np.array_equal(got[0], ref[0]), (seed, got, ref)
+        assert close(got[1], ref[1], tight=False)
+        assert got[2] == ref[2], "iterations"
+        xs = cs.srr(d, y, k, initialization=3, l=l, rng=seed)  # the mirror's own draw: the same Generator, the same atoms
+        assert np.array_equal(xs.nzind, ref[0])
+    with pytest.raises(cs.CsmpError):
+        d.ctx.srr(y, k, 1e-12, -1, 3, l, np.zeros(k, np.int64))  # duplicates (k > 1) / k = 1: a valid single atom
+    with pytest.raises(cs.CsmpError):
+        d.ctx.srr(y, k, 1e-12, -1, 3, l, np.full(k, m, np.int64) + np.arange(k))  # out of range
+
+
 def test_srr_reference_known_answer(cs, D):
     """test/twostage.jl:11-39 on seeded data: planted recovery, noiseless / noisy, k = 1, and l = k."""
     ok = 0

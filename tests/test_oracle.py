@@ -273,6 +273,15 @@ def test_reference_srr_property_and_twin(oracle, cs):
         r, t = oracle.srr(A, y, k, 1e-12, -1, init, l), oracle_np.srr(A, y, k, 1e-12, None, init, l)
         assert np.array_equal(r[0], t[0]) and r[2] == t[2], (n, m, k, l, init)
         np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
+        # initialization = 3 (random_acquisition!, src/matchingpursuit.jl:195-204) on a fixed draw: C restatement == twin,
+        # and the draw's order does not matter (sort!(ind), :197)
+        draw = np.random.default_rng(n + l).choice(m, size=k, replace=False)
+        r = oracle.srr(A, y, k, 1e-12, -1, 3, l, init=draw)
+        t = oracle_np.srr(A, y, k, 1e-12, None, 3, l, init=draw)
+        assert np.array_equal(r[0], t[0]) and r[2] == t[2], (n, m, k, l, "random")
+        np.testing.assert_allclose(r[1], t[1], rtol=1e-8, atol=1e-12)
+        r2 = oracle.srr(A, y, k, 1e-12, -1, 3, l, init=draw[::-1].copy())
+        assert np.array_equal(r[0], r2[0]) and np.array_equal(r[1], r2[1])
 
 
 def test_reference_rmp_foba_property_and_twin(oracle, cs):
