@@ -280,7 +280,7 @@ class Context:
         val = np.zeros(cap, np.float64)
         nnz = i64(0)
         iters = i64(0)
-        if int(initialization) == 3:
+        if int(initialization) == 3 and init is not None:  # (without a draw: csmp_srr refuses initialization 3 itself)
             init = np.ascontiguousarray(init, np.int64)
             if init.size != int(k):
                 raise ValueError("srr: initialization = 3 needs k initial atoms")

@@ -201,6 +201,32 @@ def test_sp_matches_oracle(cs, oracle, D, shape, dtype):
         d.ctx.sp(y, n // 2 + 1, 1e-12)  # CSMP_ERANGE from the ABI itself
 
 
+def test_sp_whole_set_path_and_gram_reuse(cs, oracle, D, monkeypatch):
+    """Supports of >= 64 atoms go through the whole-set least squares (Gram + blocked Cholesky, csrc/csmp_gram.hpp), and the second
+    solve of an SP iteration (the k atoms kept out of the 2k) gathers its Gram matrix from the first one's.  Noisy data, several
+    iterations: against the oracle, against the same library with the reuse switched off, and with the whole path switched off."""
+    n, m, k = 640, 4096, 96
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=77, dtype=np.float32)
+    d = D(A)
+    for seed, noise in ((0, 5e-3), (1, 1e-1), (2, 3e-1)):
+        xs = cs.sparse_vector(m, k + 8, rng=seed)
+        y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, noise, rng=seed + 9)
+        ref = oracle.sp(A, y, k, 1e-12)
+        got = d.ctx.sp(y, k, 1e-12)
+        assert got[2] == ref[2], "number of update! calls"
+        assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+        monkeypatch.setenv("CSMP_NO_GRAM_REUSE", "1")
+        plain = d.ctx.sp(y, k, 1e-12)
+        monkeypatch.delenv("CSMP_NO_GRAM_REUSE")
+        assert np.array_equal(got[0], plain[0]) and got[2] == plain[2]
+        np.testing.assert_allclose(got[1], plain[1], rtol=1e-11, atol=1e-13)
+        monkeypatch.setenv("CSMP_NO_GRAM", "1")
+        chain = d.ctx.sp(y, k, 1e-12)
+        monkeypatch.delenv("CSMP_NO_GRAM")
+        assert np.array_equal(got[0], chain[0]) and got[2] == chain[2]
+        np.testing.assert_allclose(got[1], chain[1], rtol=1e-9, atol=1e-12)
+
+
 def test_topk_sweep_semantics(cs, oracle, D):
     """argmaxinner!(P, k): descending by |<a,r>|, ties by ascending index -- both selection paths
     (arg-max rounds for small k, radix select for large k), including exact ties and r = 0."""
@@ -1033,7 +1059,7 @@ def test_stepwise_family_edge_cases(cs, oracle, D):
     with pytest.raises(cs.CsmpError):
         d.ctx.srr(y, 39, 1e-12, -1, 1, 2)  # k + l > M
     with pytest.raises(cs.CsmpError):
-        d.ctx.srr(y, 3, 1e-12, -1, 3, 1)  # initialization 3 is not offered
+        d.ctx.srr(y, 3, 1e-12, -1, 3, 1)  # initialization 3 without the drawn atoms (csmp_srr_from takes them)
     with pytest.raises(cs.CsmpError):
         D(np.asfortranarray(rng.standard_normal((8, 20)))).ctx.br(np.zeros(8), k=1)  # underdetermined
 
