@@ -329,7 +329,7 @@ def make_dictionary5(cs, torch, dev):
     return At5, cs.Dictionary(At5, device=dev.index)
 
 
-def run_twostage(args, cs, torch, dev, At, D):
+def run_twostage(args, cs, torch, dev, At, D, emit=True):
     """ompr / srr (src/twostage.jl) at the configs[1] shape, k = 256.  The signals carry 8 planted atoms more
     than the solvers may keep and noise 0.3, so that the replacement loops have work to do (tens of
     iterations); one step = one complete solve."""
@@ -370,10 +370,13 @@ def run_twostage(args, cs, torch, dev, At, D):
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
                         "kernel": "csmp::k_sweep_pf<float,16,true>" if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
-    print(json.dumps(out), flush=True)
+    D.ctx.profile_enable(False)
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
 
 
-def run_fr(args, cs, torch, dev, At, D):
+def run_fr(args, cs, torch, dev, At, D, emit=True):
     """Forward regression / OLS (src/forward.jl) at the configs[1] shape, k = 256 atoms per signal.  One step = one
     complete fr(A, b, sparsity=256) solve; the signals are resident in HBM and go through csmp_fr_batch (three in
     flight per tick kernel, like the default workload)."""
@@ -406,7 +409,10 @@ def run_fr(args, cs, torch, dev, At, D):
                         "kernel": "csmp::k_tick_fr<float,8,1> = forward-regression sweep of one signal (c = A'r and the OLS rescaling in one "
                                   "dictionary pass) fused with the two short append stages of two other signals",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
-    print(json.dumps(out), flush=True)
+    D.ctx.profile_enable(False)
+    if emit:
+        print(json.dumps(out), flush=True)
+    return out
 
 
 def rank_census(torch, dist, dev, use_dist, world):
@@ -560,6 +566,15 @@ def main():
                 sec["batched_c3"] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False)
             except Exception as e:  # noqa: BLE001
                 sec["batched_c3"] = {"error": repr(e)}
+            # SURVEY 8(f) rows 2 and 3 at the configs[1] shape: forward regression (batched ticks), ompr, srr
+            import copy
+            for name, wl, st_, wu in (("fr_8f3", "fr", 6, 3), ("ompr_8f2", "ompr", 3, 1), ("srr_8f2", "srr", 3, 1)):
+                a2 = copy.copy(args)
+                a2.workload, a2.steps, a2.warmup = wl, st_, wu
+                try:
+                    sec[name] = (run_fr if wl == "fr" else run_twostage)(a2, cs, torch, dev, At, D, emit=False)
+                except Exception as e:  # noqa: BLE001
+                    sec[name] = {"error": repr(e)}
             D.close()
             del B, idx, val, nnz, At
             torch.cuda.empty_cache()
