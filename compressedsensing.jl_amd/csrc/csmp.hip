@@ -69,10 +69,9 @@ struct Solver {
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
     double *Gkeep = nullptr, *gdkeep = nullptr;
     int* kpos = nullptr;
-    std::vector<int> keep_cols, hpos;
+    std::vector<int> keep_cols;
     int keep_n = 0, keep_np = 0;
     bool keep_valid = false;
-    std::vector<int> hcols;  // host copy of the column list an asynchronous upload reads from (kept until the next one)
     void* Acomp = nullptr;  // the set's columns, contiguous (np columns of Mv elements of the dictionary's type)
     int gram_np = 0, gram_split = 0;
     void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
@@ -110,6 +109,10 @@ struct csmp_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop{};
     std::string err;
+    // page-locked host buffers for the small transfers on the latency chains (slot 0: the signal going up, slot 1: results and
+    // control words coming down): a copy from or to pageable memory is staged by the runtime and blocks the host for every piece
+    void* pin[3] = {nullptr, nullptr, nullptr};  // (slot 2: column lists going up)
+    size_t pin_bytes[3] = {0, 0, 0};
     // dictionary
     void* dA = nullptr;
     bool ownA = false;
@@ -281,7 +284,24 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    for (int q = 0; q < 3; ++q)
+        if (ctx->pin[q]) (void)hipHostFree(ctx->pin[q]);
     delete ctx;
+    return CSMP_OK;
+}
+
+// slot `q` of the page-locked host buffers, at least `bytes` long (grown with the stream drained: nothing is in flight on it)
+static int pin_get(csmp_ctx* ctx, int q, size_t bytes, void** out) {
+    if (ctx->pin_bytes[q] < bytes) {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->pin[q]) HIPCHECK(hipHostFree(ctx->pin[q]));
+        ctx->pin[q] = nullptr;
+        ctx->pin_bytes[q] = 0;
+        const size_t want = std::max<size_t>(bytes, 64 * 1024);
+        HIPCHECK(hipHostMalloc(&ctx->pin[q], want, hipHostMallocDefault));
+        ctx->pin_bytes[q] = want;
+    }
+    *out = ctx->pin[q];
     return CSMP_OK;
 }
 
@@ -606,15 +626,18 @@ static int solver_fit_for_removal(csmp_ctx* ctx, int kcap) {
 static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     Solver& s = ctx->s;
     const int M = (int)ctx->M;
-    std::vector<double> hb((size_t)M);
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    // through the page-locked slot: the copy is asynchronous and the host does not wait for it.  The slot is rewritten by the
+    // next upload only -- after the stream has been drained at least once (every entry point ends with its results on the host).
+    void* pv = nullptr;
+    CHECK(pin_get(ctx, 0, (size_t)M * sizeof(double), &pv));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (a previous upload of a step-level caller may still be in flight)
+    double* hb = (double*)pv;
     if (b_dtype == CSMP_F32)
         for (int i = 0; i < M; ++i) hb[i] = (double)((const float*)b)[i];
-    else if (b_dtype == CSMP_F64)
-        memcpy(hb.data(), b, (size_t)M * sizeof(double));
     else
-        return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
-    HIPCHECK(hipMemcpyAsync(s.bstage, hb.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));  // hb goes out of scope
+        memcpy(hb, b, (size_t)M * sizeof(double));
+    HIPCHECK(hipMemcpyAsync(s.bstage, hb, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     s.keep_valid = false;  // (the kept Gram matrix carries A_S'b of the previous b)
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
@@ -1894,25 +1917,30 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     if (getenv("CSMP_GRAM_DEBUG")) fprintf(stderr, "ls_gram: n %d np %d nsplit %d M %d\n", n, np, nsplit, M);
     CHECK(gram_ensure(ctx, np, nsplit));
     CHECK(solver_restart(ctx));
-    s.hcols.assign(cols.begin(), cols.end());  // (cols may be a temporary of the caller; this copy lives until the next call)
-    s.hcols.push_back(n);
-    HIPCHECK(hipMemcpyAsync(s.cands, s.hcols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(s.ncands, s.hcols.data() + n, 4, hipMemcpyHostToDevice, ctx->stream));
+    // the column list (and, for a subset, its positions in the kept set) go up from a page-locked buffer that lives until the
+    // next call -- every caller drains the stream before it comes back here
+    void* pcv = nullptr;
+    CHECK(pin_get(ctx, 2, (size_t)(2 * n + 2) * 4, &pcv));
+    int* pcols = (int*)pcv;
+    int* ppos = pcols + n + 1;
+    for (int t = 0; t < n; ++t) pcols[t] = cols[t];
+    pcols[n] = n;
+    HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
     // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
     bool subset = s.keep_valid && n <= s.keep_n && !getenv("CSMP_NO_GRAM_REUSE");
     if (subset) {
         std::vector<std::pair<int, int>> where((size_t)s.keep_n);
         for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
         std::sort(where.begin(), where.end());
-        s.hpos.assign((size_t)n, 0);
         for (int t = 0; t < n && subset; ++t) {
             auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(cols[t], 0));
             if (it == where.end() || it->first != cols[t]) subset = false;
-            else s.hpos[t] = it->second;
+            else ppos[t] = it->second;
         }
     }
     if (subset) {
-        HIPCHECK(hipMemcpyAsync(s.kpos, s.hpos.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         const int64_t nel = (int64_t)np * np;
         hipLaunchKernelGGL(k_gram_subset, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep, s.keep_np, s.keep_n,
                            (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag);
@@ -2044,19 +2072,25 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
             HIPCHECK(hipGetLastError());
         }
         const size_t n = cols.size();
-        std::vector<int64_t> hi(n);
-        std::vector<double> hv(n);
-        DevState hs;
-        double n2 = 0.0;
-        HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-        if (resnorm) HIPCHECK(hipMemcpyAsync(&n2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        // one page-locked landing area for everything that comes back: [idx n | val n | control block | ||r||^2]
+        const size_t need = n * 16 + sizeof(DevState) + 16;
+        void* pv = nullptr;
+        CHECK(pin_get(ctx, 1, need, &pv));
+        int64_t* pi = (int64_t*)pv;
+        double* pvv = (double*)(pi + n);
+        DevState* phs = (DevState*)(pvv + n);
+        double* pn2 = (double*)((char*)phs + ((sizeof(DevState) + 7) / 8) * 8);
+        *pn2 = 0.0;
+        HIPCHECK(hipMemcpyAsync(pi, s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(pvv, s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(phs, s.st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+        if (resnorm) HIPCHECK(hipMemcpyAsync(pn2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
+        const DevState hs = *phs;
         if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
-            idx.swap(hi);
-            val.swap(hv);
-            if (resnorm) *resnorm = std::sqrt(n2);
+            idx.assign(pi, pi + n);
+            val.assign(pvv, pvv + n);
+            if (resnorm) *resnorm = std::sqrt(*pn2);
             return CSMP_OK;
         }
     }
@@ -2072,11 +2106,14 @@ static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vect
     Solver& s = ctx->s;
     CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
     CHECK(launch_topS(ctx, k));
-    std::vector<int> top((size_t)k);
-    int nt = 0;
-    HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(&nt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+    void* pv = nullptr;
+    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the two small copies do not block the host one by one)
+    int* top = (int*)pv;
+    int* pnt = top + k;
+    HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int nt = *pnt;
     std::vector<int> cols;
     for (auto i : idx) cols.push_back((int)i);
     for (int t = 0; t < nt; ++t) cols.push_back(top[t]);  // @. x[i] = NaN (:70)
