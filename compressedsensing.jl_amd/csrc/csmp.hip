@@ -1967,7 +1967,9 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         s.keep_np = np;
         s.keep_valid = true;
     }
-    const int nsteps = (n + 1 + kCholNB - 1) / kCholNB;  // (the identity padding beyond the bordered column needs no elimination)
+    // Block rows 0 .. ceil(n / 32) - 1 are all that is needed: the bordered column n is a column of their row panels (or of
+    // the last diagonal block when n is not a multiple of 32); the corner b'b - z'z and the identity padding are never read.
+    const int nsteps = (n + kCholNB - 1) / kCholNB;
     {
         const int left0 = np - kCholNB;
         hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n,

@@ -713,7 +713,16 @@ __global__ __launch_bounds__(256) void k_rs_finish(const double* __restrict__ cv
             const int me = si[t];
             const double mv = sv[t];
             int rank = 0;
-            for (int u = 0; u < n; ++u) rank += (sv[u] > mv) || (sv[u] == mv && si[u] < me);
+            int u = 0;
+            for (; u + 4 <= n; u += 4) {  // (branch-free: the short-circuit form costs a branch and an LDS round trip per entry)
+                const f64x2 v01 = *reinterpret_cast<const f64x2*>(sv + u), v23 = *reinterpret_cast<const f64x2*>(sv + u + 2);
+                const int i0 = si[u], i1 = si[u + 1], i2 = si[u + 2], i3 = si[u + 3];
+                rank += (int)(v01.x > mv) | ((int)(v01.x == mv) & (int)(i0 < me));
+                rank += (int)(v01.y > mv) | ((int)(v01.y == mv) & (int)(i1 < me));
+                rank += (int)(v23.x > mv) | ((int)(v23.x == mv) & (int)(i2 < me));
+                rank += (int)(v23.y > mv) | ((int)(v23.y == mv) & (int)(i3 < me));
+            }
+            for (; u < n; ++u) rank += (int)(sv[u] > mv) | ((int)(sv[u] == mv) & (int)(si[u] < me));
             cands[rank] = me;
             cvals[rank] = mv;
         }
@@ -1502,8 +1511,16 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
     __syncthreads();
     for (int t = tid; t < j; t += 256) {
         const int me = ssel[t];
-        int rank = 0;
-        for (int u = 0; u < j; ++u) rank += (ssel[u] < me);
+        int rank = 0, r1 = 0, r2 = 0, r3 = 0;
+        int u = 0;
+        for (; u + 4 <= j; u += 4) {
+            rank += (int)(ssel[u] < me);
+            r1 += (int)(ssel[u + 1] < me);
+            r2 += (int)(ssel[u + 2] < me);
+            r3 += (int)(ssel[u + 3] < me);
+        }
+        for (; u < j; ++u) rank += (int)(ssel[u] < me);
+        rank += r1 + r2 + r3;
         out_idx[rank] = me;
         out_val[rank] = y[t];
     }
