@@ -67,7 +67,7 @@ struct Solver {
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
     // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
-    double *Gkeep = nullptr, *gdkeep = nullptr;
+    double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr;
     int* kpos = nullptr;
     std::vector<int> keep_cols;
     int keep_n = 0, keep_np = 0;
@@ -264,7 +264,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part);
     s = Solver();
 }
 
@@ -1888,12 +1888,13 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
     CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
     CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
+    CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
@@ -1949,16 +1950,15 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         const int blk = 16;
         const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
         const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
-        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)((ldo + 255) / 256), np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
-                           (const int*)s.cands, n, (TA*)s.Acomp, ldo);
+        const int nchunk = (int)((ldo + 255) / 256);
+        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)nchunk, np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                           (const int*)s.cands, n, (TA*)s.Acomp, ldo, (const double*)s.b, np, s.rhs_part);
         hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
                            rps, s.Gpart);
         HIPCHECK(hipGetLastError());
         const int64_t nel = (int64_t)np * np;
         hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
-                           s.Gm, s.gdiag);
-        hipLaunchKernelGGL(k_gram_rhs<TA>, dim3((n + 1 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.cands,
-                           n, np, (const double*)s.b, s.Gm);
+                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk);
         HIPCHECK(hipGetLastError());
         HIPCHECK(hipMemcpyAsync(s.Gkeep, s.Gm, (size_t)np * np * 8, hipMemcpyDeviceToDevice, ctx->stream));
         HIPCHECK(hipMemcpyAsync(s.gdkeep, s.gdiag, (size_t)np * 8, hipMemcpyDeviceToDevice, ctx->stream));

@@ -8,7 +8,8 @@
 //   k_gram        G = A_S' A_S (n x n, Float64 products of the exactly promoted dictionary values) on the Float64 matrix
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
-//   k_gram_rhs    c = A_S' b, stored as column n of G (the bordered matrix [G c; c' b'b]);
+//   (k_gather_cols also sums a_j'b per row chunk: k_gram_reduce writes c = A_S'b as column n of G, the bordered matrix
+//                 [G c; c' b'b] -- k_gram_rhs is the stand-alone form of that product, kept for reference)
 //   k_chol_row / k_chol_step   right-looking blocked Cholesky G = R'R in place, 32 columns per step and ONE launch per step:
 //                 the 32 x 32 diagonal block in the registers of one wave, the row panel by substitution (one thread per
 //                 column), the trailing update of the previous panel on the matrix cores beside it.  The bordered column comes
@@ -37,13 +38,28 @@ constexpr int kCholNB = 32;     // columns per Cholesky step.  (64 was tried twi
 // beyond M and zero columns from n to np.  k_gram touches 96 columns per wave and block of rows, 16 bytes of each: from the
 // compact copy every one of those is an unconditional, aligned 16-byte load (no bounds logic in the loop), and the 32 MiB
 // of a 1024-column set at config 5 sit on a handful of pages instead of one page per access.
+// The same pass delivers the right-hand side: workgroup (row chunk, column j) sums a_j[r] * b[r] over its 256 rows (column n:
+// b[r]^2, the corner), k_gram_reduce adds the chunks in a fixed order into column n of the bordered matrix.
 template <typename TA>
 __global__ __launch_bounds__(256) void k_gather_cols(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
-                                                     TA* __restrict__ out, int64_t ldo) {
+                                                     TA* __restrict__ out, int64_t ldo, const double* __restrict__ b, int np,
+                                                     double* __restrict__ rhs_part) {
+    __shared__ double red[8];
     const int j = blockIdx.y;
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= ldo) return;
-    out[(int64_t)j * ldo + r] = (j < n && r < M) ? A[(int64_t)cols[j] * ld + r] : (TA)0;
+    double prod = 0.0;
+    if (r < ldo) {
+        const TA v = (j < n && r < M) ? A[(int64_t)cols[j] * ld + r] : (TA)0;
+        out[(int64_t)j * ldo + r] = v;
+        if (r < M && j <= n) {
+            const double br = b[r];
+            prod = (j < n ? (double)v : br) * br;
+        }
+    }
+    if (j <= n) {  // (uniform per workgroup)
+        prod = block_sum256(prod, red);
+        if (threadIdx.x == 0) rhs_part[(int64_t)blockIdx.x * np + j] = prod;
+    }
 }
 
 constexpr int kGramRpl = 4;    // rows of a column a lane holds per block of rows (16 bytes of f32)
@@ -117,7 +133,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
 // G = sum of the row-slice partials (fixed order) on the upper tiles; identity on the padding diagonal (columns beyond the
 // bordered one), zeros elsewhere in the padding; the original diagonal goes to gdiag (DGKS reference, |a_j|^2)
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ Gpart, int nsplit, int n, int np,
-                                                     double* __restrict__ G, double* __restrict__ gdiag) {
+                                                     double* __restrict__ G, double* __restrict__ gdiag,
+                                                     const double* __restrict__ rhs_part, int nchunk) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)np * np) return;
     const int row = (int)(e % np), col = (int)(e / np);
@@ -125,10 +142,12 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     double s = 0.0;
     if (row < n && col < n) {
         for (int k = 0; k < nsplit; ++k) s += Gpart[(int64_t)k * np * np + e];
+    } else if (row <= n && col == n) {  // the bordered column c = A_S'b and the corner b'b: the gather pass's row-chunk sums
+        for (int k = 0; k < nchunk; ++k) s += rhs_part[(int64_t)k * np + row];
     } else if (row == col && row > n) {
         s = 1.0;
     }
-    if (!(row < n && col == n)) G[e] = s;  // (column n, rows < n, belongs to k_gram_rhs)
+    G[e] = s;
     if (row == col && row < n) gdiag[row] = s;
 }
 
