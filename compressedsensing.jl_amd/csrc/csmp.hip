@@ -67,7 +67,7 @@ struct Solver {
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
     // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
-    double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr;
+    double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
     int* kpos = nullptr;
     std::vector<int> keep_cols;
     int keep_n = 0, keep_np = 0;
@@ -264,7 +264,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s = Solver();
 }
 
@@ -1888,12 +1888,13 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part);
+    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
     CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
     CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
+    CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
     CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
@@ -1994,7 +1995,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
                        (const int*)s.cands, (const double*)s.coef, n, s.rpart);
     hipLaunchKernelGGL(k_residual_sum, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.rpart, nch, M, (const double*)s.b,
-                       s.r, (const DevState*)s.st);
+                       s.r, (const DevState*)s.st, s.rn2part);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -2069,30 +2070,30 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
     Solver& s = ctx->s;
     if (gram_applicable(ctx, cols.size())) {
         CHECK(ls_gram(ctx, cols));
-        if (resnorm) {
-            hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
-            HIPCHECK(hipGetLastError());
-        }
         const size_t n = cols.size();
-        // one page-locked landing area for everything that comes back: [idx n | val n | control block | ||r||^2]
-        const size_t need = n * 16 + sizeof(DevState) + 16;
+        const size_t nshare = (size_t)(ctx->M + 255) / 256;  // |r|^2 comes back as the residual kernel's per-workgroup shares
+        // one page-locked landing area for everything that comes back: [idx n | val n | control block | shares of ||r||^2]
+        const size_t need = n * 16 + sizeof(DevState) + 16 + nshare * 8;
         void* pv = nullptr;
         CHECK(pin_get(ctx, 1, need, &pv));
         int64_t* pi = (int64_t*)pv;
         double* pvv = (double*)(pi + n);
         DevState* phs = (DevState*)(pvv + n);
         double* pn2 = (double*)((char*)phs + ((sizeof(DevState) + 7) / 8) * 8);
-        *pn2 = 0.0;
         HIPCHECK(hipMemcpyAsync(pi, s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipMemcpyAsync(pvv, s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipMemcpyAsync(phs, s.st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
-        if (resnorm) HIPCHECK(hipMemcpyAsync(pn2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (resnorm) HIPCHECK(hipMemcpyAsync(pn2, s.rn2part, nshare * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         const DevState hs = *phs;
         if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
             idx.assign(pi, pi + n);
             val.assign(pvv, pvv + n);
-            if (resnorm) *resnorm = std::sqrt(*pn2);
+            if (resnorm) {
+                double n2 = 0.0;
+                for (size_t q = 0; q < nshare; ++q) n2 += pn2[q];
+                *resnorm = std::sqrt(n2);
+            }
             return CSMP_OK;
         }
     }

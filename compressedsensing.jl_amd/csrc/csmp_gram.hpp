@@ -425,14 +425,21 @@ __global__ __launch_bounds__(256) void k_residual_part(const TA* __restrict__ A,
     for (; t < t1; ++t) a0 = fma((double)A[(int64_t)idx[t] * ld + row], val[t], a0);
     part[(int64_t)ch * M + row] = a0 + a1;
 }
+// (+ the workgroup's share of |r|^2 into n2part[blockIdx.x]: the host adds the M/256 shares in order -- no norm kernel)
 __global__ __launch_bounds__(256) void k_residual_sum(const double* __restrict__ part, int nch, int M, const double* __restrict__ b,
-                                                      double* __restrict__ r, const DevState* st) {
+                                                      double* __restrict__ r, const DevState* st, double* __restrict__ n2part) {
+    __shared__ double red[8];
     if (st->done & STOP_REORTH) return;
     const int row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= M) return;
-    double s = 0.0;
-    for (int c = 0; c < nch; ++c) s += part[(int64_t)c * M + row];
-    r[row] = b[row] - s;
+    double v = 0.0;
+    if (row < M) {
+        double s = 0.0;
+        for (int c = 0; c < nch; ++c) s += part[(int64_t)c * M + row];
+        v = b[row] - s;
+        r[row] = v;
+    }
+    v = block_sum256(v * v, red);
+    if (threadIdx.x == 0) n2part[blockIdx.x] = v;
 }
 
 }  // namespace csmp
