@@ -1476,6 +1476,9 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
                 drow[i] = (i < w && i > lane && lane < w) ? R[(int64_t)(i0 + i) * kcap + i0 + lane] : 0.0;
             double yv = lane < w ? y[i0 + lane] : 0.0;
             const double rd = lane < w ? 1.0 / R[(int64_t)(i0 + lane) * kcap + i0 + lane] : 0.0;
+#ifdef FIN_ABL
+            if (!(FIN_ABL & 1))
+#endif
 #pragma unroll
             for (int i = 63; i >= 0; --i) {
                 const double c = readlane_f64(yv * rd, i);  // lanes >= w carry zeros
@@ -1490,6 +1493,9 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         }
         __syncthreads();
         // rows above the block
+#ifdef FIN_ABL
+        if (!(FIN_ABL & 2))
+#endif
         for (int t = tid; t < i0; t += 256) {
             double acc = y[t];
             const double* col = R + (int64_t)i0 * kcap + t;
@@ -1509,6 +1515,9 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         if (out_order) out_order[t] = (t < j) ? ssel[t] : -1;
     }
     __syncthreads();
+#ifdef FIN_ABL
+    if (!(FIN_ABL & 4))
+#endif
     for (int t = tid; t < j; t += 256) {
         const int me = ssel[t];
         int rank = 0, r1 = 0, r2 = 0, r3 = 0;
