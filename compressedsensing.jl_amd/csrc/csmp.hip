@@ -729,7 +729,26 @@ static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
 static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
                          int* d_flag = nullptr) {
     Solver& s = ctx->s;
-    if (s.kcap > 256 && !getenv("CSMP_FINISH_W")) {  // blocked form: one memory round trip per 64 columns
+    if (s.kcap > 256 && !getenv("CSMP_FINISH_W") && !getenv("CSMP_FINISH_B")) {
+        // super-blocks of 256 columns over several CUs (k_trsv_*): the host's bound on the support says how many there are; a
+        // super-block beyond the true support returns at once
+        const int jb = s.jh > 0 ? std::min(s.jh, s.kcap) : s.kcap;
+        const int nsb = (jb + kTrsvBlk - 1) / kTrsvBlk;
+        for (int sb = nsb - 1; sb >= 0; --sb) {
+            const int off = sb * kTrsvBlk;
+            hipLaunchKernelGGL(k_trsv_blk, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.R, (const double*)s.z, (const DevState*)s.st,
+                               s.kcap, s.coef, off, sb == nsb - 1 ? 1 : 0);
+            if (sb > 0)
+                hipLaunchKernelGGL(k_trsv_upd, dim3(off / 64), dim3(256), 0, ctx->stream, (const double*)s.R, (const DevState*)s.st, s.kcap,
+                                   s.coef, off);
+        }
+        const int ne = std::max(jb, outcap);
+        hipLaunchKernelGGL(k_trsv_emit, dim3((ne + 255) / 256), dim3(256), (size_t)(s.kcap + 4) * sizeof(int), ctx->stream,
+                           (const double*)s.coef, (const int*)s.sel, (const DevState*)s.st, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
+    if (s.kcap > 256 && !getenv("CSMP_FINISH_W")) {  // blocked form in ONE workgroup: one memory round trip per 64 columns
         const size_t lds = (size_t)(s.kcap + 64) * sizeof(double) + (size_t)s.kcap * sizeof(int);
         if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_finish_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_finish_b, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,

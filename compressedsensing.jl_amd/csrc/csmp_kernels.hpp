@@ -1476,9 +1476,6 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
                 drow[i] = (i < w && i > lane && lane < w) ? R[(int64_t)(i0 + i) * kcap + i0 + lane] : 0.0;
             double yv = lane < w ? y[i0 + lane] : 0.0;
             const double rd = lane < w ? 1.0 / R[(int64_t)(i0 + lane) * kcap + i0 + lane] : 0.0;
-#ifdef FIN_ABL
-            if (!(FIN_ABL & 1))
-#endif
 #pragma unroll
             for (int i = 63; i >= 0; --i) {
                 const double c = readlane_f64(yv * rd, i);  // lanes >= w carry zeros
@@ -1493,9 +1490,6 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         }
         __syncthreads();
         // rows above the block
-#ifdef FIN_ABL
-        if (!(FIN_ABL & 2))
-#endif
         for (int t = tid; t < i0; t += 256) {
             double acc = y[t];
             const double* col = R + (int64_t)i0 * kcap + t;
@@ -1515,9 +1509,6 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         if (out_order) out_order[t] = (t < j) ? ssel[t] : -1;
     }
     __syncthreads();
-#ifdef FIN_ABL
-    if (!(FIN_ABL & 4))
-#endif
     for (int t = tid; t < j; t += 256) {
         const int me = ssel[t];
         int rank = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -1534,6 +1525,131 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         out_val[rank] = y[t];
     }
     if (tid == 0) {
+        *out_nnz = j;
+        if (flag_out) *flag_out = st->done;
+    }
+}
+
+// ---- the back substitution for LARGE supports, over several CUs.  One workgroup cannot stream R faster than one CU reads memory
+// (24 GB/s from HBM, ~60 GB/s from L2: tools/probes/finish_probe.hip -- 4 MiB of R at 1024 columns took 240 us in k_finish_b,
+// 160 us of them the rows-above updates), so the triangle is cut into SUPER-BLOCKS of 256 columns:
+//   k_trsv_blk   one workgroup solves the 256 x 256 triangle of a super-block (k_finish_b's scheme on 128 KiB);
+//   k_trsv_upd   y[rows above] -= R[rows above, super-block] * x[super-block], 64 rows per workgroup;
+//   k_trsv_emit  the sorted emission, 256 entries per workgroup.
+// 2 ceil(j / 256) launches; y lives in `coef`.
+constexpr int kTrsvBlk = 256;
+__global__ __launch_bounds__(256) void k_trsv_blk(const double* __restrict__ R, const double* __restrict__ z, const DevState* st,
+                                                  int kcap, double* __restrict__ y, int off, int init_from_z) {
+    __shared__ double yl[kTrsvBlk];
+    __shared__ double cb[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = st->nsel;
+    if (init_from_z)
+        for (int t = tid; t < j; t += 256)
+            if (t < off || t >= off + kTrsvBlk) y[t] = z[t];  // (the super-block's own entries are written below)
+    if (off >= j) return;
+    const int len = min(kTrsvBlk, j - off);
+    const int nb = (len + 63) / 64;
+    if (tid < len) yl[tid] = init_from_z ? z[off + tid] : y[off + tid];
+    __syncthreads();
+    for (int b = nb - 1; b >= 0; --b) {
+        const int i0 = b * 64, w = min(64, len - i0), g0 = off + i0;  // block columns g0 .. g0 + w - 1
+        if (wave == 0) {
+            double drow[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                drow[i] = (i < w && i > lane && lane < w) ? R[(int64_t)(g0 + i) * kcap + g0 + lane] : 0.0;
+            double yv = lane < w ? yl[i0 + lane] : 0.0;
+            const double rd = lane < w ? 1.0 / R[(int64_t)(g0 + lane) * kcap + g0 + lane] : 0.0;
+#pragma unroll
+            for (int i = 63; i >= 0; --i) {
+                const double c = readlane_f64(yv * rd, i);  // lanes >= w carry zeros
+                yv = lane == i ? c : fma(-drow[i], c, yv);
+            }
+            if (lane < w) {
+                yl[i0 + lane] = yv;
+                cb[lane] = yv;
+            } else {
+                cb[lane] = 0.0;
+            }
+        }
+        __syncthreads();
+        if (tid < i0) {  // the rows of the super-block above this block (at most 192): all 64 loads of a row in flight at once
+            const double* col = R + (int64_t)g0 * kcap + off + tid;
+            double rv[64];
+#pragma unroll
+            for (int i = 0; i < 64; ++i) rv[i] = i < w ? col[(int64_t)i * kcap] : 0.0;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 64; i += 4) {
+                a0 = fma(rv[i], cb[i], a0);
+                a1 = fma(rv[i + 1], cb[i + 1], a1);
+                a2 = fma(rv[i + 2], cb[i + 2], a2);
+                a3 = fma(rv[i + 3], cb[i + 3], a3);
+            }
+            yl[tid] -= (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+    }
+    if (tid < len) y[off + tid] = yl[tid];
+}
+// rows [64 blockIdx.x, +64) of y -= R[rows, off .. off + len) * y[off .. off + len): thread (row, column quarter), the four
+// quarters meet in LDS in a fixed order
+__global__ __launch_bounds__(256) void k_trsv_upd(const double* __restrict__ R, const DevState* st, int kcap, double* __restrict__ y,
+                                                  int off) {
+    __shared__ double xs[kTrsvBlk];
+    __shared__ double part[256];
+    const int tid = threadIdx.x, j = st->nsel;
+    if (off >= j) return;
+    const int len = min(kTrsvBlk, j - off);
+    xs[tid] = tid < len ? y[off + tid] : 0.0;
+    __syncthreads();
+    const int row = blockIdx.x * 64 + (tid & 63), cq = tid >> 6;
+    double a0 = 0.0, a1 = 0.0;
+    if (row < off) {
+        const double* col = R + (int64_t)(off + cq * 64) * kcap + row;
+#pragma unroll 16
+        for (int i = 0; i < 64; i += 2) {
+            const double r0 = cq * 64 + i < len ? col[(int64_t)i * kcap] : 0.0;
+            const double r1 = cq * 64 + i + 1 < len ? col[(int64_t)(i + 1) * kcap] : 0.0;
+            a0 = fma(r0, xs[cq * 64 + i], a0);
+            a1 = fma(r1, xs[cq * 64 + i + 1], a1);
+        }
+    }
+    part[tid] = a0 + a1;
+    __syncthreads();
+    if (tid < 64 && row < off) y[row] -= (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+}
+// (index, coefficient) pairs in ascending index order, 256 per workgroup (rank sort against the whole support in LDS)
+__global__ __launch_bounds__(256) void k_trsv_emit(const double* __restrict__ y, const int* __restrict__ sel, const DevState* st,
+                                                   int64_t* __restrict__ out_idx, double* __restrict__ out_val,
+                                                   int64_t* __restrict__ out_nnz, int64_t* __restrict__ out_order, int outcap,
+                                                   int* __restrict__ flag_out) {
+    extern __shared__ __attribute__((aligned(16))) int ssel[];  // j rounded up to 4
+    const int tid = threadIdx.x, j = st->nsel;
+    for (int t = tid; t < ((j + 3) & ~3); t += 256) ssel[t] = t < j ? sel[t] : 0x7fffffff;
+    __syncthreads();
+    const int t = blockIdx.x * 256 + tid;
+    if (t < outcap && t >= j) {
+        out_idx[t] = -1;
+        out_val[t] = 0.0;
+    }
+    if (t < outcap && out_order) out_order[t] = (t < j) ? ssel[t] : -1;
+    if (t < j) {
+        const int me = ssel[t];
+        const int4* s4 = reinterpret_cast<const int4*>(ssel);
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        for (int u = 0; u < (j + 3) >> 2; ++u) {
+            const int4 v = s4[u];
+            r0 += (int)(v.x < me);
+            r1 += (int)(v.y < me);
+            r2 += (int)(v.z < me);
+            r3 += (int)(v.w < me);
+        }
+        const int rank = r0 + r1 + r2 + r3;
+        out_idx[rank] = me;
+        out_val[rank] = y[t];
+    }
+    if (t == 0) {
         *out_nnz = j;
         if (flag_out) *flag_out = st->done;
     }
