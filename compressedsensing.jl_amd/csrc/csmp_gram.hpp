@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
 // through memory between two launches, 5 us the update, 3 + 2 us elimination and its rsqrt chain, 3.4 us substitution; the
 // trailing update runs beside it for free.  Tried and slower: rolled loops on a shifting register window (38 us: twice the
 // FMAs -- code size was NOT the limit), the update over LDS operands (24.7 us).
-constexpr int kCholRowCols = 256;   // panel columns per workgroup
+#ifndef CHOL_ROWCOLS
+#define CHOL_ROWCOLS 256
+#endif
+constexpr int kCholRowCols = CHOL_ROWCOLS;   // panel columns per workgroup
 constexpr int kCholThreads = 320;   // + the wave of the diagonal block
 
 template <bool UPD>
@@ -227,7 +230,7 @@ __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, in
     const bool diag = tid < kWave;
     const int q = tid & (NB - 1);
     const int c = diag ? c0 + q : c0 + NB + wg * kCholRowCols + (tid - kWave);
-    const bool have = diag ? tid < NB : c < np;
+    const bool have = diag ? tid < NB : (c < np && (tid - kWave) < kCholRowCols);
     double* gcol = G + c0 + (int64_t)(c < np ? c : c0) * np;  // (np is a multiple of 64: 16-byte aligned)
     double x[NB];
     {
