@@ -210,14 +210,13 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
 //     v_readlane_b32 per step.
 //   * UPD: the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: they come through the SCALAR unit (s_load of
 //     64 B from the finished panel in global memory, constant address space) and enter the FMAs as scalar operands.
-// What a step costs (tools/probes/chol_probe.hip, n = 1024): 24.1 us, of which 2.6 us launch, 4.4 us the dependent trip
+// What a step costs (tools/probes/chol_probe.hip, n = 1024): 22.4 us (24.1 with 256 columns per workgroup), of which 2.6 us launch, 4.4 us the dependent trip
 // through memory between two launches, 5 us the update, 3 + 2 us elimination and its rsqrt chain, 3.4 us substitution; the
 // trailing update runs beside it for free.  Tried and slower: rolled loops on a shifting register window (38 us: twice the
 // FMAs -- code size was NOT the limit), the update over LDS operands (24.7 us).
-#ifndef CHOL_ROWCOLS
-#define CHOL_ROWCOLS 256
-#endif
-constexpr int kCholRowCols = CHOL_ROWCOLS;   // panel columns per workgroup
+constexpr int kCholRowCols = 64;    // panel columns per workgroup: ONE column wave (waves 2..4 of a row workgroup only join the barrier).  A
+                                    // workgroup's 2 x 32 rows of its columns come through one CU's memory port: 256 columns per workgroup
+                                    // cost 24.5 us per step, 128: 23.2, 64: 22.4, 32: 22.4 (tools/probes/chol_probe.hip)
 constexpr int kCholThreads = 320;   // + the wave of the diagonal block
 
 template <bool UPD>
