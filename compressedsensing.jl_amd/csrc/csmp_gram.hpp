@@ -210,7 +210,8 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
 //     v_readlane_b32 per step.
 //   * UPD: the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: they come through the SCALAR unit (s_load of
 //     64 B from the finished panel in global memory, constant address space) and enter the FMAs as scalar operands.
-// What a step costs (tools/probes/chol_probe.hip, n = 1024): 22.4 us (24.1 with 256 columns per workgroup), of which 2.6 us launch, 4.4 us the dependent trip
+// What a step costs (tools/probes/chol_probe.hip, n = 1024): 18.9 us (24.1 with 256 columns per workgroup and a scalar update of
+// the diagonal block; 22.4 with 64 columns), of which 2.6 us launch, 4.4 us the dependent trip
 // through memory between two launches, 5 us the update, 3 + 2 us elimination and its rsqrt chain, 3.4 us substitution; the
 // trailing update runs beside it for free.  Tried and slower: rolled loops on a shifting register window (38 us: twice the
 // FMAs -- code size was NOT the limit), the update over LDS operands (24.7 us).
@@ -246,25 +247,68 @@ __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, in
         for (int p = 0; p < NB; ++p) x[p] = (p <= q) ? x[p] : 0.0;  // (below the diagonal: not part of the stored triangle)
     }
     if constexpr (UPD) {
-        const f64x2* pc = reinterpret_cast<const f64x2*>(gcol - NB);  // the previous panel's rows in this thread's column
-        double xc[NB];
+        if (diag) {
+            // The diagonal block's update is on the step's critical path (its factorisation waits for it): wave 0 forms
+            // Xd'Xd (Xd = the 32 x 32 piece of the previous panel above the block) on the matrix cores -- 24 MFMAs for the three
+            // upper 16 x 16 tiles instead of 1024 dependent scalar FMAs per lane -- and redistributes it through LDS from the
+            // MFMA layout (column = lane & 15, row = (lane >> 4) + 4 reg) to "lane q holds column q".
+            __shared__ __attribute__((aligned(16))) double Hp[NB * NB];
+            const int lane = tid, fr = lane & 15, fq = lane >> 4;
+            const double* xb = G + (c0 - NB) + fq * 8;  // lane fq supplies rows 8 fq .. 8 fq + 7 of Xd (a permutation of the summation index)
+            double a0[8], a1[8];
+            {
+                const f64x2* p0 = reinterpret_cast<const f64x2*>(xb + (int64_t)(c0 + fr) * np);
+                const f64x2* p1 = reinterpret_cast<const f64x2*>(xb + (int64_t)(c0 + 16 + fr) * np);
 #pragma unroll
-        for (int e = 0; e < NB; e += 2) {
-            const f64x2 v = pc[e / 2];
-            xc[e] = v.x;
-            xc[e + 1] = v.y;
-        }
-        typedef const double __attribute__((address_space(4))) sdouble;  // (constant address space + uniform address = s_load)
-        sdouble* xg = (sdouble*)(G + (c0 - NB) + (int64_t)c0 * np);
+                for (int e = 0; e < 8; e += 2) {
+                    const f64x2 u = p0[e / 2], v = p1[e / 2];
+                    a0[e] = u.x;
+                    a0[e + 1] = u.y;
+                    a1[e] = v.x;
+                    a1[e + 1] = v.y;
+                }
+            }
+            d4g h00 = {0.0, 0.0, 0.0, 0.0}, h01 = h00, h11 = h00;
 #pragma unroll
-        for (int p = 0; p < NB; ++p) {
-            double acc0 = 0.0, acc1 = 0.0;
+            for (int kk = 0; kk < 8; ++kk) {
+                h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], a0[kk], h00, 0, 0, 0);
+                h01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], a1[kk], h01, 0, 0, 0);
+                h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], a1[kk], h11, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int r = fq + 4 * reg;
+                Hp[r * NB + fr] = h00[reg];              // rows 0..15,  columns 0..15
+                Hp[r * NB + 16 + fr] = h01[reg];         // rows 0..15,  columns 16..31
+                Hp[(16 + r) * NB + 16 + fr] = h11[reg];  // rows 16..31, columns 16..31
+            }
+            asm volatile("" ::: "memory");  // (same wave, in-order LDS: the reads below see the writes)
+#pragma unroll
+            for (int p = 0; p < NB; ++p)
+                if (p <= q) x[p] -= Hp[p * NB + q];  // (the upper triangle is all the factorisation reads)
+        } else {
+            const f64x2* pc = reinterpret_cast<const f64x2*>(gcol - NB);  // the previous panel's rows in this thread's column
+            double xc[NB];
 #pragma unroll
             for (int e = 0; e < NB; e += 2) {
-                acc0 = fma(xc[e], xg[e + (int64_t)p * np], acc0);
-                acc1 = fma(xc[e + 1], xg[e + 1 + (int64_t)p * np], acc1);
+                const f64x2 v = pc[e / 2];
+                xc[e] = v.x;
+                xc[e + 1] = v.y;
             }
-            x[p] -= acc0 + acc1;
+            // the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: SCALAR loads (constant address space + uniform
+            // address = s_load), scalar operands of the FMAs
+            typedef const double __attribute__((address_space(4))) sdouble;
+            sdouble* xg = (sdouble*)(G + (c0 - NB) + (int64_t)c0 * np);
+#pragma unroll
+            for (int p = 0; p < NB; ++p) {
+                double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+                for (int e = 0; e < NB; e += 2) {
+                    acc0 = fma(xc[e], xg[e + (int64_t)p * np], acc0);
+                    acc1 = fma(xc[e + 1], xg[e + 1 + (int64_t)p * np], acc1);
+                }
+                x[p] -= acc0 + acc1;
+            }
         }
     }
     if (diag) {
