@@ -1542,24 +1542,32 @@ __global__ __launch_bounds__(256) void k_trsv_blk(const double* __restrict__ R, 
                                                   int kcap, double* __restrict__ y, int off, int init_from_z) {
     __shared__ double yl[kTrsvBlk];
     __shared__ double cb[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = st->nsel;
+    const int tid = threadIdx.x, lane = tid & 63, j = st->nsel;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (init_from_z)
         for (int t = tid; t < j; t += 256)
             if (t < off || t >= off + kTrsvBlk) y[t] = z[t];  // (the super-block's own entries are written below)
     if (off >= j) return;
     const int len = min(kTrsvBlk, j - off);
     const int nb = (len + 63) / 64;
+    // Wave b owns diagonal block b: it requests the block's rows NOW (row `lane` is D[lane][i] = R[g0 + lane, g0 + i], i > lane,
+    // zero elsewhere) and runs the block's chain when its turn comes -- the four round trips through memory happen together, ahead
+    // of the chain, instead of one at the head of every block.
+    double drow[64];
+    double rd = 0.0;
+    {
+        const int i0 = wave * 64, w = min(64, len - i0), g0 = off + i0;
+#pragma unroll
+        for (int i = 0; i < 64; ++i)
+            drow[i] = (wave < nb && i < w && i > lane && lane < w) ? R[(int64_t)(g0 + i) * kcap + g0 + lane] : 0.0;
+        rd = (wave < nb && lane < w) ? 1.0 / R[(int64_t)(g0 + lane) * kcap + g0 + lane] : 0.0;
+    }
     if (tid < len) yl[tid] = init_from_z ? z[off + tid] : y[off + tid];
     __syncthreads();
     for (int b = nb - 1; b >= 0; --b) {
         const int i0 = b * 64, w = min(64, len - i0), g0 = off + i0;  // block columns g0 .. g0 + w - 1
-        if (wave == 0) {
-            double drow[64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                drow[i] = (i < w && i > lane && lane < w) ? R[(int64_t)(g0 + i) * kcap + g0 + lane] : 0.0;
+        if (wave == b) {
             double yv = lane < w ? yl[i0 + lane] : 0.0;
-            const double rd = lane < w ? 1.0 / R[(int64_t)(g0 + lane) * kcap + g0 + lane] : 0.0;
 #pragma unroll
             for (int i = 63; i >= 0; --i) {
                 const double c = readlane_f64(yv * rd, i);  // lanes >= w carry zeros
