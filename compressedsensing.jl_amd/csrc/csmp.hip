@@ -1978,10 +1978,8 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         HIPCHECK(hipGetLastError());
         const int64_t nel = (int64_t)np * np;
         hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
-                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk);
+                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk, s.Gkeep, s.gdkeep);
         HIPCHECK(hipGetLastError());
-        HIPCHECK(hipMemcpyAsync(s.Gkeep, s.Gm, (size_t)np * np * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(s.gdkeep, s.gdiag, (size_t)np * 8, hipMemcpyDeviceToDevice, ctx->stream));
         s.keep_cols.assign(cols.begin(), cols.end());
         s.keep_n = n;
         s.keep_np = np;

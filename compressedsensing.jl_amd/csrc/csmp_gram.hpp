@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
 // bordered one), zeros elsewhere in the padding; the original diagonal goes to gdiag (DGKS reference, |a_j|^2)
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ Gpart, int nsplit, int n, int np,
                                                      double* __restrict__ G, double* __restrict__ gdiag,
-                                                     const double* __restrict__ rhs_part, int nchunk) {
+                                                     const double* __restrict__ rhs_part, int nchunk,
+                                                     double* __restrict__ Gkeep, double* __restrict__ gdkeep) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)np * np) return;
     const int row = (int)(e % np), col = (int)(e / np);
@@ -148,7 +149,11 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
         s = 1.0;
     }
     G[e] = s;
-    if (row == col && row < n) gdiag[row] = s;
+    Gkeep[e] = s;  // the copy that survives the factorisation (a later subset of this set gathers its matrix from it)
+    if (row == col && row < n) {
+        gdiag[row] = s;
+        gdkeep[row] = s;
+    }
 }
 
 // The bordered Gram matrix of a set that lies inside the set of the kept matrix K (kn columns, leading dimension knp): entry
