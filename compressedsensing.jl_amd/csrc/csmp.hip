@@ -622,6 +622,38 @@ static int solver_fit_for_removal(csmp_ctx* ctx, int kcap) {
     return CSMP_OK;
 }
 
+// Small results coming back on a latency chain: every piece is copied into the page-locked slot (truly asynchronous, back
+// to back), ONE wait, then the pieces are handed to their host destinations.  (A copy straight into pageable memory -- a stack
+// variable, a std::vector -- is staged by the runtime and blocks the host once per piece.)
+struct PinFetch {
+    csmp_ctx* ctx;
+    char* base = nullptr;
+    size_t used = 0;
+    struct Out { void* dst; size_t off, bytes; } outs[8];
+    int nout = 0;
+    explicit PinFetch(csmp_ctx* c) : ctx(c) {}
+    int begin(size_t total) {
+        void* pv = nullptr;
+        CHECK(pin_get(ctx, 1, total + 64, &pv));
+        base = (char*)pv;
+        used = 0;
+        nout = 0;
+        return CSMP_OK;
+    }
+    int add(void* dst, const void* dev, size_t bytes) {
+        const size_t off = (used + 7) / 8 * 8;
+        HIPCHECK(hipMemcpyAsync(base + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        outs[nout++] = {dst, off, bytes};
+        used = off + bytes;
+        return CSMP_OK;
+    }
+    int wait() {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int q = 0; q < nout; ++q) memcpy(outs[q].dst, base + outs[q].off, outs[q].bytes);
+        return CSMP_OK;
+    }
+};
+
 // b (host, any dtype) -> device Float64 b and r, state reset
 static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     Solver& s = ctx->s;
@@ -782,11 +814,13 @@ static int download_result(csmp_ctx* ctx, int outcap, int64_t* idx, double* val,
     std::vector<int64_t> hi((size_t)outcap), ho((size_t)outcap);
     std::vector<double> hv((size_t)outcap);
     int64_t hn = 0;
-    HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(ho.data(), s.out_order, (size_t)outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(&hn, s.out_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    PinFetch f(ctx);
+    CHECK(f.begin((size_t)outcap * 24 + 64));
+    CHECK(f.add(hi.data(), s.out_idx, (size_t)outcap * 8));
+    CHECK(f.add(hv.data(), s.out_val, (size_t)outcap * 8));
+    CHECK(f.add(ho.data(), s.out_order, (size_t)outcap * 8));
+    CHECK(f.add(&hn, s.out_nnz, 8));
+    CHECK(f.wait());
     for (int64_t t = 0; t < hn; ++t) {
         if (idx) idx[t] = hi[t];
         if (val) val[t] = hv[t];
@@ -1653,12 +1687,14 @@ static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<
     std::vector<int64_t> hi((size_t)s.outcap);
     std::vector<double> hv((size_t)s.outcap);
     int64_t hn = 0;
-    HIPCHECK(hipMemcpyAsync(hi.data(), s.out_idx, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(hv.data(), s.out_val, (size_t)s.outcap * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(&hn, s.out_nnz, 8, hipMemcpyDeviceToHost, ctx->stream));
     double n2 = 0.0;
-    if (resnorm) HIPCHECK(hipMemcpyAsync(&n2, s.scal + 1, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    PinFetch f(ctx);
+    CHECK(f.begin((size_t)s.outcap * 16 + 64));
+    CHECK(f.add(hi.data(), s.out_idx, (size_t)s.outcap * 8));
+    CHECK(f.add(hv.data(), s.out_val, (size_t)s.outcap * 8));
+    CHECK(f.add(&hn, s.out_nnz, 8));
+    if (resnorm) CHECK(f.add(&n2, s.scal + 1, 8));
+    CHECK(f.wait());
     idx.assign(hi.begin(), hi.begin() + hn);
     val.assign(hv.begin(), hv.begin() + hn);
     if (resnorm) *resnorm = std::sqrt(n2);
@@ -2062,8 +2098,10 @@ static int residual_norm(csmp_ctx* ctx, double* out) {
     hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
     HIPCHECK(hipGetLastError());
     double n2 = 0.0;
-    HIPCHECK(hipMemcpyAsync(&n2, s.scal, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    PinFetch f(ctx);
+    CHECK(f.begin(8));
+    CHECK(f.add(&n2, s.scal, 8));
+    CHECK(f.wait());
     *out = std::sqrt(n2);
     return CSMP_OK;
 }
@@ -2284,9 +2322,13 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
         hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
         HIPCHECK(hipGetLastError());
         DevState hs;
-        HIPCHECK(hipMemcpyAsync(cs.data(), s.coef, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        {
+            PinFetch f(ctx);
+            CHECK(f.begin((size_t)k * 8 + sizeof hs + 16));
+            CHECK(f.add(cs.data(), s.coef, (size_t)k * 8));
+            CHECK(f.add(&hs, s.st, sizeof hs));
+            CHECK(f.wait());
+        }
         int64_t cand = hs.cand;
         double ccand = hs.cval;
         if (std::binary_search(xi.begin(), xi.end(), cand)) {
@@ -2380,11 +2422,13 @@ struct Stepwise {
     int last_added = -1, last_removed = -1;  // atoms moved by the last successful forward / backward step
     DevState hs;
 
-    int read_state() {
+    int read_state(int* also_int = nullptr, const int* also_dev = nullptr) {
         Solver& s = ctx->s;
-        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        return CSMP_OK;
+        PinFetch f(ctx);
+        CHECK(f.begin(sizeof hs + 16));
+        if (also_int) CHECK(f.add(also_int, also_dev, sizeof(int)));
+        CHECK(f.add(&hs, s.st, sizeof hs));
+        return f.wait();
     }
     int clear_flags() {
         static const int zero = 0;
@@ -2475,8 +2519,7 @@ struct Stepwise {
                            lace ? (const double*)s.bwd_coef : (const double*)nullptr);
         HIPCHECK(hipGetLastError());
         CHECK(launch_delete_t(ctx));
-        HIPCHECK(hipMemcpyAsync(&last_removed, s.delmeta + 2, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        CHECK(read_state());
+        CHECK(read_state(&last_removed, s.delmeta + 2));
         if (hs.nsel == n) return CSMP_OK;  // the thresholds (or the lack of a finite score) kept every atom
         for (Pend& e : pend)
             if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_tdel_apply kept a copy
