@@ -153,6 +153,24 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     const int j = st.nsel;
     int* sel = sel_all + (int64_t)s * kcap;
 
+    // the tile candidates of the fast merge path are requested FIRST: they depend on nothing, and their round trip then
+    // overlaps the residual's (it used to start behind the norm's barriers)
+    constexpr int EPL = 8;
+    const float* cvs = cand_val + (int64_t)s * ncand;
+    const int* cis = cand_idx + (int64_t)s * ncand;
+    const int Qn = (ncand + 3) / 4;  // entries per wave
+    float ev[EPL];
+    int ei[EPL], es[EPL];
+    if (ncand <= EPL * 256) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) {
+            const int t = wave * Qn + lane + kWave * e;
+            const bool ok = (lane + kWave * e) < Qn && t < ncand;
+            ev[e] = ok ? cvs[t] : -1.0f;
+            ei[e] = ok ? cis[t] : 0x7fffffff;
+            es[e] = t & (kTileCand - 1);
+        }
+    }
     // residual in registers (thread t: rows 4(t + 256 i) .. +3), ||r||^2, eps-stop of the last step
     double rreg[NI][4];
     double n2 = 0.0;
@@ -181,24 +199,10 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     // ---- merge the tile candidates: the kKeep largest screened |c| (ties: lower atom index).
     // cert_thr bounds the screened value of every atom NOT in the list: the smallest kept value,
     // or the last (4th) candidate of a tile whose candidates were all kept (atoms hidden behind it).
-    const float* cvs = cand_val + (int64_t)s * ncand;
-    const int* cis = cand_idx + (int64_t)s * ncand;
     float cert_thr = -1.0f;
-    if (ncand <= 8 * 256) {
-        // fast path: the list lives in registers (<= 8 entries per lane).  Each wave extracts the 16 best
+    if (ncand <= EPL * 256) {
+        // fast path: the list lives in registers (<= 8 entries per lane, loaded at the top).  Each wave extracts the 16 best
         // of its quarter with wave-only shuffles (no workgroup barriers), then wave 0 merges the 4 x 16.
-        constexpr int EPL = 8;
-        const int Qn = (ncand + 3) / 4;  // entries per wave
-        float ev[EPL];
-        int ei[EPL], es[EPL];
-#pragma unroll
-        for (int e = 0; e < EPL; ++e) {
-            const int t = wave * Qn + lane + kWave * e;
-            const bool ok = (lane + kWave * e) < Qn && t < ncand;
-            ev[e] = ok ? cvs[t] : -1.0f;
-            ei[e] = ok ? cis[t] : 0x7fffffff;
-            es[e] = t & (kTileCand - 1);
-        }
         float* wlv = rv;       // [4][16] per-wave lists (rv has 256 floats)
         int* wli = ri;         // [4][16]
         int* wls = ri + 64;    // [4][16]
