@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int6
 //     v_readlane_b32 per step.
 //   * UPD: the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: they come through the SCALAR unit (s_load of
 //     64 B from the finished panel in global memory, constant address space) and enter the FMAs as scalar operands.
-// What a step costs (tools/probes/chol_probe.hip, n = 1024): 18.9 us (24.1 with 256 columns per workgroup and a scalar update of
-// the diagonal block; 22.4 with 64 columns), of which 2.6 us launch, 4.4 us the dependent trip
+// What a step costs (tools/probes/chol_probe.hip, n = 1024): 17.6 us (24.1 with 256 columns per workgroup and scalar updates;
+// 22.4 with 64 columns; 18.9 with the diagonal block's update on the matrix cores; 17.6 with the column wave's too), of which the 24.1 were 2.6 us launch, 4.4 us the dependent trip
 // through memory between two launches, 5 us the update, 3 + 2 us elimination and its rsqrt chain, 3.4 us substitution; the
 // trailing update runs beside it for free.  Tried and slower: rolled loops on a shifting register window (38 us: twice the
 // FMAs -- code size was NOT the limit), the update over LDS operands (24.7 us).
@@ -291,29 +291,60 @@ __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, in
 #pragma unroll
             for (int p = 0; p < NB; ++p)
                 if (p <= q) x[p] -= Hp[p * NB + q];  // (the upper triangle is all the factorisation reads)
-        } else {
-            const f64x2* pc = reinterpret_cast<const f64x2*>(gcol - NB);  // the previous panel's rows in this thread's column
-            double xc[NB];
+        } else if (tid < 2 * kWave) {
+            // The column wave (kCholRowCols = 64 columns: wave 1) does the same on its 32 x 64 piece of the block row:
+            // D = Xd' Xc, 2 x 4 tiles x 8 MFMA steps, handed through LDS to "thread holds its column".  (The scalar form -- 1024 FMAs
+            // with s_load operands per thread -- took 5 us and crowded the scalar pipe wave 0's elimination lives on.)
+            static_assert(kCholRowCols == kWave, "one column wave per row workgroup");
+            __shared__ __attribute__((aligned(16))) double Hc[NB * kCholRowCols];  // Hc[row * 64 + column]
+            const int lane = tid - kWave, fr = lane & 15, fq = lane >> 4;
+            const int cb = c0 + NB + wg * kCholRowCols;  // first column of this workgroup's piece
+            const double* xb = G + (c0 - NB) + fq * 8;
+            double a0[8], a1[8], bq[4][8];
+            {
+                const f64x2* p0 = reinterpret_cast<const f64x2*>(xb + (int64_t)(c0 + fr) * np);
+                const f64x2* p1 = reinterpret_cast<const f64x2*>(xb + (int64_t)(c0 + 16 + fr) * np);
 #pragma unroll
-            for (int e = 0; e < NB; e += 2) {
-                const f64x2 v = pc[e / 2];
-                xc[e] = v.x;
-                xc[e + 1] = v.y;
-            }
-            // the multipliers R[c0 - 32 + e, c0 + p] are the same for every lane: SCALAR loads (constant address space + uniform
-            // address = s_load), scalar operands of the FMAs
-            typedef const double __attribute__((address_space(4))) sdouble;
-            sdouble* xg = (sdouble*)(G + (c0 - NB) + (int64_t)c0 * np);
-#pragma unroll
-            for (int p = 0; p < NB; ++p) {
-                double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll
-                for (int e = 0; e < NB; e += 2) {
-                    acc0 = fma(xc[e], xg[e + (int64_t)p * np], acc0);
-                    acc1 = fma(xc[e + 1], xg[e + 1 + (int64_t)p * np], acc1);
+                for (int e = 0; e < 8; e += 2) {
+                    const f64x2 u = p0[e / 2], v = p1[e / 2];
+                    a0[e] = u.x;
+                    a0[e + 1] = u.y;
+                    a1[e] = v.x;
+                    a1[e + 1] = v.y;
                 }
-                x[p] -= acc0 + acc1;
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    const int cj = cb + 16 * tj + fr;
+                    const f64x2* pb = reinterpret_cast<const f64x2*>(xb + (int64_t)(cj < np ? cj : c0) * np);
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const f64x2 v = pb[e / 2];
+                        bq[tj][e] = cj < np ? v.x : 0.0;
+                        bq[tj][e + 1] = cj < np ? v.y : 0.0;
+                    }
+                }
             }
+            d4g h0[4], h1[4];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) h0[tj] = h1[tj] = d4g{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    h0[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[kk], bq[tj][kk], h0[tj], 0, 0, 0);
+                    h1[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[kk], bq[tj][kk], h1[tj], 0, 0, 0);
+                }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int r = fq + 4 * reg;
+                    Hc[r * kCholRowCols + 16 * tj + fr] = h0[tj][reg];
+                    Hc[(16 + r) * kCholRowCols + 16 * tj + fr] = h1[tj][reg];
+                }
+            asm volatile("" ::: "memory");  // (same wave, in-order LDS)
+#pragma unroll
+            for (int p = 0; p < NB; ++p) x[p] -= Hc[p * kCholRowCols + lane];
         }
     }
     if (diag) {
