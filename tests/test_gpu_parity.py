@@ -296,6 +296,24 @@ def test_lstsq_pin(cs, oracle, D):
         d2.ctx.lstsq([1, 1], b)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_lstsq_sizes_across_the_solver_paths(cs, oracle, D, dtype):
+    """csmp_lstsq = factorize! + ldiv! (src/matchingpursuit.jl:219-227) at the sizes where the implementation changes gear: the
+    append chain (< 64 columns), the whole-set path (Gram + blocked Cholesky: 64 and up; bordered column at the start / inside / at
+    the end of a 32-block), the single-wave back substitution (<= 256) and the super-block one (> 256: one, two, four super-blocks,
+    full and partial), up to the 1023-column capacity -- against numpy's least squares on the promoted matrix."""
+    rng = np.random.default_rng(21)
+    M, N = 1200, 1500
+    A = np.asfortranarray(rng.standard_normal((M, N)).astype(dtype))
+    d = D(A)
+    b = rng.standard_normal(M)
+    for n in (1, 7, 63, 64, 65, 95, 96, 97, 128, 255, 256, 257, 300, 511, 512, 513, 768, 1000, 1023):
+        cols = rng.permutation(N)[:n]
+        got = d.ctx.lstsq(cols, b)
+        want = np.linalg.lstsq(A[:, cols].astype(np.float64), b, rcond=None)[0]
+        np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-11, err_msg=f"n = {n}")
+
+
 def test_step_level_gomp_functor(cs, oracle, D):
     A, x, b = cs.sparse_data(n=64, m=256, k=6, rng=14)
     y = cs.perturb(b, 5e-3, rng=15)
