@@ -689,7 +689,7 @@ hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const _
 const char* screen_kernel_name(int mode) {
     return mode == kScreenCo ? "csmp::k_b_screen256c (v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging, fused top-4 epilogue; persistent, "
                                "168 registers: shares each CU with a k_b_step_co workgroup of the other half-batch)"
-           : mode == kScreen256p ? "csmp::k_b_screen256p (v_mfma_f32_16x16x32_bf16, 256x256 tiles, eight-phase schedule: LDS-DMA units six phases ahead, "
+           : mode == kScreen256p ? "csmp::k_b_screen256p (v_mfma_f32_16x16x32_bf16, 256x256 tiles, eight-phase schedule: LDS-DMA units four phases ahead, "
                                    "counted vmcnt, the two waves of a SIMD one barrier apart; fused top-4 epilogue)"
            : mode == kScreen256 ? "csmp::k_b_screen256 (v_mfma_f32_16x16x32_bf16, 256x256 tiles, LDS-DMA staging, fused top-4 epilogue)"
                                 : "csmp::k_b_screen (v_mfma_f32_32x32x16_bf16, 128x128 tiles, fused top-4 epilogue)";
