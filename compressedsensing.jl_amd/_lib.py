@@ -17,6 +17,11 @@ F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
+# csmp_set_option keys (include/csmp.h)
+OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE = 1, 2, 3, 4, 5, 6, 7, 8
+OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
+           "force_reorth": OPT_FORCE_REORTH, "ls_gram": OPT_LS_GRAM, "ls_gram_reuse": OPT_LS_GRAM_REUSE,
+           "twostage_update": OPT_TWOSTAGE_UPDATE}
 
 i64 = C.c_int64
 vp = C.c_void_p
@@ -59,6 +64,8 @@ SIGNATURES = {
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(C.c_double)]),
+    "csmp_set_option": (C.c_int, [vp, C.c_int, i64]),
+    "csmp_get_option": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
     "csmp_solver_step": (C.c_int, [vp, i64]),
     "csmp_solver_remove": (C.c_int, [vp, i64]),
@@ -457,6 +464,15 @@ class Context:
         return idx[:n].copy(), val[:n].copy(), res.value, order[:n].copy(), stop.value
 
     # ---- one signal, columns sharded (csmp_shard_*): torch CUDA byte tensors for the records
+    def set_option(self, key, value):
+        """csmp_set_option: key is an OPT_* constant or its lower-case name ("batch_cert", "batch_gram", ...)."""
+        self.call("csmp_set_option", int(OPTIONS.get(key, key)), int(value))
+
+    def get_option(self, key):
+        v = i64(0)
+        self.call("csmp_get_option", int(OPTIONS.get(key, key)), C.byref(v))
+        return int(v.value)
+
     def set_stream(self, hip_stream):
         """Borrow a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); 0 / None: the library's own."""
         self.call("csmp_set_stream", vp(hip_stream or 0))

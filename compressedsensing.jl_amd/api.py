@@ -287,15 +287,21 @@ def fr_batch(A, B, k, max_eps=0.0, min_delta=0.0):
             D.close()
 
 
-def omp_batch_mfma(A, B, k, eps=None):
+def omp_batch_mfma(A, B, k, eps=None, cert=None, gram=None):
     """omp_batch through the batched variant (BASELINE configs 3/4): one bf16 MFMA screening GEMM per step for all
-    signals, Float64 rescoring of the 16 best screened atoms, and a per-step certificate; signals that fail it are
-    re-solved by the exact path, so certified results equal omp_batch's.  The default certificate uses a statistical
-    (8 sigma) model of the bf16 rounding error; set CSMP_CERT=rigorous for the deterministic bound (csmp.h)."""
+    signals, Float64 rescoring of the screened atoms that could still be the exact maximum, and a per-step certificate;
+    signals that fail it are re-solved by the exact path, so certified results equal omp_batch's.
+    cert: "statistical" (default: 8 sigma of independent bf16 roundings + the coherent scaling term) or "rigorous" (the
+    deterministic bound); gram: True keeps G = A'A resident on the GPU (8 N^2 bytes) and halves the append traffic
+    (csmp_set_option CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM, include/csmp.h)."""
     eps = _meta(A)[2] if eps is None else eps
     _check_eps(eps)
     D, tmp = _dict(A)
     try:
+        if cert is not None:
+            D.ctx.set_option("batch_cert", {"statistical": 0, "rigorous": 1}[cert])
+        if gram is not None:
+            D.ctx.set_option("batch_gram", int(bool(gram)))
         idx, val, nnz = D.ctx.omp_batch_mfma(B, int(k), float(eps))
         return [SparseVector(D.shape[1], idx[:n, s], val[:n, s]) for s, n in enumerate(nnz)]
     finally:

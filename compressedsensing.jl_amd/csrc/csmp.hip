@@ -64,7 +64,7 @@ struct Solver {
     int* tmeta = nullptr;
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
-    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr;
+    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr, *Dfac = nullptr;
     // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
     double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
@@ -93,6 +93,10 @@ struct Batch {
     double *r = nullptr, *b = nullptr, *T = nullptr, *Tt = nullptr, *z = nullptr;
     int* sel = nullptr;
     BState* bs = nullptr;
+    BPick* pick = nullptr;   // k_b_pick -> k_b_append hand-off, one per signal
+    double* Gm = nullptr;    // G = A'A (upper triangle of N x N), the option CSMP_OPT_BATCH_GRAM
+    int64_t Ng = 0;
+    bool gram_valid = false;
     float* cand_val = nullptr;
     int* cand_idx = nullptr;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
@@ -101,12 +105,18 @@ struct Batch {
     int last_streams = 1;
 };
 
+// A library-owned copy of the dictionary is shared by the context that uploaded it and its clones (csmp_clone): the memory
+// lives until the LAST of them lets go (csmp_destroy, or csmp_set_dictionary replacing it), so a functor never sweeps freed
+// memory.  A BORROWED device pointer (zero-copy) stays the caller's to keep alive.
+struct DictShare {
+    void* p;
+    int refs;
+};
+
 struct csmp_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;
-    hipStream_t stream2 = nullptr;  // second stream of the batched path (half-batches alternate between screen and step)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipDeviceProp_t prop{};
     std::string err;
     // page-locked host buffers for the small transfers on the latency chains (slot 0: the signal going up, slot 1: results and
@@ -116,6 +126,7 @@ struct csmp_ctx {
     // dictionary
     void* dA = nullptr;
     bool ownA = false;
+    struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
     int dtype = CSMP_F32;
     int64_t M = 0, N = 0, ld = 0;
     int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
@@ -123,7 +134,14 @@ struct csmp_ctx {
     int sweep_grid = 0, sweep_U = 1;
     int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
     bool sweep_full = false, sweep_nt = false;
-    bool force_reorth = false;  // debug/test knob: always run the second Gram-Schmidt pass
+    bool force_reorth = false;  // CSMP_OPT_FORCE_REORTH (test switch): always run the second Gram-Schmidt pass
+    // options (csmp_set_option, include/csmp.h)
+    int opt_batch_cert = 0;        // CSMP_OPT_BATCH_CERT: 0 statistical, 1 rigorous
+    int opt_batch_gram = 0;        // CSMP_OPT_BATCH_GRAM: resident G = A'A for csmp_omp_batch_mfma
+    int opt_batch_window = 0;      // CSMP_OPT_BATCH_WINDOW: rescoring window capacity, 0 = default
+    bool opt_ls_gram = true;       // CSMP_OPT_LS_GRAM: whole-set least squares by Gram + Cholesky
+    bool opt_ls_gram_reuse = true; // CSMP_OPT_LS_GRAM_REUSE
+    int opt_twostage_update = 0;   // CSMP_OPT_TWOSTAGE_UPDATE: 0 explicit inverse, 1 Givens down-date of R, 2 refactorise
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch
@@ -166,6 +184,17 @@ struct csmp_ctx {
         int rc_ = (expr);            \
         if (rc_ != CSMP_OK) return rc_; \
     } while (0)
+
+// Tuning switches exist only in the experiments build (`make experiments`, tools/probe_*.py); the product library reads no
+// environment variable: every behavioural choice is an argument or a csmp_set_option key (include/csmp.h).
+static const char* tune_env(const char* name) {
+#ifdef CSMP_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 static int fail(csmp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
@@ -219,26 +248,23 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
         delete ctx;
         return CSMP_EHIP;
     }
-    const char* pl = getenv("CSMP_PIPELINE");  // CSMP_PIPELINE=0: solve the signals of a batch strictly one after the other
-    ctx->pipeline = !(pl && pl[0] == '0');
-    if (const char* tw = getenv("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
-    if (const char* tn = getenv("CSMP_TICK_NBLK")) ctx->tick_nblk = std::max(0, atoi(tn));
-    if (const char* to = getenv("CSMP_TICK_ORDER")) ctx->tick_sweep_first = atoi(to) != 0;
-    if (const char* tp = getenv("CSMP_TICK_PF")) ctx->tick_pf = tp[0] != '0';
-    // test knob: CSMP_FORCE_REORTH=1 always runs the second Gram-Schmidt pass (k_qr3)
-    const char* fr = getenv("CSMP_FORCE_REORTH");
-    ctx->force_reorth = fr && fr[0] == '1';
+    if (const char* tw = tune_env("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
+    if (const char* tn = tune_env("CSMP_TICK_NBLK")) ctx->tick_nblk = std::max(0, atoi(tn));
+    if (const char* to = tune_env("CSMP_TICK_ORDER")) ctx->tick_sweep_first = atoi(to) != 0;
+    if (const char* tp = tune_env("CSMP_TICK_PF")) ctx->tick_pf = tp[0] != '0';
     *out = ctx;
     return CSMP_OK;
 }
 
 static void batch_free(Batch& b, bool keep_dict) {
     dfree(b.Rb); dfree(b.r); dfree(b.b); dfree(b.T); dfree(b.Tt); dfree(b.z); dfree(b.sel); dfree(b.bs);
-    dfree(b.cand_val); dfree(b.cand_idx);
+    dfree(b.cand_val); dfree(b.cand_idx); dfree(b.pick);
     b.Bcap = b.kcap = 0;
     if (!keep_dict) {
         dfree(b.Ab);
         dfree(b.amax);
+        dfree(b.Gm);
+        b.gram_valid = false;
         b.ab_valid = false;
         b.anorm_host = -1.f;
     }
@@ -264,8 +290,18 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s = Solver();
+}
+
+static void dict_release(csmp_ctx* ctx) {
+    if (ctx->share && --ctx->share->refs == 0) {
+        (void)hipFree(ctx->share->p);
+        delete ctx->share;
+    }
+    ctx->share = nullptr;
+    ctx->dA = nullptr;
+    ctx->ownA = false;
 }
 
 extern "C" int csmp_destroy(csmp_ctx* ctx) {
@@ -277,12 +313,9 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         solver_free(ctx->s);
     }
     batch_free(ctx->bt, false);
-    if (ctx->ownA) dfree(ctx->dA);
+    dict_release(ctx);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev2) (void)hipEventDestroy(e);
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     for (int q = 0; q < 3; ++q)
         if (ctx->pin[q]) (void)hipHostFree(ctx->pin[q]);
@@ -326,6 +359,61 @@ extern "C" int csmp_sync(csmp_ctx* ctx) {
     HIPCHECK(hipSetDevice(ctx->dev));
     HIPCHECK(sync_all(ctx));
     return CSMP_OK;
+}
+
+// Options: the choices that exist only on this side of the boundary (the reference passes its own as arguments:
+// src/matchingpursuit.jl:88-91,145-148, src/twostage.jl:87).  Per context; a clone starts from its parent's values.
+static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
+    switch (key) {
+        case CSMP_OPT_BATCH_CERT: *lo = 0; *hi = 1; return &ctx->opt_batch_cert;
+        case CSMP_OPT_BATCH_GRAM: *lo = 0; *hi = 1; return &ctx->opt_batch_gram;
+        case CSMP_OPT_BATCH_WINDOW: *lo = 0; *hi = kWinMax; return &ctx->opt_batch_window;
+        case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
+        default: return nullptr;
+    }
+}
+static bool* opt_flag(csmp_ctx* ctx, int key) {
+    switch (key) {
+        case CSMP_OPT_PIPELINE: return &ctx->pipeline;
+        case CSMP_OPT_FORCE_REORTH: return &ctx->force_reorth;
+        case CSMP_OPT_LS_GRAM: return &ctx->opt_ls_gram;
+        case CSMP_OPT_LS_GRAM_REUSE: return &ctx->opt_ls_gram_reuse;
+        default: return nullptr;
+    }
+}
+extern "C" int csmp_set_option(csmp_ctx* ctx, int key, int64_t value) {
+    if (!ctx) return CSMP_EINVAL;
+    int64_t lo = 0, hi = 0;
+    if (int* p = opt_slot(ctx, key, &lo, &hi)) {
+        if (value < lo || value > hi) return fail(ctx, CSMP_EINVAL, "csmp_set_option: value out of range");
+        if (key == CSMP_OPT_BATCH_GRAM && value == 0 && ctx->bt.Gm) {  // switching the Gram matrix off releases its 8 N^2 bytes
+            HIPCHECK(hipSetDevice(ctx->dev));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            dfree(ctx->bt.Gm);
+            ctx->bt.gram_valid = false;
+        }
+        *p = (int)value;
+        return CSMP_OK;
+    }
+    if (bool* f = opt_flag(ctx, key)) {
+        if (value != 0 && value != 1) return fail(ctx, CSMP_EINVAL, "csmp_set_option: value must be 0 or 1");
+        *f = value != 0;
+        return CSMP_OK;
+    }
+    return fail(ctx, CSMP_EINVAL, "csmp_set_option: unknown key");
+}
+extern "C" int csmp_get_option(csmp_ctx* ctx, int key, int64_t* value) {
+    if (!ctx || !value) return CSMP_EINVAL;
+    int64_t lo = 0, hi = 0;
+    if (int* p = opt_slot(ctx, key, &lo, &hi)) {
+        *value = *p;
+        return CSMP_OK;
+    }
+    if (bool* f = opt_flag(ctx, key)) {
+        *value = *f ? 1 : 0;
+        return CSMP_OK;
+    }
+    return fail(ctx, CSMP_EINVAL, "csmp_get_option: unknown key");
 }
 
 extern "C" int csmp_device_info(csmp_ctx* ctx, char* name, int name_len, int* compute_units, int64_t* hbm_bytes) {
@@ -465,7 +553,7 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     ctx->sweep_full = (ctx->Mv % rows) == 0;
     ctx->sweep_U = 1;
-    const char* su = getenv("CSMP_SWEEP_U");  // tuning knob: cap the load-block size
+    const char* su = tune_env("CSMP_SWEEP_U");  // tuning knob: cap the load-block size
     const int umax = su ? atoi(su) : 16;
     if (ctx->sweep_full)
         for (int u : {16, 8, 4, 2})
@@ -474,7 +562,7 @@ static int configure_sweep(csmp_ctx* ctx) {
                 break;
             }
     ctx->tick_U = ctx->sweep_U;
-    if (ctx->sweep_full && ctx->sweep_U == 16 && !getenv("CSMP_TICK_U16")) ctx->tick_U = 8;  // (16 | nchunk implies 8 | nchunk)
+    if (ctx->sweep_full && ctx->sweep_U == 16 && !tune_env("CSMP_TICK_U16")) ctx->tick_U = 8;  // (16 | nchunk implies 8 | nchunk)
     ctx->sweep_nt = true;
     int per_cu = ctx->sweep_U == 16 ? 3 : 4;
     per_cu = (int)std::min<size_t>((size_t)per_cu, (160 * 1024) / ctx->sweep_lds);
@@ -483,8 +571,8 @@ static int configure_sweep(csmp_ctx* ctx) {
     int64_t grid = (int64_t)ctx->prop.multiProcessorCount * per_cu;
     if (ctx->sweep_full && ctx->sweep_U == 16) grid = (int64_t)ctx->prop.multiProcessorCount * 3 / 4;  // pipelined kernel
     if (ctx->sweep_full && ctx->sweep_U == 8) grid = (int64_t)ctx->prop.multiProcessorCount;
-    if (const char* sn = getenv("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));  // tuning knob
-    if (const char* sp = getenv("CSMP_SWEEP_LDS"))  // tuning knob: request at least this much LDS per workgroup
+    if (const char* sn = tune_env("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));  // tuning knob
+    if (const char* sp = tune_env("CSMP_SWEEP_LDS"))  // tuning knob: request at least this much LDS per workgroup
         ctx->sweep_lds = std::max(ctx->sweep_lds, (size_t)atoi(sp));
     ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
     return CSMP_OK;
@@ -497,9 +585,7 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
     HIPCHECK(hipSetDevice(ctx->dev));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->ownA) dfree(ctx->dA);
-    ctx->dA = nullptr;
-    ctx->ownA = false;
+    dict_release(ctx);  // (clones that still hold the previous dictionary keep it alive)
     HIPCHECK(sync_all(ctx));
     for (int q = 2; q >= 0; --q) {
         activate_slot(ctx, q);
@@ -523,6 +609,7 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
         HIPCHECK(hipMalloc(&d, (size_t)ld * (size_t)N * es));
         ctx->dA = d;
         ctx->ownA = true;
+        ctx->share = new DictShare{d, 1};
         ctx->ld = ld;
         ctx->Mv = (int)ld;
         if (ld != M) HIPCHECK(hipMemsetAsync(d, 0, (size_t)ld * (size_t)N * es, ctx->stream));
@@ -761,7 +848,7 @@ static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
 static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
                          int* d_flag = nullptr) {
     Solver& s = ctx->s;
-    if (s.kcap > 256 && !getenv("CSMP_FINISH_W") && !getenv("CSMP_FINISH_B")) {
+    if (s.kcap > 256 && !tune_env("CSMP_FINISH_W") && !tune_env("CSMP_FINISH_B")) {
         // super-blocks of 256 columns over several CUs (k_trsv_*): the host's bound on the support says how many there are; a
         // super-block beyond the true support returns at once
         const int jb = s.jh > 0 ? std::min(s.jh, s.kcap) : s.kcap;
@@ -780,7 +867,7 @@ static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* 
         HIPCHECK(hipGetLastError());
         return CSMP_OK;
     }
-    if (s.kcap > 256 && !getenv("CSMP_FINISH_W")) {  // blocked form in ONE workgroup: one memory round trip per 64 columns
+    if (s.kcap > 256 && !tune_env("CSMP_FINISH_W")) {  // blocked form in ONE workgroup: one memory round trip per 64 columns
         const size_t lds = (size_t)(s.kcap + 64) * sizeof(double) + (size_t)s.kcap * sizeof(int);
         if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_finish_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_finish_b, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
@@ -1042,7 +1129,7 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
         // Measured at 4096 x 65536 f32 (profiles/r01_bench_fr_line.json): 8-chunk blocks on one workgroup per CU
         // 168 us, 16-chunk blocks on 3/4 of the CUs (the OMP sweep's optimum) 173 us -- with a second LDS image
         // to read per chunk, the extra waves hide more than the extra DRAM streams cost.
-        const char* fu = getenv("CSMP_FR_U");  // tuning knob: cap the load-block size
+        const char* fu = tune_env("CSMP_FR_U");  // tuning knob: cap the load-block size
         const int umax = fu ? atoi(fu) : 8;
         for (int u : {16, 8})
             if (u <= umax && nchunk % u == 0) {
@@ -1054,7 +1141,7 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
     lds = fr_sweep_lds_bytes(ctx->Mv, vec, U, nq);
     const int cus = ctx->prop.multiProcessorCount;
     int64_t g = U == 16 ? (int64_t)cus * 3 / 4 : (int64_t)cus;  // as the OMP sweep (configure_sweep)
-    if (const char* sn = getenv("CSMP_FR_NBLK")) g = std::max(1, atoi(sn));  // tuning knob
+    if (const char* sn = tune_env("CSMP_FR_NBLK")) g = std::max(1, atoi(sn));  // tuning knob
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(g, groups));
 }
@@ -1117,7 +1204,7 @@ static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_
     int U, grid; bool full; size_t flds;
     fr_config(ctx, 1, U, full, flds, grid);
     int nblk = grid;
-    if (const char* tn = getenv("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
+    if (const char* tn = tune_env("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
     const size_t lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));
     if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
@@ -1453,6 +1540,15 @@ extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     }
     c->dA = src->dA;
     c->ownA = false;
+    c->share = src->share;  // (null for a borrowed device pointer: the caller keeps that alive)
+    if (c->share) c->share->refs += 1;
+    c->pipeline = src->pipeline;
+    c->force_reorth = src->force_reorth;
+    c->opt_batch_cert = src->opt_batch_cert;
+    c->opt_batch_window = src->opt_batch_window;
+    c->opt_ls_gram = src->opt_ls_gram;
+    c->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
+    c->opt_twostage_update = src->opt_twostage_update;
     c->dtype = src->dtype;
     c->M = src->M;
     c->N = src->N;
@@ -1934,7 +2030,7 @@ static int gram_split_for(const csmp_ctx* ctx, int np) {
     const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
     int nsplit = std::max(1, slots / std::max(1, pieces));
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
-    if (const char* e = getenv("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
+    if (const char* e = tune_env("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
     return std::min(nsplit, 32);
 }
 static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
@@ -1943,7 +2039,7 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
-    dfree(s.Gm); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
     CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
@@ -1952,6 +2048,7 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
     CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.Dfac, (size_t)np * kCholNB));  // the factored diagonal blocks (chol_row_body)
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
     CHECK(dmalloc(ctx, &s.rpart, (size_t)((np + kResChunk - 1) / kResChunk) * s.Mpad));
@@ -1971,7 +2068,6 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     const int n = (int)cols.size(), M = (int)ctx->M;
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int nsplit = gram_split_for(ctx, np);
-    if (getenv("CSMP_GRAM_DEBUG")) fprintf(stderr, "ls_gram: n %d np %d nsplit %d M %d\n", n, np, nsplit, M);
     CHECK(gram_ensure(ctx, np, nsplit));
     CHECK(solver_restart(ctx));
     // the column list (and, for a subset, its positions in the kept set) go up from a page-locked buffer that lives until the
@@ -1985,7 +2081,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
     // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
-    bool subset = s.keep_valid && n <= s.keep_n && !getenv("CSMP_NO_GRAM_REUSE");
+    bool subset = s.keep_valid && n <= s.keep_n && ctx->opt_ls_gram_reuse;
     if (subset) {
         std::vector<std::pair<int, int>> where((size_t)s.keep_n);
         for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
@@ -2027,7 +2123,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     {
         const int left0 = np - kCholNB;
         hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n,
-                           0, (const double*)s.gdiag, s.st);
+                           0, (const double*)s.gdiag, s.st, s.Dfac);
     }
     for (int kb = 0; kb + 1 < nsteps; ++kb) {  // one launch per step: trailing update of panel kb + block row kb + 1
         const int left = np - (kb + 1) * kCholNB;   // columns from the next block row on
@@ -2036,11 +2132,11 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
         const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
         hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n, kb, (const double*)s.gdiag, s.st,
-                           nrow);
+                           nrow, s.Dfac);
     }
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np, n,
-                       (const int*)s.cands, s.R, s.kcap, s.z, s.sel, s.st);
+                       (const int*)s.cands, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
     HIPCHECK(hipGetLastError());
     s.jh = std::min(s.kcap, n);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
@@ -2054,7 +2150,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
 }
 static bool gram_applicable(const csmp_ctx* ctx, size_t n) {
     // worth it from a few panels on; needs QR capacity for R and distinct columns (the callers guarantee those)
-    return n >= 64 && !ctx->force_reorth && !getenv("CSMP_NO_GRAM");
+    return n >= 64 && !ctx->force_reorth && ctx->opt_ls_gram;
 }
 static int ls_gram(csmp_ctx* ctx, const std::vector<int>& cols) {
     return ctx->dtype == CSMP_F32 ? ls_gram_t<float>(ctx, cols) : ls_gram_t<double>(ctx, cols);
@@ -2281,13 +2377,13 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
     if (maxiter < 0) maxiter = ctx->M;  // :185
     HIPCHECK(hipSetDevice(ctx->dev));
-    const bool want_downdate = k <= kDelMaxCols && !getenv("CSMP_OMPR_REFACTOR");
+    const bool want_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;
     if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
     CHECK(solver_ensure(ctx, (int)k, (int)k));
     ctx->s.begun = false;
     Solver& s = ctx->s;
-    const bool use_downdate = k <= kDelMaxCols && !getenv("CSMP_OMPR_REFACTOR");  // (knob: refactorise instead)
-    const bool tmode = use_downdate && !getenv("CSMP_NO_TINV");  // explicit inverse next to R (csmp_tinv.hpp)
+    const bool use_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;  // (option 2: refactorise instead)
+    const bool tmode = use_downdate && ctx->opt_twostage_update == 0;  // explicit inverse next to R (csmp_tinv.hpp)
     if (use_downdate) CHECK(del_ensure(ctx));
     if (tmode) CHECK(tinv_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
@@ -2583,7 +2679,7 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
         p0.nq = -1;
         p0.update_only = 1;
         CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
-        if (!getenv("CSMP_FR_REBUILD_SWEEPS")) {
+        if (!tune_env("CSMP_FR_REBUILD_SWEEPS")) {
             // Q'A on the Float64 matrix cores, 128 directions per pass (csmp_forward.hpp, k_fr_rebuild)
             const int grid = (int)((ctx->N + 127) / 128);  // 4 waves x 32 atoms
             for (int64_t t = 0; t < k; t += 128) {
@@ -2875,8 +2971,9 @@ __global__ __launch_bounds__(256) void k_colnorm_max(const TA* __restrict__ A, i
 static int batch_dict(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
     if (b.ab_valid) return CSMP_OK;
-    b.Mk = (int)(((ctx->M + kBK - 1) / kBK) * kBK);
-    b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles (k_b_screen256)
+    // K is padded (zeros) to an even number of 64-deep tiles, at least four: what the eight-phase screening kernel needs
+    b.Mk = (int)std::max<int64_t>(256, ((ctx->M + 127) / 128) * 128);
+    b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles
     b.n_atiles = (int)(b.Npad / kBT);
     HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
     HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
@@ -2898,6 +2995,22 @@ static int batch_dict(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
+// max_j |a_j|_2 (the deterministic screening bound), computed on first use
+static int batch_colnorm(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.anorm_host >= 0.f) return CSMP_OK;
+    HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+    const unsigned grid = (unsigned)((ctx->N + 3) / 4);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_colnorm_max<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+    else
+        hipLaunchKernelGGL(k_colnorm_max<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&b.anorm_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
+}
+
 static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     Batch& b = ctx->bt;
     const int Bpad = ((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);
@@ -2916,49 +3029,82 @@ static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     CHECK(dmalloc(ctx, &b.z, (size_t)nb * nk));
     CHECK(dmalloc(ctx, &b.sel, (size_t)nb * nk));
     CHECK(dmalloc(ctx, &b.bs, (size_t)nb));
+    CHECK(dmalloc(ctx, &b.pick, (size_t)nb));
     CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
     CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
     return CSMP_OK;
 }
 
-// co: the 168-register persistent form (one workgroup per CU), which shares CUs with the screening kernel of the other half-batch
-template <typename TA, int NI>
-static hipError_t b_step_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef, bool co) {
+// G = A'A, Float64 products of the exactly promoted dictionary values, upper triangle (row <= column) of an N x N array:
+// the option CSMP_OPT_BATCH_GRAM.  8 N^2 bytes (32 GiB at N = 65536) and 2 M N^2 / 2 flops on the Float64 matrix cores
+// (k_gram, csmp_gram.hpp: the dictionary is its own "compact copy") -- once per dictionary, like the bf16 image.
+static int batch_gram(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
-    const size_t lds = b_step_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
-    if constexpr (NI <= 4) {
-        if (co) {
-            auto kern = k_b_step_co<TA, NI, 2>;
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            hipLaunchKernelGGL(kern, dim3(std::min(nsig, ctx->prop.multiProcessorCount)), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
-                               (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
-                               b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0, nsig);
-            return hipGetLastError();
-        }
-    }
-    auto kern = k_b_step<TA, NI, ((NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : 4)>;  // (columns / row chunks whose loads are issued together)
+    if (b.gram_valid) return CSMP_OK;
+    const int64_t N = ctx->N;
+    if (ctx->ld % 16 != 0 && ctx->ld != ((ctx->M + 15) / 16) * 16) { /* any ld works: k_gram reads rows < ldo only */ }
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)N * (size_t)N * sizeof(double);
+    if (need + ((size_t)1 << 30) > free_b) return fail(ctx, CSMP_ENOMEM, "CSMP_OPT_BATCH_GRAM: 8 N^2 bytes of HBM are not available");
+    HIPCHECK(hipMalloc((void**)&b.Gm, need));
+    // k_gram tiles are 128 x 64 over np columns; np = N need not be a multiple of the tile: rows / columns >= np are clamped and
+    // never stored.  One slice of the rows (no partials): rows_per_split = the whole padded column.
+    const int np = (int)N;
+    const int64_t ldo = ctx->ld;  // rows [M, ld) of the resident dictionary are zeros in our own copy; a BORROWED dictionary has ld = M
+    const int rows = (int)(((int64_t)ctx->Mv + 15) / 16 * 16);
+    const dim3 grid((unsigned)((np + kGramWgJ - 1) / kGramWgJ), (unsigned)((np + kGramWgI - 1) / kGramWgI), 1);
+    if (rows > ldo) return fail(ctx, CSMP_ERANGE, "CSMP_OPT_BATCH_GRAM: the dictionary's rows must be padded to a multiple of 16 (copy it: pass a host pointer)");
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_gram<float>, grid, dim3(256), 0, ctx->stream, (const float*)ctx->dA, ldo, np, rows, b.Gm);
+    else
+        hipLaunchKernelGGL(k_gram<double>, grid, dim3(256), 0, ctx->stream, (const double*)ctx->dA, ldo, np, rows, b.Gm);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.Ng = N;
+    b.gram_valid = true;
+    return CSMP_OK;
+}
+
+// DEPTH of the two per-signal kernels: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
+template <typename TA, int NI>
+static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
+                                int kwin) {
+    Batch& b = ctx->bt;
+    constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 1 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
+    hipLaunchKernelGGL((k_b_pick<TA, NI, DEPTH>), dim3(nsig), dim3(256), 0, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)b.cand_val,
+                       (const int*)b.cand_idx, b.n_atiles * kTileCand, (const int*)b.sel, b.bs, b.pick, (const double*)b.r, b.Mr, b.kcap, (int)ctx->M, eps,
+                       check_eps, cert_abs, cert_rel, kwin, sig0);
+    return hipGetLastError();
+}
+template <typename TA, int NI, bool GRAM>
+static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig) {
+    Batch& b = ctx->bt;
+    constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
+    const size_t lds = b_append_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
+    auto kern = k_b_append<TA, NI, DEPTH, GRAM>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    int grid = nsig;
-    if (const char* g = getenv("CSMP_STEP_GRID")) grid = std::max(1, std::min(nsig, atoi(g)));  // (fewer resident signals: smaller cache footprint)
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
-                       (const float*)b.cand_val, (const int*)b.cand_idx, b.n_atiles * kTileCand, b.T, b.Tt, b.z, b.sel, b.bs,
-                       b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, eps, check_eps, cert_coef, sig0, nsig);
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const double*)b.Gm, b.Ng, (const BPick*)b.pick, b.T,
+                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0);
     return hipGetLastError();
 }
-
 template <typename TA>
-static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_coef, bool co) {
+static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
+                                  int kwin, bool gram) {
     const int groups = (ctx->Mv + 1023) / 1024;
-    if (groups <= 1) return b_step_launch<TA, 1>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
-    if (groups <= 2) return b_step_launch<TA, 2>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
-    if (groups <= 4) return b_step_launch<TA, 4>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, co);
-    return b_step_launch<TA, 8>(ctx, stream, sig0, nsig, eps, check_eps, cert_coef, false);
+    hipError_t e;
+#define CSMP_BSTEP(NI)                                                                                                  \
+    e = b_pick_launch<TA, NI>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin);                          \
+    if (e != hipSuccess) return e;                                                                                      \
+    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig);
+    if (groups <= 1) { CSMP_BSTEP(1) }
+    if (groups <= 2) { CSMP_BSTEP(2) }
+    if (groups <= 4) { CSMP_BSTEP(4) }
+    CSMP_BSTEP(8)
+#undef CSMP_BSTEP
 }
 
 extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
@@ -2977,6 +3123,8 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals
     ctx->s.begun = false;
     Batch& b = ctx->bt;
+    const bool gram = ctx->opt_batch_gram != 0;
+    if (gram) CHECK(batch_gram(ctx));
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     void* dB = const_cast<void*>(B);
     DevTmp tB, tIdx, tVal, tNnz;  // freed on every return path
@@ -2996,105 +3144,50 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         d_nnz = (int64_t*)tNnz.p;
     }
     const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
-    const int n_stiles = Bpad / kBT;
-#ifdef CSMP_EXPERIMENTS
-    {
-        const char* ab = getenv("CSMP_STEP_ABLATE");
-        const int v = ab ? atoi(ab) : 0;
-        HIPCHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_step_ablate), &v, sizeof(int)));
-    }
-#endif
     if (b_dtype == CSMP_F32)
         hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
     else
         hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
     HIPCHECK(hipGetLastError());
-    // 256^2 tiles with LDS-DMA staging whenever both edges tile by 256 (knob CSMP_SCREEN_128: the 128^2 kernel)
-    const bool big = !getenv("CSMP_SCREEN_128") && (b.n_atiles % 2 == 0) && (n_stiles % 2 == 0);
-    // Screening error bound delta = coef * ||r||.  Default: 8 sigma of the bf16 rounding model (independent roundings of
-    // the M products) -- a PROBABILISTIC certificate; structured dictionaries whose rounding errors add
-    // coherently are outside that model.  CSMP_CERT=rigorous: the deterministic bound
-    // |<a,r> - screened| <= (2^-7 (1 + 2^-9) + M 2^-24) |a|_2 |r|_2 (bf16 unit roundoff 2^-8 on both operands, Float32
-    // accumulation), eight times wider: more signals go to the exact path.
-    double cert_coef = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
-    if (const char* ce = getenv("CSMP_CERT")) {
-        if (ce[0] == 'r') {
-            if (b.anorm_host < 0.f) {
-                HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
-                const unsigned grid = (unsigned)((ctx->N + 3) / 4);
-                if (ctx->dtype == CSMP_F32)
-                    hipLaunchKernelGGL(k_colnorm_max<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
-                else
-                    hipLaunchKernelGGL(k_colnorm_max<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
-                HIPCHECK(hipGetLastError());
-                HIPCHECK(hipMemcpyAsync(&b.anorm_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-                HIPCHECK(hipStreamSynchronize(ctx->stream));
-            }
-            cert_coef = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
-        }
+    // Screening error bound  | |<a_n, r>| - s_n | <= cert_abs |r| + cert_rel s_n  (k_b_pick, csmp_batched.hpp).
+    // Statistical (default): 8 standard deviations of the bf16 rounding model -- independent roundings of the M products,
+    // sigma = sqrt(2/3) 2^-9 max|A_ij| |r| -- PLUS the fully coherent case the independent model misses: an operand whose
+    // entries all round the same way is a scaled operand, (1 + a)(1 + b) s with |a|, |b| <= 2^-8 (few-valued and one-magnitude
+    // dictionaries: every entry of a column rounds alike), i.e. 2^-7 s, plus the 2^-15 the packed candidate keys drop.
+    // Rigorous (CSMP_OPT_BATCH_CERT = 1): |<a,r> - screened| <= (2^-7 (1 + 2^-9) + Mk 2^-24) |a|_2 |r|_2 (bf16 unit roundoff
+    // 2^-8 on both operands, Float32 accumulation) with the largest column norm, and the key truncation: a proof, about nine
+    // times wider on a Gaussian dictionary -- the window holds more candidates (64 instead of 16), more signals overflow it.
+    double cert_abs, cert_rel;
+    int kwin;
+    if (ctx->opt_batch_cert == 1) {
+        CHECK(batch_colnorm(ctx));
+        cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+        cert_rel = std::ldexp(1.0, -14);
+        kwin = kWinMax;  // 128
+    } else {
+        cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+        cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -14);
+        kwin = kWinMax / 2;  // 64
     }
-    // CSMP_BATCH_STREAMS=2: two half-batches on two streams, so that the screening GEMM of one half (matrix cores) could
-    // run beside the rescoring / append kernel of the other (HBM gathers); each stream is the plain chain
-    // screen -> step -> screen -> ... of its own signals.  Measured at config 3: the plain kernels each fill
-    // a CU alone (LDS, registers), the two chains merely interleave and the batch gains 1.4 % -- while the per-launch
-    // timing of the screening kernel (HIP events on its stream) then also counts the time it queues behind the other
-    // stream's kernel.  Off by default; the pair that CAN share a CU is CSMP_BATCH_CO=1 (below).
-    const int tile = 2 * kBT;  // halves are whole 256-signal tiles
-    const char* nstr = getenv("CSMP_BATCH_STREAMS");
-    const bool split = nstr && nstr[0] == '2' && Bpad >= 2 * tile;
-    const int nh = split ? 2 : 1;
-    // CSMP_BATCH_CO=1 selects the co-resident kernel pair (k_b_screen256c + k_b_step_co: 168 registers each, < 160 KiB of
-    // LDS together, persistent grids of one workgroup per CU).  Only that pair can share a CU -- the plain kernels each
-    // fill one alone, and two streams of them merely interleave -- but the register diet costs more than the overlap
-    // returns (measured, DESIGN.md "Batched variant": screen 448 -> 812 us, step 430 -> 670 us per full batch; 139 ms per
-    // C3 batch against 114 ms), so it is off by default and kept as the documented experiment.
-    const size_t step_lds = b_step_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, b.kcap);
-    const char* coenv = getenv("CSMP_BATCH_CO");
-    const bool co = coenv && coenv[0] == '1' && split && big && ctx->Mv <= 4096 && step_lds <= 160 * 1024 - kScreenLds256;
-    // the eight-phase kernel needs an even number of 64-deep K-tiles; CSMP_SCREEN_8PHASE=0 falls back to the two-phase 256^2 kernel
-    const char* ph = getenv("CSMP_SCREEN_8PHASE");
-    const bool phased = big && (b.Mk % 128 == 0) && b.Mk >= 256 && !(ph && ph[0] == '0');
-    const int mode = co ? kScreenCo : phased ? kScreen256p : big ? kScreen256 : kScreen128;
-    b.last_mode = mode;
-    int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
-    if (split) {
-        hpad[0] = ((Bpad / 2 + tile - 1) / tile) * tile;
-        hpad[1] = Bpad - hpad[0];
-        h0[1] = hpad[0];
-        hn[0] = (int)std::min<int64_t>(nsig, hpad[0]);
-        hn[1] = (int)(nsig - hn[0]);
-        if (!ctx->stream2) HIPCHECK(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
-        if (!ctx->ev_fork) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        if (!ctx->ev_join) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        HIPCHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIPCHECK(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-    }
-    b.last_streams = nh;
-    b.last_screen_signals = hpad[0];
-    hipStream_t hs_[2] = {ctx->stream, ctx->stream2};
+    if (ctx->opt_batch_window > 0) kwin = std::min<int>(kWinMax, (int)ctx->opt_batch_window);
+    if (tune_env("CSMP_CERT_NOREL")) cert_rel = std::ldexp(1.0, -14);  // (experiments build: the round-2 bound, for tools/probe_structured.py)
+    b.last_mode = kScreen256p;
+    b.last_streams = 1;
+    b.last_screen_signals = Bpad;
     for (int64_t t = 0; t < k; ++t) {
-        for (int h = 0; h < nh; ++h) {
-            if (hn[h] <= 0) continue;
-            const bool timed = ctx->prof && h == 0;  // (events on the first half's stream: its screening launches)
-            if (timed) {
-                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
-            }
-            HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles,
-                                   hpad[h] / kBT, ctx->N, b.cand_val + (size_t)h0[h] * b.n_atiles * kTileCand,
-                                   b.cand_idx + (size_t)h0[h] * b.n_atiles * kTileCand, ctx->prop.multiProcessorCount));
-            if (timed) {
-                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
-            }
-            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef, co)
-                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_coef, co);
-            HIPCHECK(e);
+        const bool timed = ctx->prof;  // (HIP events around the screening launch)
+        if (timed) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
         }
-    }
-    if (split) {
-        HIPCHECK(hipEventRecord(ctx->ev_join, ctx->stream2));
-        HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        HIPCHECK(launch_screen(ctx->stream, (const __bf16*)b.Ab, (const __bf16*)b.Rb, b.Mk, b.n_atiles, Bpad / kBT, ctx->N, b.cand_val, b.cand_idx));
+        if (timed) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram)
+                                              : b_step_dispatch<double>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram);
+        HIPCHECK(e);
     }
     hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
                        (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);
@@ -3112,6 +3205,10 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         b.last_resolved += 1;
         b.last_uncertain += hs[sgn].uncertain ? 1 : 0;
         b.last_illcond += hs[sgn].illcond ? 1 : 0;
+        if (tune_env("CSMP_BATCH_DEBUG"))
+            fprintf(stderr, "signal %lld: uncertain %d illcond %d nsel %d | first failed certificate at step %d: window %d (cap %d), best exact %.6f, bound %.6f, top screened %.6f, |r| %.4f\n",
+                    (long long)sgn, hs[sgn].uncertain, hs[sgn].illcond, hs[sgn].nsel, hs[sgn].unc_step, hs[sgn].unc_nall, kwin, hs[sgn].unc_best,
+                    hs[sgn].unc_cb, hs[sgn].unc_s1, std::sqrt(hs[sgn].rnorm2));
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
                                  : init_from_device_t<double>(ctx, (const double*)col);
@@ -3245,7 +3342,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         const int64_t groups = (ctx->N + 4 * (cpwx == 3 ? 1 : cpwx) - 1) / (4 * (cpwx == 3 ? 1 : cpwx));
         grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * (per_cu ? per_cu : 4), groups));
         if (grid > ctx->prop.multiProcessorCount * 8) grid = ctx->prop.multiProcessorCount * 8;
-        if (const char* sn = getenv("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));
+        if (const char* sn = tune_env("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));
         if (ctx->Mv % (256 * U)) return fail(ctx, CSMP_EINVAL, "bench_sweep: M must be a multiple of 256*U");
         for (int i = 0; i < 3; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
         hipEvent_t e0, e1;

@@ -4,23 +4,27 @@
 // `[omp(A, B[:,s], eps, k) for s in axes(B,2)]` restructured so that the dominant cost, the
 // residual-correlation sweep, becomes ONE dense GEMM  C = A' [r_1 ... r_B]  on the matrix cores:
 //
-//   k_b_screen  bf16 MFMA (v_mfma_f32_32x32x16_bf16, f32 accumulate) 128 atoms x 128 signals tiles
-//               with a fused epilogue that keeps the 4 largest |c| per (signal, atom tile): the
-//               N x B product (256 MiB at C3) is never written.
-//   k_b_step    one workgroup per signal: merges the tile candidates to the 16 best screened atoms,
-//               RESCORES them exactly (f32 master dictionary, Float64 products and sums against the
-//               Float64 residual), picks the arg-max by the exact value (first index on ties), then
-//               appends it to the signal's factorisation and updates the residual.
+//   k_b_screen256p (csmp_screen.hip)  bf16 MFMA, f32 accumulate, 256 atoms x 256 signals per workgroup, with a fused
+//               epilogue that keeps the 4 largest |c| per (signal, 128-atom tile): the N x B product (256 MiB at C3)
+//               is never written.
+//   k_b_pick    one workgroup per signal (argmaxinner!, src/matchingpursuit.jl:181-185, + update!'s guards :63,66):
+//               takes the tile candidates whose screened value could still be the exact maximum (the WINDOW), RESCORES
+//               them exactly (f32/f64 master dictionary, Float64 products and sums against the Float64 residual), picks
+//               the arg-max by the exact value (first index on ties) and certifies it against everything not rescored.
+//   k_b_append  one workgroup per signal (addindex! + residual!, src/util.jl:118-126, src/matchingpursuit.jl:152-161):
+//               appends the atom to the signal's factorisation and updates the residual and its bf16 image.
 //
 // The bf16 product only SCREENS; every value that decides or enters the result is Float64 on the
-// exactly promoted dictionary, so supports match the Float64 oracle.  A certificate (exact best
-// > 16th screened value + an error bound) guards the screen; a signal that ever fails it (or whose
+// exactly promoted dictionary, so supports match the Float64 oracle.  The certificate (exact best > an upper bound on
+// the exact value of every atom that was not rescored) guards the screen; a signal that ever fails it (or whose
 // support becomes ill-conditioned) is re-solved by the exact single-signal path.
 //
 // Per-signal factorisation: no Q is stored (it would be M x k Float64 per signal and read twice a
 // step).  With A_S = Q R:  w = Q'a = R^-T (A_S' a),  v = a - Q w = a - A_S (R^-1 w); the inverse
 // T = R^-1 is kept explicitly (and its transpose), so both "triangular solves" are coalesced
-// mat-vecs and the only large traffic is two streams over the support's f32 columns of A.
+// mat-vecs and the only large traffic is two streams over the support's f32 columns of A -- or ONE, when the
+// caller has asked for the resident Gram matrix G = A'A (csmp_set_option CSMP_OPT_BATCH_GRAM): A_S'a is then a
+// gather of j numbers.
 #pragma once
 #include "csmp_kernels.hpp"
 #include "csmp_screen.hpp"
@@ -30,14 +34,23 @@ namespace csmp {
 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kKeep = 16;        // candidates rescored per signal and step
-#ifdef CSMP_EXPERIMENTS
-__device__ int g_step_ablate = 0;  // timing probe (tools/probe_batched.py): 1 skip the rescoring loads, 2 skip pass 1, 4 skip pass 2
-#endif
+// workgroups of the per-signal kernels a CU holds (register budget 512 / (4 x this) per lane): rows per thread = 4 NI, and
+// an f64 dictionary doubles the registers of every column in flight
+template <typename TA, int NI> constexpr int b_wgs() { return sizeof(TA) == 4 ? (NI <= 4 ? 4 : 2) : (NI <= 2 ? 4 : NI <= 4 ? 2 : 1); }
+constexpr int kWinMax = 128;      // capacity of the rescoring window (candidates rescored per signal and step)
 
 struct BState {
     int nsel, done, uncertain, illcond;
     double rnorm2;
+    // the first failed certificate of the signal (diagnostics: csmp_batch_stats' callers see only the counts)
+    int unc_step, unc_nall;
+    double unc_cb, unc_best, unc_s1;
+};
+// hand-off k_b_pick -> k_b_append, one per signal
+struct BPick {
+    int atom;       // the step's atom; -1: nothing to append (stopped, stagnated)
+    int nwin;       // candidates rescored (statistics)
+    double cexact;  // <a_atom, r>, Float64
 };
 
 // dictionary (f32/f64, column-major M x N) -> bf16 [Npad][Mk], zero padded (RNE: v_cvt_pk_bf16_f32)
@@ -115,75 +128,71 @@ __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int
 }
 
 // ---------------------------------------------------------------------------------------------
-// One OMP step of one signal, by one workgroup.  See the file header for the algebra.
-// LDS: vectors g,w,y (3 x kcap Float64) | reduction and candidate scratch | the new atom's column in the
-// dictionary's own type (f32: 16 KiB at M = 4096 -- the whole footprint stays below 32 KiB, which is what lets one
-// of these workgroups share a CU with a 128-KiB screening workgroup of the OTHER half-batch).
-// DEPTH: columns (rescoring, pass 2) / row chunks (pass 1) whose loads are issued together.
+// Selection of one OMP step of one signal, by one workgroup.
+//
+// The screening launch left, per (signal, 128-atom tile), its kTileCand largest screened values s_n ~ |<a_n, r>| (bf16
+// operands, f32 accumulation).  With an error bound  | |<a_n, r>| - s_n | <= d(s_n) = cert_abs |r| + cert_rel s_n :
+//   * window: every candidate whose upper bound s + d(s) reaches the lower bound of the largest screened value,
+//     s_1 - d(s_1), could be the exact arg-max and is rescored exactly; the others cannot (their exact value is below
+//     the exact value of the top candidate);
+//   * certificate: every atom that was NOT rescored -- a candidate outside the window, or an atom hidden behind the
+//     last kept candidate of its tile -- has an exact value <= cb = the largest upper bound among them; the exact best
+//     of the window must exceed cb, else the signal is flagged `uncertain` (and re-solved exactly by the caller).
+// A passed certificate therefore proves the pick, given the bound.  cert_abs / cert_rel: csmp.hip (statistical model of
+// independent roundings + the coherent "whole operand scaled" term, or the deterministic bound).
+// A window larger than kwin entries is a failed certificate.
 template <typename TA, int NI, int DEPTH>
-__device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
-                                           const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                           int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
-                                           double* __restrict__ z_all, int* __restrict__ sel_all,
-                                           BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
-                                           __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
-                                           int check_eps, double cert_coef, double* lds) {
-    using VT = typename Vec<TA>::type;
-    constexpr int VEC = Vec<TA>::n;
-    constexpr int ROWS = kWave * VEC;
+__global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
+    const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand,
+    const int* __restrict__ sel_all, BState* __restrict__ bs, BPick* __restrict__ pick, const double* __restrict__ r_all, int Mr,
+    int kcap, int Mrows, double eps, int check_eps, double cert_abs, double cert_rel, int kwin, int sig0) {
+    __shared__ double sc[8];
+    __shared__ double red[4 * kWinMax];
+    __shared__ float wv_[kWinMax];
+    __shared__ int wi_[kWinMax];
+    __shared__ float fsc[4];
+    __shared__ int cnt;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = sig0 + (int)blockIdx.x;
     BState& st = bs[s];
+    if (tid == 0) {
+        pick[s].atom = -1;
+        cnt = 0;
+    }
     if (st.done) return;
-    const int nchunk = (Mv + ROWS - 1) / ROWS;
-    const int Mlds = nchunk * ROWS;
-    double* gv = lds;                   // kcap
-    double* wv = gv + kcap;             // kcap
-    double* yv = wv + kcap;             // kcap
-    double* sc = yv + kcap;             // 8
-    double* red = sc + 8;               // 4 x kKeep
-    float* cv = reinterpret_cast<float*>(red + 4 * kKeep);  // kKeep
-    int* ci = reinterpret_cast<int*>(cv + kKeep);           // kKeep
-    float* rv = reinterpret_cast<float*>(ci + kKeep);       // 256 (arg-max scratch)
-    int* ri = reinterpret_cast<int*>(rv + 256);             // 256
-    int* selL = ri + 256;                                   // kcap: the support, staged once (the passes index it per column)
-    TA* aimg = reinterpret_cast<TA*>((reinterpret_cast<uintptr_t>(selL + kcap) + 15) & ~(uintptr_t)15);  // Mlds entries in natural row order: lane l of chunk t reads its
-                                                            // 16 bytes at (t * 64 + l) * 16 -- consecutive lanes, conflict-free
-
-    double* r = r_all + (int64_t)s * Mr;
-    const int j = st.nsel;
-    int* sel = sel_all + (int64_t)s * kcap;
-
-    // the tile candidates of the fast merge path are requested FIRST: they depend on nothing, and their round trip then
-    // overlaps the residual's (it used to start behind the norm's barriers)
+    // the tile candidates are requested FIRST: they depend on nothing, and their round trip overlaps the residual's
     constexpr int EPL = 8;
     const float* cvs = cand_val + (int64_t)s * ncand;
     const int* cis = cand_idx + (int64_t)s * ncand;
-    const int Qn = (ncand + 3) / 4;  // entries per wave
+    const bool inreg = ncand <= EPL * 256;
     float ev[EPL];
-    int ei[EPL], es[EPL];
-    if (ncand <= EPL * 256) {
+    int ei[EPL];
+    if (inreg) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) {
-            const int t = wave * Qn + lane + kWave * e;
-            const bool ok = (lane + kWave * e) < Qn && t < ncand;
-            ev[e] = ok ? cvs[t] : -1.0f;
-            ei[e] = ok ? cis[t] : 0x7fffffff;
-            es[e] = t & (kTileCand - 1);
+            const int t = tid + 256 * e;
+            ev[e] = t < ncand ? cvs[t] : -1.0f;
+            ei[e] = t < ncand ? cis[t] : 0x7fffffff;
         }
     }
-    // residual in registers (thread t: rows 4(t + 256 i) .. +3), ||r||^2, eps-stop of the last step
+    // residual in registers (thread t: rows 4(t + 256 i) .. +3; rows beyond M are stored zeros), ||r||^2, eps-stop
+    const double* r = r_all + (int64_t)s * Mr;
     double rreg[NI][4];
     double n2 = 0.0;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int row = 4 * (tid + 256 * i);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            rreg[i][e] = (row + e < Mrows) ? r[row + e] : 0.0;
-            n2 = fma(rreg[i][e], rreg[i][e], n2);
+        f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
+        if (row < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + row)[0];
+            hi = reinterpret_cast<const f64x2*>(r + row)[1];
         }
+        rreg[i][0] = lo.x; rreg[i][1] = lo.y; rreg[i][2] = hi.x; rreg[i][3] = hi.y;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) n2 = fma(rreg[i][e], rreg[i][e], n2);
     }
     n2 = block_sum256(n2, sc);
+    const int j = st.nsel;
     if (tid == 0) st.rnorm2 = n2;
     if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
         if (tid == 0) st.done |= STOP_EPS;
@@ -193,156 +202,65 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         if (tid == 0) st.done |= STOP_FULL;
         return;
     }
-
-    for (int t = tid; t < j; t += 256) selL[t] = sel[t];  // (visible after the merge's barriers)
-
-    // ---- merge the tile candidates: the kKeep largest screened |c| (ties: lower atom index).
-    // cert_thr bounds the screened value of every atom NOT in the list: the smallest kept value,
-    // or the last (4th) candidate of a tile whose candidates were all kept (atoms hidden behind it).
-    float cert_thr = -1.0f;
-    if (ncand <= EPL * 256) {
-        // fast path: the list lives in registers (<= 8 entries per lane, loaded at the top).  Each wave extracts the 16 best
-        // of its quarter with wave-only shuffles (no workgroup barriers), then wave 0 merges the 4 x 16.
-        float* wlv = rv;       // [4][16] per-wave lists (rv has 256 floats)
-        int* wli = ri;         // [4][16]
-        int* wls = ri + 64;    // [4][16]
-        for (int q = 0; q < kKeep; ++q) {
-            float bv = -1.0f;
-            int bi = 0x7fffffff, bs = 0;
+    // ---- the largest screened value
+    float m1 = -1.0f;
+    if (inreg) {
 #pragma unroll
-            for (int e = 0; e < EPL; ++e)
-                if (ev[e] >= 0.0f && (ev[e] > bv || (ev[e] == bv && ei[e] < bi))) {
-                    bv = ev[e];
-                    bi = ei[e];
-                    bs = es[e];
-                }
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                const float ov = __shfl_xor(bv, sft, kWave);
-                const int oi = __shfl_xor(bi, sft, kWave);
-                const int os = __shfl_xor(bs, sft, kWave);
-                if (ov > bv || (ov == bv && oi < bi)) {
-                    bv = ov;
-                    bi = oi;
-                    bs = os;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < EPL; ++e)
-                if (ei[e] == bi) ev[e] = -1.0f;  // atoms are unique: exactly one owner retires it
-            if (lane == 0) {
-                wlv[wave * kKeep + q] = bv;
-                wli[wave * kKeep + q] = bi;
-                wls[wave * kKeep + q] = bs;
-            }
-        }
-        __syncthreads();
-        if (wave == 0) {
-            float mv = wlv[lane];
-            int mi = wli[lane];
-            const int ms = wls[lane];
-            float thr = -1.0f;
-            for (int q = 0; q < kKeep; ++q) {
-                float bv = mv;
-                int bi = mi, bs = ms;
-                for (int sft = 32; sft >= 1; sft >>= 1) {
-                    const float ov = __shfl_xor(bv, sft, kWave);
-                    const int oi = __shfl_xor(bi, sft, kWave);
-                    const int os = __shfl_xor(bs, sft, kWave);
-                    if (ov > bv || (ov == bv && oi < bi)) {
-                        bv = ov;
-                        bi = oi;
-                        bs = os;
-                    }
-                }
-                if (mi == bi) mv = -1.0f;
-                if (lane == 0) {
-                    cv[q] = bv;
-                    ci[q] = bi;
-                }
-                if (bv >= 0.0f && (bs == kTileCand - 1 || q == kKeep - 1)) thr = fmaxf(thr, bv);
-            }
-            if (lane == 0) sc[4] = (double)thr;
-        }
-        __syncthreads();
-        cert_thr = (float)sc[4];
+        for (int e = 0; e < EPL; ++e) m1 = fmaxf(m1, ev[e]);
     } else {
-    float thr_v = 3.0e38f;
-    int thr_i = -1;
-    for (int q = 0; q < kKeep; ++q) {
-        float bv = -1.0f;
-        int bi = 0x7fffffff, bslot = 0;
-        for (int t = tid; t < ncand; t += 256) {
-            const float v = cvs[t];
-            const int i = cis[t];
-            const bool below = (v < thr_v) || (v == thr_v && i > thr_i);  // strictly after the previous pick
-            if (below && v >= 0.0f && (v > bv || (v == bv && i < bi))) {
-                bv = v;
-                bi = i;
-                bslot = t & (kTileCand - 1);
-            }
-        }
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            const float ov = __shfl_xor(bv, sft, kWave);
-            const int oi = __shfl_xor(bi, sft, kWave);
-            const int os = __shfl_xor(bslot, sft, kWave);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-                bslot = os;
-            }
-        }
-        __syncthreads();
-        if (lane == 0) {
-            rv[wave] = bv;
-            ri[wave] = bi;
-            ri[4 + wave] = bslot;
-        }
-        __syncthreads();
-        bv = rv[0];
-        bi = ri[0];
-        bslot = ri[4];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) {
-                bv = rv[w];
-                bi = ri[w];
-                bslot = ri[4 + w];
-            }
-        if (tid == 0) {
-            cv[q] = bv;
-            ci[q] = bi;
-        }
-        if (bv >= 0.0f && (bslot == kTileCand - 1 || q == kKeep - 1)) cert_thr = fmaxf(cert_thr, bv);
-        thr_v = bv;
-        thr_i = bi;
+        for (int t = tid; t < ncand; t += 256) m1 = fmaxf(m1, cvs[t]);
     }
-    }
+    for (int sft = 32; sft >= 1; sft >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, sft, kWave));
+    if (lane == 0) fsc[wave] = m1;
     __syncthreads();
-
-    // ---- exact rescoring: <a_c, r> in Float64 -- for the WINDOW only.  The list is sorted by screened value; an atom whose
-    // screened value lies more than 2 delta below the largest one (delta = the screening error bound, cert_coef * ||r||)
-    // cannot be the exact arg-max: its exact value is at most s + delta < s_1 - delta, which the top atom exceeds.  So only the
-    // prefix within 2 delta of s_1 is rescored (one or two atoms as a rule, instead of 16 column reads per signal and step);
-    // everything else -- the rest of the list AND the atoms outside it -- is covered by the certificate below.
-    const double delta = cert_coef * sqrt(n2);
-    int nw = 0;
-#pragma unroll 1
-    for (int q = 0; q < kKeep; ++q) nw += (cv[q] >= 0.0f && (double)cv[q] >= (double)cv[0] - 2.0 * delta) ? 1 : 0;
-    if (nw < kKeep && cv[nw] >= 0.0f) cert_thr = fmaxf(cert_thr, cv[nw]);  // the best screened value that is NOT rescored
+    m1 = fmaxf(fmaxf(fsc[0], fsc[1]), fmaxf(fsc[2], fsc[3]));
+    if (!(m1 >= 0.0f)) {  // no candidate at all (N == 0)
+        if (tid == 0) st.done |= STOP_FULL;
+        return;
+    }
+    // ---- window and certificate bound
+    const double dabs = cert_abs * sqrt(n2);
+    const double lb1 = (double)m1 - dabs - cert_rel * (double)m1;
+    double cb = -1.0;
+    auto visit = [&](float v, int i, int slot) {
+        if (!(v >= 0.0f)) return;
+        const double ub = (double)v + dabs + cert_rel * (double)v;
+        if (ub >= lb1) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < kwin) {
+                wv_[pos] = v;
+                wi_[pos] = i;
+            }
+            if (slot == kTileCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a tile's last candidate
+        } else {
+            cb = fmax(cb, ub);
+        }
+    };
+    if (inreg) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) visit(ev[e], ei[e], (tid + 256 * e) & (kTileCand - 1));
+    } else {
+        for (int t = tid; t < ncand; t += 256) visit(cvs[t], cis[t], t & (kTileCand - 1));
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
+    __syncthreads();  // (fsc and sc are free again; the window list is complete)
+    if (lane == 0) sc[wave] = cb;
+    __syncthreads();
+    cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
+    const int nall = cnt;
+    const int nw = min(nall, kwin);
+    // ---- exact rescoring of the window: <a_c, r> in Float64, DEPTH columns' loads in flight
 #pragma unroll 1
     for (int grp = 0; grp * DEPTH < nw; ++grp) {
         Raw4<TA> av[DEPTH][NI];
 #pragma unroll
         for (int q = 0; q < DEPTH; ++q) {
-            const int c = (grp * DEPTH + q < nw) ? ci[grp * DEPTH + q] : 0x7fffffff;
+            const int c = (grp * DEPTH + q < nw) ? wi_[grp * DEPTH + q] : -1;
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int row = 4 * (tid + 256 * i);
                 av[q][i].zero();
-#ifdef CSMP_EXPERIMENTS
-                if (g_step_ablate & 1) continue;
-#endif
-                if (c >= 0 && c != 0x7fffffff && row < Mv) av[q][i].load(A + (int64_t)c * ld + row, Mv - row);
+                if (c >= 0 && row < Mv) av[q][i].load(A + (int64_t)c * ld + row, Mv - row);
             }
         }
 #pragma unroll
@@ -353,44 +271,86 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc = fma(av[q][i].get(e), rreg[i][e], acc);
             for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
-            if (lane == 0) red[wave * kKeep + grp * DEPTH + q] = acc;
+            if (lane == 0 && grp * DEPTH + q < nw) red[wave * kWinMax + grp * DEPTH + q] = acc;
         }
     }
     __syncthreads();
-    // arg-max by the exact value, first index on ties (Julia argmax)
-    int best = -1;
-    double bestv = -1.0, cexact = 0.0;
+    // arg-max by the exact value, first index on ties (Julia argmax); the window list's order does not matter
     int besti = 0x7fffffff;
+    double bestv = -1.0, cexact = 0.0;
 #pragma unroll 1
     for (int q = 0; q < nw; ++q) {
-        const int c = ci[q];
-        if (c < 0 || c == 0x7fffffff) continue;
-        const double exq = (red[q] + red[kKeep + q]) + (red[2 * kKeep + q] + red[3 * kKeep + q]);
+        const int c = wi_[q];
+        const double exq = (red[q] + red[kWinMax + q]) + (red[2 * kWinMax + q] + red[3 * kWinMax + q]);
         const double v = fabs(exq);
         if (v > bestv || (v == bestv && c < besti)) {
             bestv = v;
             besti = c;
-            best = q;
             cexact = exq;
         }
     }
-    if (best < 0) {  // no candidate at all (N == 0): nothing to do
-        if (tid == 0) st.done |= STOP_FULL;
-        return;
-    }
-    // certificate: every atom that was not rescored -- outside the list, or in it below the window -- has a screened
-    // value <= cert_thr, hence an exact value <= cert_thr + delta (bf16 rounding model); the exact best must
-    // exceed that.  cert_thr < 0 means every existing atom was rescored.
-    if (cert_thr >= 0.0f && !(bestv > (double)cert_thr + delta))
-        if (tid == 0) st.uncertain += 1;
+    const bool certified = nall <= kwin && (cb < 0.0 || bestv > cb);
     // "i not in x.nzind" (:66): a re-selected atom makes every later step the same no-op
+    const int* sel = sel_all + (int64_t)s * kcap;
     int found = 0;
-    for (int t = tid; t < j; t += 256) found |= (selL[t] == besti);
+    for (int t = tid; t < j; t += 256) found |= (sel[t] == besti);
     found = __syncthreads_or(found);
-    if (found) {
-        if (tid == 0) st.done |= STOP_STAG;
-        return;
+    if (tid == 0) {
+        if (!certified) {
+            if (st.uncertain == 0) {
+                st.unc_step = j;
+                st.unc_nall = nall;
+                st.unc_cb = cb;
+                st.unc_best = bestv;
+                st.unc_s1 = (double)m1;
+            }
+            st.uncertain += 1;
+        }
+        if (found) {
+            st.done |= STOP_STAG;
+        } else {
+            pick[s].atom = besti;
+            pick[s].nwin = nw;
+            pick[s].cexact = cexact;
+        }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The append of one OMP step of one signal, by one workgroup.  See the file header for the algebra.
+// LDS: vectors g,w,y (3 x kcap Float64) | reduction scratch | the support | the new atom's column in the dictionary's own
+// type (f32: 16 KiB at M = 4096: four workgroups per CU).
+// DEPTH: columns (pass 2) / row chunks (pass 1) whose loads are issued together.  GRAM: pass 1 is a gather from G = A'A.
+template <typename TA, int NI, int DEPTH, bool GRAM>
+__global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
+    const TA* __restrict__ A, int64_t ld, int Mv, const double* __restrict__ Gm, int64_t Ng, const BPick* __restrict__ pick,
+    double* __restrict__ T_all, double* __restrict__ Tt_all, double* __restrict__ z_all, int* __restrict__ sel_all,
+    BState* __restrict__ bs, double* __restrict__ r_all, int Mr, __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, int sig0) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = sig0 + (int)blockIdx.x;
+    BState& st = bs[s];
+    if (st.done) return;
+    const int besti = pick[s].atom;
+    if (besti < 0) return;
+    const double cexact = pick[s].cexact;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    double* gv = lds;                   // kcap
+    double* wv = gv + kcap;             // kcap
+    double* yv = wv + kcap;             // kcap
+    double* sc = yv + kcap;             // 8
+    double* part = sc + 8;              // 256: partial sums of the T mat-vecs
+    int* selL = reinterpret_cast<int*>(part + 256);  // kcap: the support, staged once (the passes index it per column)
+    TA* aimg = reinterpret_cast<TA*>((reinterpret_cast<uintptr_t>(selL + kcap) + 15) & ~(uintptr_t)15);  // Mlds entries in natural row order: lane l of chunk t reads its
+                                                            // 16 bytes at (t * 64 + l) * 16 -- consecutive lanes, conflict-free
+    double* r = r_all + (int64_t)s * Mr;
+    const int j = st.nsel;
+    int* sel = sel_all + (int64_t)s * kcap;
+    for (int t = tid; t < j; t += 256) selL[t] = sel[t];  // (visible after the barrier inside block_sum256 below)
 
     // ---- a = A[:, besti] -> LDS image (natural row order, the dictionary's own type: exact); ||a||^2.  Nothing of a stays
     // in registers across pass 1 and the T mat-vecs: pass 2 takes it from the image again.
@@ -409,14 +369,19 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     for (int m = 4 * 256 * NI + tid; m < Mlds; m += 256) aimg[m] = (TA)0;
     na2 = block_sum256(na2, sc);  // (barrier inside: aimg is complete afterwards)
 
+    if constexpr (GRAM) {
+        // ---- pass 1 from the resident Gram matrix: g_i = G[s_i, atom], one 8-byte gather per support atom (upper triangle:
+        // row <= column) instead of a 16-KiB column read
+        for (int t = tid; t < j; t += 256) {
+            const int a_ = selL[t];
+            const int lo = min(a_, besti), hi = max(a_, besti);
+            gv[t] = Gm[lo + (int64_t)hi * Ng];
+        }
+    } else {
     // ---- pass 1: g_i = <a_{s_i}, a>, one wave per 4 support columns (the sweep's inner loop)
     {
         const VT* as = reinterpret_cast<const VT*>(aimg);
-#ifdef CSMP_EXPERIMENTS
-        const int jp1 = (g_step_ablate & 2) ? 0 : j;
-#else
         const int jp1 = j;
-#endif
         // Software-pipelined: the wave's work is the flat list of (4-column group, row chunk) items; DEPTH items (4 loads
         // each) are always in flight -- an item's registers are refilled for item q + DEPTH right after item q is consumed,
         // across group boundaries too, so the memory pipe never drains between the groups.
@@ -483,6 +448,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
             }
         }
     }
+    }
     __syncthreads();
 
     // ---- w = T' g (w_i = sum_{t<=i} T[t,i] g_t): thread i walks column i of T (rows of Tt contiguous)
@@ -496,7 +462,6 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     int nI = 16;
     while (nI < j) nI <<= 1;
     const int G = nI <= 256 ? 256 / nI : 1;
-    double* part = reinterpret_cast<double*>(rv);  // 256 Float64 (rv | ri: the arg-max scratch is free by now)
     double w2 = 0.0;
     if (nI <= 256) {
         const int i = tid & (nI - 1), grp = tid / nI;
@@ -622,10 +587,7 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
     // pushed this signal's early columns out of the L2 / Infinity Cache in the meantime -- the late ones are still there.
     // A ring of DEPTH columns: column i - DEPTH is requested into the registers column i has just been consumed from.
     {
-        int jtop = j;
-#ifdef CSMP_EXPERIMENTS
-        if (g_step_ablate & 4) jtop = 0;
-#endif
+        const int jtop = j;
         Raw4<TA> cv4[DEPTH][NI];
         auto issue = [&](Raw4<TA>(&dst)[NI], int i) {
             if (i >= 0) {
@@ -685,48 +647,10 @@ __device__ __forceinline__ void b_step_one(const int s, const TA* __restrict__ A
         st.nsel = j + 1;
     }
 }
-inline size_t b_step_lds_bytes(int Mv, int vec, int kcap) {
+inline size_t b_append_lds_bytes(int Mv, int vec, int kcap) {
     const int rows = kWave * vec;
     const int nchunk = (Mv + rows - 1) / rows;
-    return (size_t)(3 * kcap + 8 + 4 * kKeep) * sizeof(double) + kKeep * 8 + 256 * 8 + (size_t)kcap * 4 + (size_t)nchunk * rows * (16 / vec) + 64;
-}
-
-// Persistent form: workgroup w serves the signals sig0 + w, sig0 + w + gridDim.x, ... of its half-batch.  With one
-// workgroup per CU (grid = number of CUs) and at most 168 registers per lane (NI <= 4), one of these workgroups and one
-// 512-thread screening workgroup of the other half-batch fit a CU together: 3 x 168 registers per SIMD lane, < 160 KiB LDS.
-template <typename TA, int NI, int DEPTH>
-__global__ __launch_bounds__(256, (NI <= 4 ? 2 : 1)) void k_b_step(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
-                                                const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                                                int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
-                                                double* __restrict__ z_all, int* __restrict__ sel_all,
-                                                BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
-                                                __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
-                                                int check_eps, double cert_coef, int sig0, int nsig) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    for (int s = sig0 + (int)blockIdx.x; s < sig0 + nsig; s += (int)gridDim.x) {
-        b_step_one<TA, NI, DEPTH>(s, A, ld, Mv, N, cand_val, cand_idx, ncand, T_all, Tt_all, z_all, sel_all, bs, r_all, Mr, rb_all, Mk,
-                                  kcap, Mrows, eps, check_eps, cert_coef, lds);
-        __syncthreads();  // the LDS scratch is reused by the next signal
-    }
-}
-
-// The same kernel held to 168 registers per lane (three waves per SIMD): the form that shares a CU with a screening
-// workgroup.  Rows beyond 4096 (NI = 8) do not fit that budget and use k_b_step.
-template <typename TA, int NI, int DEPTH>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
-void k_b_step_co(const TA* __restrict__ A, int64_t ld, int Mv, int64_t N,
-                 const float* __restrict__ cand_val, const int* __restrict__ cand_idx,
-                 int ncand, double* __restrict__ T_all, double* __restrict__ Tt_all,
-                 double* __restrict__ z_all, int* __restrict__ sel_all,
-                 BState* __restrict__ bs, double* __restrict__ r_all, int Mr,
-                 __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, double eps,
-                 int check_eps, double cert_coef, int sig0, int nsig) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    for (int s = sig0 + (int)blockIdx.x; s < sig0 + nsig; s += (int)gridDim.x) {
-        b_step_one<TA, NI, DEPTH>(s, A, ld, Mv, N, cand_val, cand_idx, ncand, T_all, Tt_all, z_all, sel_all, bs, r_all, Mr, rb_all, Mk,
-                                  kcap, Mrows, eps, check_eps, cert_coef, lds);
-        __syncthreads();
-    }
+    return (size_t)(3 * kcap + 8 + 256) * sizeof(double) + (size_t)kcap * 4 + (size_t)nchunk * rows * (16 / vec) + 64;
 }
 
 // x = T z (ldiv!), sorted-index assembly; one workgroup per signal

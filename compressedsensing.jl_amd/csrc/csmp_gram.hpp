@@ -227,7 +227,7 @@ constexpr int kCholThreads = 320;   // + the wave of the diagonal block
 
 template <bool UPD>
 __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
-                                              DevState* st, int wg) {
+                                              DevState* st, int wg, double* __restrict__ Dfac) {
     constexpr int NB = kCholNB;
     __shared__ __attribute__((aligned(16))) double U[NB * NB];  // U[t * NB + q]: row t of the factored diagonal block
     __shared__ double rinv[NB];
@@ -373,10 +373,15 @@ __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, in
 #pragma unroll
             for (int t = 0; t < NB; ++t) rinv[t] = ri[t];
         }
-        if (wg == 0 && tid < NB) {  // the factored diagonal block, in place
+        // The factored diagonal block goes to a SIDE buffer (block kb: Dfac[kb * NB * NB + row + NB * column]), not back into
+        // G: every row workgroup of this launch reads the unfactored block from G at its entry and factorises it for itself, and
+        // nothing orders workgroup 0's store against a late workgroup's load (a GPU shared with another stream or process
+        // starts them far apart) -- the input stays read-only for the whole launch.  k_gram_export reads the diagonal blocks here.
+        if (wg == 0 && tid < NB) {
+            double* dcol = Dfac + (int64_t)kb * NB * NB + (int64_t)q * NB;
 #pragma unroll
             for (int t = 0; t < NB; ++t)
-                if (t <= q) gcol[t] = x[t];
+                if (t <= q) dcol[t] = x[t];
         }
     }
     __syncthreads();
@@ -395,8 +400,8 @@ __device__ __forceinline__ void chol_row_body(double* __restrict__ G, int np, in
 
 // The first block row (nothing to apply before it).
 __global__ __launch_bounds__(kCholThreads) void k_chol_row(double* __restrict__ G, int np, int n, int kb, const double* __restrict__ gdiag,
-                                                           DevState* st) {
-    chol_row_body<false>(G, np, n, kb, gdiag, st, (int)blockIdx.x);
+                                                           DevState* st, double* __restrict__ Dfac) {
+    chol_row_body<false>(G, np, n, kb, gdiag, st, (int)blockIdx.x, Dfac);
 }
 
 // The trailing update of step kb: G[i][j] -= sum_p X[p][i] X[p][j] over the NB rows X = G[c0 .. c0+NB-1, :] just finished, for
@@ -451,9 +456,10 @@ __device__ __forceinline__ void chol_trail_body(double* __restrict__ G, int np, 
 // panel kb to their own 32 x 256 part of it, factorise its diagonal block, solve.  Workgroups [nrow, ..) apply panel kb to the
 // rest of the trailing matrix meanwhile.  The two groups touch disjoint rows; panel kb itself is only read.
 __global__ __launch_bounds__(kCholThreads) void k_chol_step(double* __restrict__ G, int np, int n, int kb,
-                                                            const double* __restrict__ gdiag, DevState* st, int nrow) {
+                                                            const double* __restrict__ gdiag, DevState* st, int nrow,
+                                                            double* __restrict__ Dfac) {
     if ((int)blockIdx.x < nrow) {
-        chol_row_body<true>(G, np, n, kb + 1, gdiag, st, (int)blockIdx.x);
+        chol_row_body<true>(G, np, n, kb + 1, gdiag, st, (int)blockIdx.x, Dfac);
     } else {
         if (threadIdx.x >= 256) return;
         chol_trail_body(G, np, kb, (int)blockIdx.x - nrow, true);
@@ -464,15 +470,20 @@ __global__ __launch_bounds__(kCholThreads) void k_chol_step(double* __restrict__
 // exported when the DGKS test failed anywhere (the host sees STOP_REORTH and falls back).
 __global__ __launch_bounds__(256) void k_gram_export(const double* __restrict__ G, int np, int n, const int* __restrict__ cols,
                                                      double* __restrict__ R, int kcap, double* __restrict__ z,
-                                                     int* __restrict__ sel, DevState* st) {
+                                                     int* __restrict__ sel, DevState* st, const double* __restrict__ Dfac) {
     if (st->done & STOP_REORTH) return;
+    constexpr int NB = kCholNB;
+    // entry (row, col) of the factor: the diagonal blocks live in the side buffer (chol_row_body), the row panels in G
+    auto fac = [&](int row, int col) {
+        return (row / NB == col / NB) ? Dfac[(int64_t)(row / NB) * NB * NB + (row % NB) + (int64_t)(col % NB) * NB] : G[row + (int64_t)col * np];
+    };
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < (int64_t)n * n) {
         const int row = (int)(e % n), col = (int)(e / n);
-        if (row <= col) R[row + (int64_t)col * kcap] = G[row + (int64_t)col * np];
+        if (row <= col) R[row + (int64_t)col * kcap] = fac(row, col);
     }
     if (e < n) {
-        z[e] = G[e + (int64_t)n * np];
+        z[e] = fac((int)e, n);
         sel[e] = cols[e];
     }
     if (e == 0) {

@@ -74,7 +74,9 @@ int csmp_set_dictionary(csmp_ctx *ctx, const void *A, int64_t M, int64_t N, int6
 /* A second context on the same GPU that borrows (does not copy) src's resident dictionary: the reference's P
  * objects are independent of one another and share only A -- P1 = OMP(A, b1); P2 = OMP(A, b2)
  * (src/matchingpursuit.jl:44-60) -- so every step-level solver (csmp_solver_begin) that must live beside
- * another one gets a clone.  src must outlive the clone and keep its dictionary. */
+ * another one gets a clone.  A dictionary the library copied (host pointer, or an unaligned device pointer) is reference
+ * counted: it lives until the last context holding it is destroyed or given another dictionary, whatever the order.  A
+ * BORROWED device pointer (zero-copy, see csmp_set_dictionary) stays the caller's to keep alive. */
 int csmp_clone(csmp_ctx *src, csmp_ctx **out);
 
 /* ------------------------------------------------------------------ drivers (synchronous)
@@ -168,14 +170,11 @@ int csmp_fr_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
 
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
  * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
- * SCREENS 16 candidates per signal; those are rescored in Float64 from the f32/f64 master
- * dictionary, and a certificate (exact best > best screened value outside the list + an error bound)
- * guards every step: a signal that fails it once is re-solved by the exact path before returning, so a
- * certified result equals csmp_omp_batch's.  The DEFAULT error bound is statistical -- 8 standard deviations
- * of independent bf16 roundings -- which holds for generic (e.g. Gaussian) dictionaries but is not a proof for
- * structured ones whose rounding errors add coherently; the environment variable CSMP_CERT=rigorous selects
- * the deterministic bound (2^-7 + M 2^-24) max|a_j| |r| instead (about 8x wider: more signals take the exact
- * path, none can slip through).  Requires M <= 8192.  With out_loc == CSMP_DEVICE this call still
+ * SCREENS: per signal the candidates whose screened value could still be the exact maximum are rescored in
+ * Float64 from the f32/f64 master dictionary, and a certificate (exact best > an upper bound on the exact value of
+ * every atom that was not rescored) guards every step: a signal that fails it once is re-solved by the exact path
+ * before returning, so a certified result equals csmp_omp_batch's.  The error bound behind the certificate is
+ * chosen by CSMP_OPT_BATCH_CERT (below).  Requires M <= 8192.  With out_loc == CSMP_DEVICE this call still
  * synchronises once (to read the per-signal certificates). */
 int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                         double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
@@ -183,12 +182,36 @@ int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, 
  * why), and -- when profiling is enabled -- the number and total duration (ms) of screening GEMMs */
 int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly, int64_t *uncertain, int64_t *illcond,
                      int64_t *screen_launches, double *screen_ms);
-/* layout of the last csmp_omp_batch_mfma call (measurement only): signal columns of one timed screening launch
- * (the batch is split into two half-batches on two HIP streams, so that the screening GEMM of one half runs
- * beside the rescoring/append kernel of the other) and the number of streams used */
+/* layout of the last csmp_omp_batch_mfma call (measurement only): signal columns of one screening launch (the batch
+ * padded to whole 256-signal tiles) and the number of streams used (1: the screening GEMM and the per-signal
+ * kernels alternate on the context's stream) */
 int csmp_batch_layout(const csmp_ctx *ctx, int64_t *screen_signals, int *streams);
 /* name of the screening kernel the last csmp_omp_batch_mfma call ran (measurement only) */
 const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
+
+/* ------------------------------------------------------------------ options
+ * The reference passes every behavioural choice as an argument (src/matchingpursuit.jl:88-91,145-148;
+ * src/twostage.jl:87); those are arguments here too.  The choices that exist only on this side of the boundary are
+ * per-context options ("Config / flags").  The library reads NO environment variable.  A clone
+ * (csmp_clone) starts from its parent's values.  Unknown keys and out-of-range values: CSMP_EINVAL. */
+#define CSMP_OPT_BATCH_CERT 1      /* certificate of csmp_omp_batch_mfma.  0 (default): statistical -- 8 standard deviations of
+                                      independent bf16 roundings + the fully coherent case (an operand whose entries all round
+                                      the same way: 2^-7 of the screened value); holds for generic dictionaries, not a proof.
+                                      1: rigorous -- (2^-7 (1 + 2^-9) + M 2^-24) max|a_j| |r|, about nine times wider on a Gaussian
+                                      dictionary: more candidates are rescored per step, more signals
+                                      take the exact path, none can slip through */
+#define CSMP_OPT_BATCH_GRAM 2      /* 1: csmp_omp_batch_mfma keeps G = A'A resident (Float64, 8 N^2 bytes: 32 GiB at N = 65536;
+                                      built on first use, 2 M N^2 / 2 flops on the Float64 matrix cores) and takes A_S'a from it
+                                      instead of streaming the support's columns: half the append traffic.  0 (default) frees it */
+#define CSMP_OPT_BATCH_WINDOW 3    /* capacity of the rescoring window, 1..128; 0 (default) = 64 statistical / 128 rigorous */
+#define CSMP_OPT_PIPELINE 4        /* csmp_omp_batch / csmp_fr_batch: 1 (default) three signals in flight, 0 one at a time */
+#define CSMP_OPT_FORCE_REORTH 5    /* test switch: 1 = every append runs the second Gram-Schmidt pass (k_qr3) */
+#define CSMP_OPT_LS_GRAM 6         /* whole-set least squares (sp, lstsq): 1 (default) Gram matrix + blocked Cholesky, 0 panel appends */
+#define CSMP_OPT_LS_GRAM_REUSE 7   /* 1 (default): a set inside the last factorised one gathers its Gram matrix from the kept copy */
+#define CSMP_OPT_TWOSTAGE_UPDATE 8 /* ompr's exchange step: 0 (default) explicit inverse T = R^-1 beside R, 1 Givens down-date of R,
+                                      2 refactorise from scratch (the reference's own cost model, src/twostage.jl:171-174) */
+int csmp_set_option(csmp_ctx *ctx, int key, int64_t value);
+int csmp_get_option(csmp_ctx *ctx, int key, int64_t *value);
 
 /* ------------------------------------------------------------------ step-level API
  * Mirrors the Update functors: P = OMP(A,b,k) / MP(A,b) / GOMP(A,b,l) / FR(A,b) then update!(P,x)

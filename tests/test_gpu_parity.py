@@ -96,12 +96,13 @@ def test_omp_matches_oracle(cs, oracle, D, shape, dtype):
         assert np.array_equal(xv.nzind, ref[0]) and close(xv.nzval, ref[1])
 
 
-def test_omp_forced_reorthogonalisation_path(cs, oracle, monkeypatch):
-    """k_qr3 (second Gram-Schmidt pass) normally runs only when the DGKS test fails; force it."""
-    monkeypatch.setenv("CSMP_FORCE_REORTH", "1")
+def test_omp_forced_reorthogonalisation_path(cs, oracle):
+    """k_qr3 (second Gram-Schmidt pass) normally runs only when the DGKS test fails; force it (CSMP_OPT_FORCE_REORTH)."""
     A, x, b = cs.sparse_data(n=130, m=700, k=20, rng=77, dtype=np.float32)
     y = cs.perturb(b, 5e-3, rng=78)
     d = cs.Dictionary(A)
+    d.ctx.set_option("force_reorth", 1)
+    assert d.ctx.get_option("force_reorth") == 1
     ref = oracle.omp(A, y, 20, EPS32)
     got = d.ctx.omp(y, 20, EPS32)
     d.close()
@@ -201,7 +202,7 @@ def test_sp_matches_oracle(cs, oracle, D, shape, dtype):
         d.ctx.sp(y, n // 2 + 1, 1e-12)  # CSMP_ERANGE from the ABI itself
 
 
-def test_sp_whole_set_path_and_gram_reuse(cs, oracle, D, monkeypatch):
+def test_sp_whole_set_path_and_gram_reuse(cs, oracle, D):
     """Supports of >= 64 atoms go through the whole-set least squares (Gram + blocked Cholesky, csrc/csmp_gram.hpp), and the second
     solve of an SP iteration (the k atoms kept out of the 2k) gathers its Gram matrix from the first one's.  Noisy data, several
     iterations: against the oracle, against the same library with the reuse switched off, and with the whole path switched off."""
@@ -215,14 +216,14 @@ def test_sp_whole_set_path_and_gram_reuse(cs, oracle, D, monkeypatch):
         got = d.ctx.sp(y, k, 1e-12)
         assert got[2] == ref[2], "number of update! calls"
         assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
-        monkeypatch.setenv("CSMP_NO_GRAM_REUSE", "1")
+        d.ctx.set_option("ls_gram_reuse", 0)
         plain = d.ctx.sp(y, k, 1e-12)
-        monkeypatch.delenv("CSMP_NO_GRAM_REUSE")
+        d.ctx.set_option("ls_gram_reuse", 1)
         assert np.array_equal(got[0], plain[0]) and got[2] == plain[2]
         np.testing.assert_allclose(got[1], plain[1], rtol=1e-11, atol=1e-13)
-        monkeypatch.setenv("CSMP_NO_GRAM", "1")
+        d.ctx.set_option("ls_gram", 0)
         chain = d.ctx.sp(y, k, 1e-12)
-        monkeypatch.delenv("CSMP_NO_GRAM")
+        d.ctx.set_option("ls_gram", 1)
         assert np.array_equal(got[0], chain[0]) and got[2] == chain[2]
         np.testing.assert_allclose(got[1], chain[1], rtol=1e-9, atol=1e-12)
 

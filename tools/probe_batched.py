@@ -1,6 +1,6 @@
-"""C3 (1024 signals sharing A 4096 x 65536 f32, k = 128) through csmp_omp_batch_mfma under a list of environment
-settings (one process; the library reads its knobs per call): atoms/s, the screening launch average, and whether every
-setting returns the same supports.  usage: python tools/probe_batched.py [name=VAR:val,VAR:val ...]"""
+"""C3 (1024 signals sharing A 4096 x 65536 f32, k = 128) through csmp_omp_batch_mfma under a list of option settings
+(csmp_set_option, one process): atoms/s, the screening launch average, the batch statistics, and whether every setting
+returns the same supports.  usage: python tools/probe_batched.py [only=a,b] [name=option:val,option:val ...]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,8 +14,7 @@ D = cs.Dictionary(At, device=0)
 nsig, k = 1024, 128
 B = bench.make_signals_fast(torch, dev, At, 0, 2 * nsig, k).reshape(2, nsig, bench.M)
 torch.cuda.synchronize()
-configs = [("one-stream", {}), ("two-stream", {"CSMP_BATCH_STREAMS": "2"}), ("two-stream-co", {"CSMP_BATCH_STREAMS": "2", "CSMP_BATCH_CO": "1"}),
-           ("one-stream-128", {"CSMP_SCREEN_128": "1"}), ("two-stream-128", {"CSMP_SCREEN_128": "1", "CSMP_BATCH_STREAMS": "2"})]
+configs = [("default", {}), ("rigorous", {"batch_cert": "1"}), ("gram", {"batch_gram": "1"}), ("gram-rigorous", {"batch_gram": "1", "batch_cert": "1"})]
 only = None
 for a in sys.argv[1:]:
     if a.startswith("only="):
@@ -27,8 +26,8 @@ if only:
     configs = [c for c in configs if c[0] in only]
 ref = None
 for name, env in configs:
-    for kk, vv in env.items():
-        os.environ[kk] = vv
+    for kk in ("batch_cert", "batch_gram", "batch_window"):
+        D.ctx.set_option(kk, int(env.get(kk, 0)))
     idx = torch.full((2, nsig, k), -1, dtype=torch.int64, device=dev)
     val = torch.zeros((2, nsig, k), dtype=torch.float64, device=dev)
     nnz = torch.zeros((2, nsig), dtype=torch.int64, device=dev)
@@ -53,7 +52,6 @@ for name, env in configs:
     scr_us = st["screen_ms"] / max(st["screen_launches"], 1) * 1e3
     print(json.dumps({"config": name, "env": env, "ms_per_batch": dt * 1e3, "atoms_per_s": nsig * k / dt, "ms_per_omp_step": dt / k * 1e3,
                       "screen_us": scr_us, "screen_tflops": 2.0 * bench.M * bench.N * lay["screen_signals"] / (scr_us * 1e-6) / 1e12 if scr_us else None,
-                      "layout": lay, "resolved": st["resolved_exactly"], "same_supports_as_first": same}), flush=True)
-    for kk in env:
-        os.environ.pop(kk, None)
+                      "layout": lay, "resolved": st["resolved_exactly"], "uncertain": st["uncertain"], "illcond": st["illcond"],
+                      "same_supports_as_first": same}), flush=True)
 D.close()

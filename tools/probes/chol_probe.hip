@@ -47,11 +47,12 @@ int main(int argc, char** argv) {
             ref[p + (size_t)c * np] = s / d;
         }
     }
-    double *dG, *dG0, *dgd;
+    double *dG, *dG0, *dgd, *dfac;
     DevState* st;
     CK(hipMalloc(&dG, G.size() * 8));
     CK(hipMalloc(&dG0, G.size() * 8));
     CK(hipMalloc(&dgd, np * 8));
+    CK(hipMalloc(&dfac, (size_t)np * kCholNB * 8));  // the factored diagonal blocks (side buffer of chol_row_body)
     CK(hipMalloc(&st, sizeof(DevState)));
     CK(hipMemset(st, 0, sizeof(DevState)));
     CK(hipMemcpy(dG0, G.data(), G.size() * 8, hipMemcpyHostToDevice));
@@ -65,14 +66,14 @@ int main(int argc, char** argv) {
     auto chain = [&]() {
         const int left0 = np - kCholNB;
         hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, s, dG, np, n, 0,
-                           (const double*)dgd, st);
+                           (const double*)dgd, st, dfac);
         for (int kb = 0; kb + 1 < nsteps; ++kb) {
             const int left = np - (kb + 1) * kCholNB, left2 = left - kCholNB;
             const int Tt = (left + kGramTile - 1) / kGramTile;
             const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
             const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
             hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, s, dG, np, n, kb, (const double*)dgd, st,
-                               nrow);
+                               nrow, dfac);
         }
     };
     float best = 1e30f;
@@ -89,6 +90,11 @@ int main(int argc, char** argv) {
     CK(hipGetLastError());
     std::vector<double> out(G.size());
     CK(hipMemcpy(out.data(), dG, G.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> fac((size_t)np * kCholNB);
+    CK(hipMemcpy(fac.data(), dfac, fac.size() * 8, hipMemcpyDeviceToHost));
+    for (int j = 0; j < nn; ++j)  // diagonal blocks: from the side buffer
+        for (int i = (j / kCholNB) * kCholNB; i <= j; ++i)
+            out[i + (size_t)j * np] = fac[(size_t)(j / kCholNB) * kCholNB * kCholNB + (i % kCholNB) + (size_t)(j % kCholNB) * kCholNB];
     DevState hs;
     CK(hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost));
     double err = 0.0;
