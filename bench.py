@@ -60,8 +60,9 @@ def exchange_results(idx, val, nnz, group=None):
 
 
 def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
-    """AverageNs of the newest committed rocprofv3 --kernel-trace --stats row whose kernel name contains
-    `kernel_substr` (profiles/, named per round): lets the line state the profiler's figure beside the HIP-event one."""
+    """AverageNs of the newest COMMITTED rocprofv3 --kernel-trace --stats row whose kernel name contains `kernel_substr`
+    (profiles/, named per round).  It was measured on the build that was profiled, not in this process: the line carries it as
+    `committed_profile` with its file name and no derived fraction; every fraction in the line comes from this run's own timers."""
     import csv
     import glob
     best = None
@@ -70,7 +71,8 @@ def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
             for row in csv.DictReader(open(f)):
                 if kernel_substr in row.get("Name", ""):
                     best = {"file": os.path.relpath(f, ROOT), "kernel": row["Name"].split("(")[0], "calls": int(row["Calls"]),
-                            "avg_launch_us": float(row["AverageNs"]) / 1e3}
+                            "avg_launch_us": float(row["AverageNs"]) / 1e3,
+                            "note": "historical: rocprofv3 --kernel-trace --stats of the same command on the build that file was taken from"}
         except Exception:  # noqa: BLE001
             pass
     return best
@@ -81,7 +83,9 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=18)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr", "ompr", "srr"], default="omp",
+    p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="statistical", help="--workload batched: CSMP_OPT_BATCH_CERT")
+    p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
+    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -178,26 +182,35 @@ def make_signals_fast(torch, dev, At, first_id, count, k):
 MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparse figure is not used)
 
 
-def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
+def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=0, gram=0, nsig=1024, k=128):
     """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128.
-    A step = one batch of 1024 complete solves.  Returns the result dict on rank 0, None elsewhere."""
-    nsig, k = 1024, 128
+    A step = one batch of 1024 complete solves.  cert / gram: the options CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM of the
+    contexts (include/csmp.h).  Returns the result dict on rank 0, None elsewhere."""
     eps = D.eps
+    dsync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)  # (the gloo CPU test drives this function too)
+    D.ctx.set_option("batch_cert", cert)
+    t_setup = time.perf_counter()
+    D.ctx.set_option("batch_gram", gram)
     B = make_signals_fast(torch, dev, At, rank * (K + W), (K + W) * nsig, k).reshape(K + W, nsig, M)
     idx = torch.full((K + W, nsig, k), -1, dtype=torch.int64, device=dev)
     val = torch.zeros((K + W, nsig, k), dtype=torch.float64, device=dev)
     nnz = torch.zeros((K + W, nsig), dtype=torch.int64, device=dev)
-    torch.cuda.synchronize()
+    dsync()
+    gram_seconds = None
+    if gram:  # the resident Gram matrix is built by the first call that needs it: once per dictionary, like the bf16 image
+        D.ctx.omp_batch_mfma_device(B[0][:256].contiguous(), 1, eps, idx[0][:256, :1].contiguous(), val[0][:256, :1].contiguous(), nnz[0][:256].contiguous())
+        D.ctx.sync()
+        gram_seconds = time.perf_counter() - t_setup
     for w in range(W):
         D.ctx.omp_batch_mfma_device(B[w], k, eps, idx[w], val[w], nnz[w])
     D.ctx.sync()
     D.ctx.profile_enable(True)
     D.ctx.batch_stats()
-    torch.cuda.synchronize()
+    dsync()
     if use_dist:  # warm the collective at the size and through the packing kernels of the timed one
         exchange_results(idx[W:].reshape(-1, k), val[W:].reshape(-1, k), nnz[W:].reshape(-1))
         dist.barrier()
-        torch.cuda.synchronize()
+        dsync()
     t0 = time.perf_counter()
     resolved = uncertain = illcond = 0
     screen_n, screen_ms = 0, 0.0
@@ -212,10 +225,10 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
     D.ctx.sync()
     if use_dist:  # one gather of every rank's packed results
         exchange_results(idx[W:].reshape(-1, k), val[W:].reshape(-1, k), nnz[W:].reshape(-1))
-    torch.cuda.synchronize()
+    dsync()
     if use_dist:
         dist.barrier()
-        torch.cuda.synchronize()
+        dsync()
     dt = time.perf_counter() - t0
     D.ctx.profile_enable(False)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -227,7 +240,7 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
     if rank != 0:
         return None
     flops = 2.0 * M * N * nsig  # per OMP step of the batch
-    lay = D.ctx.batch_layout()  # the batch runs as two half-batches on two streams: a timed screening launch covers one half
+    lay = D.ctx.batch_layout()  # signal columns of one screening launch (the whole batch, padded to 256-signal tiles)
     flops_launch = 2.0 * M * N * lay["screen_signals"]
     tf = flops_launch / (screen_ms / max(screen_n, 1) / 1e3) / 1e12 if screen_n else 0.0
     ms_per_omp_step = tmax / K / k * 1e3
@@ -238,6 +251,8 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
     D.ctx.omp_batch_device(B[W][:4].contiguous(), k, eps, i2, v2, n2)
     D.ctx.sync()
     same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
+    D.ctx.set_option("batch_cert", 0)
+    D.ctx.set_option("batch_gram", 0)  # (releases the 8 N^2 bytes)
     return {
         "metric": "batched OMP atoms selected/sec, 1024 signals per GPU sharing A 4096x65536, k=128 (bf16 MFMA screen + f64 rescoring)",
         "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -254,13 +269,38 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist):
                      "whole_step": {"ms_per_omp_step": ms_per_omp_step, "achieved": flops / (ms_per_omp_step / 1e3) / 1e12,
                                     "frac": flops / (ms_per_omp_step / 1e3) / 1e12 / MFMA_PEAK_TF}},
         "batch_stats": {"resolved_by_exact_path": int(resolved), "uncertain": int(uncertain), "illcond": int(illcond)},
+        "options": {"certificate": "rigorous" if cert else "statistical", "resident_gram": bool(gram),
+                    "gram_setup_seconds": gram_seconds,
+                    "gram_bytes": (8 * N * N) if gram else 0},
         "matches_exact_path_on_sample": same,
     }
 
 
-def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None):
+def measure_lone_omp(K, W, B, D, eps):
+    """configs[1] as the reference's API shapes it: one csmp_omp call at a time (sweep -> k_qr1 -> k_qr2 per atom, nothing of
+    another signal underneath), b handed over as a host vector, results returned to the host."""
+    sigs = [B[s].cpu().numpy() for s in range(W + K)]
+    for w in range(W):
+        D.ctx.omp(sigs[w], K_ATOMS, eps)
+    t0 = time.perf_counter()
+    atoms = 0
+    for s in range(W, W + K):
+        i, v, o = D.ctx.omp(sigs[s], K_ATOMS, eps)
+        atoms += len(i)
+    dt = time.perf_counter() - t0
+    us_atom = dt / max(atoms, 1) * 1e6
+    return {"metric": "OMP atoms selected/sec at m=4096,n=65536,k=256, one omp(A,b,k) call at a time (no pipelining across signals)",
+            "value": atoms / dt, "unit": "atoms/s", "steps": K, "warmup": W, "ms_per_solve": dt / K * 1e3, "us_per_atom": us_atom,
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": M * N * 4 / (us_atom * 1e-6) / 1e9,
+                         "frac": M * N * 4 / (us_atom * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                         "note": "ALL-IN: algorithmic bytes per atom / wall time per atom of the whole call (upload of b, sweep, both append "
+                                 "stages, kernel boundaries, back substitution, download) -- not a kernel duration"}}
+
+
+def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-2):
     """configs[4]: GOMP (S = 4 atoms per step) or Subspace Pursuit on A 8192 x 131072 Float32, k = 512.
-    A step = one complete solve."""
+    A step = one complete solve.  delta: sp's residual tolerance (the reference's default is 1e-12, src/twostage.jl:87: with
+    noisy data it keeps iterating until the residual stops decreasing; 1e-2 stops after the first update!)."""
     M5, N5, k, S = 8192, 131072, 512, 4
     own = D5 is None
     if own:
@@ -279,7 +319,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None):
         if workload == "gomp":
             i, v, o = D5.ctx.gomp(b, S, k, eps)
             return len(i), 0
-        i, v, it = D5.ctx.sp(b, k, 1e-2)
+        i, v, it = D5.ctx.sp(b, k, delta)
         return len(i), it
     for w in range(W):
         solve(sigs[w])
@@ -300,8 +340,8 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None):
            "value": (atoms / dt) if workload == "gomp" else K / dt, "unit": "atoms/s" if workload == "gomp" else "solves/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
-           "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if workload == "gomp" else ", delta=1e-2"),
-                      "sweeps": int(sweeps), "sp_update_calls": int(iters)},
+           "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if workload == "gomp" else f", delta={delta:g}"),
+                      "sweeps": int(sweeps), "sp_update_calls": int(iters), "sp_update_calls_per_solve": iters / K if workload == "sp" else None},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
@@ -415,6 +455,99 @@ def run_fr(args, cs, torch, dev, At, D, emit=True):
     return out
 
 
+def colsharded_solves(K, W, sigs, k, eps, rank, world, group, make_shard, barrier, all_supports):
+    """The measured part of the column-sharded workload, free of GPU specifics (the gloo CPU test drives it with numpy
+    shards): W + K solves of omp_colsharded, the K timed ones between two barriers; then every rank's support of the first
+    timed signal is compared (all ranks run the same replicated append chain: they must agree bit for bit).
+    make_shard() -> this rank's shard object; all_supports(idx) -> list of every rank's idx array."""
+    from csmp_pkg import load
+    cs = load()
+    shard = make_shard()
+    first = None
+    for w in range(W):
+        cs.omp_colsharded(shard, sigs[w], k, eps, group=group)
+    barrier()
+    t0 = time.perf_counter()
+    atoms = 0
+    for s_ in range(W, W + K):
+        idx, val, order = cs.omp_colsharded(shard, sigs[s_], k, eps, group=group)
+        atoms += len(idx)
+        if first is None:
+            first = (idx, val, order)
+    barrier()
+    dt = time.perf_counter() - t0
+    import numpy as np
+    pad = -np.ones(k, np.int64)
+    pad[:len(first[0])] = first[0]
+    sup = all_supports(pad)
+    agree = all(np.array_equal(sup[0], x) for x in sup)
+    return {"seconds": dt, "atoms": atoms, "first": first, "ranks_agree_on_first_support": bool(agree), "supports_gathered": len(sup)}
+
+
+def run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen, devices):
+    """SURVEY 8(f)4 / 8(e) "natural": ONE signal at a time, the dictionary's COLUMNS sharded over the ranks -- the only way
+    several GPUs speed up a single omp(A, b, k) (src/matchingpursuit.jl:73-82).  Every rank holds N / world columns and a
+    replica of the solver state; one all_gather of one 16-KiB record per rank and step (sharded.omp_colsharded)."""
+    import numpy as np
+    K, W = (args.steps, args.warmup) if (args.steps, args.warmup) != (18, 3) else (3, 1)
+    At = make_dictionary(torch, dev)
+    B = make_signals(torch, dev, At, 0, K + W)  # the SAME signals on every rank
+    sigs = [B[s].cpu().numpy() for s in range(K + W)]
+    lo, hi = cs.column_range(N, rank, world)
+    Aloc = At[lo:hi].contiguous() if world > 1 else At
+    D = cs.Dictionary(Aloc, device=dev.index)
+    eps = D.eps
+    ref = None
+    if world == 1:  # the whole dictionary is here: the unsharded call is the comparison
+        ref = D.ctx.omp(sigs[W], K_ATOMS, eps)
+    del At
+    group = None
+
+    def barrier():
+        D.ctx.sync()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def all_supports(idx):
+        if not use_dist:
+            return [idx]
+        t = torch.from_numpy(idx).to(dev)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.cpu().numpy() for o in out]
+
+    res = colsharded_solves(K, W, sigs, K_ATOMS, eps, rank, world, group, lambda: cs.HipColumnShard(D.ctx, lo, dev), barrier, all_supports)
+    tmax = torch.tensor([res["seconds"]], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = tmax.item()
+    out = None
+    if rank == 0:
+        us_atom = tmax / max(res["atoms"], 1) * 1e6
+        alg = M * N * 4
+        out = {"metric": "column-sharded OMP atoms selected/sec at m=4096,n=65536,k=256 (ONE signal, columns over the GPUs)",
+               "value": res["atoms"] / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": tmax / K * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)",
+               "data": "synthetic", "us_per_atom": us_atom,
+               "config": {"workload": "SURVEY 8(f)4: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, k=256, columns sharded",
+                          "columns_per_gpu": int(hi - lo), "collective": "one all_gather_into_tensor of one record (32 B + M*4 B) per rank and step",
+                          "sharding": f"columns over {world} GPU(s), solver state replicated"},
+               "ranks_seen": ranks_seen, "devices": devices,
+               "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS * world, "achieved": alg / (us_atom * 1e-6) / 1e9,
+                            "frac": alg / (us_atom * 1e-6) / 1e9 / (HBM_PEAK_GBS * world), "traffic": None,
+                            "note": "ALL-IN per atom (sweep of N/world columns + record exchange + replicated append) against the sum of the ranks' HBM peaks"},
+               "ranks_agree_on_first_support": res["ranks_agree_on_first_support"], "supports_gathered": res["supports_gathered"]}
+        if ref is not None:
+            out["equals_unsharded_omp"] = bool(np.array_equal(ref[0], res["first"][0]) and np.array_equal(ref[2], res["first"][2]))
+        if not res["ranks_agree_on_first_support"] or res["supports_gathered"] != world:
+            out["error"] = "ranks disagree on the support of the first timed signal"
+        print(json.dumps(out), flush=True)
+    D.close()
+    return out
+
+
 def rank_census(torch, dist, dev, use_dist, world):
     """ranks_seen = the process group's own world size; devices = every rank's GPU as IT names it, gathered."""
     name = torch.cuda.get_device_name(dev) + f" (cuda:{dev.index})"
@@ -441,6 +574,10 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if local >= torch.cuda.device_count():  # (device_count() does not initialise the GPU)
+        print(f"bench.py: rank {rank} wants GPU {local} but this node shows {torch.cuda.device_count()} GPU(s): one process per GPU, "
+              f"--gpus must not exceed the visible devices", file=sys.stderr, flush=True)
+        sys.exit(2)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
@@ -453,6 +590,12 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
 
+    if args.workload == "colsharded":
+        out = run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen, devices)
+        finish()
+        if rank == 0 and out and "error" in out:
+            sys.exit(3)
+        return
     if args.workload in ("gomp", "sp"):
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
@@ -471,7 +614,8 @@ def main():
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
-        out = measure_batched(args.steps, args.warmup, cs, torch, dist, dev, rank, world, At, D, use_dist)
+        out = measure_batched(args.steps, args.warmup, cs, torch, dist, dev, rank, world, At, D, use_dist,
+                              cert=1 if args.batch_cert == "rigorous" else 0, gram=1 if args.batch_gram else 0)
         if rank == 0:
             out["ranks_seen"], out["devices"] = ranks_seen, devices
             print(json.dumps(out), flush=True)
@@ -532,9 +676,8 @@ def main():
                 "launches_timed": int(sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
                 "timer": "HIP events on the library's stream around every %d-th steady-state tick of the timed region" % args.profile_every}
         rp = rocprof_row("k_tick<float, 8, true, true>")
-        if rp:  # the same kernel's average in the committed rocprofv3 --kernel-trace --stats summary of this command
-            rp["frac"] = alg_bytes / (rp["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS
-            roof["rocprofv3"] = rp
+        if rp:
+            roof["committed_profile"] = rp
         out = {
             "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps, 3 signals pipelined)",
             "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -550,7 +693,20 @@ def main():
             "atoms_selected": int(atoms),
         }
         if use_dist:
+            # the one exchange, checked: a row for every signal of every rank, and the first timed signal of every rank
+            # recomputed HERE (rank 0 regenerates it from its global id) must be the gathered row
+            gi, gv, gn = cs.unpack_t(gathered, K_ATOMS)
+            ok = []
+            for r in range(world):
+                b_r = make_signals(torch, dev, At, r * (K + W) + W, 1)[0].cpu().numpy()
+                i_r, v_r, o_r = D.ctx.omp(b_r, K_ATOMS, eps)
+                col = r * K
+                ok.append(bool(int(gn[col]) == len(i_r) and np.array_equal(gi[:len(i_r), col], i_r)))
             out["gathered_rows"] = int(gathered.shape[0])
+            out["gather_check"] = {"rows_expected": world * K, "rows_ok": int(gathered.shape[0]) == world * K,
+                                   "first_signal_of_every_rank_equals_rank0_recomputation": ok}
+            if int(gathered.shape[0]) != world * K or not all(ok):
+                out["error"] = "gathered results do not match: see gather_check"
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 at N = 1 only
             try:
                 # selection order of signal W (first timed signal) for the parity cross-check
@@ -562,10 +718,15 @@ def main():
             # the other single-GPU configurations of BASELINE.json, measured by this same process (builder-run lines
             # of them also sit under profiles/; these are the driver-run ones)
             sec = {}
-            try:
-                sec["batched_c3"] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False)
+            try:  # the reference API's own shape of work: ONE omp(A, b, k) at a time (src/matchingpursuit.jl:73-86), nothing pipelined
+                sec["lone_omp_c2"] = measure_lone_omp(3, 1, B, D, eps)
             except Exception as e:  # noqa: BLE001
-                sec["batched_c3"] = {"error": repr(e)}
+                sec["lone_omp_c2"] = {"error": repr(e)}
+            for name, cert, gram in (("batched_c3", 0, 0), ("batched_c3_rigorous", 1, 0), ("batched_c3_gram", 0, 1)):
+                try:
+                    sec[name] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False, cert=cert, gram=gram)
+                except Exception as e:  # noqa: BLE001
+                    sec[name] = {"error": repr(e)}
             # SURVEY 8(f) rows 2 and 3 at the configs[1] shape: forward regression (batched ticks), ompr, srr
             import copy
             for name, wl, st_, wu in (("fr_8f3", "fr", 6, 3), ("ompr_8f2", "ompr", 3, 1), ("srr_8f2", "srr", 3, 1)):
@@ -582,6 +743,7 @@ def main():
                 At5, D5 = make_dictionary5(cs, torch, dev)
                 sec["gomp_c5"] = measure_config5("gomp", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5)
+                sec["sp_c5_default_delta"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5, delta=1e-12)
                 D5.close()
             except Exception as e:  # noqa: BLE001
                 sec["config5"] = {"error": repr(e)}

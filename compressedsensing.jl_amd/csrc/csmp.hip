@@ -3042,23 +3042,33 @@ static int batch_gram(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
     if (b.gram_valid) return CSMP_OK;
     const int64_t N = ctx->N;
-    if (ctx->ld % 16 != 0 && ctx->ld != ((ctx->M + 15) / 16) * 16) { /* any ld works: k_gram reads rows < ldo only */ }
     size_t free_b = 0, total_b = 0;
     HIPCHECK(hipMemGetInfo(&free_b, &total_b));
     const size_t need = (size_t)N * (size_t)N * sizeof(double);
     if (need + ((size_t)1 << 30) > free_b) return fail(ctx, CSMP_ENOMEM, "CSMP_OPT_BATCH_GRAM: 8 N^2 bytes of HBM are not available");
     HIPCHECK(hipMalloc((void**)&b.Gm, need));
     // k_gram tiles are 128 x 64 over np columns; np = N need not be a multiple of the tile: rows / columns >= np are clamped and
-    // never stored.  One slice of the rows (no partials): rows_per_split = the whole padded column.
+    // never stored.  One slice of the rows (no partials): rows_per_split = the whole column, which the kernel walks in blocks of
+    // 16 rows -- a dictionary whose leading dimension is not a multiple of 16 goes through a zero-padded temporary copy.
     const int np = (int)N;
-    const int64_t ldo = ctx->ld;  // rows [M, ld) of the resident dictionary are zeros in our own copy; a BORROWED dictionary has ld = M
-    const int rows = (int)(((int64_t)ctx->Mv + 15) / 16 * 16);
+    const size_t es = ctx->dtype == CSMP_F32 ? 4 : 8;
+    const int rows = (int)((ctx->M + 15) / 16 * 16);
+    const void* src = ctx->dA;
+    int64_t ldo = ctx->ld;
+    DevTmp padded;
+    if (ctx->ld % 16 != 0) {
+        ldo = rows;
+        HIPCHECK(padded.alloc((size_t)ldo * (size_t)N * es));
+        HIPCHECK(hipMemsetAsync(padded.p, 0, (size_t)ldo * (size_t)N * es, ctx->stream));
+        HIPCHECK(hipMemcpy2DAsync(padded.p, (size_t)ldo * es, ctx->dA, (size_t)ctx->ld * es, (size_t)ctx->M * es, (size_t)N, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+        src = padded.p;
+    }
     const dim3 grid((unsigned)((np + kGramWgJ - 1) / kGramWgJ), (unsigned)((np + kGramWgI - 1) / kGramWgI), 1);
-    if (rows > ldo) return fail(ctx, CSMP_ERANGE, "CSMP_OPT_BATCH_GRAM: the dictionary's rows must be padded to a multiple of 16 (copy it: pass a host pointer)");
     if (ctx->dtype == CSMP_F32)
-        hipLaunchKernelGGL(k_gram<float>, grid, dim3(256), 0, ctx->stream, (const float*)ctx->dA, ldo, np, rows, b.Gm);
+        hipLaunchKernelGGL(k_gram<float>, grid, dim3(256), 0, ctx->stream, (const float*)src, ldo, np, rows, b.Gm);
     else
-        hipLaunchKernelGGL(k_gram<double>, grid, dim3(256), 0, ctx->stream, (const double*)ctx->dA, ldo, np, rows, b.Gm);
+        hipLaunchKernelGGL(k_gram<double>, grid, dim3(256), 0, ctx->stream, (const double*)src, ldo, np, rows, b.Gm);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     b.Ng = N;
@@ -3066,17 +3076,23 @@ static int batch_gram(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
-// DEPTH of the two per-signal kernels: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
-template <typename TA, int NI>
+template <typename TA>
 static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
                                 int kwin) {
     Batch& b = ctx->bt;
-    constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 1 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
-    hipLaunchKernelGGL((k_b_pick<TA, NI, DEPTH>), dim3(nsig), dim3(256), 0, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)b.cand_val,
+    constexpr int U = sizeof(TA) == 4 ? 16 : 8;  // 64-lane chunks of a column in flight per wave (16 bytes per lane each)
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
+    auto kern = k_b_pick<TA, U>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)b.cand_val,
                        (const int*)b.cand_idx, b.n_atiles * kTileCand, (const int*)b.sel, b.bs, b.pick, (const double*)b.r, b.Mr, b.kcap, (int)ctx->M, eps,
                        check_eps, cert_abs, cert_rel, kwin, sig0);
     return hipGetLastError();
 }
+// DEPTH of the append kernel: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
 template <typename TA, int NI, bool GRAM>
 static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig) {
     Batch& b = ctx->bt;
@@ -3095,10 +3111,9 @@ template <typename TA>
 static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
                                   int kwin, bool gram) {
     const int groups = (ctx->Mv + 1023) / 1024;
-    hipError_t e;
+    hipError_t e = b_pick_launch<TA>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin);
+    if (e != hipSuccess) return e;
 #define CSMP_BSTEP(NI)                                                                                                  \
-    e = b_pick_launch<TA, NI>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin);                          \
-    if (e != hipSuccess) return e;                                                                                      \
     return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig);
     if (groups <= 1) { CSMP_BSTEP(1) }
     if (groups <= 2) { CSMP_BSTEP(2) }

@@ -141,17 +141,62 @@ __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int
 // A passed certificate therefore proves the pick, given the bound.  cert_abs / cert_rel: csmp.hip (statistical model of
 // independent roundings + the coherent "whole operand scaled" term, or the deterministic bound).
 // A window larger than kwin entries is a failed certificate.
-template <typename TA, int NI, int DEPTH>
-__global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
+// <A[:, c], r> in Float64 by ONE wave: the sweep's inner loop (csmp_kernels.hpp) on one column -- lane l takes 16 bytes of every
+// 64-lane chunk, U chunks' loads in flight, the residual from its LDS image (r_slot layout: conflict-free 16-byte reads).
+// Every lane returns the sum.
+template <typename TA, int U>
+__device__ __forceinline__ double wave_col_dot(const TA* __restrict__ col, int Mv, int nchunk, const double* rimg, int lane) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const VT* p = reinterpret_cast<const VT*>(col) + lane;
+    double acc0 = 0.0, acc1 = 0.0;
+    for (int t0 = 0; t0 < nchunk; t0 += U) {
+        VT v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            v[u] = (VT)0;
+            if (t < nchunk && t * ROWS + lane * VEC < Mv) v[u] = p[t * kWave];  // (default policy: the winner's column is read again by k_b_append)
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + u;
+            if (t < nchunk) {
+                if constexpr (VEC == 4) {
+                    const f64x2 r01 = *reinterpret_cast<const f64x2*>(rimg + (((2 * t) << 6) + lane) * 2);
+                    const f64x2 r23 = *reinterpret_cast<const f64x2*>(rimg + (((2 * t + 1) << 6) + lane) * 2);
+                    acc0 = fma((double)v[u].x, r01.x, acc0);
+                    acc1 = fma((double)v[u].y, r01.y, acc1);
+                    acc0 = fma((double)v[u].z, r23.x, acc0);
+                    acc1 = fma((double)v[u].w, r23.y, acc1);
+                } else {
+                    const f64x2 r01 = *reinterpret_cast<const f64x2*>(rimg + t * ROWS + lane * 2);
+                    acc0 = fma((double)v[u].x, r01.x, acc0);
+                    acc1 = fma((double)v[u].y, r01.y, acc1);
+                }
+            }
+        }
+    }
+    double acc = acc0 + acc1;
+    for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+    return acc;
+}
+
+// dynamic LDS: the residual image, nchunk * 64 * VEC Float64 (32 KiB at M = 4096: four workgroups per CU)
+template <typename TA, int U>
+__global__ __launch_bounds__(256, 4) void k_b_pick(
     const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand,
     const int* __restrict__ sel_all, BState* __restrict__ bs, BPick* __restrict__ pick, const double* __restrict__ r_all, int Mr,
     int kcap, int Mrows, double eps, int check_eps, double cert_abs, double cert_rel, int kwin, int sig0) {
+    extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
-    __shared__ double red[4 * kWinMax];
-    __shared__ float wv_[kWinMax];
+    __shared__ double red[kWinMax];
     __shared__ int wi_[kWinMax];
     __shared__ float fsc[4];
     __shared__ int cnt;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = sig0 + (int)blockIdx.x;
     BState& st = bs[s];
@@ -175,23 +220,25 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
             ei[e] = t < ncand ? cis[t] : 0x7fffffff;
         }
     }
-    // residual in registers (thread t: rows 4(t + 256 i) .. +3; rows beyond M are stored zeros), ||r||^2, eps-stop
+    // residual -> LDS image (rows beyond M are stored zeros; beyond Mr: zeros here), ||r||^2, eps-stop
     const double* r = r_all + (int64_t)s * Mr;
-    double rreg[NI][4];
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
     double n2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int row = 4 * (tid + 256 * i);
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
         f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
-        if (row < Mr) {
-            lo = reinterpret_cast<const f64x2*>(r + row)[0];
-            hi = reinterpret_cast<const f64x2*>(r + row)[1];
+        if (m0 < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + m0)[0];
+            hi = reinterpret_cast<const f64x2*>(r + m0)[1];
         }
-        rreg[i][0] = lo.x; rreg[i][1] = lo.y; rreg[i][2] = hi.x; rreg[i][3] = hi.y;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) n2 = fma(rreg[i][e], rreg[i][e], n2);
+        n2 = fma(lo.x, lo.x, n2);
+        n2 = fma(lo.y, lo.y, n2);
+        n2 = fma(hi.x, hi.x, n2);
+        n2 = fma(hi.y, hi.y, n2);
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0)) = lo;
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
     }
-    n2 = block_sum256(n2, sc);
+    n2 = block_sum256(n2, sc);  // (its barriers also complete the image)
     const int j = st.nsel;
     if (tid == 0) st.rnorm2 = n2;
     if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
@@ -227,10 +274,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
         const double ub = (double)v + dabs + cert_rel * (double)v;
         if (ub >= lb1) {
             const int pos = atomicAdd(&cnt, 1);
-            if (pos < kwin) {
-                wv_[pos] = v;
-                wi_[pos] = i;
-            }
+            if (pos < kwin) wi_[pos] = i;
             if (slot == kTileCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a tile's last candidate
         } else {
             cb = fmax(cb, ub);
@@ -243,36 +287,16 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
         for (int t = tid; t < ncand; t += 256) visit(cvs[t], cis[t], t & (kTileCand - 1));
     }
     for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
-    __syncthreads();  // (fsc and sc are free again; the window list is complete)
+    __syncthreads();  // (sc is free again; the window list is complete)
     if (lane == 0) sc[wave] = cb;
     __syncthreads();
     cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
     const int nall = cnt;
     const int nw = min(nall, kwin);
-    // ---- exact rescoring of the window: <a_c, r> in Float64, DEPTH columns' loads in flight
-#pragma unroll 1
-    for (int grp = 0; grp * DEPTH < nw; ++grp) {
-        Raw4<TA> av[DEPTH][NI];
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q) {
-            const int c = (grp * DEPTH + q < nw) ? wi_[grp * DEPTH + q] : -1;
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int row = 4 * (tid + 256 * i);
-                av[q][i].zero();
-                if (c >= 0 && row < Mv) av[q][i].load(A + (int64_t)c * ld + row, Mv - row);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < DEPTH; ++q) {
-            double acc = 0.0;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc = fma(av[q][i].get(e), rreg[i][e], acc);
-            for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
-            if (lane == 0 && grp * DEPTH + q < nw) red[wave * kWinMax + grp * DEPTH + q] = acc;
-        }
+    // ---- exact rescoring of the window: <a_c, r> in Float64, one wave per column (four columns of the signal in flight)
+    for (int q = wave; q < nw; q += 4) {
+        const double exq = wave_col_dot<TA, U>(A + (int64_t)wi_[q] * ld, Mv, nchunk, rimg, lane);
+        if (lane == 0) red[q] = exq;
     }
     __syncthreads();
     // arg-max by the exact value, first index on ties (Julia argmax); the window list's order does not matter
@@ -281,7 +305,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
 #pragma unroll 1
     for (int q = 0; q < nw; ++q) {
         const int c = wi_[q];
-        const double exq = (red[q] + red[kWinMax + q]) + (red[2 * kWinMax + q] + red[3 * kWinMax + q]);
+        const double exq = red[q];
         const double v = fabs(exq);
         if (v > bestv || (v == bestv && c < besti)) {
             bestv = v;
@@ -314,6 +338,10 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_pick(
             pick[s].cexact = cexact;
         }
     }
+}
+inline size_t b_pick_lds_bytes(int Mv, int vec) {
+    const int rows = kWave * vec;
+    return (size_t)((Mv + rows - 1) / rows) * rows * sizeof(double);
 }
 
 // ---------------------------------------------------------------------------------------------

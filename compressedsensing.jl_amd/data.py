@@ -60,3 +60,31 @@ def samesupport(x, y):
         return np.flatnonzero(np.asarray(v))
     sx, sy = supp(x), supp(y)
     return len(sx) == len(sy) and bool(np.all(sx == sy))
+
+
+def structured_dictionary(kind, n, m, rng=None, dtype=np.float32):
+    """Unit-norm dictionaries that are NOT Gaussian (n rows x m atoms, reference naming) -- not in the reference; they
+    exist to probe the bf16 screen of csmp_omp_batch_mfma where rounding errors are not independent:
+      few_valued        entries in {+-0.3, +-0.7}: every entry of a class rounds alike
+      partial_dct       n random rows of the m-point DCT-II
+      common_component  Gaussian + a strong common vector (coherent: cond(A_S) large)
+      one_magnitude     entries in {-c_j, 0, +c_j}, a different c_j per column: in bf16 a whole column is SCALED by one factor
+      signs             +-1/sqrt(n): exactly representable when n is a power of 4"""
+    rng = _rng(rng)
+    if kind == "few_valued":
+        A = rng.choice(np.array([-0.7, -0.3, 0.3, 0.7]), size=(n, m))
+    elif kind == "partial_dct":
+        rows = np.sort(rng.choice(m, size=n, replace=False))
+        A = np.cos(np.pi * (np.arange(m)[None, :] + 0.5) * rows[:, None] / m)
+    elif kind == "common_component":
+        A = rng.standard_normal((n, m)) + 1.5 * rng.standard_normal((n, 1))
+    elif kind == "one_magnitude":
+        dens = rng.uniform(0.2, 0.6, size=m)
+        A = (rng.random((n, m)) < dens[None, :]) * rng.choice(np.array([-1.0, 1.0]), size=(n, m))
+        A[0, np.abs(A).sum(axis=0) == 0] = 1.0
+    elif kind == "signs":
+        A = rng.choice(np.array([-1.0, 1.0]), size=(n, m))
+    else:
+        raise ValueError(kind)
+    A = A / np.sqrt((A * A).sum(axis=0, keepdims=True))
+    return np.asfortranarray(A.astype(dtype))

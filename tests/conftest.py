@@ -15,6 +15,16 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def cs():
+    # On the GPU box two HIP runtimes live in the test process: PyTorch's bundled one (the tests use torch for device tensors and
+    # streams) and /opt/rocm's, which libcsmp.so links.  Bring PyTorch's up FIRST: initialised late, after libcsmp has worked for
+    # a while, it stalled for minutes and then reported "no ROCm-capable device" (seen with `-k` subsets whose first torch user
+    # came after ~18 library tests).  Nothing here touches the GPU when none is visible.
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.zeros(1, device="cuda").item()
+    except ImportError:
+        pass
     from csmp_pkg import load
     return load()
 

@@ -50,3 +50,29 @@ def test_no_cpu_fallback_without_gpu(cs):
     A, x, b = cs.sparse_data(16, 24, 2, rng=0)
     with pytest.raises(cs.CsmpError):
         cs.omp(A, b, 2)
+
+
+def test_product_reads_no_environment_variable():
+    """behavioural choices are arguments or csmp_set_option keys; the only getenv left in the library is
+    inside tune_env(), which is compiled out of the product build (CSMP_EXPERIMENTS)."""
+    csrc = os.path.join(ROOT, "compressedsensing.jl_amd", "csrc")
+    hits = []
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".hpp")):
+            for ln, line in enumerate(open(os.path.join(csrc, name)), 1):
+                if re.search(r"\bgetenv\s*\(", line):
+                    hits.append((name, ln, line.strip()))
+    assert len(hits) == 1 and hits[0][0] == "csmp.hip" and "return getenv(name);" in hits[0][2], hits
+    src = open(os.path.join(csrc, "csmp.hip")).read()
+    i = src.index("static const char* tune_env(")
+    assert "#ifdef CSMP_EXPERIMENTS" in src[i:i + 200]
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    assert "-DCSMP_EXPERIMENTS" not in mk.split("experiments:")[0]
+
+
+def test_option_keys_match_the_header(cs):
+    from csmp_pkg import load
+    lib = load()._lib
+    src = open(os.path.join(ROOT, "include", "csmp.h")).read()
+    keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define CSMP_OPT_([A-Z_]+)\s+(\d+)", src)}
+    assert keys == lib.OPTIONS and len(keys) >= 8

@@ -239,3 +239,108 @@ def test_column_sharded_omp_gloo_world2(oracle):
     """SURVEY section 8f-4 on CPU: the per-step record exchange (one all_gather), the cross-shard arg-max with its
     lower-global-index tie rule and the replicated append, driven by sharded.omp_colsharded under gloo."""
     assert _spawn2(_worker_colsharded, ()) == [(0, True), (1, True)]
+
+
+# ------------------------------------------------------------------------------------------ round 3
+def _worker_bench_colsharded(rank, world, port, q):
+    """bench.py's column-sharded workload (bench.colsharded_solves: warm-up + timed solves between barriers, then the
+    cross-rank agreement check) with numpy shards under gloo."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from csmp_pkg import load
+    from oracle import oracle_c
+    import bench
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    n, m, k = 48, 200, 6
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=21)
+    rng = np.random.default_rng(5)
+    sigs = [cs.perturb(A @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng) for _ in range(3)]
+    lo, hi = cs.column_range(m, rank, world)
+
+    def all_supports(idx):
+        t = torch.from_numpy(idx)
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [o.numpy() for o in out]
+    res = bench.colsharded_solves(2, 1, sigs, k, 1e-9, rank, world, None, lambda: _NumpyColumnShard(A[:, lo:hi], lo), dist.barrier, all_supports)
+    ref = oracle_c.omp(A, sigs[1], k, 1e-9, nthreads=1)
+    ok = res["ranks_agree_on_first_support"] and res["supports_gathered"] == world and res["atoms"] == 2 * k
+    ok &= np.array_equal(res["first"][0], ref[0]) and np.array_equal(res["first"][2], ref[2])
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bench_colsharded_workload_gloo_world2(oracle):
+    assert _spawn2(_worker_bench_colsharded, ()) == [(0, True), (1, True)]
+
+
+class _FakeBatchCtx:
+    """Stands in for Context in bench.measure_batched: the batched solver is the C oracle, signal by signal."""
+
+    def __init__(self, A):
+        self.A = A
+        self.opts = {}
+
+    def set_option(self, key, value):
+        self.opts[key] = value
+
+    def _solve(self, B, k, eps, idx, val, nnz):
+        from oracle import oracle_c
+        for s in range(B.shape[0]):
+            i, v, _ = oracle_c.omp(self.A, B[s].numpy(), k, eps, nthreads=1)
+            idx[s, :len(i)] = torch_from(i)
+            val[s, :len(i)] = torch_from(v)
+            nnz[s] = len(i)
+
+    omp_batch_mfma_device = _solve
+    omp_batch_device = _solve
+
+    def sync(self):
+        pass
+
+    def profile_enable(self, on):
+        pass
+
+    def batch_stats(self):
+        return {"signals": 0, "resolved_exactly": 0, "uncertain": 0, "illcond": 0, "screen_launches": 0, "screen_ms": 0.0}
+
+    def batch_layout(self):
+        return {"screen_signals": 4, "streams": 1}
+
+    def batch_screen_kernel(self):
+        return "oracle stand-in"
+
+
+def torch_from(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _worker_bench_batched_dist(rank, world, port, q):
+    """bench.measure_batched's use_dist branch (weak scaling: every rank its own signals, ONE exchange inside the timed
+    region, max-over-ranks time, summed atoms) under gloo, with a stand-in context."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from csmp_pkg import load
+    import bench
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    bench.M, bench.N = 48, 160  # (the module's shape constants: this test runs the real functions on a toy shape)
+    A, x, b = cs.sparse_data(n=48, m=160, k=4, rng=9)
+    At = torch.from_numpy(np.ascontiguousarray(A.T))
+
+    class FakeD:
+        eps = 1e-12
+        ctx = _FakeBatchCtx(A)
+    out = bench.measure_batched(2, 1, cs, torch, dist, torch.device("cpu"), rank, world, At, FakeD, True, nsig=4, k=4)
+    ok = (out is None) if rank != 0 else (out is not None and out["n_gpus"] == world and out["matches_exact_path_on_sample"]
+                                          and abs(out["value"] * out["ms_per_step"] * 1e-3 * 2 - world * 2 * 4 * 4) < 1e-6)
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_bench_measure_batched_dist_branch_gloo_world2(oracle):
+    assert _spawn2(_worker_bench_batched_dist, ()) == [(0, True), (1, True)]

@@ -1141,6 +1141,138 @@ def test_fr_batch_matches_single_signal_calls(cs, oracle, D, cfg):
 
 
 # ------------------------------------------------------------------------------------------ round 2
+@pytest.mark.parametrize("kind", ["few_valued", "partial_dct", "one_magnitude", "common_component"])
+def test_batched_mfma_structured_dictionaries(cs, oracle, kind):
+    """The bf16 screen on dictionaries whose rounding errors are NOT independent: few-valued entries,
+    partial-DCT rows, one magnitude per column (in bf16 each atom is scaled by its own factor), a strong common component.
+    >= 200 signals per family, under both certificates (CSMP_OPT_BATCH_CERT): every support the batched path returns equals the
+    exact path's -- a screen that would mislead shows up as `uncertain` (or `illcond`) and is re-solved, never silently -- and
+    a sample is checked against the oracle."""
+    M, N, nsig = 512, 4096, 200
+    rng = np.random.default_rng(2026 + len(kind))
+    A = cs.structured_dictionary(kind, M, N, rng=rng)
+    A64 = A.astype(np.float64)
+    d = cs.Dictionary(A)
+    for family, k in (("pm1", 16), ("neartie", 2), ("neartie", 6)):
+        B = np.empty((M, nsig), order="F")
+        for s in range(nsig):
+            sup = rng.choice(N, size=k, replace=False)
+            x = rng.choice(np.array([-1.0, 1.0]), size=k)
+            if family == "neartie":  # coefficients within 0.2 % of each other: exact correlations nearly tie
+                x = x * (1.0 + 2e-3 * rng.random(k))
+            B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
+        i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
+        for cert in (0, 1):
+            d.ctx.set_option("batch_cert", cert)
+            idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
+            st = d.ctx.batch_stats()
+            assert st["signals"] == nsig and st["resolved_exactly"] <= st["uncertain"] + st["illcond"]
+            assert np.array_equal(nnz, n2), (kind, family, cert)
+            assert np.array_equal(idx, i2), (kind, family, cert, int((idx != i2).any(axis=0).sum()))
+            assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
+        d.ctx.set_option("batch_cert", 0)
+        for s in range(0, nsig, 25):
+            ref = oracle.omp(A, B[:, s], k, EPS32)
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (kind, family, s)
+            assert close(val[:nnz[s], s], ref[1], tight=False)
+    d.close()
+
+
+def test_batched_mfma_resident_gram_option(cs, oracle, D):
+    """CSMP_OPT_BATCH_GRAM: A_S'a from the resident G = A'A instead of a pass over the support's columns -- same supports, same
+    coefficients (1e-9) as the default path and the oracle; switching the option off releases the matrix."""
+    for dtype, shape in ((np.float32, (256, 2048, 12, 40)), (np.float64, (130, 700, 10, 33)), (np.float32, (1500, 3000, 16, 9))):
+        n, m, k, nsig = shape
+        A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dtype)
+        d = D(A)
+        rng = np.random.default_rng(nsig)
+        B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
+                                        for _ in range(nsig)], axis=1))
+        eps = float(np.finfo(dtype).eps)
+        i0, v0, n0 = d.ctx.omp_batch_mfma(B, k, eps)
+        d.ctx.set_option("batch_gram", 1)
+        assert d.ctx.get_option("batch_gram") == 1
+        i1, v1, n1 = d.ctx.omp_batch_mfma(B, k, eps)
+        assert d.ctx.batch_stats()["illcond"] == 0
+        d.ctx.set_option("batch_gram", 0)
+        assert np.array_equal(i0, i1) and np.array_equal(n0, n1)
+        assert np.allclose(v0, v1, rtol=1e-9, atol=1e-12)
+        for s in range(0, nsig, 7):
+            ref = oracle.omp(A, B[:, s], k, eps)
+            assert np.array_equal(i1[:n1[s], s], ref[0]) and close(v1[:n1[s], s], ref[1])
+
+
+def test_options_at_the_abi(cs, D):
+    """csmp_set_option / csmp_get_option: defaults, range checks, unknown keys, inheritance by clones."""
+    A, x, b = cs.sparse_data(n=64, m=256, k=4, rng=3, dtype=np.float32)
+    d = D(A)
+    c = d.ctx
+    defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
+                "twostage_update": 0}
+    for key, v in defaults.items():
+        assert c.get_option(key) == v, key
+    for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1)):
+        with pytest.raises(cs.CsmpError):
+            c.set_option(key, bad)
+    with pytest.raises(cs.CsmpError):
+        c.set_option(99, 1)
+    c.set_option("batch_cert", 1)
+    c.set_option("twostage_update", 1)
+    c.set_option("pipeline", 0)
+    k2 = c.clone()
+    assert k2.get_option("batch_cert") == 1 and k2.get_option("twostage_update") == 1 and k2.get_option("pipeline") == 0
+    k2.close()
+    for key, v in defaults.items():
+        c.set_option(key, v)
+
+
+def test_clone_keeps_the_dictionary_alive(cs, oracle):
+    """a functor (a clone borrowing the parent's resident dictionary) must survive the parent's csmp_destroy and
+    the parent's next csmp_set_dictionary -- the library-owned copy is reference counted."""
+    A, x, b = cs.sparse_data(n=96, m=500, k=8, rng=5, dtype=np.float32)
+    y = cs.perturb(b, 5e-3, rng=6)
+    ref = oracle.omp(A, y, 8, EPS32)
+    parent = cs.Context(0)
+    parent.set_dictionary(A)
+    child = parent.clone()
+    A2, _, b2 = cs.sparse_data(n=80, m=300, k=5, rng=7, dtype=np.float64)
+    parent.set_dictionary(A2)  # the clone still holds the first dictionary
+    got = child.omp(y, 8, EPS32)
+    assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+    ref2 = oracle.omp(A2, b2, 5, 1e-12)
+    got2 = parent.omp(b2, 5, 1e-12)
+    assert np.array_equal(got2[0], ref2[0])
+    parent.close()  # ... and outlives the parent
+    got = child.omp(y, 8, EPS32)
+    assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+    child.close()
+
+
+def test_lstsq_while_another_stream_saturates_the_gpu(cs, oracle):
+    """the blocked Cholesky's row workgroups all read the unfactored diagonal block; with the GPU busy
+    (another stream's large kernels) they start far apart, and a late one must not see workgroup 0's factored block.  The block
+    now goes to a side buffer; run the whole-set least squares under load and compare with LAPACK."""
+    import torch
+    dev = torch.device("cuda", 0)
+    A, x, b = cs.sparse_data(n=2048, m=4096, k=8, rng=11, dtype=np.float32)
+    y = cs.perturb(b, 1e-2, rng=12)
+    d = cs.Dictionary(A)
+    big = torch.randn((8192, 8192), device=dev, dtype=torch.float32)
+    side = torch.cuda.Stream(device=dev)
+    rng = np.random.default_rng(13)
+    for trial in range(6):
+        n = int(rng.choice([200, 333, 512, 700, 1000]))
+        cols = rng.choice(4096, size=n, replace=False)
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                big = torch.tanh(big @ big * 1e-4)
+        coef = d.ctx.lstsq(cols, y)
+        want = np.linalg.lstsq(A[:, cols].astype(np.float64), y, rcond=None)[0]
+        assert np.allclose(coef, want, rtol=1e-8, atol=1e-10), (trial, n, np.abs(coef - want).max())
+    torch.cuda.synchronize()
+    d.close()
+
+
 def test_full_size_config3_batched(cs, oracle):
     """BASELINE configs[2] at its real workload: 1024 signals sharing A 4096 x 65536 f32, k = 128, through
     csmp_omp_batch_mfma.  (i) oracle comparison on a sample: 8 signals x their first 16 atoms (OMP is greedy, so a

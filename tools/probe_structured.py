@@ -12,25 +12,7 @@ from csmp_pkg import load
 cs = load()
 
 
-def normalise(A):
-    return A / np.sqrt((A * A).sum(axis=0, keepdims=True))
-
-
-def dictionaries(M, N, rng):
-    out = {}
-    out["few_valued"] = normalise(rng.choice(np.array([-0.7, -0.3, 0.3, 0.7]), size=(M, N)))
-    rows = np.sort(rng.choice(N, size=M, replace=False))
-    n = np.arange(N)
-    out["partial_dct"] = normalise(np.cos(np.pi * (n[None, :] + 0.5) * rows[:, None] / N))
-    g = rng.standard_normal((M, N))
-    out["common_component"] = normalise(g + 1.5 * rng.standard_normal((M, 1)))
-    out["signs"] = normalise(rng.choice(np.array([-1.0, 1.0]), size=(M, N)))  # +-1/sqrt(M): bf16-exact when M is a power of 4
-    out["three_valued_sparse"] = normalise(rng.choice(np.array([-1.0, 0.0, 0.0, 1.0]), size=(M, N)) * 0.3 + 1e-3 * rng.standard_normal((M, N)))
-    # one magnitude per column, a different one for every column (its number of non-zeros): all entries of a column round
-    # the same way in bf16, so the screen sees every atom SCALED by its own factor in 1 +- 2^-8 -- the fully coherent case
-    dens = rng.uniform(0.2, 0.6, size=N)
-    out["one_magnitude"] = normalise((rng.random((M, N)) < dens[None, :]) * rng.choice(np.array([-1.0, 1.0]), size=(M, N)))
-    return out
+KINDS = ("few_valued", "partial_dct", "common_component", "signs", "one_magnitude")
 
 
 def signals(A, k, nsig, family, rng):
@@ -58,8 +40,8 @@ def main():
     nsig = 256
     rng = np.random.default_rng(20261003)
     eps = float(np.finfo(np.float32).eps)
-    for name, A64 in dictionaries(M, N, rng).items():
-        A = np.asfortranarray(A64.astype(np.float32))
+    for name in KINDS:
+        A = cs.structured_dictionary(name, M, N, rng=rng)
         d = cs.Dictionary(A)
         for family, k in (("pm1", 24), ("gauss", 24), ("decay", 8), ("pm1", 2), ("neartie", 2), ("neartie", 6)):
             B = signals(A.astype(np.float64), k, nsig, family, rng)
