@@ -316,35 +316,70 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
     eps = D5.eps
 
     def solve(b):
-        if workload == "gomp":
+        if workload in ("gomp", "gomp_single"):
             i, v, o = D5.ctx.gomp(b, S, k, eps)
             return len(i), 0
         i, v, it = D5.ctx.sp(b, k, delta)
         return len(i), it
-    for w in range(W):
-        solve(sigs[w])
-    D5.ctx.profile_enable(True)
-    D5.ctx.profile_read(reset=True)
-    t0 = time.perf_counter()
-    atoms, iters = 0, 0
-    for s_ in range(W, W + K):
-        n, it = solve(sigs[s_])
-        atoms += n
-        iters += it
-    dt = time.perf_counter() - t0
-    sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
-    D5.ctx.profile_enable(False)
+    if workload == "gomp":
+        # the caller's loop over signals as ONE call: csmp_gomp_batch keeps two solves in flight (a signal's short stages under
+        # the other signal's sweep); signals resident in HBM, results left on the device
+        Bd = torch.stack([torch.from_numpy(x) for x in sigs]).to(dev)
+        oi = torch.full((K + W, k), -1, dtype=torch.int64, device=dev)
+        ov = torch.zeros((K + W, k), dtype=torch.float64, device=dev)
+        on = torch.zeros(K + W, dtype=torch.int64, device=dev)
+        if W:
+            D5.ctx.gomp_batch_device(Bd[:W].contiguous(), S, k, eps, oi[:W], ov[:W], on[:W])
+        D5.ctx.sync()
+        torch.cuda.synchronize()
+        D5.ctx.profile_enable(True)
+        D5.ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        D5.ctx.gomp_batch_device(Bd[W:].contiguous(), S, k, eps, oi[W:], ov[W:], on[W:])
+        D5.ctx.sync()
+        dt = time.perf_counter() - t0
+        atoms, iters = int(on[W:].sum().item()), 0
+        sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
+        D5.ctx.profile_enable(False)
+    else:
+        for w in range(W):
+            solve(sigs[w])
+        D5.ctx.profile_enable(True)
+        D5.ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        atoms, iters = 0, 0
+        for s_ in range(W, W + K):
+            n, it = solve(sigs[s_])
+            atoms += n
+            iters += it
+        dt = time.perf_counter() - t0
+        sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
+        D5.ctx.profile_enable(False)
     alg = M5 * N5 * 4
     avg = sweep_ms / max(sweeps, 1) / 1e3
-    out = {"metric": ("GOMP (S=4) atoms selected/sec" if workload == "gomp" else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
-           "value": (atoms / dt) if workload == "gomp" else K / dt, "unit": "atoms/s" if workload == "gomp" else "solves/s",
+    isg = workload in ("gomp", "gomp_single")
+    out = {"metric": ("GOMP (S=4) atoms selected/sec" + (", two solves in flight (csmp_gomp_batch)" if workload == "gomp" else ", one gomp call at a time")
+                      if isg else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
+           "value": (atoms / dt) if isg else K / dt, "unit": "atoms/s" if isg else "solves/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
-           "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if workload == "gomp" else f", delta={delta:g}"),
-                      "sweeps": int(sweeps), "sp_update_calls": int(iters), "sp_update_calls_per_solve": iters / K if workload == "sp" else None},
+           "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if isg else f", delta={delta:g}"),
+                      "sweeps": int(sweeps), "sp_update_calls": int(iters), "sp_update_calls_per_solve": iters / K if workload == "sp" else None,
+                      "signals_in_flight": 2 if workload == "gomp" else 1},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
+    if isg:  # the whole solve against the same roofline: one dictionary pass per S atoms is all the algorithm needs
+        out["roofline"]["whole_solve"] = {"achieved": alg / S * atoms / dt / 1e9, "frac": alg / S * atoms / dt / 1e9 / HBM_PEAK_GBS,
+                                          "note": "ALL-IN: M*N*4 bytes per S atoms / wall time per atom"}
+    if workload == "gomp":
+        # two sweeps share the HBM most of the time: a launch bracketed by HIP events on ONE stream takes about twice as long as
+        # the kernel alone, so the per-launch figure says nothing here -- the block's achieved / frac are the all-in ones
+        r = out["roofline"]
+        r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
+        r["achieved"], r["frac"] = r["whole_solve"]["achieved"], r["whole_solve"]["frac"]
+        r["note"] = ("achieved / frac = ALL-IN (M*N*4 bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
+                     "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)")
     if workload == "sp":
         # the factorisations beside the sweeps: the first acquisition factorises k columns, every update! 2k and then k
         # (src/twostage.jl:74-83,104-107); thin QR of n columns = 2 M n^2 flop.  Time = the solves minus their sweeps.
@@ -741,7 +776,8 @@ def main():
             torch.cuda.empty_cache()
             try:
                 At5, D5 = make_dictionary5(cs, torch, dev)
-                sec["gomp_c5"] = measure_config5("gomp", 3, 1, cs, torch, dev, D5, At5)
+                sec["gomp_c5"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5)
+                sec["gomp_c5_single"] = measure_config5("gomp_single", 2, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5_default_delta"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5, delta=1e-12)
                 D5.close()

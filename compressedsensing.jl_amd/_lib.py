@@ -13,10 +13,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
 
 OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
+WCAPACITY = 1  # warning: the support reached the on-device QR append's capacity; results valid (include/csmp.h)
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
-STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
+STOP_EPS, STOP_STAG, STOP_FULL, STOP_CAPACITY = 1, 2, 4, 8
 # csmp_set_option keys (include/csmp.h)
 OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE = 1, 2, 3, 4, 5, 6, 7, 8
 OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
@@ -59,6 +60,7 @@ SIGNATURES = {
     "csmp_fr_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_gomp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
@@ -157,7 +159,8 @@ class Context:
             pass
 
     def check(self, rc):
-        if rc != OK:
+        self.last_status = rc  # (positive = a warning with valid results, e.g. WCAPACITY)
+        if rc < OK:
             raise CsmpError(rc, lib().csmp_last_error(self._h).decode())
 
     def call(self, name, *args):
@@ -358,6 +361,32 @@ class Context:
         self.call("csmp_omp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(k)),
                   C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
         return idx, val, nnz
+
+    def gomp_batch(self, B, l, k, eps):
+        """Host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz): gomp for every column, two solves in flight."""
+        B = np.asfortranarray(B)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        M, nsig = B.shape
+        if M != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {M} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), nsig), np.int64, order="F")
+        val = np.zeros((int(k), nsig), np.float64, order="F")
+        nnz = np.zeros(nsig, np.int64)
+        self.call("csmp_gomp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), HOST, i64(int(l)), i64(int(k)),
+                  C.c_double(eps), ptr(idx), ptr(val), ptr(nnz), HOST)
+        return idx, val, nnz
+
+    def gomp_batch_device(self, B, l, k, eps, idx, val, nnz):
+        """torch CUDA tensors: B (nsig, M) rows = signals; outputs idx (nsig, k) int64, val (nsig, k) float64, nnz (nsig,) int64."""
+        import torch
+        nsig, M = B.shape
+        assert B.is_cuda and B.is_contiguous() and M == self.M
+        assert idx.dtype == torch.int64 and val.dtype == torch.float64 and nnz.dtype == torch.int64
+        assert idx.is_contiguous() and val.is_contiguous() and idx.shape == (nsig, int(k)) and val.shape == (nsig, int(k))
+        code = F32 if B.dtype == torch.float32 else F64
+        self.call("csmp_gomp_batch", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(l)), i64(int(k)), C.c_double(eps),
+                  vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
 
     def fr_batch(self, B, k, max_eps=0.0, min_delta=0.0):
         """fr for every column of the host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz)."""

@@ -276,6 +276,19 @@ def omp_batch(A, B, k, eps=None):
             D.close()
 
 
+def gomp_batch(A, B, l, k, eps=None):
+    """[gomp(A, B[:, s], l, eps, k) for s in axes(B, 2)] on one GPU (two solves in flight): list of SparseVectors."""
+    eps = _meta(A)[2] if eps is None else eps
+    _check_eps(eps)
+    D, tmp = _dict(A)
+    try:
+        idx, val, nnz = D.ctx.gomp_batch(B, int(l), int(k), float(eps))
+        return [SparseVector(D.shape[1], idx[:n, s], val[:n, s]) for s, n in enumerate(nnz)]
+    finally:
+        if tmp:
+            D.close()
+
+
 def fr_batch(A, B, k, max_eps=0.0, min_delta=0.0):
     """[fr(A, B[:, s], max_eps, min_delta, k) for s in axes(B, 2)]: list of SparseVectors (pipelined on the device)."""
     D, tmp = _dict(A)

@@ -48,6 +48,7 @@ struct Solver {
     int algo = -1;
     bool begun = false;
     int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
+    bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
     // multi-column append (csmp_block.hpp), allocated on first use
     double *Apan = nullptr, *Vpan = nullptr, *PB1 = nullptr, *W1b = nullptr, *PG = nullptr, *Gsum = nullptr;
@@ -127,6 +128,8 @@ struct csmp_ctx {
     void* dA = nullptr;
     bool ownA = false;
     struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
+    csmp_ctx* twin = nullptr;     // csmp_gomp_batch: a clone on its own stream (the second solve in flight)
+    hipEvent_t ev_twin = nullptr;
     int dtype = CSMP_F32;
     int64_t M = 0, N = 0, ld = 0;
     int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
@@ -313,6 +316,9 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         solver_free(ctx->s);
     }
     batch_free(ctx->bt, false);
+    if (ctx->twin) (void)csmp_destroy(ctx->twin);
+    ctx->twin = nullptr;
+    if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
     dict_release(ctx);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev2) (void)hipEventDestroy(e);
@@ -585,6 +591,10 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
     HIPCHECK(hipSetDevice(ctx->dev));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->twin) {  // (the twin of csmp_gomp_batch holds the previous dictionary)
+        (void)csmp_destroy(ctx->twin);
+        ctx->twin = nullptr;
+    }
     dict_release(ctx);  // (clones that still hold the previous dictionary keep it alive)
     HIPCHECK(sync_all(ctx));
     for (int q = 2; q >= 0; --q) {
@@ -761,6 +771,7 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
+    s.capped = false;
     return CSMP_OK;
 }
 
@@ -771,6 +782,7 @@ static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
     hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
+    s.capped = false;
     return CSMP_OK;
 }
 
@@ -796,7 +808,13 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
     // the LDS vectors of the append kernels are sized by the support they can meet (jh bounds it), not by the capacity
     const int jpad = qr_jpad(jh);
     const size_t lds = qr_lds_bytes(jh);
-    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
+    if (jh >= qr_max_cols() || lds > 160 * 1024 - 512) {
+        // The append kernels keep five support-length vectors in LDS: about 3900 columns.  A solve that gets there (the
+        // reference's defaults k = size(A,1) at M = 4096 with a residual test that never fires) STOPS there: the step is
+        // withheld, the solution reached so far stays valid, and the driver reports CSMP_WCAPACITY / CSMP_STOP_CAPACITY.
+        s.capped = true;
+        return CSMP_OK;
+    }
     if (lds > 64 * 1024) {
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HIPCHECK(hipFuncSetAttribute((const void*)k_qr1<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1005,8 +1023,12 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
                               : ctx->tick_U == 16 ? (int64_t)ctx->sweep_grid * 11 / 12
                                                   : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
+    if (k > qr_max_cols()) {  // the appends stop at the support the QR kernels can hold (see launch_append): CSMP_WCAPACITY
+        k = qr_max_cols();
+        for (int q = 0; q < 3; ++q)
+            if (present[q]) sl[q]->capped = true;
+    }
     const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
-    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
         const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
@@ -1045,10 +1067,11 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     ctx->s.begun = false;
     // optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
     // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
+    bool capacity_stop = false;
     for (int pass = 0; pass < 2; ++pass) {
         const bool optimistic = pass == 0 && !ctx->force_reorth;
         CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k; ++t) {
+        for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
             CHECK(omp_step(ctx, eps, t > 0, optimistic));
             if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
                 bool stopped = false;
@@ -1060,9 +1083,13 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!(hs.done & STOP_REORTH)) break;
+        if (!(hs.done & STOP_REORTH)) {
+            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+            break;
+        }
     }
-    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+    CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
+    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ forward regression (OLS)
@@ -1205,8 +1232,12 @@ static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_
     fr_config(ctx, 1, U, full, flds, grid);
     int nblk = grid;
     if (const char* tn = tune_env("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
+    if (k > qr_max_cols()) {  // (as omp_ticks)
+        k = qr_max_cols();
+        for (int q = 0; q < 3; ++q)
+            if (present[q]) sl[q]->capped = true;
+    }
     const size_t lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));
-    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "support too large for the on-device QR append (LDS: about 3900 columns)");
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
         const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
@@ -1254,10 +1285,11 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     CHECK(fr_ensure(ctx));
     ctx->s.begun = false;
     const double min_d2 = min_delta * min_delta;  // :64
+    bool capacity_stop = false;
     for (int pass = 0; pass < 2; ++pass) {  // optimistic append chain, repeated with re-orthogonalisation if flagged (see csmp_omp)
         const bool optimistic = pass == 0 && !ctx->force_reorth;
         CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k; ++t) {
+        for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
             CHECK(fr_step(ctx, t == 0, max_eps, min_d2, optimistic));
             if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
                 bool stopped = false;
@@ -1269,15 +1301,20 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!(hs.done & STOP_REORTH)) break;
+        if (!(hs.done & STOP_REORTH)) {
+            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+            break;
+        }
     }
-    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+    CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
+    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
 }
 
 // omp (algo = CSMP_ALGO_OMP: p1 = eps) or fr (CSMP_ALGO_FR: p1 = max_eps, p2 = min_delta^2) for every column of B
 static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                       double eps, double p2, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     const bool isfr = algo == CSMP_ALGO_FR;
+    bool capacity_stop = false;
     if (!ctx) return CSMP_EINVAL;
     if (!isfr && !(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
     if (!B || nsig < 0 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "batch: bad arguments");
@@ -1377,6 +1414,8 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn)
             if (hf[sgn] & STOP_REORTH) rc = solve_one(sgn, false);
+        if (k > qr_max_cols())  // a signal that no stopping rule ended was cut at the QR append's capacity
+            for (int64_t sgn = 0; sgn < nsig; ++sgn) capacity_stop |= !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
@@ -1386,7 +1425,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
-    return rc;
+    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
 }
 
 extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
@@ -1507,21 +1546,26 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_step: no solver begun");
     HIPCHECK(hipSetDevice(ctx->dev));
+    int rc = CSMP_OK;
     switch (ctx->s.algo) {
         case CSMP_ALGO_MP: return mp_step(ctx);
         case CSMP_ALGO_OMP: {
             // update!(P::OMP, x) alone: no eps logic (that belongs to the omp driver)
             CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
-            return launch_append(ctx, 1, 0, STOP_FULL);
+            rc = launch_append(ctx, 1, 0, STOP_FULL);
+            break;
         }
         case CSMP_ALGO_FR: {
             // update!(P::FR, x): nnz < n guard, acquisition_index! = argmax δ², addindex!, solve (src/forward.jl:88-95)
             const int skip = STOP_FULL | STOP_STAG;  // (a step that found no finite score would otherwise downdate rho2 twice)
             CHECK(launch_fr_sweep(ctx, ctx->s.jh == 0, -HUGE_VAL, skip));
-            return launch_append(ctx, 3, 0, skip, false, -1.0, ctx->s.fr_grid);
+            rc = launch_append(ctx, 3, 0, skip, false, -1.0, ctx->s.fr_grid);
+            break;
         }
-        default: return gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
+        default: rc = gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
+    // a step the QR append could not take (support at its capacity): x is unchanged, the caller is told
+    return rc == CSMP_OK && ctx->s.capped ? CSMP_WCAPACITY : rc;
 }
 
 // ------------------------------------------------------------------------------------------ shared dictionary
@@ -1835,8 +1879,9 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (stop) *stop = hs.done;
         if (s.algo != CSMP_ALGO_MP) s.jh = std::min(s.kcap, hs.nsel);  // the host's support bound snaps to the true count
+        if (s.capped && s.jh < qr_max_cols()) s.capped = false;  // (the bound was loose: no-op steps had been counted)
+        if (stop) *stop = (hs.done & (STOP_EPS | STOP_STAG | STOP_FULL)) | (s.capped ? CSMP_STOP_CAPACITY : 0);
     }
     if (s.algo == CSMP_ALGO_MP) return mp_collect(ctx, nullptr, nullptr, 0, idx, val, nnz);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
@@ -1966,11 +2011,12 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     ctx->s.begun = false;
     // first with the multi-column append (the l atoms of a step join the QR in one panel); a panel
     // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain
+    bool capacity_stop = false;
     for (int pass = 0; pass < 2; ++pass) {
         const bool block = pass == 0 && !ctx->force_reorth && l <= kPanelMax;
         CHECK(upload_b(ctx, b, b_dtype));
         const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
-        for (int64_t it = 0; it < k / l; ++it) {  // :130-133
+        for (int64_t it = 0; it < k / l && !ctx->s.capped; ++it) {  // :130-133
             CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));
             if ((it + 1) % kPollSteps == 0 && it + 1 < k / l) {
                 bool stopped = false;
@@ -1984,9 +2030,127 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!(hs.done & STOP_REORTH)) break;
+        if (!(hs.done & STOP_REORTH)) {
+            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+            break;
+        }
     }
-    return download_result(ctx, ctx->s.outcap, idx, val, nnz, order);
+    CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
+    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+}
+
+// ---- gomp for many signals: TWO solves in flight, one per stream
+// One signal's step is a chain: the dictionary sweep (HBM-bound, 0.6 ms at config 5), then top-S and the panel append (eight
+// short kernels, ~55 us, a fraction of the chip) -- nothing of the same signal can run beside them.  Another signal's sweep
+// can: signals alternate between this context and a twin (a clone on its own stream), everything is enqueued up front, and
+// the twin's first sweep is held back until this context's first sweep has finished, so that the two chains run OUT of
+// phase: each signal's short stages fall under the other's sweep (in phase they would fall on each other).  Results are
+// those of csmp_gomp signal by signal (the same kernels in the same order on each stream).
+static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l, int64_t k, double eps, bool block, int64_t* d_idx,
+                        double* d_val, int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
+    int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
+    if (rc != CSMP_OK) return rc;
+    const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
+    for (int64_t it = 0; it < k / l && !c->s.capped; ++it) {  // src/matchingpursuit.jl:130-133
+        rc = gomp_update(c, l, eps, it > 0, main_skip, block);
+        if (rc != CSMP_OK) return rc;
+        if (it == 0 && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
+    }
+    const int64_t rem = k % l;
+    if (rem > 0) {  // :134-137: runs even after an eps-break
+        rc = gomp_update(c, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block);
+        if (rc != CSMP_OK) return rc;
+    }
+    return launch_finish(c, d_idx, d_val, d_nnz, nullptr, (int)k, d_flag);
+}
+
+extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t l, int64_t k,
+                               double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:127
+    if (!B || nsig < 0 || k < 1 || l < 1 || l > k || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "gomp_batch: bad arguments (needs 1 <= l <= k)");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    if (!ctx->twin) {
+        const int rc = csmp_clone(ctx, &ctx->twin);
+        if (rc != CSMP_OK) return rc;
+    }
+    csmp_ctx* cc[2] = {ctx, ctx->twin};
+    cc[1]->force_reorth = ctx->force_reorth;
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // at most k atoms are ever added (GOMP's own capacity is M: :108)
+    for (int q = 0; q < 2; ++q) {
+        const int rc = solver_ensure(cc[q], kc, (int)(k + l));
+        if (rc != CSMP_OK) {
+            if (q) ctx->err = cc[q]->err;
+            return rc;
+        }
+        cc[q]->s.begun = false;
+    }
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    DevTmp tB, tIdx, tVal, tNnz, tFlag;
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
+    }
+    HIPCHECK(tFlag.alloc((size_t)nsig * sizeof(int)));
+    int* d_flag = (int*)tFlag.p;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
+    if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+    const bool block = !ctx->force_reorth && l <= kPanelMax;
+    for (int64_t sgn = 0; sgn < nsig; ++sgn) {
+        csmp_ctx* c = cc[sgn & 1];
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
+        const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
+                                    sgn == 0 ? ctx->ev_twin : nullptr);
+        if (rc != CSMP_OK) {
+            if (c != ctx) ctx->err = c->err;
+            (void)hipStreamSynchronize(cc[0]->stream);
+            (void)hipStreamSynchronize(cc[1]->stream);
+            return rc;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(cc[1]->stream));
+    std::vector<int> hf((size_t)nsig);
+    HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    // a panel that failed its DGKS test flagged the solve (nothing committed): that signal again, column by column
+    int rc = CSMP_OK;
+    bool capacity_stop = false;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        if (hf[sgn] & STOP_REORTH) {
+            const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+            rc = gomp_enqueue(ctx, col, b_dtype, l, k, eps, false, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn, nullptr);
+            if (rc == CSMP_OK) {
+                HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHECK(hipStreamSynchronize(ctx->stream));
+                capacity_stop |= ctx->s.capped && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
+            }
+        }
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
 }
 
 // state reset + r = b for a fresh factorisation on the same b (SP re-factorises from scratch)

@@ -188,7 +188,10 @@ def omp_colsharded(shards, b, k, eps, group=None):
     mine = list(shards) if virtual else [shards]
     if not virtual:
         import torch.distributed as dist
-        world = dist.get_world_size(group)
+        if not (dist.is_available() and dist.is_initialized()):
+            virtual = True  # one process, no group: the single shard IS the whole dictionary (world size 1)
+        else:
+            world = dist.get_world_size(group)
     # On the GPU the sweeps, the record exchange and the appends are ordered by ONE stream: the library's kernels are
     # enqueued on the torch stream the collective (or the concatenation) runs on; the host never waits inside the loop.
     gpu = all(hasattr(sh, "use_stream") for sh in mine)

@@ -17,7 +17,8 @@
  *     dictionary yields the support a Float64 run of the reference would select on the same values.
  *   - Results follow SparseVector{Float64,Int64} (src/matchingpursuit.jl:76): indices sorted
  *     ascending (0-BASED here; the Julia wrapper adds 1), values aligned, nnz may be < k.
- *   - Every call returns a status (0 = ok, negative = error); csmp_last_error() gives the text.
+ *   - Every call returns a status (0 = ok, negative = error, positive = warning with valid results: CSMP_WCAPACITY);
+ *     csmp_last_error() gives the text of an error.
  *   - A ctx is bound to one GPU and one HIP stream and is not thread-safe (the reference is
  *     single-threaded too).  Caller owns every buffer passed in; the library owns device memory
  *     behind the opaque ctx.  `loc` says where a caller buffer lives: CSMP_HOST or CSMP_DEVICE.
@@ -36,6 +37,11 @@ extern "C" {
 #define CSMP_EHIP (-4)   /* HIP runtime failure / no gfx950 device */
 #define CSMP_ESTATE (-5) /* no dictionary set / no solver begun */
 #define CSMP_ENOMEM (-6)
+/* positive = a warning; the results are valid.  CSMP_WCAPACITY: the on-device QR append keeps five support-length vectors in
+ * the 160 KiB of LDS and holds about 3900 columns; a solve that reaches that support with no stopping rule having fired -- the
+ * reference's defaults omp(A, b, eps) / OMP(A, b) / gomp with k = size(A, 1) at M = 4096 and a residual test that never fires --
+ * stops THERE: the solution reached is returned (nnz = that capacity), not lost to an error. */
+#define CSMP_WCAPACITY 1
 
 #define CSMP_F32 0
 #define CSMP_F64 1
@@ -52,6 +58,7 @@ extern "C" {
 #define CSMP_STOP_EPS 1    /* norm(residual) < eps: src/matchingpursuit.jl:79,132 */
 #define CSMP_STOP_STAG 2   /* arg-max atom already selected: src/matchingpursuit.jl:66 */
 #define CSMP_STOP_FULL 4   /* nnz(x) == size(A,1): src/matchingpursuit.jl:63,117 */
+#define CSMP_STOP_CAPACITY 8 /* the support reached the on-device QR append's capacity (see CSMP_WCAPACITY); not in the reference */
 
 typedef struct csmp_ctx csmp_ctx;
 
@@ -167,6 +174,13 @@ int csmp_omp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64
  * conventions, pipelining and single synchronisation as csmp_omp_batch. */
 int csmp_fr_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                   double max_eps, double min_delta, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+
+/* gomp(A, B[:,s], l, eps, k) for s = 0..nsig-1 (src/matchingpursuit.jl:116-139 in the caller's loop), 1 <= l <= k: the conventions
+ * of csmp_omp_batch (idx / val: k x nsig).  TWO solves are in flight, one on the context's stream and one on an internal clone's,
+ * out of phase: a signal's short stages (top-l selection, the l-column panel append) run under the other signal's dictionary
+ * sweep.  Results are csmp_gomp's, signal by signal.  One synchronisation at the end. */
+int csmp_gomp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t l, int64_t k,
+                    double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
  * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only

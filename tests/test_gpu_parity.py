@@ -1399,6 +1399,63 @@ def test_reference_default_capacities_at_m4096(cs, oracle, D):
     G.close()
 
 
+@pytest.mark.parametrize("cfg", [(96, 400, 2, 7, 5, np.float32), (256, 2048, 4, 24, 9, np.float32), (130, 700, 3, 10, 4, np.float64)])
+def test_gomp_batch_equals_single_calls(cs, oracle, D, cfg):
+    """csmp_gomp_batch (two solves in flight on two streams, out of phase) = csmp_gomp signal by signal = the oracle, including
+    the remainder step (k % l != 0), a residual stop on some signals, and an odd number of signals."""
+    n, m, l, k, nsig, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + l, dtype=dtype)
+    d = D(A)
+    rng = np.random.default_rng(k)
+    cols = []
+    for s in range(nsig):
+        kk = k if s % 3 else max(1, k // 2)  # every third signal is sparser: its residual test fires early
+        cols.append(cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, kk, rng=rng).to_dense(), 1e-3, rng=rng))
+    B = np.asfortranarray(np.stack(cols, axis=1))
+    eps = 5e-3
+    idx, val, nnz = d.ctx.gomp_batch(B, l, k, eps)
+    for s in range(nsig):
+        ref = oracle.gomp(A, B[:, s], l, k, eps)
+        one = d.ctx.gomp(B[:, s], l, k, eps)
+        assert nnz[s] == len(ref[0]) == len(one[0]), (s, nnz[s], len(ref[0]))
+        assert np.array_equal(idx[:nnz[s], s], ref[0]) and np.array_equal(one[0], ref[0])
+        assert close(val[:nnz[s], s], ref[1]) and np.array_equal(val[:nnz[s], s], one[1])
+        assert np.all(idx[nnz[s]:, s] == -1)
+    xs = cs.gomp_batch(d, B, l, k, eps)
+    assert all(np.array_equal(xs[s].nzind, idx[:nnz[s], s]) for s in range(nsig))
+    with pytest.raises(cs.CsmpError):
+        d.ctx.gomp_batch(B, k + 1, k, eps)
+
+
+def test_solve_stops_at_the_qr_capacity_instead_of_failing(cs, oracle, D):
+    """omp(A, b, 0) with k = size(A,1) = 4096 on a signal no stopping rule ends used to run ~3900 steps and then
+    fail with ERANGE, losing the work.  Now the append that would not fit is withheld: the call returns CSMP_WCAPACITY (a
+    warning) with the solution reached at the capacity; the step-level API reports CSMP_STOP_CAPACITY."""
+    lib = cs._lib
+    rng = np.random.default_rng(41)
+    A = rng.standard_normal((4096, 4608)).astype(np.float32)
+    A /= np.linalg.norm(A.astype(np.float64), axis=0).astype(np.float32)
+    y = rng.standard_normal(4096)  # dense in every atom: the residual never reaches 0 before the support is full
+    d = D(A)
+    idx, val, order = d.ctx.omp(y, 4096, 0.0)
+    assert d.ctx.last_status == lib.WCAPACITY
+    cap = len(idx)
+    assert 3800 <= cap < 4096 and len(set(idx.tolist())) == cap
+    AS = A[:, idx].astype(np.float64)
+    r = y - AS @ val
+    assert np.abs(AS.T @ r).max() < 1e-8 * np.linalg.norm(y)  # the least-squares solution on the support reached
+    ref = oracle.omp(A, y, 48, 0.0)  # OMP is greedy: the first 48 selections are the k = 48 solve
+    assert np.array_equal(order[:48], ref[2])
+    # a smaller request on the same context is unaffected
+    i2, v2, o2 = d.ctx.omp(y, 48, 0.0)
+    assert d.ctx.last_status == lib.OK and np.array_equal(o2, ref[2]) and close(v2, ref[1])
+    # batch form: the warning, and every signal cut at the same capacity
+    B = np.asfortranarray(np.stack([y, -y[::-1].copy()], axis=1))
+    bi, bv, bn = d.ctx.omp_batch(B, 4096, 0.0)
+    assert d.ctx.last_status == lib.WCAPACITY and bn[0] == cap and bn[1] == cap
+    assert np.array_equal(bi[:cap, 0], idx)
+
+
 def test_capacity_growth_does_not_disable_the_removal_solvers(cs, oracle, D):
     """A call that grows the solver slot past 1023 columns (sp with 2k = 1024) must not make every later
     srr / ompr / rmp / foba / solver_remove on the same Dictionary fail: the slot is rebuilt at the size they need."""
