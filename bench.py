@@ -85,10 +85,11 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="statistical", help="--workload batched: CSMP_OPT_BATCH_CERT")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
-    p.add_argument("--workload", choices=["omp", "batched", "gomp", "sp", "fr", "ompr", "srr", "colsharded"], default="omp",
+    p.add_argument("--workload", choices=["omp", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
+    p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
@@ -341,6 +342,21 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         atoms, iters = int(on[W:].sum().item()), 0
         sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
         D5.ctx.profile_enable(False)
+    elif workload == "sp":
+        # the caller's loop over signals as ONE call: csmp_sp_batch keeps several solves in flight (contexts on their own streams
+        # and host threads); the signals are handed over as a host matrix, as csmp_sp takes its b
+        import numpy as np
+        Bh = np.asfortranarray(np.stack(sigs, axis=1))
+        if W:
+            D5.ctx.sp_batch(Bh[:, :W], k, delta)
+        D5.ctx.profile_enable(True)
+        D5.ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        bi, bv, bn, bits = D5.ctx.sp_batch(Bh[:, W:], k, delta)
+        dt = time.perf_counter() - t0
+        atoms, iters = int(bn.sum()), int(bits.sum())
+        sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
+        D5.ctx.profile_enable(False)
     else:
         for w in range(W):
             solve(sigs[w])
@@ -359,13 +375,14 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
     avg = sweep_ms / max(sweeps, 1) / 1e3
     isg = workload in ("gomp", "gomp_single")
     out = {"metric": ("GOMP (S=4) atoms selected/sec" + (", two solves in flight (csmp_gomp_batch)" if workload == "gomp" else ", one gomp call at a time")
-                      if isg else "Subspace Pursuit solves/sec") + " at m=8192,n=131072,k=512",
+                      if isg else "Subspace Pursuit solves/sec" + (", several solves in flight (csmp_sp_batch)" if workload == "sp" else ", one sp call at a time"))
+           + " at m=8192,n=131072,k=512",
            "value": (atoms / dt) if isg else K / dt, "unit": "atoms/s" if isg else "solves/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
            "config": {"workload": f"configs[4]: {workload} on A 8192x131072 Float32 Gaussian unit-norm, k=512" + (", S=4" if isg else f", delta={delta:g}"),
-                      "sweeps": int(sweeps), "sp_update_calls": int(iters), "sp_update_calls_per_solve": iters / K if workload == "sp" else None,
-                      "signals_in_flight": 2 if workload == "gomp" else 1},
+                      "sweeps": int(sweeps), "sp_update_calls": int(iters), "sp_update_calls_per_solve": iters / K if workload in ("sp", "sp_single") else None,
+                      "signals_in_flight": 2 if workload == "gomp" else (D5.ctx.get_option("solves_in_flight") if workload == "sp" else 1)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
@@ -381,6 +398,14 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         r["note"] = ("achieved / frac = ALL-IN (M*N*4 bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
                      "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)")
     if workload == "sp":
+        r = out["roofline"]  # (as for gomp: overlapping solves share the HBM, a per-launch duration measures the sharing)
+        r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
+        nsweep = K + iters  # one sweep per acquisition: the first one and one per update!
+        r["achieved"] = alg * nsweep / dt / 1e9
+        r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        r["note"] = ("achieved / frac = ALL-IN: M*N*4 bytes per acquisition sweep x sweeps / wall time of the batch -- the share of the HBM roofline "
+                     "the whole solves reach; sp_c5_single has the sweep kernel alone")
+    if workload == "sp_single":
         # the factorisations beside the sweeps: the first acquisition factorises k columns, every update! 2k and then k
         # (src/twostage.jl:74-83,104-107); thin QR of n columns = 2 M n^2 flop.  Time = the solves minus their sweeps.
         flop = 2.0 * M5 * (K * k * k + iters * ((2 * k) ** 2 + k * k))
@@ -631,11 +656,15 @@ def main():
         if rank == 0 and out and "error" in out:
             sys.exit(3)
         return
-    if args.workload in ("gomp", "sp"):
+    if args.workload in ("gomp", "sp", "gomp_single", "sp_single"):
         if args.steps == 18 and args.warmup == 3:
-            args.steps, args.warmup = 3, 1
+            args.steps, args.warmup = (9, 3) if args.workload in ("gomp", "sp") else (3, 1)
         if rank == 0:
-            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev)), flush=True)
+            At5, D5 = make_dictionary5(cs, torch, dev)
+            if args.in_flight:
+                D5.ctx.set_option("solves_in_flight", args.in_flight)
+            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5)), flush=True)
+            D5.close()
         return finish()
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
@@ -778,8 +807,9 @@ def main():
                 At5, D5 = make_dictionary5(cs, torch, dev)
                 sec["gomp_c5"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5)
                 sec["gomp_c5_single"] = measure_config5("gomp_single", 2, 1, cs, torch, dev, D5, At5)
-                sec["sp_c5"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5)
-                sec["sp_c5_default_delta"] = measure_config5("sp", 3, 1, cs, torch, dev, D5, At5, delta=1e-12)
+                sec["sp_c5"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5)
+                sec["sp_c5_single"] = measure_config5("sp_single", 3, 1, cs, torch, dev, D5, At5)
+                sec["sp_c5_default_delta"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, delta=1e-12)
                 D5.close()
             except Exception as e:  # noqa: BLE001
                 sec["config5"] = {"error": repr(e)}

@@ -19,10 +19,10 @@ HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL, STOP_CAPACITY = 1, 2, 4, 8
 # csmp_set_option keys (include/csmp.h)
-OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE = 1, 2, 3, 4, 5, 6, 7, 8
+OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
            "force_reorth": OPT_FORCE_REORTH, "ls_gram": OPT_LS_GRAM, "ls_gram_reuse": OPT_LS_GRAM_REUSE,
-           "twostage_update": OPT_TWOSTAGE_UPDATE}
+           "twostage_update": OPT_TWOSTAGE_UPDATE, "solves_in_flight": OPT_SOLVES_IN_FLIGHT}
 
 i64 = C.c_int64
 vp = C.c_void_p
@@ -61,6 +61,7 @@ SIGNATURES = {
     "csmp_ompr": (C.c_int, [vp, vp, C.c_int, i64, C.c_double, i64, vp, vp, C.POINTER(i64), C.POINTER(i64)]),
     "csmp_omp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_gomp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, i64, C.c_double, vp, vp, vp, C.c_int]),
+    "csmp_sp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, i64, C.c_double, i64, vp, vp, vp, vp]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
@@ -387,6 +388,22 @@ class Context:
         code = F32 if B.dtype == torch.float32 else F64
         self.call("csmp_gomp_batch", vp(B.data_ptr()), code, i64(M), i64(nsig), DEVICE, i64(int(l)), i64(int(k)), C.c_double(eps),
                   vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
+
+    def sp_batch(self, B, k, delta=1e-12, maxiter=-1):
+        """Host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz, iters): sp for every column, several solves in flight."""
+        B = np.asfortranarray(B)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        M, nsig = B.shape
+        if M != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {M} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), nsig), np.int64, order="F")
+        val = np.zeros((int(k), nsig), np.float64, order="F")
+        nnz = np.zeros(nsig, np.int64)
+        its = np.zeros(nsig, np.int64)
+        self.call("csmp_sp_batch", ptr(B), dtype_code(B.dtype), i64(M), i64(nsig), i64(int(k)), C.c_double(delta), i64(int(maxiter)),
+                  ptr(idx), ptr(val), ptr(nnz), ptr(its))
+        return idx, val, nnz, its
 
     def fr_batch(self, B, k, max_eps=0.0, min_delta=0.0):
         """fr for every column of the host matrix B (M x nsig, column-major) -> (idx k x nsig, val, nnz)."""

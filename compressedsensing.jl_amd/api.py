@@ -289,6 +289,17 @@ def gomp_batch(A, B, l, k, eps=None):
             D.close()
 
 
+def sp_batch(A, B, k, delta=1e-12, maxiter=None):
+    """[sp(A, B[:, s], k, delta; maxiter) for s in axes(B, 2)] on one GPU (several solves in flight): list of SparseVectors."""
+    D, tmp = _dict(A)
+    try:
+        idx, val, nnz, its = D.ctx.sp_batch(B, int(k), float(delta), -1 if maxiter is None else int(maxiter))
+        return [SparseVector(D.shape[1], idx[:n, s], val[:n, s]) for s, n in enumerate(nnz)]
+    finally:
+        if tmp:
+            D.close()
+
+
 def fr_batch(A, B, k, max_eps=0.0, min_delta=0.0):
     """[fr(A, B[:, s], max_eps, min_delta, k) for s in axes(B, 2)]: list of SparseVectors (pipelined on the device)."""
     D, tmp = _dict(A)

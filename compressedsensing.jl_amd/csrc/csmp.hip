@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace csmp;
@@ -128,7 +129,8 @@ struct csmp_ctx {
     void* dA = nullptr;
     bool ownA = false;
     struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
-    csmp_ctx* twin = nullptr;     // csmp_gomp_batch: a clone on its own stream (the second solve in flight)
+    csmp_ctx* twins[3] = {nullptr, nullptr, nullptr};  // clones on their own streams: the other solves in flight of csmp_gomp_batch / csmp_sp_batch
+    int opt_in_flight = 3;        // CSMP_OPT_SOLVES_IN_FLIGHT (csmp_sp_batch)
     hipEvent_t ev_twin = nullptr;
     int dtype = CSMP_F32;
     int64_t M = 0, N = 0, ld = 0;
@@ -316,8 +318,10 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         solver_free(ctx->s);
     }
     batch_free(ctx->bt, false);
-    if (ctx->twin) (void)csmp_destroy(ctx->twin);
-    ctx->twin = nullptr;
+    for (auto& t : ctx->twins) {
+        if (t) (void)csmp_destroy(t);
+        t = nullptr;
+    }
     if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
     dict_release(ctx);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
@@ -375,6 +379,7 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_BATCH_GRAM: *lo = 0; *hi = 1; return &ctx->opt_batch_gram;
         case CSMP_OPT_BATCH_WINDOW: *lo = 0; *hi = kWinMax; return &ctx->opt_batch_window;
         case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
+        case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
         default: return nullptr;
     }
 }
@@ -591,9 +596,9 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
     HIPCHECK(hipSetDevice(ctx->dev));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    if (ctx->twin) {  // (the twin of csmp_gomp_batch holds the previous dictionary)
-        (void)csmp_destroy(ctx->twin);
-        ctx->twin = nullptr;
+    for (auto& t : ctx->twins) {  // (the twins of the batch drivers hold the previous dictionary)
+        if (t) (void)csmp_destroy(t);
+        t = nullptr;
     }
     dict_release(ctx);  // (clones that still hold the previous dictionary keep it alive)
     HIPCHECK(sync_all(ctx));
@@ -2046,6 +2051,22 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
 // the twin's first sweep is held back until this context's first sweep has finished, so that the two chains run OUT of
 // phase: each signal's short stages fall under the other's sweep (in phase they would fall on each other).  Results are
 // those of csmp_gomp signal by signal (the same kernels in the same order on each stream).
+// the first n twins exist and carry this context's options
+static int twins_ensure(csmp_ctx* ctx, int n) {
+    for (int t = 0; t < n; ++t) {
+        if (!ctx->twins[t]) {
+            const int rc = csmp_clone(ctx, &ctx->twins[t]);
+            if (rc != CSMP_OK) return rc;
+        }
+        csmp_ctx* c = ctx->twins[t];
+        c->force_reorth = ctx->force_reorth;
+        c->opt_ls_gram = ctx->opt_ls_gram;
+        c->opt_ls_gram_reuse = ctx->opt_ls_gram_reuse;
+        c->opt_twostage_update = ctx->opt_twostage_update;
+    }
+    return CSMP_OK;
+}
+
 static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l, int64_t k, double eps, bool block, int64_t* d_idx,
                         double* d_val, int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
     int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
@@ -2073,12 +2094,8 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     if (nsig == 0) return CSMP_OK;
     HIPCHECK(hipSetDevice(ctx->dev));
-    if (!ctx->twin) {
-        const int rc = csmp_clone(ctx, &ctx->twin);
-        if (rc != CSMP_OK) return rc;
-    }
-    csmp_ctx* cc[2] = {ctx, ctx->twin};
-    cc[1]->force_reorth = ctx->force_reorth;
+    CHECK(twins_ensure(ctx, 1));
+    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // at most k atoms are ever added (GOMP's own capacity is M: :108)
     for (int q = 0; q < 2; ++q) {
         const int rc = solver_ensure(cc[q], kc, (int)(k + l));
@@ -2485,6 +2502,53 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     }
     if (nnz) *nnz = (int64_t)xi.size();
     if (iters) *iters = it;
+    return CSMP_OK;
+}
+
+// sp for many signals: up to four solves in flight, each on a context (this one + clones on their own streams) driven by its own
+// host thread.  A Subspace Pursuit solve is two HBM-bound sweeps and a long chain of short kernels with five host round trips
+// (factorisations, selections, the pruning decision): one solve leaves most of the chip idle most of the time, and another
+// signal's solve fills it.  Signal s is solved by context s mod T with the single-signal driver itself: results are csmp_sp's.
+extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int64_t k, double delta, int64_t maxiter,
+                             int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!B || nsig < 0 || k < 1 || ldB < ctx->M || !idx || !val || !nnz) return fail(ctx, CSMP_EINVAL, "sp_batch: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
+    if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->opt_in_flight, 4), nsig));
+    CHECK(twins_ensure(ctx, T - 1));
+    csmp_ctx* cc[4] = {ctx, ctx->twins[0], ctx->twins[1], ctx->twins[2]};
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    int rcs[4] = {CSMP_OK, CSMP_OK, CSMP_OK, CSMP_OK};
+    auto work = [&](int t) {
+        std::vector<int64_t> ti((size_t)2 * k);
+        std::vector<double> tv((size_t)2 * k);
+        for (int64_t sgn = t; sgn < nsig && rcs[t] == CSMP_OK; sgn += T) {
+            int64_t n = 0, it = 0;
+            const char* col = (const char*)B + (size_t)sgn * (size_t)ldB * es;
+            rcs[t] = csmp_sp(cc[t], col, b_dtype, k, delta, maxiter, ti.data(), tv.data(), &n, &it);
+            if (rcs[t] != CSMP_OK) break;
+            for (int64_t q = 0; q < k; ++q) {
+                idx[sgn * k + q] = q < n ? ti[q] : -1;
+                val[sgn * k + q] = q < n ? tv[q] : 0.0;
+            }
+            nnz[sgn] = std::min<int64_t>(n, k);
+            if (iters) iters[sgn] = it;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; ++t)
+        if (rcs[t] != CSMP_OK) {
+            if (t) ctx->err = cc[t]->err;
+            return rcs[t];
+        }
     return CSMP_OK;
 }
 

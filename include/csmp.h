@@ -182,6 +182,15 @@ int csmp_fr_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
 int csmp_gomp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t l, int64_t k,
                     double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);
 
+/* sp(A, B[:,s], k, delta; maxiter) for s = 0..nsig-1 (src/twostage.jl:87-101 in the caller's loop).  B: HOST matrix M x nsig
+ * (ldB elements); idx / val: k x nsig host arrays (tail -1 / 0), nnz and iters (may be NULL): nsig.  Up to
+ * CSMP_OPT_SOLVES_IN_FLIGHT solves run at once, each on its own context (this one and internal clones), stream and host
+ * thread: a Subspace Pursuit solve is two dictionary sweeps and a long chain of short kernels with host round trips, and
+ * another signal's solve fills the GPU it leaves idle.  Signal s is solved by csmp_sp itself: identical results.
+ * The only entry point that starts threads; the ctx must not be used by the caller while it runs. */
+int csmp_sp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int64_t k, double delta, int64_t maxiter,
+                  int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
+
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
  * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
  * SCREENS: per signal the candidates whose screened value could still be the exact maximum are rescored in
@@ -224,6 +233,7 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 #define CSMP_OPT_LS_GRAM_REUSE 7   /* 1 (default): a set inside the last factorised one gathers its Gram matrix from the kept copy */
 #define CSMP_OPT_TWOSTAGE_UPDATE 8 /* ompr's exchange step: 0 (default) explicit inverse T = R^-1 beside R, 1 Givens down-date of R,
                                       2 refactorise from scratch (the reference's own cost model, src/twostage.jl:171-174) */
+#define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
 int csmp_set_option(csmp_ctx *ctx, int key, int64_t value);
 int csmp_get_option(csmp_ctx *ctx, int key, int64_t *value);
 

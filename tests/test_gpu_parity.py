@@ -1208,10 +1208,11 @@ def test_options_at_the_abi(cs, D):
     d = D(A)
     c = d.ctx
     defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
-                "twostage_update": 0}
+                "twostage_update": 0, "solves_in_flight": 3}
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
-    for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1)):
+    for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
+                     ("solves_in_flight", 0)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -1425,6 +1426,36 @@ def test_gomp_batch_equals_single_calls(cs, oracle, D, cfg):
     assert all(np.array_equal(xs[s].nzind, idx[:nnz[s], s]) for s in range(nsig))
     with pytest.raises(cs.CsmpError):
         d.ctx.gomp_batch(B, k + 1, k, eps)
+
+
+@pytest.mark.parametrize("cfg", [(64, 256, 3, 5, np.float64), (640, 4096, 96, 7, np.float32)])
+def test_sp_batch_equals_single_calls(cs, oracle, D, cfg):
+    """csmp_sp_batch (several solves in flight, one context + host thread each) = csmp_sp signal by signal = the oracle; every
+    in-flight count gives the same answer."""
+    n, m, k, nsig, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + k, dtype=dtype)
+    d = D(A)
+    rng = np.random.default_rng(nsig)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k + (s % 3), rng=rng).to_dense(), 0.05 * (s % 2) + 5e-3, rng=rng)
+                                    for s in range(nsig)], axis=1))
+    first = None
+    for flight in (3, 1, 2, 4):
+        d.ctx.set_option("solves_in_flight", flight)
+        idx, val, nnz, its = d.ctx.sp_batch(B, k, 1e-12)
+        if first is None:
+            first = (idx.copy(), val.copy(), nnz.copy(), its.copy())
+            for s in range(nsig):
+                ref = oracle.sp(A, B[:, s], k, 1e-12)
+                one = d.ctx.sp(B[:, s], k, 1e-12)
+                assert nnz[s] == len(ref[0]) == k and its[s] == ref[2] == one[2], (s, its[s], ref[2])
+                assert np.array_equal(idx[:, s], ref[0]) and np.array_equal(idx[:, s], one[0])
+                assert close(val[:, s], ref[1]) and np.allclose(val[:, s], one[1], rtol=1e-12, atol=0)
+        else:
+            assert np.array_equal(idx, first[0]) and np.array_equal(nnz, first[2]) and np.array_equal(its, first[3])
+            assert np.allclose(val, first[1], rtol=1e-12, atol=0)
+    d.ctx.set_option("solves_in_flight", 3)
+    xs = cs.sp_batch(d, B, k)
+    assert all(np.array_equal(xs[s].nzind, first[0][:, s]) for s in range(nsig))
 
 
 def test_solve_stops_at_the_qr_capacity_instead_of_failing(cs, oracle, D):
