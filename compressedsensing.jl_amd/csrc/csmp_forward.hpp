@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick_fr(const TickFr<TA> sw, 
     }
 }
 
+#ifdef CSMP_EXPERIMENTS  // superseded by k_fr_rebuild (Q'A on the Float64 matrix cores, below)
 // Maintenance pass with FOUR directions and no residual image: rho2_j += sgn * sum_d <a_j, q0 + d*qstride>^2.
 // Rebuilds the rescaling of a support that was factorised in bulk (srr's oblivious initialisation): a
 // quarter of the dictionary passes that one direction at a time would take.  Same pipeline as
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_fr_update4(
         if (col >= N) col = -1;
     }
 }
+#endif
 
 // Bulk form of the same maintenance on the Float64 matrix cores: rho2_j -= sum_{d < nd} <a_j, q_{d0+d}>^2 for up to
 // 128 directions in ONE pass over the dictionary (k_fr_update4 needs nd/4 passes).  G = Q'A is a genuine GEMM here

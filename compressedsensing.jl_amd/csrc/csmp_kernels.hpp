@@ -1446,6 +1446,7 @@ __global__ __launch_bounds__(64) void k_finish_w(const double* __restrict__ R, c
     }
 }
 
+#ifdef CSMP_EXPERIMENTS  // superseded by k_trsv_blk / k_trsv_upd / k_trsv_emit below; kept for tools/probes/finish_probe.hip
 // Blocked form for large supports (SP's 2k = 1024 columns: 4 MiB of R): 64 columns at a time.  Wave 0 solves
 // the 64 x 64 diagonal block with its rows in REGISTERS (all 64 loads of a lane issued at once, the chain is
 // readlane + fma only); then all 256 threads subtract the block's contribution from the rows above it --
@@ -1529,6 +1530,7 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
         if (flag_out) *flag_out = st->done;
     }
 }
+#endif
 
 // ---- the back substitution for LARGE supports, over several CUs.  One workgroup cannot stream R faster than one CU reads memory
 // (24 GB/s from HBM, ~60 GB/s from L2: tools/probes/finish_probe.hip -- 4 MiB of R at 1024 columns took 240 us in k_finish_b,

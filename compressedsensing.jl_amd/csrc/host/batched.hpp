@@ -1,0 +1,337 @@
+// host/batched.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// the batched (MFMA-screened) OMP driver.
+// ------------------------------------------------------------------------------------------ batched (MFMA-screened) OMP
+__global__ void k_absmax_f32(const float* __restrict__ A, int64_t n, float* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(A[i]));
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+__global__ void k_absmax_f64(const double* __restrict__ A, int64_t n, float* out) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, (float)fabs(A[i]));
+    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m * 1.0000002f));
+}
+
+// max_j |a_j|_2 (rounded up), one wave per column
+template <typename TA>
+__global__ __launch_bounds__(256) void k_colnorm_max(const TA* __restrict__ A, int64_t ld, int M, int64_t N, float* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    double acc = 0.0;
+    for (int m = lane; m < M; m += 64) {
+        const double v = (double)A[col * ld + m];
+        acc = fma(v, v, acc);
+    }
+    for (int s = 32; s >= 1; s >>= 1) acc += __shfl_xor(acc, s, 64);
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint((float)sqrt(acc) * 1.0000002f));
+}
+
+static int batch_dict(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.ab_valid) return CSMP_OK;
+    // K is padded (zeros) to an even number of 64-deep tiles, at least four: what the eight-phase screening kernel needs
+    b.Mk = (int)std::max<int64_t>(256, ((ctx->M + 127) / 128) * 128);
+    b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles
+    b.n_atiles = (int)(b.Npad / kBT);
+    HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
+    HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
+    HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+    const int64_t total = b.Npad * (b.Mk / 8);
+    const int grid = (int)((total + 255) / 256);
+    const int64_t nel = ctx->ld * ctx->N;
+    if (ctx->dtype == CSMP_F32) {
+        hipLaunchKernelGGL(k_b_convert<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+        hipLaunchKernelGGL(k_absmax_f32, dim3(2048), dim3(256), 0, ctx->stream, (const float*)ctx->dA, nel, b.amax);
+    } else {
+        hipLaunchKernelGGL(k_b_convert<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+        hipLaunchKernelGGL(k_absmax_f64, dim3(2048), dim3(256), 0, ctx->stream, (const double*)ctx->dA, nel, b.amax);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&b.amax_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.ab_valid = true;
+    return CSMP_OK;
+}
+
+// max_j |a_j|_2 (the deterministic screening bound), computed on first use
+static int batch_colnorm(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.anorm_host >= 0.f) return CSMP_OK;
+    HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+    const unsigned grid = (unsigned)((ctx->N + 3) / 4);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_colnorm_max<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+    else
+        hipLaunchKernelGGL(k_colnorm_max<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.amax);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(&b.anorm_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
+}
+
+static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
+    Batch& b = ctx->bt;
+    const int Bpad = ((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);
+    if (b.Bcap >= Bpad && b.kcap >= kcap) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int nb = std::max(Bpad, b.Bcap), nk = std::max(kcap, b.kcap);
+    batch_free(b, true);
+    b.Bcap = nb;
+    b.kcap = nk;
+    b.Mr = (int)(((ctx->M + 3) / 4) * 4);
+    CHECK(dmalloc(ctx, &b.Rb, (size_t)nb * b.Mk));
+    CHECK(dmalloc(ctx, &b.r, (size_t)nb * b.Mr));
+    CHECK(dmalloc(ctx, &b.b, (size_t)nb * b.Mr));
+    CHECK(dmalloc(ctx, &b.T, (size_t)nb * nk * nk));
+    CHECK(dmalloc(ctx, &b.Tt, (size_t)nb * nk * nk));
+    CHECK(dmalloc(ctx, &b.z, (size_t)nb * nk));
+    CHECK(dmalloc(ctx, &b.sel, (size_t)nb * nk));
+    CHECK(dmalloc(ctx, &b.bs, (size_t)nb));
+    CHECK(dmalloc(ctx, &b.pick, (size_t)nb));
+    CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
+    CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
+    return CSMP_OK;
+}
+
+// G = A'A, Float64 products of the exactly promoted dictionary values, upper triangle (row <= column) of an N x N array:
+// the option CSMP_OPT_BATCH_GRAM.  8 N^2 bytes (32 GiB at N = 65536) and 2 M N^2 / 2 flops on the Float64 matrix cores
+// (k_gram, csmp_gram.hpp: the dictionary is its own "compact copy") -- once per dictionary, like the bf16 image.
+static int batch_gram(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.gram_valid) return CSMP_OK;
+    const int64_t N = ctx->N;
+    size_t free_b = 0, total_b = 0;
+    HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = (size_t)N * (size_t)N * sizeof(double);
+    if (need + ((size_t)1 << 30) > free_b) return fail(ctx, CSMP_ENOMEM, "CSMP_OPT_BATCH_GRAM: 8 N^2 bytes of HBM are not available");
+    HIPCHECK(hipMalloc((void**)&b.Gm, need));
+    // k_gram tiles are 128 x 64 over np columns; np = N need not be a multiple of the tile: rows / columns >= np are clamped and
+    // never stored.  One slice of the rows (no partials): rows_per_split = the whole column, which the kernel walks in blocks of
+    // 16 rows -- a dictionary whose leading dimension is not a multiple of 16 goes through a zero-padded temporary copy.
+    const int np = (int)N;
+    const size_t es = ctx->dtype == CSMP_F32 ? 4 : 8;
+    const int rows = (int)((ctx->M + 15) / 16 * 16);
+    const void* src = ctx->dA;
+    int64_t ldo = ctx->ld;
+    DevTmp padded;
+    if (ctx->ld % 16 != 0) {
+        ldo = rows;
+        HIPCHECK(padded.alloc((size_t)ldo * (size_t)N * es));
+        HIPCHECK(hipMemsetAsync(padded.p, 0, (size_t)ldo * (size_t)N * es, ctx->stream));
+        HIPCHECK(hipMemcpy2DAsync(padded.p, (size_t)ldo * es, ctx->dA, (size_t)ctx->ld * es, (size_t)ctx->M * es, (size_t)N, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+        src = padded.p;
+    }
+    const dim3 grid((unsigned)((np + kGramWgJ - 1) / kGramWgJ), (unsigned)((np + kGramWgI - 1) / kGramWgI), 1);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_gram<float>, grid, dim3(256), 0, ctx->stream, (const float*)src, ldo, np, rows, b.Gm);
+    else
+        hipLaunchKernelGGL(k_gram<double>, grid, dim3(256), 0, ctx->stream, (const double*)src, ldo, np, rows, b.Gm);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.Ng = N;
+    b.gram_valid = true;
+    return CSMP_OK;
+}
+
+template <typename TA>
+static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
+                                int kwin) {
+    Batch& b = ctx->bt;
+    constexpr int U = sizeof(TA) == 4 ? 16 : 8;  // 64-lane chunks of a column in flight per wave (16 bytes per lane each)
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
+    auto kern = k_b_pick<TA, U>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)b.cand_val,
+                       (const int*)b.cand_idx, b.n_atiles * kTileCand, (const int*)b.sel, b.bs, b.pick, (const double*)b.r, b.Mr, b.kcap, (int)ctx->M, eps,
+                       check_eps, cert_abs, cert_rel, kwin, sig0);
+    return hipGetLastError();
+}
+// DEPTH of the append kernel: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
+template <typename TA, int NI, bool GRAM>
+static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig) {
+    Batch& b = ctx->bt;
+    constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
+    const size_t lds = b_append_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
+    auto kern = k_b_append<TA, NI, DEPTH, GRAM>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const double*)b.Gm, b.Ng, (const BPick*)b.pick, b.T,
+                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0);
+    return hipGetLastError();
+}
+template <typename TA>
+static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
+                                  int kwin, bool gram) {
+    const int groups = (ctx->Mv + 1023) / 1024;
+    hipError_t e = b_pick_launch<TA>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin);
+    if (e != hipSuccess) return e;
+#define CSMP_BSTEP(NI)                                                                                                  \
+    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig);
+    if (groups <= 1) { CSMP_BSTEP(1) }
+    if (groups <= 2) { CSMP_BSTEP(2) }
+    if (groups <= 4) { CSMP_BSTEP(4) }
+    CSMP_BSTEP(8)
+#undef CSMP_BSTEP
+}
+
+extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                                   double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (!B || nsig < 1 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch_mfma: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (ctx->Mv > 8192) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: M > 8192 not supported (use csmp_omp_batch)");
+    if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    CHECK(batch_dict(ctx));
+    CHECK(batch_ensure(ctx, (int)nsig, kc));
+    CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals
+    ctx->s.begun = false;
+    Batch& b = ctx->bt;
+    const bool gram = ctx->opt_batch_gram != 0;
+    if (gram) CHECK(batch_gram(ctx));
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    DevTmp tB, tIdx, tVal, tNnz;  // freed on every return path
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
+    }
+    const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
+    if (b_dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+    else
+        hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+    HIPCHECK(hipGetLastError());
+    // Screening error bound  | |<a_n, r>| - s_n | <= cert_abs |r| + cert_rel s_n  (k_b_pick, csmp_batched.hpp).
+    // Statistical (default): 8 standard deviations of the bf16 rounding model -- independent roundings of the M products,
+    // sigma = sqrt(2/3) 2^-9 max|A_ij| |r| -- PLUS the fully coherent case the independent model misses: an operand whose
+    // entries all round the same way is a scaled operand, (1 + a)(1 + b) s with |a|, |b| <= 2^-8 (few-valued and one-magnitude
+    // dictionaries: every entry of a column rounds alike), i.e. 2^-7 s, plus the 2^-15 the packed candidate keys drop.
+    // Rigorous (CSMP_OPT_BATCH_CERT = 1): |<a,r> - screened| <= (2^-7 (1 + 2^-9) + Mk 2^-24) |a|_2 |r|_2 (bf16 unit roundoff
+    // 2^-8 on both operands, Float32 accumulation) with the largest column norm, and the key truncation: a proof, about nine
+    // times wider on a Gaussian dictionary -- the window holds more candidates (64 instead of 16), more signals overflow it.
+    double cert_abs, cert_rel;
+    int kwin;
+    if (ctx->opt_batch_cert == 1) {
+        CHECK(batch_colnorm(ctx));
+        cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+        cert_rel = std::ldexp(1.0, -14);
+        kwin = kWinMax;  // 128
+    } else {
+        cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+        cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -14);
+        kwin = kWinMax / 2;  // 64
+    }
+    if (ctx->opt_batch_window > 0) kwin = std::min<int>(kWinMax, (int)ctx->opt_batch_window);
+    if (tune_env("CSMP_CERT_NOREL")) cert_rel = std::ldexp(1.0, -14);  // (experiments build: the round-2 bound, for tools/probe_structured.py)
+    b.last_mode = kScreen256p;
+    b.last_streams = 1;
+    b.last_screen_signals = Bpad;
+    for (int64_t t = 0; t < k; ++t) {
+        const bool timed = ctx->prof;  // (HIP events around the screening launch)
+        if (timed) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        HIPCHECK(launch_screen(ctx->stream, (const __bf16*)b.Ab, (const __bf16*)b.Rb, b.Mk, b.n_atiles, Bpad / kBT, ctx->N, b.cand_val, b.cand_idx));
+        if (timed) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram)
+                                              : b_step_dispatch<double>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram);
+        HIPCHECK(e);
+    }
+    hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
+                       (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);
+    HIPCHECK(hipGetLastError());
+    // signals whose screen could not be certified (or whose support turned ill-conditioned) are
+    // re-solved by the exact single-signal path
+    std::vector<BState> hs((size_t)nsig);
+    HIPCHECK(hipMemcpyAsync(hs.data(), b.bs, (size_t)nsig * sizeof(BState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.last_signals = nsig;
+    b.last_resolved = b.last_uncertain = b.last_illcond = 0;
+    int rc = CSMP_OK;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        if (!hs[sgn].uncertain && !hs[sgn].illcond) continue;
+        b.last_resolved += 1;
+        b.last_uncertain += hs[sgn].uncertain ? 1 : 0;
+        b.last_illcond += hs[sgn].illcond ? 1 : 0;
+        if (tune_env("CSMP_BATCH_DEBUG"))
+            fprintf(stderr, "signal %lld: uncertain %d illcond %d nsel %d | first failed certificate at step %d: window %d (cap %d), best exact %.6f, bound %.6f, top screened %.6f, |r| %.4f\n",
+                    (long long)sgn, hs[sgn].uncertain, hs[sgn].illcond, hs[sgn].nsel, hs[sgn].unc_step, hs[sgn].unc_nall, kwin, hs[sgn].unc_best,
+                    hs[sgn].unc_cb, hs[sgn].unc_s1, std::sqrt(hs[sgn].rnorm2));
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
+                                 : init_from_device_t<double>(ctx, (const double*)col);
+        for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0, false);
+        if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k);
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return rc;
+}
+
+// name of the screening kernel the last csmp_omp_batch_mfma call used (for the bench's roofline line)
+extern "C" const char* csmp_batch_screen_kernel(const csmp_ctx* ctx) { return ctx ? screen_kernel_name(ctx->bt.last_mode) : ""; }
+
+// how the last csmp_omp_batch_mfma call was laid out: signal columns per screening launch, streams used
+extern "C" int csmp_batch_layout(const csmp_ctx* ctx, int64_t* screen_signals, int* streams) {
+    if (!ctx) return CSMP_EINVAL;
+    if (screen_signals) *screen_signals = ctx->bt.last_screen_signals;
+    if (streams) *streams = ctx->bt.last_streams;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_batch_stats(csmp_ctx* ctx, int64_t* signals, int64_t* resolved_exactly, int64_t* uncertain, int64_t* illcond,
+                                int64_t* screen_launches, double* screen_ms) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->ev2_used; i += 2) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, ctx->ev2[i], ctx->ev2[i + 1]));
+        ctx->prof2_ms += ms;
+        ctx->prof2_n += 1;
+    }
+    ctx->ev2_used = 0;
+    if (signals) *signals = ctx->bt.last_signals;
+    if (resolved_exactly) *resolved_exactly = ctx->bt.last_resolved;
+    if (uncertain) *uncertain = ctx->bt.last_uncertain;
+    if (illcond) *illcond = ctx->bt.last_illcond;
+    if (screen_launches) *screen_launches = ctx->prof2_n;
+    if (screen_ms) *screen_ms = ctx->prof2_ms;
+    ctx->prof2_n = 0;
+    ctx->prof2_ms = 0.0;
+    return CSMP_OK;
+}

@@ -1,0 +1,204 @@
+// host/ctx.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// context, solver and batch state; error / allocation helpers.
+static std::string g_create_err;
+static constexpr int kRsEqCap = 4096;   // entries of the bucket list (exact ties beyond it: in-order scan)
+static constexpr int kRsSettle = 256;   // a bucket this small ends the passes (k_rs_finish ranks it in LDS)
+
+struct Solver {
+    int kcap = 0, outcap = 0;
+    int qcap = 0;  // capacity of the QR arrays: kcap, or 1 for a slot that so far served MP / sweep-only calls
+    int64_t ldq = 0;
+    int G = 0, Mpad = 0;
+    double *b = nullptr, *r = nullptr, *cvec = nullptr, *pval = nullptr;
+    int* pidx = nullptr;
+    double *Q = nullptr, *R = nullptr, *z = nullptr, *W1 = nullptr, *P1 = nullptr, *P2 = nullptr, *P2s = nullptr, *P1s = nullptr;
+    double *avec = nullptr, *vvec = nullptr, *coef = nullptr, *scal = nullptr;
+    int *sel = nullptr, *cands = nullptr, *ncands = nullptr;
+    // top-S selection scratch
+    double *top_lv = nullptr, *cvals = nullptr;
+    int *top_li = nullptr, *rs_gt = nullptr, *rs_eq = nullptr, *rs_work = nullptr;
+    RsState* rs = nullptr;
+    int top_nb = 0;
+    DevState* st = nullptr;
+    double* bstage = nullptr;  // Mpad doubles: host-uploaded b
+    int64_t *out_idx = nullptr, *out_order = nullptr, *out_nnz = nullptr;
+    double* out_val = nullptr;
+    int algo = -1;
+    bool begun = false;
+    int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
+    bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
+    int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
+    // multi-column append (csmp_block.hpp), allocated on first use
+    double *Apan = nullptr, *Vpan = nullptr, *PB1 = nullptr, *W1b = nullptr, *PG = nullptr, *Gsum = nullptr;
+    int* pan_atoms = nullptr;
+    int blk_kcap = 0;
+    int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
+    double *rho2 = nullptr, *dvec = nullptr;  // forward regression: OLS rescaling and δ² scores (N each), allocated on first use
+    int fr_grid = 0;
+    // column removal (csmp_downdate.hpp), allocated on first use
+    double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *qsave = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
+    int *delmeta = nullptr, *delpos = nullptr;
+    // explicit inverse factor of the two-stage solvers (csmp_tinv.hpp)
+    double *T = nullptr, *T2 = nullptr, *tpd = nullptr, *tpn = nullptr;
+    int* tmeta = nullptr;
+    int sigcap = 0;
+    // whole-set least squares (csmp_gram.hpp), allocated on first use
+    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr, *Dfac = nullptr;
+    // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
+    // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
+    double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
+    int* kpos = nullptr;
+    std::vector<int> keep_cols;
+    int keep_n = 0, keep_np = 0;
+    bool keep_valid = false;
+    void* Acomp = nullptr;  // the set's columns, contiguous (np columns of Mv elements of the dictionary's type)
+    int gram_np = 0, gram_split = 0;
+    void* extcol = nullptr;  // column-sharded OMP (csmp_shard.hpp): the winning column of a step, Mv elements of the dictionary's type
+};
+
+// device state of the batched (MFMA-screened) path
+struct Batch {
+    __bf16* Ab = nullptr;  // dictionary as bf16 [Npad][Mk]
+    bool ab_valid = false;
+    int Mk = 0;
+    int64_t Npad = 0;
+    int n_atiles = 0;
+    float* amax = nullptr;  // max |A_ij| (device scalar) for the screening error bound
+    float amax_host = 0.f;
+    float anorm_host = -1.f;  // max column 2-norm (the deterministic bound, CSMP_CERT=rigorous), computed on first use
+    // per-batch buffers
+    int Bcap = 0, kcap = 0, Mr = 0;
+    __bf16* Rb = nullptr;
+    double *r = nullptr, *b = nullptr, *T = nullptr, *Tt = nullptr, *z = nullptr;
+    int* sel = nullptr;
+    BState* bs = nullptr;
+    BPick* pick = nullptr;   // k_b_pick -> k_b_append hand-off, one per signal
+    double* Gm = nullptr;    // G = A'A (upper triangle of N x N), the option CSMP_OPT_BATCH_GRAM
+    int64_t Ng = 0;
+    bool gram_valid = false;
+    float* cand_val = nullptr;
+    int* cand_idx = nullptr;
+    int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
+    int last_mode = 0;  // screening kernel of the last batch (kScreen128 / kScreen256 / kScreenCo)
+    int64_t last_screen_signals = 0;  // signal columns of one (timed) screening launch of the last batch
+    int last_streams = 1;
+};
+
+// A library-owned copy of the dictionary is shared by the context that uploaded it and its clones (csmp_clone): the memory
+// lives until the LAST of them lets go (csmp_destroy, or csmp_set_dictionary replacing it), so a functor never sweeps freed
+// memory.  A BORROWED device pointer (zero-copy) stays the caller's to keep alive.
+struct DictShare {
+    void* p;
+    int refs;
+};
+
+struct csmp_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipDeviceProp_t prop{};
+    std::string err;
+    // page-locked host buffers for the small transfers on the latency chains (slot 0: the signal going up, slot 1: results and
+    // control words coming down): a copy from or to pageable memory is staged by the runtime and blocks the host for every piece
+    void* pin[3] = {nullptr, nullptr, nullptr};  // (slot 2: column lists going up)
+    size_t pin_bytes[3] = {0, 0, 0};
+    // dictionary
+    void* dA = nullptr;
+    bool ownA = false;
+    struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
+    csmp_ctx* twins[3] = {nullptr, nullptr, nullptr};  // clones on their own streams: the other solves in flight of csmp_gomp_batch / csmp_sp_batch
+    int opt_in_flight = 3;        // CSMP_OPT_SOLVES_IN_FLIGHT (csmp_sp_batch)
+    hipEvent_t ev_twin = nullptr;
+    int dtype = CSMP_F32;
+    int64_t M = 0, N = 0, ld = 0;
+    int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
+    int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
+    int sweep_grid = 0, sweep_U = 1;
+    int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
+    bool sweep_full = false, sweep_nt = false;
+    bool force_reorth = false;  // CSMP_OPT_FORCE_REORTH (test switch): always run the second Gram-Schmidt pass
+    // options (csmp_set_option, include/csmp.h)
+    int opt_batch_cert = 0;        // CSMP_OPT_BATCH_CERT: 0 statistical, 1 rigorous
+    int opt_batch_gram = 0;        // CSMP_OPT_BATCH_GRAM: resident G = A'A for csmp_omp_batch_mfma
+    int opt_batch_window = 0;      // CSMP_OPT_BATCH_WINDOW: rescoring window capacity, 0 = default
+    bool opt_ls_gram = true;       // CSMP_OPT_LS_GRAM: whole-set least squares by Gram + Cholesky
+    bool opt_ls_gram_reuse = true; // CSMP_OPT_LS_GRAM_REUSE
+    int opt_twostage_update = 0;   // CSMP_OPT_TWOSTAGE_UPDATE: 0 explicit inverse, 1 Givens down-date of R, 2 refactorise
+    size_t sweep_lds = 0;
+    Solver s;        // the ACTIVE solver slot (see activate_slot)
+    Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch
+    int active = 0;
+    bool pipeline = true;
+    int tick_wg_per_cu = 2;  // sweep workgroups per CU inside the tick kernel (CSMP_TICK_WGS)
+    bool tick_pf = true;     // software-pipelined sweep inside the tick kernel (CSMP_TICK_PF)
+    int tick_nblk = 0;       // absolute override of the sweep workgroup count (CSMP_TICK_NBLK), 0 = per-CU rule
+    bool tick_sweep_first = false;  // dispatch the sweep workgroups ahead of the append stages (CSMP_TICK_ORDER=1)
+    Batch bt;
+    // profiling
+    bool prof = false;
+    int prof_every = 1;       // time every n-th sweep launch only (an event pair costs a few us of stream time)
+    int64_t prof_count = 0;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    int64_t prof_n = 0;
+    double prof_ms = 0.0;
+    // second event pool: the batched path's screening GEMM
+    std::vector<hipEvent_t> ev2;
+    size_t ev2_used = 0;
+    int64_t prof2_n = 0;
+    double prof2_ms = 0.0;
+};
+
+#define HIPCHECK(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            char buf_[512];                                                                     \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                       \
+            ctx->err = buf_;                                                                    \
+            return CSMP_EHIP;                                                                   \
+        }                                                                                       \
+    } while (0)
+
+#define CHECK(expr)                  \
+    do {                             \
+        int rc_ = (expr);            \
+        if (rc_ != CSMP_OK) return rc_; \
+    } while (0)
+
+// Tuning switches exist only in the experiments build (`make experiments`, tools/probe_*.py); the product library reads no
+// environment variable: every behavioural choice is an argument or a csmp_set_option key (include/csmp.h).
+static const char* tune_env(const char* name) {
+#ifdef CSMP_EXPERIMENTS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
+static int fail(csmp_ctx* ctx, int code, const char* msg) {
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+template <typename T>
+static int dmalloc(csmp_ctx* ctx, T** p, size_t n) {
+    HIPCHECK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    return CSMP_OK;
+}
+template <typename T>
+static void dfree(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+// device temporary of one call: released on every return path (hipFree waits for the work that uses it)
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 1)); }
+};

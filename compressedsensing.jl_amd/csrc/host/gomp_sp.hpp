@@ -1,0 +1,699 @@
+// host/gomp_sp.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// multi-column append, top-S, gomp (+ batch form), whole-set least squares, Subspace Pursuit (+ batch form), primitives.
+// ------------------------------------------------------------------------------------------ multi-column append
+static int block_ensure(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.blk_kcap >= s.kcap && s.Apan) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
+    constexpr int nent = kPanelMax * kPanelMax + 2 * kPanelMax;
+    CHECK(dmalloc(ctx, &s.Apan, (size_t)kPanelMax * s.ldq));
+    CHECK(dmalloc(ctx, &s.Vpan, (size_t)kPanelMax * s.ldq));
+    CHECK(dmalloc(ctx, &s.PB1, (size_t)s.kcap * kPanelMax * s.G));
+    CHECK(dmalloc(ctx, &s.W1b, (size_t)s.kcap * kPanelMax));
+    CHECK(dmalloc(ctx, &s.PG, (size_t)nent * s.G));
+    CHECK(dmalloc(ctx, &s.Gsum, (size_t)nent));
+    CHECK(dmalloc(ctx, &s.pan_atoms, kPanelMax));
+    s.blk_kcap = s.kcap;
+    return CSMP_OK;
+}
+
+// add_column! for up to PB atoms cands[base .. base+want) at once (atoms already in the support are skipped)
+template <typename TA, int PB>
+static int launch_block_append_t(csmp_ctx* ctx, int base, int want, int skipmask) {
+    Solver& s = ctx->s;
+    const int jh = std::min(s.jh, s.kcap);
+    const size_t l1 = blk1_lds_bytes<PB>(), l2 = blk2_lds_bytes<PB>(), l3 = blk3_lds_bytes<PB>();
+    if (l1 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk1<TA, PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1));
+    if (l2 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk2<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2));
+    if (l3 > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_blk3<PB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l3));
+    const int csplit = std::max(1, std::min(std::min(4, ctx->prop.multiProcessorCount / std::max(1, s.G)), (jh + kWave - 1) / kWave));
+    hipLaunchKernelGGL((k_blk1<TA, PB>), dim3(s.G, csplit), dim3(kQrThreads), l1, ctx->stream, (const TA*)ctx->dA, ctx->ld, (int)ctx->M,
+                       (const double*)s.Q, s.ldq, s.st, (const int*)s.cands, (const int*)s.ncands, base, want, (const int*)s.sel,
+                       s.kcap, skipmask, s.Apan, s.PB1, s.G, s.pan_atoms);
+    HIPCHECK(hipGetLastError());
+    const int n1 = jh * PB;
+    if (n1 > 0) {
+        hipLaunchKernelGGL(k_red, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.PB1, s.W1b, n1, s.G, (int64_t)s.kcap * PB, (const DevState*)s.st, s.R, s.kcap, PB);
+        HIPCHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL((k_blk2<PB>), dim3(s.G), dim3(kQrThreads), l2, ctx->stream, (const double*)s.Q, s.ldq, (const DevState*)s.st,
+                       (const double*)s.Apan, (const double*)s.W1b, (const double*)s.r, s.Vpan, s.PG, s.G);
+    HIPCHECK(hipGetLastError());
+    constexpr int nent = blk2_nent<PB>();
+    hipLaunchKernelGGL(k_red, dim3((nent + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.PG, s.Gsum, nent, s.G, (int64_t)nent, (const DevState*)s.st, (double*)nullptr, 0, PB);
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL((k_blk3<PB>), dim3(s.G), dim3(kQrThreads), l3, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.Vpan,
+                       (const double*)s.Gsum, (const double*)s.W1b, s.r, s.R, s.z, s.sel, (const int*)s.pan_atoms, s.kcap);
+    HIPCHECK(hipGetLastError());
+    s.jh = std::min(s.kcap, s.jh + std::min(want, PB));
+    return CSMP_OK;
+}
+
+// panels of <= 32 atoms over cands[0 .. n)
+static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask) {
+    CHECK(block_ensure(ctx));
+    for (int base = 0; base < n;) {
+        const int want = std::min(n - base, kPanelMax);
+        int rc;
+        if (want <= 4)
+            rc = ctx->dtype == CSMP_F32 ? launch_block_append_t<float, 4>(ctx, base, want, skipmask)
+                                        : launch_block_append_t<double, 4>(ctx, base, want, skipmask);
+        else
+            rc = ctx->dtype == CSMP_F32 ? launch_block_append_t<float, kPanelMax>(ctx, base, want, skipmask)
+                                        : launch_block_append_t<double, kPanelMax>(ctx, base, want, skipmask);
+        CHECK(rc);
+        base += want;
+    }
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ top-S, GOMP, LS, SP
+// cands[0..S) <- the S atoms with the largest |c| (descending, ties by ascending index), on device
+static int launch_topS(csmp_ctx* ctx, int S) {
+    Solver& s = ctx->s;
+    if (S < 1 || S > s.kcap) return fail(ctx, CSMP_ERANGE, "top-S: S out of range");
+    if (S <= kTopSmall && (size_t)s.top_nb * S * sizeof(double) <= 48 * 1024) {
+        hipLaunchKernelGGL(k_top_local, dim3(s.top_nb), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, S, s.top_lv, s.top_li);
+        HIPCHECK(hipGetLastError());
+        const int n = s.top_nb * S;
+        hipLaunchKernelGGL(k_top_merge, dim3(1), dim3(256), (size_t)n * sizeof(double), ctx->stream, (const double*)s.top_lv,
+                           (const int*)s.top_li, n, S, s.cands, s.cvals, s.ncands);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
+    const int S_eff = (int)std::min<int64_t>(S, ctx->N);
+    const int grid = (int)std::min<int64_t>((ctx->N + 255) / 256, (int64_t)ctx->prop.multiProcessorCount * 4);
+    hipLaunchKernelGGL(k_rs_init, dim3(1), dim3(256), 0, ctx->stream, s.rs, S_eff);
+    // (few, fat workgroups: every workgroup flushes its non-empty bins with global atomics, and pass 0 -- the exponent -- puts
+    // all keys into a dozen bins)
+    const int hgrid = (int)std::min<int64_t>((ctx->N + 2047) / 2048, (int64_t)ctx->prop.multiProcessorCount);
+    for (int pass = 0; pass < kRsPasses; ++pass)  // (a settled selection turns the remaining launches into no-ops)
+        hipLaunchKernelGGL(k_rs_hist, dim3(hgrid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, kRsSettle);
+    hipLaunchKernelGGL(k_rs_collect, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, s.rs_gt, s.rs_eq, kRsEqCap);
+    const int pairs = S_eff <= 4096 ? S_eff : 0;  // (value, index) pairs of the final rank sort staged in LDS
+    const size_t lds = (size_t)pairs * 12 + 16 + (size_t)kRsEqCap * 12 + 16;
+    HIPCHECK(hipFuncSetAttribute((const void*)k_rs_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_rs_finish, dim3((S_eff + 255) / 256), dim3(256), lds, ctx->stream, (const double*)s.cvec, ctx->N, s.rs,
+                       (const int*)s.rs_gt, (const int*)s.rs_eq, kRsEqCap, s.rs_work, s.cands, s.cvals, s.ncands, pairs);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// update!(P::GOMP, x, l): src/matchingpursuit.jl:116-123
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block = false) {
+    l = std::min<int64_t>(l, ctx->N);
+    CHECK(launch_sweep(ctx, ctx->s.r, eps, check_eps, skipmask));
+    CHECK(launch_topS(ctx, (int)l));
+    if (block && l > 1) return launch_block_appends(ctx, (int)l, skipmask);  // the l atoms join the QR together
+    for (int64_t w = 0; w < l; ++w) CHECK(launch_append(ctx, 2, (int)w, skipmask));
+    return CSMP_OK;
+}
+
+extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, int64_t k, double eps, int64_t* idx,
+                         double* val, int64_t* nnz, int64_t* order) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:127
+    if (!b || k < 0 || l < 1) return fail(ctx, CSMP_EINVAL, "gomp: b == NULL, k < 0 or l < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    // GOMP(A,b,l): QR capacity M (:108,:128); at most k atoms are ever added, and top-l needs l slots
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(k, l), std::max<int64_t>(ctx->M, l)));
+    CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k + l, 1)));
+    ctx->s.begun = false;
+    // first with the multi-column append (the l atoms of a step join the QR in one panel); a panel
+    // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain
+    bool capacity_stop = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool block = pass == 0 && !ctx->force_reorth && l <= kPanelMax;
+        CHECK(upload_b(ctx, b, b_dtype));
+        const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
+        for (int64_t it = 0; it < k / l && !ctx->s.capped; ++it) {  // :130-133
+            CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));
+            if ((it + 1) % kPollSteps == 0 && it + 1 < k / l) {
+                bool stopped = false;
+                CHECK(solver_poll(ctx, &stopped));
+                if (stopped) break;  // (the remainder step below still runs, as in the reference)
+            }
+        }
+        const int64_t rem = k % l;                                                                             // :134
+        if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block));  // :135-137: runs even after an eps-break
+        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) {
+            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+            break;
+        }
+    }
+    CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
+    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+}
+
+// ---- gomp for many signals: TWO solves in flight, one per stream
+// One signal's step is a chain: the dictionary sweep (HBM-bound, 0.6 ms at config 5), then top-S and the panel append (eight
+// short kernels, ~55 us, a fraction of the chip) -- nothing of the same signal can run beside them.  Another signal's sweep
+// can: signals alternate between this context and a twin (a clone on its own stream), everything is enqueued up front, and
+// the twin's first sweep is held back until this context's first sweep has finished, so that the two chains run OUT of
+// phase: each signal's short stages fall under the other's sweep (in phase they would fall on each other).  Results are
+// those of csmp_gomp signal by signal (the same kernels in the same order on each stream).
+// the first n twins exist and carry this context's options
+static int twins_ensure(csmp_ctx* ctx, int n) {
+    for (int t = 0; t < n; ++t) {
+        if (!ctx->twins[t]) {
+            const int rc = csmp_clone(ctx, &ctx->twins[t]);
+            if (rc != CSMP_OK) return rc;
+        }
+        csmp_ctx* c = ctx->twins[t];
+        c->force_reorth = ctx->force_reorth;
+        c->opt_ls_gram = ctx->opt_ls_gram;
+        c->opt_ls_gram_reuse = ctx->opt_ls_gram_reuse;
+        c->opt_twostage_update = ctx->opt_twostage_update;
+    }
+    return CSMP_OK;
+}
+
+static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l, int64_t k, double eps, bool block, int64_t* d_idx,
+                        double* d_val, int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
+    int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
+    if (rc != CSMP_OK) return rc;
+    const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
+    for (int64_t it = 0; it < k / l && !c->s.capped; ++it) {  // src/matchingpursuit.jl:130-133
+        rc = gomp_update(c, l, eps, it > 0, main_skip, block);
+        if (rc != CSMP_OK) return rc;
+        if (it == 0 && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
+    }
+    const int64_t rem = k % l;
+    if (rem > 0) {  // :134-137: runs even after an eps-break
+        rc = gomp_update(c, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block);
+        if (rc != CSMP_OK) return rc;
+    }
+    return launch_finish(c, d_idx, d_val, d_nnz, nullptr, (int)k, d_flag);
+}
+
+extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t l, int64_t k,
+                               double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:127
+    if (!B || nsig < 0 || k < 1 || l < 1 || l > k || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "gomp_batch: bad arguments (needs 1 <= l <= k)");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(twins_ensure(ctx, 1));
+    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // at most k atoms are ever added (GOMP's own capacity is M: :108)
+    for (int q = 0; q < 2; ++q) {
+        const int rc = solver_ensure(cc[q], kc, (int)(k + l));
+        if (rc != CSMP_OK) {
+            if (q) ctx->err = cc[q]->err;
+            return rc;
+        }
+        cc[q]->s.begun = false;
+    }
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    DevTmp tB, tIdx, tVal, tNnz, tFlag;
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
+    }
+    HIPCHECK(tFlag.alloc((size_t)nsig * sizeof(int)));
+    int* d_flag = (int*)tFlag.p;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
+    if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+    const bool block = !ctx->force_reorth && l <= kPanelMax;
+    for (int64_t sgn = 0; sgn < nsig; ++sgn) {
+        csmp_ctx* c = cc[sgn & 1];
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
+        const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
+                                    sgn == 0 ? ctx->ev_twin : nullptr);
+        if (rc != CSMP_OK) {
+            if (c != ctx) ctx->err = c->err;
+            (void)hipStreamSynchronize(cc[0]->stream);
+            (void)hipStreamSynchronize(cc[1]->stream);
+            return rc;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(cc[1]->stream));
+    std::vector<int> hf((size_t)nsig);
+    HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    // a panel that failed its DGKS test flagged the solve (nothing committed): that signal again, column by column
+    int rc = CSMP_OK;
+    bool capacity_stop = false;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        if (hf[sgn] & STOP_REORTH) {
+            const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+            rc = gomp_enqueue(ctx, col, b_dtype, l, k, eps, false, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn, nullptr);
+            if (rc == CSMP_OK) {
+                HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHECK(hipStreamSynchronize(ctx->stream));
+                capacity_stop |= ctx->s.capped && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
+            }
+        }
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
+}
+
+// state reset + r = b for a fresh factorisation on the same b (SP re-factorises from scratch)
+static int solver_restart(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.b, (int)ctx->M, s.Mpad, s.bstage, s.r, s.st);
+    HIPCHECK(hipGetLastError());
+    s.jh = 0;
+    return CSMP_OK;
+}
+
+// factorize! + ldiv! (src/matchingpursuit.jl:219-227, src/twostage.jl:104-107) on the columns
+// `cols` (host list): QR by successive appends, residual r = b - A_S c as a by-product.
+static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
+    Solver& s = ctx->s;
+    if ((int)cols.size() > s.kcap) return fail(ctx, CSMP_ERANGE, "least squares: more columns than the QR capacity");
+    CHECK(solver_restart(ctx));
+    const int n = (int)cols.size();
+    HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (n > 1 && !ctx->force_reorth) {  // panels of 32 columns; verified through the device flag
+        CHECK(launch_block_appends(ctx, n, STOP_REORTH));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) return CSMP_OK;
+        CHECK(solver_restart(ctx));  // a panel failed its DGKS test: column-wise chain with re-orthogonalisation
+    }
+    for (int w = 0; w < n; ++w) CHECK(launch_append(ctx, 2, w, 0));
+    return CSMP_OK;
+}
+
+// ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
+static int gram_split_for(const csmp_ctx* ctx, int np) {
+    // pieces of k_gram on or above the diagonal; the rows are split so that ONE round of workgroups (two per CU) covers them:
+    // a second, partly filled round would cost as much as a full one
+    const int TJ = np / kGramWgJ;
+    int pieces = 0;
+    for (int J = 0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
+    const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
+    int nsplit = std::max(1, slots / std::max(1, pieces));
+    nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
+    if (const char* e = tune_env("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
+    return std::min(nsplit, 32);
+}
+static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
+    Solver& s = ctx->s;
+    if (s.gram_np >= np && s.gram_split >= nsplit) return CSMP_OK;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    np = std::max(np, s.gram_np);
+    nsplit = std::max(nsplit, s.gram_split);
+    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    s.gram_np = s.gram_split = 0;
+    s.keep_valid = false;
+    CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
+    CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
+    CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
+    CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
+    CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.Dfac, (size_t)np * kCholNB));  // the factored diagonal blocks (chol_row_body)
+    CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
+    CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
+    CHECK(dmalloc(ctx, &s.rpart, (size_t)((np + kResChunk - 1) / kResChunk) * s.Mpad));
+    HIPCHECK(hipMalloc(&s.Acomp, (size_t)np * (size_t)((ctx->M + 15) / 16 * 16) * (ctx->dtype == CSMP_F32 ? 4 : 8)));
+    s.gram_np = np;
+    s.gram_split = nsplit;
+    return CSMP_OK;
+}
+
+// factorize! + ldiv! on the columns `cols` taken together: enqueues the Gram matrix, its Cholesky factorisation, the
+// export of (R, z, support), the back substitution + sorted emission into the slot's out arrays and the residual
+// r = b - A_S x.  No host synchronisation; a set that fails the DGKS test leaves STOP_REORTH in the control block (and
+// nothing exported): the caller checks it with the results and falls back to ls_on_columns.
+template <typename TA>
+static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
+    Solver& s = ctx->s;
+    const int n = (int)cols.size(), M = (int)ctx->M;
+    const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
+    const int nsplit = gram_split_for(ctx, np);
+    CHECK(gram_ensure(ctx, np, nsplit));
+    CHECK(solver_restart(ctx));
+    // the column list (and, for a subset, its positions in the kept set) go up from a page-locked buffer that lives until the
+    // next call -- every caller drains the stream before it comes back here
+    void* pcv = nullptr;
+    CHECK(pin_get(ctx, 2, (size_t)(2 * n + 2) * 4, &pcv));
+    int* pcols = (int*)pcv;
+    int* ppos = pcols + n + 1;
+    for (int t = 0; t < n; ++t) pcols[t] = cols[t];
+    pcols[n] = n;
+    HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
+    // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
+    bool subset = s.keep_valid && n <= s.keep_n && ctx->opt_ls_gram_reuse;
+    if (subset) {
+        std::vector<std::pair<int, int>> where((size_t)s.keep_n);
+        for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
+        std::sort(where.begin(), where.end());
+        for (int t = 0; t < n && subset; ++t) {
+            auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(cols[t], 0));
+            if (it == where.end() || it->first != cols[t]) subset = false;
+            else ppos[t] = it->second;
+        }
+    }
+    if (subset) {
+        HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        const int64_t nel = (int64_t)np * np;
+        hipLaunchKernelGGL(k_gram_subset, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep, s.keep_np, s.keep_n,
+                           (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag);
+        HIPCHECK(hipGetLastError());
+    } else {
+        const int blk = 16;
+        const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
+        const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
+        const int nchunk = (int)((ldo + 255) / 256);
+        hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)nchunk, np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                           (const int*)s.cands, n, (TA*)s.Acomp, ldo, (const double*)s.b, np, s.rhs_part);
+        hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
+                           rps, s.Gpart);
+        HIPCHECK(hipGetLastError());
+        const int64_t nel = (int64_t)np * np;
+        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
+                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk, s.Gkeep, s.gdkeep);
+        HIPCHECK(hipGetLastError());
+        s.keep_cols.assign(cols.begin(), cols.end());
+        s.keep_n = n;
+        s.keep_np = np;
+        s.keep_valid = true;
+    }
+    // Block rows 0 .. ceil(n / 32) - 1 are all that is needed: the bordered column n is a column of their row panels (or of
+    // the last diagonal block when n is not a multiple of 32); the corner b'b - z'z and the identity padding are never read.
+    const int nsteps = (n + kCholNB - 1) / kCholNB;
+    {
+        const int left0 = np - kCholNB;
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n,
+                           0, (const double*)s.gdiag, s.st, s.Dfac);
+    }
+    for (int kb = 0; kb + 1 < nsteps; ++kb) {  // one launch per step: trailing update of panel kb + block row kb + 1
+        const int left = np - (kb + 1) * kCholNB;   // columns from the next block row on
+        const int left2 = left - kCholNB;           // columns to the right of the next diagonal block
+        const int Tt = (left + kGramTile - 1) / kGramTile;
+        const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
+        const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
+        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n, kb, (const double*)s.gdiag, s.st,
+                           nrow, s.Dfac);
+    }
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np, n,
+                       (const int*)s.cands, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
+    HIPCHECK(hipGetLastError());
+    s.jh = std::min(s.kcap, n);
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
+    const int nch = (n + kResChunk - 1) / kResChunk;
+    hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                       (const int*)s.cands, (const double*)s.coef, n, s.rpart);
+    hipLaunchKernelGGL(k_residual_sum, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.rpart, nch, M, (const double*)s.b,
+                       s.r, (const DevState*)s.st, s.rn2part);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+static bool gram_applicable(const csmp_ctx* ctx, size_t n) {
+    // worth it from a few panels on; needs QR capacity for R and distinct columns (the callers guarantee those)
+    return n >= 64 && !ctx->force_reorth && ctx->opt_ls_gram;
+}
+static int ls_gram(csmp_ctx* ctx, const std::vector<int>& cols) {
+    return ctx->dtype == CSMP_F32 ? ls_gram_t<float>(ctx, cols) : ls_gram_t<double>(ctx, cols);
+}
+
+extern "C" int csmp_lstsq(csmp_ctx* ctx, const int64_t* cols, int64_t ncols, const void* b, int b_dtype, double* coef) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!cols || !b || !coef || ncols < 1) return fail(ctx, CSMP_EINVAL, "lstsq: bad arguments");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (ncols > ctx->M) return fail(ctx, CSMP_ERANGE, "lstsq: more columns than rows");
+    std::vector<int> c((size_t)ncols);
+    for (int64_t t = 0; t < ncols; ++t) {
+        if (cols[t] < 0 || cols[t] >= ctx->N) return fail(ctx, CSMP_ERANGE, "lstsq: column index out of range");
+        c[t] = (int)cols[t];
+    }
+    std::vector<int> srt = c;
+    std::sort(srt.begin(), srt.end());
+    if (std::adjacent_find(srt.begin(), srt.end()) != srt.end()) return fail(ctx, CSMP_EINVAL, "lstsq: duplicate column");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)ncols, (int)ncols));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    Solver& s = ctx->s;
+    if (gram_applicable(ctx, c.size())) {
+        CHECK(ls_gram(ctx, c));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(coef, s.coef, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));  // the order of cols
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH) && hs.nsel == (int)ncols) return CSMP_OK;
+    }
+    CHECK(ls_on_columns(ctx, c));
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    HIPCHECK(hipMemcpyAsync(coef, s.coef, (size_t)ncols * 8, hipMemcpyDeviceToHost, ctx->stream));  // insertion order = cols order
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return CSMP_OK;
+}
+
+static int residual_norm(csmp_ctx* ctx, double* out) {
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+    HIPCHECK(hipGetLastError());
+    double n2 = 0.0;
+    PinFetch f(ctx);
+    CHECK(f.begin(8));
+    CHECK(f.add(&n2, s.scal, 8));
+    CHECK(f.wait());
+    *out = std::sqrt(n2);
+    return CSMP_OK;
+}
+
+// current support + coefficients (sorted by index) to the host
+static int fetch_sorted(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val) {
+    Solver& s = ctx->s;
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    idx.assign((size_t)s.outcap, 0);
+    val.assign((size_t)s.outcap, 0.0);
+    int64_t n = 0;
+    CHECK(download_result(ctx, s.outcap, idx.data(), val.data(), &n, nullptr));
+    idx.resize((size_t)n);
+    val.resize((size_t)n);
+    return CSMP_OK;
+}
+
+// Least squares on `cols` + the sorted solution on the host (+ ||r|| when asked) in ONE synchronisation.  Large sets go
+// through the whole-set path (csmp_gram.hpp); if their DGKS test fails, or for small sets, the append chain does it.
+static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm) {
+    Solver& s = ctx->s;
+    if (gram_applicable(ctx, cols.size())) {
+        CHECK(ls_gram(ctx, cols));
+        const size_t n = cols.size();
+        const size_t nshare = (size_t)(ctx->M + 255) / 256;  // |r|^2 comes back as the residual kernel's per-workgroup shares
+        // one page-locked landing area for everything that comes back: [idx n | val n | control block | shares of ||r||^2]
+        const size_t need = n * 16 + sizeof(DevState) + 16 + nshare * 8;
+        void* pv = nullptr;
+        CHECK(pin_get(ctx, 1, need, &pv));
+        int64_t* pi = (int64_t*)pv;
+        double* pvv = (double*)(pi + n);
+        DevState* phs = (DevState*)(pvv + n);
+        double* pn2 = (double*)((char*)phs + ((sizeof(DevState) + 7) / 8) * 8);
+        HIPCHECK(hipMemcpyAsync(pi, s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(pvv, s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(phs, s.st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
+        if (resnorm) HIPCHECK(hipMemcpyAsync(pn2, s.rn2part, nshare * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        const DevState hs = *phs;
+        if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
+            idx.assign(pi, pi + n);
+            val.assign(pvv, pvv + n);
+            if (resnorm) {
+                double n2 = 0.0;
+                for (size_t q = 0; q < nshare; ++q) n2 += pn2[q];
+                *resnorm = std::sqrt(n2);
+            }
+            return CSMP_OK;
+        }
+    }
+    CHECK(ls_on_columns(ctx, cols));
+    CHECK(fetch_sorted(ctx, idx, val));
+    if (resnorm) CHECK(residual_norm(ctx, resnorm));
+    return CSMP_OK;
+}
+
+// sp_acquisition!(P, x, k): src/twostage.jl:67-72 -- sweep on the current residual, union the k best
+// atoms into the support, least squares on the union
+static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
+    Solver& s = ctx->s;
+    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+    CHECK(launch_topS(ctx, k));
+    void* pv = nullptr;
+    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the two small copies do not block the host one by one)
+    int* top = (int*)pv;
+    int* pnt = top + k;
+    HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const int nt = *pnt;
+    std::vector<int> cols;
+    for (auto i : idx) cols.push_back((int)i);
+    for (int t = 0; t < nt; ++t) cols.push_back(top[t]);  // @. x[i] = NaN (:70)
+    std::sort(cols.begin(), cols.end());
+    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    return ls_fetch(ctx, cols, idx, val, resnorm);  // solve! (:71)
+}
+
+extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
+                       double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "sp: b == NULL or k < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
+    if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
+    if (maxiter < 0) maxiter = 16 * k;  // :87
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)(2 * k), (int)(2 * k)));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, b, b_dtype));
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    double resnorm = 0.0;
+    CHECK(sp_acquire(ctx, (int)k, xi, xv, &resnorm));  // :90-91
+    int64_t it = 0;
+    while (it < maxiter) {                   // :92
+        const double oldnorm = resnorm;
+        // update!(P::SP, x): :75-83
+        CHECK(sp_acquire(ctx, (int)k, xi, xv));  // :77
+        const int64_t drop = (int64_t)xi.size() - k;
+        if (drop > 0) {  // :78-81: delete the (nnz-k) smallest |coef|, ties by position
+            std::vector<int> pos(xi.size());
+            for (size_t t = 0; t < pos.size(); ++t) pos[t] = (int)t;
+            std::stable_sort(pos.begin(), pos.end(), [&](int a, int c) { return std::fabs(xv[a]) < std::fabs(xv[c]); });
+            std::vector<char> kill(xi.size(), 0);
+            for (int64_t t = 0; t < drop; ++t) kill[pos[t]] = 1;
+            std::vector<int64_t> keep;
+            for (size_t t = 0; t < xi.size(); ++t)
+                if (!kill[t]) keep.push_back(xi[t]);
+            xi.swap(keep);
+        }
+        std::vector<int> cols;
+        for (auto i : xi) cols.push_back((int)i);
+        CHECK(ls_fetch(ctx, cols, xi, xv, &resnorm));       // :82, :95
+        ++it;
+        if (resnorm <= delta || oldnorm <= resnorm) break;   // :96
+    }
+    for (size_t t = 0; t < xi.size(); ++t) {
+        if (idx) idx[t] = xi[t];
+        if (val) val[t] = xv[t];
+    }
+    if (nnz) *nnz = (int64_t)xi.size();
+    if (iters) *iters = it;
+    return CSMP_OK;
+}
+
+// sp for many signals: up to four solves in flight, each on a context (this one + clones on their own streams) driven by its own
+// host thread.  A Subspace Pursuit solve is two HBM-bound sweeps and a long chain of short kernels with five host round trips
+// (factorisations, selections, the pruning decision): one solve leaves most of the chip idle most of the time, and another
+// signal's solve fills it.  Signal s is solved by context s mod T with the single-signal driver itself: results are csmp_sp's.
+extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int64_t k, double delta, int64_t maxiter,
+                             int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!B || nsig < 0 || k < 1 || ldB < ctx->M || !idx || !val || !nnz) return fail(ctx, CSMP_EINVAL, "sp_batch: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
+    if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->opt_in_flight, 4), nsig));
+    CHECK(twins_ensure(ctx, T - 1));
+    csmp_ctx* cc[4] = {ctx, ctx->twins[0], ctx->twins[1], ctx->twins[2]};
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    int rcs[4] = {CSMP_OK, CSMP_OK, CSMP_OK, CSMP_OK};
+    auto work = [&](int t) {
+        std::vector<int64_t> ti((size_t)2 * k);
+        std::vector<double> tv((size_t)2 * k);
+        for (int64_t sgn = t; sgn < nsig && rcs[t] == CSMP_OK; sgn += T) {
+            int64_t n = 0, it = 0;
+            const char* col = (const char*)B + (size_t)sgn * (size_t)ldB * es;
+            rcs[t] = csmp_sp(cc[t], col, b_dtype, k, delta, maxiter, ti.data(), tv.data(), &n, &it);
+            if (rcs[t] != CSMP_OK) break;
+            for (int64_t q = 0; q < k; ++q) {
+                idx[sgn * k + q] = q < n ? ti[q] : -1;
+                val[sgn * k + q] = q < n ? tv[q] : 0.0;
+            }
+            nnz[sgn] = std::min<int64_t>(n, k);
+            if (iters) iters[sgn] = it;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    for (int t = 0; t < T; ++t)
+        if (rcs[t] != CSMP_OK) {
+            if (t) ctx->err = cc[t]->err;
+            return rcs[t];
+        }
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ primitives
+extern "C" int csmp_sweep(csmp_ctx* ctx, const double* r, double* abs_corr, int64_t topk, int64_t* top_idx, double* top_val) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!r || topk < 0) return fail(ctx, CSMP_EINVAL, "sweep: bad arguments");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (topk > ctx->N) topk = ctx->N;
+    if (topk > ctx->M) return fail(ctx, CSMP_ERANGE, "sweep: topk > size(A,1) is not supported (no caller of argmaxinner!(P,k) needs it)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)std::max<int64_t>(topk, 1), 1, false));
+    ctx->s.begun = false;
+    CHECK(upload_b(ctx, r, CSMP_F64));
+    CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+    CHECK(launch_select(ctx, 0, 0));
+    if (abs_corr) {
+        HIPCHECK(hipMemcpyAsync(abs_corr, ctx->s.cvec, (size_t)ctx->N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < ctx->N; ++i) abs_corr[i] = std::fabs(abs_corr[i]);  // @. Ar = abs(Ar) on the way out
+    }
+    if (topk == 1) {
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (top_idx) top_idx[0] = hs.cand;
+        if (top_val) top_val[0] = std::fabs(hs.cval);
+    } else if (topk > 1) {
+        CHECK(launch_topS(ctx, (int)topk));
+        std::vector<int> hc((size_t)topk);
+        std::vector<double> hv((size_t)topk);
+        HIPCHECK(hipMemcpyAsync(hc.data(), ctx->s.cands, (size_t)topk * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(hv.data(), ctx->s.cvals, (size_t)topk * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (int64_t t = 0; t < topk; ++t) {
+            if (top_idx) top_idx[t] = hc[t];
+            if (top_val) top_val[t] = hv[t];
+        }
+    }
+    return CSMP_OK;
+}

@@ -1,0 +1,143 @@
+// host/omp.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// the tick pipeline (three signals in flight) and the omp driver.
+// ------------------------------------------------------------------------------------------ tick kernel (3 signals in flight)
+template <typename TA>
+static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, const Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
+    TickSweep<TA> p;
+    p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
+    p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;
+    p.eps = eps; p.check_eps = check_eps; p.skipmask = skipmask; p.nblk = nblk; p.active = active;
+    return p;
+}
+template <typename TA>
+static TickQr1<TA> tick_qr1_params(csmp_ctx* ctx, const Solver& s, int skipmask, int nblk_sweep, int jh, int active) {
+    TickQr1<TA> p;
+    p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.M = (int)ctx->M;
+    p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.P1 = s.P1;
+    p.G = s.G; p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.mode = 1;
+    p.pval = s.pval; p.pidx = s.pidx; p.nblk_sweep = nblk_sweep;
+    p.cands = s.cands; p.ncands = s.ncands; p.which = 0; p.sel = s.sel; p.skipmask = skipmask;
+    p.r = s.r; p.P1s = s.P1s; p.jh = jh; p.active = active;
+    return p;
+}
+static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optimistic, int active) {
+    TickQr2 p;
+    p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.r = s.r;
+    p.P1 = s.P1; p.P1s = s.P1s; p.G = s.G;
+    p.W1 = s.W1; p.vvec = s.vvec; p.P2 = s.P2; p.P2s = s.P2s; p.R = s.R; p.z = s.z; p.sel = s.sel;
+    p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.force_reorth = ctx->force_reorth ? 1 : 0; p.jh = jh; p.optimistic = optimistic;
+    p.active = active;
+    return p;
+}
+
+template <typename TA, int U, bool PF, bool STEADY = false>
+static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
+    auto kern = k_tick<TA, U, PF, STEADY>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, ctx->tick_sweep_first ? 1 : 0);
+    return hipGetLastError();
+}
+// steady: all three stages of this tick are live (the launches the bench's roofline is quoted on)
+template <typename TA>
+static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
+    switch (ctx->tick_U) {
+        case 16:
+            if (!ctx->tick_pf) return tick_launch_t<TA, 16, false>(ctx, sw, q1, q2, G, lds);
+            return steady ? tick_launch_t<TA, 16, true, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 16, true, false>(ctx, sw, q1, q2, G, lds);
+        case 8:
+            if (!ctx->tick_pf) return tick_launch_t<TA, 8, false>(ctx, sw, q1, q2, G, lds);
+            return steady ? tick_launch_t<TA, 8, true, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, 8, true, false>(ctx, sw, q1, q2, G, lds);
+        case 4: return tick_launch_t<TA, 4, false>(ctx, sw, q1, q2, G, lds);
+        case 2: return tick_launch_t<TA, 2, false>(ctx, sw, q1, q2, G, lds);
+        default: return tick_launch_t<TA, 1, false>(ctx, sw, q1, q2, G, lds);
+    }
+}
+
+// OMP for up to three signals (solver slots 0..2, already initialised with their b) advanced
+// together: at tick n slot n%3 sweeps, slot (n-1)%3 runs its k_qr1 stage, slot (n-2)%3 its k_qr2
+// stage.  k steps per signal = 3k+2 ticks.  present[q] == false leaves slot q idle.
+template <typename TA>
+static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    activate_slot(ctx, 0);
+    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
+    const int G = sl[0]->G;
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
+    // Measured at 4096 x 65536 f32: 8-chunk load blocks on ONE workgroup per CU (the append stages of the other two
+    // signals share those CUs) 160.4 us per tick; 16-chunk blocks on 176 workgroups (11/12 of the stand-alone sweep's
+    // optimum of 192) 162.6 us.
+    const int64_t auto_nblk = ctx->tick_U == 8 ? (int64_t)ctx->prop.multiProcessorCount
+                              : ctx->tick_U == 16 ? (int64_t)ctx->sweep_grid * 11 / 12
+                                                  : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu;
+    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
+    if (k > qr_max_cols()) {  // the appends stop at the support the QR kernels can hold (see launch_append): CSMP_WCAPACITY
+        k = qr_max_cols();
+        for (int q = 0; q < 3; ++q)
+            if (present[q]) sl[q]->capped = true;
+    }
+    const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
+    for (int64_t n = 0; n < 3 * k + 2; ++n) {
+        const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
+        const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
+        const bool az = present[zs] && n >= zs && tz < k;
+        const bool ay = present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
+        const bool ax = present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
+        if (!az && !ay && !ax) continue;
+        int jh1 = 0;
+        if (ay) {
+            jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
+            sl[ys]->jh_last = jh1;
+            if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
+        }
+        const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, nblk, az ? 1 : 0);
+        const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
+        const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
+        const bool steady = az && ay && ax;
+        const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
+        if (timed) CHECK(prof_mark(ctx));
+        HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, lds, steady));
+        if (timed) CHECK(prof_mark(ctx));
+    }
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ drivers
+extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double eps, int64_t* idx, double* val,
+                        int64_t* nnz, int64_t* order) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:74
+    if (!b || k < 0) return fail(ctx, CSMP_EINVAL, "omp: b == NULL or k < 0");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // UpdatableQR(T, n, k): :58
+    CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k, 1)));
+    ctx->s.begun = false;
+    // optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
+    // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
+    bool capacity_stop = false;
+    for (int pass = 0; pass < 2; ++pass) {
+        const bool optimistic = pass == 0 && !ctx->force_reorth;
+        CHECK(upload_b(ctx, b, b_dtype));
+        for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
+            CHECK(omp_step(ctx, eps, t > 0, optimistic));
+            if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
+                bool stopped = false;
+                CHECK(solver_poll(ctx, &stopped));
+                if (stopped) break;
+            }
+        }
+        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!(hs.done & STOP_REORTH)) {
+            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+            break;
+        }
+    }
+    CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
+    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+}

@@ -1,0 +1,192 @@
+// host/steps_sharding.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// step-level API (the Update functors), csmp_clone, column-sharded OMP, signal-sharding helpers.
+// ------------------------------------------------------------------------------------------ step-level API
+extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_dtype, int64_t kcap, const int64_t* idx0,
+                                 const double* val0, int64_t nnz0) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || kcap < 1) return fail(ctx, CSMP_EINVAL, "solver_begin: bad arguments");
+    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP && algo != CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int kc = algo == CSMP_ALGO_MP ? (int)kcap : (int)std::min<int64_t>(kcap, ctx->M);
+    CHECK(solver_ensure(ctx, kc, kc, algo != CSMP_ALGO_MP));
+    if (algo == CSMP_ALGO_FR) CHECK(fr_ensure(ctx));
+    CHECK(upload_b(ctx, b, b_dtype));
+    if (nnz0 > 0) {
+        if (algo != CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "warm start is only defined for MP (src/matchingpursuit.jl:34)");
+        CHECK(upload_support(ctx, idx0, val0, nnz0));
+    }
+    ctx->s.algo = algo;
+    ctx->s.begun = true;
+    return CSMP_OK;
+}
+
+static int gomp_update(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block);
+
+extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_step: no solver begun");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int rc = CSMP_OK;
+    switch (ctx->s.algo) {
+        case CSMP_ALGO_MP: return mp_step(ctx);
+        case CSMP_ALGO_OMP: {
+            // update!(P::OMP, x) alone: no eps logic (that belongs to the omp driver)
+            CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));
+            rc = launch_append(ctx, 1, 0, STOP_FULL);
+            break;
+        }
+        case CSMP_ALGO_FR: {
+            // update!(P::FR, x): nnz < n guard, acquisition_index! = argmax δ², addindex!, solve (src/forward.jl:88-95)
+            const int skip = STOP_FULL | STOP_STAG;  // (a step that found no finite score would otherwise downdate rho2 twice)
+            CHECK(launch_fr_sweep(ctx, ctx->s.jh == 0, -HUGE_VAL, skip));
+            rc = launch_append(ctx, 3, 0, skip, false, -1.0, ctx->s.fr_grid);
+            break;
+        }
+        default: rc = gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
+    }
+    // a step the QR append could not take (support at its capacity): x is unchanged, the caller is told
+    return rc == CSMP_OK && ctx->s.capped ? CSMP_WCAPACITY : rc;
+}
+
+// ------------------------------------------------------------------------------------------ shared dictionary
+// A second context on the same GPU that BORROWS the resident dictionary of `src` (no copy): the independent
+// P objects of the reference -- P1 = OMP(A, b1); P2 = OMP(A, b2) share A and nothing else
+// (src/matchingpursuit.jl:44-60).  `src` must outlive the clone and keep its dictionary.
+extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
+    if (!src || !out) return CSMP_EINVAL;
+    *out = nullptr;
+    if (!src->dA) return fail(src, CSMP_ESTATE, "clone: no dictionary set (csmp_set_dictionary)");
+    csmp_ctx* c = nullptr;
+    const int rc = csmp_create(&c, src->dev);
+    if (rc != CSMP_OK) {
+        src->err = g_create_err;
+        return rc;
+    }
+    c->dA = src->dA;
+    c->ownA = false;
+    c->share = src->share;  // (null for a borrowed device pointer: the caller keeps that alive)
+    if (c->share) c->share->refs += 1;
+    c->pipeline = src->pipeline;
+    c->force_reorth = src->force_reorth;
+    c->opt_batch_cert = src->opt_batch_cert;
+    c->opt_batch_window = src->opt_batch_window;
+    c->opt_ls_gram = src->opt_ls_gram;
+    c->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
+    c->opt_twostage_update = src->opt_twostage_update;
+    c->dtype = src->dtype;
+    c->M = src->M;
+    c->N = src->N;
+    c->ld = src->ld;
+    c->Mv = src->Mv;
+    c->col_offset = src->col_offset;
+    const int rc2 = configure_sweep(c);
+    if (rc2 != CSMP_OK) {
+        src->err = c->err;
+        csmp_destroy(c);
+        return rc2;
+    }
+    *out = c;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ column-sharded OMP
+// See csmp_shard.hpp.  The ctx holds columns [col_offset, col_offset + N) of the global dictionary; a solve is
+// csmp_solver_begin(CSMP_ALGO_OMP) on every rank, then per step csmp_shard_sweep -> the caller's all_gather of
+// one record per rank -> csmp_shard_append, and csmp_solver_state at the end (identical on every rank).
+extern "C" int csmp_shard_config(csmp_ctx* ctx, int64_t col_offset) {
+    if (!ctx) return CSMP_EINVAL;
+    if (col_offset < 0 || col_offset + ctx->N > 0x7fffffff) return fail(ctx, CSMP_ERANGE, "shard_config: global column indices must fit 31 bits");
+    ctx->col_offset = col_offset;
+    return CSMP_OK;
+}
+
+extern "C" int64_t csmp_shard_record_bytes(const csmp_ctx* ctx) {
+    if (!ctx || !ctx->dA) return 0;
+    return (int64_t)shard_record_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 8);
+}
+
+static int shard_ready(csmp_ctx* ctx, const char* who) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->s.begun || ctx->s.algo != CSMP_ALGO_OMP)
+        return fail(ctx, CSMP_ESTATE, (std::string(who) + ": begin the solve with csmp_solver_begin(CSMP_ALGO_OMP)").c_str());
+    return CSMP_OK;
+}
+
+// steps 1-2: argmaxinner!(P) over the local columns (+ the driver's residual test of the previous iteration,
+// src/matchingpursuit.jl:79, when check_eps != 0) and the rank's record, written to DEVICE memory at rec_dev
+extern "C" int csmp_shard_sweep(csmp_ctx* ctx, double eps, int check_eps, void* rec_dev) {
+    CHECK(shard_ready(ctx, "shard_sweep"));
+    if (!rec_dev || !(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "shard_sweep: rec_dev == NULL or eps < 0");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Solver& s = ctx->s;
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL;
+    CHECK(launch_sweep(ctx, s.r, eps, check_eps, skip));
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_shard_pack<float>, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx,
+                           ctx->sweep_grid, (const double*)s.cvec, (const float*)ctx->dA, ctx->ld, ctx->Mv, ctx->col_offset,
+                           (const DevState*)s.st, skip, (char*)rec_dev);
+    else
+        hipLaunchKernelGGL(k_shard_pack<double>, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx,
+                           ctx->sweep_grid, (const double*)s.cvec, (const double*)ctx->dA, ctx->ld, ctx->Mv, ctx->col_offset,
+                           (const DevState*)s.st, skip, (char*)rec_dev);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
+// steps 4-5: global arg-max over the nrec gathered records (DEVICE memory, csmp_shard_record_bytes apart),
+// then update!(P::OMP, x)'s guards, add_column! and the residual update on the winning column
+extern "C" int csmp_shard_append(csmp_ctx* ctx, const void* recs_dev, int nrec) {
+    CHECK(shard_ready(ctx, "shard_append"));
+    if (!recs_dev || nrec < 1) return fail(ctx, CSMP_EINVAL, "shard_append: recs_dev == NULL or nrec < 1");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Solver& s = ctx->s;
+    const size_t es = ctx->dtype == CSMP_F32 ? 4 : 8;
+    if (!s.extcol) HIPCHECK(hipMalloc(&s.extcol, (size_t)ctx->Mv * es));
+    const int64_t rb = (int64_t)shard_record_bytes(ctx->Mv, es);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_shard_pick<float>, dim3(1), dim3(256), 0, ctx->stream, (const char*)recs_dev, nrec, rb, ctx->Mv,
+                           (float*)s.extcol, s.cands, s.ncands, s.st);
+    else
+        hipLaunchKernelGGL(k_shard_pick<double>, dim3(1), dim3(256), 0, ctx->stream, (const char*)recs_dev, nrec, rb, ctx->Mv,
+                           (double*)s.extcol, s.cands, s.ncands, s.st);
+    HIPCHECK(hipGetLastError());
+    return launch_append(ctx, 4, 0, STOP_EPS | STOP_STAG | STOP_FULL, false, 0.0, 0, s.extcol);
+}
+
+// ------------------------------------------------------------------------------------------ signal sharding helpers
+// The data path of the signal-sharded batch has ONE exchange: every rank's results.  These
+// three host-side helpers fix its layout so that any host language can run it over its own collective
+// (torch.distributed / RCCL here, MPI.jl from Julia): contiguous blocks of signals per rank, and per signal one row
+// of 2k + 1 Float64 = [idx_0 .. idx_{k-1} | val_0 .. val_{k-1} | nnz] (indices are exact in Float64 below 2^53).
+extern "C" int csmp_shard_range(int64_t nsig, int rank, int world, int64_t* lo, int64_t* hi) {
+    if (nsig < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return CSMP_EINVAL;
+    const int64_t base = nsig / world, extra = nsig % world;  // block sizes differ by at most one
+    *lo = rank * base + std::min<int64_t>(rank, extra);
+    *hi = *lo + base + (rank < extra ? 1 : 0);
+    return CSMP_OK;
+}
+extern "C" int csmp_pack_results(const int64_t* idx, const double* val, const int64_t* nnz, int64_t k, int64_t nsig, double* packed) {
+    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
+    const int64_t w = 2 * k + 1;
+    for (int64_t s = 0; s < nsig; ++s) {
+        for (int64_t t = 0; t < k; ++t) {
+            packed[s * w + t] = (double)idx[s * k + t];
+            packed[s * w + k + t] = val[s * k + t];
+        }
+        packed[s * w + 2 * k] = (double)nnz[s];
+    }
+    return CSMP_OK;
+}
+extern "C" int csmp_unpack_results(const double* packed, int64_t k, int64_t nsig, int64_t* idx, double* val, int64_t* nnz) {
+    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
+    const int64_t w = 2 * k + 1;
+    for (int64_t s = 0; s < nsig; ++s) {
+        for (int64_t t = 0; t < k; ++t) {
+            idx[s * k + t] = (int64_t)packed[s * w + t];
+            val[s * k + t] = packed[s * w + k + t];
+        }
+        nnz[s] = (int64_t)packed[s * w + 2 * k];
+    }
+    return CSMP_OK;
+}

@@ -1,0 +1,577 @@
+// host/twostage.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// OMP with replacement, the stepwise-regression object, srr, rmp, foba, br.
+// ------------------------------------------------------------------------------------------ OMP with replacement
+// ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202, x starting empty.  The support is filled by
+// oblivious_acquisition! (src/matchingpursuit.jl:207-216); every update! (:134-180) is one sweep +
+// arg-max on the device, the tiny "which entry leaves" decision on k+1 numbers on the host, and --
+// when the support changes -- remove_column! as a Givens down-date of the on-device QR
+// (csmp_downdate.hpp) followed by the usual append (k > 1023: a fresh panel factorisation instead).
+extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
+                         double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "ompr: b == NULL or k < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
+    if (maxiter < 0) maxiter = ctx->M;  // :185
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const bool want_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;
+    if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
+    CHECK(solver_ensure(ctx, (int)k, (int)k));
+    ctx->s.begun = false;
+    Solver& s = ctx->s;
+    const bool use_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;  // (option 2: refactorise instead)
+    const bool tmode = use_downdate && ctx->opt_twostage_update == 0;  // explicit inverse next to R (csmp_tinv.hpp)
+    if (use_downdate) CHECK(del_ensure(ctx));
+    if (tmode) CHECK(tinv_ensure(ctx));
+    CHECK(upload_b(ctx, b, b_dtype));
+    // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
+    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+    CHECK(launch_topS(ctx, (int)k));
+    std::vector<int> top((size_t)k);
+    HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    std::sort(top.begin(), top.end());
+    CHECK(ls_on_columns(ctx, top));
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    if (tmode) {
+        CHECK(launch_tinv_build(ctx));
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+    } else {
+        CHECK(fetch_sorted(ctx, xi, xv));
+    }
+    double resnorm = 0.0;
+    CHECK(residual_norm(ctx, &resnorm));  // :192
+    int64_t it = 0;
+    std::vector<double> cs((size_t)k), call;
+    while (it < maxiter) {  // :193
+        const double oldnorm = resnorm;
+        bool have_norm = false;
+        // update!(P, x): Ar = x + A'r (eta = 1), arg-max over atoms outside the support
+        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+        CHECK(launch_select(ctx, 0, 0));
+        std::vector<int> cur(xi.begin(), xi.end());
+        HIPCHECK(hipMemcpyAsync(s.cands, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
+        HIPCHECK(hipGetLastError());
+        DevState hs;
+        {
+            PinFetch f(ctx);
+            CHECK(f.begin((size_t)k * 8 + sizeof hs + 16));
+            CHECK(f.add(cs.data(), s.coef, (size_t)k * 8));
+            CHECK(f.add(&hs, s.st, sizeof hs));
+            CHECK(f.wait());
+        }
+        int64_t cand = hs.cand;
+        double ccand = hs.cval;
+        if (std::binary_search(xi.begin(), xi.end(), cand)) {
+            // degenerate: the overall arg-max lies inside the support; scan the correlations on the host
+            call.resize((size_t)ctx->N);
+            HIPCHECK(hipMemcpy(call.data(), s.cvec, (size_t)ctx->N * 8, hipMemcpyDeviceToHost));
+            cand = -1;
+            double m = 0.0;
+            for (int64_t j = 0; j < ctx->N; ++j) {
+                if (std::binary_search(xi.begin(), xi.end(), j)) continue;
+                const double f = std::fabs(call[j]);
+                if (f > m) {  // strict '>' from m = 0: first maximum, none if everything is zero (:139-155)
+                    m = f;
+                    cand = j;
+                }
+            }
+            if (cand >= 0) ccand = call[cand];
+        } else if (!(std::fabs(ccand) > 0.0)) {
+            cand = -1;
+        }
+        ++it;
+        if (cand >= 0) {
+            // x[i] = NaN; x.nzval = Ar[x.nzind]; drop the first entry of smallest magnitude (:158-169)
+            const size_t pos = (size_t)(std::lower_bound(xi.begin(), xi.end(), cand) - xi.begin());
+            size_t jmin = 0;
+            double vmin = 0.0;
+            for (size_t t = 0; t <= xi.size(); ++t) {
+                const double v = t == pos ? ccand : (t < pos ? xv[t] + cs[t] : xv[t - 1] + cs[t - 1]);
+                if (t == 0 || std::fabs(v) < vmin) {
+                    vmin = std::fabs(v);
+                    jmin = t;
+                }
+            }
+            if (jmin != pos) {  // qr_i != j (:171): the support really changes
+                const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
+                if (use_downdate) {
+                    // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
+                    if (tmode)
+                        CHECK(launch_delete_atom_t(ctx, leaving));
+                    else
+                        CHECK(launch_delete_atom(ctx, leaving));
+                    const int one = 1, ci = (int)cand;
+                    HIPCHECK(hipMemcpyAsync(s.cands, &ci, 4, hipMemcpyHostToDevice, ctx->stream));
+                    HIPCHECK(hipMemcpyAsync(s.ncands, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+                    CHECK(launch_append(ctx, 2, 0, 0));
+                    if (tmode) CHECK(launch_tinv_append(ctx));
+                } else {
+                    std::vector<int> cols;
+                    for (size_t t = 0; t <= xi.size(); ++t) {
+                        if (t == jmin) continue;
+                        cols.push_back(t == pos ? (int)cand : (int)(t < pos ? xi[t] : xi[t - 1]));
+                    }
+                    CHECK(ls_on_columns(ctx, cols));  // :178
+                }
+                if (tmode) {
+                    CHECK(fetch_sorted_t(ctx, xi, xv, &resnorm));  // :178 and :196 in one synchronisation
+                    have_norm = true;
+                } else {
+                    CHECK(fetch_sorted(ctx, xi, xv));
+                }
+            }
+        }
+        if (!have_norm) CHECK(residual_norm(ctx, &resnorm));  // :196
+        if (resnorm <= delta || oldnorm <= resnorm) break;   // :197
+    }
+    for (size_t t = 0; t < xi.size(); ++t) {
+        if (idx) idx[t] = xi[t];
+        if (val) val[t] = xv[t];
+    }
+    if (nnz) *nnz = (int64_t)xi.size();
+    if (iters) *iters = it;
+    return CSMP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ stepwise regression object
+// StepwiseRegression = ForwardRegression (src/forward.jl:14-32) kept on the device and driven from the
+// host: forward_step! (src/forward.jl:56-73) = one dictionary sweep + one append, backward_step!
+// (src/backward.jl:51-67) = scores from T = R^-1 + column removal.  The OLS rescaling rho2 follows the
+// support through rank-one corrections folded into the NEXT sweep: -<a,q>^2 for the column a forward
+// step appended, +<a,q_drop>^2 for the direction a backward step rotated out (csmp_forward.hpp,
+// NQ = 2), so a forward/backward pair streams the dictionary once.  The host reads the 48-byte control
+// block after every step (it must know which steps changed the support).
+struct Stepwise {
+    struct Pend { const double* q; double sgn; };
+    csmp_ctx* ctx = nullptr;
+    std::vector<Pend> pend;  // corrections rho2 still lacks; q == nullptr: the last Q column (device look-up)
+    bool unmark = false;     // delmeta[2] names an atom that left the support and needs its rho2 re-seeded
+    bool rho_ready = false;  // rho2 has been initialised (|a_j|^2 at least)
+    int n = 0;               // atoms in the support
+    double last_max_d2 = 0.0;  // maximum(P.δ²) of the last forward step
+    int last_added = -1, last_removed = -1;  // atoms moved by the last successful forward / backward step
+    DevState hs;
+
+    int read_state(int* also_int = nullptr, const int* also_dev = nullptr) {
+        Solver& s = ctx->s;
+        PinFetch f(ctx);
+        CHECK(f.begin(sizeof hs + 16));
+        if (also_int) CHECK(f.add(also_int, also_dev, sizeof(int)));
+        CHECK(f.add(&hs, s.st, sizeof hs));
+        return f.wait();
+    }
+    int clear_flags() {
+        static const int zero = 0;
+        HIPCHECK(hipMemcpyAsync(&ctx->s.st->done, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        return CSMP_OK;
+    }
+    FrPass pass_of(int update_only) const {
+        const Solver& s = ctx->s;
+        FrPass ps;
+        ps.nq = rho_ready ? (int)pend.size() : -1;
+        ps.update_only = update_only;
+        if (pend.size() >= 1) { ps.q1 = pend[0].q; ps.s1 = pend[0].sgn; }
+        if (pend.size() >= 2) { ps.q2 = pend[1].q; ps.s2 = pend[1].sgn; }
+        ps.unmark = unmark ? s.delmeta + 2 : nullptr;  // (the direction that was rotated out is always the last one)
+        return ps;
+    }
+    // buffers for at most kcap atoms, b uploaded, empty support
+    int begin(csmp_ctx* c, const void* b, int b_dtype, int kcap) {
+        ctx = c;
+        CHECK(solver_fit_for_removal(ctx, kcap));
+        CHECK(solver_ensure(ctx, kcap, kcap));
+        CHECK(fr_ensure(ctx));
+        CHECK(tinv_ensure(ctx));
+        Solver& s = ctx->s;
+        s.begun = false;
+        CHECK(upload_b(ctx, b, b_dtype));
+        HIPCHECK(hipMemsetAsync(s.tmeta, 0, 2 * sizeof(int), ctx->stream));
+        pend.clear();
+        unmark = false;
+        rho_ready = false;
+        n = 0;
+        return CSMP_OK;
+    }
+    // forward_step!(P, x, max_eps, min_delta); guarded == false: update!(P::FR, x) (src/forward.jl:88-95)
+    int forward(double max_eps, double min_d2, bool guarded, bool* ok) {
+        Solver& s = ctx->s;
+        const int skipF = STOP_EPS | STOP_STAG | STOP_FULL;
+        if (!guarded) {
+            max_eps = -HUGE_VAL;
+            min_d2 = -1.0;
+        }
+        CHECK(launch_fr_pass(ctx, pass_of(0), max_eps, skipF));
+        CHECK(launch_append(ctx, 3, 0, skipF, false, min_d2, s.fr_grid));
+        CHECK(launch_tinv_append(ctx));
+        CHECK(read_state());
+        if (hs.done & skipF) {
+            // the step failed.  A residual-norm stop returns before rho2 is touched; the other guards act
+            // after the sweep, which has then consumed the pending corrections.
+            if (!(hs.done & STOP_EPS)) {
+                pend.clear();
+                unmark = false;
+                rho_ready = true;
+                last_max_d2 = hs.cval;
+            }
+            CHECK(clear_flags());
+            *ok = false;
+            return CSMP_OK;
+        }
+        last_max_d2 = hs.cval;
+        last_added = hs.cand;
+        rho_ready = true;
+        pend.clear();
+        unmark = false;
+        pend.push_back({nullptr, -1.0});
+        n = hs.nsel;
+        *ok = true;
+        return CSMP_OK;
+    }
+    // applies the pending corrections now (needed before a second removal reuses the q_drop buffer)
+    int flush() {
+        if (pend.empty() && !unmark) return CSMP_OK;
+        CHECK(launch_fr_pass(ctx, pass_of(1), 0.0, 0));
+        pend.clear();
+        unmark = false;
+        return CSMP_OK;
+    }
+    // backward_step!(P, x, max_eps, max_delta); lace: LACE's candidate rule (least |x_i|)
+    int backward(double max_eps, double max_d2, bool* ok, bool lace = false) {
+        Solver& s = ctx->s;
+        *ok = false;
+        if (n <= 0) return CSMP_OK;
+        bool has_drop = false;
+        for (const Pend& e : pend) has_drop |= e.q == s.qdrop;
+        if (has_drop) CHECK(flush());
+        CHECK(launch_tinv_solve(ctx));
+        hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
+                           (const DevState*)s.st, (const double*)s.r, (int)ctx->M, max_eps, max_d2, s.delpos, s.bwd_info,
+                           lace ? (const double*)s.bwd_coef : (const double*)nullptr);
+        HIPCHECK(hipGetLastError());
+        CHECK(launch_delete_t(ctx));
+        CHECK(read_state(&last_removed, s.delmeta + 2));
+        if (hs.nsel == n) return CSMP_OK;  // the thresholds (or the lack of a finite score) kept every atom
+        for (Pend& e : pend)
+            if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_tdel_apply kept a copy
+        pend.push_back({s.qdrop, 1.0});
+        unmark = true;
+        n = hs.nsel;
+        *ok = true;
+        return CSMP_OK;
+    }
+    int result(int64_t* idx, double* val, int64_t* nnz) {
+        std::vector<int64_t> xi;
+        std::vector<double> xv;
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        for (size_t t = 0; t < xi.size(); ++t) {
+            if (idx) idx[t] = xi[t];
+            if (val) val[t] = xv[t];
+        }
+        if (nnz) *nnz = (int64_t)xi.size();
+        return CSMP_OK;
+    }
+};
+
+static int stepwise_args(csmp_ctx* ctx, const void* b, const char* who) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b) return fail(ctx, CSMP_EINVAL, (std::string(who) + ": b == NULL").c_str());
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    return CSMP_OK;
+}
+
+// srr(A,b,k,delta; maxiter=4k, initialization, l): src/twostage.jl:3-33, x starting empty.  initialization 3
+// (random_acquisition!, src/matchingpursuit.jl:195-204) takes its k atoms from `init` (sorted, distinct): the draw is the
+// caller's -- the reference takes it from the host language's RNG.
+static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                    const std::vector<int>* init, int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    CHECK(stepwise_args(ctx, b, "srr"));
+    if (k < 1 || l < 1) return fail(ctx, CSMP_EINVAL, "srr: k < 1 or l < 1");
+    if (initialization != 1 && initialization != 2 && !(initialization == 3 && init))
+        return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression); 3 (random) through csmp_srr_from");
+    if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
+    if (k + l > kTMaxCols) return fail(ctx, CSMP_ERANGE, "srr: k + l exceeds 1023");
+    if (maxiter < 0) maxiter = 4 * k;  // :5
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, (int)(k + l)));
+    Solver& s = ctx->s;
+    if (initialization == 1 || initialization == 3) {
+        std::vector<int> top((size_t)k);
+        if (initialization == 1) {
+            // oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216
+            CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+            CHECK(launch_topS(ctx, (int)k));
+            HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            std::sort(top.begin(), top.end());
+        } else {
+            top = *init;  // random_acquisition!(P, x, k): :195-204 -- the caller's draw, sorted
+        }
+        CHECK(ls_on_columns(ctx, top));
+        // rho2_j = |a_j|^2 - |Q'a_j|^2 for the k columns just factorised: the norms, then four columns per pass
+        FrPass p0;
+        p0.nq = -1;
+        p0.update_only = 1;
+        CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
+        if (!tune_env("CSMP_FR_REBUILD_SWEEPS")) {
+            // Q'A on the Float64 matrix cores, 128 directions per pass (csmp_forward.hpp, k_fr_rebuild)
+            const int grid = (int)((ctx->N + 127) / 128);  // 4 waves x 32 atoms
+            for (int64_t t = 0; t < k; t += 128) {
+                const int nd = (int)std::min<int64_t>(128, k - t);
+                if (ctx->dtype == CSMP_F32)
+                    hipLaunchKernelGGL(k_fr_rebuild<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld,
+                                       (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);
+                else
+                    hipLaunchKernelGGL(k_fr_rebuild<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld,
+                                       (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);
+                HIPCHECK(hipGetLastError());
+            }
+        } else {
+        int U4, g4; bool f4; size_t lds4;
+            fr_config(ctx, 4, U4, f4, lds4, g4);
+            const bool four = lds4 <= 160 * 1024 - 512;  // four direction images fit the LDS (M <= ~5000)
+            for (int64_t t = 0; t < k;) {
+                FrPass ps;
+                ps.update_only = 1;
+                ps.q1 = s.Q + t * s.ldq;
+                ps.s1 = -1.0;
+                if (four && t + 4 <= k) {
+                    ps.nq = 4;
+                    ps.qstride = s.ldq;
+                    t += 4;
+                } else if (t + 2 <= k) {
+                    ps.nq = 2;
+                    ps.q2 = s.Q + (t + 1) * s.ldq;
+                    ps.s2 = -1.0;
+                    t += 2;
+                } else {
+                    ps.nq = 1;
+                    t += 1;
+                }
+                CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
+            }
+        }
+        hipLaunchKernelGGL(k_mark_inf, dim3(1), dim3(256), 0, ctx->stream, s.rho2, (const int*)s.sel, (const DevState*)s.st);
+        HIPCHECK(hipGetLastError());
+        CHECK(launch_tinv_build(ctx));
+        CHECK(P.read_state());
+        P.n = P.hs.nsel;
+        P.rho_ready = true;
+        if (P.hs.done) CHECK(P.clear_flags());
+    } else {
+        // k times update!(P::FR, x) (:12-15; src/forward.jl:88-95): enqueued back to back, no host round trips
+        const int skip = STOP_FULL | STOP_STAG;
+        for (int64_t t = 0; t < k; ++t) {
+            CHECK(launch_fr_sweep(ctx, t == 0, -HUGE_VAL, skip));
+            CHECK(launch_append(ctx, 3, 0, skip, false, -1.0, s.fr_grid));
+        }
+        CHECK(launch_tinv_build(ctx));
+        CHECK(P.read_state());
+        P.n = P.hs.nsel;
+        P.rho_ready = true;
+        if (P.n > 0) P.pend.push_back({nullptr, -1.0});  // the last appended column has not reached rho2 yet
+        if (P.hs.done) CHECK(P.clear_flags());
+    }
+    double resnorm = 0.0;
+    CHECK(residual_norm(ctx, &resnorm));  // :18
+    int64_t it = 0;
+    while (it < maxiter) {  // :19
+        const double oldnorm = resnorm;
+        std::vector<int> added, removed;
+        for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
+            bool ok;
+            CHECK(P.forward(0.0, 0.0, true, &ok));
+            if (!ok) break;
+            added.push_back(P.last_added);
+        }
+        while (P.n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
+            bool ok;
+            CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok));
+            if (!ok) break;
+            removed.push_back(P.last_removed);
+        }
+        std::sort(added.begin(), added.end());
+        std::sort(removed.begin(), removed.end());
+        // An iteration that removed exactly the atoms it added left x where it was: the residual norm is the
+        // old one (:27-28 then stops).  Measuring it instead would compare two roundings of the same number.
+        if (added == removed)
+            resnorm = oldnorm;
+        else
+            CHECK(residual_norm(ctx, &resnorm));  // :27
+        ++it;
+        if (resnorm <= delta || oldnorm <= resnorm) break;  // :28-30
+    }
+    if (iters) *iters = it;
+    return P.result(idx, val, nnz);
+}
+
+// ------------------------------------------------------------------------------------------ relevance matching pursuit, FoBa
+// src/stepwise.jl (x starting empty): loops over the two steps of the object above.  kmax bounds the
+// support the forward stage may build (at most 1023; the reference's only bound is size(A,1)): a
+// forward stage that needs more atoms than that ends with CSMP_ERANGE rather than a truncated answer.
+static int stepwise_cap(csmp_ctx* ctx, int64_t kmax, int* kcap) {
+    const int64_t lim = std::min<int64_t>(std::min<int64_t>(ctx->M, ctx->N), kTMaxCols);
+    if (kmax <= 0) kmax = lim;
+    *kcap = (int)std::min<int64_t>(kmax, lim);
+    return CSMP_OK;
+}
+static int stepwise_full(csmp_ctx* ctx, const Stepwise& P, int kcap) {
+    if (P.n >= kcap && kcap < std::min<int64_t>(ctx->M, ctx->N))
+        return fail(ctx, CSMP_ERANGE, "stepwise regression: the forward stage filled the support capacity (kmax, at most 1023 atoms)");
+    return CSMP_OK;
+}
+// !(xt ≈ x): isapprox with Julia's default rtol = sqrt(eps) on the sparse vectors
+static bool x_changed(const std::vector<int64_t>& i0, const std::vector<double>& v0, const std::vector<int64_t>& i1,
+                      const std::vector<double>& v1) {
+    double d2 = 0.0, na = 0.0, nb = 0.0;
+    size_t i = 0, j = 0;
+    while (i < i0.size() || j < i1.size()) {
+        double a = 0.0, b = 0.0;
+        if (j >= i1.size() || (i < i0.size() && i0[i] < i1[j])) a = v0[i++];
+        else if (i >= i0.size() || i1[j] < i0[i]) b = v1[j++];
+        else { a = v0[i++]; b = v1[j++]; }
+        d2 += (a - b) * (a - b);
+        na += a * a;
+        nb += b * b;
+    }
+    return !(std::sqrt(d2) <= 1.4901161193847656e-08 * std::sqrt(std::max(na, nb)));
+}
+
+// rmp(A, b, delta, maxiter): src/stepwise.jl:5-26
+
+extern "C" int csmp_srr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
+                        int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (initialization == 3) return fail(ctx, CSMP_EINVAL, "srr: initialization 3 (random) needs the drawn atoms: csmp_srr_from");
+    return srr_impl(ctx, b, b_dtype, k, delta, maxiter, initialization, nullptr, l, idx, val, nnz, iters);
+}
+
+// srr with initialization = 3: init[0..k) are the k distinct atoms random_acquisition! would have drawn (any order)
+extern "C" int csmp_srr_from(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, const int64_t* init,
+                             int64_t l, int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!init || k < 1) return fail(ctx, CSMP_EINVAL, "srr_from: init == NULL or k < 1");
+    std::vector<int> top((size_t)k);
+    for (int64_t t = 0; t < k; ++t) {
+        if (init[t] < 0 || init[t] >= ctx->N) return fail(ctx, CSMP_ERANGE, "srr_from: atom index out of range");
+        top[t] = (int)init[t];
+    }
+    std::sort(top.begin(), top.end());  // sort!(ind) (:197)
+    if (std::adjacent_find(top.begin(), top.end()) != top.end()) return fail(ctx, CSMP_EINVAL, "srr_from: duplicate atom");
+    return srr_impl(ctx, b, b_dtype, k, delta, maxiter, 3, &top, l, idx, val, nnz, iters);
+}
+extern "C" int csmp_rmp_delta(csmp_ctx* ctx, const void* b, int b_dtype, double delta, int64_t maxiter, int64_t kmax, int64_t* idx,
+                              double* val, int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "rmp"));
+    if (maxiter < 0) maxiter = 1;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    const double d2 = delta * delta;
+    std::vector<int64_t> xi0, xi;
+    std::vector<double> xv0, xv;
+    for (int64_t it = 0; it < maxiter; ++it) {  // :10
+        for (int64_t f = 0; f < ctx->M; ++f) {  // :12-14
+            bool ok;
+            CHECK(P.forward(0.0, d2, true, &ok));
+            if (!ok) break;
+        }
+        CHECK(stepwise_full(ctx, P, kcap));
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        if (!x_changed(xi0, xv0, xi, xv)) break;  // :15
+        xi0 = xi;
+        xv0 = xv;
+        for (int t = P.n; t >= 1; --t) {  // :18-20
+            bool ok;
+            CHECK(P.backward((double)HUGE_VAL, d2, &ok));
+            if (!ok) break;
+        }
+        CHECK(fetch_sorted_t(ctx, xi, xv));
+        if (!x_changed(xi0, xv0, xi, xv)) break;  // :21
+        xi0 = xi;
+        xv0 = xv;
+    }
+    return P.result(idx, val, nnz);
+}
+
+// rmp(A, b, k): src/stepwise.jl:32-43
+extern "C" int csmp_rmp_k(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, int64_t kmax, int64_t* idx, double* val,
+                          int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "rmp"));
+    if (k < 0) return fail(ctx, CSMP_EINVAL, "rmp: k < 0");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    for (int64_t f = 0; f < ctx->M; ++f) {  // :36-38
+        bool ok;
+        CHECK(P.forward(0.0, 0.0, true, &ok));
+        if (!ok) break;
+    }
+    CHECK(stepwise_full(ctx, P, kcap));
+    for (int t = P.n; t >= k + 1; --t) {  // :39-41
+        bool ok;
+        CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok));
+        if (!ok) break;
+    }
+    return P.result(idx, val, nnz);
+}
+
+// foba(A, b, delta): src/stepwise.jl:47-56
+extern "C" int csmp_foba(csmp_ctx* ctx, const void* b, int b_dtype, double delta, int64_t kmax, int64_t* idx, double* val,
+                         int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "foba"));
+    HIPCHECK(hipSetDevice(ctx->dev));
+    int kcap;
+    CHECK(stepwise_cap(ctx, kmax, &kcap));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, kcap));
+    const double d2 = delta * delta;
+    for (int64_t f = 0; f < ctx->M; ++f) {  // :50
+        bool ok;
+        CHECK(P.forward(0.0, d2, true, &ok));  // :51
+        if (!ok) break;
+        const double half = std::sqrt(P.last_max_d2) / 2.0;  // :52-53
+        for (;;) {
+            CHECK(P.backward((double)HUGE_VAL, half * half, &ok));
+            if (!ok) break;
+        }
+    }
+    CHECK(stepwise_full(ctx, P, kcap));
+    return P.result(idx, val, nnz);
+}
+
+// br(A,b,max_eps,max_delta,k) (src/backward.jl:27-35; fbr :154-162 is the same algorithm on the normal
+// equations) and, with lace != 0, lace(A,b,eps,delta,k) (:233-270): the least-squares solution on ALL
+// N <= M columns, then backward steps until k atoms are left or a threshold stops them.
+extern "C" int csmp_br(csmp_ctx* ctx, const void* b, int b_dtype, double max_eps, double max_delta, int64_t k, int lace,
+                       int64_t* idx, double* val, int64_t* nnz) {
+    CHECK(stepwise_args(ctx, b, "br"));
+    if (k < 0) return fail(ctx, CSMP_EINVAL, "br: k < 0");
+    if (max_eps != max_eps || max_delta != max_delta) return fail(ctx, CSMP_EINVAL, "br: threshold is NaN");
+    if (ctx->N > ctx->M) return fail(ctx, CSMP_ERANGE, "br: A needs to be overdetermined (size(A,2) <= size(A,1))");  // :218
+    if (ctx->N > kTMaxCols) return fail(ctx, CSMP_ERANGE, "br: more than 1023 columns");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Stepwise P;
+    CHECK(P.begin(ctx, b, b_dtype, (int)ctx->N));
+    std::vector<int> all((size_t)ctx->N);
+    for (int64_t j = 0; j < ctx->N; ++j) all[(size_t)j] = (int)j;
+    CHECK(ls_on_columns(ctx, all));  // UpdatableQR(A); x = AiQR \ b   (:11,:30)
+    CHECK(launch_tinv_build(ctx));
+    CHECK(P.read_state());
+    P.n = P.hs.nsel;
+    if (P.hs.done) CHECK(P.clear_flags());
+    const double d2 = max_delta * max_delta;
+    for (int t = P.n; t >= k + 1; --t) {  // :31-33
+        bool ok;
+        CHECK(P.backward(max_eps, d2, &ok, lace != 0));
+        if (!ok) break;
+    }
+    return P.result(idx, val, nnz);
+}
