@@ -50,10 +50,26 @@ Base.size(D::Dictionary) = (D.n, D.m)
 Base.size(D::Dictionary, i::Int) = size(D)[i]
 Base.eltype(::Dictionary{T}) where {T} = T
 
-# the reference throws bare strings (src/matchingpursuit.jl:74; src/twostage.jl:76): so do we
+# the reference throws bare strings (src/matchingpursuit.jl:74; src/twostage.jl:76): so do we.  A POSITIVE status is a
+# warning with valid results (CSMP_WCAPACITY = 1: the solve stopped at the on-device QR append's capacity, ~3900 atoms).
+const CSMP_WCAPACITY = Cint(1)
 function check(D::Dictionary, rc::Integer)
     rc == 0 && return
+    rc == CSMP_WCAPACITY && (@warn "libcsmp: the support reached the on-device QR capacity; the solution reached there is returned"; return)
     throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), D.ctx)))
+end
+
+# ---------------------------------------------------------------------------------- options (include/csmp.h, CSMP_OPT_*)
+# The reference passes its behavioural choices as arguments and so does this module; the choices that exist only on the GPU
+# side are per-Dictionary options.  The library reads no environment variable.
+const OPTIONS = Dict(:batch_cert => 1, :batch_gram => 2, :batch_window => 3, :pipeline => 4, :force_reorth => 5,
+                     :ls_gram => 6, :ls_gram_reuse => 7, :twostage_update => 8, :solves_in_flight => 9)
+set_option!(D::Dictionary, key::Symbol, value::Integer) =
+    check(D, ccall((:csmp_set_option, libcsmp), Cint, (Ptr{Cvoid}, Cint, Int64), D.ctx, OPTIONS[key], value))
+function get_option(D::Dictionary, key::Symbol)
+    v = Ref{Int64}(0)
+    check(D, ccall((:csmp_get_option, libcsmp), Cint, (Ptr{Cvoid}, Cint, Ref{Int64}), D.ctx, OPTIONS[key], v))
+    v[]
 end
 
 const MatOrDict{T} = Union{StridedMatrix{T}, Dictionary{T}}
@@ -250,7 +266,7 @@ function begin_solver(A::MatOrDict{T}, b, algo, kcap, l = 1) where {T}
     P
 end
 pcheck(P::DevicePursuit, rc::Integer) =
-    rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), P.ctx)))
+    rc >= 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), P.ctx)))  # (> 0: CSMP_WCAPACITY, x unchanged)
 MP(A, b; steps::Integer = 4096) = begin_solver(A, b, ALGO_MP, steps)                       # :19-24 (steps: length of the device's step log)
 OMP(A, b, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_OMP, min(k, size(A, 1)))      # :54-60
 GOMP(A, b, l::Int, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_GOMP, min(k, size(A, 1)), l)  # :108-114
@@ -270,10 +286,16 @@ end
 
 # ---------------------------------------------------------------------------------- many signals
 # [omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU.  method = :exact: single-signal sweeps, three signals
-# pipelined (csmp_omp_batch); :mfma: one bf16 screening GEMM per step + Float64 rescoring (csmp_omp_batch_mfma).
+# pipelined (csmp_omp_batch); :mfma: one bf16 screening GEMM per step + Float64 rescoring (csmp_omp_batch_mfma), with
+# certificate = :statistical | :rigorous and gram = true | false (CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM).
 # Returns (idx k x nsig 0-based, -1 padded; val; nnz) as the C ABI does -- the layout csmp_pack_results packs.
-function omp_batch_raw(A::MatOrDict{T}, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact) where {T}
+function omp_batch_raw(A::MatOrDict{T}, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact,
+                       certificate::Symbol = :statistical, gram::Bool = false) where {T}
     D = dict(A)
+    if method === :mfma
+        set_option!(D, :batch_cert, certificate === :rigorous ? 1 : 0)
+        set_option!(D, :batch_gram, gram ? 1 : 0)
+    end
     BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
     nsig = size(BB, 2)
     idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)
@@ -283,9 +305,34 @@ function omp_batch_raw(A::MatOrDict{T}, B::StridedMatrix, ε::Real, k::Int; meth
         D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, k, ε, idx, val, nnz, CSMP_HOST))
     idx, val, nnz
 end
-omp_batch(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact) = begin
-    idx, val, nnz = omp_batch_raw(A, B, ε, k; method = method)
+omp_batch(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int; kw...) = begin
+    idx, val, nnz = omp_batch_raw(A, B, ε, k; kw...)
     [to_sparse(size(A, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:size(B, 2)]
+end
+
+# [gomp(A, B[:, s], l, eps, k) for s in axes(B, 2)]: two solves in flight on two streams (csmp_gomp_batch)
+function gomp_batch(A::MatOrDict{T}, B::StridedMatrix, l::Int, ε::Real, k::Int) where {T}
+    D = dict(A)
+    BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
+    nsig = size(BB, 2)
+    idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)
+    GC.@preserve BB idx val nnz check(D, ccall((:csmp_gomp_batch, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
+        D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, l, k, ε, idx, val, nnz, CSMP_HOST))
+    [to_sparse(size(A, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:nsig]
+end
+
+# [sp(A, B[:, s], k, δ; maxiter) for s in axes(B, 2)]: up to four solves in flight (csmp_sp_batch; CSMP_OPT_SOLVES_IN_FLIGHT)
+function sp_batch(A::MatOrDict{T}, B::StridedMatrix, k::Int, δ::Real = 1e-12; maxiter = 16k) where {T}
+    2k > size(B, 1) && error("2k = $(2k) > $(size(B, 1)) = length(b) is invalid for Subspace Pursuit")
+    D = dict(A)
+    BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
+    nsig = size(BB, 2)
+    idx, val, nnz, its = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig), zeros(Int64, nsig)
+    GC.@preserve BB idx val nnz its check(D, ccall((:csmp_sp_batch, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Int64, Cdouble, Int64, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Int64}),
+        D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, k, δ, maxiter, idx, val, nnz, its))
+    [to_sparse(size(A, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:nsig]
 end
 
 # Signals sharded over ranks (SURVEY section 8e): rank r solves csmp_shard_range's block on its own GPU and ONE
@@ -293,12 +340,12 @@ end
 #     allgather = v -> MPI.Allgather(v, comm)        # MPI.jl; every rank passes a block of the same length
 # (blocks are padded to the longest one: ceil(nsig / world) signals).
 function omp_sharded(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int, rank::Int, world::Int, allgather;
-                     method::Symbol = :exact)
+                     method::Symbol = :exact, kw...)
     nsig = size(B, 2)
     lo, hi = Ref{Int64}(0), Ref{Int64}(0)
     ccall((:csmp_shard_range, libcsmp), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), nsig, rank, world, lo, hi)
     n = hi[] - lo[]
-    idx, val, nnz = omp_batch_raw(A, B[:, lo[]+1:hi[]], ε, k; method = method)
+    idx, val, nnz = omp_batch_raw(A, B[:, lo[]+1:hi[]], ε, k; method = method, kw...)
     maxn = cld(nsig, world)
     w = 2k + 1
     packed = zeros(Float64, w * maxn)                     # row-major rows of 2k+1: [idx | val | nnz] per signal
