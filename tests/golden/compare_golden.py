@@ -1,23 +1,35 @@
 """compare_golden.py <oracle.npz> <reference.npz> -- diff of the oracle-generated golden vectors against the ones the
 real CompressedSensing.jl produced (make_golden_reference.jl).  Supports must be identical; coefficients within the
-north_star tolerance (1e-6 relative); selection orders identical where both files carry one.  Exit code 0 = the oracle is
-pinned by the reference on every committed case."""
+north_star tolerance (1e-6 relative); selection orders identical where both files carry one.
+
+Float32 cases are reported but do NOT count: for a `Matrix{Float32}` the real package computes everything in Float32
+(src/matchingpursuit.jl:56-58: r, Ar and the UpdatableQR take eltype(A)), while this library and its oracle compute in
+Float64 on the exactly promoted values (north_star's tolerance 1e-6 cannot be met in Float32
+either).  On those cases the reference may legitimately pick another atom at a near-tie below Float32 resolution and its
+coefficients carry Float32 round-off; the pin is the Float64 cases.
+Exit code 0 = the oracle is pinned by the reference on every committed Float64 case."""
 import sys
 
 import numpy as np
 
 a, b = np.load(sys.argv[1]), np.load(sys.argv[2])
-bad = 0
+bad = bad32 = 0
 for name in (str(n) for n in a["names"]):
+    f32 = a[name + ".A"].dtype == np.float32
     ia, ib = a[name + ".idx"], b[name + ".idx"]
     va, vb = a[name + ".val"], b[name + ".val"]
     oa, ob = a[name + ".order"], b[name + ".order"]
     ok = np.array_equal(ia, ib)
+    tol = 1e-4 if f32 else 1e-6  # (Float32 arithmetic on the reference's side: its own round-off)
     if ok and np.all(np.isfinite(va)):
-        ok = np.allclose(va, vb, rtol=1e-6, atol=1e-6 * max(1e-300, float(np.abs(va).max()) if len(va) else 0.0))
+        ok = np.allclose(va, vb, rtol=tol, atol=tol * max(1e-300, float(np.abs(va).max()) if len(va) else 0.0))
     if ok and len(oa) and len(ob):
         ok = np.array_equal(oa, ob)
-    print(("ok      " if ok else "MISMATCH") + " " + name)
-    bad += not ok
-print(f"{bad} mismatching case(s)")
+    tag = "ok      " if ok else ("differs " if f32 else "MISMATCH")
+    print(tag + " " + name + ("   [Float32 dictionary: informational]" if f32 else ""))
+    if f32:
+        bad32 += not ok
+    else:
+        bad += not ok
+print(f"{bad} mismatching Float64 case(s); {bad32} differing Float32 case(s) (informational)")
 sys.exit(1 if bad else 0)

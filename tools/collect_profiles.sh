@@ -22,8 +22,12 @@ pmc() {  # pmc <name> <counters> <bench args...>
 }
 stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
 stats bench_batched --workload batched --steps 2 --warmup 1
-stats bench_sp --workload sp --steps 3 --warmup 1
-stats bench_gomp --workload gomp --steps 2 --warmup 1
+stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
+stats bench_batched_rigorous --workload batched --steps 2 --warmup 1 --batch-cert rigorous
+stats bench_sp --workload sp --steps 9 --warmup 3
+stats bench_sp_single --workload sp_single --steps 3 --warmup 1
+stats bench_gomp --workload gomp --steps 6 --warmup 2
+stats bench_gomp_single --workload gomp_single --steps 2 --warmup 1
 # HBM traffic of the steady-state tick (two passes: the TCC block cannot hold both counters)
 d1=$(pmc fetch FETCH_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 d2=$(pmc write WRITE_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
