@@ -247,23 +247,60 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     }
     if (ctx->opt_batch_window > 0) kwin = std::min<int>(kWinMax, (int)ctx->opt_batch_window);
     if (tune_env("CSMP_CERT_NOREL")) cert_rel = std::ldexp(1.0, -14);  // (experiments build: the round-2 bound, for tools/probe_structured.py)
-    b.last_mode = kScreen256p;
+    const int mode = tune_env("CSMP_SCREEN4") ? kScreen4 : kScreen256p;
+    b.last_mode = mode;
     b.last_streams = 1;
     b.last_screen_signals = Bpad;
+    // Two half-batches on two streams, out of phase (experiments build, CSMP_BATCH_HALVES=2): each half is an independent chain
+    // screen -> pick -> append -> screen ... on its own stream; the second half's first screen is held back until the first
+    // half's has finished, so that one half's screening GEMM (matrix cores) meets the other half's per-signal kernels (HBM).
+    int nh = 1;
+    if (const char* hv = tune_env("CSMP_BATCH_HALVES")) nh = (atoi(hv) == 2 && Bpad >= 4 * kBT) ? 2 : 1;
+    int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
+    hipStream_t hs_[2] = {ctx->stream, ctx->stream};
+    if (nh == 2) {
+        const int tile = 2 * kBT;
+        hpad[0] = ((Bpad / 2 + tile - 1) / tile) * tile;
+        hpad[1] = Bpad - hpad[0];
+        h0[1] = hpad[0];
+        hn[0] = (int)std::min<int64_t>(nsig, hpad[0]);
+        hn[1] = (int)(nsig - hn[0]);
+        if (hn[1] <= 0) nh = 1;
+    }
+    if (nh == 2) {
+        if (!ctx->stream_b) HIPCHECK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
+        for (auto* ev : {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_off})
+            if (!*ev) HIPCHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        hs_[1] = ctx->stream_b;
+        HIPCHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
+        HIPCHECK(hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
+        b.last_streams = 2;
+        b.last_screen_signals = hpad[0];
+    }
+    const size_t ncand = (size_t)b.n_atiles * kTileCand;
     for (int64_t t = 0; t < k; ++t) {
-        const bool timed = ctx->prof;  // (HIP events around the screening launch)
-        if (timed) {
-            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        for (int h = 0; h < nh; ++h) {
+            const bool timed = ctx->prof && h == 0;  // (HIP events around the first half's screening launch)
+            if (timed) {
+                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
+            }
+            if (t == 0 && h == 1) HIPCHECK(hipStreamWaitEvent(hs_[1], ctx->ev_off, 0));
+            HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles, hpad[h] / kBT, ctx->N,
+                                   b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand));
+            if (t == 0 && h == 0 && nh == 2) HIPCHECK(hipEventRecord(ctx->ev_off, hs_[0]));
+            if (timed) {
+                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
+            }
+            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram)
+                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram);
+            HIPCHECK(e);
         }
-        HIPCHECK(launch_screen(ctx->stream, (const __bf16*)b.Ab, (const __bf16*)b.Rb, b.Mk, b.n_atiles, Bpad / kBT, ctx->N, b.cand_val, b.cand_idx));
-        if (timed) {
-            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
-        }
-        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram)
-                                              : b_step_dispatch<double>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram);
-        HIPCHECK(e);
+    }
+    if (nh == 2) {
+        HIPCHECK(hipEventRecord(ctx->ev_join, ctx->stream_b));
+        HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     }
     hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
                        (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);

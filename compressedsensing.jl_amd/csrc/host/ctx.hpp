@@ -109,6 +109,8 @@ struct csmp_ctx {
     csmp_ctx* twins[3] = {nullptr, nullptr, nullptr};  // clones on their own streams: the other solves in flight of csmp_gomp_batch / csmp_sp_batch
     int opt_in_flight = 3;        // CSMP_OPT_SOLVES_IN_FLIGHT (csmp_sp_batch)
     hipEvent_t ev_twin = nullptr;
+    hipStream_t stream_b = nullptr;  // second stream of the batched path (half-batches out of phase)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_off = nullptr;
     int dtype = CSMP_F32;
     int64_t M = 0, N = 0, ld = 0;
     int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)

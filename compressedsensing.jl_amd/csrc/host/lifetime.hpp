@@ -97,6 +97,9 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         t = nullptr;
     }
     if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
+    if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_off})
+        if (e) (void)hipEventDestroy(e);
     dict_release(ctx);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
     for (auto& e : ctx->ev2) (void)hipEventDestroy(e);

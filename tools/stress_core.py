@@ -1,5 +1,6 @@
-"""Randomised GPU-vs-oracle comparison of the core path (omp, gomp, sp, mp-free, the two batch drivers, lstsq).
-    python tools/stress_core.py [seconds] [seed]"""
+"""Randomised GPU-vs-oracle comparison of the core path (omp, gomp, sp, the batch drivers incl. the MFMA-screened one under both
+certificates and with the resident Gram matrix, the in-flight batch forms of gomp / sp, lstsq), on Gaussian and -- every third
+round -- structured dictionaries.    python tools/stress_core.py [seconds] [seed]"""
 import os
 import sys
 import time
@@ -15,6 +16,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t0 = time.time()
 runs = bad = 0
+rounds = 0
 tally = {}
 
 
@@ -35,9 +37,16 @@ while time.time() - t0 < budget:
     N = int(rng.choice([300, 1000, 3000, 8000]))
     dtype = rng.choice([np.float32, np.float64])
     k = int(rng.integers(2, max(3, min(M // 6, 48))))
-    A = rng.standard_normal((M, N))
-    A /= np.linalg.norm(A, axis=0)
-    A = np.asfortranarray(A.astype(dtype))
+    kind = "gaussian"
+    if rounds % 3 == 2:
+        kind = str(rng.choice(["few_valued", "partial_dct", "one_magnitude", "signs"]))
+        A = cs.structured_dictionary(kind, M, max(N, M), rng=rng, dtype=dtype)
+        N = A.shape[1]
+    else:
+        A = rng.standard_normal((M, N))
+        A /= np.linalg.norm(A, axis=0)
+        A = np.asfortranarray(A.astype(dtype))
+    rounds += 1
     nsig = int(rng.choice([1, 2, 3, 5, 7]))
     B = []
     for _ in range(nsig):
@@ -46,7 +55,7 @@ while time.time() - t0 < budget:
         e = rng.standard_normal(M)
         B.append(b + 5e-3 * e / np.linalg.norm(e))
     B = np.asfortranarray(np.stack(B, axis=1))
-    cfg = (M, N, k, str(np.dtype(dtype)), nsig)
+    cfg = (kind, M, N, k, str(np.dtype(dtype)), nsig)
     eps = float(np.finfo(dtype).eps)
     D = cs.Dictionary(A)
     try:
@@ -55,13 +64,30 @@ while time.time() - t0 < budget:
         idx, val, nnz = D.ctx.omp_batch(B, k, eps)
         for s in range(nsig):
             cmp("omp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
-        idx, val, nnz = D.ctx.omp_batch_mfma(B, k, eps)
-        for s in range(nsig):
-            cmp("omp_mfma", (np.sort(idx[:nnz[s], s]), val[:nnz[s], s][np.argsort(idx[:nnz[s], s])]), refs[s], cfg)
+        for cert, gram, name in ((0, 0, "omp_mfma"), (1, 0, "omp_mfma_rigorous"), (0, 1, "omp_mfma_gram")):
+            if gram and N > 8000:
+                continue
+            D.ctx.set_option("batch_cert", cert)
+            D.ctx.set_option("batch_gram", gram)
+            idx, val, nnz = D.ctx.omp_batch_mfma(B, k, eps)
+            for s in range(nsig):
+                cmp(name, (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
+        D.ctx.set_option("batch_cert", 0)
+        D.ctx.set_option("batch_gram", 0)
         l = int(rng.choice([2, 3, 4]))
-        cmp("gomp", D.ctx.gomp(B[:, 0], l, k, eps), oc.gomp(A, B[:, 0], l, k, eps), cfg + (l,))
+        gref = [oc.gomp(A, B[:, s], l, k, eps) for s in range(nsig)]
+        cmp("gomp", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
+        if l <= k:
+            idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
+            for s in range(nsig):
+                cmp("gomp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
         if 2 * k <= M:
-            cmp("sp", D.ctx.sp(B[:, 0], k, 1e-12), oc.sp(A, B[:, 0], k, 1e-12), cfg)
+            sref = [oc.sp(A, B[:, s], k, 1e-12) for s in range(nsig)]
+            cmp("sp", D.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
+            D.ctx.set_option("solves_in_flight", int(rng.integers(1, 5)))
+            idx, val, nnz, its = D.ctx.sp_batch(B, k, 1e-12)
+            for s in range(nsig):
+                cmp("sp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), sref[s], cfg)
         cols = np.sort(rng.choice(N, min(3 * k, M // 2), replace=False))
         got = D.ctx.lstsq(cols, B[:, 0])
         ref = oc.lstsq_cols(A, cols, B[:, 0])
