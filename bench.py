@@ -471,6 +471,17 @@ def run_twostage(args, cs, torch, dev, At, D, emit=True):
                         "kernel": "csmp::k_sweep_pf<float,16,true>" if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     D.ctx.profile_enable(False)
+    # the same solves, three in flight (api.solve_in_flight: the Dictionary's context + two clones, a host thread each): one
+    # signal's long latency-bound chain (rank-one exchanges, selections, host decisions) under the others' sweeps
+    def one(c, b):
+        return c.ompr(b, K_ATOMS, 1e-6)[2] if args.workload == "ompr" else c.srr(b, K_ATOMS, 1e-12, -1, 1, 1)[2]
+    many = [sigs[W + (i % K)] for i in range(3 * K)]
+    cs.solve_in_flight(D, many[:3], one, in_flight=3)  # (the clones' first call allocates their solver slots)
+    t0 = time.perf_counter()
+    its = cs.solve_in_flight(D, many, one, in_flight=3)
+    dt3 = time.perf_counter() - t0
+    out["three_in_flight"] = {"solves": len(many), "ms_per_solve": dt3 / len(many) * 1e3, "solves_per_s": len(many) / dt3,
+                              "iterations_equal_single": bool(sum(its[:K]) == iters)}
     if emit:
         print(json.dumps(out), flush=True)
     return out

@@ -300,6 +300,44 @@ def sp_batch(A, B, k, delta=1e-12, maxiter=None):
             D.close()
 
 
+def solve_in_flight(A, signals, solve, in_flight=3):
+    """Any single-signal driver for many signals with `in_flight` solves at once on ONE GPU: `solve(ctx, b)` is called with a
+    context of its own (the Dictionary's and `in_flight - 1` clones: own stream, own solver state, the same resident dictionary)
+    from a host thread of its own -- the library calls release the GIL -- so that one signal's short, latency-bound stages run
+    under another signal's dictionary sweeps (what csmp_gomp_batch / csmp_sp_batch do inside the library).  Returns the list
+    of `solve`'s results in signal order.  Example: solve_in_flight(D, cols, lambda c, b: c.ompr(b, 64, 1e-6))."""
+    import threading
+    D, tmp = _dict(A)
+    signals = list(signals)
+    T = max(1, min(int(in_flight), len(signals)))
+    ctxs = [D.ctx] + [D.ctx.clone() for _ in range(T - 1)]
+    out = [None] * len(signals)
+    err = [None] * T
+
+    def work(t):
+        try:
+            for s in range(t, len(signals), T):
+                out[s] = solve(ctxs[t], signals[s])
+        except Exception as e:  # noqa: BLE001
+            err[t] = e
+    try:
+        th = [threading.Thread(target=work, args=(t,)) for t in range(1, T)]
+        for x in th:
+            x.start()
+        work(0)
+        for x in th:
+            x.join()
+    finally:
+        for c in ctxs[1:]:
+            c.close()
+        if tmp:
+            D.close()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
 def fr_batch(A, B, k, max_eps=0.0, min_delta=0.0):
     """[fr(A, B[:, s], max_eps, min_delta, k) for s in axes(B, 2)]: list of SparseVectors (pipelined on the device)."""
     D, tmp = _dict(A)

@@ -1458,6 +1458,26 @@ def test_sp_batch_equals_single_calls(cs, oracle, D, cfg):
     assert all(np.array_equal(xs[s].nzind, first[0][:, s]) for s in range(nsig))
 
 
+def test_solve_in_flight_with_clones(cs, oracle, D):
+    """solve_in_flight: ompr / srr / fr for many signals, three at a time on clones driven by host threads, equal the one-at-a-time
+    calls and the oracle."""
+    n, m, k, nsig = 96, 600, 6, 7
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=31, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(32)
+    cols = [cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k + 2, rng=rng).to_dense(), 0.05, rng=rng) for _ in range(nsig)]
+    got = cs.solve_in_flight(d, cols, lambda c, y: c.ompr(y, k, 1e-6), in_flight=3)
+    for s in range(nsig):
+        ref = oracle.ompr(A, cols[s], k, 1e-6)
+        assert np.array_equal(got[s][0], ref[0]) and close(got[s][1], ref[1]) and got[s][2] == ref[2]
+    got = cs.solve_in_flight(d, cols, lambda c, y: c.srr(y, k), in_flight=2)
+    for s in range(nsig):
+        ref = oracle.srr(A, cols[s], k)
+        assert np.array_equal(got[s][0], ref[0]) and close(got[s][1], ref[1])
+    with pytest.raises(cs.CsmpError):  # an error inside a worker surfaces
+        cs.solve_in_flight(d, cols, lambda c, y: c.sp(y, n, 1e-6), in_flight=3)
+
+
 def test_solve_stops_at_the_qr_capacity_instead_of_failing(cs, oracle, D):
     """omp(A, b, 0) with k = size(A,1) = 4096 on a signal no stopping rule ends used to run ~3900 steps and then
     fail with ERANGE, losing the work.  Now the append that would not fit is withheld: the call returns CSMP_WCAPACITY (a
