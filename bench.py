@@ -89,6 +89,10 @@ def parse():
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
+    p.add_argument("--share-gpu", action="store_true",
+                   help="rehearsal of the N > 1 path on a node with fewer GPUs than ranks: rank r uses GPU r mod (visible GPUs) and the "
+                        "exchange runs over gloo through host memory (RCCL refuses two ranks on one device) -- exercises every line of the "
+                        "multi-rank code; the numbers are NOT a scaling measurement")
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
@@ -584,7 +588,7 @@ def run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen
     def all_supports(idx):
         if not use_dist:
             return [idx]
-        t = torch.from_numpy(idx).to(dev)
+        t = torch.from_numpy(idx) if dist.get_backend() == "gloo" else torch.from_numpy(idx).to(dev)
         out = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(out, t)
         return [o.cpu().numpy() for o in out]
@@ -645,6 +649,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.share_gpu and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()
     if local >= torch.cuda.device_count():  # (device_count() does not initialise the GPU)
         print(f"bench.py: rank {rank} wants GPU {local} but this node shows {torch.cuda.device_count()} GPU(s): one process per GPU, "
               f"--gpus must not exceed the visible devices", file=sys.stderr, flush=True)
@@ -653,7 +659,10 @@ def main():
     dev = torch.device("cuda", local)
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # launched by torch.distributed.run
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     ranks_seen, devices = rank_census(torch, dist, dev, use_dist, world)
 
     def finish():

@@ -61,8 +61,15 @@ def gather_packed(packed, nsig, group=None):
     if packed.shape[0] != maxn:
         mine = torch.zeros((maxn, packed.shape[1]), dtype=packed.dtype, device=packed.device)
         mine[:packed.shape[0]] = packed
-    out = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(out, mine, group=group)  # the single collective of the path
+    if mine.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo gathers host tensors only (rehearsals of the multi-rank path with several ranks on one GPU: bench.py --share-gpu)
+        host = mine.cpu()
+        outh = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(outh, host, group=group)
+        out = [o.to(mine.device) for o in outh]
+    else:
+        out = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(out, mine, group=group)  # the single collective of the path
     parts = []
     for r in range(world):
         rlo, rhi = shard_range(nsig, r, world)
@@ -209,8 +216,14 @@ def omp_colsharded(shards, b, k, eps, group=None):
                 if virtual:
                     allrec, nrec = torch.cat([r.reshape(-1) for r in recs]), len(mine)
                 else:
-                    allrec = torch.empty(world * recs[0].numel(), dtype=recs[0].dtype, device=recs[0].device)
-                    dist.all_gather_into_tensor(allrec, recs[0].reshape(-1), group=group)  # the ONE collective of a step
+                    if recs[0].is_cuda and dist.get_backend(group) == "gloo":  # (rehearsal with ranks sharing a GPU: through host memory)
+                        host = recs[0].reshape(-1).cpu()
+                        allh = torch.empty(world * host.numel(), dtype=host.dtype)
+                        dist.all_gather_into_tensor(allh, host, group=group)
+                        allrec = allh.to(recs[0].device)
+                    else:
+                        allrec = torch.empty(world * recs[0].numel(), dtype=recs[0].dtype, device=recs[0].device)
+                        dist.all_gather_into_tensor(allrec, recs[0].reshape(-1), group=group)  # the ONE collective of a step
                     nrec = world
                 for sh in mine:
                     sh.append(allrec, nrec)

@@ -2,10 +2,13 @@
 ctypes host mirror), against the CPU oracle on the same seeded inputs and against the committed
 golden vectors.  Bar: identical supports / selection order (integer work: bit-exact), coefficients
 within 1e-6 relative in Float64 (north_star) -- in practice ~1e-13."""
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 RTOL = 1e-6  # BASELINE.json north_star: "coefficients within 1e-6 relative Float64"
 EPS64 = float(np.finfo(np.float64).eps)
@@ -1576,3 +1579,32 @@ def test_column_sharded_omp_ties_and_stops(cs, oracle):
         assert np.array_equal(got[2], ref[2]), (got[2], ref[2])
         assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
         assert max(j0, dup) not in got[0] and min(j0, dup) in got[0]
+
+
+@pytest.mark.parametrize("workload", ["omp", "colsharded", "batched"])
+def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
+    """The N > 1 code of bench.py end to end on the GPU box: two ranks under torchrun sharing the one GPU (--share-gpu: the
+    exchange over gloo, because RCCL refuses two ranks on one device).  Checks the JSON contract of the multi-rank line: ranks seen,
+    the gathered rows and the recomputation check of the signal-sharded workload, the cross-rank agreement of the column-sharded
+    one.  Not a scaling measurement."""
+    import json
+    import subprocess
+    import sys
+    port = 29000 + os.getpid() % 2000
+    extra = {"omp": ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
+             "colsharded": ["--workload", "colsharded", "--steps", "1", "--warmup", "0"],
+             "batched": ["--workload", "batched", "--steps", "1", "--warmup", "0"]}[workload]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2 and "error" not in line
+    if workload == "omp":
+        assert line["gathered_rows"] == 2 * 2 and line["gather_check"]["rows_ok"]
+        assert line["gather_check"]["first_signal_of_every_rank_equals_rank0_recomputation"] == [True, True]
+        assert line["atoms_selected"] == 2 * 2 * 256
+    elif workload == "colsharded":
+        assert line["ranks_agree_on_first_support"] and line["supports_gathered"] == 2 and line["scaling"] == "strong"
+    else:
+        assert line["matches_exact_path_on_sample"] and abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 1024 * 128) < 1.0
