@@ -1581,7 +1581,7 @@ def test_column_sharded_omp_ties_and_stops(cs, oracle):
         assert max(j0, dup) not in got[0] and min(j0, dup) in got[0]
 
 
-@pytest.mark.parametrize("workload", ["omp", "colsharded", "batched"])
+@pytest.mark.parametrize("workload", ["omp", "colsharded", "batched", "batched8"])
 def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
     """The N > 1 code of bench.py end to end on the GPU box: two ranks under torchrun sharing the one GPU (--share-gpu: the
     exchange over gloo, because RCCL refuses two ranks on one device).  Checks the JSON contract of the multi-rank line: ranks seen,
@@ -1591,15 +1591,17 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
     import subprocess
     import sys
     port = 29000 + os.getpid() % 2000
+    world = 8 if workload == "batched8" else 2  # batched8 = BASELINE configs[3] in shape: 8192 signals over 8 ranks, one gather
     extra = {"omp": ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
              "colsharded": ["--workload", "colsharded", "--steps", "1", "--warmup", "0"],
-             "batched": ["--workload", "batched", "--steps", "1", "--warmup", "0"]}[workload]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu"] + extra
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+             "batched": ["--workload", "batched", "--steps", "1", "--warmup", "0"],
+             "batched8": ["--workload", "batched", "--steps", "1", "--warmup", "0"]}[workload]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--share-gpu"] + extra
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1500)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and len(line["devices"]) == 2 and "error" not in line
+    assert line["n_gpus"] == world and line["ranks_seen"] == world and len(line["devices"]) == world and "error" not in line
     if workload == "omp":
         assert line["gathered_rows"] == 2 * 2 and line["gather_check"]["rows_ok"]
         assert line["gather_check"]["first_signal_of_every_rank_equals_rank0_recomputation"] == [True, True]
@@ -1607,4 +1609,4 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
     elif workload == "colsharded":
         assert line["ranks_agree_on_first_support"] and line["supports_gathered"] == 2 and line["scaling"] == "strong"
     else:
-        assert line["matches_exact_path_on_sample"] and abs(line["value"] * line["ms_per_step"] * 1e-3 - 2 * 1024 * 128) < 1.0
+        assert line["matches_exact_path_on_sample"] and abs(line["value"] * line["ms_per_step"] * 1e-3 - world * 1024 * 128) < 1.0

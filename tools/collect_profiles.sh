@@ -49,4 +49,11 @@ if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
     out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (k_b_screen256p, all 1024 signals of the batch)"
 print(json.dumps(out, indent=1))
 PY
+# HBM traffic of the batched path's kernels (default options and with the Gram matrix)
+d4=$(pmc bfetch FETCH_SIZE --workload batched --steps 1 --warmup 0)
+d5=$(pmc bwrite WRITE_SIZE --workload batched --steps 1 --warmup 0)
+python3 $R/tools/pmc_batched.py $d4 $d5 > $OUT/batched_traffic.json
+d6=$(pmc bgfetch FETCH_SIZE --workload batched --steps 1 --warmup 0 --batch-gram)
+d7=$(pmc bgwrite WRITE_SIZE --workload batched --steps 1 --warmup 0 --batch-gram)
+python3 $R/tools/pmc_batched.py $d6 $d7 gram > $OUT/batched_gram_traffic.json
 ls -la $OUT
