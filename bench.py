@@ -187,6 +187,17 @@ def make_signals_fast(torch, dev, At, first_id, count, k):
 MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the 2:1-sparse figure is not used)
 
 
+def per_signal_roofline(nsig, k, gram, us):
+    """HBM roofline of k_b_pick + k_b_append over one OMP step of a batch (averaged over the k steps of a solve)."""
+    j_avg = (k - 1) / 2.0
+    j2_avg = sum(j * j for j in range(k)) / k
+    per_signal = (1 if gram else 2) * j_avg * M * 4 + M * 4 + 2 * M * 8 + M * 2 + j2_avg * 8 + (N // 128) * 4 * 8 + M * 8
+    b = nsig * per_signal
+    return {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_step": b, "us_per_step": us,
+            "achieved": b / (us * 1e-6) / 1e9 if us > 0 else 0.0, "frac": b / (us * 1e-6) / 1e9 / HBM_PEAK_GBS if us > 0 else 0.0,
+            "traffic": None, "note": "everything of the step that is not the screening launch; rescored window columns not counted"}
+
+
 def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=0, gram=0, nsig=1024, k=128):
     """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128.
     A step = one batch of 1024 complete solves.  cert / gram: the options CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM of the
@@ -273,6 +284,11 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, ce
                      # the whole OMP step of the batch (screen + rescoring/append of every signal) against the same ceiling
                      "whole_step": {"ms_per_omp_step": ms_per_omp_step, "achieved": flops / (ms_per_omp_step / 1e3) / 1e12,
                                     "frac": flops / (ms_per_omp_step / 1e3) / 1e12 / MFMA_PEAK_TF}},
+        # the per-signal kernels of a step (k_b_pick + k_b_append) against the HBM roofline: their ALGORITHMIC bytes -- per signal and step
+        # (1 or 2) j columns of A_S, the new column, the residual in and out, its bf16 image, T and T' (j^2/2 x 8 B each), the tile
+        # candidates and the residual again for the selection; the window's rescored columns (~5 per signal and step at this
+        # workload, profiles/r03_batched_traffic.json) are NOT counted: a lower bound -- over everything of the step that is not the screen
+        "per_signal_kernels": per_signal_roofline(nsig, k, gram, ms_per_omp_step * 1e3 - (screen_ms / max(screen_n, 1) * 1e3 if screen_n else 0.0)),
         "batch_stats": {"resolved_by_exact_path": int(resolved), "uncertain": int(uncertain), "illcond": int(illcond)},
         "options": {"certificate": "rigorous" if cert else "statistical", "resident_gram": bool(gram),
                     "gram_setup_seconds": gram_seconds,

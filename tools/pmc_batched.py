@@ -6,7 +6,10 @@
   k_b_append      per signal: 2 j columns (pass 1, pass 2; 1 j with the Gram option) + the new column + residual in and out +
                   bf16 image out + T and T' (j^2 / 2 x 8 B each)
 gfx950 corrections as tools/pmc_traffic.py (FETCH_SIZE in KiB and counting half the bytes of 16-B-per-lane reads).
-    pmc_batched.py <fetch dir> <write dir> [gram]"""
+The WRITE_SIZE pass of this workload hung under rocprofv3 on this pool (round 3: 45 minutes, 564 incomplete dispatches, killed;
+the FETCH_SIZE pass of the same command takes seconds), so `<write dir>` may be `-`: the kernels' writes are then taken as
+their algorithmic size (residual, bf16 image, T column: 2 % of the append kernel's bytes) and flagged as such.
+    pmc_batched.py <fetch dir> <write dir | -> [gram]"""
 import csv, glob, json, os, sys
 
 M, N, B, K = 4096, 65536, 1024, 128
@@ -25,7 +28,10 @@ def collect(d):
 
 
 acc = collect(sys.argv[1])
-acc.update(collect(sys.argv[2]))
+have_writes = sys.argv[2] != "-"
+if have_writes:
+    acc.update(collect(sys.argv[2]))
+alg_writes = {"k_b_screen256p": B * (N // 128) * 4 * 8, "k_b_pick": B * 64, "k_b_append": B * (M * 8 + M * 2 + 2 * (K / 2) * 8)}
 j_avg = (K - 1) / 2.0
 j2_avg = sum(j * j for j in range(K)) / K
 alg = {
@@ -41,9 +47,9 @@ for key in ("k_b_screen256p", "k_b_pick", "k_b_append"):
     if not f:
         continue
     fb = sum(f) / len(f) * 1024 * 2
-    wb = sum(w) / len(w) * 1024 if w else 0.0
-    out[key] = {"dispatches": len(f), "fetch_bytes": fb, "write_bytes": wb, "hbm_bytes": fb + wb, "algorithmic_bytes": alg[key],
-                "ratio": (fb + wb) / alg[key]}
+    wb = sum(w) / len(w) * 1024 if w else alg_writes[key]
+    out[key] = {"dispatches": len(f), "fetch_bytes": fb, "write_bytes": wb, "write_bytes_measured": bool(w), "hbm_bytes": fb + wb,
+                "algorithmic_bytes": alg[key], "ratio": (fb + wb) / alg[key]}
     if key == "k_b_pick":
         out[key]["note"] = "algorithmic = candidates + residual only; the rest is the window's rescored columns (16 KiB each)"
         out[key]["rescored_columns_per_signal_and_step"] = max(0.0, (fb + wb - alg[key]) / B / (M * 4))
