@@ -121,6 +121,7 @@ def dtype_code(dt):
 
 class Context:
     """One GPU + one HIP stream + the resident dictionary (csmp_ctx)."""
+    last_status = OK  # status of the most recent call (positive = a warning with valid results, e.g. WCAPACITY)
 
     def __init__(self, device=0):
         self._h = vp()

@@ -235,12 +235,14 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
     if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
     const bool block = !ctx->force_reorth && l <= kPanelMax;
+    std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
         csmp_ctx* c = cc[sgn & 1];
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
         const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
                                     sgn == 0 ? ctx->ev_twin : nullptr);
+        capped[(size_t)sgn] = c->s.capped;  // (the host withholds the appends: known at enqueue time)
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
             (void)hipStreamSynchronize(cc[0]->stream);
@@ -262,9 +264,10 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
             if (rc == CSMP_OK) {
                 HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHECK(hipStreamSynchronize(ctx->stream));
-                capacity_stop |= ctx->s.capped && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
+                capped[(size_t)sgn] = ctx->s.capped;
             }
         }
+        if (rc == CSMP_OK) capacity_stop |= capped[(size_t)sgn] && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
