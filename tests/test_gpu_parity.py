@@ -1590,7 +1590,11 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
     import json
     import subprocess
     import sys
-    port = 29000 + os.getpid() % 2000
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))  # a free rendezvous port
+    port = sk.getsockname()[1]
+    sk.close()
     world = 8 if workload == "batched8" else 2  # batched8 = BASELINE configs[3] in shape: 8192 signals over 8 ranks, one gather
     extra = {"omp": ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary"],
              "colsharded": ["--workload", "colsharded", "--steps", "1", "--warmup", "0"],
