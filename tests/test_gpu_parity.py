@@ -1461,6 +1461,39 @@ def test_sp_batch_equals_single_calls(cs, oracle, D, cfg):
     assert all(np.array_equal(xs[s].nzind, first[0][:, s]) for s in range(nsig))
 
 
+def test_batch_forms_edge_cases(cs, oracle, D):
+    """Empty and tiny batches, k = 1, l = k, ragged shapes (M = 37, N = 301: nothing is a multiple of a tile), one signal, more
+    solves in flight than signals -- through csmp_gomp_batch, csmp_sp_batch and csmp_omp_batch_mfma with the Gram option."""
+    A, x, b = cs.sparse_data(n=37, m=301, k=3, rng=2, dtype=np.float64)
+    d = D(A)
+    rng = np.random.default_rng(9)
+    B = np.asfortranarray(np.stack([cs.perturb(A @ cs.sparse_vector(301, 3, rng=rng).to_dense(), 1e-3, rng=rng) for _ in range(3)], axis=1))
+    E = np.zeros((37, 0), order="F")
+    for fn in (lambda: d.ctx.gomp_batch(E, 1, 2, 1e-9), lambda: d.ctx.sp_batch(E, 2, 1e-9)):
+        out = fn()
+        assert out[0].shape[1] == 0 and len(out[2]) == 0
+    for l, k in ((1, 1), (3, 3), (2, 5)):
+        idx, val, nnz = d.ctx.gomp_batch(B, l, k, 1e-9)
+        for s in range(3):
+            ref = oracle.gomp(A, B[:, s], l, k, 1e-9)
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]) and close(val[:nnz[s], s], ref[1])
+    one = B[:, :1].copy(order="F")
+    d.ctx.set_option("solves_in_flight", 4)
+    idx, val, nnz, its = d.ctx.sp_batch(one, 3, 1e-12)
+    ref = oracle.sp(A, one[:, 0], 3, 1e-12)
+    assert nnz[0] == 3 and np.array_equal(idx[:, 0], ref[0]) and close(val[:, 0], ref[1]) and its[0] == ref[2]
+    d.ctx.set_option("solves_in_flight", 3)
+    d.ctx.set_option("batch_gram", 1)
+    for k in (1, 4):
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, 1e-9)
+        for s in range(3):
+            ref = oracle.omp(A, B[:, s], k, 1e-9)
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]) and close(val[:nnz[s], s], ref[1])
+    d.ctx.set_option("batch_gram", 0)
+    with pytest.raises(cs.CsmpError):
+        d.ctx.sp_batch(B, 19, 1e-9)  # 2k > M: the reference's error(...) (src/twostage.jl:55)
+
+
 def test_solve_in_flight_with_clones(cs, oracle, D):
     """solve_in_flight: ompr / srr / fr for many signals, three at a time on clones driven by host threads, equal the one-at-a-time
     calls and the oracle."""
