@@ -217,8 +217,12 @@ def rmp(A, b, delta_or_k, maxiter=1, kmax=None):
             D.close()
 
 
-def foba(A, b, delta, kmax=None):
-    """foba(A, b, δ): adaptive forward-backward greedy algorithm, src/stepwise.jl:47-56 (x empty)."""
+def foba(A, b, delta, kmax=None, isfast=True):
+    """foba(A, b, δ; isfast): adaptive forward-backward greedy algorithm, src/stepwise.jl:47-56 (x empty).
+    `isfast` is accepted for signature parity and has no effect: the reference's isfast = Val(false) computes the SAME
+    backward scores |r_{-i}|^2 - |r|^2 by re-factorising without each column in turn (naive_backward_δ!, src/backward.jl:87-105)
+    instead of x_i^2 / γ_i (backward_δ!, :79-83) -- one quantity, two costs; the device evaluates the closed form."""
+    del isfast
     D, tmp = _dict(A)
     try:
         idx, val = D.ctx.foba(b, float(delta), kmax)

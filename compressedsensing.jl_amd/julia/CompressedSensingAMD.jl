@@ -216,7 +216,9 @@ end
 rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0) =
     stepwise_call(:csmp_rmp_delta, A, b, (Float64(δ), Int64(maxiter)), (Cdouble, Int64), kmax)
 rmp(A::MatOrDict, b::AbstractVector, k::Int; kmax::Int = 0) = stepwise_call(:csmp_rmp_k, A, b, (Int64(k),), (Int64,), kmax)
-foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0) = stepwise_call(:csmp_foba, A, b, (Float64(δ),), (Cdouble,), kmax)
+# isfast is accepted for signature parity (src/stepwise.jl:47): Val(false) computes the same backward scores the slow way
+foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0, isfast::Val = Val(true)) =
+    stepwise_call(:csmp_foba, A, b, (Float64(δ),), (Cdouble,), kmax)
 
 # ---------------------------------------------------------------------------------- br = fbr, lace
 # src/backward.jl:27-41,148-162,226-242
