@@ -85,7 +85,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="statistical", help="--workload batched: CSMP_OPT_BATCH_CERT")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
-    p.add_argument("--workload", choices=["omp", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
+    p.add_argument("--workload", choices=["omp", "screened", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -316,6 +316,72 @@ def measure_lone_omp(K, W, B, D, eps):
                          "frac": M * N * 4 / (us_atom * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "note": "ALL-IN: algorithmic bytes per atom / wall time per atom of the whole call (upload of b, sweep, both append "
                                  "stages, kernel boundaries, back substitution, download) -- not a kernel duration"}}
+
+
+def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0):
+    """configs[1] with the screened sweep (CSMP_OPT_SCREENED_SWEEP): every sweep reads the bf16 image (M N 2 bytes) and the
+    pick is certified against the f32 dictionary in Float64, an uncertified solve repeated exactly -- the results are the exact
+    path's, and this function checks that on every timed signal.  Two forms: one csmp_omp call at a time, and csmp_omp_batch
+    (two solves in flight, out of phase).  The headline stays the exact path: this one depends on the certificate holding
+    (it does on these dictionaries: `fallbacks`), which is a property of the data."""
+    import numpy as np
+    B = make_signals(torch, dev, At, 500, K + W)
+    sigs = [B[s].cpu().numpy() for s in range(W + K)]
+    D.ctx.set_option("screened_sweep", 0)
+    exact = [D.ctx.omp(sigs[s], K_ATOMS, eps) for s in range(W, W + K)]
+    D.ctx.set_option("batch_cert", cert)
+    D.ctx.set_option("screened_sweep", 1)
+    out = {"metric": "OMP atoms selected/sec at m=4096,n=65536,k=256, screened sweep (bf16 image, certified picks, exact results)",
+           "unit": "atoms/s", "certificate": "rigorous" if cert else "statistical", "steps": K, "warmup": W}
+    try:
+        for w in range(W):
+            D.ctx.omp(sigs[w], K_ATOMS, eps)
+        D.ctx.screened_stats(reset=True)
+        t0 = time.perf_counter()
+        got = [D.ctx.omp(sigs[s], K_ATOMS, eps) for s in range(W, W + K)]
+        dt = time.perf_counter() - t0
+        atoms = sum(len(g[0]) for g in got)
+        same = all(np.array_equal(g[0], e[0]) and np.array_equal(g[2], e[2]) and np.allclose(g[1], e[1], rtol=1e-9, atol=1e-12)
+                   for g, e in zip(got, exact))
+        us_atom = dt / max(atoms, 1) * 1e6
+        out["lone"] = {"value": atoms / dt, "us_per_atom": us_atom, "ms_per_solve": dt / K * 1e3, "equals_exact_path": bool(same),
+                       "stats": D.ctx.screened_stats(reset=True)}
+        idx = torch.full((K + W, K_ATOMS), -1, dtype=torch.int64, device=dev)
+        val = torch.zeros((K + W, K_ATOMS), dtype=torch.float64, device=dev)
+        nnz = torch.zeros(K + W, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()
+        if W > 0:
+            D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
+        D.ctx.sync()
+        D.ctx.screened_stats(reset=True)
+        D.ctx.profile_enable(16)
+        D.ctx.profile_read(reset=True)
+        t0 = time.perf_counter()
+        D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
+        D.ctx.sync()
+        dt = time.perf_counter() - t0
+        sweeps, sweep_ms = D.ctx.profile_read(reset=True)
+        D.ctx.profile_enable(False)
+        atoms = int(nnz[W:].sum().item())
+        same = all(int(nnz[W + s]) == len(exact[s][0]) and np.array_equal(idx[W + s, :len(exact[s][0])].cpu().numpy(), exact[s][0])
+                   for s in range(K))
+        avg = sweep_ms / max(sweeps, 1) / 1e3
+        out["value"] = atoms / dt
+        out["ms_per_step"] = dt / K * 1e3
+        out["batch"] = {"value": atoms / dt, "us_per_atom": dt / max(atoms, 1) * 1e6, "equals_exact_path": bool(same),
+                        "signals_in_flight": 2, "stats": D.ctx.screened_stats(reset=True)}
+        alg = M * N * 2  # the bf16 image, streamed once per atom
+        out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": alg / avg / 1e9 if sweeps else 0.0,
+                           "frac": alg / avg / 1e9 / HBM_PEAK_GBS if sweeps else 0.0, "traffic": None,
+                           "kernel": "csmp::k_sweep_bf16<2,3,true> (while the other solve's pick / append stages run beside it)",
+                           "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg,
+                           "f32_equivalent_frac_all_in": M * N * 4 / (dt / max(atoms, 1)) / 1e9 / HBM_PEAK_GBS,
+                           "note": "algorithmic bytes of THIS path are M N 2 (bf16 image); f32_equivalent_frac_all_in prices the whole "
+                                   "batch's time per atom against the exact path's M N 4 bytes -- above 1 means faster than any exact sweep can be"}
+    finally:
+        D.ctx.set_option("screened_sweep", 0)
+        D.ctx.set_option("batch_cert", 0)
+    return out
 
 
 def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-2):
@@ -711,6 +777,14 @@ def main():
             (run_fr if args.workload == "fr" else run_twostage)(args, cs, torch, dev, At, D)
         D.close()
         return finish()
+    if args.workload == "screened":
+        if args.steps == 18 and args.warmup == 3:
+            args.steps, args.warmup = 8, 2
+        if rank == 0:
+            print(json.dumps(measure_screened_omp(args.steps, args.warmup, torch, dev, At, D, D.eps,
+                                                  cert=1 if args.batch_cert == "rigorous" else 0)), flush=True)
+        D.close()
+        return finish()
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
@@ -822,6 +896,10 @@ def main():
                 sec["lone_omp_c2"] = measure_lone_omp(3, 1, B, D, eps)
             except Exception as e:  # noqa: BLE001
                 sec["lone_omp_c2"] = {"error": repr(e)}
+            try:  # opt-in: sweeps over the bf16 image with certified picks (same results, half the bytes)
+                sec["omp_c2_screened"] = measure_screened_omp(6, 2, torch, dev, At, D, eps)
+            except Exception as e:  # noqa: BLE001
+                sec["omp_c2_screened"] = {"error": repr(e)}
             for name, cert, gram in (("batched_c3", 0, 0), ("batched_c3_rigorous", 1, 0), ("batched_c3_gram", 0, 1)):
                 try:
                     sec[name] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False, cert=cert, gram=gram)

@@ -19,10 +19,11 @@ HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL, STOP_CAPACITY = 1, 2, 4, 8
 # csmp_set_option keys (include/csmp.h)
-OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
            "force_reorth": OPT_FORCE_REORTH, "ls_gram": OPT_LS_GRAM, "ls_gram_reuse": OPT_LS_GRAM_REUSE,
-           "twostage_update": OPT_TWOSTAGE_UPDATE, "solves_in_flight": OPT_SOLVES_IN_FLIGHT}
+           "twostage_update": OPT_TWOSTAGE_UPDATE, "solves_in_flight": OPT_SOLVES_IN_FLIGHT,
+           "screened_sweep": OPT_SCREENED_SWEEP}
 
 i64 = C.c_int64
 vp = C.c_void_p
@@ -67,6 +68,7 @@ SIGNATURES = {
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(C.c_double)]),
+    "csmp_screened_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.c_int]),
     "csmp_set_option": (C.c_int, [vp, C.c_int, i64]),
     "csmp_get_option": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
@@ -472,6 +474,12 @@ class Context:
         self.call("csmp_batch_stats", *[C.byref(x) for x in v], C.byref(ms))
         return {"signals": v[0].value, "resolved_exactly": v[1].value, "uncertain": v[2].value, "illcond": v[3].value,
                 "screen_launches": v[4].value, "screen_ms": ms.value}
+
+    def screened_stats(self, reset=False):
+        """Screened solves (option screened_sweep) made by this context, and how many were repeated with the exact sweep."""
+        a, b = i64(0), i64(0)
+        self.call("csmp_screened_stats", C.byref(a), C.byref(b), int(bool(reset)))
+        return {"solves": a.value, "fallbacks": b.value}
 
     def omp_batch_device(self, B, k, eps, idx, val, nnz):
         """torch CUDA tensors: B (nsig, M) rows = signals; outputs idx (nsig, k) int64,

@@ -7,6 +7,7 @@
 #include "../../include/csmp.h"
 #include "csmp_kernels.hpp"
 #include "csmp_batched.hpp"
+#include "csmp_screened.hpp"
 #include "csmp_block.hpp"
 #include "csmp_forward.hpp"
 #include "csmp_downdate.hpp"
@@ -36,4 +37,5 @@ using namespace csmp;
 #include "host/gomp_sp.hpp"
 #include "host/twostage.hpp"
 #include "host/batched.hpp"
+#include "host/screened.hpp"
 #include "host/measure.hpp"

@@ -26,6 +26,7 @@ constexpr int kSlabRows = 64;       // rows of Q owned by one QR workgroup
 constexpr int kQrThreads = 256;
 
 enum : int { STOP_EPS = 1, STOP_STAG = 2, STOP_FULL = 4, STOP_REORTH = 8 };  // REORTH: internal, see k_qr2
+constexpr int STOP_UNCERTAIN = 256;  // (only in the flag word the finish kernels hand to the batch drivers: a screened pick failed its certificate)
 
 // Control block of one solve, in device memory.  Written only by single-workgroup control
 // kernels (k_select / k_init) and by workgroup 0 of k_qr1 / k_qr3 / k_mp_update (fields no
@@ -41,6 +42,8 @@ struct DevState {
     int pcount;     // atoms accepted into the current panel (multi-column append, csmp_block.hpp)
     double rnorm2;  // ||r||^2 seen by the last sweep prologue
     double cval;    // signed <a_cand, r> (MP coefficient, src/matchingpursuit.jl:29)
+    int uncertain;  // screened sweep (csmp_screened.hpp): steps whose pick could not be certified
+    int pad_;
 };
 
 using f32x4 = float __attribute__((ext_vector_type(4)));
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(256) void k_finish(const double* __restrict__ R, co
     }
     if (tid == 0) {
         *out_nnz = j;
-        if (flag_out) *flag_out = st->done;
+        if (flag_out) *flag_out = st->done | (st->uncertain ? STOP_UNCERTAIN : 0);
     }
 }
 
@@ -1442,7 +1445,7 @@ __global__ __launch_bounds__(64) void k_finish_w(const double* __restrict__ R, c
     }
     if (lane == 0) {
         *out_nnz = j;
-        if (flag_out) *flag_out = st->done;
+        if (flag_out) *flag_out = st->done | (st->uncertain ? STOP_UNCERTAIN : 0);
     }
 }
 
@@ -1527,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, 
     }
     if (tid == 0) {
         *out_nnz = j;
-        if (flag_out) *flag_out = st->done;
+        if (flag_out) *flag_out = st->done | (st->uncertain ? STOP_UNCERTAIN : 0);
     }
 }
 #endif
@@ -1661,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_trsv_emit(const double* __restrict__ y,
     }
     if (t == 0) {
         *out_nnz = j;
-        if (flag_out) *flag_out = st->done;
+        if (flag_out) *flag_out = st->done | (st->uncertain ? STOP_UNCERTAIN : 0);
     }
 }
 
@@ -1687,6 +1690,7 @@ __global__ __launch_bounds__(256) void k_init(const TB* __restrict__ src, int M,
         st->pcount = 0;
         st->rnorm2 = 0.0;
         st->cval = 0.0;
+        st->uncertain = 0;
     }
 }
 

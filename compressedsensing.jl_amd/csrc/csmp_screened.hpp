@@ -1,0 +1,312 @@
+// csmp_screened.hpp -- single-signal OMP with a SCREENED sweep (option CSMP_OPT_SCREENED_SWEEP).
+//
+// The exact sweep streams the f32 dictionary once per atom (1 GiB at config 2) and is bound by HBM, not by arithmetic.
+// The batched path already keeps a bf16 image of the dictionary ([Npad][Mk], half the bytes) and a machinery that turns
+// approximate correlations into EXACT selections: rescore the candidates that could still be the maximum in Float64 from
+// the master dictionary, certify the pick against an error bound, and fall back to the exact path when the certificate
+// fails (csmp_batched.hpp: k_b_pick).  SURVEY.md section 7 (hard part 1) proposes the same for one signal; this is it:
+//
+//   k_sweep_bf16   c~ = Ab' r  as a GEMV over the bf16 image: one wave per column (8 KiB contiguous at M = 4096), 16 bytes
+//                  per lane and 64-lane chunk, f32 accumulation against the f32 image of the residual in LDS, software
+//                  pipelined like k_sweep_pf; every workgroup keeps its 4 largest |c~| (ties: lower index) -- its 4th
+//                  bounds every atom it did not list.  Prologue as the exact sweep: ||r||^2 from the Float64 residual and
+//                  the driver's residual test (src/matchingpursuit.jl:79).  HBM-bound: M N 2 bytes per atom.
+//   k_pick1        ONE workgroup: window + exact rescoring + certificate, exactly k_b_pick's logic on the <= 4 x 256
+//                  candidates; publishes the pick as the single "sweep partial" (pval[0], pidx[0]) that k_qr1 (mode 1:
+//                  arg-max + update!'s guards) consumes -- the append chain is the exact path's, unchanged.
+//
+// A failed certificate raises DevState::uncertain; the driver repeats that solve with the exact sweep, so results equal
+// csmp_omp's.  Only the dictionary is rounded here (the residual enters in f32, 2^-24): the error model is the batched
+// path's with one rounded operand -- the same (conservative) bounds are used.
+#pragma once
+#include "csmp_batched.hpp"
+
+namespace csmp {
+
+constexpr int kScrCand = 4;  // candidates kept per sweep workgroup
+
+// LDS image of the residual as f32 for the bf16 sweep: lane l of chunk t (512 rows) multiplies rows 8 (64 t + l) .. + 7;
+// two planes of four floats so that consecutive lanes read consecutive 16-byte slots (conflict-free ds_read_b128)
+__device__ __forceinline__ int rf_slot(int m) {  // index in floats
+    const int t = m >> 9, l = (m & 511) >> 3, e = m & 7;
+    return ((((t << 1) + (e >> 2)) << 6) + l) * 4 + (e & 3);
+}
+
+constexpr int kScrCols = 4;  // columns a wave multiplies side by side (they share the residual registers and one reduction)
+
+// sum over the 16 lanes of a row, left in every lane of it: four DPP adds (row_mirror, row_half_mirror, quad_perm) -- no LDS trip
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // lane i <- 15 - i
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // i <- 7 - i (halves)
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad [2,3,0,1]
+    return v;
+}
+
+// The wave's work is a stream of ITEMS: U chunks (U x 1 KiB) of each of FOUR neighbouring columns; a column group is `nblocks`
+// items.  D - 1 items are in flight beyond the one being multiplied (a ring of D register sets) and the first loads are issued
+// BEFORE the residual prologue -- they do not depend on it.  The four columns share the residual's registers (a quarter of the
+// LDS reads) and ONE transposing butterfly that leaves column c's sum in lanes 16 c .. 16 c + 15 (two LDS round trips per
+// group instead of six per column: with two or three waves per SIMD that latency chain is not hidden).  Each 16-lane row keeps
+// the 4 largest of ITS columns; the workgroup's 4 largest are the top of the 16 lists.
+// FULL: Mk is a multiple of 512 U (every item is U whole chunks): no guard anywhere in the stream.  Otherwise the loads of a
+// partial item are clamped into the column and meet zeros in the residual image (rows >= Mk >= M), chunks beyond the column
+// are skipped (wave-uniform).  The image has Npad >= N columns (zeros): a group never leaves it; columns >= N are not listed.
+template <int U, int D, bool FULL>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
+                                                              const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
+                                                              int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
+                                                              int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) float rimgf[];  // nchunk * 512 floats | reduction scratch
+    constexpr int NW = kSweepThreads / kWave;
+    constexpr int C = kScrCols;
+    constexpr int NL = NW * (kWave / 16);  // lists per workgroup (one per 16-lane row)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    if (st->done & skipmask) return;
+    const int nchunk = (Mk + 511) / 512;
+    const int Ml = nchunk * 512;
+    using V = bf16x8;
+    const int nblocks = (nchunk + U - 1) / U;
+    const int64_t ngroups = (N + C - 1) / C;
+    const int64_t stride = (int64_t)nblk * NW;  // in groups
+    const int64_t g0 = (int64_t)bid * NW + wave;
+    const int ng = g0 < ngroups ? (int)((ngroups - 1 - g0) / stride) + 1 : 0;
+    const int nitems = ng * nblocks;
+    V buf[D][U][C];
+    const __bf16* lp = Ab + g0 * C * Mk;  // first column of the next item to load
+    int lb = 0, li = 0;                   // its block, its item number
+    auto load_next = [&](V (&dst)[U][C]) {
+        if (li < nitems) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = lb * U + u;
+                if (FULL || t < nchunk) {
+                    const int off = FULL ? t * 64 + lane : min(t * 64 + lane, Mk / 8 - 1);
+#pragma unroll
+                    for (int c = 0; c < C; ++c) dst[u][c] = __builtin_nontemporal_load(reinterpret_cast<const V*>(lp + (int64_t)c * Mk) + off);
+                }
+            }
+            ++li;
+            if (++lb == nblocks) {
+                lb = 0;
+                lp += stride * C * Mk;
+            }
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) load_next(buf[d]);
+    double* red = reinterpret_cast<double*>(rimgf + Ml);  // 8 doubles
+    float* wlv = reinterpret_cast<float*>(red + 8);        // [NL][4]
+    int* wli = reinterpret_cast<int*>(wlv + NL * kScrCand);
+    // residual: Float64 norm (fixed order) and the f32 image
+    double n2 = 0.0;
+    for (int m = tid; m < Ml; m += kSweepThreads) {
+        const double v = m < Mr ? r[m] : 0.0;
+        rimgf[rf_slot(m)] = (float)v;
+        n2 = fma(v, v, n2);
+    }
+    n2 = block_sum256(n2, red);
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
+    if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const f32x4* rs = reinterpret_cast<const f32x4*>(rimgf);
+    float tv[kScrCand];
+    int ti[kScrCand];
+#pragma unroll
+    for (int q = 0; q < kScrCand; ++q) {
+        tv[q] = -1.0f;
+        ti[q] = 0x7fffffff;
+    }
+    float acc0[C], acc1[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc0[c] = acc1[c] = 0.0f;
+    int cb = 0;          // block of the item being multiplied
+    int64_t cg = g0;     // its column group
+    for (int it = 0; it < nitems; it += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (it + d < nitems) {
+                load_next(buf[(d + D - 1) % D]);
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int t = cb * U + u;
+                    if (FULL || t < nchunk) {
+                        const f32x4 r0 = rs[(t * 2 + 0) * kWave + lane], r1 = rs[(t * 2 + 1) * kWave + lane];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            const V a = buf[d][u][c];
+                            acc0[c] = fmaf((float)a[0], r0.x, acc0[c]);
+                            acc1[c] = fmaf((float)a[1], r0.y, acc1[c]);
+                            acc0[c] = fmaf((float)a[2], r0.z, acc0[c]);
+                            acc1[c] = fmaf((float)a[3], r0.w, acc1[c]);
+                            acc0[c] = fmaf((float)a[4], r1.x, acc0[c]);
+                            acc1[c] = fmaf((float)a[5], r1.y, acc1[c]);
+                            acc0[c] = fmaf((float)a[6], r1.z, acc0[c]);
+                            acc1[c] = fmaf((float)a[7], r1.w, acc1[c]);
+                        }
+                    }
+                }
+                if (++cb == nblocks) {  // the group is complete: transposing butterfly, row r = lane / 16 ends with column r's sum
+                    cb = 0;
+                    float a[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        a[c] = acc0[c] + acc1[c];
+                        acc0[c] = acc1[c] = 0.0f;
+                    }
+                    float s0, s1;
+                    {
+                        const bool hi = lane & 32;
+                        const float k0 = hi ? a[2] : a[0], k1 = hi ? a[3] : a[1];
+                        const float h0 = hi ? a[0] : a[2], h1 = hi ? a[1] : a[3];
+                        s0 = k0 + __shfl_xor(h0, 32, kWave);
+                        s1 = k1 + __shfl_xor(h1, 32, kWave);
+                    }
+                    {
+                        const bool hi = lane & 16;
+                        const float k = hi ? s1 : s0, h = hi ? s0 : s1;
+                        s0 = k + __shfl_xor(h, 16, kWave);
+                    }
+                    s0 = row16_sum(s0);
+                    const int64_t col = cg * C + (lane >> 4);
+                    float v = col < N ? fabsf(s0) : -1.0f;
+                    int i = (int)col;
+                    cg += stride;
+                    // the row's running 4 largest (every lane of the row holds the same list); an equal value: the lower index
+#pragma unroll
+                    for (int q = 0; q < kScrCand; ++q) {
+                        const bool up = v > tv[q] || (v == tv[q] && i < ti[q]);
+                        const float ov = up ? tv[q] : v;
+                        const int oi = up ? ti[q] : i;
+                        tv[q] = up ? v : tv[q];
+                        ti[q] = up ? i : ti[q];
+                        v = ov;
+                        i = oi;
+                    }
+                }
+            }
+        }
+    }
+    if ((lane & 15) == 0) {
+        const int l = wave * (kWave / 16) + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < kScrCand; ++q) {
+            wlv[l * kScrCand + q] = tv[q];
+            wli[l * kScrCand + q] = ti[q];
+        }
+    }
+    __syncthreads();
+    if (tid < NL * kScrCand) {  // 64 entries, one per lane of wave 0: an entry's rank in (value desc, index asc, slot asc) is its place
+        static_assert(NL * kScrCand == kWave, "one wave ranks the workgroup's lists");
+        const float v = wlv[tid];
+        const int i = wli[tid];
+        int rank = 0;
+        for (int e = 0; e < NL * kScrCand; ++e) {
+            const float ve = wlv[e];
+            const int ie = wli[e];
+            rank += (ve > v || (ve == v && (ie < i || (ie == i && e < tid)))) ? 1 : 0;
+        }
+        if (rank < kScrCand) {
+            cand_val[bid * kScrCand + rank] = v;
+            cand_idx[bid * kScrCand + rank] = i;
+        }
+    }
+}
+inline size_t sweep_bf16_lds_bytes(int Mk) {
+    const int nchunk = (Mk + 511) / 512;
+    return (size_t)nchunk * 512 * sizeof(float) + 8 * sizeof(double) + (kSweepThreads / 16) * kScrCand * 8 + 64;
+}
+
+// The pick of one signal by ONE workgroup: k_b_pick's window / rescoring / certificate (see there) on the sweep workgroups'
+// candidates; ||r||^2 comes from the sweep's prologue (st->rnorm2).  Publishes (|<a, r>| exact, atom) as pval[0] / pidx[0]: the
+// one "partial" k_qr1 (mode 1, nblk = 1) takes its arg-max from -- its guards (already selected, full support) apply as in the
+// exact path.  dynamic LDS: the Float64 residual image (r_slot layout).
+template <typename TA, int U>
+__global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
+                                               const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
+                                               int Mr, double* __restrict__ pval, int* __restrict__ pidx, double cert_abs, double cert_rel,
+                                               int kwin, int skipmask) {
+    extern __shared__ __attribute__((aligned(16))) double rimg[];
+    __shared__ double sc[8];
+    __shared__ double red[kWinMax];
+    __shared__ int wi_[kWinMax];
+    __shared__ float fsc[4];
+    __shared__ int cnt;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (st->done & skipmask) return;
+    if (tid == 0) cnt = 0;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+        f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
+        if (m0 < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + m0)[0];
+            hi = reinterpret_cast<const f64x2*>(r + m0)[1];
+        }
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0)) = lo;
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
+    }
+    const double n2 = st->rnorm2;
+    float m1 = -1.0f;
+    for (int t = tid; t < ncand; t += 256) m1 = fmaxf(m1, cand_val[t]);
+    for (int sft = 32; sft >= 1; sft >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, sft, kWave));
+    if (lane == 0) fsc[wave] = m1;
+    __syncthreads();  // (also: cnt = 0 and the residual image are visible)
+    m1 = fmaxf(fmaxf(fsc[0], fsc[1]), fmaxf(fsc[2], fsc[3]));
+    if (!(m1 >= 0.0f)) {  // no candidate at all: k_qr1 sees an invalid atom and stops the solve as the exact path would
+        if (tid == 0) {
+            pval[0] = -1.0;
+            pidx[0] = 0x7fffffff;
+        }
+        return;
+    }
+    const double dabs = cert_abs * sqrt(n2);
+    const double lb1 = (double)m1 - dabs - cert_rel * (double)m1;
+    double cb = -1.0;
+    for (int t = tid; t < ncand; t += 256) {
+        const float v = cand_val[t];
+        if (!(v >= 0.0f)) continue;
+        const double ub = (double)v + dabs + cert_rel * (double)v;
+        if (ub >= lb1) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < kwin) wi_[pos] = cand_idx[t];
+            if ((t & (kScrCand - 1)) == kScrCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a workgroup's last candidate
+        } else {
+            cb = fmax(cb, ub);
+        }
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
+    __syncthreads();
+    if (lane == 0) sc[wave] = cb;
+    __syncthreads();
+    cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
+    const int nall = cnt;
+    const int nw = min(nall, kwin);
+    for (int q = wave; q < nw; q += 4) {
+        const double exq = wave_col_dot<TA, U>(A + (int64_t)wi_[q] * ld, Mv, nchunk, rimg, lane);
+        if (lane == 0) red[q] = exq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int besti = 0x7fffffff;
+        double bestv = -1.0;
+        for (int q = 0; q < nw; ++q) {
+            const int c = wi_[q];
+            const double v = fabs(red[q]);
+            if (v > bestv || (v == bestv && c < besti)) {
+                bestv = v;
+                besti = c;
+            }
+        }
+        if (!(nall <= kwin && (cb < 0.0 || bestv > cb))) st->uncertain += 1;
+        pval[0] = bestv;
+        pidx[0] = besti;
+    }
+}
+
+}  // namespace csmp

@@ -26,6 +26,8 @@ struct Solver {
     int algo = -1;
     bool begun = false;
     int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
+    float* scr_val = nullptr;  // screened sweep: the sweep workgroups' candidates (4 per workgroup)
+    int* scr_idx = nullptr;
     bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
     // multi-column append (csmp_block.hpp), allocated on first use
@@ -60,6 +62,7 @@ struct Solver {
 struct Batch {
     __bf16* Ab = nullptr;  // dictionary as bf16 [Npad][Mk]
     bool ab_valid = false;
+    bool ab_borrowed = false;  // a twin sweeping its parent's image (host/screened.hpp): not this context's to free
     int Mk = 0;
     int64_t Npad = 0;
     int n_atiles = 0;
@@ -126,6 +129,11 @@ struct csmp_ctx {
     bool opt_ls_gram = true;       // CSMP_OPT_LS_GRAM: whole-set least squares by Gram + Cholesky
     bool opt_ls_gram_reuse = true; // CSMP_OPT_LS_GRAM_REUSE
     int opt_twostage_update = 0;   // CSMP_OPT_TWOSTAGE_UPDATE: 0 explicit inverse, 1 Givens down-date of R, 2 refactorise
+    int64_t scr_solves = 0, scr_fallbacks = 0;  // screened solves made / repeated with the exact sweep (csmp_screened_stats)
+    int scr_grid = 0;                           // workgroups of k_sweep_bf16
+    double scr_cert_abs = 0.0, scr_cert_rel = 0.0;
+    int scr_kwin = 0, scr_cert_mode = -1;
+    int opt_screened = 0;          // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch sweep the bf16 image and certify (csmp_screened.hpp)
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch
@@ -204,3 +212,12 @@ struct DevTmp {
     ~DevTmp() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 1)); }
 };
+
+// defined in host/batched.hpp and host/screened.hpp (included later); used by the omp drivers
+static int batch_dict(csmp_ctx* ctx);
+static int batch_colnorm(csmp_ctx* ctx);
+static int screened_ensure(csmp_ctx* ctx);
+static int twins_ensure(csmp_ctx* ctx, int n);
+static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic);
+static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
+                              int64_t* idx, double* val, int64_t* nnz, int out_loc);

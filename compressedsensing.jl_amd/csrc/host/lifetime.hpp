@@ -40,6 +40,8 @@ static void batch_free(Batch& b, bool keep_dict) {
     dfree(b.cand_val); dfree(b.cand_idx); dfree(b.pick);
     b.Bcap = b.kcap = 0;
     if (!keep_dict) {
+        if (b.ab_borrowed) b.Ab = nullptr;
+        b.ab_borrowed = false;
         dfree(b.Ab);
         dfree(b.amax);
         dfree(b.Gm);
@@ -64,7 +66,7 @@ static void solver_free(Solver& s) {
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
-    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags);
+    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags); dfree(s.scr_val); dfree(s.scr_idx);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
@@ -157,6 +159,7 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_BATCH_WINDOW: *lo = 0; *hi = kWinMax; return &ctx->opt_batch_window;
         case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
         case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
+        case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 1; return &ctx->opt_screened;
         default: return nullptr;
     }
 }

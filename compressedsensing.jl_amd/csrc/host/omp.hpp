@@ -115,28 +115,42 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // UpdatableQR(T, n, k): :58
     CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k, 1)));
     ctx->s.begun = false;
-    // optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
+    // CSMP_OPT_SCREENED_SWEEP: first with the bf16-image sweep + certified picks (csmp_screened.hpp); a solve in which a pick
+    // could not be certified is repeated with the exact sweep.
+    // Within an attempt: optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
     // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
     bool capacity_stop = false;
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool optimistic = pass == 0 && !ctx->force_reorth;
-        CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
-            CHECK(omp_step(ctx, eps, t > 0, optimistic));
-            if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
-                bool stopped = false;
-                CHECK(solver_poll(ctx, &stopped));
-                if (stopped) break;
+    bool screened = ctx->opt_screened != 0;
+    if (screened) CHECK(screened_ensure(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool uncertain = false;
+        for (int pass = 0; pass < 2; ++pass) {
+            const bool optimistic = pass == 0 && !ctx->force_reorth;
+            CHECK(upload_b(ctx, b, b_dtype));
+            for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
+                CHECK(screened ? omp_step_screened(ctx, eps, t > 0, optimistic) : omp_step(ctx, eps, t > 0, optimistic));
+                if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
+                    bool stopped = false;
+                    CHECK(solver_poll(ctx, &stopped));
+                    if (stopped) break;
+                }
+            }
+            CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
+            DevState hs;
+            HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            uncertain = screened && hs.uncertain > 0;
+            if (!(hs.done & STOP_REORTH)) {
+                capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+                break;
             }
         }
-        CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
-        DevState hs;
-        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!(hs.done & STOP_REORTH)) {
-            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
-            break;
+        if (screened) {
+            ctx->scr_solves += 1;
+            ctx->scr_fallbacks += uncertain ? 1 : 0;
         }
+        if (!uncertain) break;
+        screened = false;
     }
     CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
     return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;

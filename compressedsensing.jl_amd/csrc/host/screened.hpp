@@ -1,0 +1,195 @@
+// host/screened.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// single-signal OMP with the screened sweep (csmp_screened.hpp; option CSMP_OPT_SCREENED_SWEEP).
+
+// bf16 image, certificate coefficients, sweep grid: once per dictionary / option value
+static int screened_ensure(csmp_ctx* ctx) {
+    CHECK(batch_dict(ctx));
+    Batch& b = ctx->bt;
+    if (ctx->scr_cert_mode != ctx->opt_batch_cert) {
+        // one rounded operand (the residual enters the sweep in f32): the two-operand bounds of the batched path are kept -- conservative
+        if (ctx->opt_batch_cert == 1) {
+            CHECK(batch_colnorm(ctx));
+            ctx->scr_cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+            ctx->scr_cert_rel = std::ldexp(1.0, -20);
+            ctx->scr_kwin = kWinMax;
+        } else {
+            ctx->scr_cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
+            ctx->scr_cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -20);
+            ctx->scr_kwin = kWinMax / 2;
+        }
+        ctx->scr_cert_mode = ctx->opt_batch_cert;
+    }
+    // grid: two workgroups per CU (measured at configs[1]: 256 / 512 / 768 workgroups 88-90 us, 192: 122 us), a column group per wave at least
+    const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kScrCols - 1) / ((kSweepThreads / kWave) * kScrCols);
+    const int maxgrid = ctx->prop.multiProcessorCount * 8;
+    ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(2 * ctx->prop.multiProcessorCount, maxgrid), groups));
+    if (const char* g = tune_env("CSMP_SCR_NBLK")) ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(g), maxgrid), groups));
+    return CSMP_OK;
+}
+
+template <typename TA>
+static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
+    Solver& s = ctx->s;
+    constexpr int U = sizeof(TA) == 4 ? 16 : 8;
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
+    auto kern = k_pick1<TA, U>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
+                       ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask);
+    return hipGetLastError();
+}
+
+// update!(P::OMP, x) with the screened sweep: bf16 sweep -> certified pick -> the exact path's append chain
+static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
+    Solver& s = ctx->s;
+    Batch& b = ctx->bt;
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    const int nchunk = (b.Mk + 511) / 512;
+    const size_t lds = sweep_bf16_lds_bytes(b.Mk);
+    const bool timed = prof_pick(ctx);
+    if (timed) CHECK(prof_mark(ctx));
+#define CSMP_SCR(U, DD, FULL)                                                                                                             \
+    {                                                                                                                                     \
+        if (lds > 48 * 1024)                                                                                                              \
+            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
+        hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream, (const __bf16*)b.Ab,  \
+                           b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip);                   \
+    }
+    // items of U chunks of four columns (4 U KiB per wave and load group): U whole chunks per item where the column allows
+    const bool whole = b.Mk % 512 == 0;
+    if (whole && nchunk % 2 == 0) CSMP_SCR(2, 3, true)
+    else if (whole) CSMP_SCR(1, 4, true)
+    else if (nchunk >= 2) CSMP_SCR(2, 3, false)
+    else CSMP_SCR(1, 4, false)
+#undef CSMP_SCR
+    HIPCHECK(hipGetLastError());
+    if (timed) CHECK(prof_mark(ctx));
+    HIPCHECK(ctx->dtype == CSMP_F32 ? pick1_launch<float>(ctx, ctx->scr_grid * kScrCand, skip) : pick1_launch<double>(ctx, ctx->scr_grid * kScrCand, skip));
+    return launch_append(ctx, 1, 0, skip, optimistic, 0.0, /*nblk_sweep: the pick is the only "partial"*/ 1);
+}
+
+// omp for many signals with the screened sweep: TWO solves in flight, the context's and a twin's, out of phase (the pattern of
+// csmp_gomp_batch): one signal's pick and append stages run under the other's sweep.  A signal whose solve was flagged --
+// an uncertified pick, or a column that failed the DGKS test of the optimistic append chain -- is solved again by the exact
+// path after the one synchronisation.
+static int omp_screened_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t k, double eps, int64_t* d_idx, double* d_val,
+                                int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
+    int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
+    for (int64_t t = 0; t < k && rc == CSMP_OK && !c->s.capped; ++t) {
+        rc = omp_step_screened(c, eps, t > 0, !c->force_reorth);
+        if (t == 0 && rc == CSMP_OK && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
+    }
+    if (rc != CSMP_OK) return rc;
+    return launch_finish(c, d_idx, d_val, d_nnz, nullptr, (int)k, d_flag);
+}
+
+static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
+                              int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(twins_ensure(ctx, 1));
+    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
+    cc[1]->opt_batch_cert = ctx->opt_batch_cert;
+    CHECK(screened_ensure(ctx));
+    if (!cc[1]->bt.ab_valid) {  // the twin (destroyed before this context's image is: csmp_set_dictionary, csmp_destroy) sweeps the same image
+        Batch &tb = cc[1]->bt, &pb = ctx->bt;
+        tb.Ab = pb.Ab;
+        tb.Mk = pb.Mk;
+        tb.Npad = pb.Npad;
+        tb.n_atiles = pb.n_atiles;
+        tb.amax_host = pb.amax_host;
+        tb.anorm_host = pb.anorm_host;
+        tb.ab_valid = tb.ab_borrowed = true;
+    }
+    cc[1]->bt.anorm_host = ctx->bt.anorm_host;
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    for (int q = 0; q < 2; ++q) {
+        int rc = solver_ensure(cc[q], kc, (int)k);
+        if (rc == CSMP_OK) rc = screened_ensure(cc[q]);
+        if (rc != CSMP_OK) {
+            if (q) ctx->err = cc[q]->err;
+            return rc;
+        }
+        cc[q]->s.begun = false;
+    }
+    const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+    void* dB = const_cast<void*>(B);
+    DevTmp tB, tIdx, tVal, tNnz, tFlag;
+    if (b_loc == CSMP_HOST) {
+        HIPCHECK(tB.alloc((size_t)ldB * (size_t)nsig * es));
+        dB = tB.p;
+        HIPCHECK(hipMemcpy(dB, B, (size_t)ldB * (size_t)nsig * es, hipMemcpyHostToDevice));
+    }
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(tIdx.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tVal.alloc((size_t)k * nsig * 8));
+        HIPCHECK(tNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)tIdx.p;
+        d_val = (double*)tVal.p;
+        d_nnz = (int64_t*)tNnz.p;
+    }
+    HIPCHECK(tFlag.alloc((size_t)nsig * sizeof(int)));
+    int* d_flag = (int*)tFlag.p;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+    std::vector<char> capped((size_t)nsig, 0);
+    for (int64_t sgn = 0; sgn < nsig; ++sgn) {
+        csmp_ctx* c = cc[sgn & 1];
+        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+        if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
+        const int rc = omp_screened_enqueue(c, col, b_dtype, k, eps, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
+                                            sgn == 0 ? ctx->ev_twin : nullptr);
+        capped[(size_t)sgn] = c->s.capped;
+        if (rc != CSMP_OK) {
+            if (c != ctx) ctx->err = c->err;
+            (void)hipStreamSynchronize(cc[0]->stream);
+            (void)hipStreamSynchronize(cc[1]->stream);
+            return rc;
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(cc[1]->stream));
+    std::vector<int> hf((size_t)nsig);
+    HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    int rc = CSMP_OK;
+    bool capacity_stop = false;
+    for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
+        ctx->scr_solves += 1;
+        if (hf[sgn] & (STOP_REORTH | STOP_UNCERTAIN)) {  // again, by the exact path with the full append chain
+            ctx->scr_fallbacks += (hf[sgn] & STOP_UNCERTAIN) ? 1 : 0;
+            const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
+            rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col) : init_from_device_t<double>(ctx, (const double*)col);
+            for (int64_t t = 0; t < k && rc == CSMP_OK && !ctx->s.capped; ++t) rc = omp_step(ctx, eps, t > 0, false);
+            if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k, d_flag + sgn);
+            if (rc == CSMP_OK) {
+                HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                HIPCHECK(hipStreamSynchronize(ctx->stream));
+                capped[(size_t)sgn] = ctx->s.capped;
+            }
+        }
+        if (rc == CSMP_OK) capacity_stop |= capped[(size_t)sgn] && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
+    }
+    if (out_loc == CSMP_HOST) {
+        if (rc == CSMP_OK) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)k * nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
+}
+
+// screened solves made by this context and how many of them were repeated with the exact sweep (failed certificate)
+extern "C" int csmp_screened_stats(csmp_ctx* ctx, int64_t* solves, int64_t* fallbacks, int reset) {
+    if (!ctx) return CSMP_EINVAL;
+    if (solves) *solves = ctx->scr_solves;
+    if (fallbacks) *fallbacks = ctx->scr_fallbacks;
+    if (reset) ctx->scr_solves = ctx->scr_fallbacks = 0;
+    return CSMP_OK;
+}

@@ -1211,11 +1211,11 @@ def test_options_at_the_abi(cs, D):
     d = D(A)
     c = d.ctx
     defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
-                "twostage_update": 0, "solves_in_flight": 3}
+                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0}
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
-                     ("solves_in_flight", 0)):
+                     ("solves_in_flight", 0), ("screened_sweep", 2)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -1647,3 +1647,166 @@ def test_bench_two_ranks_rehearsal_on_one_gpu(workload):
         assert line["ranks_agree_on_first_support"] and line["supports_gathered"] == 2 and line["scaling"] == "strong"
     else:
         assert line["matches_exact_path_on_sample"] and abs(line["value"] * line["ms_per_step"] * 1e-3 - world * 1024 * 128) < 1.0
+
+
+# ------------------------------------------------------------------ screened single-signal sweep (CSMP_OPT_SCREENED_SWEEP)
+@pytest.mark.parametrize("shape", [(64, 256, 6), (50, 301, 5), (130, 700, 10), (512, 4096, 24), (1500, 3000, 16), (4096, 2500, 12), (37, 5, 3)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_screened_sweep_omp_matches_oracle(cs, oracle, D, shape, dtype):
+    """csmp_omp with the sweep over the bf16 image (k_sweep_bf16 + k_pick1, certified picks): supports, selection order and
+    coefficients of the oracle (src/matchingpursuit.jl:62-90), under both certificates; the counters say the screened path ran."""
+    n, m, k = shape
+    A, x, b = cs.sparse_data(n=n, m=m, k=min(k, m), rng=n + m + k, dtype=dtype)
+    eps = float(np.finfo(dtype).eps)
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 1)
+    d.ctx.screened_stats(reset=True)
+    for cert in (0, 1):
+        d.ctx.set_option("batch_cert", cert)
+        for seed, noise in ((0, 0.0), (1, 5e-3), (2, 1e-1)):
+            y = cs.perturb(b, noise, rng=seed) if noise else b
+            ref = oracle.omp(A, y, k, eps)
+            got = d.ctx.omp(y, k, eps)
+            assert np.array_equal(got[0], ref[0]), (cert, seed, got[0], ref[0])
+            assert np.array_equal(got[2], ref[2]), "selection order"
+            assert close(got[1], ref[1], tight=False)
+    st = d.ctx.screened_stats()
+    assert st["solves"] == 6 and 0 <= st["fallbacks"] <= 6
+    d.ctx.set_option("batch_cert", 0)
+    d.ctx.set_option("screened_sweep", 0)
+    d.ctx.omp(b, k, eps)
+    assert d.ctx.screened_stats()["solves"] == 6, "option off: the exact sweep"
+
+
+def test_screened_sweep_certifies_on_gaussian_dictionaries(cs, oracle, D):
+    """On the benchmark's kind of dictionary the statistical certificate has to hold at (nearly) every step -- a screened
+    path that always falls back would be correct and useless."""
+    A, x, b = cs.sparse_data(n=1024, m=8192, k=24, rng=77, dtype=np.float32)
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 1)
+    d.ctx.screened_stats(reset=True)
+    rng = np.random.default_rng(4)
+    for s in range(8):
+        sup = rng.choice(8192, size=24, replace=False)
+        y = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=24), 5e-3, rng=rng)
+        ref = oracle.omp(A, y, 24, EPS32)
+        got = d.ctx.omp(y, 24, EPS32)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and close(got[1], ref[1], tight=False)
+    st = d.ctx.screened_stats()
+    assert st["solves"] == 8 and st["fallbacks"] <= 1, st
+    d.ctx.set_option("screened_sweep", 0)
+
+
+@pytest.mark.parametrize("kind", ["few_valued", "partial_dct", "one_magnitude", "common_component"])
+def test_screened_sweep_structured_dictionaries(cs, oracle, kind):
+    """Dictionaries whose bf16 rounding errors are not independent: whatever the certificate decides, the result is the exact
+    path's (an uncertified step repeats the solve with the exact sweep)."""
+    M, N, nsig = 512, 4096, 24
+    rng = np.random.default_rng(99 + len(kind))
+    A = cs.structured_dictionary(kind, M, N, rng=rng)
+    A64 = A.astype(np.float64)
+    d = cs.Dictionary(A)
+    for family, k in (("pm1", 16), ("neartie", 4)):
+        B = np.empty((M, nsig), order="F")
+        for s in range(nsig):
+            sup = rng.choice(N, size=k, replace=False)
+            x = rng.choice(np.array([-1.0, 1.0]), size=k)
+            if family == "neartie":
+                x = x * (1.0 + 2e-3 * rng.random(k))
+            B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
+        d.ctx.set_option("screened_sweep", 0)
+        i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
+        d.ctx.set_option("screened_sweep", 1)
+        for cert in (0, 1):
+            d.ctx.set_option("batch_cert", cert)
+            idx, val, nnz = d.ctx.omp_batch(B, k, EPS32)  # two screened solves in flight
+            assert np.array_equal(nnz, n2) and np.array_equal(idx, i2), (kind, family, cert)
+            assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
+            for s in range(0, nsig, 8):
+                got = d.ctx.omp(B[:, s], k, EPS32)
+                assert np.array_equal(got[0], np.sort(i2[:n2[s], s])) or np.array_equal(got[0], i2[:n2[s], s])
+        d.ctx.set_option("batch_cert", 0)
+        for s in range(0, nsig, 6):
+            ref = oracle.omp(A, B[:, s], k, EPS32)
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (kind, family, s)
+    d.close()
+
+
+def test_screened_sweep_ties_stops_and_fallback(cs, oracle, D):
+    """Duplicate atoms (the certificate cannot separate them: the solve falls back and the lowest index wins, as findmax does),
+    the residual test, a support that fills up, a zero signal, more duplicates than a sweep workgroup lists."""
+    rng = np.random.default_rng(12)
+    A = rng.standard_normal((96, 700)).astype(np.float32)
+    A /= np.linalg.norm(A, axis=0)
+    for c in (250, 251, 252, 253, 254, 699):  # six exact copies of atom 17, five of them in ONE sweep workgroup's columns
+        A[:, c] = A[:, 17]
+    A = np.asfortranarray(A)
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 1)
+    d.ctx.screened_stats(reset=True)
+    y = 3.0 * A[:, 17].astype(np.float64) + 0.5 * A[:, 400].astype(np.float64) - 0.25 * A[:, 5].astype(np.float64)
+    ref = oracle.omp(A, y, 3, EPS32)
+    got = d.ctx.omp(y, 3, EPS32)
+    assert got[2][0] == 17 and np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+    assert d.ctx.screened_stats()["fallbacks"] <= 1  # (copies inside the rescoring window tie exactly: lowest index, certified)
+    # more copies than the sweep's workgroups list (4 each) or the window holds: the certificate has to fail, the exact sweep decides
+    A2 = rng.standard_normal((96, 3000)).astype(np.float32)
+    A2 /= np.linalg.norm(A2, axis=0)
+    A2[:, :1500] = A2[:, [7]]
+    A2 = np.asfortranarray(A2)
+    d2 = D(A2)
+    d2.ctx.set_option("screened_sweep", 1)
+    d2.ctx.screened_stats(reset=True)
+    yd = 2.0 * A2[:, 7].astype(np.float64) + 0.7 * A2[:, 2500].astype(np.float64)
+    ref = oracle.omp(A2, yd, 2, EPS32)
+    got = d2.ctx.omp(yd, 2, EPS32)
+    assert got[2][0] == 0 and np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+    assert d2.ctx.screened_stats() == {"solves": 1, "fallbacks": 1}
+    # eps-stop: exact 2-sparse signal, k = 10
+    y2 = 2.0 * A[:, 100].astype(np.float64) - A[:, 600].astype(np.float64)
+    ref = oracle.omp(A, y2, 10, 1e-6)
+    got = d.ctx.omp(y2, 10, 1e-6)
+    assert np.array_equal(got[0], ref[0]) and len(got[0]) == 2 and close(got[1], ref[1], tight=False)
+    # zero signal: the reference adds atom 1 (findmax of zeros) then stops on the residual test
+    ref = oracle.omp(A, np.zeros(96), 4, EPS32)
+    got = d.ctx.omp(np.zeros(96), 4, EPS32)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+    # batch form: every kind of signal side by side, odd count
+    B = np.asfortranarray(np.stack([y, y2, np.zeros(96), -y, y2 + y], axis=1))
+    idx, val, nnz = d.ctx.omp_batch(B, 6, 1e-6)
+    for s in range(5):
+        ref = oracle.omp(A, B[:, s], 6, 1e-6)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), s
+        if len(ref[1]) and np.all(np.isfinite(ref[1])):
+            assert close(val[:nnz[s], s], ref[1], tight=False)
+    d.ctx.set_option("screened_sweep", 0)
+
+
+def test_screened_sweep_full_size_config2(cs, oracle):
+    """BASELINE configs[1] (4096 x 65536 f32, k = 256) with the screened sweep: the complete solve equals the exact path's
+    (support, order, coefficients), an oracle prefix pins both; the certificate holds throughout (no fallback)."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    At = bench.make_dictionary(torch, dev)
+    B = bench.make_signals(torch, dev, At, 500, 2)
+    d = cs.Dictionary(At, device=0)
+    y = B[0].cpu().numpy()
+    exact = d.ctx.omp(y, 256, EPS32)
+    d.ctx.set_option("screened_sweep", 1)
+    d.ctx.screened_stats(reset=True)
+    got = d.ctx.omp(y, 256, EPS32)
+    assert np.array_equal(got[0], exact[0]) and np.array_equal(got[2], exact[2])
+    assert np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
+    st = d.ctx.screened_stats()
+    assert st == {"solves": 1, "fallbacks": 0}, st
+    A = np.asfortranarray(At.cpu().numpy().T)
+    ref = oracle.omp(A, y, 12, EPS32)
+    assert np.array_equal(got[2][:12], ref[2])
+    idx = torch.full((2, 256), -1, dtype=torch.int64, device=dev)
+    val = torch.zeros((2, 256), dtype=torch.float64, device=dev)
+    nnz = torch.zeros(2, dtype=torch.int64, device=dev)
+    d.ctx.omp_batch_device(B, 256, EPS32, idx, val, nnz)
+    d.ctx.sync()
+    assert int(nnz[0]) == len(exact[0]) and np.array_equal(np.sort(idx[0, :int(nnz[0])].cpu().numpy()), np.sort(exact[0]))
+    d.close()
