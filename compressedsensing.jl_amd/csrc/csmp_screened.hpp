@@ -32,6 +32,16 @@ __device__ __forceinline__ int rf_slot(int m) {  // index in floats
     return ((((t << 1) + (e >> 2)) << 6) + l) * 4 + (e & 3);
 }
 
+#ifdef CSMP_SWEEP_TRACE  // tools/probes/sweep_probe.hip: wall-clock stamps (100 MHz) of workgroup phases
+__device__ unsigned long long g_sweep_trace[4096 * 8];
+#define CSMP_TRACE(slot) \
+    if (threadIdx.x == 0) g_sweep_trace[blockIdx.x * 8 + (slot)] = wall_clock64()
+#else
+#define CSMP_TRACE(slot)
+#endif
+
+constexpr int kScrPartWgs = 8;        // workgroups that share a ticket counter
+constexpr int kScrTicketStride = 64;  // words between two counters (a 256-byte line each)
 constexpr int kScrCols = 4;  // columns a wave multiplies side by side (they share the residual registers and one reduction)
 
 // sum over the 16 lanes of a row, left in every lane of it: four DPP adds (row_mirror, row_half_mirror, quad_perm) -- no LDS trip
@@ -49,35 +59,69 @@ __device__ __forceinline__ float row16_sum(float v) {
 // LDS reads) and ONE transposing butterfly that leaves column c's sum in lanes 16 c .. 16 c + 15 (two LDS round trips per
 // group instead of six per column: with two or three waves per SIMD that latency chain is not hidden).  Each 16-lane row keeps
 // the 4 largest of ITS columns; the workgroup's 4 largest are the top of the 16 lists.
+// Groups are handed out DYNAMICALLY.  With a static grid-stride split the workgroups of one launch finished between 60 and
+// 90 us at configs[1] (tools/probes/sweep_probe.hip) and the slowest set the kernel's time.  ONE ticket counter for the chip
+// is no answer: agent-scope atomics on one address execute at the memory side, ~11 ns apiece one after the other -- 18 000
+// of them made the kernel 210 us.  So the workgroups form PARTITIONS of eight consecutive block ids (one per XCD under the
+// round-robin dispatch, so a slow XCD is diluted), partition p owns the groups p, p + NP, p + 2 NP, ... (all partitions walk
+// the image at the same pace) and has its own counter on its own 256-byte line: a wave's first group is its number inside
+// the partition, every further one a ticket, asked for a whole group (32 KiB) before the answer is needed.
+// k_pick1 zeroes the counters after every sweep (kScrTicketStride words apart).
 // FULL: Mk is a multiple of 512 U (every item is U whole chunks): no guard anywhere in the stream.  Otherwise the loads of a
 // partial item are clamped into the column and meet zeros in the residual image (rows >= Mk >= M), chunks beyond the column
 // are skipped (wave-uniform).  The image has Npad >= N columns (zeros): a group never leaves it; columns >= N are not listed.
-template <int U, int D, bool FULL>
+template <int U, int D, bool FULL, int C = kScrCols>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
                                                               const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
                                                               int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
-                                                              int skipmask) {
+                                                              int skipmask, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) float rimgf[];  // nchunk * 512 floats | reduction scratch
     constexpr int NW = kSweepThreads / kWave;
-    constexpr int C = kScrCols;
+    static_assert(C == 2 || C == 4, "two or four columns side by side");
     constexpr int NL = NW * (kWave / 16);  // lists per workgroup (one per 16-lane row)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
+    CSMP_TRACE(0);
     if (st->done & skipmask) return;
+    CSMP_TRACE(1);
     const int nchunk = (Mk + 511) / 512;
     const int Ml = nchunk * 512;
     using V = bf16x8;
     const int nblocks = (nchunk + U - 1) / U;
     const int64_t ngroups = (N + C - 1) / C;
-    const int64_t stride = (int64_t)nblk * NW;  // in groups
-    const int64_t g0 = (int64_t)bid * NW + wave;
-    const int ng = g0 < ngroups ? (int)((ngroups - 1 - g0) / stride) + 1 : 0;
-    const int nitems = ng * nblocks;
+    // partition (see above): NP of them, WPP workgroups each (the host launches a multiple of 8 workgroups, or fewer than 8)
+    const int NP = nblk >= kScrPartWgs ? nblk / kScrPartWgs : 1;
+    const int WPP = nblk >= kScrPartWgs ? kScrPartWgs : nblk;
+    const int part = nblk >= kScrPartWgs ? bid / kScrPartWgs : 0;
+    const int wl = (bid - part * WPP) * NW + wave;  // the wave's number inside its partition
+    unsigned* const ticket = tickets + part * kScrTicketStride;
+    const int64_t g0 = (int64_t)wl * NP + part;
+    // the residual's loads go out FIRST: loads return in order, and behind the dictionary prefetch they would wait for 16 KiB
+    // per wave of HBM traffic before the prologue could start
+    constexpr int PR = 4;  // row quads per thread and pass (one pass at M <= 4096)
+    f64x2 rlo[PR], rhi[PR];
+    auto r_issue = [&](int base) {
+#pragma unroll
+        for (int p = 0; p < PR; ++p) {
+            const int m0 = base + (p * kSweepThreads + tid) * 4;
+            rlo[p] = rhi[p] = (f64x2)0.0;
+            if (m0 < Mr) {
+                rlo[p] = reinterpret_cast<const f64x2*>(r + m0)[0];
+                rhi[p] = reinterpret_cast<const f64x2*>(r + m0)[1];
+            }
+        }
+    };
+    r_issue(0);
     V buf[D][U][C];
-    const __bf16* lp = Ab + g0 * C * Mk;  // first column of the next item to load
-    int lb = 0, li = 0;                   // its block, its item number
-    auto load_next = [&](V (&dst)[U][C]) {
-        if (li < nitems) {
+    int sg[D];                       // group of the item in ring slot d (-1: none -- the stream has ended)
+    int lg = g0 < ngroups ? (int)g0 : -1;  // group of the next item to load
+    const __bf16* lp = Ab + g0 * C * Mk;
+    int lb = 0;                      // its block
+    unsigned tk = 0;                 // lane 0: the ticket for the group after `lg`
+    if (lg >= 0 && lane == 0) tk = atomicAdd(ticket, 1u);
+    auto load_next = [&](V (&dst)[U][C], int& slot_g) {
+        slot_g = lg;
+        if (lg >= 0) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int t = lb * U + u;
@@ -87,31 +131,56 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                     for (int c = 0; c < C; ++c) dst[u][c] = __builtin_nontemporal_load(reinterpret_cast<const V*>(lp + (int64_t)c * Mk) + off);
                 }
             }
-            ++li;
-            if (++lb == nblocks) {
+            if (++lb == nblocks) {  // the following group: the ticket asked for a group ago, and the next request
                 lb = 0;
-                lp += stride * C * Mk;
+                const int64_t g = ((int64_t)WPP * NW + (int64_t)__builtin_amdgcn_readfirstlane((int)tk)) * NP + part;
+                lg = g < ngroups ? (int)g : -1;
+                if (lg >= 0) {
+                    lp = Ab + g * C * Mk;
+                    if (lane == 0) tk = atomicAdd(ticket, 1u);
+                }
             }
         }
     };
 #pragma unroll
-    for (int d = 0; d < D - 1; ++d) load_next(buf[d]);
+    for (int d = 0; d < D - 1; ++d) load_next(buf[d], sg[d]);
     double* red = reinterpret_cast<double*>(rimgf + Ml);  // 8 doubles
     float* wlv = reinterpret_cast<float*>(red + 8);        // [NL][4]
     int* wli = reinterpret_cast<int*>(wlv + NL * kScrCand);
     // residual: Float64 norm (fixed order) and the f32 image
     double n2 = 0.0;
-    for (int m = tid; m < Ml; m += kSweepThreads) {
-        const double v = m < Mr ? r[m] : 0.0;
-        rimgf[rf_slot(m)] = (float)v;
-        n2 = fma(v, v, n2);
+    for (int base = 0; base < Ml; base += 4 * kSweepThreads * PR) {
+        if (base > 0) r_issue(base);
+#pragma unroll
+        for (int p = 0; p < PR; ++p) {
+            const int m0 = base + (p * kSweepThreads + tid) * 4;
+            if (m0 < Ml) {
+                f32x4 f;
+                f.x = (float)rlo[p].x;
+                f.y = (float)rlo[p].y;
+                f.z = (float)rhi[p].x;
+                f.w = (float)rhi[p].y;
+                *reinterpret_cast<f32x4*>(rimgf + rf_slot(m0)) = f;
+                n2 = fma(rlo[p].x, rlo[p].x, n2);
+                n2 = fma(rlo[p].y, rlo[p].y, n2);
+                n2 = fma(rhi[p].x, rhi[p].x, n2);
+                n2 = fma(rhi[p].y, rhi[p].y, n2);
+            }
+        }
     }
-    n2 = block_sum256(n2, red);
+    CSMP_TRACE(5);
+    // sum over the workgroup in a fixed order; barriers that order LDS only (a __syncthreads would drain the prefetch)
+    for (int sft = 32; sft >= 1; sft >>= 1) n2 += __shfl_xor(n2, sft, kWave);
+    if (lane == 0) red[wave] = n2;
+    CSMP_TRACE(6);
+    lds_barrier();
+    n2 = (red[0] + red[1]) + (red[2] + red[3]);
     if (bid == 0 && tid == 0) st->rnorm2 = n2;
     if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
         if (bid == 0 && tid == 0) st->done |= STOP_EPS;
         return;
     }
+    CSMP_TRACE(2);
     const f32x4* rs = reinterpret_cast<const f32x4*>(rimgf);
     float tv[kScrCand];
     int ti[kScrCand];
@@ -123,13 +192,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     float acc0[C], acc1[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc0[c] = acc1[c] = 0.0f;
-    int cb = 0;          // block of the item being multiplied
-    int64_t cg = g0;     // its column group
-    for (int it = 0; it < nitems; it += D) {
+    int cb = 0;  // block of the item being multiplied
+    bool alive = true;
+    while (alive) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            if (it + d < nitems) {
-                load_next(buf[(d + D - 1) % D]);
+            if (alive && sg[d] >= 0) {
+                load_next(buf[(d + D - 1) % D], sg[(d + D - 1) % D]);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int t = cb * U + u;
@@ -157,24 +226,31 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                         a[c] = acc0[c] + acc1[c];
                         acc0[c] = acc1[c] = 0.0f;
                     }
-                    float s0, s1;
-                    {
+                    float s0;
+                    if constexpr (C == 4) {
+                        float s1;
+                        {
+                            const bool hi = lane & 32;
+                            const float k0 = hi ? a[2] : a[0], k1 = hi ? a[3] : a[1];
+                            const float h0 = hi ? a[0] : a[2], h1 = hi ? a[1] : a[3];
+                            s0 = k0 + __shfl_xor(h0, 32, kWave);
+                            s1 = k1 + __shfl_xor(h1, 32, kWave);
+                        }
+                        {
+                            const bool hi = lane & 16;
+                            const float k = hi ? s1 : s0, h = hi ? s0 : s1;
+                            s0 = k + __shfl_xor(h, 16, kWave);
+                        }
+                    } else {  // two columns: a 32-lane half each (its second row lists nothing)
                         const bool hi = lane & 32;
-                        const float k0 = hi ? a[2] : a[0], k1 = hi ? a[3] : a[1];
-                        const float h0 = hi ? a[0] : a[2], h1 = hi ? a[1] : a[3];
-                        s0 = k0 + __shfl_xor(h0, 32, kWave);
-                        s1 = k1 + __shfl_xor(h1, 32, kWave);
-                    }
-                    {
-                        const bool hi = lane & 16;
-                        const float k = hi ? s1 : s0, h = hi ? s0 : s1;
-                        s0 = k + __shfl_xor(h, 16, kWave);
+                        const float k = hi ? a[1] : a[0], h = hi ? a[0] : a[1];
+                        s0 = k + __shfl_xor(h, 32, kWave);
+                        s0 += __shfl_xor(s0, 16, kWave);
                     }
                     s0 = row16_sum(s0);
-                    const int64_t col = cg * C + (lane >> 4);
-                    float v = col < N ? fabsf(s0) : -1.0f;
+                    const int64_t col = (int64_t)sg[d] * C + (C == 4 ? (lane >> 4) : (lane >> 5));
+                    float v = col < N && (C == 4 || !(lane & 16)) ? fabsf(s0) : -1.0f;
                     int i = (int)col;
-                    cg += stride;
                     // the row's running 4 largest (every lane of the row holds the same list); an equal value: the lower index
 #pragma unroll
                     for (int q = 0; q < kScrCand; ++q) {
@@ -187,9 +263,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                         i = oi;
                     }
                 }
+            } else {
+                alive = false;
             }
         }
     }
+    CSMP_TRACE(3);
     if ((lane & 15) == 0) {
         const int l = wave * (kWave / 16) + (lane >> 4);
 #pragma unroll
@@ -204,16 +283,23 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
         const float v = wlv[tid];
         const int i = wli[tid];
         int rank = 0;
-        for (int e = 0; e < NL * kScrCand; ++e) {
-            const float ve = wlv[e];
-            const int ie = wli[e];
-            rank += (ve > v || (ve == v && (ie < i || (ie == i && e < tid)))) ? 1 : 0;
+        using i32x4 = int __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int e4 = 0; e4 < NL; ++e4) {  // (broadcast reads, all issued before the first compare: the rolled loop cost 3.5 us)
+            const f32x4 ve = reinterpret_cast<const f32x4*>(wlv)[e4];
+            const i32x4 ie = reinterpret_cast<const i32x4*>(wli)[e4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = e4 * 4 + q;
+                rank += (ve[q] > v || (ve[q] == v && (ie[q] < i || (ie[q] == i && e < tid)))) ? 1 : 0;
+            }
         }
         if (rank < kScrCand) {
             cand_val[bid * kScrCand + rank] = v;
             cand_idx[bid * kScrCand + rank] = i;
         }
     }
+    CSMP_TRACE(4);
 }
 inline size_t sweep_bf16_lds_bytes(int Mk) {
     const int nchunk = (Mk + 511) / 512;
@@ -228,7 +314,7 @@ template <typename TA, int U>
 __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, double* __restrict__ pval, int* __restrict__ pidx, double cert_abs, double cert_rel,
-                                               int kwin, int skipmask) {
+                                               int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
     __shared__ double red[kWinMax];
@@ -238,6 +324,7 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < nparts; p += 256) tickets[p * kScrTicketStride] = 0u;  // (the sweep has ended: kernel boundary) ready for the next one
     if (st->done & skipmask) return;
     if (tid == 0) cnt = 0;
     const int nchunk = (Mv + ROWS - 1) / ROWS;

@@ -28,6 +28,7 @@ struct Solver {
     int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
     float* scr_val = nullptr;  // screened sweep: the sweep workgroups' candidates (4 per workgroup)
     int* scr_idx = nullptr;
+    unsigned* scr_tickets = nullptr;  // k_sweep_bf16's ticket counters, one per partition of workgroups, kScrTicketStride words apart
     bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
     // multi-column append (csmp_block.hpp), allocated on first use

@@ -19,11 +19,12 @@ static int screened_ensure(csmp_ctx* ctx) {
         }
         ctx->scr_cert_mode = ctx->opt_batch_cert;
     }
-    // grid: two workgroups per CU (measured at configs[1]: 256 / 512 / 768 workgroups 88-90 us, 192: 122 us), a column group per wave at least
+    // grid: one workgroup per CU (measured at configs[1], tools/probes/sweep_probe.hip: 192 / 256 / 384 / 512 workgroups 90 / 81 / 89 / 97 us)
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kScrCols - 1) / ((kSweepThreads / kWave) * kScrCols);
     const int maxgrid = ctx->prop.multiProcessorCount * 8;
-    ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(2 * ctx->prop.multiProcessorCount, maxgrid), groups));
+    ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->prop.multiProcessorCount, maxgrid), groups));
     if (const char* g = tune_env("CSMP_SCR_NBLK")) ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(g), maxgrid), groups));
+    if (ctx->scr_grid > kScrPartWgs) ctx->scr_grid -= ctx->scr_grid % kScrPartWgs;  // whole ticket partitions
     return CSMP_OK;
 }
 
@@ -38,7 +39,8 @@ static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
-                       ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask);
+                       ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask,
+                       s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1);
     return hipGetLastError();
 }
 
@@ -56,7 +58,7 @@ static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool opti
         if (lds > 48 * 1024)                                                                                                              \
             HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
         hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream, (const __bf16*)b.Ab,  \
-                           b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip);                   \
+                           b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, s.scr_tickets);     \
     }
     // items of U chunks of four columns (4 U KiB per wave and load group): U whole chunks per item where the column allows
     const bool whole = b.Mk % 512 == 0;
