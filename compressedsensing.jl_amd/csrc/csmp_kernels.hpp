@@ -274,27 +274,24 @@ __device__ __forceinline__ void sweep_body_pf(
     double* redv = red + 8;
     int* redi = reinterpret_cast<int*>(redv + 4 * NW);
 
-    double n2 = 0.0;
-    for (int m = tid; m < Mlds; m += kSweepThreads) {
-        const double v = r[m];
-        lds[r_slot<VEC>(m)] = v;
-        n2 = fma(v, v, n2);
-    }
-    n2 = block_sum256(n2, red);
-    if (bid == 0 && tid == 0) st->rnorm2 = n2;
-    if (check_eps && !(sqrt(n2) >= eps)) {
-        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-        return;
-    }
-    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
-    double bestv = -1.0;
-    int besti = 0x7fffffff;
     const int64_t stride = (int64_t)nblk * NW;
     const int nblocks = nchunk / U;  // load blocks per column
     auto ldv = [&](const VT* p) -> VT {
         if constexpr (NT) return __builtin_nontemporal_load(p);
         else return *p;
     };
+    // The residual's loads go out first and ALL AT ONCE (the rolled loop waited for each of its Mlds / 256 loads in turn:
+    // ~6 us of a 150 us kernel, tools/probes/sweep_probe.hip), the first column's loads right behind them -- loads return in
+    // order, so the prologue does not wait for the column -- and the workgroup sum uses barriers that order LDS only (a
+    // __syncthreads would drain the column's loads).  The arithmetic (per-thread order of the norm's terms, the order of
+    // the workgroup sum) is unchanged.
+    constexpr int RP = 16;  // residual elements per thread and pass (one pass up to M = 4096)
+    double rv[RP];
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+        const int m = tid + q * kSweepThreads;
+        rv[q] = m < Mlds ? r[m] : 0.0;
+    }
     int64_t col = (int64_t)bid * NW + wave;
     if (col >= N) col = -1;
     VT cur[U], nxt[U];
@@ -303,6 +300,33 @@ __device__ __forceinline__ void sweep_body_pf(
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = ldv(p + u * kWave);
     }
+    double n2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < RP; ++q) {
+        const int m = tid + q * kSweepThreads;
+        if (m < Mlds) {
+            lds[r_slot<VEC>(m)] = rv[q];
+            n2 = fma(rv[q], rv[q], n2);
+        }
+    }
+    for (int m = tid + RP * kSweepThreads; m < Mlds; m += kSweepThreads) {  // (M > 4096)
+        const double v = r[m];
+        lds[r_slot<VEC>(m)] = v;
+        n2 = fma(v, v, n2);
+    }
+    for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);  // block_sum256 with LDS-only barriers
+    lds_barrier();
+    if (lane == 0) red[wave] = n2;
+    lds_barrier();
+    n2 = (red[0] + red[1]) + (red[2] + red[3]);
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
+    if (check_eps && !(sqrt(n2) >= eps)) {
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
     while (col >= 0) {
         double acc = 0.0;
         for (int blk = 0; blk < nblocks; ++blk) {
