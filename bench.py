@@ -95,6 +95,7 @@ def parse():
                         "multi-rank code; the numbers are NOT a scaling measurement")
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single: CSMP_OPT_SCREENED_SWEEP (bf16 sweeps, certified top-S picks)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -384,10 +385,12 @@ def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0):
     return out
 
 
-def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-2):
+def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-2, screened=False):
     """configs[4]: GOMP (S = 4 atoms per step) or Subspace Pursuit on A 8192 x 131072 Float32, k = 512.
     A step = one complete solve.  delta: sp's residual tolerance (the reference's default is 1e-12, src/twostage.jl:87: with
-    noisy data it keeps iterating until the residual stops decreasing; 1e-2 stops after the first update!)."""
+    noisy data it keeps iterating until the residual stops decreasing; 1e-2 stops after the first update!).
+    screened (gomp workloads): CSMP_OPT_SCREENED_SWEEP -- sweeps over the bf16 image, the top-S pick certified in Float64
+    (identical results; the line carries the fallback count and a check of the first timed solve against the exact path)."""
     M5, N5, k, S = 8192, 131072, 512, 4
     own = D5 is None
     if own:
@@ -401,6 +404,11 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         sigs.append(((At5[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
     torch.cuda.synchronize()
     eps = D5.eps
+    screened = screened and workload in ("gomp", "gomp_single")
+    if screened:
+        exact0 = D5.ctx.gomp(sigs[W], S, k, eps)
+        D5.ctx.set_option("screened_sweep", 1)
+        D5.ctx.screened_stats(reset=True)
 
     def solve(b):
         if workload in ("gomp", "gomp_single"):
@@ -457,7 +465,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         dt = time.perf_counter() - t0
         sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
         D5.ctx.profile_enable(False)
-    alg = M5 * N5 * 4
+    alg = M5 * N5 * (2 if screened else 4)
     avg = sweep_ms / max(sweeps, 1) / 1e3
     isg = workload in ("gomp", "gomp_single")
     out = {"metric": ("GOMP (S=4) atoms selected/sec" + (", two solves in flight (csmp_gomp_batch)" if workload == "gomp" else ", one gomp call at a time")
@@ -474,15 +482,26 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     if isg:  # the whole solve against the same roofline: one dictionary pass per S atoms is all the algorithm needs
         out["roofline"]["whole_solve"] = {"achieved": alg / S * atoms / dt / 1e9, "frac": alg / S * atoms / dt / 1e9 / HBM_PEAK_GBS,
-                                          "note": "ALL-IN: M*N*4 bytes per S atoms / wall time per atom"}
+                                          "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % (2 if screened else 4)}
+    if screened:
+        import numpy as np
+        got0 = D5.ctx.gomp(sigs[W], S, k, eps)
+        st_ = D5.ctx.screened_stats(reset=True)
+        D5.ctx.set_option("screened_sweep", 0)
+        out["metric"] += ", screened sweep (bf16 image, certified top-S picks, exact results)"
+        out["roofline"]["kernel"] = "csmp::k_sweep_bf16<2,3,true> (M*N*2 bytes per sweep)"
+        out["screened"] = {"stats": st_, "first_timed_solve_equals_exact_path": bool(
+            np.array_equal(got0[0], exact0[0]) and np.array_equal(got0[2], exact0[2]) and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12)),
+            "f32_equivalent_frac_all_in": M5 * N5 * 4 / S * atoms / dt / 1e9 / HBM_PEAK_GBS}
     if workload == "gomp":
         # two sweeps share the HBM most of the time: a launch bracketed by HIP events on ONE stream takes about twice as long as
         # the kernel alone, so the per-launch figure says nothing here -- the block's achieved / frac are the all-in ones
         r = out["roofline"]
         r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
         r["achieved"], r["frac"] = r["whole_solve"]["achieved"], r["whole_solve"]["frac"]
-        r["note"] = ("achieved / frac = ALL-IN (M*N*4 bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
-                     "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)")
+        r["note"] = ("achieved / frac = ALL-IN (M*N*%d bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
+                     "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)"
+                     % (2 if screened else 4))
     if workload == "sp":
         r = out["roofline"]  # (as for gomp: overlapping solves share the HBM, a per-launch duration measures the sharing)
         r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
@@ -765,7 +784,7 @@ def main():
             At5, D5 = make_dictionary5(cs, torch, dev)
             if args.in_flight:
                 D5.ctx.set_option("solves_in_flight", args.in_flight)
-            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5)), flush=True)
+            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5, screened=args.screened)), flush=True)
             D5.close()
         return finish()
     At = make_dictionary(torch, dev)
@@ -921,6 +940,7 @@ def main():
                 At5, D5 = make_dictionary5(cs, torch, dev)
                 sec["gomp_c5"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5)
                 sec["gomp_c5_single"] = measure_config5("gomp_single", 2, 1, cs, torch, dev, D5, At5)
+                sec["gomp_c5_screened"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=True)
                 sec["sp_c5"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5)
                 sec["sp_c5_single"] = measure_config5("sp_single", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5_default_delta"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, delta=1e-12)

@@ -6,14 +6,17 @@
 // the master dictionary, certify the pick against an error bound, and fall back to the exact path when the certificate
 // fails (csmp_batched.hpp: k_b_pick).  SURVEY.md section 7 (hard part 1) proposes the same for one signal; this is it:
 //
-//   k_sweep_bf16   c~ = Ab' r  as a GEMV over the bf16 image: one wave per column (8 KiB contiguous at M = 4096), 16 bytes
-//                  per lane and 64-lane chunk, f32 accumulation against the f32 image of the residual in LDS, software
-//                  pipelined like k_sweep_pf; every workgroup keeps its 4 largest |c~| (ties: lower index) -- its 4th
-//                  bounds every atom it did not list.  Prologue as the exact sweep: ||r||^2 from the Float64 residual and
-//                  the driver's residual test (src/matchingpursuit.jl:79).  HBM-bound: M N 2 bytes per atom.
+//   k_sweep_bf16   c~ = Ab' r  as a GEMV over the bf16 image: four neighbouring columns per wave side by side, 16 bytes per
+//                  lane and 64-lane chunk, f32 accumulation against the f32 image of the residual in LDS, a ring of items in
+//                  flight, column groups handed out by partition ticket counters; every workgroup keeps its 4 largest |c~|
+//                  (ties: lower index) -- its 4th bounds every atom it did not list.  Prologue as the exact sweep: ||r||^2
+//                  from the Float64 residual and the driver's residual test (src/matchingpursuit.jl:79).  HBM-bound:
+//                  M N 2 bytes per atom.
 //   k_pick1        ONE workgroup: window + exact rescoring + certificate, exactly k_b_pick's logic on the <= 4 x 256
 //                  candidates; publishes the pick as the single "sweep partial" (pval[0], pidx[0]) that k_qr1 (mode 1:
 //                  arg-max + update!'s guards) consumes -- the append chain is the exact path's, unchanged.
+//   k_pickS        the same around the S-th largest value (GOMP's partialsortperm(abs(A'r), 1:S)): the whole top-S set and
+//                  its order certified, handed to the (panel) append kernels as k_top_merge would.
 //
 // A failed certificate raises DevState::uncertain; the driver repeats that solve with the exact sweep, so results equal
 // csmp_omp's.  Only the dictionary is rounded here (the residual enters in f32, 2^-24): the error model is the batched
@@ -395,5 +398,134 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
         pidx[0] = besti;
     }
 }
+
+// The TOP-S pick of one signal by ONE workgroup (GOMP: partialsortperm(abs(A'r), 1:S, rev=true), src/matchingpursuit.jl:192 --
+// descending |c|, ties by ascending index): k_pick1's scheme around the S-th largest screened value instead of the largest.
+// Window = every candidate whose exact value could reach the exact value of the S-th best; all of it is rescored in Float64
+// and ranked; certified when the S-th exact value beats the bound of every atom that was not rescored (a sweep workgroup's 4th
+// entry inside the window hides the atoms behind it: its bound counts).  Output: cands[0..S), cvals, ncands -- what k_top_merge
+// hands to the append kernels of the exact path.  S <= kTopSmall.
+template <typename TA, int U>
+__global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
+                                               const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
+                                               int Mr, int S, int* __restrict__ cands, double* __restrict__ cvals,
+                                               int* __restrict__ ncands, double cert_abs, double cert_rel, int kwin, int skipmask,
+                                               unsigned* __restrict__ tickets, int nparts) {
+    extern __shared__ __attribute__((aligned(16))) double rimg[];
+    __shared__ double sc[8];
+    __shared__ double red[kWinMax];
+    __shared__ int wi_[kWinMax];
+    __shared__ float fsv[4];
+    __shared__ int fsi[4];
+    __shared__ int cnt;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int p = tid; p < nparts; p += 256) tickets[p * kScrTicketStride] = 0u;
+    if (st->done & skipmask) return;
+    if (tid == 0) cnt = 0;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+        f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
+        if (m0 < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + m0)[0];
+            hi = reinterpret_cast<const f64x2*>(r + m0)[1];
+        }
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0)) = lo;
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
+    }
+    const double n2 = st->rnorm2;
+    // the S-th largest screened value: S rounds of "the best entry that is worse than the previous round's" in the total
+    // order (value desc, index asc) -- indices are distinct, so nothing has to be marked
+    float pv = __builtin_inff(), mS = -1.0f;
+    int pi = -1;
+    for (int sidx = 0; sidx < S; ++sidx) {
+        float bv = -1.0f;
+        int bi = 0x7fffffff;
+        for (int t = tid; t < ncand; t += 256) {
+            const float v = cand_val[t];
+            const int i = cand_idx[t];
+            if (!(v >= 0.0f)) continue;
+            const bool after_prev = v < pv || (v == pv && i > pi);
+            if (after_prev && (v > bv || (v == bv && i < bi))) {
+                bv = v;
+                bi = i;
+            }
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const float ov = __shfl_xor(bv, sft, kWave);
+            const int oi = __shfl_xor(bi, sft, kWave);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        __syncthreads();  // (round 0: also cnt = 0 and the residual image)
+        if (lane == 0) {
+            fsv[wave] = bv;
+            fsi[wave] = bi;
+        }
+        __syncthreads();
+        bv = fsv[0];
+        bi = fsi[0];
+        for (int w = 1; w < 4; ++w)
+            if (fsv[w] > bv || (fsv[w] == bv && fsi[w] < bi)) {
+                bv = fsv[w];
+                bi = fsi[w];
+            }
+        if (!(bv >= 0.0f)) break;  // fewer than S candidates (uniform)
+        pv = bv;
+        pi = bi;
+        mS = bv;
+        if (sidx + 1 < S) mS = -1.0f;  // (only the S-th counts; with fewer candidates everything is in the window)
+    }
+    __syncthreads();
+    const double dabs = cert_abs * sqrt(n2);
+    const double lbS = mS >= 0.0f ? (double)mS - dabs - cert_rel * (double)mS : -1.0;
+    double cb = -1.0;
+    for (int t = tid; t < ncand; t += 256) {
+        const float v = cand_val[t];
+        if (!(v >= 0.0f)) continue;
+        const double ub = (double)v + dabs + cert_rel * (double)v;
+        if (ub >= lbS) {
+            const int pos = atomicAdd(&cnt, 1);
+            if (pos < kwin) wi_[pos] = cand_idx[t];
+            if ((t & (kScrCand - 1)) == kScrCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a workgroup's last candidate
+        } else {
+            cb = fmax(cb, ub);
+        }
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
+    __syncthreads();
+    if (lane == 0) sc[wave] = cb;
+    __syncthreads();
+    cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
+    const int nall = cnt;
+    const int nw = min(nall, kwin);
+    for (int q = wave; q < nw; q += 4) {
+        const double exq = wave_col_dot<TA, U>(A + (int64_t)wi_[q] * ld, Mv, nchunk, rimg, lane);
+        if (lane == 0) red[q] = fabs(exq);
+    }
+    __syncthreads();
+    // rank of every rescored entry (value desc, index asc); the first S are the step's atoms, in that order
+    const int Seff = min(S, nw);
+    if (tid < nw) {
+        const double v = red[tid];
+        const int c = wi_[tid];
+        int rank = 0;
+        for (int q = 0; q < nw; ++q) rank += (red[q] > v || (red[q] == v && wi_[q] < c)) ? 1 : 0;
+        if (rank < Seff) {
+            cands[rank] = c;
+            cvals[rank] = v;
+        }
+        if (rank == Seff - 1 && !(nall <= kwin && (cb < 0.0 || (nw >= S && v > cb)))) st->uncertain += 1;
+    }
+    if (tid == 0) {
+        *ncands = Seff;
+        if (nw == 0) st->uncertain += 1;  // (cannot happen with a non-empty dictionary: the best candidate is always in the window)
+    }
+}
+
 
 }  // namespace csmp

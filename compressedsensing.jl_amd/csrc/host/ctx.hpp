@@ -219,6 +219,9 @@ static int batch_dict(csmp_ctx* ctx);
 static int batch_colnorm(csmp_ctx* ctx);
 static int screened_ensure(csmp_ctx* ctx);
 static int twins_ensure(csmp_ctx* ctx, int n);
+static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block);
+static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin);
+static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask);
 static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic);
 static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
                               int64_t* idx, double* val, int64_t* nnz, int out_loc);

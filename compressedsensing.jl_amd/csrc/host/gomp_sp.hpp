@@ -122,30 +122,45 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     CHECK(solver_ensure(ctx, kc, (int)std::max<int64_t>(k + l, 1)));
     ctx->s.begun = false;
     // first with the multi-column append (the l atoms of a step join the QR in one panel); a panel
-    // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain
+    // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain.  With
+    // CSMP_OPT_SCREENED_SWEEP the sweeps read the bf16 image and the top-l pick is certified (host/screened.hpp); a solve
+    // with an uncertified step is repeated with the exact sweep.
     bool capacity_stop = false;
-    for (int pass = 0; pass < 2; ++pass) {
-        const bool block = pass == 0 && !ctx->force_reorth && l <= kPanelMax;
+    bool screened = ctx->opt_screened != 0 && l <= kTopSmall;
+    if (screened) CHECK(screened_ensure(ctx));
+    bool block = !ctx->force_reorth && l <= kPanelMax;
+    for (int attempt = 0; attempt < 4; ++attempt) {
         CHECK(upload_b(ctx, b, b_dtype));
         const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
         for (int64_t it = 0; it < k / l && !ctx->s.capped; ++it) {  // :130-133
-            CHECK(gomp_update(ctx, l, eps, it > 0, main_skip, block));
+            CHECK(screened ? gomp_update_screened(ctx, l, eps, it > 0, main_skip, block) : gomp_update(ctx, l, eps, it > 0, main_skip, block));
             if ((it + 1) % kPollSteps == 0 && it + 1 < k / l) {
                 bool stopped = false;
                 CHECK(solver_poll(ctx, &stopped));
                 if (stopped) break;  // (the remainder step below still runs, as in the reference)
             }
         }
-        const int64_t rem = k % l;                                                                             // :134
-        if (rem > 0) CHECK(gomp_update(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block));  // :135-137: runs even after an eps-break
+        const int64_t rem = k % l;  // :134
+        if (rem > 0)  // :135-137: runs even after an eps-break
+            CHECK(screened ? gomp_update_screened(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block) : gomp_update(ctx, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block));
         CHECK(launch_finish(ctx, ctx->s.out_idx, ctx->s.out_val, ctx->s.out_nnz, ctx->s.out_order, ctx->s.outcap));
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!(hs.done & STOP_REORTH)) {
-            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
-            break;
+        if (screened) {
+            ctx->scr_solves += 1;
+            if (hs.uncertain > 0) {
+                ctx->scr_fallbacks += 1;
+                screened = false;
+                continue;
+            }
         }
+        if ((hs.done & STOP_REORTH) && block) {
+            block = false;
+            continue;
+        }
+        capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
+        break;
     }
     CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
     return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
@@ -175,18 +190,18 @@ static int twins_ensure(csmp_ctx* ctx, int n) {
 }
 
 static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l, int64_t k, double eps, bool block, int64_t* d_idx,
-                        double* d_val, int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
+                        double* d_val, int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep, bool screened = false) {
     int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
     if (rc != CSMP_OK) return rc;
     const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
     for (int64_t it = 0; it < k / l && !c->s.capped; ++it) {  // src/matchingpursuit.jl:130-133
-        rc = gomp_update(c, l, eps, it > 0, main_skip, block);
+        rc = screened ? gomp_update_screened(c, l, eps, it > 0, main_skip, block) : gomp_update(c, l, eps, it > 0, main_skip, block);
         if (rc != CSMP_OK) return rc;
         if (it == 0 && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
     }
     const int64_t rem = k % l;
     if (rem > 0) {  // :134-137: runs even after an eps-break
-        rc = gomp_update(c, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block);
+        rc = screened ? gomp_update_screened(c, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block) : gomp_update(c, rem, 0.0, 0, STOP_FULL | STOP_REORTH, block);
         if (rc != CSMP_OK) return rc;
     }
     return launch_finish(c, d_idx, d_val, d_nnz, nullptr, (int)k, d_flag);
@@ -235,13 +250,15 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
     if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
     const bool block = !ctx->force_reorth && l <= kPanelMax;
+    const bool screened = ctx->opt_screened != 0 && l <= kTopSmall;  // sweeps over the bf16 image, certified top-l picks (host/screened.hpp)
+    if (screened) CHECK(screened_ensure_pair(ctx, cc[1]));
     std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
         csmp_ctx* c = cc[sgn & 1];
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
         const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
-                                    sgn == 0 ? ctx->ev_twin : nullptr);
+                                    sgn == 0 ? ctx->ev_twin : nullptr, screened);
         capped[(size_t)sgn] = c->s.capped;  // (the host withholds the appends: known at enqueue time)
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
@@ -254,13 +271,23 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     std::vector<int> hf((size_t)nsig);
     HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    // a panel that failed its DGKS test flagged the solve (nothing committed): that signal again, column by column
+    // a panel that failed its DGKS test flagged the solve (nothing committed): that signal again, column by column; a solve
+    // with an uncertified pick (screened sweep): again with the exact sweep
     int rc = CSMP_OK;
     bool capacity_stop = false;
     for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
-        if (hf[sgn] & STOP_REORTH) {
+        if (screened) {
+            ctx->scr_solves += 1;
+            ctx->scr_fallbacks += (hf[sgn] & STOP_UNCERTAIN) ? 1 : 0;
+        }
+        bool blk = block;
+        while (rc == CSMP_OK && (hf[sgn] & (STOP_REORTH | STOP_UNCERTAIN))) {
+            if (hf[sgn] & STOP_REORTH) {
+                if (!blk && !(hf[sgn] & STOP_UNCERTAIN)) break;  // (the column-wise chain flags nothing it cannot handle)
+                blk = false;
+            }
             const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
-            rc = gomp_enqueue(ctx, col, b_dtype, l, k, eps, false, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn, nullptr);
+            rc = gomp_enqueue(ctx, col, b_dtype, l, k, eps, blk, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn, nullptr, false);
             if (rc == CSMP_OK) {
                 HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHECK(hipStreamSynchronize(ctx->stream));

@@ -44,11 +44,26 @@ static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
     return hipGetLastError();
 }
 
-// update!(P::OMP, x) with the screened sweep: bf16 sweep -> certified pick -> the exact path's append chain
-static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
+template <typename TA>
+static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {
+    Solver& s = ctx->s;
+    constexpr int U = sizeof(TA) == 4 ? 16 : 8;
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
+    auto kern = k_pickS<TA, U>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
+                       ncand, s.st, (const double*)s.r, s.Mpad, S, s.cands, s.cvals, s.ncands, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin,
+                       skipmask, s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1);
+    return hipGetLastError();
+}
+
+// the sweep over the bf16 image: candidates of every workgroup into s.scr_val / s.scr_idx
+static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip) {
     Solver& s = ctx->s;
     Batch& b = ctx->bt;
-    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
     const int nchunk = (b.Mk + 511) / 512;
     const size_t lds = sweep_bf16_lds_bytes(b.Mk);
     const bool timed = prof_pick(ctx);
@@ -69,8 +84,46 @@ static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool opti
 #undef CSMP_SCR
     HIPCHECK(hipGetLastError());
     if (timed) CHECK(prof_mark(ctx));
+    return CSMP_OK;
+}
+
+// update!(P::OMP, x) with the screened sweep: bf16 sweep -> certified pick -> the exact path's append chain
+static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    CHECK(launch_sweep_bf16(ctx, eps, check_eps, skip));
     HIPCHECK(ctx->dtype == CSMP_F32 ? pick1_launch<float>(ctx, ctx->scr_grid * kScrCand, skip) : pick1_launch<double>(ctx, ctx->scr_grid * kScrCand, skip));
     return launch_append(ctx, 1, 0, skip, optimistic, 0.0, /*nblk_sweep: the pick is the only "partial"*/ 1);
+}
+
+// update!(P::GOMP, x, l) with the screened sweep: bf16 sweep -> certified top-l pick -> the exact path's (panel) appends
+static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block) {
+    l = std::min<int64_t>(l, ctx->N);
+    CHECK(launch_sweep_bf16(ctx, eps, check_eps, skipmask));
+    HIPCHECK(ctx->dtype == CSMP_F32 ? pickS_launch<float>(ctx, ctx->scr_grid * kScrCand, (int)l, skipmask)
+                                    : pickS_launch<double>(ctx, ctx->scr_grid * kScrCand, (int)l, skipmask));
+    if (block && l > 1) return launch_block_appends(ctx, (int)l, skipmask);
+    for (int64_t w = 0; w < l; ++w) CHECK(launch_append(ctx, 2, (int)w, skipmask));
+    return CSMP_OK;
+}
+
+// the twin of a batch driver sweeps its parent's image (the twin is destroyed before the parent's image is: csmp_set_dictionary,
+// csmp_destroy) and carries its certificate option
+static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
+    twin->opt_batch_cert = ctx->opt_batch_cert;
+    CHECK(screened_ensure(ctx));
+    if (!twin->bt.ab_valid) {
+        Batch &tb = twin->bt, &pb = ctx->bt;
+        tb.Ab = pb.Ab;
+        tb.Mk = pb.Mk;
+        tb.Npad = pb.Npad;
+        tb.n_atiles = pb.n_atiles;
+        tb.amax_host = pb.amax_host;
+        tb.ab_valid = tb.ab_borrowed = true;
+    }
+    twin->bt.anorm_host = ctx->bt.anorm_host;
+    const int rc = screened_ensure(twin);
+    if (rc != CSMP_OK) ctx->err = twin->err;
+    return rc;
 }
 
 // omp for many signals with the screened sweep: TWO solves in flight, the context's and a twin's, out of phase (the pattern of
@@ -94,23 +147,10 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     HIPCHECK(hipSetDevice(ctx->dev));
     CHECK(twins_ensure(ctx, 1));
     csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
-    cc[1]->opt_batch_cert = ctx->opt_batch_cert;
-    CHECK(screened_ensure(ctx));
-    if (!cc[1]->bt.ab_valid) {  // the twin (destroyed before this context's image is: csmp_set_dictionary, csmp_destroy) sweeps the same image
-        Batch &tb = cc[1]->bt, &pb = ctx->bt;
-        tb.Ab = pb.Ab;
-        tb.Mk = pb.Mk;
-        tb.Npad = pb.Npad;
-        tb.n_atiles = pb.n_atiles;
-        tb.amax_host = pb.amax_host;
-        tb.anorm_host = pb.anorm_host;
-        tb.ab_valid = tb.ab_borrowed = true;
-    }
-    cc[1]->bt.anorm_host = ctx->bt.anorm_host;
+    CHECK(screened_ensure_pair(ctx, cc[1]));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
     for (int q = 0; q < 2; ++q) {
-        int rc = solver_ensure(cc[q], kc, (int)k);
-        if (rc == CSMP_OK) rc = screened_ensure(cc[q]);
+        const int rc = solver_ensure(cc[q], kc, (int)k);
         if (rc != CSMP_OK) {
             if (q) ctx->err = cc[q]->err;
             return rc;

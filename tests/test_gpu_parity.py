@@ -1810,3 +1810,116 @@ def test_screened_sweep_full_size_config2(cs, oracle):
     d.ctx.sync()
     assert int(nnz[0]) == len(exact[0]) and np.array_equal(np.sort(idx[0, :int(nnz[0])].cpu().numpy()), np.sort(exact[0]))
     d.close()
+
+
+@pytest.mark.parametrize("shape", [(32, 48, 3, 2), (64, 256, 9, 4), (37, 101, 7, 3), (256, 1024, 32, 4), (300, 5000, 40, 16), (512, 4096, 24, 4),
+                                   (1500, 3000, 17, 4)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_screened_sweep_gomp_matches_oracle(cs, oracle, D, shape, dtype):
+    """csmp_gomp / csmp_gomp_batch with the screened sweep (k_sweep_bf16 + k_pickS: the top-l pick certified as a whole):
+    supports, INSERTION ORDER and coefficients of the oracle (src/matchingpursuit.jl:116-148), both certificates, l from 2 to 16,
+    k not a multiple of l (the remainder step)."""
+    n, m, k, l = shape
+    eps = float(np.finfo(dtype).eps)
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n * 17 + m, dtype=dtype)
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 1)
+    d.ctx.screened_stats(reset=True)
+    ys = []
+    for seed in range(3):
+        xs = cs.sparse_vector(m, k, rng=seed)
+        ys.append(cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3 if seed else 0.0, rng=seed + 50) if seed else A[:, xs.nzind].astype(np.float64) @ xs.nzval)
+    refs = [oracle.gomp(A, y, l, k, eps) for y in ys]
+    for cert in (0, 1):
+        d.ctx.set_option("batch_cert", cert)
+        for y, ref in zip(ys, refs):
+            got = d.ctx.gomp(y, l, k, eps)
+            assert np.array_equal(got[2], ref[2]), ("insertion order", cert)
+            assert np.array_equal(got[0], ref[0])
+            if np.all(np.isfinite(ref[1])):
+                assert close(got[1], ref[1], tight=False)
+        idx, val, nnz = d.ctx.gomp_batch(np.asfortranarray(np.stack(ys, axis=1)), l, k, eps)
+        for s, ref in enumerate(refs):
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (cert, s)
+    st = d.ctx.screened_stats()
+    assert st["solves"] == 12 and st["fallbacks"] <= 12
+    d.ctx.set_option("batch_cert", 0)
+    d.ctx.set_option("screened_sweep", 0)
+
+
+@pytest.mark.parametrize("kind", ["few_valued", "partial_dct", "one_magnitude", "common_component"])
+def test_screened_sweep_gomp_structured_dictionaries(cs, oracle, kind):
+    M, N, nsig, k, l = 512, 4096, 12, 16, 4
+    rng = np.random.default_rng(7 + len(kind))
+    A = cs.structured_dictionary(kind, M, N, rng=rng)
+    A64 = A.astype(np.float64)
+    d = cs.Dictionary(A)
+    B = np.empty((M, nsig), order="F")
+    for s in range(nsig):
+        sup = rng.choice(N, size=k, replace=False)
+        x = rng.choice(np.array([-1.0, 1.0]), size=k) * (1.0 + (2e-3 * rng.random(k) if s % 2 else 0.0))
+        B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
+    i2, v2, n2 = d.ctx.gomp_batch(B, l, k, EPS32)
+    d.ctx.set_option("screened_sweep", 1)
+    for cert in (0, 1):
+        d.ctx.set_option("batch_cert", cert)
+        idx, val, nnz = d.ctx.gomp_batch(B, l, k, EPS32)
+        assert np.array_equal(nnz, n2) and np.array_equal(idx, i2), (kind, cert)
+        assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
+    for s in range(0, nsig, 4):
+        ref = oracle.gomp(A, B[:, s], l, k, EPS32)
+        got = d.ctx.gomp(B[:, s], l, k, EPS32)
+        assert np.array_equal(got[2], ref[2]) and np.array_equal(got[0], ref[0])
+    d.close()
+
+
+def test_screened_sweep_gomp_duplicates_and_small_dictionaries(cs, oracle, D):
+    """Exact copies among the top-l (GOMP takes an atom AND its copy: the reference's least squares is singular there, only the
+    support is defined), fewer atoms than l, a dictionary of one sweep workgroup."""
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((64, 300)).astype(np.float32)
+    A /= np.linalg.norm(A, axis=0)
+    A[:, 250] = A[:, 17]
+    A = np.asfortranarray(A)
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 1)
+    y = 3.0 * A[:, 17].astype(np.float64) + 0.5 * A[:, 40].astype(np.float64)
+    ref = oracle.gomp(A, y, 2, 4, EPS32)  # (the reference's coefficients are +-Inf from here on and it stops; only the first step is defined)
+    got = d.ctx.gomp(y, 2, 4, EPS32)
+    d.ctx.set_option("screened_sweep", 0)
+    exact = d.ctx.gomp(y, 2, 4, EPS32)
+    assert np.array_equal(got[2][:2], ref[2][:2]) and np.array_equal(got[2], exact[2]) and np.array_equal(got[0], exact[0])
+    A3 = np.asfortranarray(rng.standard_normal((16, 3)))
+    d3 = D(A3)
+    d3.ctx.set_option("screened_sweep", 1)
+    y3 = A3[:, 1] * 2.0 - A3[:, 2]
+    ref = oracle.gomp(A3, y3, 4, 3, EPS64)
+    got = d3.ctx.gomp(y3, 4, 3, EPS64)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2])
+    d.ctx.set_option("screened_sweep", 0)
+
+
+def test_screened_sweep_full_size_config5_gomp(cs, oracle):
+    """BASELINE configs[4] (8192 x 131072 f32, k = 512, S = 4): the screened solve equals the exact one atom for atom (insertion
+    order, coefficients), certified throughout; the batch form too."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    At5, D5 = bench.make_dictionary5(cs, torch, dev)
+    M5, N5, k = 8192, 131072, 512
+    g = torch.Generator(device=dev).manual_seed(77)
+    sel = torch.randperm(N5, generator=g, device=dev)[:k]
+    sign = torch.randint(0, 2, (k,), generator=g, device=dev).to(torch.float64) * 2 - 1
+    e = torch.randn(M5, generator=g, device=dev, dtype=torch.float64)
+    y = ((At5[sel].to(torch.float64) * sign[:, None]).sum(0) + e * (5e-3 / e.norm())).cpu().numpy()
+    exact = D5.ctx.gomp(y, 4, k, EPS32)
+    D5.ctx.set_option("screened_sweep", 1)
+    D5.ctx.screened_stats(reset=True)
+    got = D5.ctx.gomp(y, 4, k, EPS32)
+    assert np.array_equal(got[2], exact[2]) and np.array_equal(got[0], exact[0]) and np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
+    assert D5.ctx.screened_stats() == {"solves": 1, "fallbacks": 0}
+    bi, bv, bn = D5.ctx.gomp_batch(np.asfortranarray(np.stack([y, -y, 0.5 * y], axis=1)), 4, k, EPS32)
+    for s in range(3):
+        assert bn[s] == len(exact[0]) and np.array_equal(bi[:bn[s], s], exact[0])
+    assert D5.ctx.screened_stats()["fallbacks"] == 0
+    D5.close()

@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle comparison of the core path (omp, gomp, sp, the batch drivers incl. the MFMA-screened one under both
-certificates and with the resident Gram matrix, the in-flight batch forms of gomp / sp, lstsq), on Gaussian and -- every third
+certificates and with the resident Gram matrix, the screened single-signal sweep under both certificates, the in-flight batch forms of gomp / sp, lstsq), on Gaussian and -- every third
 round -- structured dictionaries.    python tools/stress_core.py [seconds] [seed]"""
 import os
 import sys
@@ -74,6 +74,15 @@ while time.time() - t0 < budget:
                 cmp(name, (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
+        for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
+            D.ctx.set_option("batch_cert", cert)
+            D.ctx.set_option("screened_sweep", 1)
+            cmp(name, D.ctx.omp(B[:, 0], k, eps), refs[0], cfg)
+            idx, val, nnz = D.ctx.omp_batch(B, k, eps)
+            for s in range(nsig):
+                cmp(name + "_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
+        D.ctx.set_option("screened_sweep", 0)
+        D.ctx.set_option("batch_cert", 0)
         l = int(rng.choice([2, 3, 4]))
         gref = [oc.gomp(A, B[:, s], l, k, eps) for s in range(nsig)]
         cmp("gomp", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
@@ -81,6 +90,14 @@ while time.time() - t0 < budget:
             idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
             for s in range(nsig):
                 cmp("gomp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
+            D.ctx.set_option("screened_sweep", 1)  # certified top-l picks over the bf16 image
+            D.ctx.set_option("batch_cert", int(rng.integers(0, 2)))
+            cmp("gomp_screened", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
+            idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
+            for s in range(nsig):
+                cmp("gomp_screened_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
+            D.ctx.set_option("screened_sweep", 0)
+            D.ctx.set_option("batch_cert", 0)
         if 2 * k <= M:
             sref = [oc.sp(A, B[:, s], k, 1e-12) for s in range(nsig)]
             cmp("sp", D.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
