@@ -19,11 +19,11 @@ HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL, STOP_CAPACITY = 1, 2, 4, 8
 # csmp_set_option keys (include/csmp.h)
-OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP, OPT_BATCH_SCREEN = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
            "force_reorth": OPT_FORCE_REORTH, "ls_gram": OPT_LS_GRAM, "ls_gram_reuse": OPT_LS_GRAM_REUSE,
            "twostage_update": OPT_TWOSTAGE_UPDATE, "solves_in_flight": OPT_SOLVES_IN_FLIGHT,
-           "screened_sweep": OPT_SCREENED_SWEEP}
+           "screened_sweep": OPT_SCREENED_SWEEP, "batch_screen": OPT_BATCH_SCREEN}
 
 i64 = C.c_int64
 vp = C.c_void_p

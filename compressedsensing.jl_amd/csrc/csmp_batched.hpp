@@ -45,6 +45,8 @@ struct BState {
     // the first failed certificate of the signal (diagnostics: csmp_batch_stats' callers see only the counts)
     int unc_step, unc_nall;
     double unc_cb, unc_best, unc_s1;
+    float rstep;  // int8 screen (CSMP_OPT_BATCH_SCREEN = 1): the quantisation step of the signal's residual image
+    int pad_;
 };
 // hand-off k_b_pick -> k_b_append, one per signal
 struct BPick {
@@ -70,6 +72,40 @@ __global__ __launch_bounds__(256) void k_b_convert(const TA* __restrict__ A, int
     }
     *reinterpret_cast<bf16x8*>(out + n * Mk + c * 8) = v;
 }
+
+// dictionary -> int8 [Npad][Mk8] with ONE step for the whole dictionary (astep = max|A| / 127; inv = 1 / astep), zero padded:
+// the int8 screen's operand (k_b_screen256p<true>).  A common step makes the absolute rounding error of every entry the
+// same, which is what the certificate's absolute term assumes.
+template <typename TA>
+__global__ __launch_bounds__(256) void k_b_convert_i8(const TA* __restrict__ A, int64_t ld, int M, int64_t N,
+                                                      signed char* __restrict__ out, int Mk8, int64_t Npad, float inv) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kc = Mk8 / 16;
+    const int64_t n = idx / kc;
+    const int c = (int)(idx % kc);
+    if (n >= Npad) return;
+    using c16 = signed char __attribute__((ext_vector_type(16)));
+    c16 v;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int k = c * 16 + e;
+        const float a = (n < N && k < M) ? (float)A[n * ld + k] : 0.0f;
+        v[e] = (signed char)max(-127, min(127, __float2int_rn(a * inv)));
+    }
+    *reinterpret_cast<c16*>(out + n * Mk8 + c * 16) = v;
+}
+
+// largest |v| over the 256 threads of a workgroup (every thread gets it); scratch: 4 floats
+__device__ __forceinline__ float block_absmax256(float v, float* scratch4) {
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s, kWave));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(scratch4[0], scratch4[1]), fmaxf(scratch4[2], scratch4[3]));
+}
+// the step of a residual's int8 image and what multiplies the integer dot products of the screen: astep * rstep, nudged up so
+// that the candidate values stay upper bounds
+__device__ __forceinline__ float i8_step(float rmax) { return rmax > 0.0f ? rmax * (1.0f / 127.0f) : 1.0f; }
 
 // ---------------------------------------------------------------------------------------------
 // helpers of the per-signal kernels: thread t owns the 4-row groups g = t + 256 i, i < NI
@@ -108,17 +144,32 @@ template <> struct Raw4<double> {
 template <typename TB>
 __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int64_t ldB, int M, int nsig,
                                                 double* __restrict__ r_all, double* __restrict__ b_all, int Mr,
-                                                __bf16* __restrict__ rb_all, int Mk, BState* __restrict__ bs) {
+                                                __bf16* __restrict__ rb_all, int Mk, BState* __restrict__ bs,
+                                                signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep) {
+    __shared__ float smax[4];
     const int s = blockIdx.x;
+    float amax = 0.0f;
     for (int m = threadIdx.x; m < Mk || m < Mr; m += 256) {
         const double v = (s < nsig && m < M) ? (double)Bsig[(int64_t)s * ldB + m] : 0.0;
         if (m < Mr) {
             r_all[(int64_t)s * Mr + m] = v;
             b_all[(int64_t)s * Mr + m] = v;
         }
-        if (m < Mk) rb_all[(int64_t)s * Mk + m] = (__bf16)(float)v;
+        if (m < Mk && !r8_all) rb_all[(int64_t)s * Mk + m] = (__bf16)(float)v;
+        amax = fmaxf(amax, fabsf((float)v));
+    }
+    float rstep = 0.0f;
+    if (r8_all) {  // int8 image of the signal, one step per signal
+        rstep = i8_step(block_absmax256(amax, smax));
+        const float inv = 1.0f / rstep;
+        for (int m = threadIdx.x; m < Mk8; m += 256) {
+            const float v = (s < nsig && m < M) ? (float)(double)Bsig[(int64_t)s * ldB + m] : 0.0f;
+            r8_all[(int64_t)s * Mk8 + m] = (signed char)max(-127, min(127, __float2int_rn(v * inv)));
+        }
+        if (threadIdx.x == 0) sigscale[s] = astep * rstep * (1.0f + 0x1p-20f);
     }
     if (threadIdx.x == 0) {
+        bs[s].rstep = rstep;
         bs[s].nsel = 0;
         bs[s].done = (s < nsig) ? 0 : STOP_FULL;  // padding signals never run
         bs[s].uncertain = 0;
@@ -188,7 +239,7 @@ template <typename TA, int U>
 __global__ __launch_bounds__(256, 4) void k_b_pick(
     const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand,
     const int* __restrict__ sel_all, BState* __restrict__ bs, BPick* __restrict__ pick, const double* __restrict__ r_all, int Mr,
-    int kcap, int Mrows, double eps, int check_eps, double cert_abs, double cert_rel, int kwin, int sig0) {
+    int kcap, int Mrows, double eps, int check_eps, double cert_abs, double cert_rel, int kwin, int sig0, double cert_abs2) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
     __shared__ double red[kWinMax];
@@ -266,7 +317,8 @@ __global__ __launch_bounds__(256, 4) void k_b_pick(
         return;
     }
     // ---- window and certificate bound
-    const double dabs = cert_abs * sqrt(n2);
+    // (int8 screen: the residual image's own rounding adds cert_abs2 * its step, independent of the dictionary's)
+    const double dabs = cert_abs2 > 0.0 ? sqrt(cert_abs * cert_abs * n2 + cert_abs2 * cert_abs2 * (double)st.rstep * (double)st.rstep) : cert_abs * sqrt(n2);
     const double lb1 = (double)m1 - dabs - cert_rel * (double)m1;
     double cb = -1.0;
     auto visit = [&](float v, int i, int slot) {
@@ -353,8 +405,10 @@ template <typename TA, int NI, int DEPTH, bool GRAM>
 __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
     const TA* __restrict__ A, int64_t ld, int Mv, const double* __restrict__ Gm, int64_t Ng, const BPick* __restrict__ pick,
     double* __restrict__ T_all, double* __restrict__ Tt_all, double* __restrict__ z_all, int* __restrict__ sel_all,
-    BState* __restrict__ bs, double* __restrict__ r_all, int Mr, __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, int sig0) {
+    BState* __restrict__ bs, double* __restrict__ r_all, int Mr, __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, int sig0,
+    signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ float smax[4];
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
@@ -648,19 +702,52 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
     // ---- q = v / rho, z_j = <a, r> / rho, r -= q z_j; new column of T = [-y / rho; 1 / rho]
     const double zj = cexact / rho;
     const double f = zj / rho;  // r -= v * (z_j / rho)
-    __bf16* rb = rb_all + (int64_t)s * Mk;
+    if (!r8_all) {
+        __bf16* rb = rb_all + (int64_t)s * Mk;
 #pragma unroll
-    for (int u = 0; u < NI; ++u) {
-        const int row = 4 * (tid + 256 * u);
-        bf16x4 o;
+        for (int u = 0; u < NI; ++u) {
+            const int row = 4 * (tid + 256 * u);
+            bf16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const double rold = (row + e < Mrows) ? r[row + e] : 0.0;  // (reloaded: the residual is not held in registers across the step)
-            const double nr = fma(-areg[u][e], f, rold);
-            if (row + e < Mrows) r[row + e] = nr;
-            o[e] = (__bf16)(float)((row + e < Mrows) ? nr : 0.0);
+            for (int e = 0; e < 4; ++e) {
+                const double rold = (row + e < Mrows) ? r[row + e] : 0.0;  // (reloaded: the residual is not held in registers across the step)
+                const double nr = fma(-areg[u][e], f, rold);
+                if (row + e < Mrows) r[row + e] = nr;
+                o[e] = (__bf16)(float)((row + e < Mrows) ? nr : 0.0);
+            }
+            if (row < Mk) *reinterpret_cast<bf16x4*>(rb + row) = o;
         }
-        if (row < Mk) *reinterpret_cast<bf16x4*>(rb + row) = o;
+    } else {  // int8 image: the new residual's largest magnitude first (one step per signal), then the bytes
+        float amax = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int row = 4 * (tid + 256 * u);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double rold = (row + e < Mrows) ? r[row + e] : 0.0;
+                const double nr = (row + e < Mrows) ? fma(-areg[u][e], f, rold) : 0.0;
+                if (row + e < Mrows) r[row + e] = nr;
+                areg[u][e] = nr;  // (the register's old content is spent)
+                amax = fmaxf(amax, fabsf((float)nr));
+            }
+        }
+        const float rstep = i8_step(block_absmax256(amax, smax));
+        const float inv = 1.0f / rstep;
+        signed char* r8 = r8_all + (int64_t)s * Mk8;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) {
+            const int row = 4 * (tid + 256 * u);
+            if (row < Mk8) {
+                int pk = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk |= (max(-127, min(127, __float2int_rn((float)areg[u][e] * inv))) & 0xff) << (8 * e);
+                *reinterpret_cast<int*>(r8 + row) = pk;
+            }
+        }
+        if (tid == 0) {
+            st.rstep = rstep;
+            sigscale[s] = astep * rstep * (1.0f + 0x1p-20f);
+        }
     }
     for (int t = tid; t < j; t += 256) {
         const double v = -yv[t] / rho;

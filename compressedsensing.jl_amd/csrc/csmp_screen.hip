@@ -31,9 +31,18 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // the read follows it).  A unit's LDS region is rewritten at least two phases after its last read (UB0, which phase 4
 // reads a second time, sets the lead: six phases ahead would rewrite it in the very phase that still reads it).
 // No vmcnt(0), no __syncthreads() in the loop: the DMAs stay in flight across the barriers.
+//
+// I8 = true: the SAME data movement on an int8 image (a row of Mk "bf16 slots" is 2 Mk int8 values; an LDS row of 128 bytes is a
+// K-tile of 128 instead of 64; a fragment of 16 bytes is 16 k-values instead of 8) with v_mfma_i32_16x16x64_i8 -- the same
+// cycles per instruction for twice the k, i.e. half the K-loop.  The accumulators are exact integers; the epilogue ranks
+// |acc| (one scale per signal: a rank inside a signal does not depend on it) and hands on |acc| * scale[signal], scale =
+// (dictionary step) x (the signal's residual step), see csmp_batched.hpp.
+using i32x4s = __attribute__((ext_vector_type(4))) int;
+template <bool I8>
 __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
                                                       int n_at2, int n_st2, int64_t N, int n_atiles128,
-                                                      float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+                                                      float* __restrict__ cand_val, int* __restrict__ cand_idx,
+                                                      const float* __restrict__ sigscale) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 2, wc = wave & 3, fr = lane & 15, fq = lane >> 4;
@@ -90,6 +99,13 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
     const char* laW = smem + (wr * 128 + fr) * 128;           // + stage * 65536 + m * 2048 + co
     const char* lrW = smem + 32768 + (wc * 64 + fr) * 128;    // + stage * 65536 + n * 2048 + co
     bf16x8 a[4][2], b[2][2];  // the current A sub-tile (4 m-tiles x 2 k-halves) and B sub-tile (2 n-tiles x 2 k-halves)
+    auto mma = [](const bf16x8& x, const bf16x8& y, const f32x4s& c) -> f32x4s {
+        if constexpr (I8)
+            return __builtin_bit_cast(f32x4s, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4s, x), __builtin_bit_cast(i32x4s, y),
+                                                                                    __builtin_bit_cast(i32x4s, c), 0, 0, 0));
+        else
+            return __builtin_amdgcn_mfma_f32_16x16x32_bf16(x, y, c, 0, 0, 0);
+    };
 #define CSMP_PH(STAGE, QA, QB, LOADA, LOADB, UNIT, WAITN)                                                        \
     {                                                                                                            \
         if (LOADB) {                                                                                             \
@@ -112,7 +128,7 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
         _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                         \
             _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                        \
                 _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                    \
-                    acc[(QA) * 4 + m][(QB) * 2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][kk], b[n][kk], acc[(QA) * 4 + m][(QB) * 2 + n], 0, 0, 0); \
+                    acc[(QA) * 4 + m][(QB) * 2 + n] = mma(a[m][kk], b[n][kk], acc[(QA) * 4 + m][(QB) * 2 + n]);         \
         __builtin_amdgcn_s_setprio(0);                                                                           \
         __builtin_amdgcn_s_barrier();                                                                            \
     }
@@ -159,7 +175,9 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
         for (int m = 0; m < 8; ++m)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const unsigned bits = __float_as_uint(acc[m][n][j]) & 0x7fffff00u;
+                float cv = acc[m][n][j];
+                if constexpr (I8) cv = (float)abs(__float_as_int(cv));  // (exact below 2^24, 2^-24 relative above: far inside the key's 2^-15)
+                const unsigned bits = __float_as_uint(cv) & 0x7fffff00u;
                 keyv[m * 4 + j] = bits | (unsigned)(128 - (m * 16 + j)) - (unsigned)(fq * 4);
             }
         if (ragged) {
@@ -208,6 +226,12 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
             }
             const int64_t sig = (int64_t)stile * kBT2 + wc * 64 + n * 16 + fr;
             const int64_t base = (sig * n_atiles128 + at128) * kTileCand;
+            if constexpr (I8) {
+                const float sc = sigscale[sig];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (ov[q] >= 0.0f) ov[q] *= sc;
+            }
             *reinterpret_cast<f32x4s*>(cand_val + base) = f32x4s{ov[0], ov[1], ov[2], ov[3]};
             *reinterpret_cast<int4*>(cand_idx + base) = make_int4(oi[0], oi[1], oi[2], oi[3]);
         }
@@ -376,10 +400,12 @@ __global__ __launch_bounds__(256, 2) void k_b_screen4(const __bf16* __restrict__
 #endif
 
 hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
-                         int64_t N, float* cand_val, int* cand_idx) {
+                         int64_t N, float* cand_val, int* cand_idx, const float* sigscale) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_b_screen256p, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
+        hipError_t e = hipFuncSetAttribute((const void*)k_b_screen256p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)k_b_screen256p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
         if (e != hipSuccess) return e;
 #ifdef CSMP_EXPERIMENTS
         e = hipFuncSetAttribute((const void*)k_b_screen4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds4);
@@ -395,15 +421,23 @@ hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const _
         return hipGetLastError();
     }
 #endif
-    (void)mode;
-    hipLaunchKernelGGL(k_b_screen256p, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
-                       n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx);
+    if (mode == kScreen256i8) {  // Ab / Rb are int8 images, Mk counts 2-byte slots (rows of 2 Mk int8 values)
+        if (!sigscale) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(k_b_screen256p<true>, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
+                           n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx, sigscale);
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(k_b_screen256p<false>, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
+                       n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx, (const float*)nullptr);
     return hipGetLastError();
 }
 const char* screen_kernel_name(int mode) {
     if (mode == kScreen4)
         return "csmp::k_b_screen4 (v_mfma_f32_32x32x16_bf16, 128x256 tiles, four waves = one per SIMD, 96 KiB of LDS: co-resident with the "
                "per-signal kernels of the other half-batch; LDS-DMA staging, fused top-4 epilogue)";
+    if (mode == kScreen256i8)
+        return "csmp::k_b_screen256p<true> (v_mfma_i32_16x16x64_i8 on int8 images, 256x256 tiles, eight-phase schedule, exact integer "
+               "accumulation; fused top-4 epilogue)";
     return "csmp::k_b_screen256p (v_mfma_f32_16x16x32_bf16, 256x256 tiles, eight-phase schedule: LDS-DMA units four phases ahead, "
            "counted vmcnt, the two waves of a SIMD one barrier apart; fused top-4 epilogue)";
 }

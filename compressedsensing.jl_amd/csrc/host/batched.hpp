@@ -56,6 +56,26 @@ static int batch_dict(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
+// int8 image of the dictionary under one step (max|A| / 127), for the int8 screen
+static int batch_dict8(csmp_ctx* ctx) {
+    CHECK(batch_dict(ctx));  // (amax, the tile counts; the bf16 image also serves the re-solves' callers)
+    Batch& b = ctx->bt;
+    if (b.a8_valid) return CSMP_OK;
+    b.Mk8 = (int)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256);  // bytes per row: an even number (>= 4) of 128-deep K-tiles
+    HIPCHECK(hipMalloc((void**)&b.A8, (size_t)b.Npad * b.Mk8));
+    b.astep = b.amax_host > 0.f ? b.amax_host / 127.0f : 1.0f;
+    const int64_t total = b.Npad * (b.Mk8 / 16);
+    const int grid = (int)((total + 255) / 256);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_b_convert_i8<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.A8, b.Mk8, b.Npad, 1.0f / b.astep);
+    else
+        hipLaunchKernelGGL(k_b_convert_i8<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.A8, b.Mk8, b.Npad, 1.0f / b.astep);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.a8_valid = true;
+    return CSMP_OK;
+}
+
 // max_j |a_j|_2 (the deterministic screening bound), computed on first use
 static int batch_colnorm(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
@@ -93,6 +113,8 @@ static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     CHECK(dmalloc(ctx, &b.pick, (size_t)nb));
     CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
     CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
+    CHECK(dmalloc(ctx, &b.R8, (size_t)nb * (size_t)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256)));
+    CHECK(dmalloc(ctx, &b.sigscale, (size_t)nb));
     return CSMP_OK;
 }
 
@@ -139,7 +161,7 @@ static int batch_gram(csmp_ctx* ctx) {
 
 template <typename TA>
 static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
-                                int kwin) {
+                                int kwin, double cert_abs2) {
     Batch& b = ctx->bt;
     constexpr int U = sizeof(TA) == 4 ? 16 : 8;  // 64-lane chunks of a column in flight per wave (16 bytes per lane each)
     const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
@@ -150,12 +172,12 @@ static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int
     }
     hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)b.cand_val,
                        (const int*)b.cand_idx, b.n_atiles * kTileCand, (const int*)b.sel, b.bs, b.pick, (const double*)b.r, b.Mr, b.kcap, (int)ctx->M, eps,
-                       check_eps, cert_abs, cert_rel, kwin, sig0);
+                       check_eps, cert_abs, cert_rel, kwin, sig0, cert_abs2);
     return hipGetLastError();
 }
 // DEPTH of the append kernel: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
 template <typename TA, int NI, bool GRAM>
-static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig) {
+static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, bool i8) {
     Batch& b = ctx->bt;
     constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
     const size_t lds = b_append_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
@@ -165,17 +187,17 @@ static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, i
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const double*)b.Gm, b.Ng, (const BPick*)b.pick, b.T,
-                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0);
+                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0, i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
     return hipGetLastError();
 }
 template <typename TA>
 static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
-                                  int kwin, bool gram) {
+                                  int kwin, bool gram, bool i8, double cert_abs2) {
     const int groups = (ctx->Mv + 1023) / 1024;
-    hipError_t e = b_pick_launch<TA>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin);
+    hipError_t e = b_pick_launch<TA>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin, cert_abs2);
     if (e != hipSuccess) return e;
 #define CSMP_BSTEP(NI)                                                                                                  \
-    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig);
+    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig, i8) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig, i8);
     if (groups <= 1) { CSMP_BSTEP(1) }
     if (groups <= 2) { CSMP_BSTEP(2) }
     if (groups <= 4) { CSMP_BSTEP(4) }
@@ -194,7 +216,8 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
-    CHECK(batch_dict(ctx));
+    const bool i8 = ctx->opt_batch_screen == 1 && ctx->opt_batch_cert == 0 && !tune_env("CSMP_SCREEN4");  // (the int8 screen has a statistical certificate only)
+    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
     CHECK(batch_ensure(ctx, (int)nsig, kc));
     CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals
     ctx->s.begun = false;
@@ -221,9 +244,11 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     }
     const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
     if (b_dtype == CSMP_F32)
-        hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+        hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs,
+                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
     else
-        hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs);
+        hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs,
+                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
     HIPCHECK(hipGetLastError());
     // Screening error bound  | |<a_n, r>| - s_n | <= cert_abs |r| + cert_rel s_n  (k_b_pick, csmp_batched.hpp).
     // Statistical (default): 8 standard deviations of the bf16 rounding model -- independent roundings of the M products,
@@ -233,9 +258,21 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     // Rigorous (CSMP_OPT_BATCH_CERT = 1): |<a,r> - screened| <= (2^-7 (1 + 2^-9) + Mk 2^-24) |a|_2 |r|_2 (bf16 unit roundoff
     // 2^-8 on both operands, Float32 accumulation) with the largest column norm, and the key truncation: a proof, about nine
     // times wider on a Gaussian dictionary -- the window holds more candidates (64 instead of 16), more signals overflow it.
-    double cert_abs, cert_rel;
+    // int8 screen (CSMP_OPT_BATCH_SCREEN = 1; statistical only): both operands are rounded to a uniform grid -- the dictionary to
+    // multiples of astep = max|A| / 127, every residual to multiples of its own rstep = max|r_i| / 127 -- and the integer
+    // accumulation is exact: the error of a screened value is sum(da_i r_i) + sum(a_i dr_i) (+ the product of the two), with
+    // da_i, dr_i uniform in +-step/2: sigma^2 = astep^2 |r|^2 / 12 + rstep^2 |a|^2 / 12.  8 sigma, the largest column norm; the
+    // coherent term covers a dictionary whose entries sit on few levels (all of a column's entries of one level round alike:
+    // a relative error of up to astep / (2 min level)): 2^-6 of the screened value.
+    double cert_abs, cert_rel, cert_abs2 = 0.0;
     int kwin;
-    if (ctx->opt_batch_cert == 1) {
+    if (i8) {
+        CHECK(batch_colnorm(ctx));
+        cert_abs = 8.0 * (double)b.astep / std::sqrt(12.0);
+        cert_abs2 = 8.0 * (double)b.anorm_host / std::sqrt(12.0);
+        cert_rel = std::ldexp(1.0, -6) + std::ldexp(1.0, -14);
+        kwin = kWinMax;
+    } else if (ctx->opt_batch_cert == 1) {
         CHECK(batch_colnorm(ctx));
         cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
         cert_rel = std::ldexp(1.0, -14);
@@ -247,7 +284,7 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     }
     if (ctx->opt_batch_window > 0) kwin = std::min<int>(kWinMax, (int)ctx->opt_batch_window);
     if (tune_env("CSMP_CERT_NOREL")) cert_rel = std::ldexp(1.0, -14);  // (experiments build: the round-2 bound, for tools/probe_structured.py)
-    const int mode = tune_env("CSMP_SCREEN4") ? kScreen4 : kScreen256p;
+    const int mode = i8 ? kScreen256i8 : tune_env("CSMP_SCREEN4") ? kScreen4 : kScreen256p;
     b.last_mode = mode;
     b.last_streams = 1;
     b.last_screen_signals = Bpad;
@@ -286,15 +323,19 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
                 HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
             }
             if (t == 0 && h == 1) HIPCHECK(hipStreamWaitEvent(hs_[1], ctx->ev_off, 0));
-            HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles, hpad[h] / kBT, ctx->N,
-                                   b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand));
+            if (i8)  // (rows of Mk8 bytes = Mk8 / 2 two-byte slots)
+                HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.A8, (const __bf16*)(b.R8 + (size_t)h0[h] * b.Mk8), b.Mk8 / 2, b.n_atiles, hpad[h] / kBT,
+                                       ctx->N, b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand, b.sigscale + h0[h]));
+            else
+                HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles, hpad[h] / kBT, ctx->N,
+                                       b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand));
             if (t == 0 && h == 0 && nh == 2) HIPCHECK(hipEventRecord(ctx->ev_off, hs_[0]));
             if (timed) {
                 if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
                 HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
             }
-            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram)
-                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram);
+            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram, i8, cert_abs2)
+                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram, i8, cert_abs2);
             HIPCHECK(e);
         }
     }

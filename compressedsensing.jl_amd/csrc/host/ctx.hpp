@@ -82,6 +82,14 @@ struct Batch {
     bool gram_valid = false;
     float* cand_val = nullptr;
     int* cand_idx = nullptr;
+    // int8 screen (CSMP_OPT_BATCH_SCREEN = 1): the dictionary as int8 [Npad][Mk8] under one step, the residual images, the
+    // factor of every signal's integer dot products
+    signed char* A8 = nullptr;
+    bool a8_valid = false;
+    int Mk8 = 0;
+    float astep = 0.f;
+    signed char* R8 = nullptr;
+    float* sigscale = nullptr;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
     int last_mode = 0;  // screening kernel of the last batch (kScreen128 / kScreen256 / kScreenCo)
     int64_t last_screen_signals = 0;  // signal columns of one (timed) screening launch of the last batch
@@ -134,7 +142,8 @@ struct csmp_ctx {
     int scr_grid = 0;                           // workgroups of k_sweep_bf16
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0;
     int scr_kwin = 0, scr_cert_mode = -1;
-    int opt_screened = 0;          // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch sweep the bf16 image and certify (csmp_screened.hpp)
+    int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
+    int opt_batch_screen = 0;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>)
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch

@@ -37,13 +37,15 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
 
 static void batch_free(Batch& b, bool keep_dict) {
     dfree(b.Rb); dfree(b.r); dfree(b.b); dfree(b.T); dfree(b.Tt); dfree(b.z); dfree(b.sel); dfree(b.bs);
-    dfree(b.cand_val); dfree(b.cand_idx); dfree(b.pick);
+    dfree(b.cand_val); dfree(b.cand_idx); dfree(b.pick); dfree(b.R8); dfree(b.sigscale);
     b.Bcap = b.kcap = 0;
     if (!keep_dict) {
         if (b.ab_borrowed) b.Ab = nullptr;
         b.ab_borrowed = false;
         dfree(b.Ab);
         dfree(b.amax);
+        dfree(b.A8);
+        b.a8_valid = false;
         dfree(b.Gm);
         b.gram_valid = false;
         b.ab_valid = false;
@@ -160,6 +162,7 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
         case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
         case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 1; return &ctx->opt_screened;
+        case CSMP_OPT_BATCH_SCREEN: *lo = 0; *hi = 1; return &ctx->opt_batch_screen;
         default: return nullptr;
     }
 }

@@ -71,6 +71,8 @@ extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     c->force_reorth = src->force_reorth;
     c->opt_batch_cert = src->opt_batch_cert;
     c->opt_batch_window = src->opt_batch_window;
+    c->opt_batch_screen = src->opt_batch_screen;
+    c->opt_screened = src->opt_screened;
     c->opt_ls_gram = src->opt_ls_gram;
     c->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
     c->opt_twostage_update = src->opt_twostage_update;

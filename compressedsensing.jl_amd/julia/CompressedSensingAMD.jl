@@ -63,7 +63,7 @@ end
 # The reference passes its behavioural choices as arguments and so does this module; the choices that exist only on the GPU
 # side are per-Dictionary options.  The library reads no environment variable.
 const OPTIONS = Dict(:batch_cert => 1, :batch_gram => 2, :batch_window => 3, :pipeline => 4, :force_reorth => 5,
-                     :ls_gram => 6, :ls_gram_reuse => 7, :twostage_update => 8, :solves_in_flight => 9, :screened_sweep => 10)
+                     :ls_gram => 6, :ls_gram_reuse => 7, :twostage_update => 8, :solves_in_flight => 9, :screened_sweep => 10, :batch_screen => 11)
 set_option!(D::Dictionary, key::Symbol, value::Integer) =
     check(D, ccall((:csmp_set_option, libcsmp), Cint, (Ptr{Cvoid}, Cint, Int64), D.ctx, OPTIONS[key], value))
 function get_option(D::Dictionary, key::Symbol)

@@ -242,6 +242,10 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
                                       repeated with the exact sweep before the call returns, so results are those of option 0.
                                       Costs the bf16 image (2 Mk N bytes) beside the dictionary.  Default off: the headline
                                       path stays the exact one ("Screened single-signal sweep"). */
+#define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM. 0 (default): bf16 images (v_mfma_f32_16x16x32_bf16);
+                                      1: int8 images -- the dictionary under one step max|A|/127, every residual under its own --
+                                      on v_mfma_i32_16x16x64_i8 (half the K-loop, exact integer accumulation), statistical
+                                      certificate only (ignored under CSMP_OPT_BATCH_CERT = 1).  Costs M N bytes beside the bf16 image. */
 int csmp_set_option(csmp_ctx *ctx, int key, int64_t value);
 int csmp_get_option(csmp_ctx *ctx, int key, int64_t *value);
 

@@ -1211,11 +1211,11 @@ def test_options_at_the_abi(cs, D):
     d = D(A)
     c = d.ctx
     defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
-                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0}
+                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0, "batch_screen": 0}
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
-                     ("solves_in_flight", 0), ("screened_sweep", 2)):
+                     ("solves_in_flight", 0), ("screened_sweep", 2), ("batch_screen", 2)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -1333,6 +1333,19 @@ def test_full_size_config3_batched(cs, oracle):
     # certificate sends at most a handful of signals to the exact path
     assert st["signals"] == nsig and st["illcond"] == 0
     assert st["resolved_exactly"] == st["uncertain"] and st["uncertain"] <= 8, st
+    # (iv) the same batch through the int8 screen (CSMP_OPT_BATCH_SCREEN = 1), alone and with the resident Gram matrix
+    for gram in (0, 1):
+        d.ctx.set_option("batch_screen", 1)
+        d.ctx.set_option("batch_gram", gram)
+        i8i, i8v, i8n = run(d.ctx.omp_batch_mfma_device, B, k)
+        st8 = d.ctx.batch_stats()
+        print("C3 int8 screen, gram %d, batch_stats:" % gram, st8)
+        assert "i8" in d.ctx.batch_screen_kernel()
+        assert np.array_equal(i8n, n2) and np.array_equal(i8i, i2)
+        assert np.allclose(i8v, v2, rtol=1e-9, atol=1e-12)
+        assert st8["illcond"] == 0 and st8["uncertain"] <= 8, st8
+    d.ctx.set_option("batch_screen", 0)
+    d.ctx.set_option("batch_gram", 0)
     d.close()
 
 
@@ -1923,3 +1936,60 @@ def test_screened_sweep_full_size_config5_gomp(cs, oracle):
         assert bn[s] == len(exact[0]) and np.array_equal(bi[:bn[s], s], exact[0])
     assert D5.ctx.screened_stats()["fallbacks"] == 0
     D5.close()
+
+
+# ------------------------------------------------------------------ int8 screening GEMM of the batched path (CSMP_OPT_BATCH_SCREEN)
+@pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9), (4096, 2500, 10, 260)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_batched_int8_screen_matches_oracle(cs, oracle, D, shape, dtype):
+    """csmp_omp_batch_mfma with int8 operands (k_b_screen256p<true>: v_mfma_i32_16x16x64_i8, exact integer accumulation, one step
+    for the dictionary and one per residual): every signal's support, coefficients and count equal the oracle's; whatever the
+    screen could not certify was re-solved exactly."""
+    n, m, k, nsig = shape
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m, dtype=dtype)
+    eps = float(np.finfo(dtype).eps)
+    rng = np.random.default_rng(n * 3 + nsig)
+    B = np.empty((n, nsig), order="F")
+    for s in range(nsig):
+        sup = rng.choice(m, size=k, replace=False)
+        B[:, s] = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=k), 5e-3, rng=rng)
+    d = D(A)
+    d.ctx.set_option("batch_screen", 1)
+    idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+    st = d.ctx.batch_stats()
+    d.ctx.set_option("batch_screen", 0)
+    assert "i8" in d.ctx.batch_screen_kernel()
+    assert st["signals"] == nsig and st["resolved_exactly"] <= st["uncertain"] + st["illcond"]
+    for s in range(0, nsig, max(1, nsig // 12)):
+        ref = oracle.omp(A, B[:, s], k, eps)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), s
+        assert close(val[:nnz[s], s], ref[1], tight=False)
+    i2, v2, n2 = d.ctx.omp_batch(B, k, eps)
+    assert np.array_equal(nnz, n2) and np.array_equal(idx, i2)
+
+
+@pytest.mark.parametrize("kind", ["few_valued", "partial_dct", "one_magnitude", "common_component"])
+def test_batched_int8_screen_structured_dictionaries(cs, oracle, kind):
+    M, N, nsig = 512, 4096, 200
+    rng = np.random.default_rng(515 + len(kind))
+    A = cs.structured_dictionary(kind, M, N, rng=rng)
+    A64 = A.astype(np.float64)
+    d = cs.Dictionary(A)
+    for family, k in (("pm1", 16), ("neartie", 4)):
+        B = np.empty((M, nsig), order="F")
+        for s in range(nsig):
+            sup = rng.choice(N, size=k, replace=False)
+            x = rng.choice(np.array([-1.0, 1.0]), size=k)
+            if family == "neartie":
+                x = x * (1.0 + 2e-3 * rng.random(k))
+            B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
+        i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
+        d.ctx.set_option("batch_screen", 1)
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
+        st = d.ctx.batch_stats()
+        d.ctx.set_option("batch_screen", 0)
+        print(kind, family, "int8 screen batch_stats:", st)
+        assert np.array_equal(nnz, n2), (kind, family)
+        assert np.array_equal(idx, i2), (kind, family, int((idx != i2).any(axis=0).sum()))
+        assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
+    d.close()

@@ -63,6 +63,13 @@ if which & {"c2", "c3"}:
             ref = oc.omp(A, B[s].cpu().numpy(), 256, EPS32)
             ok, rel = same(idx[s, :int(nnz[s])].cpu().numpy(), val[s, :int(nnz[s])].cpu().numpy(), ref[0], ref[1])
             report("configs[1] omp_batch (k_tick pipeline) k=256, signal %d" % s, ok, max_rel_coef_err=rel)
+        D.ctx.set_option("screened_sweep", 1)  # the screened single-signal sweep: every atom of signal 0 against the oracle
+        got = D.ctx.omp(B[0].cpu().numpy(), 256, EPS32)
+        ref = oc.omp(A, B[0].cpu().numpy(), 256, EPS32)
+        ok, rel = same(got[0], got[1], ref[0], ref[1])
+        report("configs[1] omp k=256 with the screened sweep (bf16 image, certified picks)", ok and np.array_equal(got[2], ref[2]), max_rel_coef_err=rel,
+               stats=D.ctx.screened_stats())
+        D.ctx.set_option("screened_sweep", 0)
         # forward regression at the same size, 64 atoms
         y = B[0].cpu().numpy()
         ref = oc.fr(A, y, 64)
@@ -74,9 +81,11 @@ if which & {"c2", "c3"}:
         B = bench.make_signals_fast(torch, dev, At, 7000, nsig, k).reshape(nsig, bench.M)
         sample = [0, 255, 256, 511, 777, 1023]
         refs = {s: oc.omp(A, B[s].cpu().numpy(), k, EPS32) for s in sample}
-        for name, cert, gram in (("statistical certificate", 0, 0), ("rigorous certificate", 1, 0), ("resident Gram matrix", 0, 1)):
+        for name, cert, gram, scr in (("statistical certificate", 0, 0, 0), ("rigorous certificate", 1, 0, 0), ("resident Gram matrix", 0, 1, 0),
+                                      ("int8 screen", 0, 0, 1), ("int8 screen + resident Gram matrix", 0, 1, 1)):
             D.ctx.set_option("batch_cert", cert)
             D.ctx.set_option("batch_gram", gram)
+            D.ctx.set_option("batch_screen", scr)
             idx = torch.full((nsig, k), -1, dtype=torch.int64, device=dev)
             val = torch.zeros((nsig, k), dtype=torch.float64, device=dev)
             nnz = torch.zeros(nsig, dtype=torch.int64, device=dev)
@@ -92,6 +101,7 @@ if which & {"c2", "c3"}:
                    uncertain=st["uncertain"], illcond=st["illcond"])
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
+        D.ctx.set_option("batch_screen", 0)
     D.close()
     del At, A
 
@@ -111,6 +121,12 @@ if "c5" in which:  # configs[4]: 8192 x 131072, k = 512: GOMP S = 4 and Subspace
     ok, rel = same(got[0], got[1], ref[0], ref[1])
     report("configs[4] gomp S=4 k=512: support, selection order, coefficients", ok and np.array_equal(got[2], ref[2]), atoms=len(ref[0]),
            max_rel_coef_err=rel, oracle_seconds=round(t1 - t0, 1))
+    D5.ctx.set_option("screened_sweep", 1)
+    got = D5.ctx.gomp(y, 4, k, EPS32)
+    ok, rel = same(got[0], got[1], ref[0], ref[1])
+    report("configs[4] gomp S=4 k=512 with the screened sweep (certified top-S picks)", ok and np.array_equal(got[2], ref[2]), max_rel_coef_err=rel,
+           stats=D5.ctx.screened_stats())
+    D5.ctx.set_option("screened_sweep", 0)
     bi, bv, bn = D5.ctx.gomp_batch(np.asfortranarray(np.stack([y, -y], axis=1)), 4, k, EPS32)
     ok, rel = same(bi[:bn[0], 0], bv[:bn[0], 0], ref[0], ref[1])
     ok2, rel2 = same(bi[:bn[1], 1], -bv[:bn[1], 1], ref[0], ref[1])

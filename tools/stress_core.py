@@ -64,16 +64,18 @@ while time.time() - t0 < budget:
         idx, val, nnz = D.ctx.omp_batch(B, k, eps)
         for s in range(nsig):
             cmp("omp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
-        for cert, gram, name in ((0, 0, "omp_mfma"), (1, 0, "omp_mfma_rigorous"), (0, 1, "omp_mfma_gram")):
+        for cert, gram, name in ((0, 0, "omp_mfma"), (1, 0, "omp_mfma_rigorous"), (0, 1, "omp_mfma_gram"), (0, 0, "omp_mfma_int8"), (0, 1, "omp_mfma_int8_gram")):
             if gram and N > 8000:
                 continue
             D.ctx.set_option("batch_cert", cert)
             D.ctx.set_option("batch_gram", gram)
+            D.ctx.set_option("batch_screen", 1 if "int8" in name else 0)
             idx, val, nnz = D.ctx.omp_batch_mfma(B, k, eps)
             for s in range(nsig):
                 cmp(name, (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
+        D.ctx.set_option("batch_screen", 0)
         for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
             D.ctx.set_option("batch_cert", cert)
             D.ctx.set_option("screened_sweep", 1)
