@@ -96,7 +96,8 @@ def parse():
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--batch-screen", choices=["bf16", "int8"], default="bf16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM)")
-    p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single: CSMP_OPT_SCREENED_SWEEP (bf16 sweeps, certified top-S picks)")
+    p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified top-S picks)")
+    p.add_argument("--screen-image", choices=["bf16", "int8"], default="bf16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 1 / 2)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -323,7 +324,7 @@ def measure_lone_omp(K, W, B, D, eps):
                                  "stages, kernel boundaries, back substitution, download) -- not a kernel duration"}}
 
 
-def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0):
+def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0, image=1):
     """configs[1] with the screened sweep (CSMP_OPT_SCREENED_SWEEP): every sweep reads the bf16 image (M N 2 bytes) and the
     pick is certified against the f32 dictionary in Float64, an uncertified solve repeated exactly -- the results are the exact
     path's, and this function checks that on every timed signal.  Two forms: one csmp_omp call at a time, and csmp_omp_batch
@@ -334,10 +335,13 @@ def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0):
     sigs = [B[s].cpu().numpy() for s in range(W + K)]
     D.ctx.set_option("screened_sweep", 0)
     exact = [D.ctx.omp(sigs[s], K_ATOMS, eps) for s in range(W, W + K)]
+    if image == 2:
+        cert = 0  # (the int8 image has the statistical bound only)
     D.ctx.set_option("batch_cert", cert)
-    D.ctx.set_option("screened_sweep", 1)
-    out = {"metric": "OMP atoms selected/sec at m=4096,n=65536,k=256, screened sweep (bf16 image, certified picks, exact results)",
-           "unit": "atoms/s", "certificate": "rigorous" if cert else "statistical", "steps": K, "warmup": W}
+    D.ctx.set_option("screened_sweep", image)  # 1: bf16 image, 2: int8 image
+    iname, ibytes = ("int8", 1) if image == 2 else ("bf16", 2)
+    out = {"metric": "OMP atoms selected/sec at m=4096,n=65536,k=256, screened sweep (%s image, certified picks, exact results)" % iname,
+           "unit": "atoms/s", "certificate": "rigorous" if cert else "statistical", "image": iname, "steps": K, "warmup": W}
     try:
         for w in range(W):
             D.ctx.omp(sigs[w], K_ATOMS, eps)
@@ -375,13 +379,13 @@ def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0):
         out["ms_per_step"] = dt / K * 1e3
         out["batch"] = {"value": atoms / dt, "us_per_atom": dt / max(atoms, 1) * 1e6, "equals_exact_path": bool(same),
                         "signals_in_flight": 2, "stats": D.ctx.screened_stats(reset=True)}
-        alg = M * N * 2  # the bf16 image, streamed once per atom
+        alg = M * N * ibytes  # the image, streamed once per atom
         out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": alg / avg / 1e9 if sweeps else 0.0,
                            "frac": alg / avg / 1e9 / HBM_PEAK_GBS if sweeps else 0.0, "traffic": None,
-                           "kernel": "csmp::k_sweep_bf16<2,3,true> (while the other solve's pick / append stages run beside it)",
+                           "kernel": "csmp::k_sweep_%s<2,3,true> (while the other solve's pick / append stages run beside it)" % ("i8" if image == 2 else "bf16"),
                            "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg,
                            "f32_equivalent_frac_all_in": M * N * 4 / (dt / max(atoms, 1)) / 1e9 / HBM_PEAK_GBS,
-                           "note": "algorithmic bytes of THIS path are M N 2 (bf16 image); f32_equivalent_frac_all_in prices the whole "
+                           "note": "algorithmic bytes of THIS path are M N x the image's element size; f32_equivalent_frac_all_in prices the whole "
                                    "batch's time per atom against the exact path's M N 4 bytes -- above 1 means faster than any exact sweep can be"}
     finally:
         D.ctx.set_option("screened_sweep", 0)
@@ -408,10 +412,10 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         sigs.append(((At5[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
     torch.cuda.synchronize()
     eps = D5.eps
-    screened = screened and workload in ("gomp", "gomp_single")
+    screened = int(screened) if workload in ("gomp", "gomp_single") else 0
     if screened:
         exact0 = D5.ctx.gomp(sigs[W], S, k, eps)
-        D5.ctx.set_option("screened_sweep", 1)
+        D5.ctx.set_option("screened_sweep", int(screened))  # 1: bf16 image, 2: int8 image
         D5.ctx.screened_stats(reset=True)
 
     def solve(b):
@@ -469,7 +473,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         dt = time.perf_counter() - t0
         sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
         D5.ctx.profile_enable(False)
-    alg = M5 * N5 * (2 if screened else 4)
+    alg = M5 * N5 * ({1: 2, 2: 1}[int(screened)] if screened else 4)
     avg = sweep_ms / max(sweeps, 1) / 1e3
     isg = workload in ("gomp", "gomp_single")
     out = {"metric": ("GOMP (S=4) atoms selected/sec" + (", two solves in flight (csmp_gomp_batch)" if workload == "gomp" else ", one gomp call at a time")
@@ -486,14 +490,14 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     if isg:  # the whole solve against the same roofline: one dictionary pass per S atoms is all the algorithm needs
         out["roofline"]["whole_solve"] = {"achieved": alg / S * atoms / dt / 1e9, "frac": alg / S * atoms / dt / 1e9 / HBM_PEAK_GBS,
-                                          "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % (2 if screened else 4)}
+                                          "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % ({1: 2, 2: 1}[int(screened)] if screened else 4)}
     if screened:
         import numpy as np
         got0 = D5.ctx.gomp(sigs[W], S, k, eps)
         st_ = D5.ctx.screened_stats(reset=True)
         D5.ctx.set_option("screened_sweep", 0)
-        out["metric"] += ", screened sweep (bf16 image, certified top-S picks, exact results)"
-        out["roofline"]["kernel"] = "csmp::k_sweep_bf16<2,3,true> (M*N*2 bytes per sweep)"
+        out["metric"] += ", screened sweep (%s image, certified top-S picks, exact results)" % ("int8" if int(screened) == 2 else "bf16")
+        out["roofline"]["kernel"] = "csmp::k_sweep_i8<2,3,true> (M*N bytes per sweep)" if int(screened) == 2 else "csmp::k_sweep_bf16<2,3,true> (M*N*2 bytes per sweep)"
         out["screened"] = {"stats": st_, "first_timed_solve_equals_exact_path": bool(
             np.array_equal(got0[0], exact0[0]) and np.array_equal(got0[2], exact0[2]) and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12)),
             "f32_equivalent_frac_all_in": M5 * N5 * 4 / S * atoms / dt / 1e9 / HBM_PEAK_GBS}
@@ -505,7 +509,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         r["achieved"], r["frac"] = r["whole_solve"]["achieved"], r["whole_solve"]["frac"]
         r["note"] = ("achieved / frac = ALL-IN (M*N*%d bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
                      "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)"
-                     % (2 if screened else 4))
+                     % ({1: 2, 2: 1}[int(screened)] if screened else 4))
     if workload == "sp":
         r = out["roofline"]  # (as for gomp: overlapping solves share the HBM, a per-launch duration measures the sharing)
         r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
@@ -788,7 +792,8 @@ def main():
             At5, D5 = make_dictionary5(cs, torch, dev)
             if args.in_flight:
                 D5.ctx.set_option("solves_in_flight", args.in_flight)
-            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5, screened=args.screened)), flush=True)
+            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5,
+                                                  screened=(2 if args.screen_image == "int8" else 1) if args.screened else 0)), flush=True)
             D5.close()
         return finish()
     At = make_dictionary(torch, dev)
@@ -805,7 +810,7 @@ def main():
             args.steps, args.warmup = 8, 2
         if rank == 0:
             print(json.dumps(measure_screened_omp(args.steps, args.warmup, torch, dev, At, D, D.eps,
-                                                  cert=1 if args.batch_cert == "rigorous" else 0)), flush=True)
+                                                  cert=1 if args.batch_cert == "rigorous" else 0, image=2 if args.screen_image == "int8" else 1)), flush=True)
         D.close()
         return finish()
     if args.workload == "batched":
@@ -922,6 +927,7 @@ def main():
                 sec["lone_omp_c2"] = {"error": repr(e)}
             try:  # opt-in: sweeps over the bf16 image with certified picks (same results, half the bytes)
                 sec["omp_c2_screened"] = measure_screened_omp(6, 2, torch, dev, At, D, eps)
+                sec["omp_c2_screened_int8"] = measure_screened_omp(6, 2, torch, dev, At, D, eps, image=2)
             except Exception as e:  # noqa: BLE001
                 sec["omp_c2_screened"] = {"error": repr(e)}
             for name, cert, gram, scr in (("batched_c3", 0, 0, 0), ("batched_c3_rigorous", 1, 0, 0), ("batched_c3_gram", 0, 1, 0),
@@ -946,7 +952,8 @@ def main():
                 At5, D5 = make_dictionary5(cs, torch, dev)
                 sec["gomp_c5"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5)
                 sec["gomp_c5_single"] = measure_config5("gomp_single", 2, 1, cs, torch, dev, D5, At5)
-                sec["gomp_c5_screened"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=True)
+                sec["gomp_c5_screened"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=1)
+                sec["gomp_c5_screened_int8"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=2)
                 sec["sp_c5"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5)
                 sec["sp_c5_single"] = measure_config5("sp_single", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5_default_delta"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, delta=1e-12)

@@ -43,7 +43,7 @@ struct DevState {
     double rnorm2;  // ||r||^2 seen by the last sweep prologue
     double cval;    // signed <a_cand, r> (MP coefficient, src/matchingpursuit.jl:29)
     int uncertain;  // screened sweep (csmp_screened.hpp): steps whose pick could not be certified
-    int pad_;
+    float rstep;    // int8 screened sweep: the quantisation step of the residual image of the last sweep
 };
 
 using f32x4 = float __attribute__((ext_vector_type(4)));

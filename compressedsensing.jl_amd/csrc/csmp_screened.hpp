@@ -26,7 +26,8 @@
 
 namespace csmp {
 
-constexpr int kScrCand = 4;  // candidates kept per sweep workgroup
+constexpr int kScrCand = 8;  // candidates kept per sweep workgroup (its LAST one bounds every atom it did not list: with 4, a workgroup
+                             // that happened to hold four atoms of a 60-atom GOMP window failed the certificate once per few solves)
 
 // LDS image of the residual as f32 for the bf16 sweep: lane l of chunk t (512 rows) multiplies rows 8 (64 t + l) .. + 7;
 // two planes of four floats so that consecutive lanes read consecutive 16-byte slots (conflict-free ds_read_b128)
@@ -73,23 +74,38 @@ __device__ __forceinline__ float row16_sum(float v) {
 // FULL: Mk is a multiple of 512 U (every item is U whole chunks): no guard anywhere in the stream.  Otherwise the loads of a
 // partial item are clamped into the column and meet zeros in the residual image (rows >= Mk >= M), chunks beyond the column
 // are skipped (wave-uniform).  The image has Npad >= N columns (zeros): a group never leaves it; columns >= N are not listed.
-template <int U, int D, bool FULL, int C = kScrCols>
-__global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
-                                                              const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
-                                                              int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
-                                                              int skipmask, unsigned* __restrict__ tickets) {
-    extern __shared__ __attribute__((aligned(16))) float rimgf[];  // nchunk * 512 floats | reduction scratch
+__device__ __forceinline__ int row16_sum(int v) {  // the same for the int8 sweep's exact integer sums
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    return v;
+}
+
+// I8 = true: the same stream over the INT8 image (csmp_batched.hpp: k_b_convert_i8, one step `astep` for the dictionary): a
+// 16-byte load is 16 elements, a chunk 1024 rows; the residual is quantised in the prologue under its own step (max|r_i| / 127,
+// one workgroup maximum), kept as int8 in LDS (4 KiB at M = 4096), multiplied with v_dot4c_i32_i8 -- four exact integer
+// multiply-adds per instruction -- and the candidate values are |integer sum| * astep * rstep.  Mk counts the image's
+// elements per row (bf16: 2 bytes each, int8: 1).
+template <int U, int D, bool FULL, int C, bool I8>
+__device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int Mk, int64_t N, const double* __restrict__ r, int Mr,
+                                               float* __restrict__ cand_val, int* __restrict__ cand_idx, DevState* st, double eps,
+                                               int check_eps, int skipmask, unsigned* __restrict__ tickets, float astep, char* smem) {
     constexpr int NW = kSweepThreads / kWave;
     static_assert(C == 2 || C == 4, "two or four columns side by side");
     constexpr int NL = NW * (kWave / 16);  // lists per workgroup (one per 16-lane row)
+    constexpr int EV = I8 ? 16 : 8;        // elements per 16-byte load
+    constexpr int CH = kWave * EV;         // rows per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
     CSMP_TRACE(0);
     if (st->done & skipmask) return;
     CSMP_TRACE(1);
-    const int nchunk = (Mk + 511) / 512;
-    const int Ml = nchunk * 512;
+    const int nchunk = (Mk + CH - 1) / CH;
+    const int Ml = nchunk * CH;
+    const int64_t RB = (int64_t)Mk * (I8 ? 1 : 2);  // bytes per image row
     using V = bf16x8;
+    using i32x4 = int __attribute__((ext_vector_type(4)));
     const int nblocks = (nchunk + U - 1) / U;
     const int64_t ngroups = (N + C - 1) / C;
     // partition (see above): NP of them, WPP workgroups each (the host launches a multiple of 8 workgroups, or fewer than 8)
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     V buf[D][U][C];
     int sg[D];                       // group of the item in ring slot d (-1: none -- the stream has ended)
     int lg = g0 < ngroups ? (int)g0 : -1;  // group of the next item to load
-    const __bf16* lp = Ab + g0 * C * Mk;
+    const char* lp = Ab + g0 * C * RB;
     int lb = 0;                      // its block
     unsigned tk = 0;                 // lane 0: the ticket for the group after `lg`
     if (lg >= 0 && lane == 0) tk = atomicAdd(ticket, 1u);
@@ -129,9 +145,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
             for (int u = 0; u < U; ++u) {
                 const int t = lb * U + u;
                 if (FULL || t < nchunk) {
-                    const int off = FULL ? t * 64 + lane : min(t * 64 + lane, Mk / 8 - 1);
+                    const int off = FULL ? t * 64 + lane : min(t * 64 + lane, Mk / EV - 1);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) dst[u][c] = __builtin_nontemporal_load(reinterpret_cast<const V*>(lp + (int64_t)c * Mk) + off);
+                    for (int c = 0; c < C; ++c) dst[u][c] = __builtin_nontemporal_load(reinterpret_cast<const V*>(lp + (int64_t)c * RB) + off);
                 }
             }
             if (++lb == nblocks) {  // the following group: the ticket asked for a group ago, and the next request
@@ -139,7 +155,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                 const int64_t g = ((int64_t)WPP * NW + (int64_t)__builtin_amdgcn_readfirstlane((int)tk)) * NP + part;
                 lg = g < ngroups ? (int)g : -1;
                 if (lg >= 0) {
-                    lp = Ab + g * C * Mk;
+                    lp = Ab + g * C * RB;
                     if (lane == 0) tk = atomicAdd(ticket, 1u);
                 }
             }
@@ -147,23 +163,31 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     };
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) load_next(buf[d], sg[d]);
-    double* red = reinterpret_cast<double*>(rimgf + Ml);  // 8 doubles
-    float* wlv = reinterpret_cast<float*>(red + 8);        // [NL][4]
+    float* rimgf = reinterpret_cast<float*>(smem);                    // bf16 sweep: Ml floats
+    signed char* rimg8 = reinterpret_cast<signed char*>(smem);        // int8 sweep: Ml bytes
+    double* red = reinterpret_cast<double*>(smem + (size_t)Ml * (I8 ? 1 : 4));  // 8 doubles (the last four: the maxima, as floats)
+    float* wlv = reinterpret_cast<float*>(red + 8);                   // [NL][4]
     int* wli = reinterpret_cast<int*>(wlv + NL * kScrCand);
-    // residual: Float64 norm (fixed order) and the f32 image
+    // residual: Float64 norm (fixed order), and its image -- f32, or (int8 sweep) the largest magnitude first
     double n2 = 0.0;
+    float amax = 0.0f;
+    const bool onepass = Ml <= 4 * kSweepThreads * PR;
     for (int base = 0; base < Ml; base += 4 * kSweepThreads * PR) {
         if (base > 0) r_issue(base);
 #pragma unroll
         for (int p = 0; p < PR; ++p) {
             const int m0 = base + (p * kSweepThreads + tid) * 4;
             if (m0 < Ml) {
-                f32x4 f;
-                f.x = (float)rlo[p].x;
-                f.y = (float)rlo[p].y;
-                f.z = (float)rhi[p].x;
-                f.w = (float)rhi[p].y;
-                *reinterpret_cast<f32x4*>(rimgf + rf_slot(m0)) = f;
+                if constexpr (!I8) {
+                    f32x4 f;
+                    f.x = (float)rlo[p].x;
+                    f.y = (float)rlo[p].y;
+                    f.z = (float)rhi[p].x;
+                    f.w = (float)rhi[p].y;
+                    *reinterpret_cast<f32x4*>(rimgf + rf_slot(m0)) = f;
+                } else {
+                    amax = fmaxf(fmaxf(amax, fmaxf(fabsf((float)rlo[p].x), fabsf((float)rlo[p].y))), fmaxf(fabsf((float)rhi[p].x), fabsf((float)rhi[p].y)));
+                }
                 n2 = fma(rlo[p].x, rlo[p].x, n2);
                 n2 = fma(rlo[p].y, rlo[p].y, n2);
                 n2 = fma(rhi[p].x, rhi[p].x, n2);
@@ -174,10 +198,36 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     CSMP_TRACE(5);
     // sum over the workgroup in a fixed order; barriers that order LDS only (a __syncthreads would drain the prefetch)
     for (int sft = 32; sft >= 1; sft >>= 1) n2 += __shfl_xor(n2, sft, kWave);
-    if (lane == 0) red[wave] = n2;
+    if constexpr (I8)
+        for (int sft = 32; sft >= 1; sft >>= 1) amax = fmaxf(amax, __shfl_xor(amax, sft, kWave));
+    if (lane == 0) {
+        red[wave] = n2;
+        if constexpr (I8) reinterpret_cast<float*>(red + 4)[wave] = amax;
+    }
     CSMP_TRACE(6);
     lds_barrier();
     n2 = (red[0] + red[1]) + (red[2] + red[3]);
+    float scale = 1.0f;
+    if constexpr (I8) {
+        const float* fm = reinterpret_cast<const float*>(red + 4);
+        const float rstep = i8_step(fmaxf(fmaxf(fm[0], fm[1]), fmaxf(fm[2], fm[3])));
+        const float inv = 1.0f / rstep;
+        scale = astep * rstep * (1.0f + 0x1p-20f);
+        if (bid == 0 && tid == 0) st->rstep = rstep;
+        for (int base = 0; base < Ml; base += 4 * kSweepThreads * PR) {
+            if (!onepass) r_issue(base);  // (one pass: the registers still hold it)
+#pragma unroll
+            for (int p = 0; p < PR; ++p) {
+                const int m0 = base + (p * kSweepThreads + tid) * 4;
+                if (m0 < Ml) {
+                    const int q0 = max(-127, min(127, __float2int_rn((float)rlo[p].x * inv))), q1 = max(-127, min(127, __float2int_rn((float)rlo[p].y * inv)));
+                    const int q2 = max(-127, min(127, __float2int_rn((float)rhi[p].x * inv))), q3 = max(-127, min(127, __float2int_rn((float)rhi[p].y * inv)));
+                    *reinterpret_cast<int*>(rimg8 + m0) = (q0 & 0xff) | ((q1 & 0xff) << 8) | ((q2 & 0xff) << 16) | ((q3 & 0xff) << 24);
+                }
+            }
+        }
+        lds_barrier();
+    }
     if (bid == 0 && tid == 0) st->rnorm2 = n2;
     if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break (src/matchingpursuit.jl:79)
         if (bid == 0 && tid == 0) st->done |= STOP_EPS;
@@ -185,6 +235,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     }
     CSMP_TRACE(2);
     const f32x4* rs = reinterpret_cast<const f32x4*>(rimgf);
+    const i32x4* rs8 = reinterpret_cast<const i32x4*>(rimg8);
     float tv[kScrCand];
     int ti[kScrCand];
 #pragma unroll
@@ -193,10 +244,39 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
         ti[q] = 0x7fffffff;
     }
     float acc0[C], acc1[C];
+    int acci[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) acc0[c] = acc1[c] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        acc0[c] = acc1[c] = 0.0f;
+        acci[c] = 0;
+    }
     int cb = 0;  // block of the item being multiplied
     bool alive = true;
+    // transposing butterfly over the C column sums of the lanes: row = lane / 16 ends with the sum of column row (C = 4) / row / 2
+    auto butterfly = [&](auto (&a)[C]) {
+        auto s0 = a[0];
+        if constexpr (C == 4) {
+            decltype(s0) s1;
+            {
+                const bool hi = lane & 32;
+                const auto k0 = hi ? a[2] : a[0], k1 = hi ? a[3] : a[1];
+                const auto h0 = hi ? a[0] : a[2], h1 = hi ? a[1] : a[3];
+                s0 = k0 + __shfl_xor(h0, 32, kWave);
+                s1 = k1 + __shfl_xor(h1, 32, kWave);
+            }
+            {
+                const bool hi = lane & 16;
+                const auto k = hi ? s1 : s0, h = hi ? s0 : s1;
+                s0 = k + __shfl_xor(h, 16, kWave);
+            }
+        } else {  // two columns: a 32-lane half each (its second row lists nothing)
+            const bool hi = lane & 32;
+            const auto k = hi ? a[1] : a[0], h = hi ? a[0] : a[1];
+            s0 = k + __shfl_xor(h, 32, kWave);
+            s0 += __shfl_xor(s0, 16, kWave);
+        }
+        return row16_sum(s0);
+    };
     while (alive) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -206,53 +286,52 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                 for (int u = 0; u < U; ++u) {
                     const int t = cb * U + u;
                     if (FULL || t < nchunk) {
-                        const f32x4 r0 = rs[(t * 2 + 0) * kWave + lane], r1 = rs[(t * 2 + 1) * kWave + lane];
+                        if constexpr (I8) {
+                            const i32x4 rr = rs8[t * kWave + lane];
 #pragma unroll
-                        for (int c = 0; c < C; ++c) {
-                            const V a = buf[d][u][c];
-                            acc0[c] = fmaf((float)a[0], r0.x, acc0[c]);
-                            acc1[c] = fmaf((float)a[1], r0.y, acc1[c]);
-                            acc0[c] = fmaf((float)a[2], r0.z, acc0[c]);
-                            acc1[c] = fmaf((float)a[3], r0.w, acc1[c]);
-                            acc0[c] = fmaf((float)a[4], r1.x, acc0[c]);
-                            acc1[c] = fmaf((float)a[5], r1.y, acc1[c]);
-                            acc0[c] = fmaf((float)a[6], r1.z, acc0[c]);
-                            acc1[c] = fmaf((float)a[7], r1.w, acc1[c]);
+                            for (int c = 0; c < C; ++c) {
+                                const i32x4 a = __builtin_bit_cast(i32x4, buf[d][u][c]);
+                                acci[c] = __builtin_amdgcn_sdot4(a.x, rr.x, acci[c], false);
+                                acci[c] = __builtin_amdgcn_sdot4(a.y, rr.y, acci[c], false);
+                                acci[c] = __builtin_amdgcn_sdot4(a.z, rr.z, acci[c], false);
+                                acci[c] = __builtin_amdgcn_sdot4(a.w, rr.w, acci[c], false);
+                            }
+                        } else {
+                            const f32x4 r0 = rs[(t * 2 + 0) * kWave + lane], r1 = rs[(t * 2 + 1) * kWave + lane];
+#pragma unroll
+                            for (int c = 0; c < C; ++c) {
+                                const V a = buf[d][u][c];
+                                acc0[c] = fmaf((float)a[0], r0.x, acc0[c]);
+                                acc1[c] = fmaf((float)a[1], r0.y, acc1[c]);
+                                acc0[c] = fmaf((float)a[2], r0.z, acc0[c]);
+                                acc1[c] = fmaf((float)a[3], r0.w, acc1[c]);
+                                acc0[c] = fmaf((float)a[4], r1.x, acc0[c]);
+                                acc1[c] = fmaf((float)a[5], r1.y, acc1[c]);
+                                acc0[c] = fmaf((float)a[6], r1.z, acc0[c]);
+                                acc1[c] = fmaf((float)a[7], r1.w, acc1[c]);
+                            }
                         }
                     }
                 }
-                if (++cb == nblocks) {  // the group is complete: transposing butterfly, row r = lane / 16 ends with column r's sum
+                if (++cb == nblocks) {  // the group is complete
                     cb = 0;
-                    float a[C];
+                    float vabs;
+                    if constexpr (I8) {
+                        const int si = butterfly(acci);
 #pragma unroll
-                    for (int c = 0; c < C; ++c) {
-                        a[c] = acc0[c] + acc1[c];
-                        acc0[c] = acc1[c] = 0.0f;
-                    }
-                    float s0;
-                    if constexpr (C == 4) {
-                        float s1;
-                        {
-                            const bool hi = lane & 32;
-                            const float k0 = hi ? a[2] : a[0], k1 = hi ? a[3] : a[1];
-                            const float h0 = hi ? a[0] : a[2], h1 = hi ? a[1] : a[3];
-                            s0 = k0 + __shfl_xor(h0, 32, kWave);
-                            s1 = k1 + __shfl_xor(h1, 32, kWave);
+                        for (int c = 0; c < C; ++c) acci[c] = 0;
+                        vabs = (float)abs(si) * scale;
+                    } else {
+                        float a[C];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            a[c] = acc0[c] + acc1[c];
+                            acc0[c] = acc1[c] = 0.0f;
                         }
-                        {
-                            const bool hi = lane & 16;
-                            const float k = hi ? s1 : s0, h = hi ? s0 : s1;
-                            s0 = k + __shfl_xor(h, 16, kWave);
-                        }
-                    } else {  // two columns: a 32-lane half each (its second row lists nothing)
-                        const bool hi = lane & 32;
-                        const float k = hi ? a[1] : a[0], h = hi ? a[0] : a[1];
-                        s0 = k + __shfl_xor(h, 32, kWave);
-                        s0 += __shfl_xor(s0, 16, kWave);
+                        vabs = fabsf(butterfly(a));
                     }
-                    s0 = row16_sum(s0);
                     const int64_t col = (int64_t)sg[d] * C + (C == 4 ? (lane >> 4) : (lane >> 5));
-                    float v = col < N && (C == 4 || !(lane & 16)) ? fabsf(s0) : -1.0f;
+                    float v = col < N && (C == 4 || !(lane & 16)) ? vabs : -1.0f;
                     int i = (int)col;
                     // the row's running 4 largest (every lane of the row holds the same list); an equal value: the lower index
 #pragma unroll
@@ -281,14 +360,13 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
         }
     }
     __syncthreads();
-    if (tid < NL * kScrCand) {  // 64 entries, one per lane of wave 0: an entry's rank in (value desc, index asc, slot asc) is its place
-        static_assert(NL * kScrCand == kWave, "one wave ranks the workgroup's lists");
+    if (tid < NL * kScrCand) {  // one entry per thread: an entry's rank in (value desc, index asc, slot asc) is its place
+        static_assert(NL * kScrCand <= kSweepThreads && kScrCand % 4 == 0, "the workgroup ranks its lists in one go");
         const float v = wlv[tid];
         const int i = wli[tid];
         int rank = 0;
-        using i32x4 = int __attribute__((ext_vector_type(4)));
 #pragma unroll
-        for (int e4 = 0; e4 < NL; ++e4) {  // (broadcast reads, all issued before the first compare: the rolled loop cost 3.5 us)
+        for (int e4 = 0; e4 < NL * kScrCand / 4; ++e4) {  // (broadcast reads, all issued before the first compare: the rolled loop cost 3.5 us)
             const f32x4 ve = reinterpret_cast<const f32x4*>(wlv)[e4];
             const i32x4 ie = reinterpret_cast<const i32x4*>(wli)[e4];
 #pragma unroll
@@ -304,10 +382,61 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
     }
     CSMP_TRACE(4);
 }
+template <int U, int D, bool FULL, int C = kScrCols>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
+                                                              const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
+                                                              int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
+                                                              int skipmask, unsigned* __restrict__ tickets) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sweep[];  // the residual image | reduction scratch | the lists
+    sweep_img_body<U, D, FULL, C, false>(reinterpret_cast<const char*>(Ab), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+                                         0.0f, smem_sweep);
+}
+template <int U, int D, bool FULL, int C = kScrCols>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_i8(const signed char* __restrict__ A8, int Mk8, int64_t N,
+                                                            const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
+                                                            int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
+                                                            int skipmask, unsigned* __restrict__ tickets, float astep) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sweep[];
+    sweep_img_body<U, D, FULL, C, true>(reinterpret_cast<const char*>(A8), Mk8, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+                                        astep, smem_sweep);
+}
+inline size_t sweep_i8_lds_bytes(int Mk8) {
+    const int nchunk = (Mk8 + 1023) / 1024;
+    return (size_t)nchunk * 1024 + 8 * sizeof(double) + (kSweepThreads / 16) * kScrCand * 8 + 64;
+}
 inline size_t sweep_bf16_lds_bytes(int Mk) {
     const int nchunk = (Mk + 511) / 512;
     return (size_t)nchunk * 512 * sizeof(float) + 8 * sizeof(double) + (kSweepThreads / 16) * kScrCand * 8 + 64;
 }
+
+// the sweep's candidates of one pick workgroup: thread t holds entries t, t + 256, ... (kPickEpl of them) in registers when all
+// fit, loaded by one unrolled batch; `each` visits (value, atom, entry number) from the registers or, for a larger sweep grid,
+// from memory
+constexpr int kPickEpl = 8;
+struct PickCands {
+    float v[kPickEpl];
+    int i[kPickEpl];
+    bool inreg;
+    __device__ __forceinline__ void load(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand, int tid) {
+        inreg = ncand <= 256 * kPickEpl;
+#pragma unroll
+        for (int e = 0; e < kPickEpl; ++e) {
+            const int t = tid + 256 * e;
+            const bool ok = inreg && t < ncand;
+            v[e] = ok ? cand_val[t] : -1.0f;
+            i[e] = ok ? cand_idx[t] : 0x7fffffff;
+        }
+    }
+    template <typename F>
+    __device__ __forceinline__ void each(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand, int tid, F&& f) const {
+        if (inreg) {
+#pragma unroll
+            for (int e = 0; e < kPickEpl; ++e) f(v[e], i[e], tid + 256 * e);
+        } else {
+            for (int t = tid; t < ncand; t += 256) f(cand_val[t], cand_idx[t], t);
+        }
+    }
+};
 
 // The pick of one signal by ONE workgroup: k_b_pick's window / rescoring / certificate (see there) on the sweep workgroups'
 // candidates; ||r||^2 comes from the sweep's prologue (st->rnorm2).  Publishes (|<a, r>| exact, atom) as pval[0] / pidx[0]: the
@@ -317,7 +446,7 @@ template <typename TA, int U>
 __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, double* __restrict__ pval, int* __restrict__ pidx, double cert_abs, double cert_rel,
-                                               int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts) {
+                                               int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts, double cert_abs2) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
     __shared__ double red[kWinMax];
@@ -342,8 +471,11 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
         *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
     }
     const double n2 = st->rnorm2;
+    // the candidates: one unrolled batch of loads into registers (a rolled loop waits for every load in turn) when they fit
+    PickCands pc;
+    pc.load(cand_val, cand_idx, ncand, tid);
     float m1 = -1.0f;
-    for (int t = tid; t < ncand; t += 256) m1 = fmaxf(m1, cand_val[t]);
+    pc.each(cand_val, cand_idx, ncand, tid, [&](float v, int, int) { m1 = fmaxf(m1, v); });
     for (int sft = 32; sft >= 1; sft >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, sft, kWave));
     if (lane == 0) fsc[wave] = m1;
     __syncthreads();  // (also: cnt = 0 and the residual image are visible)
@@ -355,21 +487,21 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
         }
         return;
     }
-    const double dabs = cert_abs * sqrt(n2);
+    // (int8 sweep: the residual image's own rounding adds cert_abs2 * its step)
+    const double dabs = cert_abs2 > 0.0 ? sqrt(cert_abs * cert_abs * n2 + cert_abs2 * cert_abs2 * (double)st->rstep * (double)st->rstep) : cert_abs * sqrt(n2);
     const double lb1 = (double)m1 - dabs - cert_rel * (double)m1;
     double cb = -1.0;
-    for (int t = tid; t < ncand; t += 256) {
-        const float v = cand_val[t];
-        if (!(v >= 0.0f)) continue;
+    pc.each(cand_val, cand_idx, ncand, tid, [&](float v, int i, int t) {
+        if (!(v >= 0.0f)) return;
         const double ub = (double)v + dabs + cert_rel * (double)v;
         if (ub >= lb1) {
             const int pos = atomicAdd(&cnt, 1);
-            if (pos < kwin) wi_[pos] = cand_idx[t];
+            if (pos < kwin) wi_[pos] = i;
             if ((t & (kScrCand - 1)) == kScrCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a workgroup's last candidate
         } else {
             cb = fmax(cb, ub);
         }
-    }
+    });
     for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
     __syncthreads();
     if (lane == 0) sc[wave] = cb;
@@ -410,7 +542,7 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, int S, int* __restrict__ cands, double* __restrict__ cvals,
                                                int* __restrict__ ncands, double cert_abs, double cert_rel, int kwin, int skipmask,
-                                               unsigned* __restrict__ tickets, int nparts) {
+                                               unsigned* __restrict__ tickets, int nparts, double cert_abs2) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
     __shared__ double red[kWinMax];
@@ -440,19 +572,19 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
     // order (value desc, index asc) -- indices are distinct, so nothing has to be marked
     float pv = __builtin_inff(), mS = -1.0f;
     int pi = -1;
+    PickCands pc;
+    pc.load(cand_val, cand_idx, ncand, tid);
     for (int sidx = 0; sidx < S; ++sidx) {
         float bv = -1.0f;
         int bi = 0x7fffffff;
-        for (int t = tid; t < ncand; t += 256) {
-            const float v = cand_val[t];
-            const int i = cand_idx[t];
-            if (!(v >= 0.0f)) continue;
+        pc.each(cand_val, cand_idx, ncand, tid, [&](float v, int i, int) {
+            if (!(v >= 0.0f)) return;
             const bool after_prev = v < pv || (v == pv && i > pi);
             if (after_prev && (v > bv || (v == bv && i < bi))) {
                 bv = v;
                 bi = i;
             }
-        }
+        });
         for (int sft = 32; sft >= 1; sft >>= 1) {
             const float ov = __shfl_xor(bv, sft, kWave);
             const int oi = __shfl_xor(bi, sft, kWave);
@@ -481,21 +613,21 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
         if (sidx + 1 < S) mS = -1.0f;  // (only the S-th counts; with fewer candidates everything is in the window)
     }
     __syncthreads();
-    const double dabs = cert_abs * sqrt(n2);
+    // (int8 sweep: the residual image's own rounding adds cert_abs2 * its step)
+    const double dabs = cert_abs2 > 0.0 ? sqrt(cert_abs * cert_abs * n2 + cert_abs2 * cert_abs2 * (double)st->rstep * (double)st->rstep) : cert_abs * sqrt(n2);
     const double lbS = mS >= 0.0f ? (double)mS - dabs - cert_rel * (double)mS : -1.0;
     double cb = -1.0;
-    for (int t = tid; t < ncand; t += 256) {
-        const float v = cand_val[t];
-        if (!(v >= 0.0f)) continue;
+    pc.each(cand_val, cand_idx, ncand, tid, [&](float v, int i, int t) {
+        if (!(v >= 0.0f)) return;
         const double ub = (double)v + dabs + cert_rel * (double)v;
         if (ub >= lbS) {
             const int pos = atomicAdd(&cnt, 1);
-            if (pos < kwin) wi_[pos] = cand_idx[t];
+            if (pos < kwin) wi_[pos] = i;
             if ((t & (kScrCand - 1)) == kScrCand - 1) cb = fmax(cb, ub);  // atoms hidden behind a workgroup's last candidate
         } else {
             cb = fmax(cb, ub);
         }
-    }
+    });
     for (int sft = 32; sft >= 1; sft >>= 1) cb = fmax(cb, shx(cb, sft));
     __syncthreads();
     if (lane == 0) sc[wave] = cb;
@@ -519,7 +651,12 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
             cands[rank] = c;
             cvals[rank] = v;
         }
-        if (rank == Seff - 1 && !(nall <= kwin && (cb < 0.0 || (nw >= S && v > cb)))) st->uncertain += 1;
+        if (rank == Seff - 1 && !(nall <= kwin && (cb < 0.0 || (nw >= S && v > cb)))) {
+            st->uncertain += 1;
+#ifdef CSMP_PICK_DEBUG
+            printf("pickS uncertain: nsel %d nall %d kwin %d nw %d S %d vS %.9g cb %.9g mS %.9g dabs %.9g rstep %g n2 %g\n", st->nsel, nall, kwin, nw, S, v, cb, (double)mS, dabs, (double)st->rstep, n2);
+#endif
+        }
     }
     if (tid == 0) {
         *ncands = Seff;

@@ -86,6 +86,7 @@ struct Batch {
     // factor of every signal's integer dot products
     signed char* A8 = nullptr;
     bool a8_valid = false;
+    bool a8_borrowed = false;
     int Mk8 = 0;
     float astep = 0.f;
     signed char* R8 = nullptr;
@@ -140,7 +141,7 @@ struct csmp_ctx {
     int opt_twostage_update = 0;   // CSMP_OPT_TWOSTAGE_UPDATE: 0 explicit inverse, 1 Givens down-date of R, 2 refactorise
     int64_t scr_solves = 0, scr_fallbacks = 0;  // screened solves made / repeated with the exact sweep (csmp_screened_stats)
     int scr_grid = 0;                           // workgroups of k_sweep_bf16
-    double scr_cert_abs = 0.0, scr_cert_rel = 0.0;
+    double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
     int scr_kwin = 0, scr_cert_mode = -1;
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
     int opt_batch_screen = 0;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>)
@@ -225,6 +226,7 @@ struct DevTmp {
 
 // defined in host/batched.hpp and host/screened.hpp (included later); used by the omp drivers
 static int batch_dict(csmp_ctx* ctx);
+static int batch_dict8(csmp_ctx* ctx);
 static int batch_colnorm(csmp_ctx* ctx);
 static int screened_ensure(csmp_ctx* ctx);
 static int twins_ensure(csmp_ctx* ctx, int n);

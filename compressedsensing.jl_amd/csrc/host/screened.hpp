@@ -3,9 +3,20 @@
 
 // bf16 image, certificate coefficients, sweep grid: once per dictionary / option value
 static int screened_ensure(csmp_ctx* ctx) {
-    CHECK(batch_dict(ctx));
+    const bool i8 = ctx->opt_screened == 2;
+    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
     Batch& b = ctx->bt;
-    if (ctx->scr_cert_mode != ctx->opt_batch_cert) {
+    if (i8) {  // int8 image: statistical bound only (see csmp_omp_batch_mfma, host/batched.hpp)
+        if (ctx->scr_cert_mode != 2) {
+            CHECK(batch_colnorm(ctx));
+            ctx->scr_cert_abs = 8.0 * (double)b.astep / std::sqrt(12.0);
+            ctx->scr_cert_abs2 = 8.0 * (double)b.anorm_host / std::sqrt(12.0);
+            ctx->scr_cert_rel = std::ldexp(1.0, -6) + std::ldexp(1.0, -20);
+            ctx->scr_kwin = kWinMax;
+            ctx->scr_cert_mode = 2;
+        }
+    } else if (ctx->scr_cert_mode != ctx->opt_batch_cert) {
+        ctx->scr_cert_abs2 = 0.0;
         // one rounded operand (the residual enters the sweep in f32): the two-operand bounds of the batched path are kept -- conservative
         if (ctx->opt_batch_cert == 1) {
             CHECK(batch_colnorm(ctx));
@@ -40,7 +51,7 @@ static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
                        ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask,
-                       s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1);
+                       s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2);
     return hipGetLastError();
 }
 
@@ -56,7 +67,7 @@ static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
                        ncand, s.st, (const double*)s.r, s.Mpad, S, s.cands, s.cvals, s.ncands, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin,
-                       skipmask, s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1);
+                       skipmask, s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2);
     return hipGetLastError();
 }
 
@@ -64,10 +75,31 @@ static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {
 static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip) {
     Solver& s = ctx->s;
     Batch& b = ctx->bt;
-    const int nchunk = (b.Mk + 511) / 512;
-    const size_t lds = sweep_bf16_lds_bytes(b.Mk);
     const bool timed = prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
+    if (ctx->opt_screened == 2) {  // the int8 image: chunks of 1024 rows
+        const int nchunk = (b.Mk8 + 1023) / 1024;
+        const size_t lds = sweep_i8_lds_bytes(b.Mk8);
+#define CSMP_SCR8(U, DD, FULL)                                                                                                            \
+    {                                                                                                                                     \
+        if (lds > 48 * 1024)                                                                                                              \
+            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_i8<U, DD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+        hipLaunchKernelGGL((k_sweep_i8<U, DD, FULL>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream, (const signed char*)b.A8, \
+                           b.Mk8, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, s.scr_tickets,     \
+                           b.astep);                                                                                                      \
+    }
+        const bool whole = b.Mk8 % 1024 == 0;
+        if (whole && nchunk % 2 == 0) CSMP_SCR8(2, 3, true)
+        else if (whole) CSMP_SCR8(1, 4, true)
+        else if (nchunk >= 2) CSMP_SCR8(2, 3, false)
+        else CSMP_SCR8(1, 4, false)
+#undef CSMP_SCR8
+        HIPCHECK(hipGetLastError());
+        if (timed) CHECK(prof_mark(ctx));
+        return CSMP_OK;
+    }
+    const int nchunk = (b.Mk + 511) / 512;
+    const size_t lds = sweep_bf16_lds_bytes(b.Mk);
 #define CSMP_SCR(U, DD, FULL)                                                                                                             \
     {                                                                                                                                     \
         if (lds > 48 * 1024)                                                                                                              \
@@ -110,7 +142,15 @@ static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_
 // csmp_destroy) and carries its certificate option
 static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
     twin->opt_batch_cert = ctx->opt_batch_cert;
+    twin->opt_screened = ctx->opt_screened;
     CHECK(screened_ensure(ctx));
+    if (ctx->bt.a8_valid && !twin->bt.a8_valid) {
+        Batch &tb = twin->bt, &pb = ctx->bt;
+        tb.A8 = pb.A8;
+        tb.Mk8 = pb.Mk8;
+        tb.astep = pb.astep;
+        tb.a8_valid = tb.a8_borrowed = true;
+    }
     if (!twin->bt.ab_valid) {
         Batch &tb = twin->bt, &pb = ctx->bt;
         tb.Ab = pb.Ab;

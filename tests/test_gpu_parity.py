@@ -1215,7 +1215,7 @@ def test_options_at_the_abi(cs, D):
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
-                     ("solves_in_flight", 0), ("screened_sweep", 2), ("batch_screen", 2)):
+                     ("solves_in_flight", 0), ("screened_sweep", 3), ("batch_screen", 2)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -1672,23 +1672,23 @@ def test_screened_sweep_omp_matches_oracle(cs, oracle, D, shape, dtype):
     A, x, b = cs.sparse_data(n=n, m=m, k=min(k, m), rng=n + m + k, dtype=dtype)
     eps = float(np.finfo(dtype).eps)
     d = D(A)
-    d.ctx.set_option("screened_sweep", 1)
     d.ctx.screened_stats(reset=True)
-    for cert in (0, 1):
+    for image, cert in ((1, 0), (1, 1), (2, 0)):  # bf16 image under both certificates, int8 image (statistical only)
+        d.ctx.set_option("screened_sweep", image)
         d.ctx.set_option("batch_cert", cert)
         for seed, noise in ((0, 0.0), (1, 5e-3), (2, 1e-1)):
             y = cs.perturb(b, noise, rng=seed) if noise else b
             ref = oracle.omp(A, y, k, eps)
             got = d.ctx.omp(y, k, eps)
-            assert np.array_equal(got[0], ref[0]), (cert, seed, got[0], ref[0])
+            assert np.array_equal(got[0], ref[0]), (image, cert, seed, got[0], ref[0])
             assert np.array_equal(got[2], ref[2]), "selection order"
             assert close(got[1], ref[1], tight=False)
     st = d.ctx.screened_stats()
-    assert st["solves"] == 6 and 0 <= st["fallbacks"] <= 6
+    assert st["solves"] == 9 and 0 <= st["fallbacks"] <= 9
     d.ctx.set_option("batch_cert", 0)
     d.ctx.set_option("screened_sweep", 0)
     d.ctx.omp(b, k, eps)
-    assert d.ctx.screened_stats()["solves"] == 6, "option off: the exact sweep"
+    assert d.ctx.screened_stats()["solves"] == 9, "option off: the exact sweep"
 
 
 def test_screened_sweep_certifies_on_gaussian_dictionaries(cs, oracle, D):
@@ -1696,17 +1696,18 @@ def test_screened_sweep_certifies_on_gaussian_dictionaries(cs, oracle, D):
     path that always falls back would be correct and useless."""
     A, x, b = cs.sparse_data(n=1024, m=8192, k=24, rng=77, dtype=np.float32)
     d = D(A)
-    d.ctx.set_option("screened_sweep", 1)
-    d.ctx.screened_stats(reset=True)
-    rng = np.random.default_rng(4)
-    for s in range(8):
-        sup = rng.choice(8192, size=24, replace=False)
-        y = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=24), 5e-3, rng=rng)
-        ref = oracle.omp(A, y, 24, EPS32)
-        got = d.ctx.omp(y, 24, EPS32)
-        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and close(got[1], ref[1], tight=False)
-    st = d.ctx.screened_stats()
-    assert st["solves"] == 8 and st["fallbacks"] <= 1, st
+    for image in (1, 2):
+        d.ctx.set_option("screened_sweep", image)
+        d.ctx.screened_stats(reset=True)
+        rng = np.random.default_rng(4)
+        for s in range(8):
+            sup = rng.choice(8192, size=24, replace=False)
+            y = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=24), 5e-3, rng=rng)
+            ref = oracle.omp(A, y, 24, EPS32)
+            got = d.ctx.omp(y, 24, EPS32)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and close(got[1], ref[1], tight=False)
+        st = d.ctx.screened_stats()
+        assert st["solves"] == 8 and st["fallbacks"] <= 1, (image, st)
     d.ctx.set_option("screened_sweep", 0)
 
 
@@ -1729,8 +1730,8 @@ def test_screened_sweep_structured_dictionaries(cs, oracle, kind):
             B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
         d.ctx.set_option("screened_sweep", 0)
         i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
-        d.ctx.set_option("screened_sweep", 1)
-        for cert in (0, 1):
+        for image, cert in ((1, 0), (1, 1), (2, 0)):
+            d.ctx.set_option("screened_sweep", image)
             d.ctx.set_option("batch_cert", cert)
             idx, val, nnz = d.ctx.omp_batch(B, k, EPS32)  # two screened solves in flight
             assert np.array_equal(nnz, n2) and np.array_equal(idx, i2), (kind, family, cert)
@@ -1806,13 +1807,14 @@ def test_screened_sweep_full_size_config2(cs, oracle):
     d = cs.Dictionary(At, device=0)
     y = B[0].cpu().numpy()
     exact = d.ctx.omp(y, 256, EPS32)
-    d.ctx.set_option("screened_sweep", 1)
-    d.ctx.screened_stats(reset=True)
-    got = d.ctx.omp(y, 256, EPS32)
-    assert np.array_equal(got[0], exact[0]) and np.array_equal(got[2], exact[2])
-    assert np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
-    st = d.ctx.screened_stats()
-    assert st == {"solves": 1, "fallbacks": 0}, st
+    for image in (2, 1):  # the int8 image, then the bf16 image (which the rest of the test keeps)
+        d.ctx.set_option("screened_sweep", image)
+        d.ctx.screened_stats(reset=True)
+        got = d.ctx.omp(y, 256, EPS32)
+        assert np.array_equal(got[0], exact[0]) and np.array_equal(got[2], exact[2]), image
+        assert np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
+        st = d.ctx.screened_stats()
+        assert st == {"solves": 1, "fallbacks": 0}, (image, st)
     A = np.asfortranarray(At.cpu().numpy().T)
     ref = oracle.omp(A, y, 12, EPS32)
     assert np.array_equal(got[2][:12], ref[2])
@@ -1843,7 +1845,8 @@ def test_screened_sweep_gomp_matches_oracle(cs, oracle, D, shape, dtype):
         xs = cs.sparse_vector(m, k, rng=seed)
         ys.append(cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3 if seed else 0.0, rng=seed + 50) if seed else A[:, xs.nzind].astype(np.float64) @ xs.nzval)
     refs = [oracle.gomp(A, y, l, k, eps) for y in ys]
-    for cert in (0, 1):
+    for image, cert in ((1, 0), (1, 1), (2, 0)):
+        d.ctx.set_option("screened_sweep", image)
         d.ctx.set_option("batch_cert", cert)
         for y, ref in zip(ys, refs):
             got = d.ctx.gomp(y, l, k, eps)
@@ -1855,7 +1858,7 @@ def test_screened_sweep_gomp_matches_oracle(cs, oracle, D, shape, dtype):
         for s, ref in enumerate(refs):
             assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (cert, s)
     st = d.ctx.screened_stats()
-    assert st["solves"] == 12 and st["fallbacks"] <= 12
+    assert st["solves"] == 18 and st["fallbacks"] <= 18
     d.ctx.set_option("batch_cert", 0)
     d.ctx.set_option("screened_sweep", 0)
 
@@ -1873,8 +1876,8 @@ def test_screened_sweep_gomp_structured_dictionaries(cs, oracle, kind):
         x = rng.choice(np.array([-1.0, 1.0]), size=k) * (1.0 + (2e-3 * rng.random(k) if s % 2 else 0.0))
         B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
     i2, v2, n2 = d.ctx.gomp_batch(B, l, k, EPS32)
-    d.ctx.set_option("screened_sweep", 1)
-    for cert in (0, 1):
+    for image, cert in ((1, 0), (1, 1), (2, 0)):
+        d.ctx.set_option("screened_sweep", image)
         d.ctx.set_option("batch_cert", cert)
         idx, val, nnz = d.ctx.gomp_batch(B, l, k, EPS32)
         assert np.array_equal(nnz, n2) and np.array_equal(idx, i2), (kind, cert)
@@ -1926,11 +1929,12 @@ def test_screened_sweep_full_size_config5_gomp(cs, oracle):
     e = torch.randn(M5, generator=g, device=dev, dtype=torch.float64)
     y = ((At5[sel].to(torch.float64) * sign[:, None]).sum(0) + e * (5e-3 / e.norm())).cpu().numpy()
     exact = D5.ctx.gomp(y, 4, k, EPS32)
-    D5.ctx.set_option("screened_sweep", 1)
-    D5.ctx.screened_stats(reset=True)
-    got = D5.ctx.gomp(y, 4, k, EPS32)
-    assert np.array_equal(got[2], exact[2]) and np.array_equal(got[0], exact[0]) and np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
-    assert D5.ctx.screened_stats() == {"solves": 1, "fallbacks": 0}
+    for image in (2, 1):
+        D5.ctx.set_option("screened_sweep", image)
+        D5.ctx.screened_stats(reset=True)
+        got = D5.ctx.gomp(y, 4, k, EPS32)
+        assert np.array_equal(got[2], exact[2]) and np.array_equal(got[0], exact[0]) and np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12)
+        assert D5.ctx.screened_stats() == {"solves": 1, "fallbacks": 0}, image
     bi, bv, bn = D5.ctx.gomp_batch(np.asfortranarray(np.stack([y, -y, 0.5 * y], axis=1)), 4, k, EPS32)
     for s in range(3):
         assert bn[s] == len(exact[0]) and np.array_equal(bi[:bn[s], s], exact[0])

@@ -24,7 +24,7 @@ idx = torch.full((nsig, K), -1, dtype=torch.int64, device=dev)
 val = torch.zeros((nsig, K), dtype=torch.float64, device=dev)
 nnz = torch.zeros(nsig, dtype=torch.int64, device=dev)
 res = {}
-for scr in (0, 1):
+for scr in (0, 1, 2):
     D.ctx.set_option("screened_sweep", scr)
     D.ctx.screened_stats(reset=True)
     sigs = [B[s].cpu().numpy() for s in range(nsig + 2)]
@@ -52,6 +52,7 @@ for scr in (0, 1):
     ok = all(np.array_equal(np.sort(idx[s, :int(nnz[s])].cpu().numpy()), np.sort(res[scr][s][0])) for s in range(nsig))
     print(json.dumps({"screened": scr, "form": "csmp_omp_batch", "us_per_atom": dt / atoms * 1e6, "atoms_per_s": atoms / dt,
                       "equals_lone": bool(ok), "stats": D.ctx.screened_stats()}), flush=True)
-same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12) for a, b in zip(res[0], res[1]))
+same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
+           for m in (1, 2) for a, b in zip(res[0], res[m]))
 print(json.dumps({"screened_equals_exact": bool(same)}))
 D.close()
