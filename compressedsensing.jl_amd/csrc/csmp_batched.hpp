@@ -6,7 +6,8 @@
 //
 //   k_b_screen256p (csmp_screen.hip)  bf16 MFMA, f32 accumulate, 256 atoms x 256 signals per workgroup, with a fused
 //               epilogue that keeps the 4 largest |c| per (signal, 128-atom tile): the N x B product (256 MiB at C3)
-//               is never written.
+//               is never written.  Option CSMP_OPT_BATCH_SCREEN = 1: the same kernel on int8 images (k_b_convert_i8: one
+//               step for the dictionary; k_b_init / k_b_append: one step per residual) with v_mfma_i32_16x16x64_i8.
 //   k_b_pick    one workgroup per signal (argmaxinner!, src/matchingpursuit.jl:181-185, + update!'s guards :63,66):
 //               takes the tile candidates whose screened value could still be the exact maximum (the WINDOW), RESCORES
 //               them exactly (f32/f64 master dictionary, Float64 products and sums against the Float64 residual), picks

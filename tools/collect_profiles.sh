@@ -24,6 +24,8 @@ stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
 stats bench_batched --workload batched --steps 2 --warmup 1
 stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
 stats bench_batched_rigorous --workload batched --steps 2 --warmup 1 --batch-cert rigorous
+stats bench_batched_int8 --workload batched --steps 2 --warmup 1 --batch-screen int8
+stats bench_batched_int8_gram --workload batched --steps 2 --warmup 1 --batch-screen int8 --batch-gram
 stats bench_sp --workload sp --steps 9 --warmup 3
 stats bench_sp_single --workload sp_single --steps 3 --warmup 1
 stats bench_gomp --workload gomp --steps 6 --warmup 2
