@@ -229,6 +229,10 @@ static int batch_dict(csmp_ctx* ctx);
 static int batch_dict8(csmp_ctx* ctx);
 static int batch_colnorm(csmp_ctx* ctx);
 static int screened_ensure(csmp_ctx* ctx);
+// the screened sweep is asked for and this dictionary fits its kernels (else: the exact sweep, silently -- the results are the same)
+static bool screened_on(const csmp_ctx* ctx) {
+    return ctx->opt_screened != 0 && ctx->dA && ctx->Mv <= 16384 && ctx->N >= 1;  // (pick kernels: the Float64 residual image in LDS, 8 M bytes)
+}
 static int twins_ensure(csmp_ctx* ctx, int n);
 static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block);
 static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin);

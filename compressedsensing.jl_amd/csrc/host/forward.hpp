@@ -343,7 +343,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
 extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                               double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
-    if (ctx->opt_screened && nsig > 0) {
+    if (screened_on(ctx) && nsig > 0) {
         if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
         if (!B || !idx || !val || !nnz || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "batch: bad arguments");
         if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");

@@ -126,7 +126,7 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     // CSMP_OPT_SCREENED_SWEEP the sweeps read the bf16 image and the top-l pick is certified (host/screened.hpp); a solve
     // with an uncertified step is repeated with the exact sweep.
     bool capacity_stop = false;
-    bool screened = ctx->opt_screened != 0 && l <= kTopSmall;
+    bool screened = screened_on(ctx) && l <= kTopSmall;
     if (screened) CHECK(screened_ensure(ctx));
     bool block = !ctx->force_reorth && l <= kPanelMax;
     for (int attempt = 0; attempt < 4; ++attempt) {
@@ -216,10 +216,16 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     if (nsig == 0) return CSMP_OK;
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(twins_ensure(ctx, 1));
-    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
+    // solves in flight: two (the context and a twin) on the exact sweep -- two 4-GiB sweeps already share the HBM -- and up to
+    // three (CSMP_OPT_SOLVES_IN_FLIGHT) on the screened sweep, whose launches are short enough for their fixed parts to matter
+    const bool screened = screened_on(ctx) && l <= kTopSmall;  // sweeps over the image, certified top-l picks (host/screened.hpp)
+    int T = (int)std::min<int64_t>(screened ? std::min(ctx->opt_in_flight, 3) : 2, nsig);
+    if (const char* tf = tune_env("CSMP_SCR_FLIGHT")) T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(tf), 3), nsig));
+    T = std::max(T, 1);
+    if (T > 1) CHECK(twins_ensure(ctx, T - 1));
+    csmp_ctx* cc[3] = {ctx, T > 1 ? ctx->twins[0] : nullptr, T > 2 ? ctx->twins[1] : nullptr};
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));  // at most k atoms are ever added (GOMP's own capacity is M: :108)
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < T; ++q) {
         const int rc = solver_ensure(cc[q], kc, (int)(k + l));
         if (rc != CSMP_OK) {
             if (q) ctx->err = cc[q]->err;
@@ -248,26 +254,29 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     HIPCHECK(tFlag.alloc((size_t)nsig * sizeof(int)));
     int* d_flag = (int*)tFlag.p;
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
-    if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+    for (int q = 0; q + 1 < T; ++q)
+        if (!cc[q]->ev_twin) HIPCHECK(hipEventCreateWithFlags(&cc[q]->ev_twin, hipEventDisableTiming));
     const bool block = !ctx->force_reorth && l <= kPanelMax;
-    const bool screened = ctx->opt_screened != 0 && l <= kTopSmall;  // sweeps over the bf16 image, certified top-l picks (host/screened.hpp)
-    if (screened) CHECK(screened_ensure_pair(ctx, cc[1]));
+    if (screened) {
+        if (T == 1) CHECK(screened_ensure(ctx));
+        for (int q = 1; q < T; ++q) CHECK(screened_ensure_pair(ctx, cc[q]));
+    }
     std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
-        csmp_ctx* c = cc[sgn & 1];
+        const int q = (int)(sgn % T);
+        csmp_ctx* c = cc[q];
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
-        if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
+        if (sgn > 0 && sgn < T) HIPCHECK(hipStreamWaitEvent(c->stream, cc[q - 1]->ev_twin, 0));  // a twin starts one sweep behind: out of phase
         const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
-                                    sgn == 0 ? ctx->ev_twin : nullptr, screened);
+                                    sgn + 1 < T ? c->ev_twin : nullptr, screened);
         capped[(size_t)sgn] = c->s.capped;  // (the host withholds the appends: known at enqueue time)
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
-            (void)hipStreamSynchronize(cc[0]->stream);
-            (void)hipStreamSynchronize(cc[1]->stream);
+            for (int w = 0; w < T; ++w) (void)hipStreamSynchronize(cc[w]->stream);
             return rc;
         }
     }
-    HIPCHECK(hipStreamSynchronize(cc[1]->stream));
+    for (int w = 1; w < T; ++w) HIPCHECK(hipStreamSynchronize(cc[w]->stream));
     std::vector<int> hf((size_t)nsig);
     HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));

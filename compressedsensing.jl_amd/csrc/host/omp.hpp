@@ -120,7 +120,7 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     // Within an attempt: optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
     // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
     bool capacity_stop = false;
-    bool screened = ctx->opt_screened != 0;
+    bool screened = screened_on(ctx);
     if (screened) CHECK(screened_ensure(ctx));
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool uncertain = false;

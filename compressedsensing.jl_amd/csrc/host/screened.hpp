@@ -185,11 +185,15 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
                               int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (nsig == 0) return CSMP_OK;
     HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(twins_ensure(ctx, 1));
-    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
-    CHECK(screened_ensure_pair(ctx, cc[1]));
+    // solves in flight: the context's and its twins', each one sweep behind the previous one
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->opt_in_flight, 3), nsig));  // (CSMP_OPT_SOLVES_IN_FLIGHT)
+    if (const char* tf = tune_env("CSMP_SCR_FLIGHT")) T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(tf), 3), nsig));
+    if (T > 1) CHECK(twins_ensure(ctx, T - 1));
+    csmp_ctx* cc[3] = {ctx, T > 1 ? ctx->twins[0] : nullptr, T > 2 ? ctx->twins[1] : nullptr};
+    if (T == 1) CHECK(screened_ensure(ctx));
+    for (int q = 1; q < T; ++q) CHECK(screened_ensure_pair(ctx, cc[q]));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < T; ++q) {
         const int rc = solver_ensure(cc[q], kc, (int)k);
         if (rc != CSMP_OK) {
             if (q) ctx->err = cc[q]->err;
@@ -218,23 +222,24 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     HIPCHECK(tFlag.alloc((size_t)nsig * sizeof(int)));
     int* d_flag = (int*)tFlag.p;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    if (!ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+    for (int q = 0; q + 1 < T; ++q)
+        if (!cc[q]->ev_twin) HIPCHECK(hipEventCreateWithFlags(&cc[q]->ev_twin, hipEventDisableTiming));
     std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
-        csmp_ctx* c = cc[sgn & 1];
+        const int q = (int)(sgn % T);
+        csmp_ctx* c = cc[q];
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
-        if (sgn == 1) HIPCHECK(hipStreamWaitEvent(c->stream, ctx->ev_twin, 0));  // the twin starts one sweep late: out of phase
+        if (sgn > 0 && sgn < T) HIPCHECK(hipStreamWaitEvent(c->stream, cc[q - 1]->ev_twin, 0));  // a twin starts one sweep behind: out of phase
         const int rc = omp_screened_enqueue(c, col, b_dtype, k, eps, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
-                                            sgn == 0 ? ctx->ev_twin : nullptr);
+                                            sgn + 1 < T ? c->ev_twin : nullptr);
         capped[(size_t)sgn] = c->s.capped;
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
-            (void)hipStreamSynchronize(cc[0]->stream);
-            (void)hipStreamSynchronize(cc[1]->stream);
+            for (int w = 0; w < T; ++w) (void)hipStreamSynchronize(cc[w]->stream);
             return rc;
         }
     }
-    HIPCHECK(hipStreamSynchronize(cc[1]->stream));
+    for (int w = 1; w < T; ++w) HIPCHECK(hipStreamSynchronize(cc[w]->stream));
     std::vector<int> hf((size_t)nsig);
     HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
