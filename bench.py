@@ -96,7 +96,7 @@ def parse():
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--batch-screen", choices=["bf16", "int8"], default="bf16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM)")
-    p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified top-S picks)")
+    p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single / sp / sp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified selections)")
     p.add_argument("--screen-image", choices=["bf16", "int8"], default="bf16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 1 / 2)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
@@ -416,9 +416,10 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         sigs.append(((At5[idx].to(torch.float64) * sign[:, None]).sum(0) + e * (NOISE / e.norm())).cpu().numpy())
     torch.cuda.synchronize()
     eps = D5.eps
-    screened = int(screened) if workload in ("gomp", "gomp_single") else 0
+    screened = int(screened)
+    isgw = workload in ("gomp", "gomp_single")
     if screened:
-        exact0 = D5.ctx.gomp(sigs[W], S, k, eps)
+        exact0 = D5.ctx.gomp(sigs[W], S, k, eps) if isgw else D5.ctx.sp(sigs[W], k, delta)
         D5.ctx.set_option("screened_sweep", int(screened))  # 1: bf16 image, 2: int8 image
         D5.ctx.screened_stats(reset=True)
 
@@ -498,14 +499,19 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
                                           "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % ({1: 2, 2: 1}[int(screened)] if screened else 4)}
     if screened:
         import numpy as np
-        got0 = D5.ctx.gomp(sigs[W], S, k, eps)
         st_ = D5.ctx.screened_stats(reset=True)
+        got0 = D5.ctx.gomp(sigs[W], S, k, eps) if isgw else D5.ctx.sp(sigs[W], k, delta)
+        D5.ctx.screened_stats(reset=True)
         D5.ctx.set_option("screened_sweep", 0)
-        out["metric"] += ", screened sweep (%s image, certified top-S picks, exact results)" % ("int8" if int(screened) == 2 else "bf16")
+        if not isgw:  # sp returns (idx, val, update! calls): the count has to agree too
+            exact0 = (exact0[0], exact0[1], np.asarray([exact0[2]]))
+            got0 = (got0[0], got0[1], np.asarray([got0[2]]))
+        out["metric"] += ", screened sweep (%s image, certified top-%s, exact results)" % ("int8" if int(screened) == 2 else "bf16", "S picks" if isgw else "k sets")
         out["roofline"]["kernel"] = "csmp::k_sweep_i8<2,3,true> (M*N bytes per sweep)" if int(screened) == 2 else "csmp::k_sweep_bf16<2,3,true> (M*N*2 bytes per sweep)"
         out["screened"] = {"stats": st_, "first_timed_solve_equals_exact_path": bool(
             np.array_equal(got0[0], exact0[0]) and np.array_equal(got0[2], exact0[2]) and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12)),
-            "f32_equivalent_frac_all_in": M5 * N5 * 4 / S * atoms / dt / 1e9 / HBM_PEAK_GBS}
+            "f32_equivalent_frac_all_in": (M5 * N5 * 4 / S * atoms / dt / 1e9 / HBM_PEAK_GBS) if isgw else None,
+            "stats_count": "solves" if isgw else "acquisitions (one selection each: the first and one per update!)"}
     if workload == "gomp":
         # two sweeps share the HBM most of the time: a launch bracketed by HIP events on ONE stream takes about twice as long as
         # the kernel alone, so the per-launch figure says nothing here -- the block's achieved / frac are the all-in ones
@@ -962,6 +968,7 @@ def main():
                 sec["sp_c5"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5)
                 sec["sp_c5_single"] = measure_config5("sp_single", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5_default_delta"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, delta=1e-12)
+                sec["sp_c5_screened_int8"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, screened=2)
                 D5.close()
             except Exception as e:  # noqa: BLE001
                 sec["config5"] = {"error": repr(e)}

@@ -87,7 +87,7 @@ __device__ __forceinline__ int row16_sum(int v) {  // the same for the int8 swee
 // one workgroup maximum), kept as int8 in LDS (4 KiB at M = 4096), multiplied with v_dot4c_i32_i8 -- four exact integer
 // multiply-adds per instruction -- and the candidate values are |integer sum| * astep * rstep.  Mk counts the image's
 // elements per row (bf16: 2 bytes each, int8: 1).
-template <int U, int D, bool FULL, int C, bool I8>
+template <int U, int D, bool FULL, int C, bool I8, int LC = kScrCand>
 __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int Mk, int64_t N, const double* __restrict__ r, int Mr,
                                                float* __restrict__ cand_val, int* __restrict__ cand_idx, DevState* st, double eps,
                                                int check_eps, int skipmask, unsigned* __restrict__ tickets, float astep, char* smem) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     signed char* rimg8 = reinterpret_cast<signed char*>(smem);        // int8 sweep: Ml bytes
     double* red = reinterpret_cast<double*>(smem + (size_t)Ml * (I8 ? 1 : 4));  // 8 doubles (the last four: the maxima, as floats)
     float* wlv = reinterpret_cast<float*>(red + 8);                   // [NL][4]
-    int* wli = reinterpret_cast<int*>(wlv + NL * kScrCand);
+    int* wli = reinterpret_cast<int*>(wlv + NL * LC);
     // residual: Float64 norm (fixed order), and its image -- f32, or (int8 sweep) the largest magnitude first
     double n2 = 0.0;
     float amax = 0.0f;
@@ -236,10 +236,10 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     CSMP_TRACE(2);
     const f32x4* rs = reinterpret_cast<const f32x4*>(rimgf);
     const i32x4* rs8 = reinterpret_cast<const i32x4*>(rimg8);
-    float tv[kScrCand];
-    int ti[kScrCand];
+    float tv[LC];
+    int ti[LC];
 #pragma unroll
-    for (int q = 0; q < kScrCand; ++q) {
+    for (int q = 0; q < LC; ++q) {
         tv[q] = -1.0f;
         ti[q] = 0x7fffffff;
     }
@@ -335,7 +335,7 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
                     int i = (int)col;
                     // the row's running 4 largest (every lane of the row holds the same list); an equal value: the lower index
 #pragma unroll
-                    for (int q = 0; q < kScrCand; ++q) {
+                    for (int q = 0; q < LC; ++q) {
                         const bool up = v > tv[q] || (v == tv[q] && i < ti[q]);
                         const float ov = up ? tv[q] : v;
                         const int oi = up ? ti[q] : i;
@@ -354,19 +354,19 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     if ((lane & 15) == 0) {
         const int l = wave * (kWave / 16) + (lane >> 4);
 #pragma unroll
-        for (int q = 0; q < kScrCand; ++q) {
-            wlv[l * kScrCand + q] = tv[q];
-            wli[l * kScrCand + q] = ti[q];
+        for (int q = 0; q < LC; ++q) {
+            wlv[l * LC + q] = tv[q];
+            wli[l * LC + q] = ti[q];
         }
     }
     __syncthreads();
-    if (tid < NL * kScrCand) {  // one entry per thread: an entry's rank in (value desc, index asc, slot asc) is its place
-        static_assert(NL * kScrCand <= kSweepThreads && kScrCand % 4 == 0, "the workgroup ranks its lists in one go");
+    if (tid < NL * LC) {  // one entry per thread: an entry's rank in (value desc, index asc, slot asc) is its place
+        static_assert(NL * LC <= kSweepThreads && LC % 4 == 0, "the workgroup ranks its lists in one go");
         const float v = wlv[tid];
         const int i = wli[tid];
         int rank = 0;
 #pragma unroll
-        for (int e4 = 0; e4 < NL * kScrCand / 4; ++e4) {  // (broadcast reads, all issued before the first compare: the rolled loop cost 3.5 us)
+        for (int e4 = 0; e4 < NL * LC / 4; ++e4) {  // (broadcast reads, all issued before the first compare: the rolled loop cost 3.5 us)
             const f32x4 ve = reinterpret_cast<const f32x4*>(wlv)[e4];
             const i32x4 ie = reinterpret_cast<const i32x4*>(wli)[e4];
 #pragma unroll
@@ -375,38 +375,38 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
                 rank += (ve[q] > v || (ve[q] == v && (ie[q] < i || (ie[q] == i && e < tid)))) ? 1 : 0;
             }
         }
-        if (rank < kScrCand) {
-            cand_val[bid * kScrCand + rank] = v;
-            cand_idx[bid * kScrCand + rank] = i;
+        if (rank < LC) {
+            cand_val[bid * LC + rank] = v;
+            cand_idx[bid * LC + rank] = i;
         }
     }
     CSMP_TRACE(4);
 }
-template <int U, int D, bool FULL, int C = kScrCols>
+template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
                                                               const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
                                                               int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
                                                               int skipmask, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) char smem_sweep[];  // the residual image | reduction scratch | the lists
-    sweep_img_body<U, D, FULL, C, false>(reinterpret_cast<const char*>(Ab), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+    sweep_img_body<U, D, FULL, C, false, LC>(reinterpret_cast<const char*>(Ab), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
                                          0.0f, smem_sweep);
 }
-template <int U, int D, bool FULL, int C = kScrCols>
+template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_i8(const signed char* __restrict__ A8, int Mk8, int64_t N,
                                                             const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
                                                             int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
                                                             int skipmask, unsigned* __restrict__ tickets, float astep) {
     extern __shared__ __attribute__((aligned(16))) char smem_sweep[];
-    sweep_img_body<U, D, FULL, C, true>(reinterpret_cast<const char*>(A8), Mk8, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+    sweep_img_body<U, D, FULL, C, true, LC>(reinterpret_cast<const char*>(A8), Mk8, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
                                         astep, smem_sweep);
 }
-inline size_t sweep_i8_lds_bytes(int Mk8) {
+inline size_t sweep_i8_lds_bytes(int Mk8, int lc = kScrCand) {
     const int nchunk = (Mk8 + 1023) / 1024;
-    return (size_t)nchunk * 1024 + 8 * sizeof(double) + (kSweepThreads / 16) * kScrCand * 8 + 64;
+    return (size_t)nchunk * 1024 + 8 * sizeof(double) + (kSweepThreads / 16) * lc * 8 + 64;
 }
-inline size_t sweep_bf16_lds_bytes(int Mk) {
+inline size_t sweep_bf16_lds_bytes(int Mk, int lc = kScrCand) {
     const int nchunk = (Mk + 511) / 512;
-    return (size_t)nchunk * 512 * sizeof(float) + 8 * sizeof(double) + (kSweepThreads / 16) * kScrCand * 8 + 64;
+    return (size_t)nchunk * 512 * sizeof(float) + 8 * sizeof(double) + (kSweepThreads / 16) * lc * 8 + 64;
 }
 
 // the sweep's candidates of one pick workgroup: thread t holds entries t, t + 256, ... (kPickEpl of them) in registers when all
@@ -662,6 +662,87 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
         *ncands = Seff;
         if (nw == 0) st->uncertain += 1;  // (cannot happen with a non-empty dictionary: the best candidate is always in the window)
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Subspace Pursuit's acquisition on the screened sweep: the k largest |<a_j, r>| as a SET (sp_acquisition!, src/twostage.jl:67-72;
+// argmaxinner!(P, k), src/matchingpursuit.jl:187-193), k in the hundreds.  The sweep lists kScrCandK candidates per workgroup;
+// the selection reuses the exact path's top-S machinery (radix select on an N-vector of values) twice:
+//   k_spk_scatter   cvec := 0, cvec[candidate] := its screened value           -> launch_topS: the k-th largest SCREENED value
+//   k_spk_rescore   every candidate whose upper bound reaches the k-th value's lower bound is rescored exactly (one wave per
+//                   column, Float64): cvec[candidate] := |exact|; the others := 0 and their bound goes into cb (as does the
+//                   bound of a workgroup's last listed candidate when it is inside the window: atoms hidden behind it)
+//                                                                               -> launch_topS: the k largest EXACT values
+//   k_spk_cert      certified when the k-th exact value beats cb (and there are k of them); else the acquisition is repeated
+//                   with the exact sweep (the flag is read with the selection).
+constexpr int kScrCandK = 16;
+
+__global__ __launch_bounds__(256) void k_spk_scatter(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand,
+                                                     double* __restrict__ cvec, unsigned long long* __restrict__ cb_bits, int* __restrict__ flag) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) {
+        *cb_bits = 0ull;
+        *flag = 0;
+    }
+    if (t < ncand) {
+        const float v = cand_val[t];
+        if (v >= 0.0f) cvec[cand_idx[t]] = (double)v;
+    }
+}
+
+// grid: workgroups of 4 waves, wave w of workgroup b takes candidates b * 4 + w, + 4 * gridDim.x, ...
+template <typename TA, int U>
+__global__ __launch_bounds__(256) void k_spk_rescore(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
+                                                     const int* __restrict__ cand_idx, int ncand, const DevState* __restrict__ st,
+                                                     const double* __restrict__ r, int Mr, const double* __restrict__ cvals,
+                                                     const int* __restrict__ ncands, int k, double* __restrict__ cvec,
+                                                     unsigned long long* __restrict__ cb_bits, double cert_abs, double cert_rel,
+                                                     double cert_abs2) {
+    extern __shared__ __attribute__((aligned(16))) double rimg[];
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+        f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
+        if (m0 < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + m0)[0];
+            hi = reinterpret_cast<const f64x2*>(r + m0)[1];
+        }
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0)) = lo;
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
+    }
+    const double n2 = st->rnorm2;
+    const double dabs = cert_abs2 > 0.0 ? sqrt(cert_abs * cert_abs * n2 + cert_abs2 * cert_abs2 * (double)st->rstep * (double)st->rstep) : cert_abs * sqrt(n2);
+    // the k-th largest screened value (fewer than k positive candidates: everything is in the window)
+    const double mk = (*ncands >= k) ? cvals[k - 1] : 0.0;
+    const double lbk = mk - dabs - cert_rel * mk;
+    __syncthreads();
+    double cb = 0.0;
+    for (int t = blockIdx.x * 4 + wave; t < ncand; t += 4 * gridDim.x) {
+        const float v = cand_val[t];
+        if (!(v >= 0.0f)) continue;  // (wave-uniform)
+        const double ub = (double)v + dabs + cert_rel * (double)v;
+        const int col = cand_idx[t];
+        if (ub >= lbk) {
+            const double ex = wave_col_dot<TA, U>(A + (int64_t)col * ld, Mv, nchunk, rimg, lane);
+            if (lane == 0) cvec[col] = fabs(ex);
+            if ((t & (kScrCandK - 1)) == kScrCandK - 1) cb = fmax(cb, ub);
+        } else {
+            if (lane == 0) cvec[col] = 0.0;
+            cb = fmax(cb, ub);
+        }
+    }
+    if (lane == 0 && cb > 0.0) atomicMax(cb_bits, (unsigned long long)__double_as_longlong(cb));  // (non-negative doubles: their bits order like the values)
+}
+
+__global__ void k_spk_cert(const double* __restrict__ cvals, const int* __restrict__ ncands, int k, const unsigned long long* __restrict__ cb_bits,
+                           int* __restrict__ flag) {
+    const double cb = __longlong_as_double((long long)*cb_bits);
+    const bool ok = *ncands >= k && cvals[k - 1] > cb;
+    *flag = ok ? 0 : 1;
 }
 
 

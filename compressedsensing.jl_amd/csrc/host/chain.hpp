@@ -21,8 +21,10 @@ static int solver_alloc(csmp_ctx* ctx, Solver& s, int kcap, int outcap, int qcap
     CHECK(dmalloc(ctx, &s.vvec, s.Mpad));
     CHECK(dmalloc(ctx, &s.cvec, (size_t)ctx->N));
     CHECK(dmalloc(ctx, &s.pval, maxgrid));
-    CHECK(dmalloc(ctx, &s.scr_val, (size_t)maxgrid * kScrCand));
-    CHECK(dmalloc(ctx, &s.scr_idx, (size_t)maxgrid * kScrCand));
+    CHECK(dmalloc(ctx, &s.scr_val, (size_t)maxgrid * kScrCandK));
+    CHECK(dmalloc(ctx, &s.scr_idx, (size_t)maxgrid * kScrCandK));
+    CHECK(dmalloc(ctx, &s.scr_cb, 1));
+    CHECK(dmalloc(ctx, &s.scr_flag, 2));
     CHECK(dmalloc(ctx, &s.scr_tickets, (size_t)(maxgrid / kScrPartWgs + 2) * kScrTicketStride));
     HIPCHECK(hipMemsetAsync(s.scr_tickets, 0, (size_t)(maxgrid / kScrPartWgs + 2) * kScrTicketStride * sizeof(unsigned), ctx->stream));
     CHECK(dmalloc(ctx, &s.pidx, maxgrid));

