@@ -446,7 +446,8 @@ template <typename TA, int U>
 __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, double* __restrict__ pval, int* __restrict__ pidx, double cert_abs, double cert_rel,
-                                               int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts, double cert_abs2) {
+                                               int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts, double cert_abs2,
+                                               int mp_select) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
     __shared__ double sc[8];
     __shared__ double red[kWinMax];
@@ -528,6 +529,15 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
         if (!(nall <= kwin && (cb < 0.0 || bestv > cb))) st->uncertain += 1;
         pval[0] = bestv;
         pidx[0] = besti;
+        if (mp_select) {  // Matching Pursuit: the selection kernel's job too (k_select, mode 0: no guards, atoms may repeat)
+            double signedv = 0.0;
+            for (int q = 0; q < nw; ++q)
+                if (wi_[q] == besti) signedv = red[q];
+            st->cand = besti;
+            st->cval = signedv;
+            st->j = st->nsel;
+            st->go = 1;
+        }
     }
 }
 

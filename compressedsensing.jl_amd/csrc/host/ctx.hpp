@@ -240,6 +240,7 @@ static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_
 static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin);
 static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask);
 static int sp_select_screened(csmp_ctx* ctx, int k);
+static int mp_step_screened(csmp_ctx* ctx);
 static int launch_topS(csmp_ctx* ctx, int S);
 static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic);
 static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,

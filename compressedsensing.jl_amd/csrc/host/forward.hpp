@@ -432,8 +432,31 @@ extern "C" int csmp_mp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, con
     HIPCHECK(hipSetDevice(ctx->dev));
     CHECK(solver_ensure(ctx, (int)std::max<int64_t>(std::max(k, nnz0), 1), 1, false));  // MP keeps no factorisation
     ctx->s.begun = false;
-    CHECK(upload_b(ctx, b, b_dtype));
-    if (nnz0 > 0) CHECK(upload_support(ctx, idx0, val0, nnz0));
-    for (int64_t t = 0; t < k; ++t) CHECK(mp_step(ctx));
+    // CSMP_OPT_SCREENED_SWEEP: the sweeps read the image, every pick is certified (host/screened.hpp); a solve with an uncertified
+    // pick is repeated with the exact sweep
+    bool screened = screened_on(ctx);
+    if (screened) CHECK(screened_ensure(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        CHECK(upload_b(ctx, b, b_dtype));
+        if (nnz0 > 0) CHECK(upload_support(ctx, idx0, val0, nnz0));
+        for (int64_t t = 0; t < k; ++t) {
+            if (screened) {
+                Solver& s = ctx->s;
+                if (s.jh >= s.kcap) return fail(ctx, CSMP_ERANGE, "mp: more steps than the capacity this solver was begun with");
+                s.jh += 1;
+                CHECK(mp_step_screened(ctx));
+            } else {
+                CHECK(mp_step(ctx));
+            }
+        }
+        if (!screened) break;
+        DevState hs;
+        HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        ctx->scr_solves += 1;
+        if (hs.uncertain == 0) break;
+        ctx->scr_fallbacks += 1;
+        screened = false;
+    }
     return mp_collect(ctx, idx0, val0, nnz0, idx, val, nnz);
 }

@@ -40,7 +40,7 @@ static int screened_ensure(csmp_ctx* ctx) {
 }
 
 template <typename TA>
-static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
+static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask, int mp_select = 0) {
     Solver& s = ctx->s;
     constexpr int U = sizeof(TA) == 4 ? 16 : 8;
     const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
@@ -51,7 +51,7 @@ static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask) {
     }
     hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
                        ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask,
-                       s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2);
+                       s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2, mp_select);
     return hipGetLastError();
 }
 
@@ -177,6 +177,13 @@ static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool opti
     CHECK(launch_sweep_bf16(ctx, eps, check_eps, skip));
     HIPCHECK(ctx->dtype == CSMP_F32 ? pick1_launch<float>(ctx, ctx->scr_grid * kScrCand, skip) : pick1_launch<double>(ctx, ctx->scr_grid * kScrCand, skip));
     return launch_append(ctx, 1, 0, skip, optimistic, 0.0, /*nblk_sweep: the pick is the only "partial"*/ 1);
+}
+
+// update!(P::MP, x) (src/matchingpursuit.jl:26-31) with the screened sweep: the certified pick also does k_select's job
+static int mp_step_screened(csmp_ctx* ctx) {
+    CHECK(launch_sweep_bf16(ctx, 0.0, 0, 0));
+    HIPCHECK(ctx->dtype == CSMP_F32 ? pick1_launch<float>(ctx, ctx->scr_grid * kScrCand, 0, 1) : pick1_launch<double>(ctx, ctx->scr_grid * kScrCand, 0, 1));
+    return launch_mp_update(ctx);
 }
 
 // update!(P::GOMP, x, l) with the screened sweep: bf16 sweep -> certified top-l pick -> the exact path's (panel) appends

@@ -2063,3 +2063,24 @@ def test_screened_sweep_full_size_config5_sp(cs, oracle):
     for s in range(4):
         assert np.array_equal(bi[:bn[s], s], ex[0]), s
     D5.close()
+
+
+def test_screened_sweep_mp_matches_oracle(cs, oracle, D):
+    """Matching Pursuit with the screened sweep (the certified pick also selects: no guards, atoms repeat, src/matchingpursuit.jl:26-31):
+    index / coefficient pairs of the oracle on both images, with a warm start, at a size where the sweep has many workgroups."""
+    for (n, m, k, dtype) in [(32, 48, 30, np.float64), (64, 256, 50, np.float32), (37, 101, 25, np.float32), (512, 8192, 40, np.float32)]:
+        A, x, b = cs.sparse_data(n=n, m=m, k=3, rng=n + m, dtype=dtype)
+        b = cs.perturb(b, 5e-2, rng=1)
+        d = D(A)
+        ref = oracle.mp(A, b, k)
+        for image in (1, 2):
+            d.ctx.set_option("screened_sweep", image)
+            d.ctx.screened_stats(reset=True)
+            got = d.ctx.mp(b, k)
+            assert np.array_equal(got[0], ref[0]), (n, m, image)
+            assert close(got[1], ref[1])
+            x1 = cs.mp(d, b, 7)
+            x2 = cs.mp(d, b, k - 7, x1)
+            assert np.array_equal(x2.nzind, ref[0]) and close(x2.nzval, ref[1])
+            assert d.ctx.screened_stats()["solves"] == 3
+        d.ctx.set_option("screened_sweep", 0)
