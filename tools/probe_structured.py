@@ -46,8 +46,9 @@ def main():
         for family, k in (("pm1", 24), ("gauss", 24), ("decay", 8), ("pm1", 2), ("neartie", 2), ("neartie", 6)):
             B = signals(A.astype(np.float64), k, nsig, family, rng)
             i2, v2, n2 = d.ctx.omp_batch(B, k, eps)
-            for mode in ("default", "rigorous") + (("round2",) if os.environ.get("CSMP_PROBE_ROUND2") else ()):
+            for mode in ("default", "rigorous", "int8") + (("round2",) if os.environ.get("CSMP_PROBE_ROUND2") else ()):
                 d.ctx.set_option("batch_cert", 1 if mode == "rigorous" else 0)
+                d.ctx.set_option("batch_screen", 1 if mode == "int8" else 0)  # int8 operands of the screening GEMM (statistical bound)
                 if mode == "round2":  # (experiments build only: the statistical bound without the coherent term)
                     os.environ["CSMP_CERT_NOREL"] = "1"
                 else:
