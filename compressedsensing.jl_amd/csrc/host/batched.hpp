@@ -29,28 +29,41 @@ __global__ __launch_bounds__(256) void k_colnorm_max(const TA* __restrict__ A, i
     if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint((float)sqrt(acc) * 1.0000002f));
 }
 
-static int batch_dict(csmp_ctx* ctx) {
+// tile counts, padded sizes and max|A| of the current dictionary: what both images need
+static int batch_meta(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
-    if (b.ab_valid) return CSMP_OK;
+    if (b.meta_valid) return CSMP_OK;
     // K is padded (zeros) to an even number of 64-deep tiles, at least four: what the eight-phase screening kernel needs
     b.Mk = (int)std::max<int64_t>(256, ((ctx->M + 127) / 128) * 128);
     b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles
     b.n_atiles = (int)(b.Npad / kBT);
-    HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
-    HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
+    if (!b.amax) HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
     HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
-    const int64_t total = b.Npad * (b.Mk / 8);
-    const int grid = (int)((total + 255) / 256);
     const int64_t nel = ctx->ld * ctx->N;
-    if (ctx->dtype == CSMP_F32) {
-        hipLaunchKernelGGL(k_b_convert<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+    if (ctx->dtype == CSMP_F32)
         hipLaunchKernelGGL(k_absmax_f32, dim3(2048), dim3(256), 0, ctx->stream, (const float*)ctx->dA, nel, b.amax);
-    } else {
-        hipLaunchKernelGGL(k_b_convert<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+    else
         hipLaunchKernelGGL(k_absmax_f64, dim3(2048), dim3(256), 0, ctx->stream, (const double*)ctx->dA, nel, b.amax);
-    }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(&b.amax_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.meta_valid = true;
+    return CSMP_OK;
+}
+
+// bf16 image of the dictionary [Npad][Mk]
+static int batch_dict(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.ab_valid) return CSMP_OK;
+    CHECK(batch_meta(ctx));
+    HIPCHECK(hipMalloc((void**)&b.Ab, (size_t)b.Npad * b.Mk * sizeof(__bf16)));
+    const int64_t total = b.Npad * (b.Mk / 8);
+    const int grid = (int)((total + 255) / 256);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_b_convert<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+    else
+        hipLaunchKernelGGL(k_b_convert<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ab, b.Mk, b.Npad);
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     b.ab_valid = true;
     return CSMP_OK;
@@ -58,9 +71,9 @@ static int batch_dict(csmp_ctx* ctx) {
 
 // int8 image of the dictionary under one step (max|A| / 127), for the int8 screen
 static int batch_dict8(csmp_ctx* ctx) {
-    CHECK(batch_dict(ctx));  // (amax, the tile counts; the bf16 image also serves the re-solves' callers)
     Batch& b = ctx->bt;
     if (b.a8_valid) return CSMP_OK;
+    CHECK(batch_meta(ctx));
     b.Mk8 = (int)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256);  // bytes per row: an even number (>= 4) of 128-deep K-tiles
     HIPCHECK(hipMalloc((void**)&b.A8, (size_t)b.Npad * b.Mk8));
     b.astep = b.amax_host > 0.f ? b.amax_host / 127.0f : 1.0f;

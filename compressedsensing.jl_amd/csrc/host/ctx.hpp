@@ -64,6 +64,7 @@ struct Solver {
 // device state of the batched (MFMA-screened) path
 struct Batch {
     __bf16* Ab = nullptr;  // dictionary as bf16 [Npad][Mk]
+    bool meta_valid = false;  // Mk, Npad, n_atiles, amax_host are those of the current dictionary
     bool ab_valid = false;
     bool ab_borrowed = false;  // a twin sweeping its parent's image (host/screened.hpp): not this context's to free
     int Mk = 0;
@@ -146,7 +147,7 @@ struct csmp_ctx {
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
     int scr_kwin = 0, scr_cert_mode = -1;
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
-    int opt_batch_screen = 0;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>)
+    int opt_batch_screen = 1;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 (default) int8 operands (k_b_screen256p<true>)
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch

@@ -51,6 +51,7 @@ static void batch_free(Batch& b, bool keep_dict) {
         dfree(b.Gm);
         b.gram_valid = false;
         b.ab_valid = false;
+        b.meta_valid = false;
         b.anorm_host = -1.f;
     }
 }

@@ -203,6 +203,14 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
     twin->opt_batch_cert = ctx->opt_batch_cert;
     twin->opt_screened = ctx->opt_screened;
     CHECK(screened_ensure(ctx));
+    if (!twin->bt.meta_valid) {
+        Batch &tb = twin->bt, &pb = ctx->bt;
+        tb.Mk = pb.Mk;
+        tb.Npad = pb.Npad;
+        tb.n_atiles = pb.n_atiles;
+        tb.amax_host = pb.amax_host;
+        tb.meta_valid = true;
+    }
     if (ctx->bt.a8_valid && !twin->bt.a8_valid) {
         Batch &tb = twin->bt, &pb = ctx->bt;
         tb.A8 = pb.A8;
@@ -210,7 +218,7 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
         tb.astep = pb.astep;
         tb.a8_valid = tb.a8_borrowed = true;
     }
-    if (!twin->bt.ab_valid) {
+    if (ctx->bt.ab_valid && !twin->bt.ab_valid) {
         Batch &tb = twin->bt, &pb = ctx->bt;
         tb.Ab = pb.Ab;
         tb.Mk = pb.Mk;

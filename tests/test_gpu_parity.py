@@ -512,13 +512,15 @@ def test_full_size_config5_gomp_and_sp(cs, oracle):
 
 @pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype):
-    """csmp_omp_batch_mfma: bf16 MFMA screening + Float64 rescoring must reproduce the oracle's
+@pytest.mark.parametrize("screen", [1, 0])
+def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype, screen):
+    """csmp_omp_batch_mfma: MFMA screening (int8 operands, the default, and bf16) + Float64 rescoring must reproduce the oracle's
     supports exactly and its coefficients to the north_star tolerance, signal by signal."""
     n, m, k, nsig = shape
     eps = float(np.finfo(dtype).eps)
     A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + 3 * m, dtype=dtype)
     d = D(A)
+    d.ctx.set_option("batch_screen", screen)
     rng = np.random.default_rng(nsig)
     B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
                                     for _ in range(nsig)], axis=1))
@@ -1165,15 +1167,17 @@ def test_batched_mfma_structured_dictionaries(cs, oracle, kind):
                 x = x * (1.0 + 2e-3 * rng.random(k))
             B[:, s] = cs.perturb(A64[:, sup] @ x, 5e-3, rng=rng)
         i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
-        for cert in (0, 1):
+        for screen, cert in ((0, 0), (0, 1), (1, 0)):  # bf16 statistical / rigorous, int8 (the default)
+            d.ctx.set_option("batch_screen", screen)
             d.ctx.set_option("batch_cert", cert)
             idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
             st = d.ctx.batch_stats()
             assert st["signals"] == nsig and st["resolved_exactly"] <= st["uncertain"] + st["illcond"]
-            assert np.array_equal(nnz, n2), (kind, family, cert)
-            assert np.array_equal(idx, i2), (kind, family, cert, int((idx != i2).any(axis=0).sum()))
+            assert np.array_equal(nnz, n2), (kind, family, screen, cert)
+            assert np.array_equal(idx, i2), (kind, family, screen, cert, int((idx != i2).any(axis=0).sum()))
             assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
         d.ctx.set_option("batch_cert", 0)
+        d.ctx.set_option("batch_screen", 1)
         for s in range(0, nsig, 25):
             ref = oracle.omp(A, B[:, s], k, EPS32)
             assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (kind, family, s)
@@ -1211,7 +1215,7 @@ def test_options_at_the_abi(cs, D):
     d = D(A)
     c = d.ctx
     defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
-                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0, "batch_screen": 0}
+                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0, "batch_screen": 1}
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
@@ -1312,7 +1316,8 @@ def test_full_size_config3_batched(cs, oracle):
         d.ctx.sync()
         return idx.cpu().numpy(), val.cpu().numpy(), nnz.cpu().numpy()
 
-    # (i) oracle sample
+    # (i) oracle sample -- (i)-(iii) with the bf16 screen of rounds 1-2, (iv) with the int8 screen (the default)
+    d.ctx.set_option("batch_screen", 0)
     A = np.asfortranarray(At.cpu().numpy().T)
     sample = [0, 1, 127, 128, 511, 512, 777, 1023]
     i16, v16, n16 = run(d.ctx.omp_batch_mfma_device, B[sample].contiguous(), 16)
@@ -1344,7 +1349,6 @@ def test_full_size_config3_batched(cs, oracle):
         assert np.array_equal(i8n, n2) and np.array_equal(i8i, i2)
         assert np.allclose(i8v, v2, rtol=1e-9, atol=1e-12)
         assert st8["illcond"] == 0 and st8["uncertain"] <= 8, st8
-    d.ctx.set_option("batch_screen", 0)
     d.ctx.set_option("batch_gram", 0)
     d.close()
 
@@ -1961,7 +1965,6 @@ def test_batched_int8_screen_matches_oracle(cs, oracle, D, shape, dtype):
     d.ctx.set_option("batch_screen", 1)
     idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
     st = d.ctx.batch_stats()
-    d.ctx.set_option("batch_screen", 0)
     assert "i8" in d.ctx.batch_screen_kernel()
     assert st["signals"] == nsig and st["resolved_exactly"] <= st["uncertain"] + st["illcond"]
     for s in range(0, nsig, max(1, nsig // 12)):
@@ -1991,7 +1994,6 @@ def test_batched_int8_screen_structured_dictionaries(cs, oracle, kind):
         d.ctx.set_option("batch_screen", 1)
         idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
         st = d.ctx.batch_stats()
-        d.ctx.set_option("batch_screen", 0)
         print(kind, family, "int8 screen batch_stats:", st)
         assert np.array_equal(nnz, n2), (kind, family)
         assert np.array_equal(idx, i2), (kind, family, int((idx != i2).any(axis=0).sum()))

@@ -21,8 +21,8 @@ pmc() {  # pmc <name> <counters> <bench args...>
   echo /tmp/pmc_$name
 }
 stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
-stats bench_batched --workload batched --steps 2 --warmup 1
-stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
+stats bench_batched --workload batched --steps 2 --warmup 1 --batch-screen bf16
+stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram --batch-screen bf16
 stats bench_batched_rigorous --workload batched --steps 2 --warmup 1 --batch-cert rigorous
 stats bench_batched_int8 --workload batched --steps 2 --warmup 1 --batch-screen int8
 stats bench_batched_int8_gram --workload batched --steps 2 --warmup 1 --batch-screen int8 --batch-gram
