@@ -272,7 +272,7 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, ce
     D.ctx.sync()
     same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
     D.ctx.set_option("batch_cert", 0)
-    D.ctx.set_option("batch_screen", 1)
+    D.ctx.set_option("batch_screen", 2)  # (the library's default: int8 where the dictionary is flat)
     D.ctx.set_option("batch_gram", 0)  # (releases the 8 N^2 bytes)
     i8 = bool(screen) and not cert
     return {

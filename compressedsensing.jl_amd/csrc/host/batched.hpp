@@ -1,17 +1,40 @@
 // host/batched.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
 // the batched (MFMA-screened) OMP driver.
 // ------------------------------------------------------------------------------------------ batched (MFMA-screened) OMP
+// max |A_ij| into out[0] and sum A_ij^2 into the double behind it (out + 2): the second says how FLAT the dictionary is
 __global__ void k_absmax_f32(const float* __restrict__ A, int64_t n, float* out) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(A[i]));
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+    double q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = A[i];
+        m = fmaxf(m, fabsf(v));
+        q = fma((double)v, (double)v, q);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, s, 64));
+        q += __shfl_xor(q, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+        atomicAdd(reinterpret_cast<double*>(out + 2), q);
+    }
 }
 __global__ void k_absmax_f64(const double* __restrict__ A, int64_t n, float* out) {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, (float)fabs(A[i]));
-    for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m * 1.0000002f));
+    double q = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double v = A[i];
+        m = fmaxf(m, (float)fabs(v));
+        q = fma(v, v, q);
+    }
+    for (int s = 32; s >= 1; s >>= 1) {
+        m = fmaxf(m, __shfl_xor(m, s, 64));
+        q += __shfl_xor(q, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m * 1.0000002f));
+        atomicAdd(reinterpret_cast<double*>(out + 2), q);
+    }
 }
 
 // max_j |a_j|_2 (rounded up), one wave per column
@@ -37,16 +60,22 @@ static int batch_meta(csmp_ctx* ctx) {
     b.Mk = (int)std::max<int64_t>(256, ((ctx->M + 127) / 128) * 128);
     b.Npad = ((ctx->N + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);  // whole 256-atom tiles
     b.n_atiles = (int)(b.Npad / kBT);
-    if (!b.amax) HIPCHECK(hipMalloc((void**)&b.amax, sizeof(float)));
-    HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
+    if (!b.amax) HIPCHECK(hipMalloc((void**)&b.amax, 4 * sizeof(float)));  // [max|A|, -, sum A^2 (a double)]
+    HIPCHECK(hipMemsetAsync(b.amax, 0, 4 * sizeof(float), ctx->stream));
     const int64_t nel = ctx->ld * ctx->N;
     if (ctx->dtype == CSMP_F32)
         hipLaunchKernelGGL(k_absmax_f32, dim3(2048), dim3(256), 0, ctx->stream, (const float*)ctx->dA, nel, b.amax);
     else
         hipLaunchKernelGGL(k_absmax_f64, dim3(2048), dim3(256), 0, ctx->stream, (const double*)ctx->dA, nel, b.amax);
     HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(&b.amax_host, b.amax, sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    float h4[4];
+    HIPCHECK(hipMemcpyAsync(h4, b.amax, sizeof h4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.amax_host = h4[0];
+    double sumsq;
+    memcpy(&sumsq, h4 + 2, sizeof sumsq);
+    // root mean square of the entries that exist (padding rows of a caller's leading dimension count as what they hold)
+    b.arms_host = (float)std::sqrt(sumsq / ((double)ctx->M * (double)ctx->N));
     b.meta_valid = true;
     return CSMP_OK;
 }
@@ -229,7 +258,13 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
-    const bool i8 = ctx->opt_batch_screen == 1 && ctx->opt_batch_cert == 0 && !tune_env("CSMP_SCREEN4");  // (the int8 screen has a statistical certificate only)
+    // operands of the screen: int8 (one step for the whole dictionary) where the dictionary is FLAT -- max|A| within 8 root mean
+    // squares of its entries (Gaussian unit-norm columns: 4.5-5; partial DCT: 1.4; few-valued: 1.3) --, bf16 where a few large
+    // entries would coarsen the common step for everything else (spikes beside a dense basis: max / rms = sqrt(M)).  Option
+    // values 0 / 1 force bf16 / int8; the int8 screen has a statistical certificate only.
+    CHECK(batch_meta(ctx));
+    const bool flat = ctx->bt.amax_host <= 8.0f * ctx->bt.arms_host;
+    const bool i8 = (ctx->opt_batch_screen == 1 || (ctx->opt_batch_screen == 2 && flat)) && ctx->opt_batch_cert == 0 && !tune_env("CSMP_SCREEN4");
     CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
     CHECK(batch_ensure(ctx, (int)nsig, kc));
     CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals

@@ -72,6 +72,7 @@ struct Batch {
     int n_atiles = 0;
     float* amax = nullptr;  // max |A_ij| (device scalar) for the screening error bound
     float amax_host = 0.f;
+    float arms_host = 0.f;   // root mean square of the dictionary's entries (how flat it is: the int8 screen's applicability)
     float anorm_host = -1.f;  // max column 2-norm (the deterministic bound, CSMP_CERT=rigorous), computed on first use
     // per-batch buffers
     int Bcap = 0, kcap = 0, Mr = 0;
@@ -147,7 +148,7 @@ struct csmp_ctx {
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
     int scr_kwin = 0, scr_cert_mode = -1;
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
-    int opt_batch_screen = 1;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 (default) int8 operands (k_b_screen256p<true>)
+    int opt_batch_screen = 2;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>), 2 (default) int8 where the dictionary is flat
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch

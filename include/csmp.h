@@ -245,11 +245,13 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
                                       returns, so results are those of option 0.  Costs the
                                       image (2 Mk N or Mk N bytes) beside the dictionary.  Default off: the headline path stays
                                       the exact one ("Screened single-signal sweep"). */
-#define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM. 1 (default): int8 images -- the dictionary under
-                                      one step max|A|/127, every residual under its own -- on v_mfma_i32_16x16x64_i8 (half the K-loop of
-                                      the bf16 form, exact integer accumulation); statistical certificate only, so under
+#define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM. 1: int8 images -- the dictionary under one step
+                                      max|A|/127, every residual under its own -- on v_mfma_i32_16x16x64_i8 (half the K-loop of the
+                                      bf16 form, exact integer accumulation); statistical certificate only, so under
                                       CSMP_OPT_BATCH_CERT = 1 the bf16 form runs.  0: bf16 images (v_mfma_f32_16x16x32_bf16), the form
-                                      of rounds 1-2.  The int8 image costs M N bytes beside the bf16 one. */
+                                      of rounds 1-2.  2 (default): int8 where the dictionary is flat (max|A| <= 8 x the root mean
+                                      square of its entries: one step then resolves every column), bf16 otherwise.  The int8 image
+                                      costs M N bytes, the bf16 image 2 M N; only what is used is built. */
 int csmp_set_option(csmp_ctx *ctx, int key, int64_t value);
 int csmp_get_option(csmp_ctx *ctx, int key, int64_t *value);
 

@@ -1177,7 +1177,7 @@ def test_batched_mfma_structured_dictionaries(cs, oracle, kind):
             assert np.array_equal(idx, i2), (kind, family, screen, cert, int((idx != i2).any(axis=0).sum()))
             assert np.allclose(val, v2, rtol=1e-7, atol=1e-10)
         d.ctx.set_option("batch_cert", 0)
-        d.ctx.set_option("batch_screen", 1)
+        d.ctx.set_option("batch_screen", 2)
         for s in range(0, nsig, 25):
             ref = oracle.omp(A, B[:, s], k, EPS32)
             assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (kind, family, s)
@@ -1215,11 +1215,11 @@ def test_options_at_the_abi(cs, D):
     d = D(A)
     c = d.ctx
     defaults = {"batch_cert": 0, "batch_gram": 0, "batch_window": 0, "pipeline": 1, "force_reorth": 0, "ls_gram": 1, "ls_gram_reuse": 1,
-                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0, "batch_screen": 1}
+                "twostage_update": 0, "solves_in_flight": 3, "screened_sweep": 0, "batch_screen": 2}
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
-                     ("solves_in_flight", 0), ("screened_sweep", 3), ("batch_screen", 2)):
+                     ("solves_in_flight", 0), ("screened_sweep", 3), ("batch_screen", 3)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -2086,3 +2086,35 @@ def test_screened_sweep_mp_matches_oracle(cs, oracle, D):
             assert np.array_equal(x2.nzind, ref[0]) and close(x2.nzval, ref[1])
             assert d.ctx.screened_stats()["solves"] == 3
         d.ctx.set_option("screened_sweep", 0)
+
+
+def test_batched_screen_auto_rule(cs, oracle, D):
+    """CSMP_OPT_BATCH_SCREEN = 2 (default): int8 operands where the dictionary is flat, bf16 where a few large entries would
+    coarsen the common int8 step (spikes beside a dense basis).  Forced int8 on such a dictionary still returns the exact path's
+    results -- through the certificate and the exact re-solves."""
+    rng = np.random.default_rng(31)
+    M, k, nsig = 256, 8, 40
+    G = rng.standard_normal((M, 768))
+    G /= np.linalg.norm(G, axis=0)
+    A_flat = np.asfortranarray(G.astype(np.float32))
+    A_spiky = np.asfortranarray(np.hstack([np.eye(M), G]).astype(np.float32))  # [I, G]: max|A| / rms = sqrt(M)
+    for A, expect_i8 in ((A_flat, True), (A_spiky, False)):
+        d = D(A)
+        assert d.ctx.get_option("batch_screen") == 2
+        B = np.empty((M, nsig), order="F")
+        for s in range(nsig):
+            sup = rng.choice(A.shape[1], size=k, replace=False)
+            B[:, s] = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=k), 5e-3, rng=rng)
+        i2, v2, n2 = d.ctx.omp_batch(B, k, EPS32)
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
+        assert ("i8" in d.ctx.batch_screen_kernel()) == expect_i8, d.ctx.batch_screen_kernel()
+        assert np.array_equal(nnz, n2) and np.array_equal(idx, i2) and np.allclose(val, v2, rtol=1e-7, atol=1e-10)
+        for s in range(0, nsig, 10):
+            ref = oracle.omp(A, B[:, s], k, EPS32)
+            assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0])
+        d.ctx.set_option("batch_screen", 1)  # forced int8, whatever the dictionary looks like
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, EPS32)
+        st = d.ctx.batch_stats()
+        assert "i8" in d.ctx.batch_screen_kernel()
+        assert np.array_equal(nnz, n2) and np.array_equal(idx, i2) and np.allclose(val, v2, rtol=1e-7, atol=1e-10), st
+        d.ctx.set_option("batch_screen", 2)

@@ -101,7 +101,7 @@ if which & {"c2", "c3"}:
                    uncertain=st["uncertain"], illcond=st["illcond"])
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
-        D.ctx.set_option("batch_screen", 1)
+        D.ctx.set_option("batch_screen", 2)
     D.close()
     del At, A
 

@@ -75,7 +75,7 @@ while time.time() - t0 < budget:
                 cmp(name, (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
         D.ctx.set_option("batch_cert", 0)
         D.ctx.set_option("batch_gram", 0)
-        D.ctx.set_option("batch_screen", 1)
+        D.ctx.set_option("batch_screen", 2)
         for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous"), (0, "omp_screened_int8")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
             D.ctx.set_option("batch_cert", cert)
             D.ctx.set_option("screened_sweep", 2 if "int8" in name else 1)
