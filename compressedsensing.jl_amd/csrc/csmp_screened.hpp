@@ -409,19 +409,20 @@ inline size_t sweep_bf16_lds_bytes(int Mk, int lc = kScrCand) {
     return (size_t)nchunk * 512 * sizeof(float) + 8 * sizeof(double) + (kSweepThreads / 16) * lc * 8 + 64;
 }
 
-// the sweep's candidates of one pick workgroup: thread t holds entries t, t + 256, ... (kPickEpl of them) in registers when all
+// the sweep's candidates of one pick workgroup: thread t holds entries t, t + NT, ... (2048 / NT of them) in registers when all
 // fit, loaded by one unrolled batch; `each` visits (value, atom, entry number) from the registers or, for a larger sweep grid,
 // from memory
-constexpr int kPickEpl = 8;
+template <int NT = 256>
 struct PickCands {
+    static constexpr int kPickEpl = 2048 / NT;
     float v[kPickEpl];
     int i[kPickEpl];
     bool inreg;
     __device__ __forceinline__ void load(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand, int tid) {
-        inreg = ncand <= 256 * kPickEpl;
+        inreg = ncand <= NT * kPickEpl;
 #pragma unroll
         for (int e = 0; e < kPickEpl; ++e) {
-            const int t = tid + 256 * e;
+            const int t = tid + NT * e;
             const bool ok = inreg && t < ncand;
             v[e] = ok ? cand_val[t] : -1.0f;
             i[e] = ok ? cand_idx[t] : 0x7fffffff;
@@ -431,9 +432,9 @@ struct PickCands {
     __device__ __forceinline__ void each(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int ncand, int tid, F&& f) const {
         if (inreg) {
 #pragma unroll
-            for (int e = 0; e < kPickEpl; ++e) f(v[e], i[e], tid + 256 * e);
+            for (int e = 0; e < kPickEpl; ++e) f(v[e], i[e], tid + NT * e);
         } else {
-            for (int t = tid; t < ncand; t += 256) f(cand_val[t], cand_idx[t], t);
+            for (int t = tid; t < ncand; t += NT) f(cand_val[t], cand_idx[t], t);
         }
     }
 };
@@ -442,27 +443,30 @@ struct PickCands {
 // candidates; ||r||^2 comes from the sweep's prologue (st->rnorm2).  Publishes (|<a, r>| exact, atom) as pval[0] / pidx[0]: the
 // one "partial" k_qr1 (mode 1, nblk = 1) takes its arg-max from -- its guards (already selected, full support) apply as in the
 // exact path.  dynamic LDS: the Float64 residual image (r_slot layout).
-template <typename TA, int U>
-__global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
+// NT threads: every wave rescores one window column at a time, so 16 waves finish a 10-15 column window (the int8 image's) in one
+// round where 4 waves needed three or four.
+template <typename TA, int U, int NT = 1024>
+__global__ __launch_bounds__(NT) void k_pick1(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, double* __restrict__ pval, int* __restrict__ pidx, double cert_abs, double cert_rel,
                                                int kwin, int skipmask, unsigned* __restrict__ tickets, int nparts, double cert_abs2,
                                                int mp_select) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
-    __shared__ double sc[8];
+    constexpr int NWV = NT / kWave;
+    __shared__ double sc[NWV];
     __shared__ double red[kWinMax];
     __shared__ int wi_[kWinMax];
-    __shared__ float fsc[4];
+    __shared__ float fsc[NWV];
     __shared__ int cnt;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int p = tid; p < nparts; p += 256) tickets[p * kScrTicketStride] = 0u;  // (the sweep has ended: kernel boundary) ready for the next one
+    for (int p = tid; p < nparts; p += NT) tickets[p * kScrTicketStride] = 0u;  // (the sweep has ended: kernel boundary) ready for the next one
     if (st->done & skipmask) return;
     if (tid == 0) cnt = 0;
     const int nchunk = (Mv + ROWS - 1) / ROWS;
     const int Mlds = nchunk * ROWS;
-    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * NT) {
         f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
         if (m0 < Mr) {
             lo = reinterpret_cast<const f64x2*>(r + m0)[0];
@@ -473,14 +477,16 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
     }
     const double n2 = st->rnorm2;
     // the candidates: one unrolled batch of loads into registers (a rolled loop waits for every load in turn) when they fit
-    PickCands pc;
+    PickCands<NT> pc;
     pc.load(cand_val, cand_idx, ncand, tid);
     float m1 = -1.0f;
     pc.each(cand_val, cand_idx, ncand, tid, [&](float v, int, int) { m1 = fmaxf(m1, v); });
     for (int sft = 32; sft >= 1; sft >>= 1) m1 = fmaxf(m1, __shfl_xor(m1, sft, kWave));
     if (lane == 0) fsc[wave] = m1;
     __syncthreads();  // (also: cnt = 0 and the residual image are visible)
-    m1 = fmaxf(fmaxf(fsc[0], fsc[1]), fmaxf(fsc[2], fsc[3]));
+    m1 = fsc[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m1 = fmaxf(m1, fsc[w]);
     if (!(m1 >= 0.0f)) {  // no candidate at all: k_qr1 sees an invalid atom and stops the solve as the exact path would
         if (tid == 0) {
             pval[0] = -1.0;
@@ -507,10 +513,12 @@ __global__ __launch_bounds__(256) void k_pick1(const TA* __restrict__ A, int64_t
     __syncthreads();
     if (lane == 0) sc[wave] = cb;
     __syncthreads();
-    cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
+    cb = sc[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) cb = fmax(cb, sc[w]);
     const int nall = cnt;
     const int nw = min(nall, kwin);
-    for (int q = wave; q < nw; q += 4) {
+    for (int q = wave; q < nw; q += NWV) {
         const double exq = wave_col_dot<TA, U>(A + (int64_t)wi_[q] * ld, Mv, nchunk, rimg, lane);
         if (lane == 0) red[q] = exq;
     }
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
     // order (value desc, index asc) -- indices are distinct, so nothing has to be marked
     float pv = __builtin_inff(), mS = -1.0f;
     int pi = -1;
-    PickCands pc;
+    PickCands<256> pc;
     pc.load(cand_val, cand_idx, ncand, tid);
     for (int sidx = 0; sidx < S; ++sidx) {
         float bv = -1.0f;

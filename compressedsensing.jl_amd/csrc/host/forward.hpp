@@ -436,6 +436,11 @@ extern "C" int csmp_mp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, con
     // pick is repeated with the exact sweep
     bool screened = screened_on(ctx);
     if (screened) CHECK(screened_ensure(ctx));
+    ctx->scr_lone = true;  // (one solve at a time: reset on every way out below)
+    struct LoneReset {
+        csmp_ctx* c;
+        ~LoneReset() { c->scr_lone = false; }
+    } lone_reset{ctx};
     for (int attempt = 0; attempt < 2; ++attempt) {
         CHECK(upload_b(ctx, b, b_dtype));
         if (nnz0 > 0) CHECK(upload_support(ctx, idx0, val0, nnz0));

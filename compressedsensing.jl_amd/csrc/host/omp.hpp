@@ -122,6 +122,11 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     bool capacity_stop = false;
     bool screened = screened_on(ctx);
     if (screened) CHECK(screened_ensure(ctx));
+    struct LoneGuard {  // (csmp_omp is one solve at a time)
+        csmp_ctx* c;
+        explicit LoneGuard(csmp_ctx* x) : c(x) { c->scr_lone = true; }
+        ~LoneGuard() { c->scr_lone = false; }
+    } lone_guard(ctx);
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool uncertain = false;
         for (int pass = 0; pass < 2; ++pass) {

@@ -39,20 +39,26 @@ static int screened_ensure(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
-template <typename TA>
-static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask, int mp_select = 0) {
+// NT = 1024 when the solve runs alone (16 waves rescore the window in one round); 256 in the batch forms, where a 1024-thread
+// workgroup (126 registers) would not fit on a CU beside another solve's sweep workgroup and would wait for one to finish
+template <typename TA, int NT>
+static hipError_t pick1_launch_t(csmp_ctx* ctx, int ncand, int skipmask, int mp_select) {
     Solver& s = ctx->s;
     constexpr int U = sizeof(TA) == 4 ? 16 : 8;
     const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
-    auto kern = k_pick1<TA, U>;
+    auto kern = k_pick1<TA, U, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
+    hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
                        ncand, s.st, (const double*)s.r, s.Mpad, s.pval, s.pidx, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin, skipmask,
                        s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2, mp_select);
     return hipGetLastError();
+}
+template <typename TA>
+static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask, int mp_select = 0) {
+    return ctx->scr_lone ? pick1_launch_t<TA, 1024>(ctx, ncand, skipmask, mp_select) : pick1_launch_t<TA, 256>(ctx, ncand, skipmask, mp_select);
 }
 
 template <typename TA>
