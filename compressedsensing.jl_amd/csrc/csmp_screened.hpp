@@ -555,28 +555,29 @@ __global__ __launch_bounds__(NT) void k_pick1(const TA* __restrict__ A, int64_t 
 // and ranked; certified when the S-th exact value beats the bound of every atom that was not rescored (a sweep workgroup's 4th
 // entry inside the window hides the atoms behind it: its bound counts).  Output: cands[0..S), cvals, ncands -- what k_top_merge
 // hands to the append kernels of the exact path.  S <= kTopSmall.
-template <typename TA, int U>
-__global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
+template <typename TA, int U, int NT = 256>
+__global__ __launch_bounds__(NT) void k_pickS(const TA* __restrict__ A, int64_t ld, int Mv, const float* __restrict__ cand_val,
                                                const int* __restrict__ cand_idx, int ncand, DevState* st, const double* __restrict__ r,
                                                int Mr, int S, int* __restrict__ cands, double* __restrict__ cvals,
                                                int* __restrict__ ncands, double cert_abs, double cert_rel, int kwin, int skipmask,
                                                unsigned* __restrict__ tickets, int nparts, double cert_abs2) {
     extern __shared__ __attribute__((aligned(16))) double rimg[];
-    __shared__ double sc[8];
+    constexpr int NWV = NT / kWave;
+    __shared__ double sc[NWV];
     __shared__ double red[kWinMax];
     __shared__ int wi_[kWinMax];
-    __shared__ float fsv[4];
-    __shared__ int fsi[4];
+    __shared__ float fsv[NWV];
+    __shared__ int fsi[NWV];
     __shared__ int cnt;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int p = tid; p < nparts; p += 256) tickets[p * kScrTicketStride] = 0u;
+    for (int p = tid; p < nparts; p += NT) tickets[p * kScrTicketStride] = 0u;
     if (st->done & skipmask) return;
     if (tid == 0) cnt = 0;
     const int nchunk = (Mv + ROWS - 1) / ROWS;
     const int Mlds = nchunk * ROWS;
-    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * NT) {
         f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
         if (m0 < Mr) {
             lo = reinterpret_cast<const f64x2*>(r + m0)[0];
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
     // order (value desc, index asc) -- indices are distinct, so nothing has to be marked
     float pv = __builtin_inff(), mS = -1.0f;
     int pi = -1;
-    PickCands<256> pc;
+    PickCands<NT> pc;
     pc.load(cand_val, cand_idx, ncand, tid);
     for (int sidx = 0; sidx < S; ++sidx) {
         float bv = -1.0f;
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
         __syncthreads();
         bv = fsv[0];
         bi = fsi[0];
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NWV; ++w)
             if (fsv[w] > bv || (fsv[w] == bv && fsi[w] < bi)) {
                 bv = fsv[w];
                 bi = fsi[w];
@@ -650,10 +651,12 @@ __global__ __launch_bounds__(256) void k_pickS(const TA* __restrict__ A, int64_t
     __syncthreads();
     if (lane == 0) sc[wave] = cb;
     __syncthreads();
-    cb = fmax(fmax(sc[0], sc[1]), fmax(sc[2], sc[3]));
+    cb = sc[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) cb = fmax(cb, sc[w]);
     const int nall = cnt;
     const int nw = min(nall, kwin);
-    for (int q = wave; q < nw; q += 4) {
+    for (int q = wave; q < nw; q += NWV) {
         const double exq = wave_col_dot<TA, U>(A + (int64_t)wi_[q] * ld, Mv, nchunk, rimg, lane);
         if (lane == 0) red[q] = fabs(exq);
     }

@@ -128,6 +128,11 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     bool capacity_stop = false;
     bool screened = screened_on(ctx) && l <= kTopSmall;
     if (screened) CHECK(screened_ensure(ctx));
+    ctx->scr_lone = true;  // (one solve at a time: the pick kernel may take a whole CU)
+    struct LoneReset {
+        csmp_ctx* c;
+        ~LoneReset() { c->scr_lone = false; }
+    } lone_reset{ctx};
     bool block = !ctx->force_reorth && l <= kPanelMax;
     for (int attempt = 0; attempt < 4; ++attempt) {
         CHECK(upload_b(ctx, b, b_dtype));

@@ -61,20 +61,24 @@ static hipError_t pick1_launch(csmp_ctx* ctx, int ncand, int skipmask, int mp_se
     return ctx->scr_lone ? pick1_launch_t<TA, 1024>(ctx, ncand, skipmask, mp_select) : pick1_launch_t<TA, 256>(ctx, ncand, skipmask, mp_select);
 }
 
-template <typename TA>
-static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {
+template <typename TA, int NT>
+static hipError_t pickS_launch_t(csmp_ctx* ctx, int ncand, int S, int skipmask) {
     Solver& s = ctx->s;
     constexpr int U = sizeof(TA) == 4 ? 16 : 8;
     const size_t lds = b_pick_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)));
-    auto kern = k_pickS<TA, U>;
+    auto kern = k_pickS<TA, U, NT>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(1), dim3(256), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
+    hipLaunchKernelGGL(kern, dim3(1), dim3(NT), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const float*)s.scr_val, (const int*)s.scr_idx,
                        ncand, s.st, (const double*)s.r, s.Mpad, S, s.cands, s.cvals, s.ncands, ctx->scr_cert_abs, ctx->scr_cert_rel, ctx->scr_kwin,
                        skipmask, s.scr_tickets, ctx->scr_grid / kScrPartWgs + 1, ctx->scr_cert_abs2);
     return hipGetLastError();
+}
+template <typename TA>
+static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) {  // (workgroup size: as pick1_launch)
+    return ctx->scr_lone ? pickS_launch_t<TA, 1024>(ctx, ncand, S, skipmask) : pickS_launch_t<TA, 256>(ctx, ncand, S, skipmask);
 }
 
 // the sweep over the bf16 image: candidates of every workgroup into s.scr_val / s.scr_idx
