@@ -147,6 +147,7 @@ struct csmp_ctx {
     int scr_grid = 0;                           // workgroups of k_sweep_bf16
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
     int scr_kwin = 0, scr_cert_mode = -1;
+    int scr_image = 1;       // the image the screened sweeps of this context read: 1 bf16, 2 int8 (option 2 on a flat dictionary)
     bool scr_lone = false;   // the solve in progress runs alone on the GPU (csmp_omp, csmp_mp): the pick kernel may take a whole CU
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
     int opt_batch_screen = 2;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>), 2 (default) int8 where the dictionary is flat
@@ -232,6 +233,7 @@ struct DevTmp {
 // defined in host/batched.hpp and host/screened.hpp (included later); used by the omp drivers
 static int batch_dict(csmp_ctx* ctx);
 static int batch_dict8(csmp_ctx* ctx);
+static int batch_meta(csmp_ctx* ctx);
 static int batch_colnorm(csmp_ctx* ctx);
 static int screened_ensure(csmp_ctx* ctx);
 // the screened sweep is asked for and this dictionary fits its kernels (else: the exact sweep, silently -- the results are the same)

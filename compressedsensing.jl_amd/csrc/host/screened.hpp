@@ -3,9 +3,13 @@
 
 // bf16 image, certificate coefficients, sweep grid: once per dictionary / option value
 static int screened_ensure(csmp_ctx* ctx) {
-    const bool i8 = ctx->opt_screened == 2;
-    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
+    // the int8 image only where one step resolves every column (see csmp_omp_batch_mfma): a dictionary that is not flat gets the
+    // bf16 image instead of a screen that certifies nothing
+    CHECK(batch_meta(ctx));
     Batch& b = ctx->bt;
+    const bool i8 = ctx->opt_screened == 2 && b.amax_host <= 8.0f * b.arms_host;
+    ctx->scr_image = i8 ? 2 : 1;
+    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
     if (i8) {  // int8 image: statistical bound only (see csmp_omp_batch_mfma, host/batched.hpp)
         if (ctx->scr_cert_mode != 2) {
             CHECK(batch_colnorm(ctx));
@@ -88,7 +92,7 @@ static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip,
     const bool timed = prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
     const int lc = wide ? kScrCandK : kScrCand;  // candidates listed per workgroup (wide: Subspace Pursuit's top-k)
-    if (ctx->opt_screened == 2) {  // the int8 image: chunks of 1024 rows
+    if (ctx->scr_image == 2) {  // the int8 image: chunks of 1024 rows
         const int nchunk = (b.Mk8 + 1023) / 1024;
         const size_t lds = sweep_i8_lds_bytes(b.Mk8, lc);
 #define CSMP_SCR8L(U, DD, FULL, LCV)                                                                                                      \
@@ -219,6 +223,7 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
         tb.Npad = pb.Npad;
         tb.n_atiles = pb.n_atiles;
         tb.amax_host = pb.amax_host;
+        tb.arms_host = pb.arms_host;
         tb.meta_valid = true;
     }
     if (ctx->bt.a8_valid && !twin->bt.a8_valid) {

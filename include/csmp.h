@@ -236,7 +236,8 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 #define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
 #define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) (k <= 4096): 0 (default) every sweep reads
                                       the f32/f64 dictionary (exact, 4 bytes per element); 1 the sweep reads the bf16 image (2 bytes
-                                      per element, f32 accumulate), 2 the int8 image (1 byte per element under one step max|A|/127,
+                                      per element, f32 accumulate), 2 the int8 image where the dictionary is flat (max|A| <= 8 rms of its entries;
+                                      otherwise the bf16 image) (1 byte per element under one step max|A|/127,
                                       the residual quantised per sweep, exact integer accumulation) and only SCREENS: the best
                                       candidates are rescored in Float64 from the master dictionary under the batched variant's
                                       certificate (1: CSMP_OPT_BATCH_CERT selects it; 2: the statistical one; gomp: the whole

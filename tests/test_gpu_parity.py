@@ -2118,3 +2118,26 @@ def test_batched_screen_auto_rule(cs, oracle, D):
         assert "i8" in d.ctx.batch_screen_kernel()
         assert np.array_equal(nnz, n2) and np.array_equal(idx, i2) and np.allclose(val, v2, rtol=1e-7, atol=1e-10), st
         d.ctx.set_option("batch_screen", 2)
+
+
+def test_screened_sweep_int8_image_only_on_flat_dictionaries(cs, oracle, D):
+    """CSMP_OPT_SCREENED_SWEEP = 2 on a dictionary with spikes beside a dense basis ([I, G]: max|A| / rms = sqrt(M)): one int8 step
+    would leave the dense atoms a handful of levels, so the sweeps read the bf16 image instead -- the picks certify (no solve is
+    repeated) and the results are the oracle's."""
+    rng = np.random.default_rng(32)
+    M, k = 256, 8
+    G = rng.standard_normal((M, 768))
+    G /= np.linalg.norm(G, axis=0)
+    A = np.asfortranarray(np.hstack([np.eye(M), G]).astype(np.float32))
+    d = D(A)
+    d.ctx.set_option("screened_sweep", 2)
+    d.ctx.screened_stats(reset=True)
+    for s in range(6):
+        sup = rng.choice(A.shape[1], size=k, replace=False)
+        y = cs.perturb(A[:, sup].astype(np.float64) @ rng.choice(np.array([-1.0, 1.0]), size=k), 5e-3, rng=rng)
+        ref = oracle.omp(A, y, k, EPS32)
+        got = d.ctx.omp(y, k, EPS32)
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[2], ref[2]) and close(got[1], ref[1], tight=False)
+    st = d.ctx.screened_stats()
+    assert st["solves"] == 6 and st["fallbacks"] <= 1, st
+    d.ctx.set_option("screened_sweep", 0)
