@@ -1950,7 +1950,8 @@ def test_screened_sweep_full_size_config5_gomp(cs, oracle):
 
 
 # ------------------------------------------------------------------ int8 screening GEMM of the batched path (CSMP_OPT_BATCH_SCREEN)
-@pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9), (4096, 2500, 10, 260)])
+@pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9), (4096, 2500, 10, 260),
+                                   (8192, 600, 6, 8), (8000, 520, 5, 3)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_batched_int8_screen_matches_oracle(cs, oracle, D, shape, dtype):
     """csmp_omp_batch_mfma with int8 operands (k_b_screen256p<true>: v_mfma_i32_16x16x64_i8, exact integer accumulation, one step
