@@ -572,6 +572,13 @@ def run_twostage(args, cs, torch, dev, At, D, emit=True):
         if args.workload == "ompr":
             return D.ctx.ompr(b, K_ATOMS, 1e-6)[2]
         return D.ctx.srr(b, K_ATOMS, 1e-12, -1, 1, 1)[2]
+    # ompr with the screened sweep (--screened): the result of the first timed signal is compared with the exact path's
+    image = 0
+    if args.workload == "ompr" and getattr(args, "screened", False):
+        image = 2 if getattr(args, "screen_image", "bf16") == "int8" else 1
+        exact0 = D.ctx.ompr(sigs[W], K_ATOMS, 1e-6)
+        D.ctx.set_option("screened_sweep", image)
+        D.ctx.screened_stats(reset=True)
     for w in range(W):
         solve(sigs[w])
     D.ctx.profile_enable(1)
@@ -582,8 +589,16 @@ def run_twostage(args, cs, torch, dev, At, D, emit=True):
         iters += solve(sigs[s_])
     dt = time.perf_counter() - t0
     sweeps, sweep_ms = D.ctx.profile_read(reset=True)
-    alg = M * N * 4
+    alg = M * N * ({0: 4, 1: 2, 2: 1}[image])
     avg = sweep_ms / max(sweeps, 1) / 1e3
+    scr_info = None
+    if image:
+        st_ = D.ctx.screened_stats(reset=True)
+        got0 = D.ctx.ompr(sigs[W], K_ATOMS, 1e-6)
+        D.ctx.set_option("screened_sweep", 0)
+        scr_info = {"image": "int8" if image == 2 else "bf16", "stats": st_, "stats_count": "sweeps (one certified selection each)",
+                    "first_timed_solve_equals_exact_path": bool(np.array_equal(got0[0], exact0[0]) and got0[2] == exact0[2]
+                                                                and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12))}
     name = {"ompr": "OMP with replacement", "srr": "stepwise regression with replacement (oblivious start, l=1)"}[args.workload]
     out = {"metric": f"{name} solves/sec at m=4096,n=65536,k=256", "value": K / dt, "unit": "solves/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -592,9 +607,13 @@ def run_twostage(args, cs, torch, dev, At, D, emit=True):
                       "iterations": int(iters), "iterations_per_s": iters / dt, "sweeps_timed": int(sweeps)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
-                        "kernel": "csmp::k_sweep_pf<float,16,true>" if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
+                        "kernel": ("csmp::k_sweep_i8<2,3,true>" if image == 2 else "csmp::k_sweep_bf16<2,3,true>" if image == 1 else "csmp::k_sweep_pf<float,16,true>")
+                        if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     D.ctx.profile_enable(False)
+    if scr_info:
+        out["metric"] += ", screened sweep (%s image, certified selections, exact results)" % scr_info["image"]
+        out["screened"] = scr_info
     # the same solves, three in flight (api.solve_in_flight: the Dictionary's context + two clones, a host thread each): one
     # signal's long latency-bound chain (rank-one exchanges, selections, host decisions) under the others' sweeps
     def one(c, b):
@@ -951,9 +970,10 @@ def main():
                     sec[name] = {"error": repr(e)}
             # SURVEY 8(f) rows 2 and 3 at the configs[1] shape: forward regression (batched ticks), ompr, srr
             import copy
-            for name, wl, st_, wu in (("fr_8f3", "fr", 6, 3), ("ompr_8f2", "ompr", 3, 1), ("srr_8f2", "srr", 3, 1)):
+            for name, wl, st_, wu in (("fr_8f3", "fr", 6, 3), ("ompr_8f2", "ompr", 3, 1), ("ompr_8f2_screened_int8", "ompr", 3, 1), ("srr_8f2", "srr", 3, 1)):
                 a2 = copy.copy(args)
                 a2.workload, a2.steps, a2.warmup = wl, st_, wu
+                a2.screened, a2.screen_image = name.endswith("screened_int8"), "int8"
                 try:
                     sec[name] = (run_fr if wl == "fr" else run_twostage)(a2, cs, torch, dev, At, D, emit=False)
                 except Exception as e:  # noqa: BLE001

@@ -767,4 +767,32 @@ __global__ void k_spk_cert(const double* __restrict__ cvals, const int* __restri
 }
 
 
+// <a_j, r> (signed, Float64) for a short list of atoms -- the correlations ompr needs on its SUPPORT (x.nzval = Ar[x.nzind],
+// src/twostage.jl:158-160) when the sweep ran on an image and left no exact correlation vector: one wave per column.
+template <typename TA, int U>
+__global__ __launch_bounds__(256) void k_cols_dot(const TA* __restrict__ A, int64_t ld, int Mv, const int* __restrict__ cols, int n,
+                                                  const double* __restrict__ r, int Mr, double* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double rimg[];
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = (Mv + ROWS - 1) / ROWS;
+    const int Mlds = nchunk * ROWS;
+    for (int m0 = 4 * tid; m0 < Mlds; m0 += 4 * 256) {
+        f64x2 lo = (f64x2)0.0, hi = (f64x2)0.0;
+        if (m0 < Mr) {
+            lo = reinterpret_cast<const f64x2*>(r + m0)[0];
+            hi = reinterpret_cast<const f64x2*>(r + m0)[1];
+        }
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0)) = lo;
+        *reinterpret_cast<f64x2*>(rimg + r_slot<VEC>(m0 + 2)) = hi;
+    }
+    __syncthreads();
+    for (int t = blockIdx.x * 4 + wave; t < n; t += 4 * gridDim.x) {
+        const double ex = wave_col_dot<TA, U>(A + (int64_t)cols[t] * ld, Mv, nchunk, rimg, lane);
+        if (lane == 0) out[t] = ex;
+    }
+}
+
+
 }  // namespace csmp

@@ -246,6 +246,7 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin);
 static int launch_block_appends(csmp_ctx* ctx, int n, int skipmask);
 static int sp_select_screened(csmp_ctx* ctx, int k);
 static int mp_step_screened(csmp_ctx* ctx);
+static int ompr_sweep_screened(csmp_ctx* ctx, const int* cols_dev, int n);
 static int launch_topS(csmp_ctx* ctx, int S);
 static int omp_step_screened(csmp_ctx* ctx, double eps, int check_eps, bool optimistic);
 static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,

@@ -200,6 +200,27 @@ static int mp_step_screened(csmp_ctx* ctx) {
     return launch_mp_update(ctx);
 }
 
+// ompr's update! with the screened sweep: the image sweep, the certified arg-max (which also does k_select's job) and the exact
+// correlations on the support (cols: the support's atoms on the device, n of them) into s.coef
+static int ompr_sweep_screened(csmp_ctx* ctx, const int* cols_dev, int n) {
+    Solver& s = ctx->s;
+    CHECK(launch_sweep_bf16(ctx, 0.0, 0, 0));
+    HIPCHECK(ctx->dtype == CSMP_F32 ? pick1_launch<float>(ctx, ctx->scr_grid * kScrCand, 0, 1) : pick1_launch<double>(ctx, ctx->scr_grid * kScrCand, 0, 1));
+    const size_t lds = b_pick_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2);
+    const int grid = std::max(1, std::min((n + 3) / 4, ctx->prop.multiProcessorCount));
+    if (ctx->dtype == CSMP_F32) {
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_cols_dot<float, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_cols_dot<float, 16>), dim3(grid), dim3(256), lds, ctx->stream, (const float*)ctx->dA, ctx->ld, ctx->Mv, cols_dev, n,
+                           (const double*)s.r, s.Mpad, s.coef);
+    } else {
+        if (lds > 48 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_cols_dot<double, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_cols_dot<double, 8>), dim3(grid), dim3(256), lds, ctx->stream, (const double*)ctx->dA, ctx->ld, ctx->Mv, cols_dev, n,
+                           (const double*)s.r, s.Mpad, s.coef);
+    }
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
 // update!(P::GOMP, x, l) with the screened sweep: bf16 sweep -> certified top-l pick -> the exact path's (panel) appends
 static int gomp_update_screened(csmp_ctx* ctx, int64_t l, double eps, int check_eps, int skipmask, bool block) {
     l = std::min<int64_t>(l, ctx->N);

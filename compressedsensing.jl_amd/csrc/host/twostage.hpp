@@ -24,12 +24,38 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     if (use_downdate) CHECK(del_ensure(ctx));
     if (tmode) CHECK(tinv_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
+    // CSMP_OPT_SCREENED_SWEEP: the sweeps read the image; the oblivious acquisition's top-k set and every update!'s arg-max are
+    // certified (host/screened.hpp), the correlations on the support are computed exactly beside them; a sweep whose
+    // selection could not be certified is repeated exactly on the spot (the host reads the state after every sweep anyway)
+    const bool screened = screened_on(ctx) && k <= 4096;
+    if (screened) CHECK(screened_ensure(ctx));
+    ctx->scr_lone = true;
+    struct LoneReset {
+        csmp_ctx* c;
+        ~LoneReset() { c->scr_lone = false; }
+    } lone_reset{ctx};
     // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
-    CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-    CHECK(launch_topS(ctx, (int)k));
     std::vector<int> top((size_t)k);
-    HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    {
+        bool scr = screened;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int flag = 0;
+            if (scr) {
+                CHECK(sp_select_screened(ctx, (int)k));
+                HIPCHECK(hipMemcpyAsync(&flag, s.scr_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+            } else {
+                CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+                CHECK(launch_topS(ctx, (int)k));
+            }
+            HIPCHECK(hipMemcpyAsync(top.data(), s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            if (!scr) break;
+            ctx->scr_solves += 1;
+            if (!flag) break;
+            ctx->scr_fallbacks += 1;
+            scr = false;
+        }
+    }
     std::sort(top.begin(), top.end());
     CHECK(ls_on_columns(ctx, top));
     std::vector<int64_t> xi;
@@ -44,23 +70,37 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     CHECK(residual_norm(ctx, &resnorm));  // :192
     int64_t it = 0;
     std::vector<double> cs((size_t)k), call;
+    int unc_seen = 0;  // DevState::uncertain seen so far (the screened sweeps count up in it)
     while (it < maxiter) {  // :193
         const double oldnorm = resnorm;
         bool have_norm = false;
         // update!(P, x): Ar = x + A'r (eta = 1), arg-max over atoms outside the support
-        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-        CHECK(launch_select(ctx, 0, 0));
         std::vector<int> cur(xi.begin(), xi.end());
-        HIPCHECK(hipMemcpyAsync(s.cands, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
-        HIPCHECK(hipGetLastError());
         DevState hs;
-        {
-            PinFetch f(ctx);
-            CHECK(f.begin((size_t)k * 8 + sizeof hs + 16));
-            CHECK(f.add(cs.data(), s.coef, (size_t)k * 8));
-            CHECK(f.add(&hs, s.st, sizeof hs));
-            CHECK(f.wait());
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool scr = screened && attempt == 0;
+            HIPCHECK(hipMemcpyAsync(s.cands, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (scr) {
+                CHECK(ompr_sweep_screened(ctx, s.cands, (int)k));
+            } else {
+                CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+                CHECK(launch_select(ctx, 0, 0));
+                hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
+                HIPCHECK(hipGetLastError());
+            }
+            {
+                PinFetch f(ctx);
+                CHECK(f.begin((size_t)k * 8 + sizeof hs + 16));
+                CHECK(f.add(cs.data(), s.coef, (size_t)k * 8));
+                CHECK(f.add(&hs, s.st, sizeof hs));
+                CHECK(f.wait());
+            }
+            if (!scr) break;
+            ctx->scr_solves += 1;
+            const bool degenerate = std::binary_search(xi.begin(), xi.end(), (int64_t)hs.cand);
+            if (hs.uncertain == unc_seen && !degenerate) break;  // certified, and the arg-max is a new atom
+            if (hs.uncertain != unc_seen) ctx->scr_fallbacks += 1;
+            unc_seen = hs.uncertain;  // (repeat with the exact sweep: it also leaves the correlation vector the degenerate case scans)
         }
         int64_t cand = hs.cand;
         double ccand = hs.cval;

@@ -234,7 +234,7 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 #define CSMP_OPT_TWOSTAGE_UPDATE 8 /* ompr's exchange step: 0 (default) explicit inverse T = R^-1 beside R, 1 Givens down-date of R,
                                       2 refactorise from scratch (the reference's own cost model, src/twostage.jl:171-174) */
 #define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
-#define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) (k <= 4096): 0 (default) every sweep reads
+#define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) and csmp_ompr (k <= 4096): 0 (default) every sweep reads
                                       the f32/f64 dictionary (exact, 4 bytes per element); 1 the sweep reads the bf16 image (2 bytes
                                       per element, f32 accumulate), 2 the int8 image where the dictionary is flat (max|A| <= 8 rms of its entries;
                                       otherwise the bf16 image) (1 byte per element under one step max|A|/127,

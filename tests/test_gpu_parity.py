@@ -2145,3 +2145,26 @@ def test_screened_sweep_int8_image_only_on_flat_dictionaries(cs, oracle, D):
     st = d.ctx.screened_stats()
     assert st["solves"] == 6 and st["fallbacks"] <= 1, st
     d.ctx.set_option("screened_sweep", 0)
+
+
+@pytest.mark.parametrize("cfg", [(32, 64, 3, np.float64), (128, 512, 12, np.float32), (100, 333, 9, np.float64), (256, 2048, 40, np.float32), (512, 8192, 48, np.float32)])
+def test_screened_sweep_ompr_matches_oracle(cs, oracle, D, cfg):
+    """OMP with replacement on the screened sweep (certified top-k of the oblivious acquisition, certified arg-max of every update!,
+    exact correlations on the support; an uncertified sweep repeated exactly on the spot): supports, coefficients and iteration
+    counts of the oracle (src/twostage.jl:110-202) on both images, noisy signals that make the replacement loop work."""
+    n, m, k, dtype = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + m + k, dtype=dtype)
+    d = D(A)
+    for seed, noise in ((0, 0.0), (1, 5e-3), (2, 2e-1)):
+        xs = cs.sparse_vector(m, k + 2, rng=seed)
+        y = A[:, xs.nzind].astype(np.float64) @ xs.nzval
+        if noise:
+            y = cs.perturb(y, noise, rng=seed + 50)
+        ref = oracle.ompr(A, y, k, 1e-6, -1)
+        for image in (1, 2):
+            d.ctx.set_option("screened_sweep", image)
+            got = d.ctx.ompr(y, k, 1e-6)
+            assert np.array_equal(got[0], ref[0]), (seed, image, got, ref)
+            assert close(got[1], ref[1], tight=False)
+            assert got[2] == ref[2], "iterations"
+        d.ctx.set_option("screened_sweep", 0)
