@@ -63,7 +63,11 @@ while time.time() - t0 < budget:
             if k + l <= M:
                 for init in (1, 2):
                     cmp(f"srr{init}", D.ctx.srr(b, k, 1e-12, -1, init, l), oc.srr(A, b, k, 1e-12, -1, init, l), cfg + (l,), iters=True)
-            cmp("ompr", D.ctx.ompr(b, k, 1e-9), oc.ompr(A, b, k, 1e-9), cfg, iters=True)
+            ref_ompr = oc.ompr(A, b, k, 1e-9)
+            cmp("ompr", D.ctx.ompr(b, k, 1e-9), ref_ompr, cfg, iters=True)
+            D.ctx.set_option("screened_sweep", int(rng.integers(1, 3)))  # image sweeps, certified selections (bf16 / int8 image)
+            cmp("ompr_screened", D.ctx.ompr(b, k, 1e-9), ref_ompr, cfg, iters=True)
+            D.ctx.set_option("screened_sweep", 0)
         if noise > 0:
             cmp("rmp_d", D.ctx.rmp(b, noise), oc.rmp(A, b, noise), cfg)
             cmp("foba", D.ctx.foba(b, noise), oc.foba(A, b, noise), cfg)
