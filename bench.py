@@ -78,6 +78,66 @@ def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
     return best
 
 
+LINE_BUDGET = 3000  # bytes: the driver keeps ~8 KB of stdout tail; round 3's 30 KB line was cut and the record did not parse
+DETAIL_FILE = "bench_secondary.json"
+_ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_timed", "avg_launch_us",
+              "algorithmic_bytes_per_launch", "flops_per_launch")
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+             "dtype", "data", "signals_per_sec", "config", "roofline", "cpu_baseline", "secondary", "secondary_file", "gather_check",
+             "ranks_seen", "matches_exact_path_on_sample", "batch_stats", "equals_unsharded_omp", "ranks_agree_on_first_support", "error")
+
+
+def _rnd(x):
+    """Floats to 6 significant digits (the line is a report, not a checkpoint)."""
+    if isinstance(x, float):
+        return float("%.6g" % x)
+    if isinstance(x, dict):
+        return {k: _rnd(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_rnd(v) for v in x]
+    return x
+
+
+def headline(out):
+    """The ONE compact JSON object bench.py prints as its LAST stdout line (<= LINE_BUDGET bytes): the contract's fields, the
+    headline roofline and cpu_baseline, and ONE scalar per secondary workload.  Everything else (per-workload rooflines, notes,
+    option dumps) is the detail written to DETAIL_FILE by emit()."""
+    o = {k: out[k] for k in _TOP_KEYS if k in out}
+    if "roofline" in o:
+        r = out["roofline"]
+        o["roofline"] = {k: r[k] for k in _ROOF_KEYS if k in r}
+        if isinstance(o["roofline"].get("kernel"), str):
+            o["roofline"]["kernel"] = o["roofline"]["kernel"].split(" = ")[0].split(" (")[0][:64]
+    if "config" in o:
+        o["config"] = {k: (v if not isinstance(v, str) else v[:200]) for k, v in out["config"].items() if isinstance(v, (str, int, float, bool)) or v is None}
+    if isinstance(o.get("cpu_baseline"), dict):
+        c = out["cpu_baseline"]
+        o["cpu_baseline"] = {k: (c[k][:160] if isinstance(c[k], str) else c[k]) for k in ("value", "unit", "cores", "kind", "sample", "selection_order_matches_gpu", "error") if k in c}
+    if isinstance(o.get("secondary"), dict):
+        o["secondary"] = {name: (blk.get("value") if isinstance(blk, dict) and "error" not in blk else None) for name, blk in out["secondary"].items()}
+    if isinstance(o.get("metric"), str):
+        o["metric"] = o["metric"][:200]
+    o = _rnd(o)
+    line = json.dumps(o, separators=(",", ":"))
+    for drop in ("batch_stats", "ranks_seen", "gather_check", "secondary"):  # never needed at today's sizes: a guard, not a plan
+        if len(line) <= LINE_BUDGET:
+            break
+        o.pop(drop, None)
+        line = json.dumps(o, separators=(",", ":"))
+    return line
+
+
+def emit(out):
+    """Detail to DETAIL_FILE in the cwd (best effort), then the compact headline as the last stdout line."""
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            json.dump(out, f, indent=1)
+        out = dict(out, secondary_file=DETAIL_FILE)
+    except OSError:
+        pass
+    print(headline(out), flush=True)
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -553,7 +613,7 @@ def make_dictionary5(cs, torch, dev):
     return At5, cs.Dictionary(At5, device=dev.index)
 
 
-def run_twostage(args, cs, torch, dev, At, D, emit=True):
+def run_twostage(args, cs, torch, dev, At, D, show=True):
     """ompr / srr (src/twostage.jl) at the configs[1] shape, k = 256.  The signals carry 8 planted atoms more
     than the solvers may keep and noise 0.3, so that the replacement loops have work to do (tens of
     iterations); one step = one complete solve."""
@@ -625,12 +685,12 @@ def run_twostage(args, cs, torch, dev, At, D, emit=True):
     dt3 = time.perf_counter() - t0
     out["three_in_flight"] = {"solves": len(many), "ms_per_solve": dt3 / len(many) * 1e3, "solves_per_s": len(many) / dt3,
                               "iterations_equal_single": bool(sum(its[:K]) == iters)}
-    if emit:
-        print(json.dumps(out), flush=True)
+    if show:
+        emit(out)
     return out
 
 
-def run_fr(args, cs, torch, dev, At, D, emit=True):
+def run_fr(args, cs, torch, dev, At, D, show=True):
     """Forward regression / OLS (src/forward.jl) at the configs[1] shape, k = 256 atoms per signal.  One step = one
     complete fr(A, b, sparsity=256) solve; the signals are resident in HBM and go through csmp_fr_batch (three in
     flight per tick kernel, like the default workload)."""
@@ -664,8 +724,8 @@ def run_fr(args, cs, torch, dev, At, D, emit=True):
                                   "dictionary pass) fused with the two short append stages of two other signals",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     D.ctx.profile_enable(False)
-    if emit:
-        print(json.dumps(out), flush=True)
+    if show:
+        emit(out)
     return out
 
 
@@ -757,7 +817,7 @@ def run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen
             out["equals_unsharded_omp"] = bool(np.array_equal(ref[0], res["first"][0]) and np.array_equal(ref[2], res["first"][2]))
         if not res["ranks_agree_on_first_support"] or res["supports_gathered"] != world:
             out["error"] = "ranks disagree on the support of the first timed signal"
-        print(json.dumps(out), flush=True)
+        emit(out)
     D.close()
     return out
 
@@ -822,8 +882,8 @@ def main():
             At5, D5 = make_dictionary5(cs, torch, dev)
             if args.in_flight:
                 D5.ctx.set_option("solves_in_flight", args.in_flight)
-            print(json.dumps(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5,
-                                                  screened=(2 if args.screen_image == "int8" else 1) if args.screened else 0)), flush=True)
+            emit(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5,
+                                 screened=(2 if args.screen_image == "int8" else 1) if args.screened else 0))
             D5.close()
         return finish()
     At = make_dictionary(torch, dev)
@@ -839,8 +899,8 @@ def main():
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 9, 3
         if rank == 0:
-            print(json.dumps(measure_screened_omp(args.steps, args.warmup, torch, dev, At, D, D.eps,
-                                                  cert=1 if args.batch_cert == "rigorous" else 0, image=2 if args.screen_image == "int8" else 1)), flush=True)
+            emit(measure_screened_omp(args.steps, args.warmup, torch, dev, At, D, D.eps,
+                                      cert=1 if args.batch_cert == "rigorous" else 0, image=2 if args.screen_image == "int8" else 1))
         D.close()
         return finish()
     if args.workload == "batched":
@@ -851,7 +911,7 @@ def main():
                               screen=1 if args.batch_screen == "int8" else 0)
         if rank == 0:
             out["ranks_seen"], out["devices"] = ranks_seen, devices
-            print(json.dumps(out), flush=True)
+            emit(out)
         D.close()
         return finish()
     eps = D.eps  # eps(Float32): omp(A, b, k) default (src/matchingpursuit.jl:85)
@@ -915,7 +975,7 @@ def main():
             "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps, 3 signals pipelined)",
             "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64 (f32 dictionary, Float64 accumulate/QR)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "signals_per_sec": K * world / tmax,
             "config": {"workload": "configs[1]: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, "
                                    "k=256, planted +-1 256-sparse x0 + noise 5e-3, eps=eps(Float32)",
@@ -975,7 +1035,7 @@ def main():
                 a2.workload, a2.steps, a2.warmup = wl, st_, wu
                 a2.screened, a2.screen_image = name.endswith("screened_int8"), "int8"
                 try:
-                    sec[name] = (run_fr if wl == "fr" else run_twostage)(a2, cs, torch, dev, At, D, emit=False)
+                    sec[name] = (run_fr if wl == "fr" else run_twostage)(a2, cs, torch, dev, At, D, show=False)
                 except Exception as e:  # noqa: BLE001
                     sec[name] = {"error": repr(e)}
             D.close()
@@ -1001,7 +1061,7 @@ def main():
                                                     "equals_exact_path": sc["batch"]["equals_exact_path"], "fallbacks": sc["batch"]["stats"]["fallbacks"]}
             except Exception:  # noqa: BLE001
                 pass
-        print(json.dumps(out), flush=True)
+        emit(out)
     D.close()
     finish()
 
