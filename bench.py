@@ -143,7 +143,7 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=18)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="statistical", help="--workload batched: CSMP_OPT_BATCH_CERT")
+    p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="rigorous", help="--workload batched: CSMP_OPT_BATCH_CERT (rigorous is the library's default)")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
     p.add_argument("--workload", choices=["omp", "screened", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
@@ -155,7 +155,7 @@ def parse():
                         "multi-rank code; the numbers are NOT a scaling measurement")
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--batch-screen", choices=["bf16", "int8"], default="int8", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM; int8 is the library's default)")
+    p.add_argument("--batch-screen", choices=["bf16", "int8"], default="bf16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM; int8 needs --batch-cert statistical)")
     p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single / sp / sp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified selections)")
     p.add_argument("--screen-image", choices=["bf16", "int8"], default="bf16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 1 / 2)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
@@ -261,14 +261,14 @@ def per_signal_roofline(nsig, k, gram, us):
             "traffic": None, "note": "everything of the step that is not the screening launch; rescored window columns not counted"}
 
 
-def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=0, gram=0, nsig=1024, k=128, screen=1):
+def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=1, gram=0, nsig=1024, k=128, screen=0):
     """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128.
     A step = one batch of 1024 complete solves.  cert / gram: the options CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM of the
     contexts (include/csmp.h).  Returns the result dict on rank 0, None elsewhere."""
     eps = D.eps
     dsync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)  # (the gloo CPU test drives this function too)
     D.ctx.set_option("batch_cert", cert)
-    D.ctx.set_option("batch_screen", screen)  # 1 (the library's default): int8 operands for the screening GEMM (v_mfma_i32_16x16x64_i8); 0: bf16
+    D.ctx.set_option("batch_screen", screen)  # 0: bf16 operands; 1: int8 operands (v_mfma_i32_16x16x64_i8; statistical certificate only)
     t_setup = time.perf_counter()
     D.ctx.set_option("batch_gram", gram)
     B = make_signals_fast(torch, dev, At, rank * (K + W), (K + W) * nsig, k).reshape(K + W, nsig, M)
@@ -331,8 +331,8 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, ce
     D.ctx.omp_batch_device(B[W][:4].contiguous(), k, eps, i2, v2, n2)
     D.ctx.sync()
     same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
-    D.ctx.set_option("batch_cert", 0)
-    D.ctx.set_option("batch_screen", 2)  # (the library's default: int8 where the dictionary is flat)
+    D.ctx.set_option("batch_cert", 1)  # (back to the library's defaults)
+    D.ctx.set_option("batch_screen", 2)
     D.ctx.set_option("batch_gram", 0)  # (releases the 8 N^2 bytes)
     i8 = bool(screen) and not cert
     return {
@@ -1022,8 +1022,9 @@ def main():
                 sec["omp_c2_screened"] = {"error": repr(e)}
             # library defaults (int8 operands for the screen) / the rigorous certificate (bf16 operands) / + the resident Gram matrix /
             # the bf16 screen of rounds 1-2 with and without the Gram matrix
-            for name, cert, gram, scr in (("batched_c3", 0, 0, 1), ("batched_c3_rigorous", 1, 0, 0), ("batched_c3_gram", 0, 1, 1),
-                                          ("batched_c3_bf16", 0, 0, 0), ("batched_c3_bf16_gram", 0, 1, 0)):
+            # library defaults (the rigorous certificate) / + the resident Gram matrix / the opt-in statistical certificates
+            for name, cert, gram, scr in (("batched_c3", 1, 0, 0), ("batched_c3_gram", 1, 1, 0), ("batched_c3_statistical_int8", 0, 0, 1),
+                                          ("batched_c3_statistical_int8_gram", 0, 1, 1), ("batched_c3_statistical_bf16", 0, 0, 0)):
                 try:
                     sec[name] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False, cert=cert, gram=gram, screen=scr)
                 except Exception as e:  # noqa: BLE001

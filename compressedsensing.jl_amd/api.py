@@ -324,14 +324,15 @@ def solve_in_flight(A, signals, solve, in_flight=3):
                 out[s] = solve(ctxs[t], signals[s])
         except Exception as e:  # noqa: BLE001
             err[t] = e
+    th = [threading.Thread(target=work, args=(t,)) for t in range(1, T)]
     try:
-        th = [threading.Thread(target=work, args=(t,)) for t in range(1, T)]
         for x in th:
             x.start()
         work(0)
-        for x in th:
-            x.join()
     finally:
+        for x in th:  # (also when work(0) left through a BaseException: no clone is closed under a thread that still uses it)
+            if x.is_alive():
+                x.join()
         for c in ctxs[1:]:
             c.close()
         if tmp:
@@ -357,22 +358,30 @@ def omp_batch_mfma(A, B, k, eps=None, cert=None, gram=None):
     """omp_batch through the batched variant (BASELINE configs 3/4): one bf16 MFMA screening GEMM per step for all
     signals, Float64 rescoring of the screened atoms that could still be the exact maximum, and a per-step certificate;
     signals that fail it are re-solved by the exact path, so certified results equal omp_batch's.
-    cert: "statistical" (default: 8 sigma of independent bf16 roundings + the coherent scaling term) or "rigorous" (the
-    deterministic bound); gram: True keeps G = A'A resident on the GPU (8 N^2 bytes) and halves the append traffic
-    (csmp_set_option CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM, include/csmp.h)."""
+    cert: "rigorous" (the library's default: a deterministic error bound, a passed certificate proves the pick) or "statistical"
+    (opt-in: 8 sigma of independent roundings + a coherent term; narrower windows, faster, NOT a proof -- see
+    tests/test_gpu_parity.py::test_batched_certificate_against_adversarial_residuals); gram: True keeps G = A'A resident on the
+    GPU (8 N^2 bytes) and halves the append traffic (csmp_set_option CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM, include/csmp.h).
+    Options given here hold for this call only: a caller-owned Dictionary gets its own values back."""
     eps = _meta(A)[2] if eps is None else eps
     _check_eps(eps)
     D, tmp = _dict(A)
+    saved = {}
     try:
         if cert is not None:
+            saved["batch_cert"] = D.ctx.get_option("batch_cert")
             D.ctx.set_option("batch_cert", {"statistical": 0, "rigorous": 1}[cert])
         if gram is not None:
+            saved["batch_gram"] = D.ctx.get_option("batch_gram")
             D.ctx.set_option("batch_gram", int(bool(gram)))
         idx, val, nnz = D.ctx.omp_batch_mfma(B, int(k), float(eps))
         return [SparseVector(D.shape[1], idx[:n, s], val[:n, s]) for s, n in enumerate(nnz)]
     finally:
         if tmp:
             D.close()
+        else:
+            for key, v in saved.items():
+                D.ctx.set_option(key, v)
 
 
 # ------------------------------------------------------------------------------------ functors

@@ -122,6 +122,7 @@ static int batch_dict8(csmp_ctx* ctx) {
 static int batch_colnorm(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
     if (b.anorm_host >= 0.f) return CSMP_OK;
+    if (!b.amax) HIPCHECK(hipMalloc((void**)&b.amax, 4 * sizeof(float)));  // (a twin that took its parent's meta has none of its own)
     HIPCHECK(hipMemsetAsync(b.amax, 0, sizeof(float), ctx->stream));
     const unsigned grid = (unsigned)((ctx->N + 3) / 4);
     if (ctx->dtype == CSMP_F32)

@@ -137,7 +137,7 @@ struct csmp_ctx {
     bool sweep_full = false, sweep_nt = false;
     bool force_reorth = false;  // CSMP_OPT_FORCE_REORTH (test switch): always run the second Gram-Schmidt pass
     // options (csmp_set_option, include/csmp.h)
-    int opt_batch_cert = 0;        // CSMP_OPT_BATCH_CERT: 0 statistical, 1 rigorous
+    int opt_batch_cert = 1;        // CSMP_OPT_BATCH_CERT: 1 rigorous (default), 0 statistical (opt-in)
     int opt_batch_gram = 0;        // CSMP_OPT_BATCH_GRAM: resident G = A'A for csmp_omp_batch_mfma
     int opt_batch_window = 0;      // CSMP_OPT_BATCH_WINDOW: rescoring window capacity, 0 = default
     bool opt_ls_gram = true;       // CSMP_OPT_LS_GRAM: whole-set least squares by Gram + Cholesky
@@ -146,7 +146,7 @@ struct csmp_ctx {
     int64_t scr_solves = 0, scr_fallbacks = 0;  // screened solves made / repeated with the exact sweep (csmp_screened_stats)
     int scr_grid = 0;                           // workgroups of k_sweep_bf16
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
-    int scr_kwin = 0, scr_cert_mode = -1;
+    int scr_kwin = 0;
     int scr_image = 1;       // the image the screened sweeps of this context read: 1 bf16, 2 int8 (option 2 on a flat dictionary)
     bool scr_lone = false;   // the solve in progress runs alone on the GPU (csmp_omp, csmp_mp): the pick kernel may take a whole CU
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)

@@ -185,11 +185,7 @@ static int twins_ensure(csmp_ctx* ctx, int n) {
             const int rc = csmp_clone(ctx, &ctx->twins[t]);
             if (rc != CSMP_OK) return rc;
         }
-        csmp_ctx* c = ctx->twins[t];
-        c->force_reorth = ctx->force_reorth;
-        c->opt_ls_gram = ctx->opt_ls_gram;
-        c->opt_ls_gram_reuse = ctx->opt_ls_gram_reuse;
-        c->opt_twostage_update = ctx->opt_twostage_update;
+        copy_options(ctx->twins[t], ctx);
     }
     return CSMP_OK;
 }

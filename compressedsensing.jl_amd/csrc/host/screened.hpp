@@ -10,16 +10,15 @@ static int screened_ensure(csmp_ctx* ctx) {
     const bool i8 = ctx->opt_screened == 2 && b.amax_host <= 8.0f * b.arms_host;
     ctx->scr_image = i8 ? 2 : 1;
     CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
+    // The certificate's coefficients are recomputed on every call (a few flops; the column-norm reduction behind them is cached per
+    // dictionary in bt.anorm_host, which csmp_set_dictionary resets): nothing of a previous dictionary can survive in them.
     if (i8) {  // int8 image: statistical bound only (see csmp_omp_batch_mfma, host/batched.hpp)
-        if (ctx->scr_cert_mode != 2) {
-            CHECK(batch_colnorm(ctx));
-            ctx->scr_cert_abs = 8.0 * (double)b.astep / std::sqrt(12.0);
-            ctx->scr_cert_abs2 = 8.0 * (double)b.anorm_host / std::sqrt(12.0);
-            ctx->scr_cert_rel = std::ldexp(1.0, -6) + std::ldexp(1.0, -20);
-            ctx->scr_kwin = kWinMax;
-            ctx->scr_cert_mode = 2;
-        }
-    } else if (ctx->scr_cert_mode != ctx->opt_batch_cert) {
+        CHECK(batch_colnorm(ctx));
+        ctx->scr_cert_abs = 8.0 * (double)b.astep / std::sqrt(12.0);
+        ctx->scr_cert_abs2 = 8.0 * (double)b.anorm_host / std::sqrt(12.0);
+        ctx->scr_cert_rel = std::ldexp(1.0, -6) + std::ldexp(1.0, -20);
+        ctx->scr_kwin = kWinMax;
+    } else {
         ctx->scr_cert_abs2 = 0.0;
         // one rounded operand (the residual enters the sweep in f32): the two-operand bounds of the batched path are kept -- conservative
         if (ctx->opt_batch_cert == 1) {
@@ -32,7 +31,6 @@ static int screened_ensure(csmp_ctx* ctx) {
             ctx->scr_cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -20);
             ctx->scr_kwin = kWinMax / 2;
         }
-        ctx->scr_cert_mode = ctx->opt_batch_cert;
     }
     // grid: one workgroup per CU (measured at configs[1], tools/probes/sweep_probe.hip: 192 / 256 / 384 / 512 workgroups 90 / 81 / 89 / 97 us)
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kScrCols - 1) / ((kSweepThreads / kWave) * kScrCols);

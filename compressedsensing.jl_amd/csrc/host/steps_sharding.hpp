@@ -53,6 +53,21 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
 // A second context on the same GPU that BORROWS the resident dictionary of `src` (no copy): the independent
 // P objects of the reference -- P1 = OMP(A, b1); P2 = OMP(A, b2) share A and nothing else
 // (src/matchingpursuit.jl:44-60).  `src` must outlive the clone and keep its dictionary.
+// Every per-context option (csmp_set_option) of src -> dst: what a clone starts from, and what the internal twins of the batch
+// drivers are refreshed with on every call.  The resident Gram matrix is NOT inherited (8 N^2 bytes per context: a clone that wants
+// it asks for it).
+static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
+    dst->pipeline = src->pipeline;
+    dst->force_reorth = src->force_reorth;
+    dst->opt_in_flight = src->opt_in_flight;
+    dst->opt_batch_cert = src->opt_batch_cert;
+    dst->opt_batch_window = src->opt_batch_window;
+    dst->opt_batch_screen = src->opt_batch_screen;
+    dst->opt_screened = src->opt_screened;
+    dst->opt_ls_gram = src->opt_ls_gram;
+    dst->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
+    dst->opt_twostage_update = src->opt_twostage_update;
+}
 extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     if (!src || !out) return CSMP_EINVAL;
     *out = nullptr;
@@ -67,15 +82,7 @@ extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     c->ownA = false;
     c->share = src->share;  // (null for a borrowed device pointer: the caller keeps that alive)
     if (c->share) c->share->refs += 1;
-    c->pipeline = src->pipeline;
-    c->force_reorth = src->force_reorth;
-    c->opt_batch_cert = src->opt_batch_cert;
-    c->opt_batch_window = src->opt_batch_window;
-    c->opt_batch_screen = src->opt_batch_screen;
-    c->opt_screened = src->opt_screened;
-    c->opt_ls_gram = src->opt_ls_gram;
-    c->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
-    c->opt_twostage_update = src->opt_twostage_update;
+    copy_options(c, src);
     c->dtype = src->dtype;
     c->M = src->M;
     c->N = src->N;

@@ -289,15 +289,31 @@ end
 # ---------------------------------------------------------------------------------- many signals
 # [omp(A, B[:, s], eps, k) for s in axes(B, 2)] on one GPU.  method = :exact: single-signal sweeps, three signals
 # pipelined (csmp_omp_batch); :mfma: one bf16 screening GEMM per step + Float64 rescoring (csmp_omp_batch_mfma), with
-# certificate = :statistical | :rigorous and gram = true | false (CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM).
+# certificate = :rigorous (the library's default) | :statistical and gram = true | false (CSMP_OPT_BATCH_CERT /
+# CSMP_OPT_BATCH_GRAM).  A keyword that is not given leaves the Dictionary's option (set_option!) alone; one that is given holds
+# for this call only.
 # Returns (idx k x nsig 0-based, -1 padded; val; nnz) as the C ABI does -- the layout csmp_pack_results packs.
 function omp_batch_raw(A::MatOrDict{T}, B::StridedMatrix, ε::Real, k::Int; method::Symbol = :exact,
-                       certificate::Symbol = :statistical, gram::Bool = false) where {T}
+                       certificate::Union{Symbol,Nothing} = nothing, gram::Union{Bool,Nothing} = nothing) where {T}
     D = dict(A)
-    if method === :mfma
+    saved = Pair{Symbol,Int64}[]
+    if method === :mfma && certificate !== nothing
+        push!(saved, :batch_cert => get_option(D, :batch_cert))
         set_option!(D, :batch_cert, certificate === :rigorous ? 1 : 0)
+    end
+    if method === :mfma && gram !== nothing
+        push!(saved, :batch_gram => get_option(D, :batch_gram))
         set_option!(D, :batch_gram, gram ? 1 : 0)
     end
+    try
+        return omp_batch_call(D, B, ε, k, method)
+    finally
+        for (key, v) in saved
+            set_option!(D, key, v)
+        end
+    end
+end
+function omp_batch_call(D::Dictionary, B::StridedMatrix, ε::Real, k::Int, method::Symbol)
     BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
     nsig = size(BB, 2)
     idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)

@@ -217,12 +217,15 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
  * src/twostage.jl:87); those are arguments here too.  The choices that exist only on this side of the boundary are
  * per-context options ("Config / flags").  The library reads NO environment variable.  A clone
  * (csmp_clone) starts from its parent's values.  Unknown keys and out-of-range values: CSMP_EINVAL. */
-#define CSMP_OPT_BATCH_CERT 1      /* certificate of csmp_omp_batch_mfma.  0 (default): statistical -- 8 standard deviations of
-                                      independent bf16 roundings + the fully coherent case (an operand whose entries all round
-                                      the same way: 2^-7 of the screened value); holds for generic dictionaries, not a proof.
-                                      1: rigorous -- (2^-7 (1 + 2^-9) + M 2^-24) max|a_j| |r|, about nine times wider on a Gaussian
-                                      dictionary: more candidates are rescored per step, more signals
-                                      take the exact path, none can slip through */
+#define CSMP_OPT_BATCH_CERT 1      /* certificate of csmp_omp_batch_mfma (and of the screened sweeps, CSMP_OPT_SCREENED_SWEEP).
+                                      1 (default): rigorous -- a deterministic bound on the screen's error (unit roundoff of both
+                                      operands' images, Float32 accumulation, key truncation) with the largest column norm: a
+                                      passed certificate PROVES the pick; no residual, however constructed, can slip through
+                                      (tests: test_batched_certificate_against_adversarial_residuals).
+                                      0 (opt-in): statistical -- 8 standard deviations of independent roundings + a coherent
+                                      term; narrower windows (fewer rescored candidates, int8 operands allowed), holds for generic
+                                      data, NOT a proof: a residual aligned with the rounding errors of a near-tied atom passes
+                                      the certificate with the wrong atom */
 #define CSMP_OPT_BATCH_GRAM 2      /* 1: csmp_omp_batch_mfma keeps G = A'A resident (Float64, 8 N^2 bytes: 32 GiB at N = 65536;
                                       built on first use, 2 M N^2 / 2 flops on the Float64 matrix cores) and takes A_S'a from it
                                       instead of streaming the support's columns: half the append traffic.  0 (default) frees it */
