@@ -155,7 +155,7 @@ def parse():
                         "multi-rank code; the numbers are NOT a scaling measurement")
     p.add_argument("--in-flight", type=int, default=0, help="--workload sp: CSMP_OPT_SOLVES_IN_FLIGHT (1..4; 0 = the library's default)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--batch-screen", choices=["bf16", "int8"], default="bf16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM; int8 needs --batch-cert statistical)")
+    p.add_argument("--batch-screen", choices=["f16", "bf16", "int8"], default="f16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM; int8 needs --batch-cert statistical)")
     p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single / sp / sp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified selections)")
     p.add_argument("--screen-image", choices=["bf16", "int8"], default="bf16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 1 / 2)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
@@ -261,14 +261,14 @@ def per_signal_roofline(nsig, k, gram, us):
             "traffic": None, "note": "everything of the step that is not the screening launch; rescored window columns not counted"}
 
 
-def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=1, gram=0, nsig=1024, k=128, screen=0):
+def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, cert=1, gram=0, nsig=1024, k=128, screen=3):
     """configs[2] (1 GPU) / configs[3] (8192 signals over 8 GPUs): 1024 signals per GPU sharing A, k = 128.
     A step = one batch of 1024 complete solves.  cert / gram: the options CSMP_OPT_BATCH_CERT / CSMP_OPT_BATCH_GRAM of the
     contexts (include/csmp.h).  Returns the result dict on rank 0, None elsewhere."""
     eps = D.eps
     dsync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)  # (the gloo CPU test drives this function too)
     D.ctx.set_option("batch_cert", cert)
-    D.ctx.set_option("batch_screen", screen)  # 0: bf16 operands; 1: int8 operands (v_mfma_i32_16x16x64_i8; statistical certificate only)
+    D.ctx.set_option("batch_screen", screen)  # 3: binary16 operands (the default); 0: bf16; 1: int8 (v_mfma_i32_16x16x64_i8; statistical certificate only)
     t_setup = time.perf_counter()
     D.ctx.set_option("batch_gram", gram)
     B = make_signals_fast(torch, dev, At, rank * (K + W), (K + W) * nsig, k).reshape(K + W, nsig, M)
@@ -332,14 +332,16 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, ce
     D.ctx.sync()
     same = bool((i2 == idx[W][:4]).all().item()) and float((v2 - val[W][:4]).abs().max().item()) < 1e-9
     D.ctx.set_option("batch_cert", 1)  # (back to the library's defaults)
-    D.ctx.set_option("batch_screen", 2)
+    D.ctx.set_option("batch_screen", 3)
     D.ctx.set_option("batch_gram", 0)  # (releases the 8 N^2 bytes)
-    i8 = bool(screen) and not cert
+    i8 = screen == 1 and not cert
+    opname = "int8" if i8 else "bf16" if screen == 0 else "f16"
     return {
-        "metric": "batched OMP atoms selected/sec, 1024 signals per GPU sharing A 4096x65536, k=128 (%s MFMA screen + f64 rescoring)" % ("int8" if i8 else "bf16"),
+        "metric": "batched OMP atoms selected/sec, 1024 signals per GPU sharing A 4096x65536, k=128 (%s MFMA screen + f64 rescoring, %s certificate)" % (
+            opname, "rigorous" if cert else "statistical"),
         "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("int8 MFMA screen (i32 accumulate)" if i8 else "bf16 MFMA screen (f32 accumulate)") + " + f64 rescoring/append", "data": "synthetic",
+        "dtype": ("int8 MFMA screen (i32 accumulate)" if i8 else opname + " MFMA screen (f32 accumulate)") + " + f64 rescoring/append", "data": "synthetic",
         "signals_per_sec": K * nsig * world / tmax,
         "config": {"workload": "configs[2]/[3]: batched OMP, 1024 signals per GPU sharing A 4096x65536 Float32, k=128",
                    "signals_per_gpu_per_step": nsig, "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
@@ -360,7 +362,7 @@ def measure_batched(K, W, cs, torch, dist, dev, rank, world, At, D, use_dist, ce
         # workload, profiles/r03_batched_traffic.json) are NOT counted: a lower bound -- over everything of the step that is not the screen
         "per_signal_kernels": per_signal_roofline(nsig, k, gram, ms_per_omp_step * 1e3 - (screen_ms / max(screen_n, 1) * 1e3 if screen_n else 0.0)),
         "batch_stats": {"resolved_by_exact_path": int(resolved), "uncertain": int(uncertain), "illcond": int(illcond)},
-        "options": {"certificate": "rigorous" if cert else "statistical", "resident_gram": bool(gram), "screen_operands": "int8" if i8 else "bf16",
+        "options": {"certificate": "rigorous" if cert else "statistical", "resident_gram": bool(gram), "screen_operands": opname,
                     "gram_setup_seconds": gram_seconds,
                     "gram_bytes": (8 * N * N) if gram else 0},
         "matches_exact_path_on_sample": same,
@@ -908,7 +910,7 @@ def main():
             args.steps, args.warmup = 3, 1
         out = measure_batched(args.steps, args.warmup, cs, torch, dist, dev, rank, world, At, D, use_dist,
                               cert=1 if args.batch_cert == "rigorous" else 0, gram=1 if args.batch_gram else 0,
-                              screen=1 if args.batch_screen == "int8" else 0)
+                              screen={"f16": 3, "bf16": 0, "int8": 1}[args.batch_screen])
         if rank == 0:
             out["ranks_seen"], out["devices"] = ranks_seen, devices
             emit(out)
@@ -1023,8 +1025,8 @@ def main():
             # library defaults (int8 operands for the screen) / the rigorous certificate (bf16 operands) / + the resident Gram matrix /
             # the bf16 screen of rounds 1-2 with and without the Gram matrix
             # library defaults (the rigorous certificate) / + the resident Gram matrix / the opt-in statistical certificates
-            for name, cert, gram, scr in (("batched_c3", 1, 0, 0), ("batched_c3_gram", 1, 1, 0), ("batched_c3_statistical_int8", 0, 0, 1),
-                                          ("batched_c3_statistical_int8_gram", 0, 1, 1), ("batched_c3_statistical_bf16", 0, 0, 0)):
+            for name, cert, gram, scr in (("batched_c3", 1, 0, 3), ("batched_c3_gram", 1, 1, 3), ("batched_c3_rigorous_bf16", 1, 0, 0),
+                                          ("batched_c3_statistical_int8", 0, 0, 1), ("batched_c3_statistical_int8_gram", 0, 1, 1)):
                 try:
                     sec[name] = measure_batched(2, 1, cs, torch, dist, dev, 0, 1, At, D, False, cert=cert, gram=gram, screen=scr)
                 except Exception as e:  # noqa: BLE001

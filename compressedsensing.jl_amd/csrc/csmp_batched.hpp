@@ -74,6 +74,29 @@ __global__ __launch_bounds__(256) void k_b_convert(const TA* __restrict__ A, int
     *reinterpret_cast<bf16x8*>(out + n * Mk + c * 8) = v;
 }
 
+// dictionary (f32/f64, column-major M x N) -> binary16 [Npad][Mk] of scale * A, zero padded.  scale is a power of two that puts
+// max|A| in [2^14, 2^15): exact, and nothing the narrow exponent range of binary16 could flush (entries below 2^-28 max|A|
+// become subnormal: an ABSOLUTE error of at most 2^-39 max|A|, part of the certificate's bound).
+using f16x8v = __attribute__((ext_vector_type(8))) _Float16;
+template <typename TA>
+__global__ __launch_bounds__(256) void k_b_convert_f16(const TA* __restrict__ A, int64_t ld, int M, int64_t N,
+                                                       _Float16* __restrict__ out, int Mk, int64_t Npad, float scale) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kc = Mk / 8;
+    const int64_t n = idx / kc;
+    const int c = (int)(idx % kc);
+    if (n >= Npad) return;
+    f16x8v v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = c * 8 + e;
+        v[e] = (_Float16)((n < N && k < M) ? (float)A[n * ld + k] * scale : 0.0f);
+    }
+    *reinterpret_cast<f16x8v*>(out + n * Mk + c * 8) = v;
+}
+// power of two that scales a largest magnitude vmax into [2^14, 2^15) (1 for vmax == 0)
+__host__ __device__ __forceinline__ float f16_scale(float vmax) { return vmax > 0.0f ? ldexpf(1.0f, 14 - ilogbf(vmax)) : 1.0f; }
+
 // dictionary -> int8 [Npad][Mk8] with ONE step for the whole dictionary (astep = max|A| / 127; inv = 1 / astep), zero padded:
 // the int8 screen's operand (k_b_screen256p<true>).  A common step makes the absolute rounding error of every entry the
 // same, which is what the certificate's absolute term assumes.
@@ -146,7 +169,7 @@ template <typename TB>
 __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int64_t ldB, int M, int nsig,
                                                 double* __restrict__ r_all, double* __restrict__ b_all, int Mr,
                                                 __bf16* __restrict__ rb_all, int Mk, BState* __restrict__ bs,
-                                                signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep) {
+                                                signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep, int img) {
     __shared__ float smax[4];
     const int s = blockIdx.x;
     float amax = 0.0f;
@@ -156,11 +179,20 @@ __global__ __launch_bounds__(256) void k_b_init(const TB* __restrict__ Bsig, int
             r_all[(int64_t)s * Mr + m] = v;
             b_all[(int64_t)s * Mr + m] = v;
         }
-        if (m < Mk && !r8_all) rb_all[(int64_t)s * Mk + m] = (__bf16)(float)v;
+        if (m < Mk && img == kOpBf16) rb_all[(int64_t)s * Mk + m] = (__bf16)(float)v;
         amax = fmaxf(amax, fabsf((float)v));
     }
     float rstep = 0.0f;
-    if (r8_all) {  // int8 image of the signal, one step per signal
+    if (img == kOpF16) {  // binary16 image of the signal under its own power-of-two scale (astep = 1 / the dictionary's scale)
+        const float sc = f16_scale(block_absmax256(amax, smax));
+        _Float16* rh = reinterpret_cast<_Float16*>(rb_all) + (int64_t)s * Mk;
+        for (int m = threadIdx.x; m < Mk; m += 256) {
+            const double v = (s < nsig && m < M) ? (double)Bsig[(int64_t)s * ldB + m] : 0.0;
+            rh[m] = (_Float16)(float)(v * (double)sc);
+        }
+        if (threadIdx.x == 0) sigscale[s] = astep / sc;
+    }
+    if (img == kOpI8) {  // int8 image of the signal, one step per signal
         rstep = i8_step(block_absmax256(amax, smax));
         const float inv = 1.0f / rstep;
         for (int m = threadIdx.x; m < Mk8; m += 256) {
@@ -407,7 +439,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
     const TA* __restrict__ A, int64_t ld, int Mv, const double* __restrict__ Gm, int64_t Ng, const BPick* __restrict__ pick,
     double* __restrict__ T_all, double* __restrict__ Tt_all, double* __restrict__ z_all, int* __restrict__ sel_all,
     BState* __restrict__ bs, double* __restrict__ r_all, int Mr, __bf16* __restrict__ rb_all, int Mk, int kcap, int Mrows, int sig0,
-    signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep) {
+    signed char* __restrict__ r8_all, int Mk8, float* __restrict__ sigscale, float astep, int img) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ float smax[4];
     using VT = typename Vec<TA>::type;
@@ -703,7 +735,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
     // ---- q = v / rho, z_j = <a, r> / rho, r -= q z_j; new column of T = [-y / rho; 1 / rho]
     const double zj = cexact / rho;
     const double f = zj / rho;  // r -= v * (z_j / rho)
-    if (!r8_all) {
+    if (img == kOpBf16) {
         __bf16* rb = rb_all + (int64_t)s * Mk;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
@@ -718,7 +750,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
             }
             if (row < Mk) *reinterpret_cast<bf16x4*>(rb + row) = o;
         }
-    } else {  // int8 image: the new residual's largest magnitude first (one step per signal), then the bytes
+    } else {  // int8 / binary16 image: the new residual's largest magnitude first (one step / scale per signal), then the image
         float amax = 0.0f;
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
@@ -732,6 +764,20 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
                 amax = fmaxf(amax, fabsf((float)nr));
             }
         }
+        if (img == kOpF16) {  // binary16 image under the new residual's own power-of-two scale
+            const float sc = f16_scale(block_absmax256(amax, smax));
+            _Float16* rh = reinterpret_cast<_Float16*>(rb_all) + (int64_t)s * Mk;
+            using f16x4v = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int row = 4 * (tid + 256 * u);
+                f16x4v o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (_Float16)(float)(areg[u][e] * (double)sc);
+                if (row < Mk) *reinterpret_cast<f16x4v*>(rh + row) = o;
+            }
+            if (tid == 0) sigscale[s] = astep / sc;
+        } else {
         const float rstep = i8_step(block_absmax256(amax, smax));
         const float inv = 1.0f / rstep;
         signed char* r8 = r8_all + (int64_t)s * Mk8;
@@ -748,6 +794,7 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
         if (tid == 0) {
             st.rstep = rstep;
             sigscale[s] = astep * rstep * (1.0f + 0x1p-20f);
+        }
         }
     }
     for (int t = tid; t < j; t += 256) {

@@ -32,13 +32,19 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // reads a second time, sets the lead: six phases ahead would rewrite it in the very phase that still reads it).
 // No vmcnt(0), no __syncthreads() in the loop: the DMAs stay in flight across the barriers.
 //
-// I8 = true: the SAME data movement on an int8 image (a row of Mk "bf16 slots" is 2 Mk int8 values; an LDS row of 128 bytes is a
+// OP selects the operands (kOpBf16 / kOpI8 / kOpF16).  kOpF16: v_mfma_f32_16x16x32_f16 on binary16 images -- the same instruction
+// shape, rate and data movement as bf16 with eleven significand bits instead of eight: the rigorous certificate's bound is
+// 2^-10 instead of 2^-7 of |a||r| (csmp_omp_batch_mfma, host/batched.hpp).  Both images carry power-of-two scales (the dictionary
+// one, every residual its own) that put their largest entry in [2^14, 2^15): binary16's narrow exponent range loses nothing, and the
+// epilogue multiplies the candidate values by scale[signal] = 1 / (dictionary scale x residual scale), an exact operation.
+// kOpI8: the SAME data movement on an int8 image (a row of Mk "bf16 slots" is 2 Mk int8 values; an LDS row of 128 bytes is a
 // K-tile of 128 instead of 64; a fragment of 16 bytes is 16 k-values instead of 8) with v_mfma_i32_16x16x64_i8 -- the same
 // cycles per instruction for twice the k, i.e. half the K-loop.  The accumulators are exact integers; the epilogue ranks
 // |acc| (one scale per signal: a rank inside a signal does not depend on it) and hands on |acc| * scale[signal], scale =
 // (dictionary step) x (the signal's residual step), see csmp_batched.hpp.
 using i32x4s = __attribute__((ext_vector_type(4))) int;
-template <bool I8>
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+template <int OP>
 __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
                                                       int n_at2, int n_st2, int64_t N, int n_atiles128,
                                                       float* __restrict__ cand_val, int* __restrict__ cand_idx,
@@ -99,8 +105,11 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
     const char* laW = smem + (wr * 128 + fr) * 128;           // + stage * 65536 + m * 2048 + co
     const char* lrW = smem + 32768 + (wc * 64 + fr) * 128;    // + stage * 65536 + n * 2048 + co
     bf16x8 a[4][2], b[2][2];  // the current A sub-tile (4 m-tiles x 2 k-halves) and B sub-tile (2 n-tiles x 2 k-halves)
+    constexpr bool I8 = OP == kOpI8;
     auto mma = [](const bf16x8& x, const bf16x8& y, const f32x4s& c) -> f32x4s {
-        if constexpr (I8)
+        if constexpr (OP == kOpF16)
+            return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), c, 0, 0, 0);
+        else if constexpr (I8)
             return __builtin_bit_cast(f32x4s, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4s, x), __builtin_bit_cast(i32x4s, y),
                                                                                     __builtin_bit_cast(i32x4s, c), 0, 0, 0));
         else
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
             }
             const int64_t sig = (int64_t)stile * kBT2 + wc * 64 + n * 16 + fr;
             const int64_t base = (sig * n_atiles128 + at128) * kTileCand;
-            if constexpr (I8) {
+            if constexpr (OP != kOpBf16) {
                 const float sc = sigscale[sig];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -238,207 +247,33 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
     }
 }
 
-#ifdef CSMP_EXPERIMENTS
-// ---------------------------------------------------------------------------------------------
-// k_b_screen4 (EXPERIMENTS BUILD ONLY -- measured, not adopted: DESIGN.md "Overlapping the screen", profiles/r03_coresident_experiment.txt):
-// the screening GEMM in a footprint that leaves room on the CU -- FOUR waves (one per SIMD, <= 256 registers),
-// 96 KiB of LDS -- so that two k_b_append workgroups (<= 128 registers, 22 KiB each) of the OTHER half-batch run on the same
-// CU at the same time: the matrix cores and the HBM stream genuinely overlap (tools/probes/overlap_probe.hip: 1.4 PFLOP/s of
-// MFMA and 5.7 TB/s of loads side by side on every CU).  One wave per SIMD cannot issue 16x16x32 MFMAs back to back
-// (58 % of the peak); the 32x32x16 form amortises the issue gap (81 %), so this kernel uses v_mfma_f32_32x32x16_bf16:
-// 128 atoms x 256 signals per workgroup, wave w = signals [64w, 64w + 64) x all 128 atoms = 4 x 2 tiles of 32 x 32
-// (128 accumulator registers; a lane's 16 registers of a tile are 16 atoms of ONE signal: column = lane & 31,
-// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)).  Operand tiles global -> LDS by DMA with the same XOR swizzle as
-// k_b_screen256p (rows of 128 B, chunk ^= (row >> 1) & 7: a fragment read's 16-lane groups hit 16 distinct slots).
-// K-loop: K-tiles of 64 in two LDS stages of 48 KiB; a K-tile is two halves of two 16-deep MFMA steps: the fragments of
-// the next half are requested before the 16 MFMAs of the current one are issued; the barrier that hands a stage over sits
-// between the halves, and the DMAs of tile t + 2 are issued right behind it (1.5 tiles ahead).
-constexpr size_t kScreenLds4 = 2 * (128 + 256) * 128;  // 98,304 B
-__global__ __launch_bounds__(256, 2) void k_b_screen4(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
-                                                      int n_at, int n_st2, int64_t N, float* __restrict__ cand_val,
-                                                      int* __restrict__ cand_idx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 31, lh = lane >> 5;
-    int atile, stile;
-    {
-        const int bid = blockIdx.x;
-        if ((n_at & 7) == 0) {  // an atom tile's signal tiles back to back on ONE XCD (workgroups are dealt round-robin over the 8)
-            const int xcd = bid & 7, local = bid >> 3;
-            stile = local % n_st2;
-            atile = (local / n_st2) * 8 + xcd;
-        } else {
-            stile = bid % n_st2;
-            atile = bid / n_st2;
-        }
-    }
-    const __bf16* gA = Ab + (int64_t)atile * 128 * Mk;
-    const __bf16* gR = Rb + (int64_t)stile * 256 * Mk;
-    f32x16s acc[4][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x16s)0.0f;
-    // DMA map: a K-tile is 48 pieces of 8 rows x 128 B (pieces 0..15: A rows 8p.., pieces 16..47: R rows 8(p - 16)..); wave w issues
-    // pieces w, w + 4, ...  Lane l lands at row r0 + (l >> 3), slot l & 7, and fetches chunk (l & 7) ^ key(row), key = (row >> 1) & 7
-    // = (l >> 4) ^ ((r0 >> 1) & 4): two lane patterns (bit 3 of r0).
-    int lanepart[2];
-#pragma unroll
-    for (int v = 0; v < 2; ++v) lanepart[v] = (lane >> 3) * Mk + (((lane & 7) ^ (lane >> 4) ^ (4 * v)) << 3);
-    const int nkb = Mk / kBK;
-    auto issue = [&](int t) {
-        char* l = smem + (size_t)(t & 1) * 49152;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int pc = wv + 4 * i;  // (scalar)
-            const bool isA = pc < 16;
-            const int r0 = (isA ? pc : pc - 16) * 8;
-            const __bf16* g = (isA ? gA : gR) + t * kBK;
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(g + (int64_t)r0 * Mk + lanepart[(r0 >> 3) & 1]),
-                                             (lds_void_t*)(l + (isA ? 0 : 16384) + r0 * 128), 16, 0, 0);
-        }
-    };
-    // fragment addresses: tile row = 32 m + lr (A) / 64 wv + 32 n + lr (R); 16-byte chunk = 2 ks + lh, swizzled by key(row) = (lr >> 1) & 7
-    const int key = (lr >> 1) & 7;
-    const char* laW = smem + lr * 128;                           // + stage * 49152 + m * 4096 + chunk offset
-    const char* lrW = smem + 16384 + (wv * 64 + lr) * 128;       // + stage * 49152 + n * 4096 + chunk offset
-    int co[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) co[ks] = ((2 * ks + lh) ^ key) << 4;
-    bf16x8 fa[2][4][2], fb[2][2][2];  // [register set][tile][k-step of the half]
-    auto frags = [&](int set, int stage, int half) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) fb[set][n][q] = *reinterpret_cast<const bf16x8*>(lrW + stage * 49152 + n * 4096 + co[2 * half + q]);
-#pragma unroll
-            for (int m = 0; m < 4; ++m) fa[set][m][q] = *reinterpret_cast<const bf16x8*>(laW + stage * 49152 + m * 4096 + co[2 * half + q]);
-        }
-    };
-    auto mfmas = [&](int set) {
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][m][q], fb[set][n][q], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    // prologue: tiles 0 and 1 on their way, tile 0 landed, its first half in registers
-    issue(0);
-    if (nkb > 1) issue(1);
-    if (nkb > 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    frags(0, 0, 0);
-    for (int t = 0; t < nkb; ++t) {
-        const int st = t & 1;
-        frags(1, st, 1);                                  // second half of tile t (overlaps the MFMAs below)
-        asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory");  // (the first half's 12 reads have landed; the 12 just issued may be in flight)
-        mfmas(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave has read everything it needs from stage st
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // tile t + 1 (issued 1.5 tiles ago) has landed
-        __builtin_amdgcn_s_barrier();                        // ... for every wave: stage st is free, stage st ^ 1 complete
-        if (t + 2 < nkb) issue(t + 2);                       // -> stage st
-        if (t + 1 < nkb) frags(0, st ^ 1, 0);                // first half of tile t + 1 (overlaps the MFMAs below)
-        mfmas(1);
-    }
-    // epilogue: per signal the 4 largest |c| over the tile's 128 atoms on packed keys (see k_b_screen256p): the upper 23 bits of |c|
-    // over 8 bits of (128 - atom-in-tile); lane l holds 64 of a signal's 128 atoms, lane l ^ 32 the others
-    const bool ragged = (int64_t)(atile + 1) * 128 > N;
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        unsigned w[4] = {0u, 0u, 0u, 0u};
-        // running top-4 over the lane's 64 keys (descending insertion; keys are distinct: the low byte is the atom)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int rg = 0; rg < 16; ++rg) {
-                const int at = m * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * lh;
-                unsigned kv = (__float_as_uint(acc[m][n][rg]) & 0x7fffff00u) | (unsigned)(128 - at);
-                if (ragged && (int64_t)atile * 128 + at >= N) kv = 0u;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const unsigned hi = kv > w[q] ? kv : w[q], lo = kv > w[q] ? w[q] : kv;
-                    w[q] = hi;
-                    kv = lo;
-                }
-            }
-        {   // merge with the partner lane's four (bitonic: max of w[q] and o[3 - q], then sort the four)
-            unsigned o[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (unsigned)__shfl_xor((int)w[q], 32, kSWave);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = w[q] > o[3 - q] ? w[q] : o[3 - q];
-            auto cx = [&](int x, int y) {
-                const unsigned hi = w[x] > w[y] ? w[x] : w[y], lo = w[x] > w[y] ? w[y] : w[x];
-                w[x] = hi;
-                w[y] = lo;
-            };
-            cx(0, 1); cx(2, 3); cx(0, 2); cx(1, 3); cx(1, 2);
-        }
-        if (lh == 0) {
-            float ov[4];
-            int oi[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const bool ok = w[q] != 0u;
-                ov[q] = ok ? __uint_as_float(w[q] | 0xffu) : -1.0f;
-                oi[q] = ok ? atile * 128 + (128 - (int)(w[q] & 0xffu)) : 0x7fffffff;
-            }
-            const int64_t sig = (int64_t)stile * 256 + wv * 64 + n * 32 + lr;
-            const int64_t base = (sig * n_at + atile) * kTileCand;
-            *reinterpret_cast<f32x4s*>(cand_val + base) = f32x4s{ov[0], ov[1], ov[2], ov[3]};
-            *reinterpret_cast<int4*>(cand_idx + base) = make_int4(oi[0], oi[1], oi[2], oi[3]);
-        }
-    }
-}
-
-#endif
 
 hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
                          int64_t N, float* cand_val, int* cand_idx, const float* sigscale) {
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_b_screen256p<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)k_b_screen256p<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
-        if (e != hipSuccess) return e;
-#ifdef CSMP_EXPERIMENTS
-        e = hipFuncSetAttribute((const void*)k_b_screen4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds4);
-        if (e != hipSuccess) return e;
-#endif
+        for (const void* k : {(const void*)k_b_screen256p<kOpBf16>, (const void*)k_b_screen256p<kOpI8>, (const void*)k_b_screen256p<kOpF16>}) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kScreenLds256);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
     if ((n_atiles & 1) || (n_stiles & 1) || Mk % (2 * kBK) != 0 || Mk < 4 * kBK) return hipErrorInvalidValue;  // (batch_dict / batch_ensure pad to these)
-#ifdef CSMP_EXPERIMENTS
-    if (mode == kScreen4) {
-        hipLaunchKernelGGL(k_b_screen4, dim3(n_atiles * (n_stiles / 2)), dim3(256), kScreenLds4, stream, Ab, Rb, Mk, n_atiles, n_stiles / 2, N,
-                           cand_val, cand_idx);
-        return hipGetLastError();
-    }
-#endif
-    if (mode == kScreen256i8) {  // Ab / Rb are int8 images, Mk counts 2-byte slots (rows of 2 Mk int8 values)
-        if (!sigscale) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(k_b_screen256p<true>, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
-                           n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx, sigscale);
-        return hipGetLastError();
-    }
-    hipLaunchKernelGGL(k_b_screen256p<false>, dim3((n_atiles / 2) * (n_stiles / 2)), dim3(512), kScreenLds256, stream, Ab, Rb, Mk,
-                       n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx, (const float*)nullptr);
+    if (mode != kScreen256p && !sigscale) return hipErrorInvalidValue;
+    const dim3 grid((n_atiles / 2) * (n_stiles / 2)), block(512);
+    // (int8: Ab / Rb are int8 images, Mk counts 2-byte slots -- rows of 2 Mk int8 values)
+    auto kern = mode == kScreen256i8 ? k_b_screen256p<kOpI8> : mode == kScreen256f16 ? k_b_screen256p<kOpF16> : k_b_screen256p<kOpBf16>;
+    hipLaunchKernelGGL(kern, grid, block, kScreenLds256, stream, Ab, Rb, Mk, n_atiles / 2, n_stiles / 2, N, n_atiles, cand_val, cand_idx, sigscale);
     return hipGetLastError();
 }
 const char* screen_kernel_name(int mode) {
-    if (mode == kScreen4)
-        return "csmp::k_b_screen4 (v_mfma_f32_32x32x16_bf16, 128x256 tiles, four waves = one per SIMD, 96 KiB of LDS: co-resident with the "
-               "per-signal kernels of the other half-batch; LDS-DMA staging, fused top-4 epilogue)";
     if (mode == kScreen256i8)
-        return "csmp::k_b_screen256p<true> (v_mfma_i32_16x16x64_i8 on int8 images, 256x256 tiles, eight-phase schedule, exact integer "
+        return "csmp::k_b_screen256p<i8> (v_mfma_i32_16x16x64_i8 on int8 images, 256x256 tiles, eight-phase schedule, exact integer "
                "accumulation; fused top-4 epilogue)";
-    return "csmp::k_b_screen256p (v_mfma_f32_16x16x32_bf16, 256x256 tiles, eight-phase schedule: LDS-DMA units four phases ahead, "
+    if (mode == kScreen256f16)
+        return "csmp::k_b_screen256p<f16> (v_mfma_f32_16x16x32_f16 on binary16 images, 256x256 tiles, eight-phase schedule: LDS-DMA units "
+               "four phases ahead, counted vmcnt, the two waves of a SIMD one barrier apart; fused top-4 epilogue)";
+    return "csmp::k_b_screen256p<bf16> (v_mfma_f32_16x16x32_bf16, 256x256 tiles, eight-phase schedule: LDS-DMA units four phases ahead, "
            "counted vmcnt, the two waves of a SIMD one barrier apart; fused top-4 epilogue)";
 }
 

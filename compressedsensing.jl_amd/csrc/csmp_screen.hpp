@@ -18,7 +18,8 @@ constexpr size_t kScreenLds256 = 2 * 2 * 256 * 128;  // 2 buffers x (A 32 KiB + 
 
 // one screening launch: D = Ab Rb' in 256 x 256 tiles with the fused top-4-per-(signal, 128-atom tile) epilogue.
 // Needs n_atiles and n_stiles (counted in 128s) even and Mk an even number (>= 4) of 64-deep K-tiles.
-enum : int { kScreen256p = 3, kScreen4 = 4, kScreen256i8 = 5 };  // 4: the four-wave kernel that shares its CU with the per-signal kernels; 5: int8 images
+enum : int { kScreen256p = 3, kScreen256i8 = 5, kScreen256f16 = 6 };  // operands: bf16 / int8 / binary16 images
+enum : int { kOpBf16 = 0, kOpI8 = 1, kOpF16 = 2 };
 hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const __bf16* Rb, int Mk, int n_atiles, int n_stiles,
                          int64_t N, float* cand_val, int* cand_idx, const float* sigscale = nullptr);
 const char* screen_kernel_name(int mode);

@@ -98,6 +98,25 @@ static int batch_dict(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
+// binary16 image of the dictionary [Npad][Mk] under one power-of-two scale
+static int batch_dict16(csmp_ctx* ctx) {
+    Batch& b = ctx->bt;
+    if (b.ah_valid) return CSMP_OK;
+    CHECK(batch_meta(ctx));
+    HIPCHECK(hipMalloc((void**)&b.Ah, (size_t)b.Npad * b.Mk * sizeof(_Float16)));
+    b.ascale16 = f16_scale(b.amax_host);
+    const int64_t total = b.Npad * (b.Mk / 8);
+    const int grid = (int)((total + 255) / 256);
+    if (ctx->dtype == CSMP_F32)
+        hipLaunchKernelGGL(k_b_convert_f16<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ah, b.Mk, b.Npad, b.ascale16);
+    else
+        hipLaunchKernelGGL(k_b_convert_f16<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, (int)ctx->M, ctx->N, b.Ah, b.Mk, b.Npad, b.ascale16);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    b.ah_valid = true;
+    return CSMP_OK;
+}
+
 // int8 image of the dictionary under one step (max|A| / 127), for the int8 screen
 static int batch_dict8(csmp_ctx* ctx) {
     Batch& b = ctx->bt;
@@ -220,7 +239,7 @@ static hipError_t b_pick_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int
 }
 // DEPTH of the append kernel: columns whose loads are issued together (registers: DEPTH x NI x 16 bytes per lane)
 template <typename TA, int NI, bool GRAM>
-static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, bool i8) {
+static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, int img) {
     Batch& b = ctx->bt;
     constexpr int DEPTH = (NI >= 8 || (sizeof(TA) == 8 && NI >= 4)) ? 2 : (NI >= 4 || sizeof(TA) == 8) ? 2 : 4;
     const size_t lds = b_append_lds_bytes(ctx->Mv, (int)(16 / sizeof(TA)), b.kcap);
@@ -230,17 +249,18 @@ static hipError_t b_append_launch(csmp_ctx* ctx, hipStream_t stream, int sig0, i
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(nsig), dim3(256), lds, stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, (const double*)b.Gm, b.Ng, (const BPick*)b.pick, b.T,
-                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0, i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
+                       b.Tt, b.z, b.sel, b.bs, b.r, b.Mr, b.Rb, b.Mk, b.kcap, (int)ctx->M, sig0, img == kOpI8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale,
+                       img == kOpF16 ? 1.0f / b.ascale16 : b.astep, img);
     return hipGetLastError();
 }
 template <typename TA>
 static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, int nsig, double eps, int check_eps, double cert_abs, double cert_rel,
-                                  int kwin, bool gram, bool i8, double cert_abs2) {
+                                  int kwin, bool gram, int img, double cert_abs2) {
     const int groups = (ctx->Mv + 1023) / 1024;
     hipError_t e = b_pick_launch<TA>(ctx, stream, sig0, nsig, eps, check_eps, cert_abs, cert_rel, kwin, cert_abs2);
     if (e != hipSuccess) return e;
 #define CSMP_BSTEP(NI)                                                                                                  \
-    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig, i8) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig, i8);
+    return gram ? b_append_launch<TA, NI, true>(ctx, stream, sig0, nsig, img) : b_append_launch<TA, NI, false>(ctx, stream, sig0, nsig, img);
     if (groups <= 1) { CSMP_BSTEP(1) }
     if (groups <= 2) { CSMP_BSTEP(2) }
     if (groups <= 4) { CSMP_BSTEP(4) }
@@ -259,14 +279,16 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
     HIPCHECK(hipSetDevice(ctx->dev));
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
-    // operands of the screen: int8 (one step for the whole dictionary) where the dictionary is FLAT -- max|A| within 8 root mean
-    // squares of its entries (Gaussian unit-norm columns: 4.5-5; partial DCT: 1.4; few-valued: 1.3) --, bf16 where a few large
-    // entries would coarsen the common step for everything else (spikes beside a dense basis: max / rms = sqrt(M)).  Option
-    // values 0 / 1 force bf16 / int8; the int8 screen has a statistical certificate only.
+    // Operands of the screen (CSMP_OPT_BATCH_SCREEN).  3 (default): binary16 images -- eleven significand bits: the rigorous bound is
+    // 2^-10 |a||r| where bf16's is 2^-7.  0: bf16 images (the form of rounds 1-3).  1 / 2: int8 images (2: only where the dictionary is
+    // FLAT -- max|A| within 8 root mean squares of its entries: Gaussian unit-norm columns 4.5-5, partial DCT 1.4, few-valued 1.3;
+    // spikes beside a dense basis, max / rms = sqrt(M), would coarsen the common step for everything else); the int8 screen has a
+    // statistical certificate only, so under the rigorous certificate (the default) an int8 request runs binary16.
     CHECK(batch_meta(ctx));
     const bool flat = ctx->bt.amax_host <= 8.0f * ctx->bt.arms_host;
-    const bool i8 = (ctx->opt_batch_screen == 1 || (ctx->opt_batch_screen == 2 && flat)) && ctx->opt_batch_cert == 0 && !tune_env("CSMP_SCREEN4");
-    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
+    const bool i8 = (ctx->opt_batch_screen == 1 || (ctx->opt_batch_screen == 2 && flat)) && ctx->opt_batch_cert == 0;
+    const int img = i8 ? kOpI8 : ctx->opt_batch_screen == 0 ? kOpBf16 : kOpF16;
+    CHECK(img == kOpI8 ? batch_dict8(ctx) : img == kOpF16 ? batch_dict16(ctx) : batch_dict(ctx));
     CHECK(batch_ensure(ctx, (int)nsig, kc));
     CHECK(solver_ensure(ctx, kc, (int)k));  // the exact path re-solves flagged signals
     ctx->s.begun = false;
@@ -294,27 +316,35 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     const int Bpad = (int)(((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT));  // whole 256-signal tiles
     if (b_dtype == CSMP_F32)
         hipLaunchKernelGGL(k_b_init<float>, dim3(Bpad), dim3(256), 0, ctx->stream, (const float*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs,
-                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
+                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, img == kOpF16 ? 1.0f / b.ascale16 : b.astep, img);
     else
         hipLaunchKernelGGL(k_b_init<double>, dim3(Bpad), dim3(256), 0, ctx->stream, (const double*)dB, ldB, (int)ctx->M, (int)nsig, b.r, b.b, b.Mr, b.Rb, b.Mk, b.bs,
-                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, b.astep);
+                           i8 ? b.R8 : (signed char*)nullptr, b.Mk8, b.sigscale, img == kOpF16 ? 1.0f / b.ascale16 : b.astep, img);
     HIPCHECK(hipGetLastError());
     // Screening error bound  | |<a_n, r>| - s_n | <= cert_abs |r| + cert_rel s_n  (k_b_pick, csmp_batched.hpp).
-    // Statistical (default): 8 standard deviations of the bf16 rounding model -- independent roundings of the M products,
-    // sigma = sqrt(2/3) 2^-9 max|A_ij| |r| -- PLUS the fully coherent case the independent model misses: an operand whose
-    // entries all round the same way is a scaled operand, (1 + a)(1 + b) s with |a|, |b| <= 2^-8 (few-valued and one-magnitude
-    // dictionaries: every entry of a column rounds alike), i.e. 2^-7 s, plus the 2^-15 the packed candidate keys drop.
-    // Rigorous (CSMP_OPT_BATCH_CERT = 1): |<a,r> - screened| <= (2^-7 (1 + 2^-9) + Mk 2^-24) |a|_2 |r|_2 (bf16 unit roundoff
-    // 2^-8 on both operands, Float32 accumulation) with the largest column norm, and the key truncation: a proof, about nine
-    // times wider on a Gaussian dictionary -- the window holds more candidates (64 instead of 16), more signals overflow it.
-    // int8 screen (CSMP_OPT_BATCH_SCREEN = 1; statistical only): both operands are rounded to a uniform grid -- the dictionary to
-    // multiples of astep = max|A| / 127, every residual to multiples of its own rstep = max|r_i| / 127 -- and the integer
-    // accumulation is exact: the error of a screened value is sum(da_i r_i) + sum(a_i dr_i) (+ the product of the two), with
-    // da_i, dr_i uniform in +-step/2: sigma^2 = astep^2 |r|^2 / 12 + rstep^2 |a|^2 / 12.  8 sigma, the largest column norm; the
-    // coherent term covers a dictionary whose entries sit on few levels (all of a column's entries of one level round alike:
-    // a relative error of up to astep / (2 min level)): 2^-6 of the screened value.
+    //
+    // RIGOROUS (CSMP_OPT_BATCH_CERT = 1, the default; binary16 or bf16 operands).  The images are round-to-nearest: a_i (1 + d_i),
+    // r_i (1 + e_i) with |d_i|, |e_i| <= u (u = 2^-11 binary16, 2^-8 bf16; + 2^-23 for the Float64 -> Float32 -> image double rounding);
+    // the products of two images are exact in Float32's accumulator width, and the accumulation of the Mk products is charged
+    // 2^-23 per addition -- unit roundoff of Float32 under ANY rounding mode (the matrix cores' internal order and rounding are
+    // not documented; truncation is covered) -- over at most Mk additions:
+    //     |<a,r> - screened| <= (2u + u^2 + Mk 2^-23 (1 + u)^2) sum|a_i r_i| <= (...) |a|_2 |r|_2,
+    // with the largest column norm for |a|_2.  binary16 only: the power-of-two scales are exact; image entries below the normal
+    // range carry an absolute error <= 2^-25 in scaled units, i.e. 2^-39 of the operand's largest entry: sqrt(Mk) 2^-38 |a||r| for
+    // both operands together.  cert_rel: the 2^-15 the packed candidate keys drop and the rounding of the scale multiplication.
+    // A proof: nothing about the data is assumed (tests: test_batched_certificate_against_adversarial_residuals).
+    //
+    // STATISTICAL (CSMP_OPT_BATCH_CERT = 0, opt-in): 8 standard deviations of a model of INDEPENDENT roundings of the M products,
+    // sigma = sqrt(2/3) u/2 max|A_ij| |r|, plus a coherent term (an operand whose entries all round the same way is a scaled
+    // operand: 2u of the screened value).  Narrower windows; holds for generic data; a residual aligned with the rounding errors
+    // of a near-tied atom defeats it (the same test shows that).
+    // int8 screen (statistical only): both operands are rounded to a uniform grid -- the dictionary to multiples of astep =
+    // max|A| / 127, every residual to multiples of its own rstep = max|r_i| / 127 -- and the integer accumulation is exact: the
+    // error of a screened value is sum(da_i r_i) + sum(a_i dr_i) (+ the product of the two), with da_i, dr_i uniform in
+    // +-step/2: sigma^2 = astep^2 |r|^2 / 12 + rstep^2 |a|^2 / 12.  8 sigma, the largest column norm; coherent term 2^-6.
     double cert_abs, cert_rel, cert_abs2 = 0.0;
     int kwin;
+    const double u_img = (img == kOpF16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8)) + std::ldexp(1.0, -23);
     if (i8) {
         CHECK(batch_colnorm(ctx));
         cert_abs = 8.0 * (double)b.astep / std::sqrt(12.0);
@@ -323,74 +353,38 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         kwin = kWinMax;
     } else if (ctx->opt_batch_cert == 1) {
         CHECK(batch_colnorm(ctx));
-        cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+        cert_abs = (2.0 * u_img + u_img * u_img + (double)b.Mk * std::ldexp(1.0, -23) * (1.0 + u_img) * (1.0 + u_img) +
+                    (img == kOpF16 ? std::sqrt((double)b.Mk) * std::ldexp(1.0, -38) : 0.0)) * (double)b.anorm_host;
         cert_rel = std::ldexp(1.0, -14);
         kwin = kWinMax;  // 128
     } else {
-        cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
-        cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -14);
+        cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * u_img * 0.5 * (double)b.amax_host;
+        cert_rel = 2.0 * u_img * 1.01 + std::ldexp(1.0, -14);
         kwin = kWinMax / 2;  // 64
     }
     if (ctx->opt_batch_window > 0) kwin = std::min<int>(kWinMax, (int)ctx->opt_batch_window);
-    if (tune_env("CSMP_CERT_NOREL")) cert_rel = std::ldexp(1.0, -14);  // (experiments build: the round-2 bound, for tools/probe_structured.py)
-    const int mode = i8 ? kScreen256i8 : tune_env("CSMP_SCREEN4") ? kScreen4 : kScreen256p;
+    const int mode = i8 ? kScreen256i8 : img == kOpF16 ? kScreen256f16 : kScreen256p;
     b.last_mode = mode;
     b.last_streams = 1;
     b.last_screen_signals = Bpad;
-    // Two half-batches on two streams, out of phase (experiments build, CSMP_BATCH_HALVES=2): each half is an independent chain
-    // screen -> pick -> append -> screen ... on its own stream; the second half's first screen is held back until the first
-    // half's has finished, so that one half's screening GEMM (matrix cores) meets the other half's per-signal kernels (HBM).
-    int nh = 1;
-    if (const char* hv = tune_env("CSMP_BATCH_HALVES")) nh = (atoi(hv) == 2 && Bpad >= 4 * kBT) ? 2 : 1;
-    int h0[2] = {0, 0}, hpad[2] = {Bpad, 0}, hn[2] = {(int)nsig, 0};
-    hipStream_t hs_[2] = {ctx->stream, ctx->stream};
-    if (nh == 2) {
-        const int tile = 2 * kBT;
-        hpad[0] = ((Bpad / 2 + tile - 1) / tile) * tile;
-        hpad[1] = Bpad - hpad[0];
-        h0[1] = hpad[0];
-        hn[0] = (int)std::min<int64_t>(nsig, hpad[0]);
-        hn[1] = (int)(nsig - hn[0]);
-        if (hn[1] <= 0) nh = 1;
-    }
-    if (nh == 2) {
-        if (!ctx->stream_b) HIPCHECK(hipStreamCreateWithFlags(&ctx->stream_b, hipStreamNonBlocking));
-        for (auto* ev : {&ctx->ev_fork, &ctx->ev_join, &ctx->ev_off})
-            if (!*ev) HIPCHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-        hs_[1] = ctx->stream_b;
-        HIPCHECK(hipEventRecord(ctx->ev_fork, ctx->stream));
-        HIPCHECK(hipStreamWaitEvent(ctx->stream_b, ctx->ev_fork, 0));
-        b.last_streams = 2;
-        b.last_screen_signals = hpad[0];
-    }
-    const size_t ncand = (size_t)b.n_atiles * kTileCand;
+    // (Two overlap schemes for the MFMA-bound screen and the HBM-bound per-signal kernels were measured in round 3 and lost:
+    // profiles/r03_cusplit_experiment.txt, profiles/r03_coresident_experiment.txt.  One stream, phases back to back.)
+    const __bf16* dimg = img == kOpI8 ? (const __bf16*)b.A8 : img == kOpF16 ? (const __bf16*)b.Ah : (const __bf16*)b.Ab;
+    const __bf16* rimg = img == kOpI8 ? (const __bf16*)b.R8 : (const __bf16*)b.Rb;
+    const int mk2 = img == kOpI8 ? b.Mk8 / 2 : b.Mk;  // row length in 2-byte slots
     for (int64_t t = 0; t < k; ++t) {
-        for (int h = 0; h < nh; ++h) {
-            const bool timed = ctx->prof && h == 0;  // (HIP events around the first half's screening launch)
-            if (timed) {
-                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
-            }
-            if (t == 0 && h == 1) HIPCHECK(hipStreamWaitEvent(hs_[1], ctx->ev_off, 0));
-            if (i8)  // (rows of Mk8 bytes = Mk8 / 2 two-byte slots)
-                HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.A8, (const __bf16*)(b.R8 + (size_t)h0[h] * b.Mk8), b.Mk8 / 2, b.n_atiles, hpad[h] / kBT,
-                                       ctx->N, b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand, b.sigscale + h0[h]));
-            else
-                HIPCHECK(launch_screen(hs_[h], mode, (const __bf16*)b.Ab, (const __bf16*)b.Rb + (size_t)h0[h] * b.Mk, b.Mk, b.n_atiles, hpad[h] / kBT, ctx->N,
-                                       b.cand_val + (size_t)h0[h] * ncand, b.cand_idx + (size_t)h0[h] * ncand));
-            if (t == 0 && h == 0 && nh == 2) HIPCHECK(hipEventRecord(ctx->ev_off, hs_[0]));
-            if (timed) {
-                if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
-                HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], hs_[h]));
-            }
-            hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram, i8, cert_abs2)
-                                                  : b_step_dispatch<double>(ctx, hs_[h], h0[h], hn[h], eps, t > 0, cert_abs, cert_rel, kwin, gram, i8, cert_abs2);
-            HIPCHECK(e);
+        if (ctx->prof) {  // HIP events around the screening launch
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
         }
-    }
-    if (nh == 2) {
-        HIPCHECK(hipEventRecord(ctx->ev_join, ctx->stream_b));
-        HIPCHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        HIPCHECK(launch_screen(ctx->stream, mode, dimg, rimg, mk2, b.n_atiles, Bpad / kBT, ctx->N, b.cand_val, b.cand_idx, img == kOpBf16 ? nullptr : b.sigscale));
+        if (ctx->prof) {
+            if (ctx->ev2_used == ctx->ev2.size()) { hipEvent_t e; HIPCHECK(hipEventCreate(&e)); ctx->ev2.push_back(e); }
+            HIPCHECK(hipEventRecord(ctx->ev2[ctx->ev2_used++], ctx->stream));
+        }
+        hipError_t e = ctx->dtype == CSMP_F32 ? b_step_dispatch<float>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram, img, cert_abs2)
+                                              : b_step_dispatch<double>(ctx, ctx->stream, 0, (int)nsig, eps, t > 0, cert_abs, cert_rel, kwin, gram, img, cert_abs2);
+        HIPCHECK(e);
     }
     hipLaunchKernelGGL(k_b_finish, dim3((int)nsig), dim3(256), (size_t)(b.kcap + 2) * 8, ctx->stream, (const double*)b.T,
                        (const double*)b.z, (const int*)b.sel, (const BState*)b.bs, b.kcap, (int)k, d_idx, d_val, d_nnz);
@@ -408,10 +402,6 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         b.last_resolved += 1;
         b.last_uncertain += hs[sgn].uncertain ? 1 : 0;
         b.last_illcond += hs[sgn].illcond ? 1 : 0;
-        if (tune_env("CSMP_BATCH_DEBUG"))
-            fprintf(stderr, "signal %lld: uncertain %d illcond %d nsel %d | first failed certificate at step %d: window %d (cap %d), best exact %.6f, bound %.6f, top screened %.6f, |r| %.4f\n",
-                    (long long)sgn, hs[sgn].uncertain, hs[sgn].illcond, hs[sgn].nsel, hs[sgn].unc_step, hs[sgn].unc_nall, kwin, hs[sgn].unc_best,
-                    hs[sgn].unc_cb, hs[sgn].unc_s1, std::sqrt(hs[sgn].rnorm2));
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
         rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
                                  : init_from_device_t<double>(ctx, (const double*)col);

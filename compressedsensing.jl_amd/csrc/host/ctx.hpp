@@ -95,6 +95,11 @@ struct Batch {
     float astep = 0.f;
     signed char* R8 = nullptr;
     float* sigscale = nullptr;
+    // binary16 screen (CSMP_OPT_BATCH_SCREEN = 3, the default): the dictionary as binary16 [Npad][Mk] of ascale16 * A (a power of two
+    // that puts max|A| in [2^14, 2^15)); the residual images live in Rb under per-signal scales
+    _Float16* Ah = nullptr;
+    bool ah_valid = false;
+    float ascale16 = 1.f;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
     int last_mode = 0;  // screening kernel of the last batch (kScreen128 / kScreen256 / kScreenCo)
     int64_t last_screen_signals = 0;  // signal columns of one (timed) screening launch of the last batch
@@ -150,7 +155,7 @@ struct csmp_ctx {
     int scr_image = 1;       // the image the screened sweeps of this context read: 1 bf16, 2 int8 (option 2 on a flat dictionary)
     bool scr_lone = false;   // the solve in progress runs alone on the GPU (csmp_omp, csmp_mp): the pick kernel may take a whole CU
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
-    int opt_batch_screen = 2;     // CSMP_OPT_BATCH_SCREEN: 0 bf16 operands, 1 int8 operands (k_b_screen256p<true>), 2 (default) int8 where the dictionary is flat
+    int opt_batch_screen = 3;     // CSMP_OPT_BATCH_SCREEN: 3 (default) binary16 operands, 0 bf16, 1 int8, 2 int8 where the dictionary is flat (int8: statistical certificate only)
     size_t sweep_lds = 0;
     Solver s;        // the ACTIVE solver slot (see activate_slot)
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch

@@ -48,6 +48,8 @@ static void batch_free(Batch& b, bool keep_dict) {
         b.a8_borrowed = false;
         dfree(b.A8);
         b.a8_valid = false;
+        dfree(b.Ah);
+        b.ah_valid = false;
         dfree(b.Gm);
         b.gram_valid = false;
         b.ab_valid = false;
@@ -165,7 +167,7 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
         case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
         case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 2; return &ctx->opt_screened;
-        case CSMP_OPT_BATCH_SCREEN: *lo = 0; *hi = 2; return &ctx->opt_batch_screen;
+        case CSMP_OPT_BATCH_SCREEN: *lo = 0; *hi = 3; return &ctx->opt_batch_screen;
         default: return nullptr;
     }
 }

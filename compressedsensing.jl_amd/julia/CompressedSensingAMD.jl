@@ -203,22 +203,39 @@ end
 
 # ---------------------------------------------------------------------------------- rmp, foba
 # src/stepwise.jl:5-56 (x starting empty).  kmax bounds the support the forward stage may build (<= 1023).
-function stepwise_call(sym::Symbol, A::MatOrDict, b::AbstractVector, args, argtypes, kmax::Int)
+# (one literal ccall per entry point: ccall needs its symbol and its argument types as constants)
+function stepwise_out(A::MatOrDict, kmax::Int)
+    cap = min(size(A, 1), size(A, 2), 1023, kmax > 0 ? kmax : typemax(Int))
+    cap, zeros(Int64, cap + 1), zeros(Float64, cap + 1), Ref{Int64}(0)
+end
+function rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0)
     D = dict(A)
     bb, bt = bvec(b)
-    cap = min(size(A, 1), size(A, 2), 1023, kmax > 0 ? kmax : typemax(Int))
-    idx, val, nnz = zeros(Int64, cap + 1), zeros(Float64, cap + 1), Ref{Int64}(0)
-    GC.@preserve bb idx val check(D, ccall((sym, libcsmp), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, argtypes..., Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
-        D.ctx, bb, bt, args..., cap, idx, val, nnz))
+    cap, idx, val, nnz = stepwise_out(A, kmax)
+    GC.@preserve bb idx val check(D, ccall((:csmp_rmp_delta, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Int64, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, Float64(δ), Int64(maxiter), cap, idx, val, nnz))
     to_sparse(size(D, 2), idx, val, nnz[])
 end
-rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0) =
-    stepwise_call(:csmp_rmp_delta, A, b, (Float64(δ), Int64(maxiter)), (Cdouble, Int64), kmax)
-rmp(A::MatOrDict, b::AbstractVector, k::Int; kmax::Int = 0) = stepwise_call(:csmp_rmp_k, A, b, (Int64(k),), (Int64,), kmax)
+function rmp(A::MatOrDict, b::AbstractVector, k::Int; kmax::Int = 0)
+    D = dict(A)
+    bb, bt = bvec(b)
+    cap, idx, val, nnz = stepwise_out(A, kmax)
+    GC.@preserve bb idx val check(D, ccall((:csmp_rmp_k, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, Int64(k), cap, idx, val, nnz))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
 # isfast is accepted for signature parity (src/stepwise.jl:47): Val(false) computes the same backward scores the slow way
-foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0, isfast::Val = Val(true)) =
-    stepwise_call(:csmp_foba, A, b, (Float64(δ),), (Cdouble,), kmax)
+function foba(A::MatOrDict, b::AbstractVector, δ::Real; kmax::Int = 0, isfast::Val = Val(true))
+    D = dict(A)
+    bb, bt = bvec(b)
+    cap, idx, val, nnz = stepwise_out(A, kmax)
+    GC.@preserve bb idx val check(D, ccall((:csmp_foba, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cdouble, Int64, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}),
+        D.ctx, bb, bt, Float64(δ), cap, idx, val, nnz))
+    to_sparse(size(D, 2), idx, val, nnz[])
+end
 
 # ---------------------------------------------------------------------------------- br = fbr, lace
 # src/backward.jl:27-41,148-162,226-242
@@ -317,10 +334,15 @@ function omp_batch_call(D::Dictionary, B::StridedMatrix, ε::Real, k::Int, metho
     BB = eltype(B) <: Union{Float32,Float64} ? B : convert(Matrix{Float64}, B)
     nsig = size(BB, 2)
     idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)
-    f = method === :mfma ? :csmp_omp_batch_mfma : :csmp_omp_batch
-    GC.@preserve BB idx val nnz check(D, ccall((f, libcsmp), Cint,
-        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
-        D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, k, ε, idx, val, nnz, CSMP_HOST))
+    if method === :mfma
+        GC.@preserve BB idx val nnz check(D, ccall((:csmp_omp_batch_mfma, libcsmp), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
+            D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, k, ε, idx, val, nnz, CSMP_HOST))
+    else
+        GC.@preserve BB idx val nnz check(D, ccall((:csmp_omp_batch, libcsmp), Cint,
+            (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Cdouble, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
+            D.ctx, BB, dtype_code(eltype(BB)), stride(BB, 2), nsig, CSMP_HOST, k, ε, idx, val, nnz, CSMP_HOST))
+    end
     idx, val, nnz
 end
 omp_batch(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int; kw...) = begin

@@ -192,8 +192,8 @@ int csmp_sp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
                   int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
 
 /* The same contract, solved by the batched variant (BASELINE configs 3/4): the residual sweeps of
- * all signals become ONE bf16 MFMA GEMM per step (A' [r_1 .. r_B], f32 accumulate) that only
- * SCREENS: per signal the candidates whose screened value could still be the exact maximum are rescored in
+ * all signals become ONE MFMA GEMM per step (A' [r_1 .. r_B] on 16-bit images -- binary16 by default, bf16 or int8 by option --,
+ * f32 accumulate) that only SCREENS: per signal the candidates whose screened value could still be the exact maximum are rescored in
  * Float64 from the f32/f64 master dictionary, and a certificate (exact best > an upper bound on the exact value of
  * every atom that was not rescored) guards every step: a signal that fails it once is re-solved by the exact path
  * before returning, so a certified result equals csmp_omp_batch's.  The error bound behind the certificate is
@@ -249,13 +249,17 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
                                       returns, so results are those of option 0.  Costs the
                                       image (2 Mk N or Mk N bytes) beside the dictionary.  Default off: the headline path stays
                                       the exact one ("Screened single-signal sweep"). */
-#define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM. 1: int8 images -- the dictionary under one step
-                                      max|A|/127, every residual under its own -- on v_mfma_i32_16x16x64_i8 (half the K-loop of the
-                                      bf16 form, exact integer accumulation); statistical certificate only, so under
-                                      CSMP_OPT_BATCH_CERT = 1 the bf16 form runs.  0: bf16 images (v_mfma_f32_16x16x32_bf16), the form
-                                      of rounds 1-2.  2 (default): int8 where the dictionary is flat (max|A| <= 8 x the root mean
-                                      square of its entries: one step then resolves every column), bf16 otherwise.  The int8 image
-                                      costs M N bytes, the bf16 image 2 M N; only what is used is built. */
+#define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM.
+                                      3 (default): binary16 images (v_mfma_f32_16x16x32_f16; the dictionary and every residual under
+                                      exact power-of-two scales): the same rate and bytes as bf16 with eleven significand bits --
+                                      the rigorous bound is 2^-10 |a||r| instead of 2^-7 |a||r|, windows as narrow as bf16's
+                                      statistical ones.  0: bf16 images (v_mfma_f32_16x16x32_bf16), the form of rounds 1-3.
+                                      1: int8 images -- the dictionary under one step max|A|/127, every residual under its own -- on
+                                      v_mfma_i32_16x16x64_i8 (half the K-loop, exact integer accumulation); 2: int8 where the
+                                      dictionary is flat (max|A| <= 8 x the root mean square of its entries), binary16 otherwise.
+                                      The int8 screen has a statistical certificate only: it runs under CSMP_OPT_BATCH_CERT = 0;
+                                      under the rigorous certificate 1 and 2 run binary16.  Only the image in use is built
+                                      (2 M N bytes; int8: M N). */
 int csmp_set_option(csmp_ctx *ctx, int key, int64_t value);
 int csmp_get_option(csmp_ctx *ctx, int key, int64_t *value);
 

@@ -29,7 +29,7 @@ def _usable_cores():
 
 
 NT = _usable_cores()  # OpenMP threads for the oracle's full-size solves
-DEFAULT_SCREEN = 2  # CSMP_OPT_BATCH_SCREEN's default (include/csmp.h)
+DEFAULT_SCREEN = 3  # CSMP_OPT_BATCH_SCREEN's default: binary16 operands (include/csmp.h)
 
 
 def close(v, ref, tight=True):
@@ -553,7 +553,7 @@ def test_full_size_config5_gomp_and_sp(cs, oracle):
 
 @pytest.mark.parametrize("shape", [(64, 256, 6, 5), (256, 2048, 12, 40), (130, 700, 10, 130), (512, 4096, 24, 200), (1500, 3000, 16, 9)])
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("mode", ["defaults", "statistical_bf16", "statistical_int8"])
+@pytest.mark.parametrize("mode", ["defaults", "rigorous_bf16", "statistical_f16", "statistical_bf16", "statistical_int8"])
 def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype, mode):
     """csmp_omp_batch_mfma: MFMA screening (the library's defaults = the rigorous certificate; the opt-in statistical certificates
     with bf16 and int8 operands) + Float64 rescoring must reproduce the oracle's supports exactly and its coefficients to the
@@ -563,8 +563,8 @@ def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype, mode):
     A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + 3 * m, dtype=dtype)
     d = D(A)
     if mode != "defaults":
-        d.ctx.set_option("batch_cert", 0)
-        d.ctx.set_option("batch_screen", 1 if mode.endswith("int8") else 0)
+        d.ctx.set_option("batch_cert", 1 if mode.startswith("rigorous") else 0)
+        d.ctx.set_option("batch_screen", {"int8": 1, "bf16": 0, "f16": 3}[mode.split("_")[1]])
     rng = np.random.default_rng(nsig)
     B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
                                     for _ in range(nsig)], axis=1))
@@ -1263,7 +1263,7 @@ def test_options_at_the_abi(cs, D):
     for key, v in defaults.items():
         assert c.get_option(key) == v, key
     for key, bad in (("batch_cert", 2), ("batch_window", 129), ("pipeline", 2), ("twostage_update", 3), ("batch_gram", -1), ("solves_in_flight", 5),
-                     ("solves_in_flight", 0), ("screened_sweep", 3), ("batch_screen", 3)):
+                     ("solves_in_flight", 0), ("screened_sweep", 3), ("batch_screen", 4)):
         with pytest.raises(cs.CsmpError):
             c.set_option(key, bad)
     with pytest.raises(cs.CsmpError):
@@ -1386,8 +1386,8 @@ def test_full_size_config3_batched(cs, oracle):
     # certificate sends at most a handful of signals to the exact path
     assert st["signals"] == nsig and st["illcond"] == 0
     assert st["resolved_exactly"] == st["uncertain"] and st["uncertain"] <= 8, st
-    # (iv) every option combination: certificate (0 statistical / 1 rigorous) x screen operands (0 bf16 / 1 int8) x resident Gram
-    for cert, screen, gram in ((1, 0, 0), (0, 0, 0), (0, 1, 0), (1, 0, 1), (0, 1, 1)):
+    # (iv) option combinations: certificate (0 statistical / 1 rigorous) x screen operands (3 binary16 / 0 bf16 / 1 int8) x resident Gram
+    for cert, screen, gram in ((1, 3, 1), (1, 0, 0), (0, 3, 0), (0, 0, 0), (0, 1, 0), (0, 1, 1)):
         d.ctx.set_option("batch_cert", cert)
         d.ctx.set_option("batch_screen", screen)
         d.ctx.set_option("batch_gram", gram)
@@ -1395,7 +1395,7 @@ def test_full_size_config3_batched(cs, oracle):
         sto = d.ctx.batch_stats()
         what = "cert %d screen %d gram %d" % (cert, screen, gram)
         print("C3", what, d.ctx.batch_screen_kernel(), sto)
-        assert ("i8" in d.ctx.batch_screen_kernel()) == bool(screen), what
+        assert {0: "<bf16>", 1: "<i8>", 3: "<f16>"}[screen] in d.ctx.batch_screen_kernel(), what
         check_oracle(oi, ov, on, what)
         assert np.array_equal(on, n2) and np.array_equal(oi, i2), what
         assert np.allclose(ov, v2, rtol=1e-9, atol=1e-12), what
@@ -2327,15 +2327,19 @@ def test_batched_certificate_against_adversarial_residuals(cs, oracle, image_nam
             np.array_equal(idx[:nnz[s], s], refs[s][0]) if kk == k else int(idx[0, s]) == int(refs[s][2][0])))]
         return wrong, st, val, nnz
 
-    # (1) the library's defaults
-    for kk in (1, k):
-        wrong, st, val, nnz = run(kk)
-        print("adversarial[%s] defaults, k=%d: %s wrong %s" % (image_name, kk, d.ctx.batch_screen_kernel().split(" ")[0], wrong), st)
-        assert wrong == [], (kk, wrong, st)
-    for s in range(B.shape[1]):
-        assert close(val[:nnz[s], s], refs[s][1], tight=False), s
-    # (2) the opt-in modes, reported
-    for name, cert, screen in (("statistical bf16", 0, 0), ("statistical int8", 0, 1)):
+    # (1) the library's defaults, and the rigorous certificate with each 16-bit operand type: never wrong
+    for name, cert, screen in (("defaults", None, None), ("rigorous bf16", 1, 0), ("rigorous binary16", 1, 3)):
+        if cert is not None:
+            d.ctx.set_option("batch_cert", cert)
+            d.ctx.set_option("batch_screen", screen)
+        for kk in (1, k):
+            wrong, st, val, nnz = run(kk)
+            print("adversarial[%s] %s, k=%d: %s wrong %s" % (image_name, name, kk, d.ctx.batch_screen_kernel().split(" ")[0], wrong), st)
+            assert wrong == [], (name, kk, wrong, st)
+        for s in range(B.shape[1]):
+            assert close(val[:nnz[s], s], refs[s][1], tight=False), s
+    # (2) the opt-in statistical certificates, reported
+    for name, cert, screen in (("statistical bf16", 0, 0), ("statistical binary16", 0, 3), ("statistical int8", 0, 1)):
         d.ctx.set_option("batch_cert", cert)
         d.ctx.set_option("batch_screen", screen)
         wrong, st, _, _ = run(1)
