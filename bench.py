@@ -59,6 +59,20 @@ def exchange_results(idx, val, nnz, group=None):
     return cs.gather_packed(packed, packed.shape[0] * dist.get_world_size(group), group)
 
 
+def library_collective(cs, dist, D, use_dist, share_gpu):
+    """True when the ONE collective of the signal-sharded path runs inside the library (csmp_omp_sharded: ncclAllGather on the
+    context's stream): every N > 1 run under the "nccl" backend.  The gloo rehearsal (--share-gpu: RCCL refuses two ranks on one
+    device) and a box whose RCCL cannot be bound keep the host-side all_gather of the same packed rows."""
+    if not use_dist or share_gpu or dist.get_backend() != "nccl":
+        return False
+    try:
+        cs.library_comm(D.ctx)
+        return True
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: csmp_comm_init failed ({e!r}); the gather falls back to torch.distributed", file=sys.stderr, flush=True)
+        return False
+
+
 def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
     """AverageNs of the newest COMMITTED rocprofv3 --kernel-trace --stats row whose kernel name contains `kernel_substr`
     (profiles/, named per round).  It was measured on the build that was profiled, not in this process: the line carries it as
@@ -84,7 +98,7 @@ _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", 
               "algorithmic_bytes_per_launch", "flops_per_launch")
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "signals_per_sec", "config", "roofline", "cpu_baseline", "secondary", "secondary_file", "gather_check",
-             "ranks_seen", "matches_exact_path_on_sample", "batch_stats", "equals_unsharded_omp", "ranks_agree_on_first_support", "error")
+             "ranks_seen", "devices", "matches_exact_path_on_sample", "batch_stats", "equals_unsharded_omp", "ranks_agree_on_first_support", "error")
 
 
 def _rnd(x):
@@ -118,8 +132,10 @@ def headline(out):
     if isinstance(o.get("metric"), str):
         o["metric"] = o["metric"][:200]
     o = _rnd(o)
+    if isinstance(o.get("devices"), list):
+        o["devices"] = [str(d)[:48] for d in o["devices"]]
     line = json.dumps(o, separators=(",", ":"))
-    for drop in ("batch_stats", "ranks_seen", "gather_check", "secondary"):  # never needed at today's sizes: a guard, not a plan
+    for drop in ("batch_stats", "devices", "gather_check", "secondary"):  # never needed at today's sizes: a guard, not a plan
         if len(line) <= LINE_BUDGET:
             break
         o.pop(drop, None)
@@ -931,18 +947,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    lib_gather = library_collective(cs, dist, D, use_dist, args.share_gpu)
+    if lib_gather:  # every rank's results of all world * K timed signals, on the device, in global order
+        g_idx = torch.full((world * K, K_ATOMS), -1, dtype=torch.int64, device=dev)
+        g_val = torch.zeros((world * K, K_ATOMS), dtype=torch.float64, device=dev)
+        g_nnz = torch.zeros(world * K, dtype=torch.int64, device=dev)
     if W > 0:
         D.ctx.omp_batch_device(B[:W], K_ATOMS, eps, idx[:W], val[:W], nnz[:W])
-    if use_dist:  # warm the collective too, at the size and through the packing kernels of the timed one
+    if lib_gather:  # warm the collective too (one signal per rank through the same call)
+        D.ctx.omp_sharded_device(B[W:W + 1].contiguous(), world, K_ATOMS, eps, g_idx[:world], g_val[:world], g_nnz[:world])
+    elif use_dist:
         exchange_results(idx[W:], val[W:], nnz[W:])
     D.ctx.profile_enable(args.profile_every)  # HIP events around every n-th sweep launch of the timed region
     D.ctx.profile_read(reset=True)
     barrier()
     t0 = time.perf_counter()
-    D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
-    D.ctx.sync()
-    if use_dist:  # the single collective of the path: every rank's (idx, val, nnz) shard, device buffers over RCCL
-        gathered = exchange_results(idx[W:], val[W:], nnz[W:])
+    if lib_gather:  # the block's solves + the single collective of the path, inside the library (csmp_omp_sharded)
+        D.ctx.omp_sharded_device(B[W:], world * K, K_ATOMS, eps, g_idx, g_val, g_nnz)
+        idx[W:], val[W:], nnz[W:] = g_idx[rank * K:(rank + 1) * K], g_val[rank * K:(rank + 1) * K], g_nnz[rank * K:(rank + 1) * K]
+        gathered = cs.pack_t(g_idx, g_val, g_nnz)
+    else:
+        D.ctx.omp_batch_device(B[W:], K_ATOMS, eps, idx[W:], val[W:], nnz[W:])
+        D.ctx.sync()
+        if use_dist:  # the single collective of the path: every rank's (idx, val, nnz) shard over the host-side group
+            gathered = exchange_results(idx[W:], val[W:], nnz[W:])
     barrier()
     dt = time.perf_counter() - t0
     sweeps, sweep_ms = D.ctx.profile_read(reset=True)
@@ -982,7 +1010,8 @@ def main():
             "config": {"workload": "configs[1]: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, "
                                    "k=256, planted +-1 256-sparse x0 + noise 5e-3, eps=eps(Float32)",
                        "signals_per_gpu": K, "signals_in_flight": 3,
-                       "sharding": f"signals over {world} GPU(s), A replicated, one all_gather"},
+                       "sharding": f"signals over {world} GPU(s), A replicated, one all_gather",
+                       "collective": "ncclAllGather inside csmp_omp_sharded" if lib_gather else ("torch.distributed all_gather" if use_dist else "none (one rank)")},
             "ranks_seen": ranks_seen, "devices": devices,
             "roofline": roof,
             "atoms_selected": int(atoms),

@@ -44,6 +44,10 @@ SIGNATURES = {
     "csmp_shard_sweep": (C.c_int, [vp, C.c_double, C.c_int, vp]),
     "csmp_shard_append": (C.c_int, [vp, vp, C.c_int]),
     "csmp_shard_range": (C.c_int, [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
+    "csmp_comm_id": (C.c_int, [vp]),
+    "csmp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
+    "csmp_comm_free": (C.c_int, [vp]),
+    "csmp_omp_sharded": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, C.c_int, vp, vp, vp, C.c_int]),
     "csmp_pack_results": (C.c_int, [vp, vp, vp, i64, i64, vp]),
     "csmp_unpack_results": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "csmp_mp": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
@@ -81,6 +85,18 @@ SIGNATURES = {
     "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
+
+
+COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
+
+
+def comm_id():
+    """rank 0: a fresh RCCL communicator id (bytes) to hand to every rank's Context.comm_init."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().csmp_comm_id(C.cast(buf, vp))
+    if rc != 0:
+        raise CsmpError(rc, lib().csmp_last_error(None).decode())
+    return buf.raw
 
 
 class CsmpError(RuntimeError):
@@ -462,6 +478,40 @@ class Context:
 
     def batch_screen_kernel(self):
         return lib().csmp_batch_screen_kernel(self._h).decode()
+
+    # ---- signals sharded over GPUs with the collective inside the library (csmp_comm_*, csmp_omp_sharded)
+    def comm_init(self, comm_id, rank, world):
+        """ncclCommInitRank on this context's GPU; comm_id: the COMM_ID_BYTES bytes rank 0 got from comm_id()."""
+        buf = (C.c_char * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self.call("csmp_comm_init", C.cast(buf, vp), int(rank), int(world))
+
+    def comm_free(self):
+        self.call("csmp_comm_free")
+
+    def omp_sharded(self, B_local, nsig, k, eps, method="exact"):
+        """This rank's block B_local (M x nloc, host) of `nsig` signals in all -> (idx k x nsig, val, nnz) of ALL signals."""
+        B = np.asfortranarray(B_local)
+        if B.dtype not in (np.float32, np.float64):
+            B = B.astype(np.float64)
+        if B.shape[0] != self.M:
+            raise CsmpError(EDIM, f"size(B, 1) = {B.shape[0]} but size(A, 1) = {self.M}")
+        idx = np.zeros((int(k), int(nsig)), np.int64, order="F")
+        val = np.zeros((int(k), int(nsig)), np.float64, order="F")
+        nnz = np.zeros(int(nsig), np.int64)
+        self.call("csmp_omp_sharded", ptr(B), dtype_code(B.dtype), i64(self.M), i64(int(nsig)), HOST, i64(int(k)), C.c_double(eps),
+                  {"exact": 0, "mfma": 1}[method], ptr(idx), ptr(val), ptr(nnz), HOST)
+        return idx, val, nnz
+
+    def omp_sharded_device(self, B_local, nsig, k, eps, idx, val, nnz, method="exact"):
+        """torch CUDA tensors: B_local (nloc, M) rows = this rank's signals; idx / val (nsig, k), nnz (nsig): all signals."""
+        import torch
+        nloc, M = B_local.shape
+        assert B_local.is_cuda and B_local.is_contiguous() and M == self.M
+        assert idx.dtype == torch.int64 and val.dtype == torch.float64 and nnz.dtype == torch.int64
+        assert idx.is_contiguous() and val.is_contiguous() and idx.shape == (int(nsig), int(k)) and val.shape == (int(nsig), int(k))
+        code = F32 if B_local.dtype == torch.float32 else F64
+        self.call("csmp_omp_sharded", vp(B_local.data_ptr() if nloc else 0), code, i64(M), i64(int(nsig)), DEVICE, i64(int(k)), C.c_double(eps),
+                  {"exact": 0, "mfma": 1}[method], vp(idx.data_ptr()), vp(val.data_ptr()), vp(nnz.data_ptr()), DEVICE)
 
     def batch_layout(self):
         n, st = i64(0), C.c_int(0)

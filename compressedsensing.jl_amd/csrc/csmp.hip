@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -39,3 +40,4 @@ using namespace csmp;
 #include "host/batched.hpp"
 #include "host/screened.hpp"
 #include "host/measure.hpp"
+#include "host/rccl.hpp"

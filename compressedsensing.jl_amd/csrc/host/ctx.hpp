@@ -142,6 +142,8 @@ struct csmp_ctx {
     bool sweep_full = false, sweep_nt = false;
     bool force_reorth = false;  // CSMP_OPT_FORCE_REORTH (test switch): always run the second Gram-Schmidt pass
     // options (csmp_set_option, include/csmp.h)
+    void* comm = nullptr;          // ncclComm_t of the signal-sharded solve (csmp_comm_init, host/rccl.hpp); this rank and the group's size
+    int comm_rank = 0, comm_world = 1;
     int opt_batch_cert = 1;        // CSMP_OPT_BATCH_CERT: 1 rigorous (default), 0 statistical (opt-in)
     int opt_batch_gram = 0;        // CSMP_OPT_BATCH_GRAM: resident G = A'A for csmp_omp_batch_mfma
     int opt_batch_window = 0;      // CSMP_OPT_BATCH_WINDOW: rescoring window capacity, 0 = default
@@ -214,6 +216,7 @@ static int fail(csmp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
     return code;
 }
+static int fail(csmp_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg.c_str()); }
 
 template <typename T>
 static int dmalloc(csmp_ctx* ctx, T** p, size_t n) {

@@ -101,6 +101,7 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         solver_free(ctx->s);
     }
     batch_free(ctx->bt, false);
+    if (ctx->comm) (void)csmp_comm_free(ctx);
     for (auto& t : ctx->twins) {
         if (t) (void)csmp_destroy(t);
         t = nullptr;

@@ -1,0 +1,189 @@
+// host/rccl.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
+// the signal-sharded solve with the ONE collective inside the library (BASELINE configs[3]): every rank
+// (one process per GPU) solves its contiguous block of signals with csmp_omp_batch / csmp_omp_batch_mfma, the results stay on
+// the device, are packed there into rows of 2k+1 Float64 (csmp_pack_results' wire layout), moved by ONE ncclAllGather over
+// xGMI on the context's stream, and unpacked on the device into global signal order.  A host language needs no collective
+// library of its own (the reference's Project.toml has none): the 128-byte communicator id is the only thing ranks exchange,
+// by whatever means they were started with.
+//
+// RCCL is bound LAZILY (dlopen of librccl.so.1 at csmp_comm_id / csmp_comm_init): libcsmp.so does not link it, so a host that
+// never shards pays nothing, and a process that already holds an RCCL (PyTorch's) shares that one -- one collective runtime
+// per process.  Only the five entry points below are resolved.
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only; no symbol of it is referenced at link time
+
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mu;
+
+static_assert(CSMP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "csmp.h's id size is RCCL's");
+
+bool rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.AllGather) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        g_rccl.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.handle) break;
+    }
+    if (!g_rccl.handle) {
+        const char* e = dlerror();
+        g_rccl.why = std::string("librccl.so.1 could not be loaded: ") + (e ? e : "?");
+        return false;
+    }
+    auto sym = [&](const char* n) -> void* {
+        void* p = dlsym(g_rccl.handle, n);
+        if (!p) g_rccl.why = std::string("librccl has no ") + n;
+        return p;
+    };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    void* ag = sym("ncclAllGather");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.GetErrorString || !ag) return false;
+    g_rccl.AllGather = (decltype(g_rccl.AllGather))ag;  // (set last: it is the "loaded" flag)
+    return true;
+}
+int rccl_fail(csmp_ctx* ctx, const char* what, ncclResult_t r) {
+    return fail(ctx, CSMP_ERCCL, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+}
+}  // namespace
+
+// rows of 2k+1 Float64 [idx | val | nnz] from the batch drivers' device outputs (idx, val: k x nloc, nnz: nloc); rows >= nloc: zeros
+__global__ void k_pack_rows(const int64_t* __restrict__ idx, const double* __restrict__ val, const int64_t* __restrict__ nnz, int64_t k,
+                            int64_t nloc, int64_t rows, double* __restrict__ packed) {
+    const int64_t w = 2 * k + 1, n = rows * w;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t s = i / w, t = i % w;
+        double v = 0.0;
+        if (s < nloc) v = t < k ? (double)idx[s * k + t] : t < 2 * k ? val[s * k + (t - k)] : (double)nnz[s];
+        packed[i] = v;
+    }
+}
+// the gathered blocks (world x rows x (2k+1)) -> idx / val (k x nsig) and nnz (nsig) in global signal order; rank r owns the
+// contiguous block csmp_shard_range(nsig, r, world): base = nsig / world signals, the first nsig % world ranks one more
+__global__ void k_unpack_rows(const double* __restrict__ all, int64_t k, int64_t nsig, int world, int64_t rows, int64_t* __restrict__ idx,
+                              double* __restrict__ val, int64_t* __restrict__ nnz) {
+    const int64_t w = 2 * k + 1, base = nsig / world, extra = nsig % world;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nsig * w; i += (int64_t)gridDim.x * 256) {
+        const int64_t s = i / w, t = i % w;
+        const int64_t cut = extra * (base + 1);  // signals below `cut` live on the ranks that hold base + 1
+        const int64_t r = s < cut ? s / (base + 1) : extra + (s - cut) / (base > 0 ? base : 1);
+        const int64_t lo = r * base + (r < extra ? r : extra);
+        const double v = all[(r * rows + (s - lo)) * w + t];
+        if (t < k) idx[s * k + t] = (int64_t)v;
+        else if (t < 2 * k) val[s * k + (t - k)] = v;
+        else nnz[s] = (int64_t)v;
+    }
+}
+
+extern "C" int csmp_comm_id(void* id) {
+    if (!id) return CSMP_EINVAL;
+    if (!rccl_load()) {
+        g_create_err = g_rccl.why;
+        return CSMP_ERCCL;
+    }
+    ncclUniqueId u;
+    const ncclResult_t r = g_rccl.GetUniqueId(&u);
+    if (r != ncclSuccess) {
+        g_create_err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r);
+        return CSMP_ERCCL;
+    }
+    memcpy(id, u.internal, CSMP_COMM_ID_BYTES);
+    return CSMP_OK;
+}
+
+extern "C" int csmp_comm_free(csmp_ctx* ctx) {
+    if (!ctx) return CSMP_EINVAL;
+    if (ctx->comm) {
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+        ctx->comm = nullptr;
+    }
+    ctx->comm_rank = 0;
+    ctx->comm_world = 1;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_comm_init(csmp_ctx* ctx, const void* id, int rank, int world) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!id || world < 1 || rank < 0 || rank >= world) return fail(ctx, CSMP_EINVAL, "comm_init: bad id / rank / world");
+    if (!rccl_load()) return fail(ctx, CSMP_ERCCL, g_rccl.why);
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(csmp_comm_free(ctx));
+    ncclUniqueId u;
+    memcpy(u.internal, id, CSMP_COMM_ID_BYTES);
+    ncclComm_t c = nullptr;
+    const ncclResult_t r = g_rccl.CommInitRank(&c, world, u, rank);
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclCommInitRank", r);
+    ctx->comm = (void*)c;
+    ctx->comm_rank = rank;
+    ctx->comm_world = world;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
+                                int method, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->comm) return fail(ctx, CSMP_ESTATE, "omp_sharded: no communicator (csmp_comm_init)");
+    if (nsig < 0 || k < 1 || !idx || !val || !nnz || (method != 0 && method != 1)) return fail(ctx, CSMP_EINVAL, "omp_sharded: bad arguments");
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (nsig == 0) return CSMP_OK;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int world = ctx->comm_world, rank = ctx->comm_rank;
+    int64_t lo = 0, hi = 0;
+    CHECK(csmp_shard_range(nsig, rank, world, &lo, &hi));
+    const int64_t nloc = hi - lo, rows = (nsig + world - 1) / world, w = 2 * k + 1;
+    if (nloc > 0 && !B) return fail(ctx, CSMP_EINVAL, "omp_sharded: B == NULL");
+    // the block's solves: results stay in device memory
+    DevTmp tIdx, tVal, tNnz, tPack, tAll, oIdx, oVal, oNnz;
+    HIPCHECK(tIdx.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8));
+    HIPCHECK(tVal.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8));
+    HIPCHECK(tNnz.alloc((size_t)std::max<int64_t>(1, nloc) * 8));
+    HIPCHECK(tPack.alloc((size_t)(rows * w) * 8));
+    HIPCHECK(tAll.alloc((size_t)(world * rows * w) * 8));
+    int wrc = CSMP_OK;
+    if (nloc > 0) {
+        const int rc = method == 1
+            ? csmp_omp_batch_mfma(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE)
+            : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE);
+        if (rc < 0) return rc;
+        wrc = rc;  // (CSMP_WCAPACITY travels with valid results)
+    }
+    const int grid = (int)std::min<int64_t>(1024, (rows * w + 255) / 256);
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k, nloc,
+                       rows, (double*)tPack.p);
+    HIPCHECK(hipGetLastError());
+    // THE collective: every rank's packed block, device memory to device memory, ordered on the context's stream
+    const ncclResult_t r = g_rccl.AllGather(tPack.p, tAll.p, (size_t)(rows * w), ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
+    int64_t *d_idx = idx, *d_nnz = nnz;
+    double* d_val = val;
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(oIdx.alloc((size_t)(k * nsig) * 8));
+        HIPCHECK(oVal.alloc((size_t)(k * nsig) * 8));
+        HIPCHECK(oNnz.alloc((size_t)nsig * 8));
+        d_idx = (int64_t*)oIdx.p;
+        d_val = (double*)oVal.p;
+        d_nnz = (int64_t*)oNnz.p;
+    }
+    const int grid2 = (int)std::min<int64_t>(1024, (nsig * w + 255) / 256);
+    hipLaunchKernelGGL(k_unpack_rows, dim3(grid2), dim3(256), 0, ctx->stream, (const double*)tAll.p, k, nsig, world, rows, d_idx, d_val, d_nnz);
+    HIPCHECK(hipGetLastError());
+    if (out_loc == CSMP_HOST) {
+        HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the temporaries are released on return)
+    return wrc;
+}

@@ -375,10 +375,39 @@ function sp_batch(A::MatOrDict{T}, B::StridedMatrix, k::Int, δ::Real = 1e-12; m
     [to_sparse(size(A, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:nsig]
 end
 
-# Signals sharded over ranks (SURVEY section 8e): rank r solves csmp_shard_range's block on its own GPU and ONE
-# gather moves the results.  `allgather(v::Vector{Float64}) -> Vector{Float64}` is the host's collective, e.g.
-#     allgather = v -> MPI.Allgather(v, comm)        # MPI.jl; every rank passes a block of the same length
-# (blocks are padded to the longest one: ceil(nsig / world) signals).
+# Signals sharded over ranks (SURVEY section 8e), ONE PROCESS PER GPU, the collective INSIDE the library (csmp_omp_sharded: one
+# ncclAllGather over xGMI, device memory to device memory) -- no collective package on the Julia side:
+#     id = rank == 0 ? comm_id() : nothing          # 128 bytes; hand them to every rank by whatever started the ranks
+#     comm_init!(D, id, rank, world)                # (a file, a socket, Distributed.remotecall_fetch, ...): collective
+#     xs = omp_sharded(D, B[:, lo+1:hi], nsig, ε, k; method = :mfma)   # every rank: its block in, ALL nsig results out
+const CSMP_COMM_ID_BYTES = 128
+function comm_id()
+    id = zeros(UInt8, CSMP_COMM_ID_BYTES)
+    rc = ccall((:csmp_comm_id, libcsmp), Cint, (Ptr{Cvoid},), id)
+    rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), C_NULL)))
+    id
+end
+comm_init!(D::Dictionary, id::Vector{UInt8}, rank::Integer, world::Integer) =
+    check(D, ccall((:csmp_comm_init, libcsmp), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Cint), D.ctx, id, rank, world))
+comm_free!(D::Dictionary) = check(D, ccall((:csmp_comm_free, libcsmp), Cint, (Ptr{Cvoid},), D.ctx))
+# this rank's contiguous block of nsig signals, 1-based inclusive (csmp_shard_range)
+function shard_range(nsig::Integer, rank::Integer, world::Integer)
+    lo, hi = Ref{Int64}(0), Ref{Int64}(0)
+    ccall((:csmp_shard_range, libcsmp), Cint, (Int64, Cint, Cint, Ref{Int64}, Ref{Int64}), nsig, rank, world, lo, hi)
+    (lo[] + 1):hi[]
+end
+function omp_sharded(D::Dictionary, Bblock::StridedMatrix, nsig::Integer, ε::Real, k::Int; method::Symbol = :exact)
+    BB = eltype(Bblock) <: Union{Float32,Float64} ? Bblock : convert(Matrix{Float64}, Bblock)
+    idx, val, nnz = fill(Int64(-1), k, nsig), zeros(Float64, k, nsig), zeros(Int64, nsig)
+    GC.@preserve BB idx val nnz check(D, ccall((:csmp_omp_sharded, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Int64, Cint, Int64, Cdouble, Cint, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int64}, Cint),
+        D.ctx, BB, dtype_code(eltype(BB)), max(stride(BB, 2), size(D, 1)), nsig, CSMP_HOST, k, ε, method === :mfma ? 1 : 0, idx, val, nnz, CSMP_HOST))
+    [to_sparse(size(D, 2), idx[:, s], val[:, s], nnz[s]) for s in 1:nsig]
+end
+
+# The same sharding under a collective the HOST brings (any single-signal driver, or a site that already runs MPI):
+# `allgather(v::Vector{Float64}) -> Vector{Float64}`; every rank passes a block of the same length (blocks are padded to the
+# longest one: ceil(nsig / world) signals).
 function omp_sharded(A::MatOrDict, B::StridedMatrix, ε::Real, k::Int, rank::Int, world::Int, allgather;
                      method::Symbol = :exact, kw...)
     nsig = size(B, 2)

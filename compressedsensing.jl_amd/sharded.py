@@ -82,14 +82,29 @@ def unpack_t(full, k):
     return unpack(full.cpu().numpy(), k)
 
 
+def library_comm(ctx, group=None):
+    """Give `ctx` its RCCL communicator over the ranks of `group` (csmp_comm_init), once per (context, group): rank 0 draws the id
+    (csmp_comm_id), the process group broadcasts those 128 bytes -- the only thing the host-side group is used for."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    key = (id(group), rank, world)
+    if getattr(ctx, "_comm_key", None) == key:
+        return
+    from . import _lib
+    ids = [_lib.comm_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    ctx.comm_init(ids[0], rank, world)
+    ctx._comm_key = key
+
+
 def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None, method="exact"):
     """Solve omp for every column of B (M x nsig, identical on all ranks) with the ranks of the
     default (or given) process group; every rank returns the full (idx, val, nnz) arrays.
 
     method: "exact" = csmp_omp_batch (single-signal sweeps, three signals pipelined), "mfma" = csmp_omp_batch_mfma
     (the batched variant BASELINE configs[3] names: bf16 MFMA screening GEMM + Float64 rescoring; same results).
-    With the "nccl" backend the local results stay on the GPU: they are packed there and gathered by RCCL straight
-    from device memory.  `solver(B_local, k, eps) -> (idx, val, nnz)` replaces the HIP path; the gloo CPU tests
+    With the "nccl" backend the whole exchange runs inside the library (csmp_omp_sharded: the block's solves, the packing, ONE
+    ncclAllGather over xGMI and the unpacking, all in device memory).  `solver(B_local, k, eps) -> (idx, val, nnz)` replaces the HIP path; the gloo CPU tests
     inject a stand-in there to exercise the sharding/gather logic only."""
     import torch
     import torch.distributed as dist
@@ -100,8 +115,20 @@ def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None, method=
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
     if method not in ("exact", "mfma"):
         raise ValueError('omp_sharded: method must be "exact" or "mfma"')
+    if solver is None and dev.type == "cuda" and backend == "nccl":
+        # the whole exchange inside the library (csmp_omp_sharded): solves, packing, ONE ncclAllGather on the context's stream,
+        # unpacking -- device memory throughout; the process group only carries the 128-byte communicator id, once
+        eps = D.eps if eps is None else eps
+        library_comm(D.ctx, group)
+        Bl = torch.from_numpy(np.ascontiguousarray(np.asarray(B)[:, lo:hi].T)).to(dev)  # (n, M): rows = signals
+        idx = torch.full((nsig, k), -1, dtype=torch.int64, device=dev)
+        val = torch.zeros((nsig, k), dtype=torch.float64, device=dev)
+        nnz = torch.zeros(nsig, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        D.ctx.omp_sharded_device(Bl, nsig, k, eps, idx, val, nnz, method)
+        return idx.T.cpu().numpy(), val.T.cpu().numpy(), nnz.cpu().numpy()
     if solver is None and dev.type == "cuda":
-        # device-resident path: signals uploaded once, results packed on the GPU, RCCL gathers device buffers
+        # device-resident path under a host-side collective (gloo rehearsals): results packed on the GPU
         eps = D.eps if eps is None else eps
         Bl = torch.from_numpy(np.ascontiguousarray(np.asarray(B)[:, lo:hi].T)).to(dev)  # (n, M): rows = signals
         n = hi - lo

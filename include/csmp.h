@@ -37,6 +37,7 @@ extern "C" {
 #define CSMP_EHIP (-4)   /* HIP runtime failure / no gfx950 device */
 #define CSMP_ESTATE (-5) /* no dictionary set / no solver begun */
 #define CSMP_ENOMEM (-6)
+#define CSMP_ERCCL (-7)  /* RCCL could not be loaded, or a communicator / collective call failed */
 /* positive = a warning; the results are valid.  CSMP_WCAPACITY: the on-device QR append keeps five support-length vectors in
  * the 160 KiB of LDS and holds about 3900 columns; a solve that reaches that support with no stopping rule having fired -- the
  * reference's defaults omp(A, b, eps) / OMP(A, b) / gomp with k = size(A, 1) at M = 4096 and a residual test that never fires --
@@ -297,13 +298,30 @@ int64_t csmp_shard_record_bytes(const csmp_ctx *ctx);
 int csmp_shard_sweep(csmp_ctx *ctx, double eps, int check_eps, void *rec_dev);
 int csmp_shard_append(csmp_ctx *ctx, const void *recs_dev, int nrec);
 
-/* ------------------------------------------------------------------ many signals sharded over GPUs (host helpers)
- * signals are independent given A, so rank r solves the contiguous block
- * [lo, hi) = csmp_shard_range(nsig, r, world) with csmp_omp_batch / csmp_omp_batch_mfma on its own GPU (A
- * replicated) and ONE exchange moves the results: per signal a row of 2k + 1 Float64
- * [idx_0..idx_{k-1} | val_0..val_{k-1} | nnz] (csmp_pack_results), gathered by the host's collective
- * (torch.distributed all_gather over RCCL; MPI.Allgather! from Julia -- INTEGRATION.md) and split again by
- * csmp_unpack_results.  Host memory, no ctx: these fix the wire layout for every host language. */
+/* ------------------------------------------------------------------ many signals sharded over GPUs
+ * SURVEY.md section 8e, BASELINE configs[3]: signals are independent given A (the loop a caller of the reference writes around
+ * omp, src/matchingpursuit.jl:73-82), so rank r -- ONE PROCESS PER GPU, A replicated -- solves the contiguous block
+ * [lo, hi) = csmp_shard_range(nsig, r, world) and ONE collective moves the results: per signal a row of 2k + 1 Float64
+ * [idx_0..idx_{k-1} | val_0..val_{k-1} | nnz].
+ *
+ * csmp_omp_sharded does all of it inside the library: the block's solves (method 0: csmp_omp_batch, 1: csmp_omp_batch_mfma),
+ * the packing on the device, ONE ncclAllGather over xGMI on the context's stream (device memory to device memory), and the
+ * unpacking into global signal order.  B: THIS RANK'S block, M x (hi - lo) column-major (ldB elements), host or device (b_loc);
+ * idx / val (k x nsig, tail -1 / 0) and nnz (nsig): ALL signals, on every rank, host or device (out_loc).  nsig is the
+ * global count and must be the same on every rank; the call is collective.
+ * The communicator: rank 0 calls csmp_comm_id (ncclGetUniqueId, CSMP_COMM_ID_BYTES of host memory), the host passes those
+ * bytes to the other ranks by whatever started them (a file, a socket, Julia's Distributed, torch.distributed's store), and
+ * every rank calls csmp_comm_init(ctx, id, rank, world) (ncclCommInitRank on the ctx's GPU; collective).  The host language
+ * needs no collective library of its own.  RCCL is bound lazily (librccl.so.1) by these calls only.  csmp_destroy frees the
+ * communicator; csmp_comm_free does it earlier. */
+#define CSMP_COMM_ID_BYTES 128
+int csmp_comm_id(void *id);
+int csmp_comm_init(csmp_ctx *ctx, const void *id, int rank, int world);
+int csmp_comm_free(csmp_ctx *ctx);
+int csmp_omp_sharded(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
+                     int method, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+/* The same wire layout for hosts that bring their own collective (torch.distributed all_gather in sharded.py's gloo tests and
+ * single-signal solver families; MPI): host memory, no ctx. */
 int csmp_shard_range(int64_t nsig, int rank, int world, int64_t *lo, int64_t *hi);
 int csmp_pack_results(const int64_t *idx, const double *val, const int64_t *nnz, int64_t k, int64_t nsig, double *packed);
 int csmp_unpack_results(const double *packed, int64_t k, int64_t nsig, int64_t *idx, double *val, int64_t *nnz);

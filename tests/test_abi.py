@@ -41,7 +41,13 @@ def test_product_does_not_link_the_oracle(cs):
         for f in files:
             if f.endswith((".hip", ".hpp")):
                 src = open(os.path.join(d, f)).read()  # (comments may NAME the oracle; nothing may include, load or call it)
-                assert not re.search(r'#include[^\n]*oracle|csmp_oracle|cso_[a-z]+\s*\(|dlopen|dlsym', src), f
+                assert not re.search(r'#include[^\n]*oracle|csmp_oracle|cso_[a-z]+\s*\(', src), f
+                if f != "rccl.hpp":  # the ONE place that binds anything at run time: RCCL, by name (checked below)
+                    assert not re.search(r'dlopen|dlsym', src), f
+    rccl = open(os.path.join(csrc, "host", "rccl.hpp")).read()
+    assert re.findall(r'for \(const char\* name : \{([^}]*)\}\)', rccl) == ['"librccl.so.1", "librccl.so"']
+    assert set(re.findall(r'sym\("([A-Za-z]+)"\)', rccl)) == {"ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclGetErrorString", "ncclAllGather"}
+    assert "rccl" not in out  # not linked either: bound lazily by csmp_comm_id / csmp_comm_init only
 
 
 def test_no_cpu_fallback_without_gpu(cs):
