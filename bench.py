@@ -173,7 +173,7 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--batch-screen", choices=["f16", "bf16", "int8"], default="f16", help="--workload batched: CSMP_OPT_BATCH_SCREEN (operands of the screening GEMM; int8 needs --batch-cert statistical)")
     p.add_argument("--screened", action="store_true", help="--workload gomp / gomp_single / sp / sp_single: CSMP_OPT_SCREENED_SWEEP (image sweeps, certified selections)")
-    p.add_argument("--screen-image", choices=["bf16", "int8"], default="bf16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 1 / 2)")
+    p.add_argument("--screen-image", choices=["f16", "bf16", "int8"], default="f16", help="--workload screened, --screened: the image the sweeps read (CSMP_OPT_SCREENED_SWEEP = 3 / 1 / 2)")
     p.add_argument("--no-secondary", action="store_true", help="skip the configs[2] / configs[4] blocks of the default line")
     p.add_argument("--profile-every", type=int, default=8, help="time every n-th sweep launch with HIP events (1 = all)")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -406,7 +406,7 @@ def measure_lone_omp(K, W, B, D, eps):
                                  "stages, kernel boundaries, back substitution, download) -- not a kernel duration"}}
 
 
-def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0, image=1):
+def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=1, image=3):
     """configs[1] with the screened sweep (CSMP_OPT_SCREENED_SWEEP): every sweep reads the bf16 image (M N 2 bytes) and the
     pick is certified against the f32 dictionary in Float64, an uncertified solve repeated exactly -- the results are the exact
     path's, and this function checks that on every timed signal.  Two forms: one csmp_omp call at a time, and csmp_omp_batch
@@ -420,8 +420,8 @@ def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0, image=1):
     if image == 2:
         cert = 0  # (the int8 image has the statistical bound only)
     D.ctx.set_option("batch_cert", cert)
-    D.ctx.set_option("screened_sweep", image)  # 1: bf16 image, 2: int8 image
-    iname, ibytes = ("int8", 1) if image == 2 else ("bf16", 2)
+    D.ctx.set_option("screened_sweep", image)  # 3: binary16 image, 1: bf16 image, 2: int8 image
+    iname, ibytes = {1: ("bf16", 2), 2: ("int8", 1), 3: ("f16", 2)}[image]
     out = {"metric": "OMP atoms selected/sec at m=4096,n=65536,k=256, screened sweep (%s image, certified picks, exact results)" % iname,
            "unit": "atoms/s", "certificate": "rigorous" if cert else "statistical", "image": iname, "steps": K, "warmup": W}
     try:
@@ -464,14 +464,14 @@ def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=0, image=1):
         alg = M * N * ibytes  # the image, streamed once per atom
         out["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": alg / avg / 1e9 if sweeps else 0.0,
                            "frac": alg / avg / 1e9 / HBM_PEAK_GBS if sweeps else 0.0, "traffic": None,
-                           "kernel": "csmp::k_sweep_%s<2,3,true> (while the other solve's pick / append stages run beside it)" % ("i8" if image == 2 else "bf16"),
+                           "kernel": "csmp::k_sweep_%s<2,3,true> (while the other solve's pick / append stages run beside it)" % {1: "bf16", 2: "i8", 3: "f16"}[image],
                            "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg,
                            "f32_equivalent_frac_all_in": M * N * 4 / (dt / max(atoms, 1)) / 1e9 / HBM_PEAK_GBS,
                            "note": "algorithmic bytes of THIS path are M N x the image's element size; f32_equivalent_frac_all_in prices the whole "
                                    "batch's time per atom against the exact path's M N 4 bytes -- above 1 means faster than any exact sweep can be"}
     finally:
         D.ctx.set_option("screened_sweep", 0)
-        D.ctx.set_option("batch_cert", 0)
+        D.ctx.set_option("batch_cert", 1)
     return out
 
 
@@ -498,7 +498,8 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
     isgw = workload in ("gomp", "gomp_single")
     if screened:
         exact0 = D5.ctx.gomp(sigs[W], S, k, eps) if isgw else D5.ctx.sp(sigs[W], k, delta)
-        D5.ctx.set_option("screened_sweep", int(screened))  # 1: bf16 image, 2: int8 image
+        D5.ctx.set_option("batch_cert", 1 if int(screened) == 3 else 0)  # binary16 image: the rigorous certificate (the default); bf16 / int8: statistical
+        D5.ctx.set_option("screened_sweep", int(screened))  # 3: binary16 image, 1: bf16 image, 2: int8 image
         D5.ctx.screened_stats(reset=True)
 
     def solve(b):
@@ -556,7 +557,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         dt = time.perf_counter() - t0
         sweeps, sweep_ms = D5.ctx.profile_read(reset=True)
         D5.ctx.profile_enable(False)
-    alg = M5 * N5 * ({1: 2, 2: 1}[int(screened)] if screened else 4)
+    alg = M5 * N5 * ({1: 2, 2: 1, 3: 2}[int(screened)] if screened else 4)
     avg = sweep_ms / max(sweeps, 1) / 1e3
     isg = workload in ("gomp", "gomp_single")
     out = {"metric": ("GOMP (S=4) atoms selected/sec" + ((", three solves in flight (csmp_gomp_batch)" if screened else ", two solves in flight (csmp_gomp_batch)") if workload == "gomp" else ", one gomp call at a time")
@@ -574,18 +575,20 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     if isg:  # the whole solve against the same roofline: one dictionary pass per S atoms is all the algorithm needs
         out["roofline"]["whole_solve"] = {"achieved": alg / S * atoms / dt / 1e9, "frac": alg / S * atoms / dt / 1e9 / HBM_PEAK_GBS,
-                                          "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % ({1: 2, 2: 1}[int(screened)] if screened else 4)}
+                                          "note": "ALL-IN: M*N*%d bytes per S atoms / wall time per atom" % ({1: 2, 2: 1, 3: 2}[int(screened)] if screened else 4)}
     if screened:
         import numpy as np
         st_ = D5.ctx.screened_stats(reset=True)
         got0 = D5.ctx.gomp(sigs[W], S, k, eps) if isgw else D5.ctx.sp(sigs[W], k, delta)
         D5.ctx.screened_stats(reset=True)
         D5.ctx.set_option("screened_sweep", 0)
+        D5.ctx.set_option("batch_cert", 1)
         if not isgw:  # sp returns (idx, val, update! calls): the count has to agree too
             exact0 = (exact0[0], exact0[1], np.asarray([exact0[2]]))
             got0 = (got0[0], got0[1], np.asarray([got0[2]]))
-        out["metric"] += ", screened sweep (%s image, certified top-%s, exact results)" % ("int8" if int(screened) == 2 else "bf16", "S picks" if isgw else "k sets")
-        out["roofline"]["kernel"] = "csmp::k_sweep_i8<2,3,true> (M*N bytes per sweep)" if int(screened) == 2 else "csmp::k_sweep_bf16<2,3,true> (M*N*2 bytes per sweep)"
+        iname5 = {1: "bf16", 2: "int8", 3: "f16"}[int(screened)]
+        out["metric"] += ", screened sweep (%s image, %s certificate, certified top-%s, exact results)" % (iname5, "rigorous" if int(screened) == 3 else "statistical", "S picks" if isgw else "k sets")
+        out["roofline"]["kernel"] = "csmp::k_sweep_i8<2,3,true> (M*N bytes per sweep)" if int(screened) == 2 else "csmp::k_sweep_%s<2,3,true> (M*N*2 bytes per sweep)" % iname5
         out["screened"] = {"stats": st_, "first_timed_solve_equals_exact_path": bool(
             np.array_equal(got0[0], exact0[0]) and np.array_equal(got0[2], exact0[2]) and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12)),
             "f32_equivalent_frac_all_in": (M5 * N5 * 4 / S * atoms / dt / 1e9 / HBM_PEAK_GBS) if isgw else None,
@@ -598,7 +601,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
         r["achieved"], r["frac"] = r["whole_solve"]["achieved"], r["whole_solve"]["frac"]
         r["note"] = ("achieved / frac = ALL-IN (M*N*%d bytes per S atoms / wall time per atom): with two solves in flight the sweeps of the two "
                      "streams overlap and a per-launch duration measures the sharing, not the kernel (gomp_c5_single has the kernel alone)"
-                     % ({1: 2, 2: 1}[int(screened)] if screened else 4))
+                     % ({1: 2, 2: 1, 3: 2}[int(screened)] if screened else 4))
     if workload == "sp":
         r = out["roofline"]  # (as for gomp: overlapping solves share the HBM, a per-launch duration measures the sharing)
         r["sweep_launch_while_sharing_the_gpu"] = {"avg_launch_us": r["avg_launch_us"], "achieved": r["achieved"], "frac": r["frac"]}
@@ -653,8 +656,9 @@ def run_twostage(args, cs, torch, dev, At, D, show=True):
     # ompr with the screened sweep (--screened): the result of the first timed signal is compared with the exact path's
     image = 0
     if args.workload == "ompr" and getattr(args, "screened", False):
-        image = 2 if getattr(args, "screen_image", "bf16") == "int8" else 1
+        image = {"f16": 3, "bf16": 1, "int8": 2}[getattr(args, "screen_image", "f16")]
         exact0 = D.ctx.ompr(sigs[W], K_ATOMS, 1e-6)
+        D.ctx.set_option("batch_cert", 1 if image == 3 else 0)
         D.ctx.set_option("screened_sweep", image)
         D.ctx.screened_stats(reset=True)
     for w in range(W):
@@ -667,14 +671,15 @@ def run_twostage(args, cs, torch, dev, At, D, show=True):
         iters += solve(sigs[s_])
     dt = time.perf_counter() - t0
     sweeps, sweep_ms = D.ctx.profile_read(reset=True)
-    alg = M * N * ({0: 4, 1: 2, 2: 1}[image])
+    alg = M * N * ({0: 4, 1: 2, 2: 1, 3: 2}[image])
     avg = sweep_ms / max(sweeps, 1) / 1e3
     scr_info = None
     if image:
         st_ = D.ctx.screened_stats(reset=True)
         got0 = D.ctx.ompr(sigs[W], K_ATOMS, 1e-6)
         D.ctx.set_option("screened_sweep", 0)
-        scr_info = {"image": "int8" if image == 2 else "bf16", "stats": st_, "stats_count": "sweeps (one certified selection each)",
+        D.ctx.set_option("batch_cert", 1)
+        scr_info = {"image": {1: "bf16", 2: "int8", 3: "f16"}[image], "stats": st_, "stats_count": "sweeps (one certified selection each)",
                     "first_timed_solve_equals_exact_path": bool(np.array_equal(got0[0], exact0[0]) and got0[2] == exact0[2]
                                                                 and np.allclose(got0[1], exact0[1], rtol=1e-9, atol=1e-12))}
     name = {"ompr": "OMP with replacement", "srr": "stepwise regression with replacement (oblivious start, l=1)"}[args.workload]
@@ -685,7 +690,7 @@ def run_twostage(args, cs, torch, dev, At, D, show=True):
                       "iterations": int(iters), "iterations_per_s": iters / dt, "sweeps_timed": int(sweeps)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
-                        "kernel": ("csmp::k_sweep_i8<2,3,true>" if image == 2 else "csmp::k_sweep_bf16<2,3,true>" if image == 1 else "csmp::k_sweep_pf<float,16,true>")
+                        "kernel": ("csmp::k_sweep_i8<2,3,true>" if image == 2 else "csmp::k_sweep_bf16<2,3,true>" if image == 1 else "csmp::k_sweep_f16<2,3,true>" if image == 3 else "csmp::k_sweep_pf<float,16,true>")
                         if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     D.ctx.profile_enable(False)
@@ -901,7 +906,7 @@ def main():
             if args.in_flight:
                 D5.ctx.set_option("solves_in_flight", args.in_flight)
             emit(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5,
-                                 screened=(2 if args.screen_image == "int8" else 1) if args.screened else 0))
+                                 screened={"f16": 3, "bf16": 1, "int8": 2}[args.screen_image] if args.screened else 0))
             D5.close()
         return finish()
     At = make_dictionary(torch, dev)
@@ -918,7 +923,7 @@ def main():
             args.steps, args.warmup = 9, 3
         if rank == 0:
             emit(measure_screened_omp(args.steps, args.warmup, torch, dev, At, D, D.eps,
-                                      cert=1 if args.batch_cert == "rigorous" else 0, image=2 if args.screen_image == "int8" else 1))
+                                      cert=1 if args.batch_cert == "rigorous" else 0, image={"f16": 3, "bf16": 1, "int8": 2}[args.screen_image]))
         D.close()
         return finish()
     if args.workload == "batched":
@@ -1047,10 +1052,10 @@ def main():
             except Exception as e:  # noqa: BLE001
                 sec["lone_omp_c2"] = {"error": repr(e)}
             try:  # opt-in: sweeps over the bf16 image with certified picks (same results, half the bytes)
-                sec["omp_c2_screened"] = measure_screened_omp(6, 2, torch, dev, At, D, eps)
-                sec["omp_c2_screened_int8"] = measure_screened_omp(6, 2, torch, dev, At, D, eps, image=2)
+                sec["omp_c2_screened_f16"] = measure_screened_omp(6, 2, torch, dev, At, D, eps)  # (binary16 image, rigorous certificate)
+                sec["omp_c2_screened_int8"] = measure_screened_omp(6, 2, torch, dev, At, D, eps, cert=0, image=2)
             except Exception as e:  # noqa: BLE001
-                sec["omp_c2_screened"] = {"error": repr(e)}
+                sec["omp_c2_screened_f16"] = {"error": repr(e)}
             # library defaults (int8 operands for the screen) / the rigorous certificate (bf16 operands) / + the resident Gram matrix /
             # the bf16 screen of rounds 1-2 with and without the Gram matrix
             # library defaults (the rigorous certificate) / + the resident Gram matrix / the opt-in statistical certificates
@@ -1077,20 +1082,21 @@ def main():
                 At5, D5 = make_dictionary5(cs, torch, dev)
                 sec["gomp_c5"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5)
                 sec["gomp_c5_single"] = measure_config5("gomp_single", 2, 1, cs, torch, dev, D5, At5)
-                sec["gomp_c5_screened"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=1)
+                sec["gomp_c5_screened_f16"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=3)
                 sec["gomp_c5_screened_int8"] = measure_config5("gomp", 6, 2, cs, torch, dev, D5, At5, screened=2)
                 sec["sp_c5"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5)
                 sec["sp_c5_single"] = measure_config5("sp_single", 3, 1, cs, torch, dev, D5, At5)
                 sec["sp_c5_default_delta"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, delta=1e-12)
+                sec["sp_c5_screened_f16"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, screened=3)
                 sec["sp_c5_screened_int8"] = measure_config5("sp", 9, 3, cs, torch, dev, D5, At5, screened=2)
                 D5.close()
             except Exception as e:  # noqa: BLE001
                 sec["config5"] = {"error": repr(e)}
             out["secondary"] = sec
-            try:  # the fastest path of this line whose results are identical to the headline's (opt-in: see DESIGN.md)
-                sc = sec["omp_c2_screened_int8"]
-                out["fastest_identical_results"] = {"value": sc["value"], "unit": "atoms/s", "where": "secondary.omp_c2_screened_int8 (csmp_omp_batch, CSMP_OPT_SCREENED_SWEEP = 2)",
-                                                    "equals_exact_path": sc["batch"]["equals_exact_path"], "fallbacks": sc["batch"]["stats"]["fallbacks"]}
+            try:  # the fastest PROVABLY identical path of this line (opt-in: binary16 image, rigorous certificate)
+                sc = sec["omp_c2_screened_f16"]
+                out["fastest_provably_identical_results"] = {"value": sc["value"], "unit": "atoms/s", "where": "secondary.omp_c2_screened_f16 (csmp_omp_batch, CSMP_OPT_SCREENED_SWEEP = 3, rigorous certificate)",
+                                                             "equals_exact_path": sc["batch"]["equals_exact_path"], "fallbacks": sc["batch"]["stats"]["fallbacks"]}
             except Exception:  # noqa: BLE001
                 pass
         emit(out)

@@ -1025,11 +1025,21 @@ __device__ __forceinline__ void slab_x_minus_qw(const double* __restrict__ Q, in
 }
 
 // LDS carve shared by the QR kernels (dynamic): part[4*jpad] | ws[jpad] | xs[64] | tmp[512] | sc[8]
+// spill (k_qr1s / k_qr2s / k_qr3s): supports beyond what 160 KiB of LDS hold (five vectors of ~3900 Float64) keep the five
+// support-length vectors of workgroup g in GLOBAL memory (L2-resident: 5 jpad doubles per workgroup), only the slab scratch in
+// LDS.  The bodies order their accesses to these vectors with __syncthreads() only (a workgroup-scope fence for global memory
+// as well), so the same code runs on either kind of pointer; spill == nullptr is a compile-time constant in the LDS kernels.
 __device__ __forceinline__ void qr_carve(double* base, int jpad, double*& part, double*& ws, double*& xs,
-                                         double*& tmp, double*& sc) {
-    part = base;
-    ws = part + 4 * jpad;
-    xs = ws + jpad;
+                                         double*& tmp, double*& sc, double* spill = nullptr, int g = 0) {
+    if (spill) {
+        part = spill + (size_t)g * 5 * (size_t)jpad;
+        ws = part + 4 * jpad;
+        xs = base;
+    } else {
+        part = base;
+        ws = part + 4 * jpad;
+        xs = ws + jpad;
+    }
     tmp = xs + kSlabRows;
     sc = tmp + 8 * kSlabRows;
 }
@@ -1037,6 +1047,8 @@ inline int qr_jpad(int kcap) { return ((kcap + 63) / 64) * 64 + 2; }
 inline size_t qr_lds_bytes(int kcap) {
     return (size_t)(5 * qr_jpad(kcap) + kSlabRows + 8 * kSlabRows + 8) * sizeof(double);
 }
+inline size_t qr_spill_lds_bytes() { return (size_t)(kSlabRows + 8 * kSlabRows + 8) * sizeof(double); }
+inline size_t qr_spill_doubles(int G, int kcap) { return (size_t)G * 5 * (size_t)qr_jpad(kcap); }
 
 // mode 1 (OMP): atom = arg-max over the sweep's workgroup partials; guards nnz < M (:63) and
 //   "i not in x.nzind" (:66) -- a failed guard makes every later update! the same no-op: done.
@@ -1057,9 +1069,9 @@ __device__ __forceinline__ void qr1_body(const TA* __restrict__ A, int64_t ld, i
                                                     const int* __restrict__ cands, const int* __restrict__ ncands,
                                                     int which, const int* __restrict__ sel, int skipmask,
                                                     const double* __restrict__ r, double* __restrict__ P1s, int jh, const int g, double* lds,
-                                                    const double min_d2 = 0.0) {
+                                                    const double min_d2 = 0.0, double* spill = nullptr) {
     double *part, *ws, *xs, *tmp, *sc;
-    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc, spill, g);
     const int tid = threadIdx.x;
     QtPre<W> pre;
     slab_qt_prefetch<W>(pre, Q, ldq, g, jh);
@@ -1132,6 +1144,19 @@ __global__ __launch_bounds__(kQrThreads) void k_qr1(const TA* __restrict__ A, in
     extern __shared__ __attribute__((aligned(16))) double lds[];
     qr1_body<TA, 4>(A, ld, M, Q, ldq, st, avec, P1, G, kcap, jpad, mode, pval, pidx, nblk, cands, ncands, which, sel, skipmask, r, P1s, jh, (int)blockIdx.x, lds, min_d2);
 }
+template <typename TA>
+__global__ __launch_bounds__(kQrThreads) void k_qr1s(const TA* __restrict__ A, int64_t ld, int M,
+                                                     const double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                     double* __restrict__ avec, double* __restrict__ P1, int G, int kcap,
+                                                     int jpad, int mode, const double* __restrict__ pval,
+                                                     const int* __restrict__ pidx, int nblk,
+                                                     const int* __restrict__ cands, const int* __restrict__ ncands,
+                                                     int which, const int* __restrict__ sel, int skipmask,
+                                                     const double* __restrict__ r, double* __restrict__ P1s, int jh,
+                                                     double min_d2, double* __restrict__ spill) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr1_body<TA, 4>(A, ld, M, Q, ldq, st, avec, P1, G, kcap, jpad, mode, pval, pidx, nblk, cands, ncands, which, sel, skipmask, r, P1s, jh, (int)blockIdx.x, lds, min_d2, spill);
+}
 
 // Publishes the new column (shared by the accept path of k_qr2 and by k_qr3).
 __device__ __forceinline__ void qr_commit(double* __restrict__ Q, int64_t ldq, DevState* st, double* __restrict__ r,
@@ -1169,12 +1194,12 @@ __device__ __forceinline__ void qr2_body(double* __restrict__ Q, int64_t ldq, De
                                                     double* __restrict__ P2, double* __restrict__ P2s,
                                                     double* __restrict__ R, double* __restrict__ z,
                                                     int* __restrict__ sel, int kcap, int jpad, int force_reorth,
-                                                    int jh, int optimistic, const int g, double* lds) {
+                                                    int jh, int optimistic, const int g, double* lds, double* spill = nullptr) {
     XmPre<NX> pre;
     slab_xm_prefetch<NX>(pre, Q, ldq, g, jh);
     if (!st->go) return;
     double *part, *ws, *xs, *tmp, *sc;
-    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc, spill, g);
     const int tid = threadIdx.x, j = st->j;
     double rr = 0.0, na2 = 0.0, ar = 0.0;
     if (tid < kSlabRows) {
@@ -1238,16 +1263,26 @@ __global__ __launch_bounds__(kQrThreads) void k_qr2(double* __restrict__ Q, int6
     extern __shared__ __attribute__((aligned(16))) double lds[];
     qr2_body<32>(Q, ldq, st, avec, r, P1, P1s, G, W1, vvec, P2, P2s, R, z, sel, kcap, jpad, force_reorth, jh, optimistic, (int)blockIdx.x, lds);
 }
-
-__global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int64_t ldq, DevState* st,
-                                                    const double* __restrict__ vvec, double* __restrict__ r,
-                                                    const double* __restrict__ P2, const double* __restrict__ P2s,
-                                                    int G, const double* __restrict__ W1, double* __restrict__ R,
-                                                    double* __restrict__ z, int* __restrict__ sel, int kcap, int jpad) {
+__global__ __launch_bounds__(kQrThreads) void k_qr2s(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                     const double* __restrict__ avec, double* __restrict__ r,
+                                                     const double* __restrict__ P1, const double* __restrict__ P1s,
+                                                     int G, double* __restrict__ W1, double* __restrict__ vvec,
+                                                     double* __restrict__ P2, double* __restrict__ P2s,
+                                                     double* __restrict__ R, double* __restrict__ z,
+                                                     int* __restrict__ sel, int kcap, int jpad, int force_reorth,
+                                                     int jh, int optimistic, double* __restrict__ spill) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr2_body<32>(Q, ldq, st, avec, r, P1, P1s, G, W1, vvec, P2, P2s, R, z, sel, kcap, jpad, force_reorth, jh, optimistic, (int)blockIdx.x, lds, spill);
+}
+
+__device__ __forceinline__ void qr3_body(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                         const double* __restrict__ vvec, double* __restrict__ r,
+                                         const double* __restrict__ P2, const double* __restrict__ P2s,
+                                         int G, const double* __restrict__ W1, double* __restrict__ R,
+                                         double* __restrict__ z, int* __restrict__ sel, int kcap, int jpad, double* lds, double* spill = nullptr) {
     if (!st->go || !st->go2) return;
     double *part, *ws, *xs, *tmp, *sc;
-    qr_carve(lds, jpad, part, ws, xs, tmp, sc);
+    qr_carve(lds, jpad, part, ws, xs, tmp, sc, spill, (int)blockIdx.x);
     const int tid = threadIdx.x, g = blockIdx.x, j = st->j;
     double rr = 0.0, n2 = 0.0, vr = 0.0;
     if (tid < kSlabRows) {
@@ -1267,6 +1302,23 @@ __global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int6
     const double zj = (rho > 0.0) ? vr / rho : 0.0;  // z_j = q_j' r
     slab_x_minus_qw(Q, ldq, g, j, ws, xs, tmp);      // v_g - Q_g w2
     qr_commit(Q, ldq, st, r, R, z, sel, kcap, g, j, xs, rr, rho, zj, W1, ws);
+}
+__global__ __launch_bounds__(kQrThreads) void k_qr3(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                    const double* __restrict__ vvec, double* __restrict__ r,
+                                                    const double* __restrict__ P2, const double* __restrict__ P2s,
+                                                    int G, const double* __restrict__ W1, double* __restrict__ R,
+                                                    double* __restrict__ z, int* __restrict__ sel, int kcap, int jpad) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr3_body(Q, ldq, st, vvec, r, P2, P2s, G, W1, R, z, sel, kcap, jpad, lds);
+}
+__global__ __launch_bounds__(kQrThreads) void k_qr3s(double* __restrict__ Q, int64_t ldq, DevState* st,
+                                                     const double* __restrict__ vvec, double* __restrict__ r,
+                                                     const double* __restrict__ P2, const double* __restrict__ P2s,
+                                                     int G, const double* __restrict__ W1, double* __restrict__ R,
+                                                     double* __restrict__ z, int* __restrict__ sel, int kcap, int jpad,
+                                                     double* __restrict__ spill) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    qr3_body(Q, ldq, st, vvec, r, P2, P2s, G, W1, R, z, sel, kcap, jpad, lds, spill);
 }
 
 // ---------------------------------------------------------------------------------------------

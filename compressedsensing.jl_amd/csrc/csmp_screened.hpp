@@ -23,6 +23,7 @@
 // path's with one rounded operand -- the same (conservative) bounds are used.
 #pragma once
 #include "csmp_batched.hpp"
+#include <type_traits>
 
 namespace csmp {
 
@@ -87,10 +88,15 @@ __device__ __forceinline__ int row16_sum(int v) {  // the same for the int8 swee
 // one workgroup maximum), kept as int8 in LDS (4 KiB at M = 4096), multiplied with v_dot4c_i32_i8 -- four exact integer
 // multiply-adds per instruction -- and the candidate values are |integer sum| * astep * rstep.  Mk counts the image's
 // elements per row (bf16: 2 bytes each, int8: 1).
-template <int U, int D, bool FULL, int C, bool I8, int LC = kScrCand>
+// IMG = kOpF16: the same stream as bf16 over the BINARY16 image (csmp_batched.hpp: k_b_convert_f16, the dictionary under one
+// power-of-two scale): eleven significand bits instead of eight -- the rigorous certificate's bound shrinks from 2^-8 to 2^-11 of
+// |a||r| (one rounded operand: the residual enters in f32) -- at the same 2 bytes per element; the candidate values are multiplied
+// by `astep` = 1 / scale (exact).
+template <int U, int D, bool FULL, int C, int IMG, int LC = kScrCand>
 __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int Mk, int64_t N, const double* __restrict__ r, int Mr,
                                                float* __restrict__ cand_val, int* __restrict__ cand_idx, DevState* st, double eps,
                                                int check_eps, int skipmask, unsigned* __restrict__ tickets, float astep, char* smem) {
+    constexpr bool I8 = IMG == kOpI8;
     constexpr int NW = kSweepThreads / kWave;
     static_assert(C == 2 || C == 4, "two or four columns side by side");
     constexpr int NL = NW * (kWave / 16);  // lists per workgroup (one per 16-lane row)
@@ -300,7 +306,8 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
                             const f32x4 r0 = rs[(t * 2 + 0) * kWave + lane], r1 = rs[(t * 2 + 1) * kWave + lane];
 #pragma unroll
                             for (int c = 0; c < C; ++c) {
-                                const V a = buf[d][u][c];
+                                using VE = typename std::conditional<IMG == kOpF16, f16x8v, V>::type;
+                                const VE a = __builtin_bit_cast(VE, buf[d][u][c]);
                                 acc0[c] = fmaf((float)a[0], r0.x, acc0[c]);
                                 acc1[c] = fmaf((float)a[1], r0.y, acc1[c]);
                                 acc0[c] = fmaf((float)a[2], r0.z, acc0[c]);
@@ -329,6 +336,7 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
                             acc0[c] = acc1[c] = 0.0f;
                         }
                         vabs = fabsf(butterfly(a));
+                        if constexpr (IMG == kOpF16) vabs *= astep;  // (1 / the image's power-of-two scale: exact)
                     }
                     const int64_t col = (int64_t)sg[d] * C + (C == 4 ? (lane >> 4) : (lane >> 5));
                     float v = col < N && (C == 4 || !(lane & 16)) ? vabs : -1.0f;
@@ -388,8 +396,17 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                                                               int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
                                                               int skipmask, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) char smem_sweep[];  // the residual image | reduction scratch | the lists
-    sweep_img_body<U, D, FULL, C, false, LC>(reinterpret_cast<const char*>(Ab), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
-                                         0.0f, smem_sweep);
+    sweep_img_body<U, D, FULL, C, kOpBf16, LC>(reinterpret_cast<const char*>(Ab), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+                                           0.0f, smem_sweep);
+}
+template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_f16(const _Float16* __restrict__ Ah, int Mk, int64_t N,
+                                                             const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
+                                                             int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
+                                                             int skipmask, unsigned* __restrict__ tickets, float inv_scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sweep[];
+    sweep_img_body<U, D, FULL, C, kOpF16, LC>(reinterpret_cast<const char*>(Ah), Mk, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+                                          inv_scale, smem_sweep);
 }
 template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_i8(const signed char* __restrict__ A8, int Mk8, int64_t N,
@@ -397,8 +414,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_i8(const signed char* _
                                                             int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
                                                             int skipmask, unsigned* __restrict__ tickets, float astep) {
     extern __shared__ __attribute__((aligned(16))) char smem_sweep[];
-    sweep_img_body<U, D, FULL, C, true, LC>(reinterpret_cast<const char*>(A8), Mk8, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
-                                        astep, smem_sweep);
+    sweep_img_body<U, D, FULL, C, kOpI8, LC>(reinterpret_cast<const char*>(A8), Mk8, N, r, Mr, cand_val, cand_idx, st, eps, check_eps, skipmask, tickets,
+                                         astep, smem_sweep);
 }
 inline size_t sweep_i8_lds_bytes(int Mk8, int lc = kScrCand) {
     const int nchunk = (Mk8 + 1023) / 1024;

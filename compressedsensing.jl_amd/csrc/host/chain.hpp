@@ -185,10 +185,38 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
     const int jpad = qr_jpad(jh);
     const size_t lds = qr_lds_bytes(jh);
     if (jh >= qr_max_cols() || lds > 160 * 1024 - 512) {
-        // The append kernels keep five support-length vectors in LDS: about 3900 columns.  A solve that gets there (the
-        // reference's defaults k = size(A,1) at M = 4096 with a residual test that never fires) STOPS there: the step is
-        // withheld, the solution reached so far stays valid, and the driver reports CSMP_WCAPACITY / CSMP_STOP_CAPACITY.
-        s.capped = true;
+        // The append kernels keep five support-length vectors in LDS: about 3900 columns.  A support beyond that -- the
+        // reference's defaults k = size(A,1) at M >= 4096 with a residual test that never fires (src/matchingpursuit.jl:54,89,108)
+        // -- is served by the SPILL kernels: the same bodies with those vectors in global memory (5 jpad doubles per workgroup,
+        // L2-resident), only the slab scratch in LDS.
+        const int jpc = qr_jpad(s.kcap);  // (sized by the capacity once: the launches below follow jh growing to it)
+        if (!s.spill || s.spill_cap < qr_spill_doubles(s.G, s.kcap)) {
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            dfree(s.spill);
+            CHECK(dmalloc(ctx, &s.spill, qr_spill_doubles(s.G, s.kcap)));
+            s.spill_cap = qr_spill_doubles(s.G, s.kcap);
+        }
+        const size_t slds = qr_spill_lds_bytes();
+        if (ctx->dtype == CSMP_F32)
+            hipLaunchKernelGGL(k_qr1s<float>, dim3(s.G), dim3(kQrThreads), slds, ctx->stream, (const float*)dA, ldA,
+                               (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, jpc, mode,
+                               (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
+                               (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2, s.spill);
+        else
+            hipLaunchKernelGGL(k_qr1s<double>, dim3(s.G), dim3(kQrThreads), slds, ctx->stream, (const double*)dA, ldA,
+                               (int)ctx->M, (const double*)s.Q, s.ldq, s.st, s.avec, s.P1, s.G, s.kcap, jpc, mode,
+                               (const double*)s.pval, (const int*)s.pidx, nblk_sweep > 0 ? nblk_sweep : ctx->sweep_grid, (const int*)s.cands,
+                               (const int*)s.ncands, which, (const int*)s.sel, skipmask, (const double*)s.r, s.P1s, jh, min_d2, s.spill);
+        HIPCHECK(hipGetLastError());
+        hipLaunchKernelGGL(k_qr2s, dim3(s.G), dim3(kQrThreads), slds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
+                           (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
+                           jpc, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0, s.spill);
+        HIPCHECK(hipGetLastError());
+        if (s.jh < s.kcap) s.jh += 1;
+        if (optimistic) return CSMP_OK;
+        hipLaunchKernelGGL(k_qr3s, dim3(s.G), dim3(kQrThreads), slds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.vvec, s.r,
+                           (const double*)s.P2, (const double*)s.P2s, s.G, (const double*)s.W1, s.R, s.z, s.sel, s.kcap, jpc, s.spill);
+        HIPCHECK(hipGetLastError());
         return CSMP_OK;
     }
     if (lds > 64 * 1024) {

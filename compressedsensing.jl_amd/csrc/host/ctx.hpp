@@ -31,6 +31,8 @@ struct Solver {
     unsigned long long* scr_cb = nullptr;  // sp_select_screened: the bound of everything that was not rescored (bits of a double)
     int* scr_flag = nullptr;               // ... and 1 when the selection could not be certified
     unsigned* scr_tickets = nullptr;  // k_sweep_bf16's ticket counters, one per partition of workgroups, kScrTicketStride words apart
+    double* spill = nullptr;  // supports beyond the LDS append kernels' ~3900 columns: their five support-length vectors per workgroup (launch_append)
+    size_t spill_cap = 0;
     bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
     // multi-column append (csmp_block.hpp), allocated on first use
@@ -99,6 +101,7 @@ struct Batch {
     // that puts max|A| in [2^14, 2^15)); the residual images live in Rb under per-signal scales
     _Float16* Ah = nullptr;
     bool ah_valid = false;
+    bool ah_borrowed = false;  // (a twin sweeping its parent's image)
     float ascale16 = 1.f;
     int64_t last_signals = 0, last_resolved = 0, last_uncertain = 0, last_illcond = 0;
     int last_mode = 0;  // screening kernel of the last batch (kScreen128 / kScreen256 / kScreenCo)
@@ -241,6 +244,7 @@ struct DevTmp {
 // defined in host/batched.hpp and host/screened.hpp (included later); used by the omp drivers
 static int batch_dict(csmp_ctx* ctx);
 static int batch_dict8(csmp_ctx* ctx);
+static int batch_dict16(csmp_ctx* ctx);
 static int batch_meta(csmp_ctx* ctx);
 static int batch_colnorm(csmp_ctx* ctx);
 static int screened_ensure(csmp_ctx* ctx);

@@ -278,7 +278,9 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     // of one signal and the two short append stages of the other two, so the latency-bound chain
     // is hidden underneath the HBM-bound sweep.  Bit-identical to the one-at-a-time path.
     const bool opt = !ctx->force_reorth;
-    bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full;
+    // (the tick kernel carries the LDS form of the append stages: supports beyond qr_max_cols() go one signal at a time through
+    // launch_append, whose spill kernels have no such bound)
+    bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full && kc <= qr_max_cols();
     if (isfr) {  // the tick kernel exists for the exact-tiling FR sweeps only
         int U, g; bool full; size_t l;
         fr_config(ctx, 1, U, full, l, g);

@@ -48,6 +48,8 @@ static void batch_free(Batch& b, bool keep_dict) {
         b.a8_borrowed = false;
         dfree(b.A8);
         b.a8_valid = false;
+        if (b.ah_borrowed) b.Ah = nullptr;
+        b.ah_borrowed = false;
         dfree(b.Ah);
         b.ah_valid = false;
         dfree(b.Gm);
@@ -69,6 +71,7 @@ static void activate_slot(csmp_ctx* ctx, int slot) {
 static hipError_t sync_all(csmp_ctx* ctx) { return hipStreamSynchronize(ctx->stream); }
 
 static void solver_free(Solver& s) {
+    dfree(s.spill); s.spill_cap = 0;
     dfree(s.b); dfree(s.r); dfree(s.cvec); dfree(s.pval); dfree(s.pidx); dfree(s.Q); dfree(s.R); dfree(s.z);
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
@@ -167,7 +170,7 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_BATCH_WINDOW: *lo = 0; *hi = kWinMax; return &ctx->opt_batch_window;
         case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
         case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
-        case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 2; return &ctx->opt_screened;
+        case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 3; return &ctx->opt_screened;
         case CSMP_OPT_BATCH_SCREEN: *lo = 0; *hi = 3; return &ctx->opt_batch_screen;
         default: return nullptr;
     }

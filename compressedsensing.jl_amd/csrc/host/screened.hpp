@@ -8,8 +8,9 @@ static int screened_ensure(csmp_ctx* ctx) {
     CHECK(batch_meta(ctx));
     Batch& b = ctx->bt;
     const bool i8 = ctx->opt_screened == 2 && b.amax_host <= 8.0f * b.arms_host;
-    ctx->scr_image = i8 ? 2 : 1;
-    CHECK(i8 ? batch_dict8(ctx) : batch_dict(ctx));
+    const bool f16 = ctx->opt_screened == 3;
+    ctx->scr_image = i8 ? 2 : f16 ? 3 : 1;
+    CHECK(i8 ? batch_dict8(ctx) : f16 ? batch_dict16(ctx) : batch_dict(ctx));
     // The certificate's coefficients are recomputed on every call (a few flops; the column-norm reduction behind them is cached per
     // dictionary in bt.anorm_host, which csmp_set_dictionary resets): nothing of a previous dictionary can survive in them.
     if (i8) {  // int8 image: statistical bound only (see csmp_omp_batch_mfma, host/batched.hpp)
@@ -20,15 +21,20 @@ static int screened_ensure(csmp_ctx* ctx) {
         ctx->scr_kwin = kWinMax;
     } else {
         ctx->scr_cert_abs2 = 0.0;
-        // one rounded operand (the residual enters the sweep in f32): the two-operand bounds of the batched path are kept -- conservative
+        // ONE rounded operand here: the image of the dictionary (unit roundoff u: 2^-11 binary16, 2^-8 bf16; + 2^-23 for a Float64
+        // dictionary's double rounding); the residual enters the sweep in Float32 (2^-24) and the sums are Float32 FMAs in a fixed
+        // order, round to nearest (2^-24 each, fewer than Mk of them on any path to a sum):
+        //     |<a,r> - screened| <= (u + 2^-24 + Mk 2^-24)(1 + 2^-10) |a|_2 |r|_2  [+ binary16's subnormal entries: sqrt(Mk) 2^-38]
+        const double u_img = (f16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8)) + std::ldexp(1.0, -23);
         if (ctx->opt_batch_cert == 1) {
             CHECK(batch_colnorm(ctx));
-            ctx->scr_cert_abs = (std::ldexp(1.0, -7) * (1.0 + std::ldexp(1.0, -9)) + (double)b.Mk * std::ldexp(1.0, -24)) * (double)b.anorm_host;
+            ctx->scr_cert_abs = ((u_img + std::ldexp(1.0, -24) + (double)b.Mk * std::ldexp(1.0, -24)) * (1.0 + std::ldexp(1.0, -10)) +
+                                 (f16 ? std::sqrt((double)b.Mk) * std::ldexp(1.0, -38) : 0.0)) * (double)b.anorm_host;
             ctx->scr_cert_rel = std::ldexp(1.0, -20);
             ctx->scr_kwin = kWinMax;
-        } else {
-            ctx->scr_cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * std::ldexp(1.0, -9) * (double)b.amax_host;
-            ctx->scr_cert_rel = std::ldexp(1.0, -7) * 1.01 + std::ldexp(1.0, -20);
+        } else {  // statistical: 8 sigma of independent roundings of the image's entries + the coherent term (host/batched.hpp)
+            ctx->scr_cert_abs = 8.0 * std::sqrt(2.0 / 3.0) * u_img * 0.5 * (double)b.amax_host;
+            ctx->scr_cert_rel = 2.0 * u_img * 1.01 + std::ldexp(1.0, -20);
             ctx->scr_kwin = kWinMax / 2;
         }
     }
@@ -119,13 +125,22 @@ static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip,
     }
     const int nchunk = (b.Mk + 511) / 512;
     const size_t lds = sweep_bf16_lds_bytes(b.Mk, lc);
+    const bool f16 = ctx->scr_image == 3;  // the binary16 image: the same stream, layout and LDS as bf16
 #define CSMP_SCRL(U, DD, FULL, LCV)                                                                                                       \
     {                                                                                                                                     \
-        if (lds > 48 * 1024)                                                                                                              \
-            HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,           \
-                           (const __bf16*)b.Ab, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
-                           s.scr_tickets);                                                                                                \
+        if (f16) {                                                                                                                        \
+            if (lds > 48 * 1024)                                                                                                          \
+                HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_f16<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_sweep_f16<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,        \
+                               (const _Float16*)b.Ah, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
+                               s.scr_tickets, 1.0f / b.ascale16);                                                                         \
+        } else {                                                                                                                          \
+            if (lds > 48 * 1024)                                                                                                          \
+                HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_bf16<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((k_sweep_bf16<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,       \
+                               (const __bf16*)b.Ab, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
+                               s.scr_tickets);                                                                                            \
+        }                                                                                                                                 \
     }
 #define CSMP_SCR(U, DD, FULL)                                   \
     {                                                           \
@@ -251,6 +266,16 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
         tb.Mk8 = pb.Mk8;
         tb.astep = pb.astep;
         tb.a8_valid = tb.a8_borrowed = true;
+    }
+    if (ctx->bt.ah_valid && !twin->bt.ah_valid) {
+        Batch &tb = twin->bt, &pb = ctx->bt;
+        tb.Ah = pb.Ah;
+        tb.ascale16 = pb.ascale16;
+        tb.Mk = pb.Mk;
+        tb.Npad = pb.Npad;
+        tb.n_atiles = pb.n_atiles;
+        tb.amax_host = pb.amax_host;
+        tb.ah_valid = tb.ah_borrowed = true;
     }
     if (ctx->bt.ab_valid && !twin->bt.ab_valid) {
         Batch &tb = twin->bt, &pb = ctx->bt;

@@ -238,18 +238,21 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
 #define CSMP_OPT_TWOSTAGE_UPDATE 8 /* ompr's exchange step: 0 (default) explicit inverse T = R^-1 beside R, 1 Givens down-date of R,
                                       2 refactorise from scratch (the reference's own cost model, src/twostage.jl:171-174) */
 #define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
-#define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) and csmp_ompr (k <= 4096): 0 (default) every sweep reads
-                                      the f32/f64 dictionary (exact, 4 bytes per element); 1 the sweep reads the bf16 image (2 bytes
-                                      per element, f32 accumulate), 2 the int8 image where the dictionary is flat (max|A| <= 8 rms of its entries;
-                                      otherwise the bf16 image) (1 byte per element under one step max|A|/127,
-                                      the residual quantised per sweep, exact integer accumulation) and only SCREENS: the best
-                                      candidates are rescored in Float64 from the master dictionary under the batched variant's
-                                      certificate (1: CSMP_OPT_BATCH_CERT selects it; 2: the statistical one; gomp: the whole
-                                      top-l set and its order are certified; sp: every acquisition's top-k SET); a solve (sp: an
-                                      acquisition) with an uncertified step is repeated with the exact sweep before the call
-                                      returns, so results are those of option 0.  Costs the
-                                      image (2 Mk N or Mk N bytes) beside the dictionary.  Default off: the headline path stays
-                                      the exact one ("Screened single-signal sweep"). */
+#define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) and csmp_ompr (k <= 4096): 0 (default) every sweep
+                                      reads the f32/f64 dictionary (exact, 4 / 8 bytes per element).  1 / 3 / 2: the sweep reads an IMAGE of the
+                                      dictionary and only SCREENS -- the best candidates are rescored in Float64 from the master dictionary under the
+                                      batched variant's certificate (CSMP_OPT_BATCH_CERT; gomp: the whole top-l set and its order are certified; sp:
+                                      every acquisition's top-k SET), and a solve (sp: an acquisition) with an uncertified step is repeated with the
+                                      exact sweep before the call returns: results are those of option 0.
+                                      3: the binary16 image (2 bytes per element under one power-of-two scale, f32 accumulate): with the rigorous
+                                      certificate (the default) its bound is 2^-11 |a||r| -- narrow enough to certify (nearly) every step on the
+                                      benchmark dictionaries: a PROVABLY exact solve at half the bytes per atom.
+                                      1: the bf16 image (2 bytes, bound 2^-8 |a||r|: under the rigorous certificate most solves fall back; useful with
+                                      CSMP_OPT_BATCH_CERT = 0).  2: the int8 image where the dictionary is flat (max|A| <= 8 rms of its entries;
+                                      otherwise the bf16 image): 1 byte per element under one step max|A|/127, the residual quantised per sweep,
+                                      exact integer accumulation; statistical certificate only.
+                                      Costs the image (2 Mk N or Mk N bytes) beside the dictionary.  Default off: the headline path stays the
+                                      exact sweep ("Screened single-signal sweep"). */
 #define CSMP_OPT_BATCH_SCREEN 11   /* csmp_omp_batch_mfma: operands of the screening GEMM.
                                       3 (default): binary16 images (v_mfma_f32_16x16x32_f16; the dictionary and every residual under
                                       exact power-of-two scales): the same rate and bytes as bf16 with eleven significand bits --
