@@ -13,17 +13,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
 
 OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
-WCAPACITY = 1  # warning: the support reached the on-device QR append's capacity; results valid (include/csmp.h)
 F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
-STOP_EPS, STOP_STAG, STOP_FULL, STOP_CAPACITY = 1, 2, 4, 8
+STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
 # csmp_set_option keys (include/csmp.h)
-OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_FORCE_REORTH, OPT_LS_GRAM, OPT_LS_GRAM_REUSE, OPT_TWOSTAGE_UPDATE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP, OPT_BATCH_SCREEN = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP, OPT_BATCH_SCREEN = 1, 2, 3, 4, 9, 10, 11
 OPTIONS = {"batch_cert": OPT_BATCH_CERT, "batch_gram": OPT_BATCH_GRAM, "batch_window": OPT_BATCH_WINDOW, "pipeline": OPT_PIPELINE,
-           "force_reorth": OPT_FORCE_REORTH, "ls_gram": OPT_LS_GRAM, "ls_gram_reuse": OPT_LS_GRAM_REUSE,
-           "twostage_update": OPT_TWOSTAGE_UPDATE, "solves_in_flight": OPT_SOLVES_IN_FLIGHT,
-           "screened_sweep": OPT_SCREENED_SWEEP, "batch_screen": OPT_BATCH_SCREEN}
+           "solves_in_flight": OPT_SOLVES_IN_FLIGHT, "screened_sweep": OPT_SCREENED_SWEEP, "batch_screen": OPT_BATCH_SCREEN}
 
 i64 = C.c_int64
 vp = C.c_void_p
@@ -139,7 +136,7 @@ def dtype_code(dt):
 
 class Context:
     """One GPU + one HIP stream + the resident dictionary (csmp_ctx)."""
-    last_status = OK  # status of the most recent call (positive = a warning with valid results, e.g. WCAPACITY)
+    last_status = OK  # status of the most recent call
 
     def __init__(self, device=0):
         self._h = vp()
@@ -179,7 +176,7 @@ class Context:
             pass
 
     def check(self, rc):
-        self.last_status = rc  # (positive = a warning with valid results, e.g. WCAPACITY)
+        self.last_status = rc
         if rc < OK:
             raise CsmpError(rc, lib().csmp_last_error(self._h).decode())
 

@@ -1,12 +1,11 @@
-// csmp_downdate.hpp -- removing a column from the on-device thin QR, and the backward-step scores.
+// csmp_downdate.hpp -- removing a column from the on-device thin QR.
 //
 // Reference primitives replaced (paths relative to the reference repository):
 //   k_qrdel_r + k_qrdel_q   remove_column!(AiQR, i) via _dropindex!(x, AiQR, i)   src/util.jl:137-161
 //                           (UpdatableQRFactorizations.jl: Givens down-date of the updatable QR)
 //                           call sites: backward_step! src/backward.jl:58-62, OMPR update!
 //                           src/twostage.jl:171-176
-//   k_bwd_scores            backward_δ! / get_gamma:  γ = diag((R'R)^-1),  δ²_i = x_i^2 / γ_i
-//                                                                        src/backward.jl:70-83
+//   (the backward scores backward_δ!, src/backward.jl:70-83, come from the explicit inverse: csmp_tinv.hpp)
 //
 // The factorisation lives in insertion order (column t of Q/R belongs to atom sel[t]); deleting
 // position p leaves R upper Hessenberg from column p on.  Rotations G_p .. G_{n-2} on row pairs
@@ -176,86 +175,6 @@ __global__ __launch_bounds__(256) void k_find_pos(const int* __restrict__ sel, c
         if (sel[t] == atom) pos = t;
     __syncthreads();
     if (threadIdx.x == 0) *delpos = pos;
-}
-
-// Backward scores.  Workgroup p (one wave) solves R' y = e_p by forward substitution on the trailing
-// block; then gamma_p = |y|^2 = ((R'R)^-1)_pp, x_p = y'z (the least-squares coefficient of atom
-// sel[p]) and delta2_p = x_p^2 / gamma_p: the growth of |r|^2 if that atom were removed
-// (src/backward.jl:77-83).  out[p] = delta2_p, coef[p] = x_p.
-// Right-looking, one wave, no LDS: lane l owns the columns i = p+1+l+64u of R (contiguous in memory)
-// with a partial sum each; at step t every lane adds R[t,i] y_t to its sums, the owner of column t+1
-// closes y_{t+1} and v_readlane broadcasts it.  R values are requested D steps ahead.
-template <int NU, int D>
-__global__ __launch_bounds__(64) void k_bwd_scores(const double* __restrict__ R, int kcap, const double* __restrict__ z,
-                                                   const DevState* st, double* __restrict__ out,
-                                                   double* __restrict__ coef) {
-    const int n = st->nsel, p = blockIdx.x, lane = threadIdx.x;
-    if (p >= n) return;
-    const double* colp[NU];
-    double acc[NU], rdg[NU], zr[NU];
-    bool own[NU];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int i = p + 1 + lane + 64 * u;
-        own[u] = i < n;
-        colp[u] = R + (int64_t)(own[u] ? i : p) * kcap;
-        acc[u] = 0.0;
-        rdg[u] = own[u] ? 1.0 / colp[u][i] : 0.0;
-        zr[u] = own[u] ? z[i] : 0.0;
-    }
-    double yt = 1.0 / R[(int64_t)p * kcap + p];
-    double g = 0.0, x = 0.0;
-    if (lane == 0) {
-        g = yt * yt;
-        x = yt * z[p];
-    }
-    double cur[D][NU], nxt[D][NU];
-    auto fetch = [&](double (*dst)[NU], int t0) {  // rows t0 .. t0+D-1 of the owned columns (row t < column index)
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int t = t0 + d, i = p + 1 + lane + 64 * u;
-                dst[d][u] = (own[u] && t < i) ? colp[u][t] : 0.0;
-            }
-    };
-    fetch(cur, p);
-    for (int tb = p; tb <= n - 2; tb += D) {
-        fetch(nxt, tb + D);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int t = tb + d;
-            if (t <= n - 2) {  // uniform
-                const int rel = t - p, su = rel >> 6, sl = rel & 63;  // column t+1: lane sl, slot su
-                double mine = 0.0, zs = 0.0;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    acc[u] = fma(cur[d][u], yt, acc[u]);
-                    if (u == su) {
-                        mine = -acc[u] * rdg[u];
-                        zs = zr[u];
-                    }
-                }
-                yt = readlane_f64(mine, sl);
-                if (lane == sl) {
-                    g = fma(yt, yt, g);
-                    x = fma(yt, zs, x);
-                }
-            }
-        }
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
-    }
-    for (int sft = 32; sft >= 1; sft >>= 1) {
-        g += shx(g, sft);
-        x += shx(x, sft);
-    }
-    if (lane == 0) {
-        out[p] = x * x / g;
-        coef[p] = x;
-    }
 }
 
 // argmin over the backward scores, first minimum in SORTED-INDEX order (findmin over x.nzval order,

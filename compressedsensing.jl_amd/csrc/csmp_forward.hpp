@@ -265,107 +265,6 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick_fr(const TickFr<TA> sw, 
     }
 }
 
-#ifdef CSMP_EXPERIMENTS  // superseded by k_fr_rebuild (Q'A on the Float64 matrix cores, below)
-// Maintenance pass with FOUR directions and no residual image: rho2_j += sgn * sum_d <a_j, q0 + d*qstride>^2.
-// Rebuilds the rescaling of a support that was factorised in bulk (srr's oblivious initialisation): a
-// quarter of the dictionary passes that one direction at a time would take.  Same pipeline as
-// k_fr_sweep; the four LDS images are what fits next to nothing else at M = 4096.
-template <typename TA, int U, bool FULL>
-__global__ __launch_bounds__(kSweepThreads) void k_fr_update4(
-    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ q0, int64_t qstride,
-    double sgn, double* __restrict__ rho2) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    using VT = typename Vec<TA>::type;
-    constexpr int VEC = Vec<TA>::n;
-    constexpr int ROWS = kWave * VEC;
-    constexpr int NW = kSweepThreads / kWave;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bid = blockIdx.x, nblk = gridDim.x;
-    const int nchunk = (Mv + ROWS - 1) / ROWS;
-    const int nblocks = (nchunk + U - 1) / U;
-    const int Mlds = nblocks * U * ROWS;
-    double* im0 = lds;
-    double* im1 = lds + Mlds;
-    double* im2 = lds + 2 * (size_t)Mlds;
-    double* im3 = lds + 3 * (size_t)Mlds;
-    for (int m = tid; m < Mlds; m += kSweepThreads) {
-        const bool in = m < Mv;
-        const int sl = r_slot<VEC>(m);
-        im0[sl] = in ? q0[m] : 0.0;
-        im1[sl] = in ? q0[qstride + m] : 0.0;
-        im2[sl] = in ? q0[2 * qstride + m] : 0.0;
-        im3[sl] = in ? q0[3 * qstride + m] : 0.0;
-    }
-    __syncthreads();
-    const f64x2* s0 = reinterpret_cast<const f64x2*>(im0);
-    const f64x2* s1 = reinterpret_cast<const f64x2*>(im1);
-    const f64x2* s2 = reinterpret_cast<const f64x2*>(im2);
-    const f64x2* s3 = reinterpret_cast<const f64x2*>(im3);
-    const int64_t stride = (int64_t)nblk * NW;
-    auto load_block = [&](VT* dst, int64_t c, int blk) {
-        const VT* p = reinterpret_cast<const VT*>(A + c * ld) + lane + (int64_t)blk * U * kWave;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (FULL) {
-                dst[u] = __builtin_nontemporal_load(p + u * kWave);
-            } else {
-                dst[u] = (VT)0;
-                if ((blk * U + u) * ROWS + lane * VEC < Mv) dst[u] = __builtin_nontemporal_load(p + u * kWave);
-            }
-        }
-    };
-    int64_t col = (int64_t)bid * NW + wave;
-    if (col >= N) col = -1;
-    VT cur[U], nxt[U];
-    if (col >= 0) load_block(cur, col, 0);
-    while (col >= 0) {
-        const double rho_old = rho2[col];
-        double g0 = 0.0, g1 = 0.0, g2 = 0.0, g3 = 0.0;
-        for (int blk = 0; blk < nblocks; ++blk) {
-            const bool last = blk + 1 == nblocks;
-            const int64_t ncol = last ? col + stride : col;
-            if (!last || ncol < N) load_block(nxt, ncol, last ? 0 : blk + 1);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = blk * U + u;
-                if constexpr (VEC == 4) {
-                    const int o0 = (t * 2 + 0) * kWave + lane, o1 = (t * 2 + 1) * kWave + lane;
-                    const f64x2 x0 = s0[o0], y0 = s0[o1], x1 = s1[o0], y1 = s1[o1];
-                    const f64x2 x2 = s2[o0], y2 = s2[o1], x3 = s3[o0], y3 = s3[o1];
-                    const double a0 = (double)cur[u].x, a1 = (double)cur[u].y, a2 = (double)cur[u].z, a3 = (double)cur[u].w;
-                    g0 = fma(a0, x0.x, g0); g0 = fma(a1, x0.y, g0); g0 = fma(a2, y0.x, g0); g0 = fma(a3, y0.y, g0);
-                    g1 = fma(a0, x1.x, g1); g1 = fma(a1, x1.y, g1); g1 = fma(a2, y1.x, g1); g1 = fma(a3, y1.y, g1);
-                    g2 = fma(a0, x2.x, g2); g2 = fma(a1, x2.y, g2); g2 = fma(a2, y2.x, g2); g2 = fma(a3, y2.y, g2);
-                    g3 = fma(a0, x3.x, g3); g3 = fma(a1, x3.y, g3); g3 = fma(a2, y3.x, g3); g3 = fma(a3, y3.y, g3);
-                } else {
-                    const int o0 = t * kWave + lane;
-                    const f64x2 x0 = s0[o0], x1 = s1[o0], x2 = s2[o0], x3 = s3[o0];
-                    const double a0 = (double)cur[u].x, a1 = (double)cur[u].y;
-                    g0 = fma(a0, x0.x, g0); g0 = fma(a1, x0.y, g0);
-                    g1 = fma(a0, x1.x, g1); g1 = fma(a1, x1.y, g1);
-                    g2 = fma(a0, x2.x, g2); g2 = fma(a1, x2.y, g2);
-                    g3 = fma(a0, x3.x, g3); g3 = fma(a1, x3.y, g3);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            g0 += shx(g0, sft);
-            g1 += shx(g1, sft);
-            g2 += shx(g2, sft);
-            g3 += shx(g3, sft);
-        }
-        double rho = fma(sgn * g0, g0, rho_old);
-        rho = fma(sgn * g1, g1, rho);
-        rho = fma(sgn * g2, g2, rho);
-        rho = fma(sgn * g3, g3, rho);
-        if (lane == 0) rho2[col] = rho;
-        col += stride;
-        if (col >= N) col = -1;
-    }
-}
-#endif
 
 // Bulk form of the same maintenance on the Float64 matrix cores: rho2_j -= sum_{d < nd} <a_j, q_{d0+d}>^2 for up to
 // 128 directions in ONE pass over the dictionary (k_fr_update4 needs nd/4 passes).  G = Q'A is a genuine GEMM here

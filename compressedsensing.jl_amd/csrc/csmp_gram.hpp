@@ -9,7 +9,7 @@
 //                 cores, upper 64 x 64 tiles only, the long dimension (M rows) split over workgroups;
 //   k_gram_reduce the partials summed in a fixed order; the diagonal is kept aside for the DGKS test;
 //   (k_gather_cols also sums a_j'b per row chunk: k_gram_reduce writes c = A_S'b as column n of G, the bordered matrix
-//                 [G c; c' b'b] -- k_gram_rhs is the stand-alone form of that product, kept for reference)
+//                 [G c; c' b'b])
 //   k_chol_row / k_chol_step   right-looking blocked Cholesky G = R'R in place, 32 columns per step and ONE launch per step:
 //                 the 32 x 32 diagonal block in the registers of one wave, the row panel by substitution (one thread per
 //                 column), the trailing update of the previous panel on the matrix cores beside it.  The bordered column comes
@@ -179,30 +179,6 @@ __global__ __launch_bounds__(256) void k_gram_subset(const double* __restrict__ 
     }
     G[e] = s;
     if (row == col && row < n) gdiag[row] = kdiag[pos[row]];
-}
-
-// column n of the bordered matrix: c_j = <a_{s_j}, b> (one wave per column, Float64), and the corner b'b
-template <typename TA>
-__global__ __launch_bounds__(256) void k_gram_rhs(const TA* __restrict__ A, int64_t ld, int M, const int* __restrict__ cols, int n,
-                                                  int np, const double* __restrict__ b, double* __restrict__ G) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * 4 + wave;
-    if (j > n) return;
-    double acc = 0.0, acc1 = 0.0;
-    if (j < n) {
-        const TA* a = A + (int64_t)cols[j] * ld;
-        int m = lane;
-        for (; m + 64 < M; m += 128) {
-            acc = fma((double)a[m], b[m], acc);
-            acc1 = fma((double)a[m + 64], b[m + 64], acc1);
-        }
-        for (; m < M; m += 64) acc = fma((double)a[m], b[m], acc);
-    } else {
-        for (int m = lane; m < M; m += 64) acc = fma(b[m], b[m], acc);
-    }
-    acc += acc1;
-    for (int s = 32; s >= 1; s >>= 1) acc += shx(acc, s);
-    if (lane == 0) G[j + (int64_t)n * np] = acc;
 }
 
 // Block row kb of the factor, by workgroups of 5 waves: wave 0 factorises the 32 x 32 diagonal block in its registers (every

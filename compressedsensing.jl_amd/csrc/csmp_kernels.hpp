@@ -1525,91 +1525,6 @@ __global__ __launch_bounds__(64) void k_finish_w(const double* __restrict__ R, c
     }
 }
 
-#ifdef CSMP_EXPERIMENTS  // superseded by k_trsv_blk / k_trsv_upd / k_trsv_emit below; kept for tools/probes/finish_probe.hip
-// Blocked form for large supports (SP's 2k = 1024 columns: 4 MiB of R): 64 columns at a time.  Wave 0 solves
-// the 64 x 64 diagonal block with its rows in REGISTERS (all 64 loads of a lane issued at once, the chain is
-// readlane + fma only); then all 256 threads subtract the block's contribution from the rows above it --
-// a 64-column mat-vec whose loads are independent and coalesced.  A column-at-a-time solve pays one memory
-// round trip per column (0.6 us x 1024); here it is one per block plus the bandwidth of one CU.
-__global__ __launch_bounds__(256) void k_finish_b(const double* __restrict__ R, const double* __restrict__ z,
-                                                  const int* __restrict__ sel, const DevState* st, int kcap,
-                                                  double* __restrict__ coef, int64_t* __restrict__ out_idx,
-                                                  double* __restrict__ out_val, int64_t* __restrict__ out_nnz,
-                                                  int64_t* __restrict__ out_order, int outcap, int* __restrict__ flag_out) {
-    extern __shared__ __attribute__((aligned(16))) double y[];  // y[kcap] | c[64] | sel copy (ints)
-    double* cb = y + kcap;
-    int* ssel = reinterpret_cast<int*>(cb + 64);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = st->nsel;
-    for (int t = tid; t < j; t += 256) {
-        y[t] = z[t];
-        ssel[t] = sel[t];
-    }
-    __syncthreads();
-    const int nb = (j + 63) / 64;
-    for (int b = nb - 1; b >= 0; --b) {
-        const int i0 = b * 64, w = min(64, j - i0);  // block columns i0 .. i0 + w - 1
-        if (wave == 0) {
-            // row `lane` of the diagonal block: D[lane][i] = R[i0 + lane, i0 + i], i > lane (zero elsewhere)
-            double drow[64];
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                drow[i] = (i < w && i > lane && lane < w) ? R[(int64_t)(i0 + i) * kcap + i0 + lane] : 0.0;
-            double yv = lane < w ? y[i0 + lane] : 0.0;
-            const double rd = lane < w ? 1.0 / R[(int64_t)(i0 + lane) * kcap + i0 + lane] : 0.0;
-#pragma unroll
-            for (int i = 63; i >= 0; --i) {
-                const double c = readlane_f64(yv * rd, i);  // lanes >= w carry zeros
-                yv = lane == i ? c : fma(-drow[i], c, yv);
-            }
-            if (lane < w) {
-                y[i0 + lane] = yv;
-                cb[lane] = yv;
-            } else {
-                cb[lane] = 0.0;
-            }
-        }
-        __syncthreads();
-        // rows above the block
-        for (int t = tid; t < i0; t += 256) {
-            double acc = y[t];
-            const double* col = R + (int64_t)i0 * kcap + t;
-#pragma unroll 16
-            for (int i = 0; i < 64; ++i) {
-                const double rv = i < w ? col[(int64_t)i * kcap] : 0.0;
-                acc = fma(-rv, cb[i], acc);
-            }
-            y[t] = acc;
-        }
-        __syncthreads();
-    }
-    for (int t = tid; t < j; t += 256) coef[t] = y[t];
-    for (int t = tid; t < outcap; t += 256) {
-        out_idx[t] = -1;
-        out_val[t] = 0.0;
-        if (out_order) out_order[t] = (t < j) ? ssel[t] : -1;
-    }
-    __syncthreads();
-    for (int t = tid; t < j; t += 256) {
-        const int me = ssel[t];
-        int rank = 0, r1 = 0, r2 = 0, r3 = 0;
-        int u = 0;
-        for (; u + 4 <= j; u += 4) {
-            rank += (int)(ssel[u] < me);
-            r1 += (int)(ssel[u + 1] < me);
-            r2 += (int)(ssel[u + 2] < me);
-            r3 += (int)(ssel[u + 3] < me);
-        }
-        for (; u < j; ++u) rank += (int)(ssel[u] < me);
-        rank += r1 + r2 + r3;
-        out_idx[rank] = me;
-        out_val[rank] = y[t];
-    }
-    if (tid == 0) {
-        *out_nnz = j;
-        if (flag_out) *flag_out = st->done | (st->uncertain ? STOP_UNCERTAIN : 0);
-    }
-}
-#endif
 
 // ---- the back substitution for LARGE supports, over several CUs.  One workgroup cannot stream R faster than one CU reads memory
 // (24 GB/s from HBM, ~60 GB/s from L2: tools/probes/finish_probe.hip -- 4 MiB of R at 1024 columns took 240 us in k_finish_b,

@@ -147,7 +147,6 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
-    s.capped = false;
     return CSMP_OK;
 }
 
@@ -158,7 +157,6 @@ static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
     hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
-    s.capped = false;
     return CSMP_OK;
 }
 
@@ -210,7 +208,7 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
         HIPCHECK(hipGetLastError());
         hipLaunchKernelGGL(k_qr2s, dim3(s.G), dim3(kQrThreads), slds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
                            (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
-                           jpc, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0, s.spill);
+                           jpc, 0, jh, optimistic ? 1 : 0, s.spill);
         HIPCHECK(hipGetLastError());
         if (s.jh < s.kcap) s.jh += 1;
         if (optimistic) return CSMP_OK;
@@ -238,7 +236,7 @@ static int launch_append(csmp_ctx* ctx, int mode, int which, int skipmask, bool 
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_qr2, dim3(s.G), dim3(kQrThreads), lds, ctx->stream, s.Q, s.ldq, s.st, (const double*)s.avec, s.r,
                        (const double*)s.P1, (const double*)s.P1s, s.G, s.W1, s.vvec, s.P2, s.P2s, s.R, s.z, s.sel, s.kcap,
-                       jpad, ctx->force_reorth ? 1 : 0, jh, optimistic ? 1 : 0);
+                       jpad, 0, jh, optimistic ? 1 : 0);
     HIPCHECK(hipGetLastError());
     if (s.jh < s.kcap) s.jh += 1;
     if (optimistic) return CSMP_OK;  // k_qr3 (second Gram-Schmidt pass) only in the safe chain
@@ -270,7 +268,7 @@ static int omp_step(csmp_ctx* ctx, double eps, int check_eps, bool optimistic) {
 static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* d_nnz, int64_t* d_order, int outcap,
                          int* d_flag = nullptr) {
     Solver& s = ctx->s;
-    if (s.kcap > 256 && !tune_env("CSMP_FINISH_W") && !tune_env("CSMP_FINISH_B")) {
+    if (s.kcap > 256) {
         // super-blocks of 256 columns over several CUs (k_trsv_*): the host's bound on the support says how many there are; a
         // super-block beyond the true support returns at once
         const int jb = s.jh > 0 ? std::min(s.jh, s.kcap) : s.kcap;
@@ -289,16 +287,6 @@ static int launch_finish(csmp_ctx* ctx, int64_t* d_idx, double* d_val, int64_t* 
         HIPCHECK(hipGetLastError());
         return CSMP_OK;
     }
-#ifdef CSMP_EXPERIMENTS
-    if (s.kcap > 256 && !tune_env("CSMP_FINISH_W")) {  // blocked form in ONE workgroup: one memory round trip per 64 columns
-        const size_t lds = (size_t)(s.kcap + 64) * sizeof(double) + (size_t)s.kcap * sizeof(int);
-        if (lds > 64 * 1024) HIPCHECK(hipFuncSetAttribute((const void*)k_finish_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_finish_b, dim3(1), dim3(256), lds, ctx->stream, (const double*)s.R, (const double*)s.z,
-                           (const int*)s.sel, (const DevState*)s.st, s.kcap, s.coef, d_idx, d_val, d_nnz, d_order, outcap, d_flag);
-        HIPCHECK(hipGetLastError());
-        return CSMP_OK;
-    }
-#endif
     if (s.kcap <= 1024) {  // single-wave form
         const size_t lds = (size_t)s.kcap * sizeof(int);
         if (s.kcap <= 256)

@@ -33,7 +33,6 @@ struct Solver {
     unsigned* scr_tickets = nullptr;  // k_sweep_bf16's ticket counters, one per partition of workgroups, kScrTicketStride words apart
     double* spill = nullptr;  // supports beyond the LDS append kernels' ~3900 columns: their five support-length vectors per workgroup (launch_append)
     size_t spill_cap = 0;
-    bool capped = false; // an append was withheld: the support reached what the on-device QR append can hold (qr_max_cols)
     int jh_last = 0;     // jh used by the most recent k_qr1 stage (the matching k_qr2 stage reuses it)
     // multi-column append (csmp_block.hpp), allocated on first use
     double *Apan = nullptr, *Vpan = nullptr, *PB1 = nullptr, *W1b = nullptr, *PG = nullptr, *Gsum = nullptr;
@@ -143,16 +142,12 @@ struct csmp_ctx {
     int sweep_grid = 0, sweep_U = 1;
     int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
     bool sweep_full = false, sweep_nt = false;
-    bool force_reorth = false;  // CSMP_OPT_FORCE_REORTH (test switch): always run the second Gram-Schmidt pass
     // options (csmp_set_option, include/csmp.h)
     void* comm = nullptr;          // ncclComm_t of the signal-sharded solve (csmp_comm_init, host/rccl.hpp); this rank and the group's size
     int comm_rank = 0, comm_world = 1;
     int opt_batch_cert = 1;        // CSMP_OPT_BATCH_CERT: 1 rigorous (default), 0 statistical (opt-in)
     int opt_batch_gram = 0;        // CSMP_OPT_BATCH_GRAM: resident G = A'A for csmp_omp_batch_mfma
     int opt_batch_window = 0;      // CSMP_OPT_BATCH_WINDOW: rescoring window capacity, 0 = default
-    bool opt_ls_gram = true;       // CSMP_OPT_LS_GRAM: whole-set least squares by Gram + Cholesky
-    bool opt_ls_gram_reuse = true; // CSMP_OPT_LS_GRAM_REUSE
-    int opt_twostage_update = 0;   // CSMP_OPT_TWOSTAGE_UPDATE: 0 explicit inverse, 1 Givens down-date of R, 2 refactorise
     int64_t scr_solves = 0, scr_fallbacks = 0;  // screened solves made / repeated with the exact sweep (csmp_screened_stats)
     int scr_grid = 0;                           // workgroups of k_sweep_bf16
     double scr_cert_abs = 0.0, scr_cert_rel = 0.0, scr_cert_abs2 = 0.0;
@@ -204,17 +199,7 @@ struct csmp_ctx {
         if (rc_ != CSMP_OK) return rc_; \
     } while (0)
 
-// Tuning switches exist only in the experiments build (`make experiments`, tools/probe_*.py); the product library reads no
-// environment variable: every behavioural choice is an argument or a csmp_set_option key (include/csmp.h).
-static const char* tune_env(const char* name) {
-#ifdef CSMP_EXPERIMENTS
-    return getenv(name);
-#else
-    (void)name;
-    return nullptr;
-#endif
-}
-
+// The library reads no environment variable: every behavioural choice is an argument or a csmp_set_option key (include/csmp.h).
 static int fail(csmp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
     return code;

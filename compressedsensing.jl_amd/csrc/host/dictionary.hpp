@@ -14,20 +14,6 @@ static hipError_t sweep_launch_t(csmp_ctx* ctx, int grid, size_t lds, const doub
     return hipGetLastError();
 }
 
-#ifdef CSMP_EXPERIMENTS  // kernel variants kept only for the tuning probes (tools/probe_sweep*.py, `make experiments`)
-template <typename TA, typename TACC>
-static hipError_t sweep_dispatch(csmp_ctx* ctx, int U, bool full, bool nt, int grid, size_t lds, const double* r,
-                                 double eps, int check_eps, int skipmask) {
-    if (!full) return sweep_launch_t<TA, TACC, 1, false, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-    if (U == 4) return nt ? sweep_launch_t<TA, TACC, 4, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
-                          : sweep_launch_t<TA, TACC, 4, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-    if (U == 2) return nt ? sweep_launch_t<TA, TACC, 2, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
-                          : sweep_launch_t<TA, TACC, 2, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-    return nt ? sweep_launch_t<TA, TACC, 1, true, true>(ctx, grid, lds, r, eps, check_eps, skipmask)
-              : sweep_launch_t<TA, TACC, 1, true, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-}
-
-#endif
 
 // product configuration: one column per wave at a time (CPW = 1), U chunks = U KiB in flight per lane-row
 template <typename TA>
@@ -72,34 +58,6 @@ static int prof_mark(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
-#ifdef CSMP_EXPERIMENTS
-// one sweep with the product configuration (or an explicit experimental one)
-static int launch_sweep_cfg(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, int U, bool nt,
-                            bool f32acc, int grid) {
-    const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
-    const int rows = kWave * vec;
-    bool full = (ctx->Mv % (rows * U)) == 0;
-    if (!full && (ctx->Mv % rows) == 0) {  // fall back to the largest U that divides
-        for (int u : {2, 1})
-            if (u < U && ctx->Mv % (rows * u) == 0) {
-                U = u;
-                full = true;
-                break;
-            }
-    }
-    if (ctx->prof) CHECK(prof_mark(ctx));
-    hipError_t e;
-    if (ctx->dtype == CSMP_F32)
-        e = f32acc ? sweep_dispatch<float, float>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask)
-                   : sweep_dispatch<float, double>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
-    else
-        e = sweep_dispatch<double, double>(ctx, U, full, nt, grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
-    HIPCHECK(e);
-    if (ctx->prof) CHECK(prof_mark(ctx));
-    return CSMP_OK;
-}
-
-#endif
 
 static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
     const bool timed = prof_pick(ctx);
@@ -126,8 +84,7 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     ctx->sweep_full = (ctx->Mv % rows) == 0;
     ctx->sweep_U = 1;
-    const char* su = tune_env("CSMP_SWEEP_U");  // tuning knob: cap the load-block size
-    const int umax = su ? atoi(su) : 16;
+    const int umax = 16;
     if (ctx->sweep_full)
         for (int u : {16, 8, 4, 2})
             if (u <= umax && nchunk % u == 0) {
@@ -135,7 +92,7 @@ static int configure_sweep(csmp_ctx* ctx) {
                 break;
             }
     ctx->tick_U = ctx->sweep_U;
-    if (ctx->sweep_full && ctx->sweep_U == 16 && !tune_env("CSMP_TICK_U16")) ctx->tick_U = 8;  // (16 | nchunk implies 8 | nchunk)
+    if (ctx->sweep_full && ctx->sweep_U == 16) ctx->tick_U = 8;  // (16 | nchunk implies 8 | nchunk)
     ctx->sweep_nt = true;
     int per_cu = ctx->sweep_U == 16 ? 3 : 4;
     per_cu = (int)std::min<size_t>((size_t)per_cu, (160 * 1024) / ctx->sweep_lds);
@@ -144,9 +101,6 @@ static int configure_sweep(csmp_ctx* ctx) {
     int64_t grid = (int64_t)ctx->prop.multiProcessorCount * per_cu;
     if (ctx->sweep_full && ctx->sweep_U == 16) grid = (int64_t)ctx->prop.multiProcessorCount * 3 / 4;  // pipelined kernel
     if (ctx->sweep_full && ctx->sweep_U == 8) grid = (int64_t)ctx->prop.multiProcessorCount;
-    if (const char* sn = tune_env("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));  // tuning knob
-    if (const char* sp = tune_env("CSMP_SWEEP_LDS"))  // tuning knob: request at least this much LDS per workgroup
-        ctx->sweep_lds = std::max(ctx->sweep_lds, (size_t)atoi(sp));
     ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
     return CSMP_OK;
 }

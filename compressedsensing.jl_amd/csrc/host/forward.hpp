@@ -33,20 +33,7 @@ static hipError_t fr_sweep_launch_nq(csmp_ctx* ctx, const FrPass& ps, int grid, 
         case 0: return fr_sweep_launch_t<TA, U, FULL, 0>(ctx, ps, grid, lds, max_eps, skipmask);
         case 1: return fr_sweep_launch_t<TA, U, FULL, 1>(ctx, ps, grid, lds, max_eps, skipmask);
         case 2: return fr_sweep_launch_t<TA, U, FULL, 2>(ctx, ps, grid, lds, max_eps, skipmask);
-#ifdef CSMP_EXPERIMENTS
-        default: {
-            auto kern = k_fr_update4<TA, U, FULL>;
-            if (lds > 64 * 1024) {
-                hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                if (e != hipSuccess) return e;
-            }
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv, ctx->N,
-                               ps.q1, ps.qstride, ps.s1, ctx->s.rho2);
-            return hipGetLastError();
-        }
-#else
         default: return hipErrorInvalidValue;
-#endif
     }
 }
 template <typename TA>
@@ -68,8 +55,7 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
         // Measured at 4096 x 65536 f32 (profiles/r01_bench_fr_line.json): 8-chunk blocks on one workgroup per CU
         // 168 us, 16-chunk blocks on 3/4 of the CUs (the OMP sweep's optimum) 173 us -- with a second LDS image
         // to read per chunk, the extra waves hide more than the extra DRAM streams cost.
-        const char* fu = tune_env("CSMP_FR_U");  // tuning knob: cap the load-block size
-        const int umax = fu ? atoi(fu) : 8;
+        const int umax = 8;
         for (int u : {16, 8})
             if (u <= umax && nchunk % u == 0) {
                 U = u;
@@ -80,7 +66,6 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
     lds = fr_sweep_lds_bytes(ctx->Mv, vec, U, nq);
     const int cus = ctx->prop.multiProcessorCount;
     int64_t g = U == 16 ? (int64_t)cus * 3 / 4 : (int64_t)cus;  // as the OMP sweep (configure_sweep)
-    if (const char* sn = tune_env("CSMP_FR_NBLK")) g = std::max(1, atoi(sn));  // tuning knob
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(g, groups));
 }
@@ -143,12 +128,6 @@ static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_
     int U, grid; bool full; size_t flds;
     fr_config(ctx, 1, U, full, flds, grid);
     int nblk = grid;
-    if (const char* tn = tune_env("CSMP_FR_TICK_NBLK")) nblk = std::max(1, atoi(tn));
-    if (k > qr_max_cols()) {  // (as omp_ticks)
-        k = qr_max_cols();
-        for (int q = 0; q < 3; ++q)
-            if (present[q]) sl[q]->capped = true;
-    }
     const size_t lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
@@ -197,11 +176,10 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     CHECK(fr_ensure(ctx));
     ctx->s.begun = false;
     const double min_d2 = min_delta * min_delta;  // :64
-    bool capacity_stop = false;
     for (int pass = 0; pass < 2; ++pass) {  // optimistic append chain, repeated with re-orthogonalisation if flagged (see csmp_omp)
-        const bool optimistic = pass == 0 && !ctx->force_reorth;
+        const bool optimistic = pass == 0;
         CHECK(upload_b(ctx, b, b_dtype));
-        for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
+        for (int64_t t = 0; t < k; ++t) {
             CHECK(fr_step(ctx, t == 0, max_eps, min_d2, optimistic));
             if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
                 bool stopped = false;
@@ -214,19 +192,17 @@ extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
         HIPCHECK(hipMemcpyAsync(&hs, ctx->s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         if (!(hs.done & STOP_REORTH)) {
-            capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
             break;
         }
     }
     CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
-    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+    return CSMP_OK;
 }
 
 // omp (algo = CSMP_ALGO_OMP: p1 = eps) or fr (CSMP_ALGO_FR: p1 = max_eps, p2 = min_delta^2) for every column of B
 static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                       double eps, double p2, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     const bool isfr = algo == CSMP_ALGO_FR;
-    bool capacity_stop = false;
     if (!ctx) return CSMP_EINVAL;
     if (!isfr && !(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
     if (!B || nsig < 0 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "batch: bad arguments");
@@ -277,7 +253,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     // taken three at a time through the tick kernel (k_tick): one launch per atom carries the sweep
     // of one signal and the two short append stages of the other two, so the latency-bound chain
     // is hidden underneath the HBM-bound sweep.  Bit-identical to the one-at-a-time path.
-    const bool opt = !ctx->force_reorth;
+    const bool opt = true;
     // (the tick kernel carries the LDS form of the append stages: supports beyond qr_max_cols() go one signal at a time through
     // launch_append, whose spill kernels have no such bound)
     bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full && kc <= qr_max_cols();
@@ -328,8 +304,6 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn)
             if (hf[sgn] & STOP_REORTH) rc = solve_one(sgn, false);
-        if (k > qr_max_cols())  // a signal that no stopping rule ended was cut at the QR append's capacity
-            for (int64_t sgn = 0; sgn < nsig; ++sgn) capacity_stop |= !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
@@ -339,7 +313,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
-    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
+    return rc;
 }
 
 extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,

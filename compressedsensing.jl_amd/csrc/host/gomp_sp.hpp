@@ -125,7 +125,6 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
     // that fails its DGKS test flags the solve, which is then repeated with the column-wise chain.  With
     // CSMP_OPT_SCREENED_SWEEP the sweeps read the bf16 image and the top-l pick is certified (host/screened.hpp); a solve
     // with an uncertified step is repeated with the exact sweep.
-    bool capacity_stop = false;
     bool screened = screened_on(ctx) && l <= kTopSmall;
     if (screened) CHECK(screened_ensure(ctx));
     ctx->scr_lone = true;  // (one solve at a time: the pick kernel may take a whole CU)
@@ -133,11 +132,11 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
         csmp_ctx* c;
         ~LoneReset() { c->scr_lone = false; }
     } lone_reset{ctx};
-    bool block = !ctx->force_reorth && l <= kPanelMax;
+    bool block = l <= kPanelMax;
     for (int attempt = 0; attempt < 4; ++attempt) {
         CHECK(upload_b(ctx, b, b_dtype));
         const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
-        for (int64_t it = 0; it < k / l && !ctx->s.capped; ++it) {  // :130-133
+        for (int64_t it = 0; it < k / l; ++it) {  // :130-133
             CHECK(screened ? gomp_update_screened(ctx, l, eps, it > 0, main_skip, block) : gomp_update(ctx, l, eps, it > 0, main_skip, block));
             if ((it + 1) % kPollSteps == 0 && it + 1 < k / l) {
                 bool stopped = false;
@@ -164,11 +163,10 @@ extern "C" int csmp_gomp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t l, i
             block = false;
             continue;
         }
-        capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
         break;
     }
     CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
-    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+    return CSMP_OK;
 }
 
 // ---- gomp for many signals: TWO solves in flight, one per stream
@@ -195,7 +193,7 @@ static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l
     int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
     if (rc != CSMP_OK) return rc;
     const int main_skip = STOP_EPS | STOP_FULL | STOP_REORTH;
-    for (int64_t it = 0; it < k / l && !c->s.capped; ++it) {  // src/matchingpursuit.jl:130-133
+    for (int64_t it = 0; it < k / l; ++it) {  // src/matchingpursuit.jl:130-133
         rc = screened ? gomp_update_screened(c, l, eps, it > 0, main_skip, block) : gomp_update(c, l, eps, it > 0, main_skip, block);
         if (rc != CSMP_OK) return rc;
         if (it == 0 && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
@@ -221,7 +219,6 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     // three (CSMP_OPT_SOLVES_IN_FLIGHT) on the screened sweep, whose launches are short enough for their fixed parts to matter
     const bool screened = screened_on(ctx) && l <= kTopSmall;  // sweeps over the image, certified top-l picks (host/screened.hpp)
     int T = (int)std::min<int64_t>(screened ? std::min(ctx->opt_in_flight, 3) : 2, nsig);
-    if (const char* tf = tune_env("CSMP_SCR_FLIGHT")) T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(tf), 3), nsig));
     T = std::max(T, 1);
     if (T > 1) CHECK(twins_ensure(ctx, T - 1));
     csmp_ctx* cc[3] = {ctx, T > 1 ? ctx->twins[0] : nullptr, T > 2 ? ctx->twins[1] : nullptr};
@@ -257,12 +254,11 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the caller's buffers and our temporaries are ready before either stream starts)
     for (int q = 0; q + 1 < T; ++q)
         if (!cc[q]->ev_twin) HIPCHECK(hipEventCreateWithFlags(&cc[q]->ev_twin, hipEventDisableTiming));
-    const bool block = !ctx->force_reorth && l <= kPanelMax;
+    const bool block = l <= kPanelMax;
     if (screened) {
         if (T == 1) CHECK(screened_ensure(ctx));
         for (int q = 1; q < T; ++q) CHECK(screened_ensure_pair(ctx, cc[q]));
     }
-    std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
         const int q = (int)(sgn % T);
         csmp_ctx* c = cc[q];
@@ -270,7 +266,6 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
         if (sgn > 0 && sgn < T) HIPCHECK(hipStreamWaitEvent(c->stream, cc[q - 1]->ev_twin, 0));  // a twin starts one sweep behind: out of phase
         const int rc = gomp_enqueue(c, col, b_dtype, l, k, eps, block, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
                                     sgn + 1 < T ? c->ev_twin : nullptr, screened);
-        capped[(size_t)sgn] = c->s.capped;  // (the host withholds the appends: known at enqueue time)
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
             for (int w = 0; w < T; ++w) (void)hipStreamSynchronize(cc[w]->stream);
@@ -284,7 +279,6 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
     // a panel that failed its DGKS test flagged the solve (nothing committed): that signal again, column by column; a solve
     // with an uncertified pick (screened sweep): again with the exact sweep
     int rc = CSMP_OK;
-    bool capacity_stop = false;
     for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
         if (screened) {
             ctx->scr_solves += 1;
@@ -301,10 +295,8 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
             if (rc == CSMP_OK) {
                 HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHECK(hipStreamSynchronize(ctx->stream));
-                capped[(size_t)sgn] = ctx->s.capped;
             }
         }
-        if (rc == CSMP_OK) capacity_stop |= capped[(size_t)sgn] && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
@@ -314,7 +306,7 @@ extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
-    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
+    return rc;
 }
 
 // state reset + r = b for a fresh factorisation on the same b (SP re-factorises from scratch)
@@ -336,7 +328,7 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, cols.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, &n, 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    if (n > 1 && !ctx->force_reorth) {  // panels of 32 columns; verified through the device flag
+    if (n > 1) {  // panels of 32 columns; verified through the device flag
         CHECK(launch_block_appends(ctx, n, STOP_REORTH));
         DevState hs;
         HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -358,7 +350,6 @@ static int gram_split_for(const csmp_ctx* ctx, int np) {
     const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
     int nsplit = std::max(1, slots / std::max(1, pieces));
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
-    if (const char* e = tune_env("CSMP_GRAM_SPLIT")) nsplit = std::max(1, atoi(e));  // tuning / debugging knob
     return std::min(nsplit, 32);
 }
 static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
@@ -409,7 +400,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
     // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
-    bool subset = s.keep_valid && n <= s.keep_n && ctx->opt_ls_gram_reuse;
+    bool subset = s.keep_valid && n <= s.keep_n;
     if (subset) {
         std::vector<std::pair<int, int>> where((size_t)s.keep_n);
         for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
@@ -478,7 +469,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
 }
 static bool gram_applicable(const csmp_ctx* ctx, size_t n) {
     // worth it from a few panels on; needs QR capacity for R and distinct columns (the callers guarantee those)
-    return n >= 64 && !ctx->force_reorth && ctx->opt_ls_gram;
+    return n >= 64;
 }
 static int ls_gram(csmp_ctx* ctx, const std::vector<int>& cols) {
     return ctx->dtype == CSMP_F32 ? ls_gram_t<float>(ctx, cols) : ls_gram_t<double>(ctx, cols);

@@ -27,10 +27,6 @@ extern "C" int csmp_create(csmp_ctx** out, int device_id) {
         delete ctx;
         return CSMP_EHIP;
     }
-    if (const char* tw = tune_env("CSMP_TICK_WGS")) ctx->tick_wg_per_cu = std::max(1, atoi(tw));
-    if (const char* tn = tune_env("CSMP_TICK_NBLK")) ctx->tick_nblk = std::max(0, atoi(tn));
-    if (const char* to = tune_env("CSMP_TICK_ORDER")) ctx->tick_sweep_first = atoi(to) != 0;
-    if (const char* tp = tune_env("CSMP_TICK_PF")) ctx->tick_pf = tp[0] != '0';
     *out = ctx;
     return CSMP_OK;
 }
@@ -168,7 +164,6 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
         case CSMP_OPT_BATCH_CERT: *lo = 0; *hi = 1; return &ctx->opt_batch_cert;
         case CSMP_OPT_BATCH_GRAM: *lo = 0; *hi = 1; return &ctx->opt_batch_gram;
         case CSMP_OPT_BATCH_WINDOW: *lo = 0; *hi = kWinMax; return &ctx->opt_batch_window;
-        case CSMP_OPT_TWOSTAGE_UPDATE: *lo = 0; *hi = 2; return &ctx->opt_twostage_update;
         case CSMP_OPT_SOLVES_IN_FLIGHT: *lo = 1; *hi = 4; return &ctx->opt_in_flight;
         case CSMP_OPT_SCREENED_SWEEP: *lo = 0; *hi = 3; return &ctx->opt_screened;
         case CSMP_OPT_BATCH_SCREEN: *lo = 0; *hi = 3; return &ctx->opt_batch_screen;
@@ -178,9 +173,6 @@ static int* opt_slot(csmp_ctx* ctx, int key, int64_t* lo, int64_t* hi) {
 static bool* opt_flag(csmp_ctx* ctx, int key) {
     switch (key) {
         case CSMP_OPT_PIPELINE: return &ctx->pipeline;
-        case CSMP_OPT_FORCE_REORTH: return &ctx->force_reorth;
-        case CSMP_OPT_LS_GRAM: return &ctx->opt_ls_gram;
-        case CSMP_OPT_LS_GRAM_REUSE: return &ctx->opt_ls_gram_reuse;
         default: return nullptr;
     }
 }

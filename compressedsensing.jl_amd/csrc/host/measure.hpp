@@ -30,31 +30,6 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
 }
 
 // experimental column-per-wave variants (f32 dictionary, full chunks only): cpw in {1,2}, U in {4,8,16}
-#ifdef CSMP_EXPERIMENTS
-template <int U>
-static hipError_t sweep_launch_pf(csmp_ctx* ctx, int grid, const double* r) {
-    auto kern = k_sweep_pf<float, U, true>;
-    Solver& s = ctx->s;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const float*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, r, s.cvec, s.pval, s.pidx, s.st, 0.0, 0, 0);
-    return hipGetLastError();
-}
-static hipError_t sweep_launch_cpw(csmp_ctx* ctx, int cpw, int U, int grid, const double* r) {
-    const size_t lds = ctx->sweep_lds;
-    if (cpw == 3 && U == 16) return sweep_launch_pf<16>(ctx, grid, r);
-    if (cpw == 3 && U == 8) return sweep_launch_pf<8>(ctx, grid, r);
-    if (cpw == 3 && U == 4) return sweep_launch_pf<4>(ctx, grid, r);
-    if (cpw == 3 && U == 2) return sweep_launch_pf<2>(ctx, grid, r);
-    if (cpw == 1 && U == 4) return sweep_launch_t<float, double, 4, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
-    if (cpw == 1 && U == 8) return sweep_launch_t<float, double, 8, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
-    if (cpw == 1 && U == 16) return sweep_launch_t<float, double, 16, true, true, 1>(ctx, grid, lds, r, 0.0, 0, 0);
-    if (cpw == 2 && U == 2) return sweep_launch_t<float, double, 2, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
-    if (cpw == 2 && U == 4) return sweep_launch_t<float, double, 4, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
-    if (cpw == 2 && U == 8) return sweep_launch_t<float, double, 8, true, true, 2>(ctx, grid, lds, r, 0.0, 0, 0);
-    return hipErrorInvalidValue;
-}
-
-#endif
 
 // variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (0 = product configuration)
 // variant >= 1<<20: experimental: (variant>>20) = cpw, bits 0-7 = U, bits 8-15 = workgroups per CU
@@ -73,48 +48,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     CHECK(upload_b(ctx, r.data(), CSMP_F64));
     int U = ctx->sweep_U, grid = ctx->sweep_grid;
     bool nt = ctx->sweep_nt, f32acc = false;
-#ifdef CSMP_EXPERIMENTS
-    const int cpwx = variant >> 20;
-    if (cpwx) {
-        if (ctx->dtype != CSMP_F32) return fail(ctx, CSMP_EINVAL, "bench_sweep: experimental variants are f32 only");
-        U = variant & 0xff;
-        const int per_cu = (variant >> 8) & 0xff;
-        const int64_t groups = (ctx->N + 4 * (cpwx == 3 ? 1 : cpwx) - 1) / (4 * (cpwx == 3 ? 1 : cpwx));
-        grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * (per_cu ? per_cu : 4), groups));
-        if (grid > ctx->prop.multiProcessorCount * 8) grid = ctx->prop.multiProcessorCount * 8;
-        if (const char* sn = tune_env("CSMP_SWEEP_NBLK")) grid = std::max(1, atoi(sn));
-        if (ctx->Mv % (256 * U)) return fail(ctx, CSMP_EINVAL, "bench_sweep: M must be a multiple of 256*U");
-        for (int i = 0; i < 3; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
-        hipEvent_t e0, e1;
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, ctx->stream));
-        for (int i = 0; i < reps; ++i) HIPCHECK(sweep_launch_cpw(ctx, cpwx, U, grid, ctx->s.r));
-        HIPCHECK(hipEventRecord(e1, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        float ms = 0.f;
-        HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (avg_ms) *avg_ms = (double)ms / reps;
-        return CSMP_OK;
-    }
-#else
-    if (variant != 0) return fail(ctx, CSMP_ESTATE, "bench_sweep: experimental variants need a build with -DCSMP_EXPERIMENTS (make experiments)");
-#endif
-#ifdef CSMP_EXPERIMENTS
-    if (variant != 0) {
-        U = variant & 7;
-        nt = (variant & 8) != 0;
-        f32acc = (variant & 16) != 0;
-        const int per_cu = (variant >> 8) & 0xff;
-        if (per_cu > 0) {
-            const int64_t groups = (ctx->N + 15) / 16;
-            grid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ctx->prop.multiProcessorCount * per_cu, groups));
-        }
-        if (U != 1 && U != 2 && U != 4) return fail(ctx, CSMP_EINVAL, "bench_sweep: U must be 1, 2 or 4");
-    }
-#endif
+    if (variant != 0) return fail(ctx, CSMP_ESTATE, "bench_sweep: variant 0 (the product kernel) is the only one");
     const bool was = ctx->prof;
     ctx->prof = false;
     if (variant == 0) {
@@ -134,24 +68,6 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         if (avg_ms) *avg_ms = (double)ms0 / reps;
         return CSMP_OK;
     }
-#ifdef CSMP_EXPERIMENTS
-    for (int i = 0; i < 3; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
-    hipEvent_t e0, e1;
-    HIPCHECK(hipEventCreate(&e0));
-    HIPCHECK(hipEventCreate(&e1));
-    HIPCHECK(hipEventRecord(e0, ctx->stream));
-    for (int i = 0; i < reps; ++i) CHECK(launch_sweep_cfg(ctx, ctx->s.r, 0.0, 0, 0, U, nt, f32acc, grid));
-    HIPCHECK(hipEventRecord(e1, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    ctx->prof = was;
-    if (avg_ms) *avg_ms = (double)ms / reps;
-    return CSMP_OK;
-#else
     (void)U; (void)grid; (void)nt; (void)f32acc;
     return CSMP_OK;
-#endif
 }

@@ -25,7 +25,7 @@ static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optim
     p.Q = s.Q; p.ldq = s.ldq; p.st = s.st; p.avec = s.avec; p.r = s.r;
     p.P1 = s.P1; p.P1s = s.P1s; p.G = s.G;
     p.W1 = s.W1; p.vvec = s.vvec; p.P2 = s.P2; p.P2s = s.P2s; p.R = s.R; p.z = s.z; p.sel = s.sel;
-    p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.force_reorth = ctx->force_reorth ? 1 : 0; p.jh = jh; p.optimistic = optimistic;
+    p.kcap = s.kcap; p.jpad = qr_jpad(jh); p.force_reorth = 0; p.jh = jh; p.optimistic = optimistic;
     p.active = active;
     return p;
 }
@@ -73,11 +73,6 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
                               : ctx->tick_U == 16 ? (int64_t)ctx->sweep_grid * 11 / 12
                                                   : (int64_t)ctx->prop.multiProcessorCount * ctx->tick_wg_per_cu;
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
-    if (k > qr_max_cols()) {  // the appends stop at the support the QR kernels can hold (see launch_append): CSMP_WCAPACITY
-        k = qr_max_cols();
-        for (int q = 0; q < 3; ++q)
-            if (present[q]) sl[q]->capped = true;
-    }
     const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
@@ -119,7 +114,6 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     // could not be certified is repeated with the exact sweep.
     // Within an attempt: optimistic two-kernel append chain first; if any column failed the DGKS test (flagged on the
     // device, nothing committed) the solve is repeated with the second Gram-Schmidt pass enabled
-    bool capacity_stop = false;
     bool screened = screened_on(ctx);
     if (screened) CHECK(screened_ensure(ctx));
     struct LoneGuard {  // (csmp_omp is one solve at a time)
@@ -130,9 +124,9 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool uncertain = false;
         for (int pass = 0; pass < 2; ++pass) {
-            const bool optimistic = pass == 0 && !ctx->force_reorth;
+            const bool optimistic = pass == 0;
             CHECK(upload_b(ctx, b, b_dtype));
-            for (int64_t t = 0; t < k && !ctx->s.capped; ++t) {
+            for (int64_t t = 0; t < k; ++t) {
                 CHECK(screened ? omp_step_screened(ctx, eps, t > 0, optimistic) : omp_step(ctx, eps, t > 0, optimistic));
                 if ((t + 1) % kPollSteps == 0 && t + 1 < k) {
                     bool stopped = false;
@@ -146,7 +140,6 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
             HIPCHECK(hipStreamSynchronize(ctx->stream));
             uncertain = screened && hs.uncertain > 0;
             if (!(hs.done & STOP_REORTH)) {
-                capacity_stop = ctx->s.capped && !(hs.done & (STOP_EPS | STOP_STAG | STOP_FULL));
                 break;
             }
         }
@@ -158,5 +151,5 @@ extern "C" int csmp_omp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, do
         screened = false;
     }
     CHECK(download_result(ctx, ctx->s.outcap, idx, val, nnz, order));
-    return capacity_stop ? CSMP_WCAPACITY : CSMP_OK;
+    return CSMP_OK;
 }

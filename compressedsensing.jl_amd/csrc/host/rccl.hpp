@@ -151,13 +151,11 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
     HIPCHECK(tNnz.alloc((size_t)std::max<int64_t>(1, nloc) * 8));
     HIPCHECK(tPack.alloc((size_t)(rows * w) * 8));
     HIPCHECK(tAll.alloc((size_t)(world * rows * w) * 8));
-    int wrc = CSMP_OK;
     if (nloc > 0) {
         const int rc = method == 1
             ? csmp_omp_batch_mfma(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE)
             : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE);
-        if (rc < 0) return rc;
-        wrc = rc;  // (CSMP_WCAPACITY travels with valid results)
+        if (rc != CSMP_OK) return rc;
     }
     const int grid = (int)std::min<int64_t>(1024, (rows * w + 255) / 256);
     hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k, nloc,
@@ -185,5 +183,5 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
         HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
     }
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the temporaries are released on return)
-    return wrc;
+    return CSMP_OK;
 }

@@ -170,8 +170,7 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
         HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         if (s.algo != CSMP_ALGO_MP) s.jh = std::min(s.kcap, hs.nsel);  // the host's support bound snaps to the true count
-        if (s.capped && s.jh < qr_max_cols()) s.capped = false;  // (the bound was loose: no-op steps had been counted)
-        if (stop) *stop = (hs.done & (STOP_EPS | STOP_STAG | STOP_FULL)) | (s.capped ? CSMP_STOP_CAPACITY : 0);
+        if (stop) *stop = hs.done & (STOP_EPS | STOP_STAG | STOP_FULL);
     }
     if (s.algo == CSMP_ALGO_MP) return mp_collect(ctx, nullptr, nullptr, 0, idx, val, nnz);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));

@@ -42,7 +42,6 @@ static int screened_ensure(csmp_ctx* ctx) {
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) * kScrCols - 1) / ((kSweepThreads / kWave) * kScrCols);
     const int maxgrid = ctx->prop.multiProcessorCount * 8;
     ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->prop.multiProcessorCount, maxgrid), groups));
-    if (const char* g = tune_env("CSMP_SCR_NBLK")) ctx->scr_grid = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(g), maxgrid), groups));
     if (ctx->scr_grid > kScrPartWgs) ctx->scr_grid -= ctx->scr_grid % kScrPartWgs;  // whole ticket partitions
     return CSMP_OK;
 }
@@ -299,8 +298,8 @@ static int screened_ensure_pair(csmp_ctx* ctx, csmp_ctx* twin) {
 static int omp_screened_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t k, double eps, int64_t* d_idx, double* d_val,
                                 int64_t* d_nnz, int* d_flag, hipEvent_t after_first_sweep) {
     int rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col_dev) : init_from_device_t<double>(c, (const double*)col_dev);
-    for (int64_t t = 0; t < k && rc == CSMP_OK && !c->s.capped; ++t) {
-        rc = omp_step_screened(c, eps, t > 0, !c->force_reorth);
+    for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) {
+        rc = omp_step_screened(c, eps, t > 0, true);
         if (t == 0 && rc == CSMP_OK && after_first_sweep && hipEventRecord(after_first_sweep, c->stream) != hipSuccess) return CSMP_EHIP;
     }
     if (rc != CSMP_OK) return rc;
@@ -313,7 +312,6 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     HIPCHECK(hipSetDevice(ctx->dev));
     // solves in flight: the context's and its twins', each one sweep behind the previous one
     int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->opt_in_flight, 3), nsig));  // (CSMP_OPT_SOLVES_IN_FLIGHT)
-    if (const char* tf = tune_env("CSMP_SCR_FLIGHT")) T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(atoi(tf), 3), nsig));
     if (T > 1) CHECK(twins_ensure(ctx, T - 1));
     csmp_ctx* cc[3] = {ctx, T > 1 ? ctx->twins[0] : nullptr, T > 2 ? ctx->twins[1] : nullptr};
     if (T == 1) CHECK(screened_ensure(ctx));
@@ -350,7 +348,6 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     for (int q = 0; q + 1 < T; ++q)
         if (!cc[q]->ev_twin) HIPCHECK(hipEventCreateWithFlags(&cc[q]->ev_twin, hipEventDisableTiming));
-    std::vector<char> capped((size_t)nsig, 0);
     for (int64_t sgn = 0; sgn < nsig; ++sgn) {
         const int q = (int)(sgn % T);
         csmp_ctx* c = cc[q];
@@ -358,7 +355,6 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         if (sgn > 0 && sgn < T) HIPCHECK(hipStreamWaitEvent(c->stream, cc[q - 1]->ev_twin, 0));  // a twin starts one sweep behind: out of phase
         const int rc = omp_screened_enqueue(c, col, b_dtype, k, eps, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, d_flag + sgn,
                                             sgn + 1 < T ? c->ev_twin : nullptr);
-        capped[(size_t)sgn] = c->s.capped;
         if (rc != CSMP_OK) {
             if (c != ctx) ctx->err = c->err;
             for (int w = 0; w < T; ++w) (void)hipStreamSynchronize(cc[w]->stream);
@@ -370,22 +366,19 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
     HIPCHECK(hipMemcpyAsync(hf.data(), d_flag, (size_t)nsig * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     int rc = CSMP_OK;
-    bool capacity_stop = false;
     for (int64_t sgn = 0; sgn < nsig && rc == CSMP_OK; ++sgn) {
         ctx->scr_solves += 1;
         if (hf[sgn] & (STOP_REORTH | STOP_UNCERTAIN)) {  // again, by the exact path with the full append chain
             ctx->scr_fallbacks += (hf[sgn] & STOP_UNCERTAIN) ? 1 : 0;
             const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
             rc = b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col) : init_from_device_t<double>(ctx, (const double*)col);
-            for (int64_t t = 0; t < k && rc == CSMP_OK && !ctx->s.capped; ++t) rc = omp_step(ctx, eps, t > 0, false);
+            for (int64_t t = 0; t < k && rc == CSMP_OK; ++t) rc = omp_step(ctx, eps, t > 0, false);
             if (rc == CSMP_OK) rc = launch_finish(ctx, d_idx + sgn * k, d_val + sgn * k, d_nnz + sgn, nullptr, (int)k, d_flag + sgn);
             if (rc == CSMP_OK) {
                 HIPCHECK(hipMemcpyAsync(&hf[sgn], d_flag + sgn, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
                 HIPCHECK(hipStreamSynchronize(ctx->stream));
-                capped[(size_t)sgn] = ctx->s.capped;
             }
         }
-        if (rc == CSMP_OK) capacity_stop |= capped[(size_t)sgn] && !(hf[sgn] & (STOP_EPS | STOP_STAG | STOP_FULL));
     }
     if (out_loc == CSMP_HOST) {
         if (rc == CSMP_OK) {
@@ -395,7 +388,7 @@ static int omp_batch_screened(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
         }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
-    return rc == CSMP_OK && capacity_stop ? CSMP_WCAPACITY : rc;
+    return rc;
 }
 
 // screened solves made by this context and how many of them were repeated with the exact sweep (failed certificate)

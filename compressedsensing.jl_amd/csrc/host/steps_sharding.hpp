@@ -45,8 +45,7 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
         }
         default: rc = gomp_update(ctx, l, 0.0, 0, STOP_FULL, false);
     }
-    // a step the QR append could not take (support at its capacity): x is unchanged, the caller is told
-    return rc == CSMP_OK && ctx->s.capped ? CSMP_WCAPACITY : rc;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ shared dictionary
@@ -58,15 +57,11 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
 // it asks for it).
 static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->pipeline = src->pipeline;
-    dst->force_reorth = src->force_reorth;
     dst->opt_in_flight = src->opt_in_flight;
     dst->opt_batch_cert = src->opt_batch_cert;
     dst->opt_batch_window = src->opt_batch_window;
     dst->opt_batch_screen = src->opt_batch_screen;
     dst->opt_screened = src->opt_screened;
-    dst->opt_ls_gram = src->opt_ls_gram;
-    dst->opt_ls_gram_reuse = src->opt_ls_gram_reuse;
-    dst->opt_twostage_update = src->opt_twostage_update;
 }
 extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     if (!src || !out) return CSMP_EINVAL;

@@ -14,13 +14,13 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
     if (maxiter < 0) maxiter = ctx->M;  // :185
     HIPCHECK(hipSetDevice(ctx->dev));
-    const bool want_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;
+    const bool want_downdate = k <= kDelMaxCols;
     if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
     CHECK(solver_ensure(ctx, (int)k, (int)k));
     ctx->s.begun = false;
     Solver& s = ctx->s;
-    const bool use_downdate = k <= kDelMaxCols && ctx->opt_twostage_update != 2;  // (option 2: refactorise instead)
-    const bool tmode = use_downdate && ctx->opt_twostage_update == 0;  // explicit inverse next to R (csmp_tinv.hpp)
+    const bool use_downdate = k <= kDelMaxCols;  // (option 2: refactorise instead)
+    const bool tmode = use_downdate;  // explicit inverse next to R (csmp_tinv.hpp)
     if (use_downdate) CHECK(del_ensure(ctx));
     if (tmode) CHECK(tinv_ensure(ctx));
     CHECK(upload_b(ctx, b, b_dtype));
@@ -356,7 +356,7 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
         p0.nq = -1;
         p0.update_only = 1;
         CHECK(launch_fr_pass(ctx, p0, 0.0, 0));
-        if (!tune_env("CSMP_FR_REBUILD_SWEEPS")) {
+        {
             // Q'A on the Float64 matrix cores, 128 directions per pass (csmp_forward.hpp, k_fr_rebuild)
             const int grid = (int)((ctx->N + 127) / 128);  // 4 waves x 32 atoms
             for (int64_t t = 0; t < k; t += 128) {
@@ -368,30 +368,6 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
                     hipLaunchKernelGGL(k_fr_rebuild<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld,
                                        (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);
                 HIPCHECK(hipGetLastError());
-            }
-        } else {
-        int U4, g4; bool f4; size_t lds4;
-            fr_config(ctx, 4, U4, f4, lds4, g4);
-            const bool four = lds4 <= 160 * 1024 - 512;  // four direction images fit the LDS (M <= ~5000)
-            for (int64_t t = 0; t < k;) {
-                FrPass ps;
-                ps.update_only = 1;
-                ps.q1 = s.Q + t * s.ldq;
-                ps.s1 = -1.0;
-                if (four && t + 4 <= k) {
-                    ps.nq = 4;
-                    ps.qstride = s.ldq;
-                    t += 4;
-                } else if (t + 2 <= k) {
-                    ps.nq = 2;
-                    ps.q2 = s.Q + (t + 1) * s.ldq;
-                    ps.s2 = -1.0;
-                    t += 2;
-                } else {
-                    ps.nq = 1;
-                    t += 1;
-                }
-                CHECK(launch_fr_pass(ctx, ps, 0.0, 0));
             }
         }
         hipLaunchKernelGGL(k_mark_inf, dim3(1), dim3(256), 0, ctx->stream, s.rho2, (const int*)s.sel, (const DevState*)s.st);

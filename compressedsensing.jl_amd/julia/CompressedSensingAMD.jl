@@ -50,20 +50,17 @@ Base.size(D::Dictionary) = (D.n, D.m)
 Base.size(D::Dictionary, i::Int) = size(D)[i]
 Base.eltype(::Dictionary{T}) where {T} = T
 
-# the reference throws bare strings (src/matchingpursuit.jl:74; src/twostage.jl:76): so do we.  A POSITIVE status is a
-# warning with valid results (CSMP_WCAPACITY = 1: the solve stopped at the on-device QR append's capacity, ~3900 atoms).
-const CSMP_WCAPACITY = Cint(1)
+# the reference throws bare strings (src/matchingpursuit.jl:74; src/twostage.jl:76): so do we
 function check(D::Dictionary, rc::Integer)
     rc == 0 && return
-    rc == CSMP_WCAPACITY && (@warn "libcsmp: the support reached the on-device QR capacity; the solution reached there is returned"; return)
     throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), D.ctx)))
 end
 
 # ---------------------------------------------------------------------------------- options (include/csmp.h, CSMP_OPT_*)
 # The reference passes its behavioural choices as arguments and so does this module; the choices that exist only on the GPU
 # side are per-Dictionary options.  The library reads no environment variable.
-const OPTIONS = Dict(:batch_cert => 1, :batch_gram => 2, :batch_window => 3, :pipeline => 4, :force_reorth => 5,
-                     :ls_gram => 6, :ls_gram_reuse => 7, :twostage_update => 8, :solves_in_flight => 9, :screened_sweep => 10, :batch_screen => 11)
+const OPTIONS = Dict(:batch_cert => 1, :batch_gram => 2, :batch_window => 3, :pipeline => 4, :solves_in_flight => 9, :screened_sweep => 10,
+                     :batch_screen => 11)
 set_option!(D::Dictionary, key::Symbol, value::Integer) =
     check(D, ccall((:csmp_set_option, libcsmp), Cint, (Ptr{Cvoid}, Cint, Int64), D.ctx, OPTIONS[key], value))
 function get_option(D::Dictionary, key::Symbol)
@@ -285,7 +282,7 @@ function begin_solver(A::MatOrDict{T}, b, algo, kcap, l = 1) where {T}
     P
 end
 pcheck(P::DevicePursuit, rc::Integer) =
-    rc >= 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), P.ctx)))  # (> 0: CSMP_WCAPACITY, x unchanged)
+    rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), P.ctx)))
 MP(A, b; steps::Integer = 4096) = begin_solver(A, b, ALGO_MP, steps)                       # :19-24 (steps: length of the device's step log)
 OMP(A, b, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_OMP, min(k, size(A, 1)))      # :54-60
 GOMP(A, b, l::Int, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_GOMP, min(k, size(A, 1)), l)  # :108-114

@@ -17,7 +17,7 @@
  *     dictionary yields the support a Float64 run of the reference would select on the same values.
  *   - Results follow SparseVector{Float64,Int64} (src/matchingpursuit.jl:76): indices sorted
  *     ascending (0-BASED here; the Julia wrapper adds 1), values aligned, nnz may be < k.
- *   - Every call returns a status (0 = ok, negative = error, positive = warning with valid results: CSMP_WCAPACITY);
+ *   - Every call returns a status (0 = ok, negative = error);
  *     csmp_last_error() gives the text of an error.
  *   - A ctx is bound to one GPU and one HIP stream and is not thread-safe (the reference is
  *     single-threaded too).  Caller owns every buffer passed in; the library owns device memory
@@ -38,12 +38,6 @@ extern "C" {
 #define CSMP_ESTATE (-5) /* no dictionary set / no solver begun */
 #define CSMP_ENOMEM (-6)
 #define CSMP_ERCCL (-7)  /* RCCL could not be loaded, or a communicator / collective call failed */
-/* positive = a warning; the results are valid.  CSMP_WCAPACITY: the on-device QR append keeps five support-length vectors in
- * the 160 KiB of LDS and holds about 3900 columns; a solve that reaches that support with no stopping rule having fired -- the
- * reference's defaults omp(A, b, eps) / OMP(A, b) / gomp with k = size(A, 1) at M = 4096 and a residual test that never fires --
- * stops THERE: the solution reached is returned (nnz = that capacity), not lost to an error. */
-#define CSMP_WCAPACITY 1
-
 #define CSMP_F32 0
 #define CSMP_F64 1
 #define CSMP_HOST 0
@@ -59,7 +53,6 @@ extern "C" {
 #define CSMP_STOP_EPS 1    /* norm(residual) < eps: src/matchingpursuit.jl:79,132 */
 #define CSMP_STOP_STAG 2   /* arg-max atom already selected: src/matchingpursuit.jl:66 */
 #define CSMP_STOP_FULL 4   /* nnz(x) == size(A,1): src/matchingpursuit.jl:63,117 */
-#define CSMP_STOP_CAPACITY 8 /* the support reached the on-device QR append's capacity (see CSMP_WCAPACITY); not in the reference */
 
 typedef struct csmp_ctx csmp_ctx;
 
@@ -217,7 +210,9 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
  * The reference passes every behavioural choice as an argument (src/matchingpursuit.jl:88-91,145-148;
  * src/twostage.jl:87); those are arguments here too.  The choices that exist only on this side of the boundary are
  * per-context options ("Config / flags").  The library reads NO environment variable.  A clone
- * (csmp_clone) starts from its parent's values.  Unknown keys and out-of-range values: CSMP_EINVAL. */
+ * (csmp_clone) starts from its parent's values (the resident Gram matrix excepted: 8 N^2 bytes per context are asked for, not
+ * inherited).  Unknown keys and out-of-range values: CSMP_EINVAL.  (Keys 5-8 of rounds 2-3 -- a test switch and three choices with
+ * one sane value each -- are gone: the library takes the default they had.) */
 #define CSMP_OPT_BATCH_CERT 1      /* certificate of csmp_omp_batch_mfma (and of the screened sweeps, CSMP_OPT_SCREENED_SWEEP).
                                       1 (default): rigorous -- a deterministic bound on the screen's error (unit roundoff of both
                                       operands' images, Float32 accumulation, key truncation) with the largest column norm: a
@@ -232,11 +227,6 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
                                       instead of streaming the support's columns: half the append traffic.  0 (default) frees it */
 #define CSMP_OPT_BATCH_WINDOW 3    /* capacity of the rescoring window, 1..128; 0 (default) = 64 statistical / 128 rigorous */
 #define CSMP_OPT_PIPELINE 4        /* csmp_omp_batch / csmp_fr_batch: 1 (default) three signals in flight, 0 one at a time */
-#define CSMP_OPT_FORCE_REORTH 5    /* test switch: 1 = every append runs the second Gram-Schmidt pass (k_qr3) */
-#define CSMP_OPT_LS_GRAM 6         /* whole-set least squares (sp, lstsq): 1 (default) Gram matrix + blocked Cholesky, 0 panel appends */
-#define CSMP_OPT_LS_GRAM_REUSE 7   /* 1 (default): a set inside the last factorised one gathers its Gram matrix from the kept copy */
-#define CSMP_OPT_TWOSTAGE_UPDATE 8 /* ompr's exchange step: 0 (default) explicit inverse T = R^-1 beside R, 1 Givens down-date of R,
-                                      2 refactorise from scratch (the reference's own cost model, src/twostage.jl:171-174) */
 #define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
 #define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) and csmp_ompr (k <= 4096): 0 (default) every sweep
                                       reads the f32/f64 dictionary (exact, 4 / 8 bytes per element).  1 / 3 / 2: the sweep reads an IMAGE of the
