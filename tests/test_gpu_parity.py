@@ -1922,8 +1922,8 @@ def test_screened_sweep_gomp_matches_oracle(cs, oracle, D, shape, dtype):
         for s, ref in enumerate(refs):
             assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), (cert, s)
     st = d.ctx.screened_stats()
-    assert st["solves"] == 18 and st["fallbacks"] <= 18
-    d.ctx.set_option("batch_cert", 0)
+    assert st["solves"] == 30 and st["fallbacks"] <= 30
+    d.ctx.set_option("batch_cert", 1)
     d.ctx.set_option("screened_sweep", 0)
 
 

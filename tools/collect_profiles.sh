@@ -1,40 +1,50 @@
 #!/bin/bash
-# collect_profiles.sh <outdir> -- the rocprofv3 evidence of a round, on the GPU box (gpurun): kernel-trace statistics of the
-# default bench command and of the secondary workloads, and the PMC passes (separate runs, --kernel-trace only, as the
-# pool requires).  Run from the repository root; summaries land in <outdir> (copy the ones to keep into profiles/).
+# collect_profiles.sh <outdir> -- the rocprofv3 evidence of a round, on the GPU box (gpurun): kernel-trace statistics of the default
+# bench command and of the secondary workloads, and the PMC passes (separate runs, --kernel-trace only, as the pool requires).
+# Run from the repository root; summaries land in <outdir> (copy the ones to keep into profiles/, named per round).
 set -u
 OUT=$(realpath "$1"); mkdir -p "$OUT"
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-stats() {  # stats <name> <bench args...>
+stats() {  # stats <name> <bench args...>: headline line + csmp kernel rows of rocprofv3 --kernel-trace --stats
   local name=$1; shift
-  rm -rf /tmp/prof_$name
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" > $OUT/${name}_line.json 2> $OUT/${name}.err
+  rm -rf /tmp/prof_$name /tmp/w_$name; mkdir -p /tmp/w_$name; cd /tmp/w_$name
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" > $OUT/${name}_stdout.txt 2> $OUT/${name}.err
   local f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && grep -E '^"Name"|csmp::' "$f" > $OUT/${name}_kernel_stats.csv
-  grep '^{' $OUT/${name}_line.json > $OUT/${name}_line.tmp && mv $OUT/${name}_line.tmp $OUT/${name}_line.json
+  grep '^{' $OUT/${name}_stdout.txt | tail -1 > $OUT/${name}_line.json; rm -f $OUT/${name}_stdout.txt
+  [ -f bench_secondary.json ] && cp bench_secondary.json $OUT/${name}_detail.json
+  cd /tmp
 }
-pmc() {  # pmc <name> <counters> <bench args...>
+pmc() {  # pmc <name> <counters> <bench args...> -> prints the output directory
   local name=$1 ctr=$2; shift 2
   rm -rf /tmp/pmc_$name
   timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $R/bench.py "$@" > /dev/null 2> $OUT/pmc_${name}.err
   echo /tmp/pmc_$name
 }
+# the driver's command, unprofiled: the compact headline (last stdout line) and the detail file
+mkdir -p /tmp/w_plain; cd /tmp/w_plain
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default_stdout.txt 2> $OUT/bench_default.err
+tail -1 $OUT/bench_default_stdout.txt > $OUT/bench_default_line.json; cp bench_secondary.json $OUT/bench_default_detail.json; rm -f $OUT/bench_default_stdout.txt
+cd /tmp
 stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
-stats bench_batched --workload batched --steps 2 --warmup 1 --batch-screen bf16
-stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram --batch-screen bf16
-stats bench_batched_rigorous --workload batched --steps 2 --warmup 1 --batch-cert rigorous
-stats bench_batched_int8 --workload batched --steps 2 --warmup 1 --batch-screen int8
-stats bench_batched_int8_gram --workload batched --steps 2 --warmup 1 --batch-screen int8 --batch-gram
+stats bench_batched --workload batched --steps 2 --warmup 1
+stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
+stats bench_batched_statistical_int8 --workload batched --steps 2 --warmup 1 --batch-cert statistical --batch-screen int8
 stats bench_sp --workload sp --steps 9 --warmup 3
 stats bench_sp_single --workload sp_single --steps 3 --warmup 1
 stats bench_gomp --workload gomp --steps 6 --warmup 2
 stats bench_gomp_single --workload gomp_single --steps 2 --warmup 1
+stats bench_screened_f16 --workload screened --steps 6 --warmup 2
+stats bench_gomp_single_screened_f16 --workload gomp_single --steps 2 --warmup 1 --screened
 # HBM traffic of the steady-state tick (two passes: the TCC block cannot hold both counters)
 d1=$(pmc fetch FETCH_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 d2=$(pmc write WRITE_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 python3 $R/tools/pmc_traffic.py $d1 $d2 > $OUT/sweep_traffic.json
-# matrix-core counters of the screening kernel
+# HBM fetch bytes of the binary16-image sweep
+d5=$(pmc scr FETCH_SIZE --workload screened --steps 2 --warmup 1)
+python3 $R/tools/pmc_traffic.py --kernel k_sweep_f16 $d5 > $OUT/screened_f16_traffic.json
+# matrix-core counters of the screening kernel (binary16 operands: the default)
 d3=$(pmc mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" --workload batched --steps 1 --warmup 0)
 python3 - "$d3" > $OUT/batched_mfma_pmc.json <<'PY'
 import csv, glob, json, os, sys
@@ -48,13 +58,10 @@ out = {k: {"dispatches": len(v), "avg": sum(v) / len(v)} for k, v in acc.items()
 if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
     # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over the 256 CUs x 4 SIMDs
     out["mfma_util"] = out["SQ_VALU_MFMA_BUSY_CYCLES"]["avg"] / (out["GRBM_GUI_ACTIVE"]["avg"] / 8.0 * 1024.0)
-    out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (k_b_screen256p, all 1024 signals of the batch)"
+    out["note"] = "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), per screening launch (k_b_screen256p<f16>, all 1024 signals of the batch)"
 print(json.dumps(out, indent=1))
 PY
-# HBM traffic of the batched path's kernels (default options and with the Gram matrix): FETCH_SIZE only -- the WRITE_SIZE pass of
-# this workload hung under the profiler in round 3 (tools/pmc_batched.py)
+# HBM fetch bytes of the batched path's kernels (default options)
 d4=$(pmc bfetch FETCH_SIZE --workload batched --steps 1 --warmup 0)
 python3 $R/tools/pmc_batched.py $d4 - > $OUT/batched_traffic.json
-d6=$(pmc bgfetch FETCH_SIZE --workload batched --steps 1 --warmup 0 --batch-gram)
-python3 $R/tools/pmc_batched.py $d6 - gram > $OUT/batched_gram_traffic.json
 ls -la $OUT
