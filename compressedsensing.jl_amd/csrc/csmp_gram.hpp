@@ -75,13 +75,14 @@ constexpr int kGramWgJ = 64;   // G columns per workgroup
 // one wave per SIMD cannot issue Float64 MFMAs back to back (measured: 35 TFLOP/s with one, 47 with two waves per SIMD).
 template <typename TA>
 __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const TA* __restrict__ Ac, int64_t ldo, int np,
-                                                                         int rows_per_split, double* __restrict__ Gpart) {
+                                                                         int rows_per_split, double* __restrict__ Gpart, int jtile0 = 0) {
     constexpr int RPL = kGramRpl, BLK = 4 * RPL;
     struct alignas(sizeof(TA) * RPL) Frag { TA v[RPL]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int wi = wave >> 1, wj = wave & 1;
     const int I = blockIdx.y, J = blockIdx.x, ks = blockIdx.z;
     if (I * kGramWgI > J * kGramWgJ + kGramWgJ - 1) return;  // entirely below the diagonal
+    if (J < jtile0) return;  // (bordered extension: only the new columns' tiles are needed, k_ext_reduce)
     const int k0 = ks * rows_per_split, k1 = (int)min((int64_t)ldo, (int64_t)k0 + rows_per_split);
     const int i0 = I * kGramWgI + wi * 64, j0 = J * kGramWgJ + wj * 32;
     const TA *ci[4], *cj[2];
@@ -461,6 +462,156 @@ __global__ __launch_bounds__(256) void k_gram_export(const double* __restrict__ 
     if (e < n) {
         z[e] = fac((int)e, n);
         sel[e] = cols[e];
+    }
+    if (e == 0) {
+        st->nsel = n;
+        st->j = n;
+        st->steps += 1;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Bordered extension of a factorised set (Subspace Pursuit's update!: the 2k-set T = F + N holds the k atoms F whose factor
+// the previous solve left in the solver slot -- src/twostage.jl:74 "IDEA: could add efficient qr updating"; this is that idea on
+// the normal equations).  With G_TT = [G_FF G_FN; . G_NN] and R_F'R_F = G_FF already known,
+//     R_T = [R_F W; 0 R_C],   W = R_F^-T G_FN,   R_C'R_C = G_NN - W'W,   z_T = [z_F; R_C^-T (c_N - W'z_F)]
+// -- the block Cholesky of G_TT in the column order [F | N], of which only the N part is computed: n_N/32 dependent steps instead
+// of (n_F + n_N)/32, the substitution W as n_N independent columns in ONE launch (k_trsm_rt), the Schur complement on the
+// Float64 matrix cores (k_gram<double> on W, bordered by z_F).
+//
+// k_ext_reduce: the kept bordered Gram matrix of T (Knew, np x np, upper tiles; the next subset solve gathers from it) from
+//   * the old kept matrix (G_FF: entry (posF[i], posF[j])), * k_gram's partials (columns >= nF), * k_gather_cols' right-hand side;
+// and Wb (ldw x np2, zero padded) = [G_FN | z_F]: the substitution's input, the Schur product's border.
+__global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ Gpart, int nsplit, int nF, int n, int np,
+                                                    const double* __restrict__ rhs_part, int nchunk, const double* __restrict__ Kold,
+                                                    int knp, const int* __restrict__ posF, const double* __restrict__ zF,
+                                                    double* __restrict__ Knew, double* __restrict__ kdnew, double* __restrict__ Wb,
+                                                    int ldw, int np2) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (int64_t)ldw * np2) {  // Wb's padding and border first (entries of G_FN are written below, by their owners)
+        const int row = (int)(e % ldw), col = (int)(e / ldw), nN = n - nF;
+        if (row >= nF || col > nN) Wb[e] = 0.0;
+        else if (col == nN) Wb[e] = zF[row];
+    }
+    if (e >= (int64_t)np * np) return;
+    const int row = (int)(e % np), col = (int)(e / np);
+    if ((row / kGramTile) > (col / kGramTile)) return;  // lower tiles are never read
+    double s = 0.0;
+    if (row < nF && col < nF) {
+        const int a = posF[row], b = posF[col];
+        s = Kold[min(a, b) + (int64_t)max(a, b) * knp];
+    } else if (row < n && col < n) {  // (col >= nF: the tiles k_gram computed)
+        for (int k = 0; k < nsplit; ++k) s += Gpart[(int64_t)k * np * np + e];
+        if (row < nF) Wb[row + (int64_t)(col - nF) * ldw] = s;
+    } else if (row <= n && col == n) {
+        for (int k = 0; k < nchunk; ++k) s += rhs_part[(int64_t)k * np + row];
+    } else if (row == col && row > n) {
+        s = 1.0;
+    }
+    Knew[e] = s;
+    if (row == col && row < n) kdnew[row] = s;
+}
+
+// W = R_F^-T G_FN, column by column: wave c solves R_F' y = g (g = column c of Wb, overwritten by y) right-looking, as
+// k_tinv_build does for the unit vectors: lane l owns the entries t = l + 64 u with a partial sum each; at step s every lane
+// adds R[s, t] y_s to its sums, the owner of t = s + 1 closes y_{s+1} and v_readlane broadcasts it.  R values D steps ahead.
+template <int NU, int D>
+__global__ __launch_bounds__(64) void k_trsm_rt(const double* __restrict__ R, int kcap, int nF, double* __restrict__ Wb, int ldw) {
+    const int lane = threadIdx.x;
+    double* g = Wb + (int64_t)blockIdx.x * ldw;
+    const double* colp[NU];
+    double acc[NU], rdg[NU], gv[NU];
+    bool own[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const int t = lane + 64 * u;
+        own[u] = t < nF;
+        colp[u] = R + (int64_t)(own[u] ? t : 0) * kcap;
+        acc[u] = 0.0;
+        rdg[u] = own[u] ? 1.0 / colp[u][t] : 0.0;
+        gv[u] = own[u] ? g[t] : 0.0;
+    }
+    double ys = readlane_f64(gv[0] * rdg[0], 0);
+    if (lane == 0) g[0] = ys;
+    double cur[D][NU], nxt[D][NU];
+    auto fetch = [&](double (*dst)[NU], int s0) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int sidx = s0 + d, t = lane + 64 * u;
+                dst[d][u] = (own[u] && sidx < t) ? colp[u][sidx] : 0.0;
+            }
+    };
+    fetch(cur, 0);
+    for (int sb = 0; sb <= nF - 2; sb += D) {
+        fetch(nxt, sb + D);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int sidx = sb + d;
+            if (sidx <= nF - 2) {
+                const int nt = sidx + 1, su = nt >> 6, sl = nt & 63;
+                double mine = 0.0;
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    acc[u] = fma(cur[d][u], ys, acc[u]);
+                    if (u == su) mine = (gv[u] - acc[u]) * rdg[u];
+                }
+                ys = readlane_f64(mine, sl);
+                if (lane == sl) g[nt] = ys;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
+    }
+}
+
+// The Schur complement, bordered: G2 (np2 x np2, the layout k_chol_* expects) = [G_NN c_N; . .] - sum of k_gram<double>'s
+// partials of [W z_F]'[W z_F]; identity on the padding diagonal; gdiag2 = diag(G_NN) = |a_j|^2 (the DGKS reference).
+__global__ __launch_bounds__(256) void k_schur_reduce(const double* __restrict__ Knew, int np, int nF, int nN, int np2,
+                                                      const double* __restrict__ Wpart, int nsplit, double* __restrict__ G2,
+                                                      double* __restrict__ gdiag2) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)np2 * np2) return;
+    const int row = (int)(e % np2), col = (int)(e / np2);
+    if ((row / kGramTile) > (col / kGramTile)) return;
+    double s = 0.0;
+    if (row <= nN && col <= nN) {
+        s = Knew[(nF + row) + (int64_t)(nF + col) * np];
+        double w = 0.0;
+        for (int k = 0; k < nsplit; ++k) w += Wpart[(int64_t)k * np2 * np2 + e];
+        if (row == col && row < nN) gdiag2[row] = s;
+        s -= w;
+    } else if (row == col) {
+        s = 1.0;
+    }
+    G2[e] = s;
+}
+
+// R_T's new blocks into the solver slot: W (rows of F, columns of N), R_C, z_N, the new atoms; count = nF + nN.
+__global__ __launch_bounds__(256) void k_gram_export_b(const double* __restrict__ G2, int np2, int nF, int nN, const int* __restrict__ cols,
+                                                       const double* __restrict__ Wb, int ldw, double* __restrict__ R, int kcap,
+                                                       double* __restrict__ z, int* __restrict__ sel, DevState* st,
+                                                       const double* __restrict__ Dfac) {
+    if (st->done & STOP_REORTH) return;
+    constexpr int NB = kCholNB;
+    auto fac = [&](int row, int col) {
+        return (row / NB == col / NB) ? Dfac[(int64_t)(row / NB) * NB * NB + (row % NB) + (int64_t)(col % NB) * NB] : G2[row + (int64_t)col * np2];
+    };
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = nF + nN;
+    if (e < (int64_t)n * nN) {
+        const int row = (int)(e % n), j = (int)(e / n);
+        double* dst = R + row + (int64_t)(nF + j) * kcap;
+        if (row < nF) *dst = Wb[row + (int64_t)j * ldw];
+        else if (row - nF <= j) *dst = fac(row - nF, j);
+    }
+    if (e < nN) {
+        z[nF + e] = fac((int)e, nN);
+        sel[nF + e] = cols[nF + e];
     }
     if (e == 0) {
         st->nsel = n;

@@ -143,7 +143,8 @@ static int upload_b(csmp_ctx* ctx, const void* b, int b_dtype) {
     else
         memcpy(hb, b, (size_t)M * sizeof(double));
     HIPCHECK(hipMemcpyAsync(s.bstage, hb, (size_t)M * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    s.keep_valid = false;  // (the kept Gram matrix carries A_S'b of the previous b)
+    s.keep_valid = false;
+    s.fac_valid = false;  // (the kept Gram matrix carries A_S'b of the previous b)
     hipLaunchKernelGGL(k_init<double>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, (const double*)s.bstage, M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;
@@ -154,6 +155,7 @@ template <typename TB>
 static int init_from_device_t(csmp_ctx* ctx, const TB* col) {
     Solver& s = ctx->s;
     s.keep_valid = false;
+    s.fac_valid = false;
     hipLaunchKernelGGL(k_init<TB>, dim3(s.Mpad / 256), dim3(256), 0, ctx->stream, col, (int)ctx->M, s.Mpad, s.b, s.r, s.st);
     HIPCHECK(hipGetLastError());
     s.jh = 0;

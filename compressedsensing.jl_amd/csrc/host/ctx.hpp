@@ -54,6 +54,10 @@ struct Solver {
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
     double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
     int* kpos = nullptr;
+    // bordered extension (ls_gram_extend_t): the second kept matrix (ping-pong), W's workspace, and the set whose factor the slot holds
+    double *Gkeep2 = nullptr, *gdkeep2 = nullptr, *Wb = nullptr;
+    std::vector<int> fac_cols, fac_pending;  // factor order of the last CONFIRMED whole-set solve / of the one in flight
+    bool fac_valid = false;                  // R, z, sel hold fac_cols' factor on the current b (dropped by anything that rewrites them)
     std::vector<int> keep_cols;
     int keep_n = 0, keep_np = 0;
     bool keep_valid = false;

@@ -322,6 +322,7 @@ static int solver_restart(csmp_ctx* ctx) {
 // `cols` (host list): QR by successive appends, residual r = b - A_S c as a by-product.
 static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
     Solver& s = ctx->s;
+    s.fac_valid = false;
     if ((int)cols.size() > s.kcap) return fail(ctx, CSMP_ERANGE, "least squares: more columns than the QR capacity");
     CHECK(solver_restart(ctx));
     const int n = (int)cols.size();
@@ -359,10 +360,15 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
     dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
+    s.fac_valid = false;
     CHECK(dmalloc(ctx, &s.Gkeep, (size_t)np * np));
     CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
+    CHECK(dmalloc(ctx, &s.Gkeep2, (size_t)np * np));  // the bordered extension assembles the next kept matrix beside the current one
+    CHECK(dmalloc(ctx, &s.gdkeep2, (size_t)np));
+    CHECK(dmalloc(ctx, &s.Wb, (size_t)np * np));      // [G_FN | z_F] -> W = R_F^-T G_FN (k_trsm_rt)
     CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
     CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
     CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
@@ -381,13 +387,129 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
 // export of (R, z, support), the back substitution + sorted emission into the slot's out arrays and the residual
 // r = b - A_S x.  No host synchronisation; a set that fails the DGKS test leaves STOP_REORTH in the control block (and
 // nothing exported): the caller checks it with the results and falls back to ls_on_columns.
+// Bordered extension (csmp_gram.hpp): `cols` holds the set F whose factor the slot still carries (same b) plus new columns.
+// Enqueues everything ls_gram_t does, with the Cholesky chain over the NEW columns only.  order = [F in factor order | new, sorted].
+template <typename TA>
+static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF, const std::vector<int>& posF) {
+    Solver& s = ctx->s;
+    const int n = (int)order.size(), nN = n - nF, M = (int)ctx->M;
+    const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
+    const int np2 = ((nN + 1 + kGramTile - 1) / kGramTile) * kGramTile;
+    const int ldw = ((nF + 15) / 16) * 16;
+    const int nsplit = gram_split_for(ctx, np);
+    // (gram_ensure has run: the caller checked the buffers' sizes before it decided for this path)
+    CHECK(solver_restart(ctx));  // r = b, control block reset; R, z, sel of F stay where they are
+    void* pcv = nullptr;
+    CHECK(pin_get(ctx, 2, (size_t)(2 * n + 2) * 4, &pcv));
+    int* pcols = (int*)pcv;
+    int* ppos = pcols + n + 1;
+    for (int t = 0; t < n; ++t) pcols[t] = order[t];
+    pcols[n] = n;
+    for (int t = 0; t < nF; ++t) ppos[t] = posF[t];
+    HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)nF * 4, hipMemcpyHostToDevice, ctx->stream));
+    const int blk = 16;
+    const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
+    const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
+    const int nchunk = (int)((ldo + 255) / 256);
+    hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)nchunk, np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                       (const int*)s.cands, n, (TA*)s.Acomp, ldo, (const double*)s.b, np, s.rhs_part);
+    hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
+                       rps, s.Gpart, nF / kGramWgJ);
+    HIPCHECK(hipGetLastError());
+    const int64_t nel = std::max<int64_t>((int64_t)np * np, (int64_t)ldw * np2);
+    hipLaunchKernelGGL(k_ext_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, nF, n, np,
+                       (const double*)s.rhs_part, nchunk, (const double*)s.Gkeep, s.keep_np, (const int*)s.kpos, (const double*)s.z, s.Gkeep2, s.gdkeep2,
+                       s.Wb, ldw, np2);
+    HIPCHECK(hipGetLastError());
+    if (nF <= 256) hipLaunchKernelGGL((k_trsm_rt<4, 4>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
+    else if (nF <= 512) hipLaunchKernelGGL((k_trsm_rt<8, 4>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
+    else hipLaunchKernelGGL((k_trsm_rt<16, 2>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
+    HIPCHECK(hipGetLastError());
+    // [W z_F]'[W z_F] on the Float64 matrix cores: the columns of Wb are the "dictionary" (ldw rows), a few row slices
+    const int nsplit2 = std::max(1, std::min(std::min(nsplit, 8), ldw / 64));
+    const int rps2 = (((ldw + nsplit2 - 1) / nsplit2 + blk - 1) / blk) * blk;
+    hipLaunchKernelGGL(k_gram<double>, dim3(np2 / kGramWgJ, (np2 + kGramWgI - 1) / kGramWgI, nsplit2), dim3(256), 0, ctx->stream, (const double*)s.Wb,
+                       (int64_t)ldw, np2, rps2, s.Gpart, 0);
+    const int64_t nel2 = (int64_t)np2 * np2;
+    hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((nel2 + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep2, np, nF, nN, np2,
+                       (const double*)s.Gpart, nsplit2, s.Gm, s.gdiag);
+    HIPCHECK(hipGetLastError());
+    const int nsteps = (nN + kCholNB - 1) / kCholNB;
+    {
+        const int left0 = np2 - kCholNB;
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np2, nN,
+                           0, (const double*)s.gdiag, s.st, s.Dfac);
+    }
+    for (int kb = 0; kb + 1 < nsteps; ++kb) {
+        const int left = np2 - (kb + 1) * kCholNB;
+        const int left2 = left - kCholNB;
+        const int Tt = (left + kGramTile - 1) / kGramTile;
+        const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
+        const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
+        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np2, nN, kb, (const double*)s.gdiag, s.st,
+                           nrow, s.Dfac);
+    }
+    HIPCHECK(hipGetLastError());
+    hipLaunchKernelGGL(k_gram_export_b, dim3((unsigned)(((int64_t)n * nN + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np2, nF, nN,
+                       (const int*)s.cands, (const double*)s.Wb, ldw, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
+    HIPCHECK(hipGetLastError());
+    std::swap(s.Gkeep, s.Gkeep2);
+    std::swap(s.gdkeep, s.gdkeep2);
+    s.keep_cols = order;
+    s.keep_n = n;
+    s.keep_np = np;
+    s.keep_valid = true;
+    s.jh = std::min(s.kcap, n);
+    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    const int nch = (n + kResChunk - 1) / kResChunk;
+    hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
+                       (const int*)s.cands, (const double*)s.coef, n, s.rpart);
+    hipLaunchKernelGGL(k_residual_sum, dim3((M + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.rpart, nch, M, (const double*)s.b,
+                       s.r, (const DevState*)s.st, s.rn2part);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
 template <typename TA>
 static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     Solver& s = ctx->s;
     const int n = (int)cols.size(), M = (int)ctx->M;
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int nsplit = gram_split_for(ctx, np);
-    CHECK(gram_ensure(ctx, np, nsplit));
+    CHECK(gram_ensure(ctx, np, nsplit));  // (a reallocation drops fac_valid and keep_valid)
+    const bool can_extend = s.fac_valid;
+    s.fac_valid = false;  // whatever happens below rewrites the slot; the caller confirms the new factor once it has seen it succeed
+    s.fac_pending.assign(cols.begin(), cols.end());  // the factor order of this solve
+    if (can_extend) {
+        // The slot still holds the factor of a set F on this very b.  If F lies inside `cols` (and its Gram matrix inside the kept
+        // one), only the new columns are factorised (ls_gram_extend_t).
+        const int nF = (int)s.fac_cols.size();
+        if (nF >= 64 && nF < n && s.keep_valid && n <= s.kcap) {
+            std::vector<std::pair<int, int>> where((size_t)s.keep_n);
+            for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
+            std::sort(where.begin(), where.end());
+            std::vector<int> posF((size_t)nF);
+            bool ok = true;
+            for (int t = 0; t < nF && ok; ++t) {
+                auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(s.fac_cols[t], 0));
+                ok = it != where.end() && it->first == s.fac_cols[t] && std::binary_search(cols.begin(), cols.end(), s.fac_cols[t]);
+                if (ok) posF[t] = it->second;
+            }
+            if (ok && std::is_sorted(cols.begin(), cols.end())) {
+                std::vector<int> order(s.fac_cols);
+                std::vector<int> fs(s.fac_cols);
+                std::sort(fs.begin(), fs.end());
+                for (int c : cols)
+                    if (!std::binary_search(fs.begin(), fs.end(), c)) order.push_back(c);
+                if ((int)order.size() == n) {
+                    s.fac_pending = order;
+                    return ls_gram_extend_t<TA>(ctx, order, nF, posF);
+                }
+            }
+        }
+    }
     CHECK(solver_restart(ctx));
     // the column list (and, for a subset, its positions in the kept set) go up from a page-locked buffer that lives until the
     // next call -- every caller drains the stream before it comes back here
@@ -557,6 +679,8 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         const DevState hs = *phs;
         if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
+            s.fac_cols.swap(s.fac_pending);  // the slot now holds this set's factor (R, z, sel) on the current b: a later superset extends it
+            s.fac_valid = true;
             idx.assign(pi, pi + n);
             val.assign(pvv, pvv + n);
             if (resnorm) {
