@@ -133,11 +133,27 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
 
 // G = sum of the row-slice partials (fixed order) on the upper tiles; identity on the padding diagonal (columns beyond the
 // bordered one), zeros elsewhere in the padding; the original diagonal goes to gdiag (DGKS reference, |a_j|^2)
+// AUGMENTED form (npa > np): G has leading dimension npa and npa - np further columns, the first n of them the unit vectors
+// e_0 .. e_{n-1} (zeros otherwise).  The Cholesky kernels treat them like the bordered column: their row panels come out as
+// R^-T e_j, i.e. the block G[0:n, np:np+n] ends up holding (R^-1)' -- the explicit inverse a LATER extension of this set needs
+// (ls_gram_extend_t: W = R_F^-T G_FN as one tiled product), for the price of wider row panels in launches whose duration is
+// set by their dependent chain, not by their width.
+__device__ __forceinline__ bool gram_aug_entry(int64_t e, int np, int npa, int n, double* __restrict__ G) {
+    // entries of the augmented columns, one per thread e in [np * npa, npa * npa): true when e was one of them
+    if (e < (int64_t)np * npa) return false;
+    if (e < (int64_t)npa * npa) {
+        const int row = (int)(e % npa), col = (int)(e / npa);
+        G[e] = (row < n && row == col - np) ? 1.0 : 0.0;
+    }
+    return true;
+}
 __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ Gpart, int nsplit, int n, int np,
                                                      double* __restrict__ G, double* __restrict__ gdiag,
                                                      const double* __restrict__ rhs_part, int nchunk,
-                                                     double* __restrict__ Gkeep, double* __restrict__ gdkeep) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                     double* __restrict__ Gkeep, double* __restrict__ gdkeep, int npa) {
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gram_aug_entry(e0 - (int64_t)np * np + (int64_t)np * npa, np, npa, n, G)) return;  // (threads beyond np * np take the augmented columns)
+    const int64_t e = e0;
     if (e >= (int64_t)np * np) return;
     const int row = (int)(e % np), col = (int)(e / np);
     if ((row / kGramTile) > (col / kGramTile)) return;  // lower tiles are never read
@@ -149,7 +165,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
     } else if (row == col && row > n) {
         s = 1.0;
     }
-    G[e] = s;
+    G[row + (int64_t)col * npa] = s;
     Gkeep[e] = s;  // the copy that survives the factorisation (a later subset of this set gathers its matrix from it)
     if (row == col && row < n) {
         gdiag[row] = s;
@@ -162,8 +178,10 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double* __restrict__ 
 // the corner come from K's bordered column, the diagonal reference from K's.  Same layout rules as k_gram_reduce.
 __global__ __launch_bounds__(256) void k_gram_subset(const double* __restrict__ K, int knp, int kn, const double* __restrict__ kdiag,
                                                      const int* __restrict__ pos, int n, int np, double* __restrict__ G,
-                                                     double* __restrict__ gdiag) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+                                                     double* __restrict__ gdiag, int npa) {
+    const int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gram_aug_entry(e0 - (int64_t)np * np + (int64_t)np * npa, np, npa, n, G)) return;
+    const int64_t e = e0;
     if (e >= (int64_t)np * np) return;
     const int row = (int)(e % np), col = (int)(e / np);
     if ((row / kGramTile) > (col / kGramTile)) return;  // lower tiles are never read
@@ -178,7 +196,7 @@ __global__ __launch_bounds__(256) void k_gram_subset(const double* __restrict__ 
     } else if (row == col && row > n) {
         s = 1.0;
     }
-    G[e] = s;
+    G[row + (int64_t)col * npa] = s;
     if (row == col && row < n) gdiag[row] = kdiag[pos[row]];
 }
 
@@ -385,13 +403,14 @@ __global__ __launch_bounds__(kCholThreads) void k_chol_row(double* __restrict__ 
 // the upper 64 x 64 tile `p` of the trailing matrix (columns >= c0 + NB).  Matrix cores; lane fq takes 8 consecutive rows of X
 // per pass (NB / 32 passes); the accumulators start from G itself and one operand enters negated, so the loads of a pass are
 // all issued before its first MFMA.  skip_first: rows c0+NB .. c0+2NB-1 (the next block row) are left to chol_row_body<true>.
-__device__ __forceinline__ void chol_trail_body(double* __restrict__ G, int np, int kb, int p, bool skip_first) {
+__device__ __forceinline__ void chol_trail_body(double* __restrict__ G, int np, int kb, int p, bool skip_first, int rowlim) {
     constexpr int NB = kCholNB;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
     const int c0 = kb * NB, t0 = c0 + NB;  // trailing matrix starts at column t0
     int J = 0;
     while ((J + 1) * (J + 2) / 2 <= p) ++J;
     const int I = p - J * (J + 1) / 2;
+    if (t0 + I * kGramTile >= rowlim) return;  // (augmented factorisation: rows beyond the real matrix are never factorised)
     const int tlo = (skip_first && I == 0) ? NB / 16 : 0;  // 16-row sub-tiles of the tile that belong to the next block row
     const int cj = t0 + J * kGramTile + wave * 16 + fr;
     d4g acc[4];
@@ -434,12 +453,12 @@ __device__ __forceinline__ void chol_trail_body(double* __restrict__ G, int np, 
 // rest of the trailing matrix meanwhile.  The two groups touch disjoint rows; panel kb itself is only read.
 __global__ __launch_bounds__(kCholThreads) void k_chol_step(double* __restrict__ G, int np, int n, int kb,
                                                             const double* __restrict__ gdiag, DevState* st, int nrow,
-                                                            double* __restrict__ Dfac) {
+                                                            double* __restrict__ Dfac, int rowlim) {
     if ((int)blockIdx.x < nrow) {
         chol_row_body<true>(G, np, n, kb + 1, gdiag, st, (int)blockIdx.x, Dfac);
     } else {
         if (threadIdx.x >= 256) return;
-        chol_trail_body(G, np, kb, (int)blockIdx.x - nrow, true);
+        chol_trail_body(G, np, kb, (int)blockIdx.x - nrow, true, rowlim);
     }
 }
 
@@ -482,12 +501,12 @@ __global__ __launch_bounds__(256) void k_gram_export(const double* __restrict__ 
 //
 // k_ext_reduce: the kept bordered Gram matrix of T (Knew, np x np, upper tiles; the next subset solve gathers from it) from
 //   * the old kept matrix (G_FF: entry (posF[i], posF[j])), * k_gram's partials (columns >= nF), * k_gather_cols' right-hand side;
-// and Wb (ldw x np2, zero padded) = [G_FN | z_F]: the substitution's input, the Schur product's border.
+// G_FN into Gin (ldw x nN: k_wgemm's input), and Wb's (ldw x np2) zero padding and border column z_F (k_wgemm fills the rest).
 __global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ Gpart, int nsplit, int nF, int n, int np,
                                                     const double* __restrict__ rhs_part, int nchunk, const double* __restrict__ Kold,
                                                     int knp, const int* __restrict__ posF, const double* __restrict__ zF,
                                                     double* __restrict__ Knew, double* __restrict__ kdnew, double* __restrict__ Wb,
-                                                    int ldw, int np2) {
+                                                    int ldw, int np2, double* __restrict__ Gin) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e < (int64_t)ldw * np2) {  // Wb's padding and border first (entries of G_FN are written below, by their owners)
         const int row = (int)(e % ldw), col = (int)(e / ldw), nN = n - nF;
@@ -503,7 +522,7 @@ __global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ G
         s = Kold[min(a, b) + (int64_t)max(a, b) * knp];
     } else if (row < n && col < n) {  // (col >= nF: the tiles k_gram computed)
         for (int k = 0; k < nsplit; ++k) s += Gpart[(int64_t)k * np * np + e];
-        if (row < nF) Wb[row + (int64_t)(col - nF) * ldw] = s;
+        if (row < nF) Gin[row + (int64_t)(col - nF) * ldw] = s;  // (k_wgemm's input; its output goes to Wb)
     } else if (row <= n && col == n) {
         for (int k = 0; k < nchunk; ++k) s += rhs_part[(int64_t)k * np + row];
     } else if (row == col && row > n) {
@@ -513,60 +532,55 @@ __global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ G
     if (row == col && row < n) kdnew[row] = s;
 }
 
-// W = R_F^-T G_FN, column by column: wave c solves R_F' y = g (g = column c of Wb, overwritten by y) right-looking, as
-// k_tinv_build does for the unit vectors: lane l owns the entries t = l + 64 u with a partial sum each; at step s every lane
-// adds R[s, t] y_s to its sums, the owner of t = s + 1 closes y_{s+1} and v_readlane broadcasts it.  R values D steps ahead.
-template <int NU, int D>
-__global__ __launch_bounds__(64) void k_trsm_rt(const double* __restrict__ R, int kcap, int nF, double* __restrict__ Wb, int ldw) {
-    const int lane = threadIdx.x;
-    double* g = Wb + (int64_t)blockIdx.x * ldw;
-    const double* colp[NU];
-    double acc[NU], rdg[NU], gv[NU];
-    bool own[NU];
+// W = R_F^-T G_FN = Tt G_FN as a tiled product (no chain): W[i][c] = sum_{t <= i} Tt[i, t] G[t, c], Tt = (R_F^-1)' from the
+// augmented factorisation of F (lower triangular: zeros above its diagonal).  32 x 32 output tiles (256 workgroups at n_F = n_N = 512),
+// 256 threads with 2 x 2 outputs each, K-tiles of 32 through LDS, the next K-tile's operands already on their way (registers)
+// while the current one is multiplied; K-tiles beyond the output tile's rows are skipped.
+__global__ __launch_bounds__(256) void k_wgemm(const double* __restrict__ Tt, int ldt, const double* __restrict__ Gin, int ldg, int nF, int nN,
+                                               double* __restrict__ Wb, int ldw) {
+    constexpr int TM = 32, TN = 32, TK = 32;
+    __shared__ double As[TK][TM + 1];  // As[k][i] = Tt[i0 + i, k0 + k]
+    __shared__ double Bs[TK][TN + 1];  // Bs[k][c] = Gin[k0 + k, c0 + c]
+    const int i0 = blockIdx.x * TM, c0 = blockIdx.y * TN;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // outputs rows i0 + tx, i0 + tx + 16; columns c0 + ty, c0 + ty + 16
+    const int li = threadIdx.x & 31, lk = threadIdx.x >> 5;  // loads: element li of the contiguous dimension, 4 of the 32 others (lk + 8 j)
+    double acc00 = 0.0, acc01 = 0.0, acc10 = 0.0, acc11 = 0.0;
+    const int kend = min(nF, i0 + TM);
+    double ra[4], rb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int t = lane + 64 * u;
-        own[u] = t < nF;
-        colp[u] = R + (int64_t)(own[u] ? t : 0) * kcap;
-        acc[u] = 0.0;
-        rdg[u] = own[u] ? 1.0 / colp[u][t] : 0.0;
-        gv[u] = own[u] ? g[t] : 0.0;
-    }
-    double ys = readlane_f64(gv[0] * rdg[0], 0);
-    if (lane == 0) g[0] = ys;
-    double cur[D][NU], nxt[D][NU];
-    auto fetch = [&](double (*dst)[NU], int s0) {
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int sidx = s0 + d, t = lane + 64 * u;
-                dst[d][u] = (own[u] && sidx < t) ? colp[u][sidx] : 0.0;
-            }
-    };
-    fetch(cur, 0);
-    for (int sb = 0; sb <= nF - 2; sb += D) {
-        fetch(nxt, sb + D);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int sidx = sb + d;
-            if (sidx <= nF - 2) {
-                const int nt = sidx + 1, su = nt >> 6, sl = nt & 63;
-                double mine = 0.0;
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    acc[u] = fma(cur[d][u], ys, acc[u]);
-                    if (u == su) mine = (gv[u] - acc[u]) * rdg[u];
-                }
-                ys = readlane_f64(mine, sl);
-                if (lane == sl) g[nt] = ys;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int kk = lk + 8 * j;
+            const int gi = i0 + li, gk = k0 + kk;  // Tt: contiguous along i
+            ra[j] = (gi < nF && gk < nF) ? Tt[gi + (int64_t)gk * ldt] : 0.0;
+            const int gkb = k0 + li, gc = c0 + kk;  // Gin: contiguous along t = k
+            rb[j] = (gkb < nF && gc < nN) ? Gin[gkb + (int64_t)gc * ldg] : 0.0;
         }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < kend; k0 += TK) {
 #pragma unroll
-        for (int d = 0; d < D; ++d)
-#pragma unroll
-            for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
+        for (int j = 0; j < 4; ++j) {
+            As[lk + 8 * j][li] = ra[j];
+            Bs[li][lk + 8 * j] = rb[j];
+        }
+        __syncthreads();
+        if (k0 + TK < kend) fetch(k0 + TK);
+#pragma unroll 8
+        for (int k = 0; k < TK; ++k) {
+            const double a0 = As[k][tx], a1 = As[k][tx + 16], b0 = Bs[k][ty], b1 = Bs[k][ty + 16];
+            acc00 = fma(a0, b0, acc00);
+            acc01 = fma(a0, b1, acc01);
+            acc10 = fma(a1, b0, acc10);
+            acc11 = fma(a1, b1, acc11);
+        }
+        __syncthreads();
     }
+    const int gi0 = i0 + tx, gi1 = i0 + tx + 16, gc0 = c0 + ty, gc1 = c0 + ty + 16;
+    if (gi0 < nF && gc0 < nN) Wb[gi0 + (int64_t)gc0 * ldw] = acc00;
+    if (gi0 < nF && gc1 < nN) Wb[gi0 + (int64_t)gc1 * ldw] = acc01;
+    if (gi1 < nF && gc0 < nN) Wb[gi1 + (int64_t)gc0 * ldw] = acc10;
+    if (gi1 < nF && gc1 < nN) Wb[gi1 + (int64_t)gc1 * ldw] = acc11;
 }
 
 // The Schur complement, bordered: G2 (np2 x np2, the layout k_chol_* expects) = [G_NN c_N; . .] - sum of k_gram<double>'s

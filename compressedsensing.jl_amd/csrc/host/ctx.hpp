@@ -55,7 +55,10 @@ struct Solver {
     double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
     int* kpos = nullptr;
     // bordered extension (ls_gram_extend_t): the second kept matrix (ping-pong), W's workspace, and the set whose factor the slot holds
-    double *Gkeep2 = nullptr, *gdkeep2 = nullptr, *Wb = nullptr;
+    double *Gkeep2 = nullptr, *gdkeep2 = nullptr, *Wb = nullptr, *Gin = nullptr;
+    int64_t fac_gen = 0, tt_gen = -1;  // (R^-1)' of the factor confirmed as number tt_gen sits in Gm's augmented columns:
+    int tt_col0 = 0, tt_ld = 0;        //   Gm + tt_col0 * tt_ld, leading dimension tt_ld
+    bool tt_pending = false;
     std::vector<int> fac_cols, fac_pending;  // factor order of the last CONFIRMED whole-set solve / of the one in flight
     bool fac_valid = false;                  // R, z, sel hold fac_cols' factor on the current b (dropped by anything that rewrites them)
     std::vector<int> keep_cols;

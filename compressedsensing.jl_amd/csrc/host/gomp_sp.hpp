@@ -360,7 +360,7 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
     dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
-    dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb);
+    dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
     s.fac_valid = false;
@@ -368,7 +368,8 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     CHECK(dmalloc(ctx, &s.gdkeep, (size_t)np));
     CHECK(dmalloc(ctx, &s.Gkeep2, (size_t)np * np));  // the bordered extension assembles the next kept matrix beside the current one
     CHECK(dmalloc(ctx, &s.gdkeep2, (size_t)np));
-    CHECK(dmalloc(ctx, &s.Wb, (size_t)np * np));      // [G_FN | z_F] -> W = R_F^-T G_FN (k_trsm_rt)
+    CHECK(dmalloc(ctx, &s.Wb, (size_t)np * np));      // W = R_F^-T G_FN bordered by z_F
+    CHECK(dmalloc(ctx, &s.Gin, (size_t)np * np));     // G_FN (k_wgemm's input)
     CHECK(dmalloc(ctx, &s.kpos, (size_t)np));
     CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
     CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
@@ -421,11 +422,12 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     const int64_t nel = std::max<int64_t>((int64_t)np * np, (int64_t)ldw * np2);
     hipLaunchKernelGGL(k_ext_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, nF, n, np,
                        (const double*)s.rhs_part, nchunk, (const double*)s.Gkeep, s.keep_np, (const int*)s.kpos, (const double*)s.z, s.Gkeep2, s.gdkeep2,
-                       s.Wb, ldw, np2);
+                       s.Wb, ldw, np2, s.Gin);
     HIPCHECK(hipGetLastError());
-    if (nF <= 256) hipLaunchKernelGGL((k_trsm_rt<4, 4>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
-    else if (nF <= 512) hipLaunchKernelGGL((k_trsm_rt<8, 4>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
-    else hipLaunchKernelGGL((k_trsm_rt<16, 2>), dim3(nN), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap, nF, s.Wb, ldw);
+    // W = R_F^-T G_FN = Tt G_FN: a tiled product, no dependent chain; Tt = (R_F^-1)' sits in the augmented columns of F's own
+    // factorisation (s.Gm: k_schur_reduce below overwrites it AFTER this product, in stream order)
+    hipLaunchKernelGGL(k_wgemm, dim3((nF + 31) / 32, (nN + 31) / 32), dim3(256), 0, ctx->stream, (const double*)(s.Gm + (size_t)s.tt_col0 * s.tt_ld), s.tt_ld,
+                       (const double*)s.Gin, ldw, nF, nN, s.Wb, ldw);
     HIPCHECK(hipGetLastError());
     // [W z_F]'[W z_F] on the Float64 matrix cores: the columns of Wb are the "dictionary" (ldw rows), a few row slices
     const int nsplit2 = std::max(1, std::min(std::min(nsplit, 8), ldw / 64));
@@ -449,12 +451,13 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
         const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
         const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
         hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np2, nN, kb, (const double*)s.gdiag, s.st,
-                           nrow, s.Dfac);
+                           nrow, s.Dfac, np2);
     }
     HIPCHECK(hipGetLastError());
     hipLaunchKernelGGL(k_gram_export_b, dim3((unsigned)(((int64_t)n * nN + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np2, nF, nN,
                        (const int*)s.cands, (const double*)s.Wb, ldw, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
     HIPCHECK(hipGetLastError());
+    s.tt_pending = false;
     std::swap(s.Gkeep, s.Gkeep2);
     std::swap(s.gdkeep, s.gdkeep2);
     s.keep_cols = order;
@@ -478,7 +481,11 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     const int n = (int)cols.size(), M = (int)ctx->M;
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int nsplit = gram_split_for(ctx, np);
-    CHECK(gram_ensure(ctx, np, nsplit));  // (a reallocation drops fac_valid and keep_valid)
+    // A set that k further columns may extend (Subspace Pursuit: the k atoms of the support before an acquisition) is factorised
+    // AUGMENTED by the unit vectors (csmp_gram.hpp, k_gram_reduce): (R^-1)' comes out beside R, for free on this chain.
+    const bool aug = n >= 64 && 2 * n <= s.kcap;
+    const int npa = aug ? ((np + n + kGramTile - 1) / kGramTile) * kGramTile : np;
+    CHECK(gram_ensure(ctx, npa, nsplit));  // (a reallocation drops fac_valid and keep_valid)
     const bool can_extend = s.fac_valid;
     s.fac_valid = false;  // whatever happens below rewrites the slot; the caller confirms the new factor once it has seen it succeed
     s.fac_pending.assign(cols.begin(), cols.end());  // the factor order of this solve
@@ -486,7 +493,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         // The slot still holds the factor of a set F on this very b.  If F lies inside `cols` (and its Gram matrix inside the kept
         // one), only the new columns are factorised (ls_gram_extend_t).
         const int nF = (int)s.fac_cols.size();
-        if (nF >= 64 && nF < n && s.keep_valid && n <= s.kcap) {
+        if (nF >= 64 && nF < n && s.keep_valid && n <= s.kcap && s.tt_gen == s.fac_gen) {  // (tt_gen: (R_F^-1)' sits in s.Gm)
             std::vector<std::pair<int, int>> where((size_t)s.keep_n);
             for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
             std::sort(where.begin(), where.end());
@@ -535,9 +542,9 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     }
     if (subset) {
         HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-        const int64_t nel = (int64_t)np * np;
+        const int64_t nel = (int64_t)np * np + (int64_t)(npa - np) * npa;
         hipLaunchKernelGGL(k_gram_subset, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep, s.keep_np, s.keep_n,
-                           (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag);
+                           (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag, npa);
         HIPCHECK(hipGetLastError());
     } else {
         const int blk = 16;
@@ -549,9 +556,9 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
                            rps, s.Gpart);
         HIPCHECK(hipGetLastError());
-        const int64_t nel = (int64_t)np * np;
+        const int64_t nel = (int64_t)np * np + (int64_t)(npa - np) * npa;
         hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
-                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk, s.Gkeep, s.gdkeep);
+                           s.Gm, s.gdiag, (const double*)s.rhs_part, nchunk, s.Gkeep, s.gdkeep, npa);
         HIPCHECK(hipGetLastError());
         s.keep_cols.assign(cols.begin(), cols.end());
         s.keep_n = n;
@@ -560,25 +567,29 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     }
     // Block rows 0 .. ceil(n / 32) - 1 are all that is needed: the bordered column n is a column of their row panels (or of
     // the last diagonal block when n is not a multiple of 32); the corner b'b - z'z and the identity padding are never read.
+    // (augmented: the row panels run on to column npa; trailing tiles whose ROWS lie in the augmented range are skipped)
     const int nsteps = (n + kCholNB - 1) / kCholNB;
     {
-        const int left0 = np - kCholNB;
-        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n,
+        const int left0 = npa - kCholNB;
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, npa, n,
                            0, (const double*)s.gdiag, s.st, s.Dfac);
     }
     for (int kb = 0; kb + 1 < nsteps; ++kb) {  // one launch per step: trailing update of panel kb + block row kb + 1
-        const int left = np - (kb + 1) * kCholNB;   // columns from the next block row on
+        const int left = npa - (kb + 1) * kCholNB;  // columns from the next block row on
         const int left2 = left - kCholNB;           // columns to the right of the next diagonal block
         const int Tt = (left + kGramTile - 1) / kGramTile;
         const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
         const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
-        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np, n, kb, (const double*)s.gdiag, s.st,
-                           nrow, s.Dfac);
+        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, npa, n, kb, (const double*)s.gdiag, s.st,
+                           nrow, s.Dfac, np);
     }
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np, n,
+    hipLaunchKernelGGL(k_gram_export, dim3((unsigned)(((int64_t)n * n + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, npa, n,
                        (const int*)s.cands, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
     HIPCHECK(hipGetLastError());
+    s.tt_pending = aug;  // (confirmed with the factor: ls_fetch)
+    s.tt_col0 = np;
+    s.tt_ld = npa;
     s.jh = std::min(s.kcap, n);
     CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
     const int nch = (n + kResChunk - 1) / kResChunk;
@@ -681,6 +692,8 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
         if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
             s.fac_cols.swap(s.fac_pending);  // the slot now holds this set's factor (R, z, sel) on the current b: a later superset extends it
             s.fac_valid = true;
+            s.fac_gen += 1;
+            if (s.tt_pending) s.tt_gen = s.fac_gen;
             idx.assign(pi, pi + n);
             val.assign(pvv, pvv + n);
             if (resnorm) {

@@ -77,7 +77,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s = Solver();
 }
 
