@@ -123,7 +123,24 @@ struct DictShare {
     int refs;
 };
 
+struct csmp_ctx;
+// Subspace Pursuit as a resumable job: see host/gomp_sp.hpp
+struct SpJob {
+    csmp_ctx* c = nullptr;
+    int64_t k = 0, maxiter = 0, it = 0;
+    double delta = 0.0, resnorm = 0.0, oldnorm = 0.0;
+    std::vector<int64_t> xi;  // the support (sorted) and its coefficients
+    std::vector<double> xv;
+    std::vector<int> cols;    // the set whose least squares is in flight
+    enum Phase { IDLE, SELECT, LS_FIRST, LS_UNION, LS_PRUNED, DONE } phase = IDLE;
+    bool screened = false, sel_screened = false, want_norm = false, gram_inflight = false;
+    hipEvent_t ev = nullptr;
+    int rc = CSMP_OK;
+};
+
+
 struct csmp_ctx {
+    SpJob spjob;  // the Subspace Pursuit solve this context is carrying (csmp_sp, csmp_sp_batch)
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;

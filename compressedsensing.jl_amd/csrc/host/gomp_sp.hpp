@@ -667,15 +667,49 @@ static int fetch_sorted(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<do
     return CSMP_OK;
 }
 
-// Least squares on `cols` + the sorted solution on the host (+ ||r|| when asked) in ONE synchronisation.  Large sets go
-// through the whole-set path (csmp_gram.hpp); if their DGKS test fails, or for small sets, the append chain does it.
-static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm) {
+// ---- Subspace Pursuit as a RESUMABLE job (src/twostage.jl:54-101).
+// One sp is a chain of device phases separated by host decisions on a few hundred numbers: which atoms join (the union with the
+// support), which leave (the prune by |coefficient|), whether to go on (the residual norms).  A job ENQUEUES a phase -- kernels,
+// the copies of what the host has to look at into the context's page-locked landing area, an event -- and RESUMES once the event
+// has fired.  csmp_sp drives one job with blocking waits; csmp_sp_batch drives several, each on a context (stream) of its own,
+// from the CALLING thread: a job whose event has not fired yet is skipped and another one advanced -- no threads inside the
+// library, nothing of one signal waits on the host work of another.
+// sp_acquisition!(P, x, k), first half (src/twostage.jl:67-69): sweep on the current residual + the k best atoms, on their way to
+// the host.  CSMP_OPT_SCREENED_SWEEP: the sweep reads the image and the top-k SET is certified (host/screened.hpp).
+static int sp_job_select(SpJob& j, bool scr) {
+    csmp_ctx* ctx = j.c;
+    j.sel_screened = scr;
     Solver& s = ctx->s;
-    if (gram_applicable(ctx, cols.size())) {
-        CHECK(ls_gram(ctx, cols));
-        const size_t n = cols.size();
-        const size_t nshare = (size_t)(ctx->M + 255) / 256;  // |r|^2 comes back as the residual kernel's per-workgroup shares
-        // one page-locked landing area for everything that comes back: [idx n | val n | control block | shares of ||r||^2]
+    const int k = (int)j.k;
+    void* pv = nullptr;
+    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the small copies do not block the host one by one)
+    int* top = (int*)pv;
+    int* pnt = top + k;
+    pnt[1] = 0;
+    if (scr) {
+        CHECK(sp_select_screened(ctx, k));
+        HIPCHECK(hipMemcpyAsync(pnt + 1, s.scr_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    } else {
+        CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+        CHECK(launch_topS(ctx, k));
+    }
+    HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipEventRecord(j.ev, ctx->stream));
+    return CSMP_OK;
+}
+
+// Least squares on j.cols, first half: the whole-set path enqueued with everything the host needs afterwards ([idx | val | control
+// block | shares of ||r||^2] into ONE landing area); small or coherent sets take the append chain, synchronously (rare here).
+static int sp_job_ls(SpJob& j, bool want_norm) {
+    csmp_ctx* ctx = j.c;
+    Solver& s = ctx->s;
+    j.want_norm = want_norm;
+    j.gram_inflight = gram_applicable(ctx, j.cols.size());
+    if (j.gram_inflight) {
+        CHECK(ls_gram(ctx, j.cols));
+        const size_t n = j.cols.size();
+        const size_t nshare = (size_t)(ctx->M + 255) / 256;
         const size_t need = n * 16 + sizeof(DevState) + 16 + nshare * 8;
         void* pv = nullptr;
         CHECK(pin_get(ctx, 1, need, &pv));
@@ -686,66 +720,135 @@ static int ls_fetch(csmp_ctx* ctx, const std::vector<int>& cols, std::vector<int
         HIPCHECK(hipMemcpyAsync(pi, s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipMemcpyAsync(pvv, s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipMemcpyAsync(phs, s.st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
-        if (resnorm) HIPCHECK(hipMemcpyAsync(pn2, s.rn2part, nshare * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (want_norm) HIPCHECK(hipMemcpyAsync(pn2, s.rn2part, nshare * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHECK(hipEventRecord(j.ev, ctx->stream));
+    return CSMP_OK;
+}
+// ... second half: the solution (sorted) into the job, ||r|| when asked; a set the whole-set path refused goes through the chain
+static int sp_job_ls_done(SpJob& j) {
+    csmp_ctx* ctx = j.c;
+    Solver& s = ctx->s;
+    if (j.gram_inflight) {
+        const size_t n = j.cols.size();
+        const size_t nshare = (size_t)(ctx->M + 255) / 256;
+        int64_t* pi = (int64_t*)ctx->pin[1];
+        double* pvv = (double*)(pi + n);
+        DevState* phs = (DevState*)(pvv + n);
+        double* pn2 = (double*)((char*)phs + ((sizeof(DevState) + 7) / 8) * 8);
         const DevState hs = *phs;
         if (!(hs.done & STOP_REORTH) && hs.nsel == (int)n) {
             s.fac_cols.swap(s.fac_pending);  // the slot now holds this set's factor (R, z, sel) on the current b: a later superset extends it
             s.fac_valid = true;
             s.fac_gen += 1;
             if (s.tt_pending) s.tt_gen = s.fac_gen;
-            idx.assign(pi, pi + n);
-            val.assign(pvv, pvv + n);
-            if (resnorm) {
+            j.xi.assign(pi, pi + n);
+            j.xv.assign(pvv, pvv + n);
+            if (j.want_norm) {
                 double n2 = 0.0;
                 for (size_t q = 0; q < nshare; ++q) n2 += pn2[q];
-                *resnorm = std::sqrt(n2);
+                j.resnorm = std::sqrt(n2);
             }
             return CSMP_OK;
         }
     }
-    CHECK(ls_on_columns(ctx, cols));
-    CHECK(fetch_sorted(ctx, idx, val));
-    if (resnorm) CHECK(residual_norm(ctx, resnorm));
+    CHECK(ls_on_columns(ctx, j.cols));
+    CHECK(fetch_sorted(ctx, j.xi, j.xv));
+    if (j.want_norm) CHECK(residual_norm(ctx, &j.resnorm));
     return CSMP_OK;
 }
 
-// sp_acquisition!(P, x, k): src/twostage.jl:67-72 -- sweep on the current residual, union the k best
-// atoms into the support, least squares on the union
-static int sp_acquire(csmp_ctx* ctx, int k, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
-    Solver& s = ctx->s;
-    void* pv = nullptr;
-    CHECK(pin_get(ctx, 1, (size_t)k * 4 + 16, &pv));  // (page-locked: the small copies do not block the host one by one)
-    int* top = (int*)pv;
-    int* pnt = top + k;
-    pnt[1] = 0;
-    // CSMP_OPT_SCREENED_SWEEP: the sweep reads the image and the top-k SET is certified (host/screened.hpp); an acquisition
-    // that could not be certified is repeated with the exact sweep right here
-    bool screened = screened_on(ctx) && k <= 4096;
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (screened) {
-            CHECK(sp_select_screened(ctx, k));
-            HIPCHECK(hipMemcpyAsync(pnt + 1, s.scr_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        } else {
-            CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-            CHECK(launch_topS(ctx, k));
-        }
-        HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (!screened) break;
+// the selection has arrived: an uncertified screened acquisition is repeated with the exact sweep; else @. x[i] = NaN (:70) --
+// the union with the support -- and solve! (:71) goes out
+static int sp_job_selected(SpJob& j, SpJob::Phase next) {
+    csmp_ctx* ctx = j.c;
+    const int k = (int)j.k;
+    const int* top = (const int*)ctx->pin[1];
+    const int* pnt = top + k;
+    if (j.sel_screened) {
         ctx->scr_solves += 1;
-        if (pnt[1] == 0) break;
-        ctx->scr_fallbacks += 1;
-        screened = false;
+        if (pnt[1] != 0) {
+            ctx->scr_fallbacks += 1;
+            return sp_job_select(j, false);  // (the same phase again, with the exact sweep -- this acquisition only)
+        }
     }
     const int nt = *pnt;
-    std::vector<int> cols;
-    for (auto i : idx) cols.push_back((int)i);
-    for (int t = 0; t < nt; ++t) cols.push_back(top[t]);  // @. x[i] = NaN (:70)
-    std::sort(cols.begin(), cols.end());
-    cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-    return ls_fetch(ctx, cols, idx, val, resnorm);  // solve! (:71)
+    j.cols.clear();
+    for (auto i : j.xi) j.cols.push_back((int)i);
+    for (int t = 0; t < nt; ++t) j.cols.push_back(top[t]);
+    std::sort(j.cols.begin(), j.cols.end());
+    j.cols.erase(std::unique(j.cols.begin(), j.cols.end()), j.cols.end());
+    j.phase = next;
+    return sp_job_ls(j, next == SpJob::LS_FIRST);
+}
+
+static int sp_job_begin(SpJob& j, csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter) {
+    j.c = ctx;
+    j.k = k;
+    j.delta = delta;
+    j.maxiter = maxiter < 0 ? 16 * k : maxiter;  // :87
+    j.it = 0;
+    j.xi.clear();
+    j.xv.clear();
+    j.rc = CSMP_OK;
+    if (!j.ev) HIPCHECK(hipEventCreateWithFlags(&j.ev, hipEventDisableTiming));
+    HIPCHECK(hipSetDevice(ctx->dev));
+    CHECK(solver_ensure(ctx, (int)(2 * k), (int)(2 * k)));
+    ctx->s.begun = false;
+    j.screened = screened_on(ctx) && k <= 4096;
+    if (j.screened) CHECK(screened_ensure(ctx));
+    CHECK(upload_b(ctx, b, b_dtype));
+    j.phase = SpJob::SELECT;
+    j.oldnorm = -1.0;  // (marks the first acquisition: :90-91)
+    return sp_job_select(j, j.screened);
+}
+
+// the pending phase's event has fired: take its results, enqueue the next phase (or finish)
+static int sp_job_advance(SpJob& j) {
+    switch (j.phase) {
+        case SpJob::SELECT:
+            return sp_job_selected(j, j.oldnorm < 0.0 ? SpJob::LS_FIRST : SpJob::LS_UNION);
+        case SpJob::LS_FIRST:  // :90-91 done; the loop starts (:92)
+            CHECK(sp_job_ls_done(j));
+            if (j.it >= j.maxiter) {
+                j.phase = SpJob::DONE;
+                return CSMP_OK;
+            }
+            j.oldnorm = j.resnorm;
+            j.phase = SpJob::SELECT;
+            return sp_job_select(j, j.screened);  // update!(P::SP, x): :75-83, acquisition :77
+        case SpJob::LS_UNION: {
+            CHECK(sp_job_ls_done(j));
+            const int64_t drop = (int64_t)j.xi.size() - j.k;
+            if (drop > 0) {  // :78-81: delete the (nnz-k) smallest |coef|, ties by position
+                std::vector<int> pos(j.xi.size());
+                for (size_t t = 0; t < pos.size(); ++t) pos[t] = (int)t;
+                std::stable_sort(pos.begin(), pos.end(), [&](int a, int c) { return std::fabs(j.xv[a]) < std::fabs(j.xv[c]); });
+                std::vector<char> kill(j.xi.size(), 0);
+                for (int64_t t = 0; t < drop; ++t) kill[pos[t]] = 1;
+                std::vector<int64_t> keep;
+                for (size_t t = 0; t < j.xi.size(); ++t)
+                    if (!kill[t]) keep.push_back(j.xi[t]);
+                j.xi.swap(keep);
+            }
+            j.cols.clear();
+            for (auto i : j.xi) j.cols.push_back((int)i);
+            j.phase = SpJob::LS_PRUNED;
+            return sp_job_ls(j, true);  // :82, :95
+        }
+        case SpJob::LS_PRUNED:
+            CHECK(sp_job_ls_done(j));
+            ++j.it;
+            if (j.resnorm <= j.delta || j.oldnorm <= j.resnorm || j.it >= j.maxiter) {  // :96, :92
+                j.phase = SpJob::DONE;
+                return CSMP_OK;
+            }
+            j.oldnorm = j.resnorm;
+            j.phase = SpJob::SELECT;
+            return sp_job_select(j, j.screened);
+        default:
+            return CSMP_OK;
+    }
 }
 
 extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
@@ -755,52 +858,27 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
     if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
-    if (maxiter < 0) maxiter = 16 * k;  // :87
-    HIPCHECK(hipSetDevice(ctx->dev));
-    CHECK(solver_ensure(ctx, (int)(2 * k), (int)(2 * k)));
-    ctx->s.begun = false;
-    if (screened_on(ctx)) CHECK(screened_ensure(ctx));
-    CHECK(upload_b(ctx, b, b_dtype));
-    std::vector<int64_t> xi;
-    std::vector<double> xv;
-    double resnorm = 0.0;
-    CHECK(sp_acquire(ctx, (int)k, xi, xv, &resnorm));  // :90-91
-    int64_t it = 0;
-    while (it < maxiter) {                   // :92
-        const double oldnorm = resnorm;
-        // update!(P::SP, x): :75-83
-        CHECK(sp_acquire(ctx, (int)k, xi, xv));  // :77
-        const int64_t drop = (int64_t)xi.size() - k;
-        if (drop > 0) {  // :78-81: delete the (nnz-k) smallest |coef|, ties by position
-            std::vector<int> pos(xi.size());
-            for (size_t t = 0; t < pos.size(); ++t) pos[t] = (int)t;
-            std::stable_sort(pos.begin(), pos.end(), [&](int a, int c) { return std::fabs(xv[a]) < std::fabs(xv[c]); });
-            std::vector<char> kill(xi.size(), 0);
-            for (int64_t t = 0; t < drop; ++t) kill[pos[t]] = 1;
-            std::vector<int64_t> keep;
-            for (size_t t = 0; t < xi.size(); ++t)
-                if (!kill[t]) keep.push_back(xi[t]);
-            xi.swap(keep);
-        }
-        std::vector<int> cols;
-        for (auto i : xi) cols.push_back((int)i);
-        CHECK(ls_fetch(ctx, cols, xi, xv, &resnorm));       // :82, :95
-        ++it;
-        if (resnorm <= delta || oldnorm <= resnorm) break;   // :96
+    SpJob& j = ctx->spjob;
+    int rc = sp_job_begin(j, ctx, b, b_dtype, k, delta, maxiter);
+    while (rc == CSMP_OK && j.phase != SpJob::DONE) {
+        HIPCHECK(hipEventSynchronize(j.ev));
+        rc = sp_job_advance(j);
     }
-    for (size_t t = 0; t < xi.size(); ++t) {
-        if (idx) idx[t] = xi[t];
-        if (val) val[t] = xv[t];
+    if (rc != CSMP_OK) return rc;
+    for (size_t t = 0; t < j.xi.size(); ++t) {
+        if (idx) idx[t] = j.xi[t];
+        if (val) val[t] = j.xv[t];
     }
-    if (nnz) *nnz = (int64_t)xi.size();
-    if (iters) *iters = it;
+    if (nnz) *nnz = (int64_t)j.xi.size();
+    if (iters) *iters = j.it;
     return CSMP_OK;
 }
 
-// sp for many signals: up to four solves in flight, each on a context (this one + clones on their own streams) driven by its own
-// host thread.  A Subspace Pursuit solve is two HBM-bound sweeps and a long chain of short kernels with five host round trips
-// (factorisations, selections, the pruning decision): one solve leaves most of the chip idle most of the time, and another
-// signal's solve fills it.  Signal s is solved by context s mod T with the single-signal driver itself: results are csmp_sp's.
+// sp for many signals: up to four solves in flight, each on a context of its own (this one + clones on their own streams), all
+// driven by the CALLING thread: it advances whichever job's pending phase has finished (hipEventQuery) and never blocks on one
+// while another could move.  A Subspace Pursuit solve is two HBM-bound sweeps and a chain of short kernels with five host decisions:
+// one solve leaves most of the chip idle most of the time, and another signal's solve fills it.  Signal s is solved by the very
+// job csmp_sp runs: results are csmp_sp's.
 extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int64_t k, double delta, int64_t maxiter,
                              int64_t* idx, double* val, int64_t* nnz, int64_t* iters) {
     if (!ctx) return CSMP_EINVAL;
@@ -820,38 +898,53 @@ extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t 
         for (int t = 1; t < T; ++t) CHECK(screened_ensure_pair(ctx, cc[t]));
     }
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
-    int rcs[4] = {CSMP_OK, CSMP_OK, CSMP_OK, CSMP_OK};
-    auto work = [&](int t) {
-        std::vector<int64_t> ti((size_t)2 * k);
-        std::vector<double> tv((size_t)2 * k);
-        for (int64_t sgn = t; sgn < nsig && rcs[t] == CSMP_OK; sgn += T) {
-            int64_t n = 0, it = 0;
-            const char* col = (const char*)B + (size_t)sgn * (size_t)ldB * es;
-            rcs[t] = csmp_sp(cc[t], col, b_dtype, k, delta, maxiter, ti.data(), tv.data(), &n, &it);
-            if (rcs[t] != CSMP_OK) break;
+    int64_t sig_of[4] = {-1, -1, -1, -1}, next = 0, finished = 0;
+    int rc = CSMP_OK;
+    auto start = [&](int t) -> int {
+        sig_of[t] = next++;
+        return sp_job_begin(cc[t]->spjob, cc[t], (const char*)B + (size_t)sig_of[t] * (size_t)ldB * es, b_dtype, k, delta, maxiter);
+    };
+    for (int t = 0; t < T && rc == CSMP_OK; ++t) rc = start(t);
+    int spins = 0;
+    while (rc == CSMP_OK && finished < nsig) {
+        bool moved = false;
+        for (int t = 0; t < T && rc == CSMP_OK; ++t) {
+            if (sig_of[t] < 0) continue;
+            SpJob& j = cc[t]->spjob;
+            if (j.phase != SpJob::DONE) {
+                const hipError_t q = hipEventQuery(j.ev);
+                if (q == hipErrorNotReady) continue;
+                if (q != hipSuccess) { rc = fail(ctx, CSMP_EHIP, hipGetErrorString(q)); break; }
+                HIPCHECK(hipSetDevice(ctx->dev));
+                rc = sp_job_advance(j);
+                moved = true;
+                if (rc != CSMP_OK || j.phase != SpJob::DONE) continue;
+            }
+            const int64_t sgn = sig_of[t], n = (int64_t)j.xi.size();
             for (int64_t q = 0; q < k; ++q) {
-                idx[sgn * k + q] = q < n ? ti[q] : -1;
-                val[sgn * k + q] = q < n ? tv[q] : 0.0;
+                idx[sgn * k + q] = q < n ? j.xi[q] : -1;
+                val[sgn * k + q] = q < n ? j.xv[q] : 0.0;
             }
             nnz[sgn] = std::min<int64_t>(n, k);
-            if (iters) iters[sgn] = it;
+            if (iters) iters[sgn] = j.it;
+            ++finished;
+            moved = true;
+            sig_of[t] = -1;
+            if (next < nsig) rc = start(t);
         }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto& x : th) x.join();
+        if (!moved && ++spins > 64) {  // nothing to do right now: let the GPU work (the wait is microseconds)
+            std::this_thread::yield();
+            spins = 0;
+        }
+    }
+    for (int t = 0; t < T; ++t) (void)hipStreamSynchronize(cc[t]->stream);
     for (int t = 1; t < T; ++t) {  // (the twins' screened-selection counters belong to this context's statistics)
         ctx->scr_solves += cc[t]->scr_solves;
         ctx->scr_fallbacks += cc[t]->scr_fallbacks;
         cc[t]->scr_solves = cc[t]->scr_fallbacks = 0;
+        if (rc != CSMP_OK && cc[t]->err.size() && ctx->err.empty()) ctx->err = cc[t]->err;
     }
-    for (int t = 0; t < T; ++t)
-        if (rcs[t] != CSMP_OK) {
-            if (t) ctx->err = cc[t]->err;
-            return rcs[t];
-        }
-    return CSMP_OK;
+    return rc;
 }
 
 // ------------------------------------------------------------------------------------------ primitives
