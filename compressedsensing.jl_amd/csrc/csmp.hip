@@ -22,7 +22,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
-#include <thread>
+#include <thread>  // (std::this_thread::yield in csmp_sp_batch's polling loop; the library starts no threads)
 #include <vector>
 
 using namespace csmp;

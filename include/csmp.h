@@ -178,10 +178,11 @@ int csmp_gomp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int6
 
 /* sp(A, B[:,s], k, delta; maxiter) for s = 0..nsig-1 (src/twostage.jl:87-101 in the caller's loop).  B: HOST matrix M x nsig
  * (ldB elements); idx / val: k x nsig host arrays (tail -1 / 0), nnz and iters (may be NULL): nsig.  Up to
- * CSMP_OPT_SOLVES_IN_FLIGHT solves run at once, each on its own context (this one and internal clones), stream and host
- * thread: a Subspace Pursuit solve is two dictionary sweeps and a long chain of short kernels with host round trips, and
- * another signal's solve fills the GPU it leaves idle.  Signal s is solved by csmp_sp itself: identical results.
- * The only entry point that starts threads; the ctx must not be used by the caller while it runs. */
+ * CSMP_OPT_SOLVES_IN_FLIGHT solves run at once, each on its own context (this one and internal clones) and stream, all driven by
+ * the CALLING thread: a Subspace Pursuit solve is two dictionary sweeps and a chain of short kernels with a handful of host
+ * decisions (which atoms join, which leave, whether to go on); a solve whose pending device phase has not finished is skipped and
+ * another one advanced, so one signal's chain runs under another's sweeps.  Signal s is solved by the very job csmp_sp runs:
+ * identical results.  No threads are started; the ctx must not be used by another thread while the call runs. */
 int csmp_sp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int64_t k, double delta, int64_t maxiter,
                   int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
 
@@ -227,7 +228,7 @@ const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
                                       instead of streaming the support's columns: half the append traffic.  0 (default) frees it */
 #define CSMP_OPT_BATCH_WINDOW 3    /* capacity of the rescoring window, 1..128; 0 (default) = 64 statistical / 128 rigorous */
 #define CSMP_OPT_PIPELINE 4        /* csmp_omp_batch / csmp_fr_batch: 1 (default) three signals in flight, 0 one at a time */
-#define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams and host threads), 1..4, default 3 */
+#define CSMP_OPT_SOLVES_IN_FLIGHT 9 /* csmp_sp_batch: solves in flight (contexts on their own streams, one host thread), 1..4, default 3 */
 #define CSMP_OPT_SCREENED_SWEEP 10 /* csmp_mp, csmp_omp(_batch), csmp_gomp(_batch) (l <= 16), csmp_sp(_batch) and csmp_ompr (k <= 4096): 0 (default) every sweep
                                       reads the f32/f64 dictionary (exact, 4 / 8 bytes per element).  1 / 3 / 2: the sweep reads an IMAGE of the
                                       dictionary and only SCREENS -- the best candidates are rescored in Float64 from the master dictionary under the
