@@ -321,7 +321,7 @@ class Context:
         return idx[:n].copy(), val[:n].copy(), iters.value
 
     def _stepwise_cap(self, kmax):
-        lim = min(self.M, self.N, 1023)
+        lim = min(self.M, self.N, 4095)
         return lim if kmax is None or kmax <= 0 else min(int(kmax), lim)
 
     def rmp(self, b, delta_or_k, maxiter=1, kmax=None):

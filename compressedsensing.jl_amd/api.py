@@ -207,7 +207,7 @@ def srr(A, b, k, delta=1e-12, maxiter=None, initialization=1, l=1, rng=None, ini
 
 def rmp(A, b, delta_or_k, maxiter=1, kmax=None):
     """rmp(A, b, δ, maxiter=1) -- δ a float -- and rmp(A, b, k) -- k an int: relevance matching pursuit,
-    src/stepwise.jl:5-43 (x empty).  kmax bounds the support of the forward stage (default min(M, N, 1023))."""
+    src/stepwise.jl:5-43 (x empty).  kmax bounds the support of the forward stage (default min(M, N, 4095))."""
     D, tmp = _dict(A)
     try:
         idx, val = D.ctx.rmp(b, delta_or_k, maxiter, kmax)

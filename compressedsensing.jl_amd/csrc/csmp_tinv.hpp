@@ -25,7 +25,7 @@
 namespace csmp {
 
 constexpr int kTChunk = 32;  // columns per partial dot product
-constexpr int kTMaxCols = 1023;
+constexpr int kTMaxCols = 4095;  // k_tinv_build_big<64>: 64 entries per lane; k_tdel_prep<4>: four columns per thread
 
 // tmeta[0] = number of columns T currently holds
 
@@ -83,6 +83,46 @@ __global__ __launch_bounds__(64) void k_tinv_build(const double* __restrict__ R,
         for (int d = 0; d < D; ++d)
 #pragma unroll
             for (int u = 0; u < NU; ++u) cur[d][u] = nxt[d][u];
+    }
+}
+
+// The same for supports beyond 1024 columns (NU = 32: up to 2049, 64: up to 4097): column pointers are formed on the fly and the
+// closing division takes the diagonal entry by a wave-uniform load, so that a lane's state is its NU partial sums and one row of
+// prefetched entries -- no second and third per-lane array (they would not fit the register file).  Run once per solve.
+template <int NU>
+__global__ __launch_bounds__(64) void k_tinv_build_big(const double* __restrict__ R, int kcap, const DevState* st,
+                                                       double* __restrict__ T, int* __restrict__ tmeta) {
+    const int n = st->nsel, p = blockIdx.x, lane = threadIdx.x;
+    if (p == 0 && lane == 0) tmeta[0] = n;
+    if (p >= n) return;
+    double acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = 0.0;
+    double yt = 1.0 / R[(int64_t)p * kcap + p];
+    if (lane == 0) T[(int64_t)p * kcap + p] = yt;
+    double cur[NU], nxt[NU];
+    auto fetch = [&](double* dst, int t) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int i = p + 1 + lane + 64 * u;
+            dst[u] = (i < n && t < i) ? R[(int64_t)i * kcap + t] : 0.0;
+        }
+    };
+    fetch(cur, p);
+    for (int t = p; t <= n - 2; ++t) {
+        fetch(nxt, t + 1);
+        const int rel = t - p, su = rel >> 6, sl = rel & 63;
+        const double rd = 1.0 / R[(int64_t)(t + 1) * kcap + (t + 1)];  // (uniform)
+        double mine = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            acc[u] = fma(cur[u], yt, acc[u]);
+            if (u == su) mine = -acc[u] * rd;
+        }
+        yt = readlane_f64(mine, sl);
+        if (lane == sl) T[(int64_t)(t + 1) * kcap + p] = yt;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) cur[u] = nxt[u];
     }
 }
 
@@ -185,9 +225,11 @@ __global__ __launch_bounds__(256) void k_emit_sorted(const double* __restrict__ 
     if (tid == 0) *out_nnz = j;
 }
 
-// Removal, step 1 (one workgroup of 1024 threads, thread c <-> column c): the rotations from row p of T.
+// Removal, step 1 (one workgroup of 1024 threads; thread c <-> the CPT consecutive columns c CPT .. c CPT + CPT - 1, CPT = 1 up to
+// 1024 columns, 4 up to 4096): the rotations from row p of T.
 // G[2i], G[2i+1] = (cs_i, sn_i), i = p..n-2; scal[0] = zeta = u'z / sigma_{n-1} (the component of b along
 // the direction that leaves); meta = (p, n, leaving atom); sel shifted; nsel, tmeta[0] decremented.
+template <int CPT>
 __global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T, int kcap, const double* __restrict__ z,
                                                     int* __restrict__ sel, DevState* st, const int* __restrict__ delpos,
                                                     double* __restrict__ G, double* __restrict__ scal,
@@ -203,13 +245,23 @@ __global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T
         }
         return;
     }
-    const bool in = c >= p && c < n;
-    const double u = in ? T[(int64_t)c * kcap + p] : 0.0;
-    const int mysel = c < n ? sel[c] : -1;
-    // inclusive scan of u^2 (Hillis-Steele, ping-pong in LDS)
+    double u[CPT], S[CPT];
+    int mysel[CPT];
+    double loc = 0.0, uz = 0.0;
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int i = c * CPT + q;
+        const bool in = i >= p && i < n;
+        u[q] = in ? T[(int64_t)i * kcap + p] : 0.0;
+        mysel[q] = i < n ? sel[i] : -1;
+        loc = fma(u[q], u[q], loc);
+        S[q] = loc;  // inclusive prefix inside the thread
+        uz = in ? fma(u[q], z[i], uz) : uz;
+    }
+    // inclusive scan of the threads' totals (Hillis-Steele, ping-pong in LDS)
     double* a = sa;
     double* b = sb;
-    a[c] = u * u;
+    a[c] = loc;
     __syncthreads();
     for (int off = 1; off < (int)blockDim.x; off <<= 1) {
         b[c] = a[c] + (c >= off ? a[c - off] : 0.0);
@@ -218,32 +270,45 @@ __global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T
         a = b;
         b = t;
     }
-    const double S = a[c];
-    const double sig = c == p ? u : sqrt(S);  // sigma_p keeps the sign of u_p; positive from there on
+    const double before = c > 0 ? a[c - 1] : 0.0;  // sum of u^2 over the columns of the threads before this one
+    const double total = a[blockDim.x - 1];
     __syncthreads();
-    b[c] = sig;
+    // sigma_i: sigma_p keeps the sign of u_p; positive from there on.  b[c] = sigma of the thread's LAST column (its right
+    // neighbour's first rotation needs it)
+    double sig[CPT];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int i = c * CPT + q;
+        sig[q] = i == p ? u[q] : sqrt(before + S[q]);
+    }
+    b[c] = sig[CPT - 1];
     // zeta = u'z / sigma_{n-1}
-    double uz = in ? u * z[c] : 0.0;
-    for (int s = 32; s >= 1; s >>= 1) uz += shx(uz, s);
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) uz += shx(uz, s_);
     if ((c & 63) == 0) red[c >> 6] = uz;
     __syncthreads();
-    if (c > p && c < n) {
-        const double inv = 1.0 / sig;
-        G[2 * (c - 1)] = u * inv;
-        G[2 * (c - 1) + 1] = -b[c - 1] * inv;
-        sel[c - 1] = mysel;  // (thread c-1 took its own value before the barriers above)
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int i = c * CPT + q;
+        if (i > p && i < n) {
+            const double inv = 1.0 / sig[q];
+            const double sprev = q > 0 ? sig[q - 1] : b[c - 1];  // sigma_{i-1}
+            G[2 * (i - 1)] = u[q] * inv;
+            G[2 * (i - 1) + 1] = -sprev * inv;
+            sel[i - 1] = mysel[q];  // (every thread took its own values before the barriers above)
+        }
+        if (i == p) meta[2] = mysel[q];
     }
     if (c == 0) {
         double tot = 0.0;
         for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += red[w];
-        scal[0] = tot / b[n - 1];
+        const double slast = (n - 1 == p) ? T[(int64_t)p * kcap + p] : sqrt(total);  // sigma_{n-1}
+        scal[0] = tot / slast;
         meta[0] = p;
         meta[1] = n;
         st->nsel = n - 1;
         st->done &= ~(STOP_FULL | STOP_STAG);
         tmeta[0] = n - 1;
     }
-    if (c == p) meta[2] = mysel;
 }
 
 // Removal, step 2: every row of Q and of T, every column of R, and z take the rotations -- one thread

@@ -84,11 +84,11 @@ static int solver_ensure(csmp_ctx* ctx, int kcap, int outcap, bool qr = true) {
 }
 
 // The column-removal kernels (csmp_downdate.hpp, csmp_tinv.hpp) address R and T with the slot's capacity as
-// leading dimension and scan one support in one workgroup: at most kDelMaxCols columns.  A slot that an earlier
+// leading dimension and scan one support in one workgroup: at most kTMaxCols columns (kDelMaxCols for the functor's down-date).  A slot that an earlier
 // call grew beyond that is rebuilt at the size this call needs.
 static int solver_fit_for_removal(csmp_ctx* ctx, int kcap) {
     Solver& s = ctx->s;
-    if (s.kcap > kDelMaxCols && kcap <= kDelMaxCols) {
+    if (s.kcap > kTMaxCols && kcap <= kTMaxCols) {
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         solver_free(s);
     }

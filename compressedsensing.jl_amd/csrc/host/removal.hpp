@@ -3,7 +3,7 @@
 // ------------------------------------------------------------------------------------------ column removal
 static int del_ensure(csmp_ctx* ctx) {
     Solver& s = ctx->s;
-    if (s.kcap > kDelMaxCols) return fail(ctx, CSMP_ERANGE, "column removal supports at most 1023 columns");
+    if (s.kcap > kTMaxCols) return fail(ctx, CSMP_ERANGE, "column removal supports at most 4095 columns");
     if (s.R2) return CSMP_OK;
     CHECK(dmalloc(ctx, &s.R2, (size_t)s.kcap * s.kcap));
     CHECK(dmalloc(ctx, &s.Gdel, (size_t)2 * s.kcap + 2));
@@ -57,8 +57,14 @@ static int launch_tinv_build(csmp_ctx* ctx) {
     if (s.kcap <= 257)
         hipLaunchKernelGGL((k_tinv_build<4, 4>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
                            (const DevState*)s.st, s.T, s.tmeta);
-    else
+    else if (s.kcap <= 1025)
         hipLaunchKernelGGL((k_tinv_build<16, 2>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
+                           (const DevState*)s.st, s.T, s.tmeta);
+    else if (s.kcap <= 2049)
+        hipLaunchKernelGGL((k_tinv_build_big<32>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
+                           (const DevState*)s.st, s.T, s.tmeta);
+    else  // up to 4096 columns: 64 entries per lane
+        hipLaunchKernelGGL((k_tinv_build_big<64>), dim3(s.kcap), dim3(64), 0, ctx->stream, (const double*)s.R, s.kcap,
                            (const DevState*)s.st, s.T, s.tmeta);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
@@ -81,9 +87,14 @@ static int launch_tinv_solve(csmp_ctx* ctx) { return launch_tinv_mv(ctx, 0); }
 // remove_column!(AiQR, *delpos) with the rotations taken from T
 static int launch_delete_t(csmp_ctx* ctx) {
     Solver& s = ctx->s;
-    const int threads = std::min(1024, ((s.kcap + 1 + 63) / 64) * 64);
-    hipLaunchKernelGGL(k_tdel_prep, dim3(1), dim3(threads), 0, ctx->stream, (const double*)s.T, s.kcap, (const double*)s.z, s.sel,
-                       s.st, (const int*)s.delpos, s.Gdel, s.scal, s.delmeta, s.tmeta);
+    if (s.kcap <= 1023) {
+        const int threads = std::min(1024, ((s.kcap + 1 + 63) / 64) * 64);
+        hipLaunchKernelGGL(k_tdel_prep<1>, dim3(1), dim3(threads), 0, ctx->stream, (const double*)s.T, s.kcap, (const double*)s.z, s.sel,
+                           s.st, (const int*)s.delpos, s.Gdel, s.scal, s.delmeta, s.tmeta);
+    } else {  // four columns per thread: supports up to 4096
+        hipLaunchKernelGGL(k_tdel_prep<4>, dim3(1), dim3(1024), 0, ctx->stream, (const double*)s.T, s.kcap, (const double*)s.z, s.sel,
+                           s.st, (const int*)s.delpos, s.Gdel, s.scal, s.delmeta, s.tmeta);
+    }
     HIPCHECK(hipGetLastError());
     const int NB = (s.kcap + 63) / 64;
     hipLaunchKernelGGL(k_tdel_apply, dim3(s.G + 2 * NB + 1), dim3(64), 0, ctx->stream, s.Q, s.ldq, s.G, (const double*)s.T, s.T2,
@@ -138,6 +149,8 @@ extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
     if (ctx->s.algo == CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "solver_remove: MP keeps no factorisation");
     if (ctx->s.algo == CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_remove: use csmp_srr / the backward step for FR");
     HIPCHECK(hipSetDevice(ctx->dev));
+    if (ctx->s.kcap > kDelMaxCols)  // (the functor's down-date walks R with one thread per column in one workgroup: k_qrdel_r)
+        return fail(ctx, CSMP_ERANGE, "solver_remove: the step-level solver's column removal supports a capacity of at most 1023 columns");
     CHECK(del_ensure(ctx));
     return launch_delete_atom(ctx, (int)atom);
 }

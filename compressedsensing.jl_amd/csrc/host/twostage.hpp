@@ -14,12 +14,12 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
     if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
     if (maxiter < 0) maxiter = ctx->M;  // :185
     HIPCHECK(hipSetDevice(ctx->dev));
-    const bool want_downdate = k <= kDelMaxCols;
+    const bool want_downdate = k <= kTMaxCols;
     if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
     CHECK(solver_ensure(ctx, (int)k, (int)k));
     ctx->s.begun = false;
     Solver& s = ctx->s;
-    const bool use_downdate = k <= kDelMaxCols;  // (option 2: refactorise instead)
+    const bool use_downdate = k <= kTMaxCols;  // (beyond: refactorise instead)
     const bool tmode = use_downdate;  // explicit inverse next to R (csmp_tinv.hpp)
     if (use_downdate) CHECK(del_ensure(ctx));
     if (tmode) CHECK(tinv_ensure(ctx));
@@ -332,7 +332,7 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
     if (initialization != 1 && initialization != 2 && !(initialization == 3 && init))
         return fail(ctx, CSMP_EINVAL, "srr: initialization must be 1 (oblivious) or 2 (forward regression); 3 (random) through csmp_srr_from");
     if (k > ctx->N || k + l > ctx->M) return fail(ctx, CSMP_ERANGE, "srr: k exceeds size(A)");
-    if (k + l > kTMaxCols) return fail(ctx, CSMP_ERANGE, "srr: k + l exceeds 1023");
+    if (k + l > kTMaxCols) return fail(ctx, CSMP_ERANGE, "srr: k + l exceeds 4095");
     if (maxiter < 0) maxiter = 4 * k;  // :5
     HIPCHECK(hipSetDevice(ctx->dev));
     Stepwise P;
@@ -426,7 +426,7 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
 
 // ------------------------------------------------------------------------------------------ relevance matching pursuit, FoBa
 // src/stepwise.jl (x starting empty): loops over the two steps of the object above.  kmax bounds the
-// support the forward stage may build (at most 1023; the reference's only bound is size(A,1)): a
+// support the forward stage may build (at most 4095; the reference's only bound is size(A,1)): a
 // forward stage that needs more atoms than that ends with CSMP_ERANGE rather than a truncated answer.
 static int stepwise_cap(csmp_ctx* ctx, int64_t kmax, int* kcap) {
     const int64_t lim = std::min<int64_t>(std::min<int64_t>(ctx->M, ctx->N), kTMaxCols);
@@ -436,7 +436,7 @@ static int stepwise_cap(csmp_ctx* ctx, int64_t kmax, int* kcap) {
 }
 static int stepwise_full(csmp_ctx* ctx, const Stepwise& P, int kcap) {
     if (P.n >= kcap && kcap < std::min<int64_t>(ctx->M, ctx->N))
-        return fail(ctx, CSMP_ERANGE, "stepwise regression: the forward stage filled the support capacity (kmax, at most 1023 atoms)");
+        return fail(ctx, CSMP_ERANGE, "stepwise regression: the forward stage filled the support capacity (kmax, at most 4095 atoms)");
     return CSMP_OK;
 }
 // !(xt ≈ x): isapprox with Julia's default rtol = sqrt(eps) on the sparse vectors
@@ -572,7 +572,7 @@ extern "C" int csmp_br(csmp_ctx* ctx, const void* b, int b_dtype, double max_eps
     if (k < 0) return fail(ctx, CSMP_EINVAL, "br: k < 0");
     if (max_eps != max_eps || max_delta != max_delta) return fail(ctx, CSMP_EINVAL, "br: threshold is NaN");
     if (ctx->N > ctx->M) return fail(ctx, CSMP_ERANGE, "br: A needs to be overdetermined (size(A,2) <= size(A,1))");  // :218
-    if (ctx->N > kTMaxCols) return fail(ctx, CSMP_ERANGE, "br: more than 1023 columns");
+    if (ctx->N > kTMaxCols) return fail(ctx, CSMP_ERANGE, "br: more than 4095 columns");
     HIPCHECK(hipSetDevice(ctx->dev));
     Stepwise P;
     CHECK(P.begin(ctx, b, b_dtype, (int)ctx->N));

@@ -199,10 +199,10 @@ function srr(A::MatOrDict{T}, b::AbstractVector, k::Int, δ::Real = 1e-12; maxit
 end
 
 # ---------------------------------------------------------------------------------- rmp, foba
-# src/stepwise.jl:5-56 (x starting empty).  kmax bounds the support the forward stage may build (<= 1023).
+# src/stepwise.jl:5-56 (x starting empty).  kmax bounds the support the forward stage may build (<= 4095).
 # (one literal ccall per entry point: ccall needs its symbol and its argument types as constants)
 function stepwise_out(A::MatOrDict, kmax::Int)
-    cap = min(size(A, 1), size(A, 2), 1023, kmax > 0 ? kmax : typemax(Int))
+    cap = min(size(A, 1), size(A, 2), 4095, kmax > 0 ? kmax : typemax(Int))
     cap, zeros(Int64, cap + 1), zeros(Float64, cap + 1), Ref{Int64}(0)
 end
 function rmp(A::MatOrDict, b::AbstractVector, δ::Real, maxiter::Int = 1; kmax::Int = 0)

@@ -125,7 +125,7 @@ int csmp_fr_scores(csmp_ctx *ctx, double *delta2);
  * x starting empty.  initialization 1 = oblivious_acquisition! (src/matchingpursuit.jl:207-216),
  * 2 = k forward-regression steps; each iteration takes l forward steps (src/forward.jl:56-73) and then
  * backward steps (src/backward.jl:51-83) until k atoms remain.  maxiter < 0 selects the default 4k.
- * Capacity k + l (at most 1023).  *iters (may be NULL) = iterations made. */
+ * Capacity k + l (at most 4095).  *iters (may be NULL) = iterations made. */
 int csmp_srr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta, int64_t maxiter, int initialization,
              int64_t l, int64_t *idx, double *val, int64_t *nnz, int64_t *iters);
 /* srr with initialization = 3 (random_acquisition!, src/matchingpursuit.jl:195-204; src/twostage.jl:14-16): init[0..k) are the k
@@ -138,7 +138,7 @@ int csmp_srr_from(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double d
 
 /* rmp(A,b,delta,maxiter) (src/stepwise.jl:5-26), rmp(A,b,k) (:32-43) and foba(A,b,delta) (:47-56), x
  * starting empty: loops over forward_step! (src/forward.jl:56-73) and backward_step!
- * (src/backward.jl:51-67) of the StepwiseRegression object.  kmax (<= 0: min(M, N, 1023)) is the largest
+ * (src/backward.jl:51-67) of the StepwiseRegression object.  kmax (<= 0: min(M, N, 4095)) is the largest
  * support the forward stage may build; reaching it below min(M,N) is CSMP_ERANGE.  Capacity of idx/val:
  * kmax.  maxiter < 0 selects the default 1. */
 int csmp_rmp_delta(csmp_ctx *ctx, const void *b, int b_dtype, double delta, int64_t maxiter, int64_t kmax,
@@ -150,7 +150,7 @@ int csmp_foba(csmp_ctx *ctx, const void *b, int b_dtype, double delta, int64_t k
 
 /* br(A,b,max_eps,max_delta,k) = fbr (src/backward.jl:27-35,154-162) and, with lace != 0,
  * lace(A,b,eps,delta,k) (:233-270): backward regression from the least-squares solution on all N <= M
- * columns (N <= 1023).  Infinite thresholds are passed as HUGE_VAL.  Capacity of idx/val: N. */
+ * columns (N <= 4095).  Infinite thresholds are passed as HUGE_VAL.  Capacity of idx/val: N. */
 int csmp_br(csmp_ctx *ctx, const void *b, int b_dtype, double max_eps, double max_delta, int64_t k, int lace,
             int64_t *idx, double *val, int64_t *nnz);
 

@@ -2393,3 +2393,26 @@ def test_omp_sharded_in_library_rccl(cs, oracle, D):
     with pytest.raises(cs.CsmpError):
         d.ctx.omp_sharded(B, nsig, k, EPS32)
     d.ctx.comm_init(cs.comm_id(), 0, 1)  # a second communicator on the same context; freed by csmp_destroy
+
+
+@pytest.mark.parametrize("cfg", [(2304, 4608, 1100, 2, 4), (4096, 8192, 2048, 1, 2)])
+def test_srr_and_ompr_beyond_1023_columns(cs, oracle, cfg):
+    """The two-stage solvers' supports are bounded by size(A,1) in the reference (src/twostage.jl:3-33,110-202); rounds 1-3 capped
+    them at 1023 columns (one thread per column in the removal kernels).  The explicit-inverse removal now scans four columns per
+    thread (k_tdel_prep<4>) and builds T = R^-1 with up to 64 entries per lane (k_tinv_build_big): srr at k = 2048, M = 4096 --
+    oblivious start, forward + backward steps, supports, coefficients and iteration counts against the oracle (a bounded number of
+    iterations: the oracle refactorises from scratch at every change)."""
+    n, m, k, l, maxiter = cfg
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=n + k, dtype=np.float32)
+    xs = cs.sparse_vector(m, k + 2, rng=1)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, 5e-3, rng=2)
+    d = cs.Dictionary(A)
+    ref = oracle.srr(A, y, k, 1e-12, maxiter, 1, l)
+    got = d.ctx.srr(y, k, 1e-12, maxiter, 1, l)
+    assert len(got[0]) == k and np.array_equal(got[0], ref[0]), int((got[0] != ref[0]).sum())
+    assert close(got[1], ref[1], tight=False) and got[2] == ref[2]
+    if k <= 1100:  # ompr on the same data: the exchange steps go through the same removal kernels
+        ro = oracle.ompr(A, y, k, 1e-6, 3)
+        go = d.ctx.ompr(y, k, 1e-6, 3)
+        assert np.array_equal(go[0], ro[0]) and close(go[1], ro[1], tight=False) and go[2] == ro[2]
+    d.close()
