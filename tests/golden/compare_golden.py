@@ -2,18 +2,42 @@
 real CompressedSensing.jl produced (make_golden_reference.jl).  Supports must be identical; coefficients within the
 north_star tolerance (1e-6 relative); selection orders identical where both files carry one.
 
-Float32 cases are reported but do NOT count: for a `Matrix{Float32}` the real package computes everything in Float32
-(src/matchingpursuit.jl:56-58: r, Ar and the UpdatableQR take eltype(A)), while this library and its oracle compute in
-Float64 on the exactly promoted values (north_star's tolerance 1e-6 cannot be met in Float32
-either).  On those cases the reference may legitimately pick another atom at a near-tie below Float32 resolution and its
-coefficients carry Float32 round-off; the pin is the Float64 cases.
-Exit code 0 = the oracle is pinned by the reference on every committed Float64 case."""
+Float32 cases: for a `Matrix{Float32}` the real package computes everything in Float32 (src/matchingpursuit.jl:56-58: r, Ar
+and the UpdatableQR take eltype(A)), while this library and its oracle compute in Float64 on the exactly promoted values (SURVEY.md
+section 7; north_star's tolerance 1e-6 cannot be met in Float32 either).  There the reference may legitimately pick another atom
+at a near-tie below Float32 resolution, and its coefficients carry Float32 round-off (compared at 1e-4).  A Float32 case still
+COUNTS as a mismatch when its selection order leaves the oracle's at a step whose top correlations are NOT that close: the residual
+of the common prefix is rebuilt in Float64 and the two picks' |<a, r>| must lie within `F32_GAP` of the largest -- otherwise the
+difference is not a rounding matter.  Cases without a selection order (or that differ only in coefficients) stay informational.
+Exit code 0 = the oracle is pinned by the reference on every committed Float64 case and on every Float32 case without such a
+near-tie."""
 import sys
 
 import numpy as np
 
+F32_GAP = 1e-4  # relative to the step's largest |<a, r>|: ~ sqrt(M) eps(Float32) of a Float32 sweep, with margin
+
+
+def explained_by_f32_near_tie(A, y, oa, ob):
+    """The orders oa (oracle) and ob (reference) share a prefix; at the first differing step both picks must be near-tied in
+    Float64 on the promoted data (the residual of the prefix by least squares)."""
+    t = 0
+    while t < min(len(oa), len(ob)) and oa[t] == ob[t]:
+        t += 1
+    if t >= min(len(oa), len(ob)):
+        return True  # one is a prefix of the other: a stopping-rule matter, not a selection
+    A64 = A.astype(np.float64)
+    r = y.astype(np.float64)
+    if t:
+        S = A64[:, np.asarray(oa[:t], dtype=np.int64)]
+        r = r - S @ np.linalg.lstsq(S, r, rcond=None)[0]
+    c = np.abs(A64.T @ r)
+    top = float(c.max())
+    return top > 0.0 and (c[int(oa[t])] - c[int(ob[t])]) <= F32_GAP * top and (top - c[int(oa[t])]) <= F32_GAP * top
+
+
 a, b = np.load(sys.argv[1]), np.load(sys.argv[2])
-bad = bad32 = 0
+bad = bad32 = info32 = 0
 for name in (str(n) for n in a["names"]):
     f32 = a[name + ".A"].dtype == np.float32
     ia, ib = a[name + ".idx"], b[name + ".idx"]
@@ -25,11 +49,18 @@ for name in (str(n) for n in a["names"]):
         ok = np.allclose(va, vb, rtol=tol, atol=tol * max(1e-300, float(np.abs(va).max()) if len(va) else 0.0))
     if ok and len(oa) and len(ob):
         ok = np.array_equal(oa, ob)
-    tag = "ok      " if ok else ("differs " if f32 else "MISMATCH")
-    print(tag + " " + name + ("   [Float32 dictionary: informational]" if f32 else ""))
-    if f32:
-        bad32 += not ok
-    else:
+    note = ""
+    if f32 and not ok:
+        # (0-based orders in both files; the Julia script subtracts 1)
+        if len(oa) and len(ob) and not np.array_equal(oa, ob) and not explained_by_f32_near_tie(a[name + ".A"], a[name + ".b"], oa, ob):
+            bad32 += 1
+            note = "   [Float32 dictionary: the selections part where the correlations are NOT near-tied]"
+        else:
+            info32 += 1
+            note = "   [Float32 dictionary: a near-tie below Float32 resolution / Float32 round-off -- informational]"
+    tag = "ok      " if ok else ("MISMATCH" if (not f32 or "NOT near-tied" in note) else "differs ")
+    print(tag + " " + name + note)
+    if not f32:
         bad += not ok
-print(f"{bad} mismatching Float64 case(s); {bad32} differing Float32 case(s) (informational)")
-sys.exit(1 if bad else 0)
+print(f"{bad} mismatching Float64 case(s); {bad32} Float32 case(s) that no near-tie explains; {info32} differing Float32 case(s) (informational)")
+sys.exit(1 if (bad or bad32) else 0)
