@@ -532,6 +532,26 @@ __global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ G
     if (row == col && row < n) kdnew[row] = s;
 }
 
+// x = R^-1 z as a product with the explicit inverse the augmented factorisation left: x_j = sum_{t >= j} Tt[t, j] z_t (column j of
+// Tt = (R^-1)', contiguous), one wave per coefficient -- instead of the back substitution's chain of 256-column super-blocks.
+__global__ __launch_bounds__(256) void k_tt_gemv(const double* __restrict__ Tt, int ldt, const double* __restrict__ z, const DevState* st,
+                                                 int n, double* __restrict__ x) {
+    if (st->nsel != n) return;  // (nothing was exported: the set failed its DGKS test)
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= n) return;
+    const double* col = Tt + (int64_t)j * ldt;
+    double a0 = 0.0, a1 = 0.0;
+    int t = j + lane;
+    for (; t + 64 < n; t += 128) {
+        a0 = fma(col[t], z[t], a0);
+        a1 = fma(col[t + 64], z[t + 64], a1);
+    }
+    if (t < n) a0 = fma(col[t], z[t], a0);
+    double a = a0 + a1;
+    for (int s_ = 32; s_ >= 1; s_ >>= 1) a += shx(a, s_);
+    if (lane == 0) x[j] = a;
+}
+
 // W = R_F^-T G_FN = Tt G_FN as a tiled product (no chain): W[i][c] = sum_{t <= i} Tt[i, t] G[t, c], Tt = (R_F^-1)' from the
 // augmented factorisation of F (lower triangular: zeros above its diagonal).  32 x 32 output tiles (256 workgroups at n_F = n_N = 512),
 // 256 threads with 2 x 2 outputs each, K-tiles of 32 through LDS, the next K-tile's operands already on their way (registers)

@@ -591,7 +591,17 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     s.tt_col0 = np;
     s.tt_ld = npa;
     s.jh = std::min(s.kcap, n);
-    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
+    if (aug) {  // x = R^-1 z through the explicit inverse beside R: one product instead of the back substitution's chain
+        hipLaunchKernelGGL(k_tt_gemv, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(s.Gm + (size_t)np * npa), npa, (const double*)s.z,
+                           (const DevState*)s.st, n, s.coef);
+        const int ne = std::max(n, s.outcap);
+        hipLaunchKernelGGL(k_trsv_emit, dim3((ne + 255) / 256), dim3(256), (size_t)(s.kcap + 4) * sizeof(int), ctx->stream,
+                           (const double*)s.coef, (const int*)s.sel, (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap,
+                           (int*)nullptr);
+        HIPCHECK(hipGetLastError());
+    } else {
+        CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));  // x = R^-1 z (s.coef: the order of cols) + sorted emission
+    }
     const int nch = (n + kResChunk - 1) / kResChunk;
     hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
                        (const int*)s.cands, (const double*)s.coef, n, s.rpart);
