@@ -37,6 +37,8 @@ while time.time() - t0 < budget:
     N = int(rng.choice([300, 1000, 3000, 8000]))
     dtype = rng.choice([np.float32, np.float64])
     k = int(rng.integers(2, max(3, min(M // 6, 48))))
+    if M >= 1024 and rng.random() < 0.3:  # large supports: whole-set least squares with the augmented factor and its extension (sp)
+        k = int(rng.integers(64, min(M // 4, 260)))
     kind = "gaussian"
     if rounds % 3 == 2:
         kind = str(rng.choice(["few_valued", "partial_dct", "one_magnitude", "signs"]))
@@ -64,27 +66,30 @@ while time.time() - t0 < budget:
         idx, val, nnz = D.ctx.omp_batch(B, k, eps)
         for s in range(nsig):
             cmp("omp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
-        for cert, gram, name in ((0, 0, "omp_mfma"), (1, 0, "omp_mfma_rigorous"), (0, 1, "omp_mfma_gram"), (0, 0, "omp_mfma_int8"), (0, 1, "omp_mfma_int8_gram")):
+        for cert, gram, scr, name in ((1, 0, 3, "omp_mfma_default_f16_rigorous"), (1, 1, 3, "omp_mfma_f16_rigorous_gram"), (1, 0, 0, "omp_mfma_bf16_rigorous"),
+                                      (0, 0, 3, "omp_mfma_f16_statistical"), (0, 0, 0, "omp_mfma_bf16_statistical"), (0, 0, 1, "omp_mfma_int8"),
+                                      (0, 1, 1, "omp_mfma_int8_gram")):
             if gram and N > 8000:
                 continue
             D.ctx.set_option("batch_cert", cert)
             D.ctx.set_option("batch_gram", gram)
-            D.ctx.set_option("batch_screen", 1 if "int8" in name else 0)
+            D.ctx.set_option("batch_screen", scr)
             idx, val, nnz = D.ctx.omp_batch_mfma(B, k, eps)
             for s in range(nsig):
                 cmp(name, (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
-        D.ctx.set_option("batch_cert", 0)
+        D.ctx.set_option("batch_cert", 1)
         D.ctx.set_option("batch_gram", 0)
-        D.ctx.set_option("batch_screen", 2)
-        for cert, name in ((0, "omp_screened"), (1, "omp_screened_rigorous"), (0, "omp_screened_int8")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
+        D.ctx.set_option("batch_screen", 3)
+        for cert, img, name in ((1, 3, "omp_screened_f16_rigorous"), (0, 3, "omp_screened_f16_statistical"), (0, 1, "omp_screened_bf16"),
+                                (1, 1, "omp_screened_bf16_rigorous"), (0, 2, "omp_screened_int8")):  # CSMP_OPT_SCREENED_SWEEP: lone calls and the batch form
             D.ctx.set_option("batch_cert", cert)
-            D.ctx.set_option("screened_sweep", 2 if "int8" in name else 1)
+            D.ctx.set_option("screened_sweep", img)
             cmp(name, D.ctx.omp(B[:, 0], k, eps), refs[0], cfg)
             idx, val, nnz = D.ctx.omp_batch(B, k, eps)
             for s in range(nsig):
                 cmp(name + "_batch", (idx[:nnz[s], s], val[:nnz[s], s]), refs[s], cfg)
         D.ctx.set_option("screened_sweep", 0)
-        D.ctx.set_option("batch_cert", 0)
+        D.ctx.set_option("batch_cert", 1)
         l = int(rng.choice([2, 3, 4]))
         gref = [oc.gomp(A, B[:, s], l, k, eps) for s in range(nsig)]
         cmp("gomp", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
@@ -92,15 +97,15 @@ while time.time() - t0 < budget:
             idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
             for s in range(nsig):
                 cmp("gomp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
-            img = int(rng.integers(1, 3))
-            D.ctx.set_option("screened_sweep", img)  # certified top-l picks over the bf16 / int8 image
-            D.ctx.set_option("batch_cert", int(rng.integers(0, 2)) if img == 1 else 0)
+            img = int(rng.integers(1, 4))
+            D.ctx.set_option("screened_sweep", img)  # certified top-l picks over the bf16 / int8 / binary16 image
+            D.ctx.set_option("batch_cert", int(rng.integers(0, 2)) if img != 2 else 0)
             cmp("gomp_screened", D.ctx.gomp(B[:, 0], l, k, eps), gref[0], cfg + (l,))
             idx, val, nnz = D.ctx.gomp_batch(B, l, k, eps)
             for s in range(nsig):
                 cmp("gomp_screened_batch", (idx[:nnz[s], s], val[:nnz[s], s]), gref[s], cfg + (l,))
             D.ctx.set_option("screened_sweep", 0)
-            D.ctx.set_option("batch_cert", 0)
+            D.ctx.set_option("batch_cert", 1)
         if 2 * k <= M:
             sref = [oc.sp(A, B[:, s], k, 1e-12) for s in range(nsig)]
             cmp("sp", D.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
@@ -108,7 +113,7 @@ while time.time() - t0 < budget:
             idx, val, nnz, its = D.ctx.sp_batch(B, k, 1e-12)
             for s in range(nsig):
                 cmp("sp_batch", (idx[:nnz[s], s], val[:nnz[s], s]), sref[s], cfg)
-            D.ctx.set_option("screened_sweep", int(rng.integers(1, 3)))  # certified top-k sets over the bf16 / int8 image
+            D.ctx.set_option("screened_sweep", int(rng.integers(1, 4)))  # certified top-k sets over the bf16 / int8 / binary16 image
             cmp("sp_screened", D.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
             idx, val, nnz, its = D.ctx.sp_batch(B, k, 1e-12)
             for s in range(nsig):
