@@ -1878,7 +1878,8 @@ def test_screened_sweep_full_size_config2(cs, oracle):
         st = d.ctx.screened_stats()
         # (the column groups are handed out dynamically: which workgroup lists which atoms varies from run to run, and with it -- very
         # rarely -- whether a pick certifies; the results above do not depend on it)
-        assert st["solves"] == 1 and st["fallbacks"] <= (0 if image == 3 else 1), (image, cert, st)
+        assert st["solves"] == 1 and st["fallbacks"] <= 1, (image, cert, st)
+        print("C2 screened image", image, "cert", cert, st)
     A = np.asfortranarray(At.cpu().numpy().T)
     ref = oracle.omp(A, y, 12, EPS32)
     assert np.array_equal(got[2][:12], ref[2])
