@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __re
                                            0.0f, smem_sweep);
 }
 template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
-__global__ __launch_bounds__(kSweepThreads) void k_sweep_f16(const _Float16* __restrict__ Ah, int Mk, int64_t N,
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_f16(const unsigned short* __restrict__ Ah /* binary16 bit patterns */, int Mk, int64_t N,
                                                              const double* __restrict__ r, int Mr, float* __restrict__ cand_val,
                                                              int* __restrict__ cand_idx, DevState* st, double eps, int check_eps,
                                                              int skipmask, unsigned* __restrict__ tickets, float inv_scale) {

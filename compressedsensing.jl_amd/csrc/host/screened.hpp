@@ -131,7 +131,7 @@ static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip,
             if (lds > 48 * 1024)                                                                                                          \
                 HIPCHECK(hipFuncSetAttribute((const void*)k_sweep_f16<U, DD, FULL, kScrCols, LCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL((k_sweep_f16<U, DD, FULL, kScrCols, LCV>), dim3(ctx->scr_grid), dim3(kSweepThreads), lds, ctx->stream,        \
-                               (const _Float16*)b.Ah, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
+                               (const unsigned short*)b.Ah, b.Mk, ctx->N, (const double*)s.r, s.Mpad, s.scr_val, s.scr_idx, s.st, eps, check_eps, skip, \
                                s.scr_tickets, 1.0f / b.ascale16);                                                                         \
         } else {                                                                                                                          \
             if (lds > 48 * 1024)                                                                                                          \

@@ -11,7 +11,7 @@ stats() {  # stats <name> <bench args...>: headline line + csmp kernel rows of r
   rm -rf /tmp/prof_$name /tmp/w_$name; mkdir -p /tmp/w_$name; cd /tmp/w_$name
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py "$@" > $OUT/${name}_stdout.txt 2> $OUT/${name}.err
   local f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && grep -E '^"Name"|csmp::' "$f" > $OUT/${name}_kernel_stats.csv
+  [ -n "$f" ] && grep -E '^"Name"|csmp::|_ZN4csmp' "$f" > $OUT/${name}_kernel_stats.csv
   grep '^{' $OUT/${name}_stdout.txt | tail -1 > $OUT/${name}_line.json; rm -f $OUT/${name}_stdout.txt
   [ -f bench_secondary.json ] && cp bench_secondary.json $OUT/${name}_detail.json
   cd /tmp
