@@ -45,6 +45,8 @@ SIGNATURES = {
     "csmp_comm_init": (C.c_int, [vp, vp, C.c_int, C.c_int]),
     "csmp_comm_free": (C.c_int, [vp]),
     "csmp_omp_sharded": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, C.c_int, vp, vp, vp, C.c_int]),
+    "csmp_pack_block_device": (C.c_int, [vp, vp, vp, vp, i64, i64, i64, vp]),
+    "csmp_unpack_gathered_device": (C.c_int, [vp, vp, i64, i64, C.c_int, vp, vp, vp]),
     "csmp_pack_results": (C.c_int, [vp, vp, vp, i64, i64, vp]),
     "csmp_unpack_results": (C.c_int, [vp, i64, i64, vp, vp, vp]),
     "csmp_mp": (C.c_int, [vp, vp, C.c_int, i64, vp, vp, i64, vp, vp, C.POINTER(i64)]),
@@ -484,6 +486,26 @@ class Context:
 
     def comm_free(self):
         self.call("csmp_comm_free")
+
+    def pack_block_device(self, idx, val, nnz, rows):
+        """torch CUDA tensors idx / val (nloc, k), nnz (nloc,) -> (rows, 2k+1) float64 tensor on the device (rows >= nloc, surplus zero)."""
+        import torch
+        nloc, k = idx.shape
+        out = torch.empty((int(rows), 2 * k + 1), dtype=torch.float64, device=idx.device)
+        self.call("csmp_pack_block_device", vp(idx.data_ptr() if nloc else 0), vp(val.data_ptr() if nloc else 0), vp(nnz.data_ptr() if nloc else 0),
+                  i64(k), i64(nloc), i64(int(rows)), vp(out.data_ptr()))
+        return out
+
+    def unpack_gathered_device(self, gathered, k, nsig, world):
+        """(world * rows, 2k+1) float64 CUDA tensor of every rank's packed block -> idx (nsig, k) int64, val (nsig, k), nnz (nsig,) on the device."""
+        import torch
+        dev = gathered.device
+        idx = torch.empty((int(nsig), int(k)), dtype=torch.int64, device=dev)
+        val = torch.empty((int(nsig), int(k)), dtype=torch.float64, device=dev)
+        nnz = torch.empty(int(nsig), dtype=torch.int64, device=dev)
+        self.call("csmp_unpack_gathered_device", vp(gathered.data_ptr()), i64(int(k)), i64(int(nsig)), int(world), vp(idx.data_ptr()),
+                  vp(val.data_ptr()), vp(nnz.data_ptr()))
+        return idx, val, nnz
 
     def omp_sharded(self, B_local, nsig, k, eps, method="exact"):
         """This rank's block B_local (M x nloc, host) of `nsig` signals in all -> (idx k x nsig, val, nnz) of ALL signals."""

@@ -86,6 +86,31 @@ __global__ void k_unpack_rows(const double* __restrict__ all, int64_t k, int64_t
     }
 }
 
+// The two device-side halves of the exchange on their own (csmp_omp_sharded runs them around its ncclAllGather): for a host that keeps
+// results on the device and brings its own collective, and so that the layout arithmetic for world > 1 can be exercised on one GPU.
+extern "C" int csmp_pack_block_device(csmp_ctx* ctx, const int64_t* idx, const double* val, const int64_t* nnz, int64_t k, int64_t nloc,
+                                      int64_t rows, double* packed) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!packed || k < 1 || nloc < 0 || rows < nloc || (nloc > 0 && (!idx || !val || !nnz))) return fail(ctx, CSMP_EINVAL, "pack_block_device: bad arguments");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int64_t w = 2 * k + 1;
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows * w + 255) / 256));
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, idx, val, nnz, k, nloc, rows, packed);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+extern "C" int csmp_unpack_gathered_device(csmp_ctx* ctx, const double* gathered, int64_t k, int64_t nsig, int world, int64_t* idx, double* val,
+                                           int64_t* nnz) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!gathered || !idx || !val || !nnz || k < 1 || nsig < 1 || world < 1) return fail(ctx, CSMP_EINVAL, "unpack_gathered_device: bad arguments");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    const int64_t w = 2 * k + 1, rows = (nsig + world - 1) / world;
+    const int grid = (int)std::min<int64_t>(1024, (nsig * w + 255) / 256);
+    hipLaunchKernelGGL(k_unpack_rows, dim3(grid), dim3(256), 0, ctx->stream, gathered, k, nsig, world, rows, idx, val, nnz);
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
 extern "C" int csmp_comm_id(void* id) {
     if (!id) return CSMP_EINVAL;
     if (!rccl_load()) {
@@ -157,10 +182,7 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
             : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE);
         if (rc != CSMP_OK) return rc;
     }
-    const int grid = (int)std::min<int64_t>(1024, (rows * w + 255) / 256);
-    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k, nloc,
-                       rows, (double*)tPack.p);
-    HIPCHECK(hipGetLastError());
+    CHECK(csmp_pack_block_device(ctx, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k, nloc, rows, (double*)tPack.p));
     // THE collective: every rank's packed block, device memory to device memory, ordered on the context's stream
     const ncclResult_t r = g_rccl.AllGather(tPack.p, tAll.p, (size_t)(rows * w), ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
     if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
@@ -174,9 +196,7 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
         d_val = (double*)oVal.p;
         d_nnz = (int64_t*)oNnz.p;
     }
-    const int grid2 = (int)std::min<int64_t>(1024, (nsig * w + 255) / 256);
-    hipLaunchKernelGGL(k_unpack_rows, dim3(grid2), dim3(256), 0, ctx->stream, (const double*)tAll.p, k, nsig, world, rows, d_idx, d_val, d_nnz);
-    HIPCHECK(hipGetLastError());
+    CHECK(csmp_unpack_gathered_device(ctx, (const double*)tAll.p, k, nsig, world, d_idx, d_val, d_nnz));
     if (out_loc == CSMP_HOST) {
         HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));

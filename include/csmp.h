@@ -314,6 +314,14 @@ int csmp_comm_init(csmp_ctx *ctx, const void *id, int rank, int world);
 int csmp_comm_free(csmp_ctx *ctx);
 int csmp_omp_sharded(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
                      int method, int64_t *idx, double *val, int64_t *nnz, int out_loc);
+/* The device-side halves of that exchange on their own, stream-ordered on the ctx (device pointers throughout): rows of 2k + 1 Float64
+ * from a block's results (idx, val: k x nloc; nnz: nloc; `rows` >= nloc rows are written, the surplus zeroed -- every rank packs
+ * ceil(nsig / world) rows so that the blocks gather), and the gathered world x rows x (2k + 1) array into idx / val (k x nsig) and nnz
+ * (nsig) in global signal order.  For a host that keeps results on the device under a collective of its own. */
+int csmp_pack_block_device(csmp_ctx *ctx, const int64_t *idx, const double *val, const int64_t *nnz, int64_t k, int64_t nloc,
+                           int64_t rows, double *packed);
+int csmp_unpack_gathered_device(csmp_ctx *ctx, const double *gathered, int64_t k, int64_t nsig, int world, int64_t *idx, double *val,
+                                int64_t *nnz);
 /* The same wire layout for hosts that bring their own collective (torch.distributed all_gather in sharded.py's gloo tests and
  * single-signal solver families; MPI): host memory, no ctx. */
 int csmp_shard_range(int64_t nsig, int rank, int world, int64_t *lo, int64_t *hi);

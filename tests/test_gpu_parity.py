@@ -2417,3 +2417,37 @@ def test_srr_and_ompr_beyond_1023_columns(cs, oracle, cfg):
         go = d.ctx.ompr(y, k, 1e-6, 3)
         assert np.array_equal(go[0], ro[0]) and close(go[1], ro[1], tight=False) and go[2] == ro[2]
     d.close()
+
+
+@pytest.mark.parametrize("cfg", [(11, 3, 5), (8, 8, 4), (5, 8, 3), (64, 4, 16), (1, 1, 2), (7, 2, 1)])
+def test_sharded_wire_layout_on_the_device_for_several_ranks(cs, D, cfg):
+    """The device-side halves of csmp_omp_sharded (k_pack_rows / k_unpack_rows) for world > 1 -- which RCCL cannot exercise on one GPU:
+    every "rank" packs its contiguous block (csmp_shard_range) padded to ceil(nsig / world) rows, the blocks are concatenated as
+    an all-gather would deliver them, and the unpacked arrays must be the original ones in global signal order; the rows equal the
+    host packer's (csmp_pack_results), so both paths speak one wire layout."""
+    import torch
+    nsig, world, k = cfg
+    A, x, b = cs.sparse_data(n=32, m=64, k=2, rng=1, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(nsig * 31 + world)
+    nnz = rng.integers(0, k + 1, size=nsig)
+    idx = np.full((nsig, k), -1, np.int64)
+    val = np.zeros((nsig, k))
+    for s in range(nsig):
+        idx[s, :nnz[s]] = np.sort(rng.choice(10_000_000, size=nnz[s], replace=False))
+        val[s, :nnz[s]] = rng.standard_normal(nnz[s])
+    rows = -(-nsig // world)
+    blocks = []
+    for r in range(world):
+        lo, hi = cs.shard_range(nsig, r, world)
+        ti, tv, tn = (torch.from_numpy(np.ascontiguousarray(a[lo:hi])).cuda() for a in (idx, val, nnz.astype(np.int64)))
+        pk = d.ctx.pack_block_device(ti, tv, tn, rows)
+        d.ctx.sync()
+        host = cs.sharded.pack(idx[lo:hi].T, val[lo:hi].T, nnz[lo:hi]) if hi > lo else np.zeros((0, 2 * k + 1))
+        assert np.array_equal(pk.cpu().numpy()[:hi - lo], host) and not pk.cpu().numpy()[hi - lo:].any()
+        blocks.append(pk)
+    gi, gv, gn = d.ctx.unpack_gathered_device(torch.cat(blocks, dim=0).contiguous(), k, nsig, world)
+    d.ctx.sync()
+    assert np.array_equal(gn.cpu().numpy(), nnz)
+    for s in range(nsig):
+        assert np.array_equal(gi[s, :nnz[s]].cpu().numpy(), idx[s, :nnz[s]]) and np.array_equal(gv[s, :nnz[s]].cpu().numpy(), val[s, :nnz[s]])
