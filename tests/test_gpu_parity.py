@@ -1598,10 +1598,10 @@ def test_reference_default_capacity_reaches_size_a1(cs, oracle, D):
     assert d.ctx.last_status == lib.OK and bn[0] == M and bn[1] == M
     assert np.array_equal(bi[:, 0], ref[0]) and np.array_equal(bi[:, 1], ref[0])
     assert np.allclose(bv[:, 0], ref[1], rtol=1e-6, atol=1e-6 * np.abs(ref[1]).max()) and np.allclose(bv[:, 1], -bv[:, 0], rtol=1e-9, atol=1e-12)
-    # gomp(A, b, l) at its default capacity size(A,1) (:108): l = 3 does not divide 4096, the remainder step fills the support; the
-    # full support is the whole space, so the least-squares residual vanishes (a second full-size oracle solve is not spent on it)
+    # gomp(A, b, l) at its default capacity size(A,1) (:108): l = 3 does not divide 4096, the remainder step fills the support
     gi, gv, go = d.ctx.gomp(y, 3, M, 0.0)
-    assert len(gi) == M and len(set(go.tolist())) == M
+    rg = oracle.gomp(A, y, 3, M, 0.0, nthreads=NT)
+    assert len(gi) == len(rg[0]) == M and np.array_equal(go, rg[2])
     assert np.linalg.norm(y - A[:, gi].astype(np.float64) @ gv) < 1e-8 * np.linalg.norm(y)
 
 
