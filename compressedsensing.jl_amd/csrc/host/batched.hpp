@@ -330,8 +330,9 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     // not documented; truncation is covered) -- over at most Mk additions:
     //     |<a,r> - screened| <= (2u + u^2 + Mk 2^-23 (1 + u)^2) sum|a_i r_i| <= (...) |a|_2 |r|_2,
     // with the largest column norm for |a|_2.  binary16 only: the power-of-two scales are exact; image entries below the normal
-    // range carry an absolute error <= 2^-25 in scaled units, i.e. 2^-39 of the operand's largest entry: sqrt(Mk) 2^-38 |a||r| for
-    // both operands together.  cert_rel: the 2^-15 the packed candidate keys drop and the rounding of the scale multiplication.
+    // range (2^-14 in scaled units, the largest entry of an operand sitting in [2^14, 2^15)) are charged a FLUSH TO ZERO -- an
+    // absolute error of up to 2^-14 against a partner of at most 2^15, Mk of them, both operands: Mk 2^-26 |a||r| -- whether or
+    // not the conversion keeps subnormals (it does by default; the bound does not rest on the mode register).  cert_rel: the 2^-15 the packed candidate keys drop and the rounding of the scale multiplication.
     // A proof: nothing about the data is assumed (tests: test_batched_certificate_against_adversarial_residuals).
     //
     // STATISTICAL (CSMP_OPT_BATCH_CERT = 0, opt-in): 8 standard deviations of a model of INDEPENDENT roundings of the M products,
@@ -354,7 +355,7 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     } else if (ctx->opt_batch_cert == 1) {
         CHECK(batch_colnorm(ctx));
         cert_abs = (2.0 * u_img + u_img * u_img + (double)b.Mk * std::ldexp(1.0, -23) * (1.0 + u_img) * (1.0 + u_img) +
-                    (img == kOpF16 ? std::sqrt((double)b.Mk) * std::ldexp(1.0, -38) : 0.0)) * (double)b.anorm_host;
+                    (img == kOpF16 ? (double)b.Mk * std::ldexp(1.0, -26) : 0.0)) * (double)b.anorm_host;
         cert_rel = std::ldexp(1.0, -14);
         kwin = kWinMax;  // 128
     } else {

@@ -24,12 +24,12 @@ static int screened_ensure(csmp_ctx* ctx) {
         // ONE rounded operand here: the image of the dictionary (unit roundoff u: 2^-11 binary16, 2^-8 bf16; + 2^-23 for a Float64
         // dictionary's double rounding); the residual enters the sweep in Float32 (2^-24) and the sums are Float32 FMAs in a fixed
         // order, round to nearest (2^-24 each, fewer than Mk of them on any path to a sum):
-        //     |<a,r> - screened| <= (u + 2^-24 + Mk 2^-24)(1 + 2^-10) |a|_2 |r|_2  [+ binary16's subnormal entries: sqrt(Mk) 2^-38]
+        //     |<a,r> - screened| <= (u + 2^-24 + Mk 2^-24)(1 + 2^-10) |a|_2 |r|_2  [+ binary16 entries below the normal range, charged a flush to zero: Mk 2^-27]
         const double u_img = (f16 ? std::ldexp(1.0, -11) : std::ldexp(1.0, -8)) + std::ldexp(1.0, -23);
         if (ctx->opt_batch_cert == 1) {
             CHECK(batch_colnorm(ctx));
             ctx->scr_cert_abs = ((u_img + std::ldexp(1.0, -24) + (double)b.Mk * std::ldexp(1.0, -24)) * (1.0 + std::ldexp(1.0, -10)) +
-                                 (f16 ? std::sqrt((double)b.Mk) * std::ldexp(1.0, -38) : 0.0)) * (double)b.anorm_host;
+                                 (f16 ? (double)b.Mk * std::ldexp(1.0, -27) : 0.0)) * (double)b.anorm_host;
             ctx->scr_cert_rel = std::ldexp(1.0, -20);
             ctx->scr_kwin = kWinMax;
         } else {  // statistical: 8 sigma of independent roundings of the image's entries + the coherent term (host/batched.hpp)
