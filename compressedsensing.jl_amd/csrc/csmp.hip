@@ -16,6 +16,7 @@
 #include "csmp_gram.hpp"
 
 #include <algorithm>
+#include <iterator>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

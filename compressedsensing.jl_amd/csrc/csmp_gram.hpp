@@ -462,6 +462,40 @@ __global__ __launch_bounds__(kCholThreads) void k_chol_step(double* __restrict__
     }
 }
 
+// ---- the host link of a whole-set solve: ONE kernel up, ONE kernel down (a small hipMemcpyAsync is a blit kernel of its own,
+// 2-5 us on the chain each, and there were three and four of them per phase).  Page-locked host memory is mapped into the
+// device's address space under the same pointer: the kernels read / write it directly over the link.
+// up: [cols (n) | n | positions (npos)] from the staging buffer into the slot's column list, its count and the position list
+__global__ __launch_bounds__(256) void k_put_lists(const int* __restrict__ src, int n, int npos, int* __restrict__ cands, int* __restrict__ ncands,
+                                                   int* __restrict__ kpos) {
+    const int t = (int)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) cands[t] = src[t];
+    if (t == 0) *ncands = src[n];
+    if (t < npos) kpos[t] = src[n + 1 + t];
+}
+// down: [idx (n) | val (n) | control block | shares of ||r||^2 (nshare)] into the landing area
+__global__ __launch_bounds__(256) void k_land_ls(const int64_t* __restrict__ out_idx, const double* __restrict__ out_val, int n,
+                                                 const DevState* __restrict__ st, const double* __restrict__ rn2part, int nshare,
+                                                 int64_t* __restrict__ hi, double* __restrict__ hv, int* __restrict__ hst, double* __restrict__ hn2) {
+    const int t = (int)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) {
+        hi[t] = out_idx[t];
+        hv[t] = out_val[t];
+    }
+    if (t < (int)(sizeof(DevState) / sizeof(int))) hst[t] = reinterpret_cast<const int*>(st)[t];
+    if (t < nshare) hn2[t] = rn2part[t];
+}
+// down: the k selected atoms, their count and (screened selection) the certificate flag
+__global__ __launch_bounds__(256) void k_land_sel(const int* __restrict__ cands, const int* __restrict__ ncands, int k, const int* __restrict__ flag,
+                                                  int* __restrict__ dst) {
+    const int t = (int)blockIdx.x * 256 + threadIdx.x;
+    if (t < k) dst[t] = cands[t];
+    if (t == 0) {
+        dst[k] = *ncands;
+        dst[k + 1] = flag ? *flag : 0;
+    }
+}
+
 // R (n x n upper, leading dimension kcap), z = column n, support = cols, count = n -> the solver slot.  Nothing is
 // exported when the DGKS test failed anywhere (the host sees STOP_REORTH and falls back).
 __global__ __launch_bounds__(256) void k_gram_export(const double* __restrict__ G, int np, int n, const int* __restrict__ cols,

@@ -14,6 +14,7 @@ constexpr int kSWave = 64;
 constexpr int kBT = 128;         // tile edge: atoms x signals
 constexpr int kBK = 64;          // k elements staged per step
 constexpr int kTileCand = 4;     // candidates kept per (signal, atom tile)
+constexpr int kBatchMaxRows = 8192;  // rows of the dictionary the batched path's per-signal kernels hold (registers + LDS)
 constexpr size_t kScreenLds256 = 2 * 2 * 256 * 128;  // 2 buffers x (A 32 KiB + R 32 KiB) = 131,072 B
 
 // one screening launch: D = Ab Rb' in 256 x 256 tiles with the fused top-4-per-(signal, 128-atom tile) epilogue.

@@ -275,9 +275,20 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     if (!B || nsig < 1 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch_mfma: bad arguments");
     if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
-    if (ctx->Mv > 8192) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: M > 8192 not supported (use csmp_omp_batch)");
     if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
     HIPCHECK(hipSetDevice(ctx->dev));
+    if (ctx->Mv > kBatchMaxRows) {
+        // The per-signal kernels of this path keep a signal's column slice in registers and its residual in LDS (8 M bytes):
+        // beyond 8192 rows the contract -- csmp_omp_batch's results -- is met by csmp_omp_batch itself (exact sweeps, three signals
+        // in flight).  The statistics say so: no screening kernel, nothing re-solved.
+        Batch& b0 = ctx->bt;
+        b0.last_mode = 0;
+        b0.last_streams = 1;
+        b0.last_screen_signals = 0;
+        b0.last_signals = nsig;
+        b0.last_resolved = b0.last_uncertain = b0.last_illcond = 0;
+        return csmp_omp_batch(ctx, B, b_dtype, ldB, nsig, b_loc, k, eps, idx, val, nnz, out_loc);
+    }
     const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
     // Operands of the screen (CSMP_OPT_BATCH_SCREEN).  3 (default): binary16 images -- eleven significand bits: the rigorous bound is
     // 2^-10 |a||r| where bf16's is 2^-7.  0: bf16 images (the form of rounds 1-3).  1 / 2: int8 images (2: only where the dictionary is

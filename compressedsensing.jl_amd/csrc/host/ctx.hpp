@@ -5,6 +5,9 @@ static constexpr int kRsEqCap = 4096;   // entries of the bucket list (exact tie
 static constexpr int kRsSettle = 256;   // a bucket this small ends the passes (k_rs_finish ranks it in LDS)
 
 struct Solver {
+    std::vector<int> hpos;           // host-side atom -> position marks (whole-set solves' set algebra: host/gomp_sp.hpp)
+    std::vector<unsigned> hstamp;
+    unsigned hgen = 0;
     int kcap = 0, outcap = 0;
     int qcap = 0;  // capacity of the QR arrays: kcap, or 1 for a slot that so far served MP / sweep-only calls
     int64_t ldq = 0;

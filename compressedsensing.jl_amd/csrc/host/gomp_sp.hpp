@@ -342,6 +342,25 @@ static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols) {
 }
 
 // ---- whole-set least squares (csmp_gram.hpp): Gram matrix on the matrix cores + blocked Cholesky, no Q
+// atom -> position marks of the host-side set algebra (one generation per question; N entries, allocated on first use)
+static void marks_begin(csmp_ctx* ctx) {
+    Solver& s = ctx->s;
+    if (s.hstamp.size() != (size_t)ctx->N) {
+        s.hstamp.assign((size_t)ctx->N, 0u);
+        s.hpos.assign((size_t)ctx->N, 0);
+        s.hgen = 0;
+    }
+    if (++s.hgen == 0) {
+        std::fill(s.hstamp.begin(), s.hstamp.end(), 0u);
+        s.hgen = 1;
+    }
+}
+static inline void mark_put(csmp_ctx* ctx, int atom, int pos) {
+    ctx->s.hstamp[(size_t)atom] = ctx->s.hgen;
+    ctx->s.hpos[(size_t)atom] = pos;
+}
+static inline int mark_get(const csmp_ctx* ctx, int atom) { return ctx->s.hstamp[(size_t)atom] == ctx->s.hgen ? ctx->s.hpos[(size_t)atom] : -1; }
+
 static int gram_split_for(const csmp_ctx* ctx, int np) {
     // pieces of k_gram on or above the diagonal; the rows are split so that ONE round of workgroups (two per CU) covers them:
     // a second, partly filled round would cost as much as a full one
@@ -407,9 +426,7 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     for (int t = 0; t < n; ++t) pcols[t] = order[t];
     pcols[n] = n;
     for (int t = 0; t < nF; ++t) ppos[t] = posF[t];
-    HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)nF * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_put_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const int*)pcols, n, nF, s.cands, s.ncands, s.kpos);
     const int blk = 16;
     const int rps = (((M + nsplit - 1) / nsplit + blk - 1) / blk) * blk;
     const int64_t ldo = ((int64_t)M + 15) / 16 * 16;
@@ -493,23 +510,26 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         // The slot still holds the factor of a set F on this very b.  If F lies inside `cols` (and its Gram matrix inside the kept
         // one), only the new columns are factorised (ls_gram_extend_t).
         const int nF = (int)s.fac_cols.size();
-        if (nF >= 64 && nF < n && s.keep_valid && n <= s.kcap && s.tt_gen == s.fac_gen) {  // (tt_gen: (R_F^-1)' sits in s.Gm)
-            std::vector<std::pair<int, int>> where((size_t)s.keep_n);
-            for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
-            std::sort(where.begin(), where.end());
+        if (nF >= 64 && nF < n && s.keep_valid && n <= s.kcap && s.tt_gen == s.fac_gen &&  // (tt_gen: (R_F^-1)' sits in s.Gm)
+            std::is_sorted(cols.begin(), cols.end())) {
+            // (set algebra on atom marks: linear in the sets -- these lines sit on the solve's latency chain)
             std::vector<int> posF((size_t)nF);
             bool ok = true;
-            for (int t = 0; t < nF && ok; ++t) {
-                auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(s.fac_cols[t], 0));
-                ok = it != where.end() && it->first == s.fac_cols[t] && std::binary_search(cols.begin(), cols.end(), s.fac_cols[t]);
-                if (ok) posF[t] = it->second;
+            marks_begin(ctx);
+            for (int t = 0; t < s.keep_n; ++t) mark_put(ctx, s.keep_cols[t], t);
+            for (int t = 0; t < nF && ok; ++t) ok = (posF[t] = mark_get(ctx, s.fac_cols[t])) >= 0;  // F inside the kept set
+            if (ok) {
+                marks_begin(ctx);
+                for (int t = 0; t < n; ++t) mark_put(ctx, cols[t], t);
+                for (int t = 0; t < nF && ok; ++t) ok = mark_get(ctx, s.fac_cols[t]) >= 0;  // F inside cols
             }
-            if (ok && std::is_sorted(cols.begin(), cols.end())) {
+            if (ok) {
+                marks_begin(ctx);
+                for (int t = 0; t < nF; ++t) mark_put(ctx, s.fac_cols[t], t);
                 std::vector<int> order(s.fac_cols);
-                std::vector<int> fs(s.fac_cols);
-                std::sort(fs.begin(), fs.end());
+                order.reserve((size_t)n);
                 for (int c : cols)
-                    if (!std::binary_search(fs.begin(), fs.end(), c)) order.push_back(c);
+                    if (mark_get(ctx, c) < 0) order.push_back(c);
                 if ((int)order.size() == n) {
                     s.fac_pending = order;
                     return ls_gram_extend_t<TA>(ctx, order, nF, posF);
@@ -526,22 +546,15 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     int* ppos = pcols + n + 1;
     for (int t = 0; t < n; ++t) pcols[t] = cols[t];
     pcols[n] = n;
-    HIPCHECK(hipMemcpyAsync(s.cands, pcols, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(s.ncands, pcols + n, 4, hipMemcpyHostToDevice, ctx->stream));
     // A set inside the last computed one: its bordered Gram matrix is a principal submatrix of the kept one -- gathered, not recomputed
     bool subset = s.keep_valid && n <= s.keep_n;
     if (subset) {
-        std::vector<std::pair<int, int>> where((size_t)s.keep_n);
-        for (int t = 0; t < s.keep_n; ++t) where[t] = {s.keep_cols[t], t};
-        std::sort(where.begin(), where.end());
-        for (int t = 0; t < n && subset; ++t) {
-            auto it = std::lower_bound(where.begin(), where.end(), std::make_pair(cols[t], 0));
-            if (it == where.end() || it->first != cols[t]) subset = false;
-            else ppos[t] = it->second;
-        }
+        marks_begin(ctx);
+        for (int t = 0; t < s.keep_n; ++t) mark_put(ctx, s.keep_cols[t], t);
+        for (int t = 0; t < n && subset; ++t) subset = (ppos[t] = mark_get(ctx, cols[t])) >= 0;
     }
+    hipLaunchKernelGGL(k_put_lists, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const int*)pcols, n, subset ? n : 0, s.cands, s.ncands, s.kpos);
     if (subset) {
-        HIPCHECK(hipMemcpyAsync(s.kpos, ppos, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
         const int64_t nel = (int64_t)np * np + (int64_t)(npa - np) * npa;
         hipLaunchKernelGGL(k_gram_subset, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep, s.keep_np, s.keep_n,
                            (const double*)s.gdkeep, (const int*)s.kpos, n, np, s.Gm, s.gdiag, npa);
@@ -698,13 +711,13 @@ static int sp_job_select(SpJob& j, bool scr) {
     pnt[1] = 0;
     if (scr) {
         CHECK(sp_select_screened(ctx, k));
-        HIPCHECK(hipMemcpyAsync(pnt + 1, s.scr_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     } else {
         CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
         CHECK(launch_topS(ctx, k));
     }
-    HIPCHECK(hipMemcpyAsync(top, s.cands, (size_t)k * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipMemcpyAsync(pnt, s.ncands, 4, hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(k_land_sel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, (const int*)s.cands, (const int*)s.ncands, k,
+                       scr ? (const int*)s.scr_flag : (const int*)nullptr, top);  // [atoms | count | flag], written over the host link
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipEventRecord(j.ev, ctx->stream));
     return CSMP_OK;
 }
@@ -727,10 +740,10 @@ static int sp_job_ls(SpJob& j, bool want_norm) {
         double* pvv = (double*)(pi + n);
         DevState* phs = (DevState*)(pvv + n);
         double* pn2 = (double*)((char*)phs + ((sizeof(DevState) + 7) / 8) * 8);
-        HIPCHECK(hipMemcpyAsync(pi, s.out_idx, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(pvv, s.out_val, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(phs, s.st, sizeof(DevState), hipMemcpyDeviceToHost, ctx->stream));
-        if (want_norm) HIPCHECK(hipMemcpyAsync(pn2, s.rn2part, nshare * 8, hipMemcpyDeviceToHost, ctx->stream));
+        const int nthr = (int)std::max<size_t>(std::max(n, nshare), sizeof(DevState) / sizeof(int));
+        hipLaunchKernelGGL(k_land_ls, dim3((nthr + 255) / 256), dim3(256), 0, ctx->stream, (const int64_t*)s.out_idx, (const double*)s.out_val, (int)n,
+                           (const DevState*)s.st, (const double*)s.rn2part, want_norm ? (int)nshare : 0, pi, pvv, (int*)phs, pn2);
+        HIPCHECK(hipGetLastError());
     }
     HIPCHECK(hipEventRecord(j.ev, ctx->stream));
     return CSMP_OK;
@@ -783,11 +796,11 @@ static int sp_job_selected(SpJob& j, SpJob::Phase next) {
         }
     }
     const int nt = *pnt;
+    std::vector<int> mine(j.xi.begin(), j.xi.end()), fresh(top, top + nt);  // (the support comes sorted; the k best atoms by value)
+    std::sort(fresh.begin(), fresh.end());
+    fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
     j.cols.clear();
-    for (auto i : j.xi) j.cols.push_back((int)i);
-    for (int t = 0; t < nt; ++t) j.cols.push_back(top[t]);
-    std::sort(j.cols.begin(), j.cols.end());
-    j.cols.erase(std::unique(j.cols.begin(), j.cols.end()), j.cols.end());
+    std::set_union(mine.begin(), mine.end(), fresh.begin(), fresh.end(), std::back_inserter(j.cols));
     j.phase = next;
     return sp_job_ls(j, next == SpJob::LS_FIRST);
 }
@@ -833,7 +846,10 @@ static int sp_job_advance(SpJob& j) {
             if (drop > 0) {  // :78-81: delete the (nnz-k) smallest |coef|, ties by position
                 std::vector<int> pos(j.xi.size());
                 for (size_t t = 0; t < pos.size(); ++t) pos[t] = (int)t;
-                std::stable_sort(pos.begin(), pos.end(), [&](int a, int c) { return std::fabs(j.xv[a]) < std::fabs(j.xv[c]); });
+                std::nth_element(pos.begin(), pos.begin() + drop, pos.end(), [&](int a, int c) {  // (|coef|, position): a strict order
+                    const double fa = std::fabs(j.xv[a]), fc = std::fabs(j.xv[c]);
+                    return fa < fc || (fa == fc && a < c);
+                });
                 std::vector<char> kill(j.xi.size(), 0);
                 for (int64_t t = 0; t < drop; ++t) kill[pos[t]] = 1;
                 std::vector<int64_t> keep;
@@ -871,7 +887,12 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     SpJob& j = ctx->spjob;
     int rc = sp_job_begin(j, ctx, b, b_dtype, k, delta, maxiter);
     while (rc == CSMP_OK && j.phase != SpJob::DONE) {
-        HIPCHECK(hipEventSynchronize(j.ev));
+        // a phase lasts 0.1-1 ms and the solve resumes on this thread: poll (the wake-up of a blocking wait would sit on the chain
+        // five times per solve); something that takes far longer than a phase is waited for the ordinary way
+        hipError_t q = hipErrorNotReady;
+        for (int spin = 0; spin < 50000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(j.ev);
+        if (q == hipErrorNotReady) q = hipEventSynchronize(j.ev);
+        HIPCHECK(q);
         rc = sp_job_advance(j);
     }
     if (rc != CSMP_OK) return rc;

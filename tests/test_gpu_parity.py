@@ -563,6 +563,26 @@ def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype, mode):
     assert np.allclose(val, v2, rtol=1e-9, atol=1e-12)
 
 
+def test_batched_mfma_beyond_8192_rows_runs_the_exact_batch(cs, oracle, D):
+    """include/csmp.h: a dictionary of more than 8192 rows (the per-signal kernels' register/LDS budget) is not refused: the call
+    returns csmp_omp_batch's results (the contract) and reports that no screening kernel ran."""
+    n, m, k, nsig = 8200, 1024, 6, 5
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=5, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(6)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
+                                    for _ in range(nsig)], axis=1))
+    eps = float(np.finfo(np.float32).eps)
+    idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+    st = d.ctx.batch_stats()
+    assert st["signals"] == nsig and st["resolved_exactly"] == 0
+    assert d.ctx.batch_screen_kernel().startswith("none")
+    for s in range(nsig):
+        ref = oracle.omp(A, B[:, s], k, eps)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]) and close(val[:nnz[s], s], ref[1])
+    d.close()
+
+
 def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
     # noiseless 3-sparse signals, k = 8: every signal stops after 3 atoms (eps-stop inside k_b_step)
     A, x, b = cs.sparse_data(n=96, m=400, k=3, rng=1, dtype=np.float32)
