@@ -161,7 +161,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="rigorous", help="--workload batched: CSMP_OPT_BATCH_CERT (rigorous is the library's default)")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
-    p.add_argument("--workload", choices=["omp", "screened", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
+    p.add_argument("--workload", choices=["omp", "screened", "streamed", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -404,6 +404,37 @@ def measure_lone_omp(K, W, B, D, eps):
                          "frac": M * N * 4 / (us_atom * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                          "note": "ALL-IN: algorithmic bytes per atom / wall time per atom of the whole call (upload of b, sweep, both append "
                                  "stages, kernel boundaries, back substitution, download) -- not a kernel duration"}}
+
+
+def measure_streamed_omp(cs, torch, dev, At, D, B, eps, k=16, solves=2):
+    """SURVEY 8(f-4), second half: the configs[1] dictionary left in HOST memory (CSMP_HOST_STREAMED) -- what a dictionary larger
+    than HBM has to do: every sweep reads its M N 4 bytes over the host link.  k atoms per solve (a k = 256 solve would be 256 GiB
+    over the link); the support must be the resident dictionary's, atom for atom."""
+    import numpy as np
+    Ah = np.asfortranarray(At.cpu().numpy().T)  # (M, N) column-major host copy of the same dictionary
+    t0 = time.perf_counter()
+    Ds = cs.Dictionary(Ah, streamed=True)
+    t_map = time.perf_counter() - t0
+    sigs = [B[s].cpu().numpy() for s in range(solves + 1)]
+    Ds.ctx.omp(sigs[0], 2, eps)  # warm-up: two sweeps
+    same = True
+    t0 = time.perf_counter()
+    atoms = 0
+    res = []
+    for s in range(1, solves + 1):
+        res.append(Ds.ctx.omp(sigs[s], k, eps))
+        atoms += len(res[-1][0])
+    dt = time.perf_counter() - t0
+    for s in range(1, solves + 1):
+        i2, v2, o2 = D.ctx.omp(sigs[s], k, eps)
+        same = same and np.array_equal(res[s - 1][2], o2) and np.array_equal(res[s - 1][1], v2)
+    Ds.close()
+    gbs = atoms * M * N * 4 / dt / 1e9
+    return {"metric": "OMP atoms selected/sec at m=4096,n=65536 with the dictionary STREAMED from host memory (CSMP_HOST_STREAMED), k=%d" % k,
+            "value": atoms / dt, "unit": "atoms/s", "steps": solves, "warmup": 1, "ms_per_solve": dt / solves * 1e3,
+            "identical_to_resident_dictionary": bool(same), "map_seconds": t_map,
+            "roofline": {"bound": "host link (PCIe 5 x16)", "unit": "GB/s", "peak": 64.0, "achieved": gbs, "frac": gbs / 64.0, "traffic": None,
+                         "note": "ALL-IN: algorithmic bytes per atom (the dictionary once) / wall time per atom; peak = the link's raw 64 GB/s per direction"}}
 
 
 def measure_screened_omp(K, W, torch, dev, At, D, eps, cert=1, image=3):
@@ -926,6 +957,15 @@ def main():
                                       cert=1 if args.batch_cert == "rigorous" else 0, image={"f16": 3, "bf16": 1, "int8": 2}[args.screen_image]))
         D.close()
         return finish()
+    if args.workload == "streamed":
+        if rank == 0:
+            Bs = make_signals(torch, dev, At, 0, 4)
+            out = measure_streamed_omp(cs, torch, dev, At, D, Bs, D.eps, solves=3 if args.steps == 18 else max(1, min(args.steps, 3)))
+            out.update({"n_gpus": 1, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "ms_per_step": out["ms_per_solve"], "config": {"workload": "configs[1] dictionary (4096x65536 Float32, 1 GiB) in host memory, k=16"}})
+            emit(out)
+        D.close()
+        return finish()
     if args.workload == "batched":
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = 3, 1
@@ -1051,6 +1091,10 @@ def main():
                 sec["lone_omp_c2"] = measure_lone_omp(3, 1, B, D, eps)
             except Exception as e:  # noqa: BLE001
                 sec["lone_omp_c2"] = {"error": repr(e)}
+            try:  # the same dictionary left in host memory, every sweep over the host link
+                sec["omp_c2_streamed"] = measure_streamed_omp(cs, torch, dev, At, D, B, eps)
+            except Exception as e:  # noqa: BLE001
+                sec["omp_c2_streamed"] = {"error": repr(e)}
             try:  # opt-in: sweeps over the bf16 image with certified picks (same results, half the bytes)
                 sec["omp_c2_screened_f16"] = measure_screened_omp(6, 2, torch, dev, At, D, eps)  # (binary16 image, rigorous certificate)
                 sec["omp_c2_screened_int8"] = measure_screened_omp(6, 2, torch, dev, At, D, eps, cert=0, image=2)

@@ -12,9 +12,9 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
 
-OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM, ERCCL, EIO = 0, -1, -2, -3, -4, -5, -6, -7, -8
 F32, F64 = 0, 1
-HOST, DEVICE = 0, 1
+HOST, DEVICE, HOST_STREAMED = 0, 1, 2
 ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
 STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
 # csmp_set_option keys (include/csmp.h)
@@ -35,6 +35,9 @@ SIGNATURES = {
     "csmp_sync": (C.c_int, [vp]),
     "csmp_device_info": (C.c_int, [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(i64)]),
     "csmp_set_dictionary": (C.c_int, [vp, vp, i64, i64, i64, C.c_int, C.c_int]),
+    "csmp_dictionary_file_write": (C.c_int, [C.c_char_p, vp, i64, i64, i64, C.c_int]),
+    "csmp_dictionary_file_info": (C.c_int, [C.c_char_p, C.POINTER(i64), C.POINTER(i64), C.POINTER(C.c_int)]),
+    "csmp_set_dictionary_file": (C.c_int, [vp, C.c_char_p, C.c_int]),
     "csmp_clone": (C.c_int, [vp, C.POINTER(vp)]),
     "csmp_shard_config": (C.c_int, [vp, i64]),
     "csmp_shard_record_bytes": (i64, [vp]),
@@ -96,6 +99,29 @@ def comm_id():
     if rc != 0:
         raise CsmpError(rc, lib().csmp_last_error(None).decode())
     return buf.raw
+
+
+def write_dictionary_file(path, A):
+    """A (numpy, M x N, float32 / float64) -> a dictionary file (include/csmp.h: 64-byte header + the columns padded to 16 bytes).
+    Host only: no GPU is touched."""
+    A = np.asarray(A)
+    if A.ndim != 2 or A.dtype not in (np.float32, np.float64):
+        raise ValueError("A must be a float32 or float64 matrix")
+    if not A.flags.f_contiguous:
+        A = np.asfortranarray(A)
+    M, N = A.shape
+    rc = lib().csmp_dictionary_file_write(os.fsencode(path), ptr(A), i64(M), i64(N), i64(M), dtype_code(A.dtype))
+    if rc != 0:
+        raise CsmpError(rc, f"cannot write {path}")
+
+
+def dictionary_file_info(path):
+    """(M, N, numpy dtype) of a dictionary file."""
+    M, N, dt = i64(0), i64(0), C.c_int(0)
+    rc = lib().csmp_dictionary_file_info(os.fsencode(path), C.byref(M), C.byref(N), C.byref(dt))
+    if rc != 0:
+        raise CsmpError(rc, f"{path} is not a dictionary file")
+    return int(M.value), int(N.value), (np.float32 if dt.value == dtype_code(np.dtype(np.float32)) else np.float64)
 
 
 class CsmpError(RuntimeError):
@@ -186,18 +212,20 @@ class Context:
         self.check(getattr(lib(), name)(self._h, *args))
 
     # ---- dictionary
-    def set_dictionary(self, A):
+    def set_dictionary(self, A, streamed=False):
         """A: numpy array (host; copied once to HBM) or a torch CUDA tensor holding the
-        column-major dictionary as a (N, M) row-major tensor, i.e. `A_torch[j]` is atom j."""
+        column-major dictionary as a (N, M) row-major tensor, i.e. `A_torch[j]` is atom j.
+        streamed=True (numpy only): A stays in host memory, mapped into the device; every sweep crosses the host link
+        (CSMP_HOST_STREAMED: for a dictionary larger than HBM).  The array is kept alive by this object."""
         if isinstance(A, np.ndarray):
             if A.ndim != 2:
                 raise ValueError("A must be a matrix")
             if not A.flags.f_contiguous:
                 A = np.asfortranarray(A)
             M, N = A.shape
-            self.call("csmp_set_dictionary", ptr(A), i64(M), i64(N), i64(M), dtype_code(A.dtype), HOST)
+            self.call("csmp_set_dictionary", ptr(A), i64(M), i64(N), i64(M), dtype_code(A.dtype), HOST_STREAMED if streamed else HOST)
             self.dtype = A.dtype
-            self._keep = None
+            self._keep = A if streamed else None
         else:  # torch tensor on the GPU, shape (N, M): rows are atoms
             import torch
             if not (isinstance(A, torch.Tensor) and A.is_cuda and A.dim() == 2 and A.is_contiguous()):
@@ -210,6 +238,14 @@ class Context:
             self.dtype = np.dtype(dt)
             self._keep = A
         self.M, self.N = int(M), int(N)
+
+    def set_dictionary_file(self, path, streamed=False):
+        """A dictionary file (write_dictionary_file) read to where it will live: HBM, or mapped host memory (streamed=True)."""
+        M, N, dt = dictionary_file_info(path)
+        self.call("csmp_set_dictionary_file", os.fsencode(path), HOST_STREAMED if streamed else DEVICE)
+        self.dtype = np.dtype(dt)
+        self._keep = None
+        self.M, self.N = M, N
 
     def sync(self):
         self.call("csmp_sync")

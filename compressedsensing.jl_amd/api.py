@@ -32,9 +32,14 @@ from .sparsevec import SparseVector, spzeros
 class Dictionary:
     """The measurement matrix resident in HBM (the `A` field of MP/OMP/GOMP/SP)."""
 
-    def __init__(self, A, device=0):
+    def __init__(self, A, device=0, streamed=False):
+        """A: numpy matrix / torch CUDA tensor of atoms (see Context.set_dictionary), or the path of a dictionary file.
+        streamed=True: A stays in host memory and is read over the host link by every sweep -- a dictionary larger than HBM."""
         self.ctx = _lib.Context(device)
-        self.ctx.set_dictionary(A)
+        if isinstance(A, (str, bytes)) or hasattr(A, "__fspath__"):
+            self.ctx.set_dictionary_file(A, streamed=streamed)
+        else:
+            self.ctx.set_dictionary(A, streamed=streamed)
         self.shape = (self.ctx.M, self.ctx.N)
         self.dtype = np.dtype(self.ctx.dtype)
 

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <iterator>
+#include <iterator>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>

@@ -124,6 +124,7 @@ struct Batch {
 struct DictShare {
     void* p;
     int refs;
+    int kind = 0;  // how p is given back: 0 hipFree (HBM), 1 hipHostFree (library-owned page-locked memory), 2 hipHostUnregister (the caller's)
 };
 
 struct csmp_ctx;
@@ -157,6 +158,7 @@ struct csmp_ctx {
     void* dA = nullptr;
     bool ownA = false;
     struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
+    bool streamed = false;  // the dictionary lives in HOST memory mapped into the device's address space: every sweep crosses the host link
     csmp_ctx* twins[3] = {nullptr, nullptr, nullptr};  // clones on their own streams: the other solves in flight of csmp_gomp_batch / csmp_sp_batch
     int opt_in_flight = 3;        // CSMP_OPT_SOLVES_IN_FLIGHT (csmp_sp_batch)
     hipEvent_t ev_twin = nullptr;

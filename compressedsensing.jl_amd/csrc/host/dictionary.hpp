@@ -105,11 +105,8 @@ static int configure_sweep(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
-extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc) {
-    if (!ctx) return CSMP_EINVAL;
-    if (!A || M < 1 || N < 1 || ldA < M) return fail(ctx, CSMP_EDIM, "set_dictionary: need A != NULL, M,N >= 1, ldA >= M");
-    if (dtype != CSMP_F32 && dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "set_dictionary: dtype must be CSMP_F32 or CSMP_F64");
-    if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
+// the context lets go of its dictionary and of everything sized by it
+static int dict_forget(csmp_ctx* ctx) {
     HIPCHECK(hipSetDevice(ctx->dev));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     for (auto& t : ctx->twins) {  // (the twins of the batch drivers hold the previous dictionary)
@@ -123,13 +120,62 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
         solver_free(ctx->s);
     }
     batch_free(ctx->bt, false);
+    return CSMP_OK;
+}
+
+extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!A || M < 1 || N < 1 || ldA < M) return fail(ctx, CSMP_EDIM, "set_dictionary: need A != NULL, M,N >= 1, ldA >= M");
+    if (dtype != CSMP_F32 && dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "set_dictionary: dtype must be CSMP_F32 or CSMP_F64");
+    if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
+    if (loc != CSMP_HOST && loc != CSMP_DEVICE && loc != CSMP_HOST_STREAMED)
+        return fail(ctx, CSMP_EINVAL, "set_dictionary: loc must be CSMP_HOST, CSMP_DEVICE or CSMP_HOST_STREAMED");
+    CHECK(dict_forget(ctx));
     const size_t es = dtype == CSMP_F32 ? 4 : 8;
     const int vec = 16 / (int)es;
-    const bool borrow = loc == CSMP_DEVICE && ((uintptr_t)A % 16 == 0) && (M % vec == 0) && (ldA % vec == 0);
+    const bool aligned = ((uintptr_t)A % 16 == 0) && (M % vec == 0) && (ldA % vec == 0);
+    const bool borrow = loc == CSMP_DEVICE && aligned;
     ctx->dtype = dtype;
     ctx->M = M;
     ctx->N = N;
     ctx->col_offset = 0;
+    if (loc == CSMP_HOST_STREAMED) {
+        // The dictionary stays in HOST memory, page-locked and mapped into the device's address space; ctx->dA is its device
+        // alias, and every kernel that reads A (the sweeps, the column gathers of the appends) reads it over the host link.
+        // An aligned array is registered where it lies (no second copy in host memory: the point of the mode is a dictionary
+        // that does not fit anywhere twice); anything else gets a padded page-locked copy.
+        void* hostp = const_cast<void*>(A);
+        int kind = 2;
+        int64_t ld = ldA;
+        if (aligned) {
+            const hipError_t e = hipHostRegister(hostp, (size_t)ldA * (size_t)N * es, hipHostRegisterMapped | hipHostRegisterPortable);
+            if (e == hipErrorHostMemoryAlreadyRegistered) {
+                (void)hipGetLastError();
+                kind = -1;  // (page-locked by the caller already -- hipHostMalloc, or registered: nothing to undo later)
+            } else {
+                HIPCHECK(e);
+            }
+        } else {
+            ld = ((M + vec - 1) / vec) * vec;
+            HIPCHECK(hipHostMalloc(&hostp, (size_t)ld * (size_t)N * es, hipHostMallocMapped | hipHostMallocPortable));
+            kind = 1;
+            memset(hostp, 0, (size_t)ld * (size_t)N * es);
+            for (int64_t c = 0; c < N; ++c) memcpy((char*)hostp + (size_t)c * (size_t)ld * es, (const char*)A + (size_t)c * (size_t)ldA * es, (size_t)M * es);
+        }
+        void* dalias = nullptr;
+        const hipError_t e2 = hipHostGetDevicePointer(&dalias, hostp, 0);
+        if (e2 != hipSuccess) {
+            if (kind == 2) (void)hipHostUnregister(hostp);
+            if (kind == 1) (void)hipHostFree(hostp);
+            HIPCHECK(e2);
+        }
+        ctx->dA = dalias;
+        ctx->ld = ld;
+        ctx->Mv = aligned ? (int)M : (int)ld;
+        if (kind >= 1) ctx->share = new DictShare{hostp, 1, kind};
+        ctx->streamed = true;
+        return configure_sweep(ctx);
+    }
     if (borrow) {
         ctx->dA = const_cast<void*>(A);
         ctx->ld = ldA;
@@ -147,6 +193,150 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
         HIPCHECK(hipMemcpy2DAsync(d, (size_t)ld * es, A, (size_t)ldA * es, (size_t)M * es, (size_t)N,
                                   loc == CSMP_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return configure_sweep(ctx);
+}
+
+// ------------------------------------------------------------------------------------------ dictionary files
+// SURVEY §8(f-4), second half: a dictionary on disk, and one larger than HBM.  The file is the array as the kernels want it --
+// a 64-byte header, then N columns of ld elements each (ld = M rounded up to 16 bytes, the padding zero), little-endian IEEE:
+//     bytes 0-7 "CSMPDICT" | u32 version = 1 | u32 dtype (CSMP_F32 / CSMP_F64) | i64 M | i64 N | i64 ld | 24 bytes zero
+// csmp_set_dictionary_file reads it straight to where it will live: HBM (CSMP_DEVICE: through two page-locked staging buffers,
+// the read of one chunk under the upload of the other) or page-locked host memory mapped into the device (CSMP_HOST_STREAMED:
+// every sweep then crosses the host link -- ~50 GB/s against HBM's 6.6 TB/s; the mode for a dictionary that does not fit).
+struct DictFileHeader {
+    char magic[8];
+    uint32_t version, dtype;
+    int64_t M, N, ld;
+    char pad[24];
+};
+static_assert(sizeof(DictFileHeader) == 64, "header layout");
+
+extern "C" int csmp_dictionary_file_write(const char* path, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype) {
+    if (!path || !A || M < 1 || N < 1 || ldA < M || (dtype != CSMP_F32 && dtype != CSMP_F64)) return CSMP_EINVAL;
+    const size_t es = dtype == CSMP_F32 ? 4 : 8;
+    const int64_t vec = 16 / (int64_t)es, ld = ((M + vec - 1) / vec) * vec;
+    FILE* f = fopen(path, "wb");
+    if (!f) return CSMP_EIO;
+    DictFileHeader h{};
+    memcpy(h.magic, "CSMPDICT", 8);
+    h.version = 1;
+    h.dtype = (uint32_t)dtype;
+    h.M = M;
+    h.N = N;
+    h.ld = ld;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    const char zeros[16] = {0};
+    for (int64_t c = 0; c < N && ok; ++c) {
+        ok = fwrite((const char*)A + (size_t)c * (size_t)ldA * es, es, (size_t)M, f) == (size_t)M;
+        if (ok && ld > M) ok = fwrite(zeros, es, (size_t)(ld - M), f) == (size_t)(ld - M);
+    }
+    ok = (fclose(f) == 0) && ok;
+    return ok ? CSMP_OK : CSMP_EIO;
+}
+
+static int dict_file_open(const char* path, FILE** out, DictFileHeader* h) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return CSMP_EIO;
+    if (fread(h, sizeof *h, 1, f) != 1 || memcmp(h->magic, "CSMPDICT", 8) != 0 || h->version != 1 ||
+        (h->dtype != (uint32_t)CSMP_F32 && h->dtype != (uint32_t)CSMP_F64) || h->M < 1 || h->N < 1 || h->ld < h->M ||
+        (h->ld * (h->dtype == (uint32_t)CSMP_F32 ? 4 : 8)) % 16 != 0) {
+        fclose(f);
+        return CSMP_EIO;
+    }
+    *out = f;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_dictionary_file_info(const char* path, int64_t* M, int64_t* N, int* dtype) {
+    if (!path) return CSMP_EINVAL;
+    FILE* f = nullptr;
+    DictFileHeader h;
+    const int rc = dict_file_open(path, &f, &h);
+    if (rc != CSMP_OK) return rc;
+    fclose(f);
+    if (M) *M = h.M;
+    if (N) *N = h.N;
+    if (dtype) *dtype = (int)h.dtype;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_set_dictionary_file(csmp_ctx* ctx, const char* path, int loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!path) return fail(ctx, CSMP_EINVAL, "set_dictionary_file: path == NULL");
+    if (loc != CSMP_DEVICE && loc != CSMP_HOST_STREAMED)
+        return fail(ctx, CSMP_EINVAL, "set_dictionary_file: loc must be CSMP_DEVICE (resident in HBM) or CSMP_HOST_STREAMED");
+    FILE* f = nullptr;
+    DictFileHeader h;
+    if (dict_file_open(path, &f, &h) != CSMP_OK) return fail(ctx, CSMP_EIO, std::string("set_dictionary_file: cannot read a dictionary from ") + path);
+    struct Closer {
+        FILE* f;
+        ~Closer() { if (f) fclose(f); }
+    } closer{f};
+    if (h.M > (int64_t)1 << 30 || h.N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary_file: M or N too large");
+    const size_t es = h.dtype == (uint32_t)CSMP_F32 ? 4 : 8;
+    const size_t total = (size_t)h.ld * (size_t)h.N * es;
+    CHECK(dict_forget(ctx));
+    ctx->dtype = (int)h.dtype;
+    ctx->M = h.M;
+    ctx->N = h.N;
+    ctx->col_offset = 0;
+    ctx->ld = h.ld;
+    ctx->Mv = (int)h.ld;  // (the padding rows are zero in the file)
+    if (loc == CSMP_HOST_STREAMED) {
+        void* hostp = nullptr;
+        HIPCHECK(hipHostMalloc(&hostp, total, hipHostMallocMapped | hipHostMallocPortable));
+        size_t got = 0;
+        while (got < total) {
+            const size_t n = fread((char*)hostp + got, 1, std::min<size_t>(total - got, (size_t)64 << 20), f);
+            if (n == 0) break;
+            got += n;
+        }
+        void* dalias = nullptr;
+        const hipError_t e2 = got == total ? hipHostGetDevicePointer(&dalias, hostp, 0) : hipSuccess;
+        if (got != total || e2 != hipSuccess) {
+            (void)hipHostFree(hostp);
+            if (got != total) return fail(ctx, CSMP_EIO, "set_dictionary_file: file shorter than its header says");
+            HIPCHECK(e2);
+        }
+        ctx->dA = dalias;
+        ctx->share = new DictShare{hostp, 1, 1};
+        ctx->streamed = true;
+        return configure_sweep(ctx);
+    }
+    void* d = nullptr;
+    HIPCHECK(hipMalloc(&d, total));
+    ctx->dA = d;
+    ctx->ownA = true;
+    ctx->share = new DictShare{d, 1, 0};
+    const size_t chunk = std::min<size_t>(total, (size_t)64 << 20);
+    void* stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = CSMP_OK;
+    auto cleanup = [&]() {
+        for (int q = 0; q < 2; ++q) {
+            if (stage[q]) (void)hipHostFree(stage[q]);
+            if (done[q]) (void)hipEventDestroy(done[q]);
+        }
+    };
+    for (int q = 0; q < 2 && rc == CSMP_OK; ++q) {
+        if (hipHostMalloc(&stage[q], chunk, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&done[q], hipEventDisableTiming) != hipSuccess)
+            rc = fail(ctx, CSMP_ENOMEM, "set_dictionary_file: no page-locked staging memory");
+    }
+    size_t off = 0;
+    for (int q = 0; rc == CSMP_OK && off < total; q ^= 1) {
+        if (hipEventSynchronize(done[q]) != hipSuccess) { rc = fail(ctx, CSMP_EHIP, "set_dictionary_file: staging event"); break; }  // (buffer q's previous upload)
+        const size_t want = std::min(chunk, total - off);
+        if (fread(stage[q], 1, want, f) != want) { rc = fail(ctx, CSMP_EIO, "set_dictionary_file: file shorter than its header says"); break; }
+        if (hipMemcpyAsync((char*)d + off, stage[q], want, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipEventRecord(done[q], ctx->stream) != hipSuccess) { rc = fail(ctx, CSMP_EHIP, "set_dictionary_file: upload"); break; }
+        off += want;
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (rc != CSMP_OK) {
+        dict_release(ctx);
+        return rc;
     }
     return configure_sweep(ctx);
 }

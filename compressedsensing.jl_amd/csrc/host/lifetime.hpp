@@ -83,12 +83,15 @@ static void solver_free(Solver& s) {
 
 static void dict_release(csmp_ctx* ctx) {
     if (ctx->share && --ctx->share->refs == 0) {
-        (void)hipFree(ctx->share->p);
+        if (ctx->share->kind == 0) (void)hipFree(ctx->share->p);
+        else if (ctx->share->kind == 1) (void)hipHostFree(ctx->share->p);
+        else (void)hipHostUnregister(ctx->share->p);
         delete ctx->share;
     }
     ctx->share = nullptr;
     ctx->dA = nullptr;
     ctx->ownA = false;
+    ctx->streamed = false;
 }
 
 extern "C" int csmp_destroy(csmp_ctx* ctx) {

@@ -77,6 +77,7 @@ extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     c->ownA = false;
     c->share = src->share;  // (null for a borrowed device pointer: the caller keeps that alive)
     if (c->share) c->share->refs += 1;
+    c->streamed = src->streamed;
     copy_options(c, src);
     c->dtype = src->dtype;
     c->M = src->M;

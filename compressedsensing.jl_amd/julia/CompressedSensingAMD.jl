@@ -17,7 +17,7 @@ using Random
 const libcsmp = get(ENV, "LIBCSMP", joinpath(@__DIR__, "..", "csrc", "libcsmp.so"))
 
 const CSMP_F32, CSMP_F64 = Cint(0), Cint(1)
-const CSMP_HOST = Cint(0)
+const CSMP_HOST, CSMP_DEVICE, CSMP_HOST_STREAMED = Cint(0), Cint(1), Cint(2)
 const ALGO_MP, ALGO_OMP, ALGO_GOMP = Cint(0), Cint(1), Cint(2)
 
 dtype_code(::Type{Float32}) = CSMP_F32
@@ -25,26 +25,55 @@ dtype_code(::Type{Float64}) = CSMP_F64
 
 # ---------------------------------------------------------------------------------- context
 """
-    Dictionary(A; device = 0)
+    Dictionary(A; device = 0, streamed = false)
+    Dictionary(path::AbstractString; device = 0, streamed = false)
 
 The measurement matrix resident in HBM (uploaded once).  Stands in for the `A` field of the
-reference's MP / OMP / GOMP / SP structs.
+reference's MP / OMP / GOMP / SP structs.  `streamed = true` leaves it in host memory, mapped into the
+device: every sweep reads it over the host link -- for a dictionary larger than HBM (the array is kept
+alive by the object and must not be changed).  `path`: a dictionary file (`write_dictionary_file`).
 """
 mutable struct Dictionary{T<:Union{Float32,Float64}}
     ctx::Ptr{Cvoid}
     n::Int   # rows  (reference: n, m = size(A), src/matchingpursuit.jl:20)
     m::Int   # atoms
-    function Dictionary(A::StridedMatrix{T}; device::Integer = 0) where {T<:Union{Float32,Float64}}
+    keep::Any  # a streamed array, held for the context's lifetime
+    function Dictionary{T}(n::Integer, m::Integer, device::Integer) where {T<:Union{Float32,Float64}}
         ref = Ref{Ptr{Cvoid}}(C_NULL)
         rc = ccall((:csmp_create, libcsmp), Cint, (Ref{Ptr{Cvoid}}, Cint), ref, device)
         rc == 0 || throw(unsafe_string(ccall((:csmp_last_error, libcsmp), Cstring, (Ptr{Cvoid},), C_NULL)))
-        D = new{T}(ref[], size(A, 1), size(A, 2))
+        D = new{T}(ref[], n, m, nothing)
         finalizer(d -> ccall((:csmp_destroy, libcsmp), Cint, (Ptr{Cvoid},), d.ctx), D)
-        GC.@preserve A check(D, ccall((:csmp_set_dictionary, libcsmp), Cint,
-            (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint),
-            D.ctx, pointer(A), size(A, 1), size(A, 2), stride(A, 2), dtype_code(T), CSMP_HOST))
         return D
     end
+end
+function Dictionary(A::StridedMatrix{T}; device::Integer = 0, streamed::Bool = false) where {T<:Union{Float32,Float64}}
+    D = Dictionary{T}(size(A, 1), size(A, 2), device)
+    GC.@preserve A check(D, ccall((:csmp_set_dictionary, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int64, Int64, Cint, Cint),
+        D.ctx, pointer(A), size(A, 1), size(A, 2), stride(A, 2), dtype_code(T), streamed ? CSMP_HOST_STREAMED : CSMP_HOST))
+    streamed && (D.keep = A)
+    return D
+end
+function Dictionary(path::AbstractString; device::Integer = 0, streamed::Bool = false)
+    n, m, dt = Ref{Int64}(0), Ref{Int64}(0), Ref{Cint}(0)
+    rc = ccall((:csmp_dictionary_file_info, libcsmp), Cint, (Cstring, Ref{Int64}, Ref{Int64}, Ref{Cint}), path, n, m, dt)
+    rc == 0 || throw("$path is not a dictionary file")
+    D = Dictionary{dt[] == CSMP_F32 ? Float32 : Float64}(n[], m[], device)
+    check(D, ccall((:csmp_set_dictionary_file, libcsmp), Cint, (Ptr{Cvoid}, Cstring, Cint), D.ctx, path, streamed ? CSMP_HOST_STREAMED : CSMP_DEVICE))
+    return D
+end
+
+"""
+    write_dictionary_file(path, A)
+
+`A` as a dictionary file (include/csmp.h: a 64-byte header and the columns, padded to 16 bytes); host only.
+"""
+function write_dictionary_file(path::AbstractString, A::StridedMatrix{T}) where {T<:Union{Float32,Float64}}
+    rc = GC.@preserve A ccall((:csmp_dictionary_file_write, libcsmp), Cint, (Cstring, Ptr{Cvoid}, Int64, Int64, Int64, Cint),
+        path, pointer(A), size(A, 1), size(A, 2), stride(A, 2), dtype_code(T))
+    rc == 0 || throw("cannot write $path")
+    return path
 end
 Base.size(D::Dictionary) = (D.n, D.m)
 Base.size(D::Dictionary, i::Int) = size(D)[i]

@@ -38,10 +38,12 @@ extern "C" {
 #define CSMP_ESTATE (-5) /* no dictionary set / no solver begun */
 #define CSMP_ENOMEM (-6)
 #define CSMP_ERCCL (-7)  /* RCCL could not be loaded, or a communicator / collective call failed */
+#define CSMP_EIO (-8)    /* a dictionary file could not be read or written */
 #define CSMP_F32 0
 #define CSMP_F64 1
 #define CSMP_HOST 0
 #define CSMP_DEVICE 1
+#define CSMP_HOST_STREAMED 2 /* csmp_set_dictionary / csmp_set_dictionary_file only: the dictionary stays in host memory (below) */
 
 #define CSMP_ALGO_MP 0
 #define CSMP_ALGO_OMP 1
@@ -72,6 +74,20 @@ int csmp_device_info(csmp_ctx *ctx, char *name, int name_len, int *compute_units
  * src/twostage.jl:42-61).  Uploaded once, stays resident in HBM.  A CSMP_DEVICE pointer that is
  * 16-byte aligned with M and ldA multiples of 16 bytes is borrowed without a copy. */
 int csmp_set_dictionary(csmp_ctx *ctx, const void *A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc);
+/* A dictionary LARGER THAN HBM (not in the reference, whose A is whatever the host's memory holds):
+ * loc = CSMP_HOST_STREAMED leaves A in HOST memory, page-locked and mapped into the device's address space, and every kernel that
+ * reads A -- the sweeps, the column gathers of the appends -- reads it over the host link (PCIe 5 x16: ~50 GB/s against
+ * 6.6 TB/s from HBM; the results are those of the resident dictionary, bit for bit).  A 16-byte aligned array with M and ldA
+ * multiples of 16 bytes is registered where it lies (hipHostRegister: no second copy; the caller keeps it alive and unchanged
+ * until the context is destroyed or given another dictionary); anything else is copied into page-locked memory of the library's.
+ *
+ * Dictionary files: a 64-byte header ("CSMPDICT", u32 version 1, u32 dtype, i64 M, i64 N, i64 ld, 24 zero bytes) followed by
+ * the N columns, ld elements each (M rounded up to 16 bytes, zero padded), little-endian.  csmp_dictionary_file_write writes one
+ * from host memory; csmp_set_dictionary_file reads one to where it will live -- HBM (loc = CSMP_DEVICE: chunked upload, the file
+ * never sits in host memory whole) or mapped host memory (loc = CSMP_HOST_STREAMED). */
+int csmp_dictionary_file_write(const char *path, const void *A, int64_t M, int64_t N, int64_t ldA, int dtype);
+int csmp_dictionary_file_info(const char *path, int64_t *M, int64_t *N, int *dtype);
+int csmp_set_dictionary_file(csmp_ctx *ctx, const char *path, int loc);
 /* A second context on the same GPU that borrows (does not copy) src's resident dictionary: the reference's P
  * objects are independent of one another and share only A -- P1 = OMP(A, b1); P2 = OMP(A, b2)
  * (src/matchingpursuit.jl:44-60) -- so every step-level solver (csmp_solver_begin) that must live beside

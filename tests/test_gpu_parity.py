@@ -563,6 +563,46 @@ def test_batched_mfma_matches_oracle(cs, oracle, D, shape, dtype, mode):
     assert np.allclose(val, v2, rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("shape", [(64, 512, 8, np.float32), (50, 301, 5, np.float64), (256, 2048, 24, np.float32)])
+def test_streamed_dictionary_and_dictionary_files(cs, oracle, shape, tmp_path):
+    """SURVEY §8(f-4), second half: a dictionary that stays in HOST memory (CSMP_HOST_STREAMED: every kernel reads A over the host
+    link -- the mode for a dictionary larger than HBM) and dictionary files read into HBM or into mapped host memory.  All of them
+    must return what the resident dictionary returns: the oracle's supports, coefficients to the north_star tolerance -- for omp,
+    gomp, sp and the batched path.  (64 / 256 rows: the array is registered where it lies; 50 rows: padded page-locked copy.)"""
+    n, m, k, dtype = shape
+    eps = float(np.finfo(dtype).eps)
+    A, x, b = cs.sparse_data(n=n, m=m, k=k, rng=3 * n + m, dtype=dtype)
+    path = str(tmp_path / "dict.csmp")
+    cs.write_dictionary_file(path, A)
+    assert cs.dictionary_file_info(path) == (n, m, dtype)
+    variants = {"resident": cs.Dictionary(A), "streamed": cs.Dictionary(A, streamed=True),
+                "file_resident": cs.Dictionary(path), "file_streamed": cs.Dictionary(path, streamed=True)}
+    ref = oracle.omp(A, b, k, eps)
+    refg = oracle.gomp(A, b, 2, k, eps)
+    refs = oracle.sp(A, b, min(k, n // 2), 1e-9)
+    rng = np.random.default_rng(n)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, k, rng=rng).to_dense(), 5e-3, rng=rng)
+                                    for _ in range(4)], axis=1))
+    base = None
+    for name, d in variants.items():
+        assert d.shape == (n, m) and d.dtype == np.dtype(dtype), name
+        g = d.ctx.omp(b, k, eps)
+        assert np.array_equal(g[0], ref[0]) and close(g[1], ref[1]), name
+        gg = d.ctx.gomp(b, 2, k, eps)
+        assert np.array_equal(gg[0], refg[0]) and close(gg[1], refg[1]), name
+        gs = d.ctx.sp(b, min(k, n // 2), 1e-9)
+        assert np.array_equal(gs[0], refs[0]) and close(gs[1], refs[1]), name
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+        if base is None:
+            base = (idx, val, nnz)
+        else:  # bit for bit the resident dictionary's results
+            assert np.array_equal(idx, base[0]) and np.array_equal(nnz, base[2]) and np.array_equal(val, base[1]), name
+    for d in variants.values():
+        d.close()
+    with pytest.raises(cs.CsmpError):
+        cs.Dictionary(str(tmp_path / "missing.csmp"))
+
+
 def test_batched_mfma_beyond_8192_rows_runs_the_exact_batch(cs, oracle, D):
     """include/csmp.h: a dictionary of more than 8192 rows (the per-signal kernels' register/LDS budget) is not refused: the call
     returns csmp_omp_batch's results (the contract) and reports that no screening kernel ran."""

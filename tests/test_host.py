@@ -90,3 +90,28 @@ def test_signal_sharding_wire_layout_helpers(cs):
     assert np.array_equal(packed, sh.pack(idx.T, val.T, nnz))
     i2, v2, n2 = L.unpack_results(packed, k)
     assert np.array_equal(i2, idx) and np.array_equal(v2, val) and np.array_equal(n2, nnz)
+
+
+def test_dictionary_file_format_round_trip(cs, tmp_path):
+    """include/csmp.h: 64-byte header ("CSMPDICT", version, dtype, M, N, ld) + the columns padded to 16 bytes.  Host-only entry
+    points of the library (no GPU is touched)."""
+    import struct
+    rng = np.random.default_rng(0)
+    for dtype, M, N in [(np.float32, 5, 7), (np.float64, 6, 3), (np.float32, 8, 2)]:
+        A = np.asfortranarray(rng.standard_normal((M, N)).astype(dtype))
+        path = str(tmp_path / f"d_{M}_{N}.csmp")
+        cs.write_dictionary_file(path, A)
+        es = np.dtype(dtype).itemsize
+        vec = 16 // es
+        ld = (M + vec - 1) // vec * vec
+        raw = open(path, "rb").read()
+        assert len(raw) == 64 + ld * N * es
+        magic, version, code, m_, n_, ld_ = struct.unpack("<8sIIqqq", raw[:40])
+        assert magic == b"CSMPDICT" and version == 1 and (m_, n_, ld_) == (M, N, ld) and raw[40:64] == bytes(24)
+        body = np.frombuffer(raw[64:], dtype=dtype).reshape(N, ld)
+        assert np.array_equal(body[:, :M].T, A) and not body[:, M:].any()
+        assert cs.dictionary_file_info(path) == (M, N, dtype)
+    bad = tmp_path / "bad.csmp"
+    bad.write_bytes(b"not a dictionary" * 8)
+    with pytest.raises(cs.CsmpError):
+        cs.dictionary_file_info(str(bad))
