@@ -569,8 +569,8 @@ __global__ __launch_bounds__(256) void k_ext_reduce(const double* __restrict__ G
 // x = R^-1 z as a product with the explicit inverse the augmented factorisation left: x_j = sum_{t >= j} Tt[t, j] z_t (column j of
 // Tt = (R^-1)', contiguous), one wave per coefficient -- instead of the back substitution's chain of 256-column super-blocks.
 __global__ __launch_bounds__(256) void k_tt_gemv(const double* __restrict__ Tt, int ldt, const double* __restrict__ z, const DevState* st,
-                                                 int n, double* __restrict__ x) {
-    if (st->nsel != n) return;  // (nothing was exported: the set failed its DGKS test)
+                                                 int n, double* __restrict__ x, int nsel) {
+    if (st->nsel != nsel) return;  // (nothing was exported: the set failed its DGKS test)
     const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= n) return;
     const double* col = Tt + (int64_t)j * ldt;
@@ -639,10 +639,12 @@ __global__ __launch_bounds__(256) void k_wgemm(const double* __restrict__ Tt, in
 
 // The Schur complement, bordered: G2 (np2 x np2, the layout k_chol_* expects) = [G_NN c_N; . .] - sum of k_gram<double>'s
 // partials of [W z_F]'[W z_F]; identity on the padding diagonal; gdiag2 = diag(G_NN) = |a_j|^2 (the DGKS reference).
+// npa2 > np2: augmented by the unit vectors like k_gram_reduce's matrix -- (R_C^-1)' comes out beside R_C.
 __global__ __launch_bounds__(256) void k_schur_reduce(const double* __restrict__ Knew, int np, int nF, int nN, int np2,
                                                       const double* __restrict__ Wpart, int nsplit, double* __restrict__ G2,
-                                                      double* __restrict__ gdiag2) {
+                                                      double* __restrict__ gdiag2, int npa2) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gram_aug_entry(e - (int64_t)np2 * np2 + (int64_t)np2 * npa2, np2, npa2, nN, G2)) return;
     if (e >= (int64_t)np2 * np2) return;
     const int row = (int)(e % np2), col = (int)(e / np2);
     if ((row / kGramTile) > (col / kGramTile)) return;
@@ -656,7 +658,28 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double* __restrict__
     } else if (row == col) {
         s = 1.0;
     }
-    G2[e] = s;
+    G2[row + (int64_t)col * npa2] = s;
+}
+
+// y = z_F - W x_N (the coupling of the bordered extension's back substitution: x_F = R_F^-1 y); rows in 64s, four column
+// phases per row summed through LDS in a fixed order
+__global__ __launch_bounds__(256) void k_wx(const double* __restrict__ Wb, int ldw, int nF, int nN, const double* __restrict__ z,
+                                            const double* __restrict__ xN, const DevState* st, int nsel, double* __restrict__ y) {
+    if (st->nsel != nsel) return;
+    __shared__ double part[4][64];
+    const int r = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + r;
+    double a0 = 0.0, a1 = 0.0;
+    if (i < nF) {
+        int j = g;
+        for (; j + 4 < nN; j += 8) {
+            a0 = fma(Wb[i + (int64_t)j * ldw], xN[j], a0);
+            a1 = fma(Wb[i + (int64_t)(j + 4) * ldw], xN[j + 4], a1);
+        }
+        if (j < nN) a0 = fma(Wb[i + (int64_t)j * ldw], xN[j], a0);
+    }
+    part[g][r] = a0 + a1;
+    __syncthreads();
+    if (g == 0 && i < nF) y[i] = z[i] - (((part[0][r] + part[1][r]) + part[2][r]) + part[3][r]);
 }
 
 // R_T's new blocks into the solver slot: W (rows of F, columns of N), R_C, z_N, the new atoms; count = nF + nN.

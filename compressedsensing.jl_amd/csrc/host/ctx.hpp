@@ -52,7 +52,7 @@ struct Solver {
     int* tmeta = nullptr;
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
-    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr, *Dfac = nullptr;
+    double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr, *Dfac = nullptr, *Gm2 = nullptr, *ytmp = nullptr;
     // the last bordered Gram matrix that was COMPUTED (before its factorisation), for the sets that are subsets of it: SP solves
     // on T = S + k new atoms and then on the k atoms of T it keeps -- the second system is a principal submatrix of the first
     double *Gkeep = nullptr, *gdkeep = nullptr, *rhs_part = nullptr, *rn2part = nullptr;
@@ -158,6 +158,8 @@ struct csmp_ctx {
     void* dA = nullptr;
     bool ownA = false;
     struct DictShare* share = nullptr;  // library-owned dictionary memory, shared with the clones (reference counted)
+    hipEvent_t* gate = nullptr;  // csmp_sp_batch: the completion of the most recently enqueued sweep of ANY solve in flight (owned by the parent)
+    hipEvent_t ev_gate = nullptr;
     bool streamed = false;  // the dictionary lives in HOST memory mapped into the device's address space: every sweep crosses the host link
     csmp_ctx* twins[3] = {nullptr, nullptr, nullptr};  // clones on their own streams: the other solves in flight of csmp_gomp_batch / csmp_sp_batch
     int opt_in_flight = 3;        // CSMP_OPT_SOLVES_IN_FLIGHT (csmp_sp_batch)

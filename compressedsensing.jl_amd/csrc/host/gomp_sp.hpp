@@ -379,7 +379,7 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     np = std::max(np, s.gram_np);
     nsplit = std::max(nsplit, s.gram_split);
     dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
-    dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin);
+    dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin); dfree(s.Gm2); dfree(s.ytmp);
     s.gram_np = s.gram_split = 0;
     s.keep_valid = false;
     s.fac_valid = false;
@@ -393,6 +393,8 @@ static int gram_ensure(csmp_ctx* ctx, int np, int nsplit) {
     CHECK(dmalloc(ctx, &s.rn2part, (size_t)(ctx->M + 255) / 256));
     CHECK(dmalloc(ctx, &s.rhs_part, (size_t)np * (size_t)(((ctx->M + 15) / 16 * 16 + 255) / 256)));
     CHECK(dmalloc(ctx, &s.Gm, (size_t)np * np));
+    CHECK(dmalloc(ctx, &s.Gm2, (size_t)np * np));  // the extension's Schur complement is factorised here: (R_F^-1)' stays in Gm for its back substitution
+    CHECK(dmalloc(ctx, &s.ytmp, (size_t)np));
     CHECK(dmalloc(ctx, &s.Dfac, (size_t)np * kCholNB));  // the factored diagonal blocks (chol_row_body)
     CHECK(dmalloc(ctx, &s.Gpart, (size_t)nsplit * np * np));
     CHECK(dmalloc(ctx, &s.gdiag, (size_t)np));
@@ -451,27 +453,34 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     const int rps2 = (((ldw + nsplit2 - 1) / nsplit2 + blk - 1) / blk) * blk;
     hipLaunchKernelGGL(k_gram<double>, dim3(np2 / kGramWgJ, (np2 + kGramWgI - 1) / kGramWgI, nsplit2), dim3(256), 0, ctx->stream, (const double*)s.Wb,
                        (int64_t)ldw, np2, rps2, s.Gpart, 0);
-    const int64_t nel2 = (int64_t)np2 * np2;
+    // The Schur complement is factorised AUGMENTED by the unit vectors too (room permitting), in a buffer of its own: with
+    // (R_C^-1)' beside R_C and (R_F^-1)' still in s.Gm the solution is three products -- x_N = R_C^-1 z_N, y = z_F - W x_N,
+    // x_F = R_F^-1 y -- instead of the back substitution's chain over all n columns (four 256-column super-blocks at n = 1024).
+    const int npa2c = ((np2 + nN + kGramTile - 1) / kGramTile) * kGramTile;
+    const bool aug2 = npa2c <= s.gram_np;
+    const int npa2 = aug2 ? npa2c : np2;
+    double* G2 = aug2 ? s.Gm2 : s.Gm;
+    const int64_t nel2 = (int64_t)np2 * np2 + (int64_t)(npa2 - np2) * npa2;
     hipLaunchKernelGGL(k_schur_reduce, dim3((unsigned)((nel2 + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gkeep2, np, nF, nN, np2,
-                       (const double*)s.Gpart, nsplit2, s.Gm, s.gdiag);
+                       (const double*)s.Gpart, nsplit2, G2, s.gdiag, npa2);
     HIPCHECK(hipGetLastError());
     const int nsteps = (nN + kCholNB - 1) / kCholNB;
     {
-        const int left0 = np2 - kCholNB;
-        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, s.Gm, np2, nN,
+        const int left0 = npa2 - kCholNB;
+        hipLaunchKernelGGL(k_chol_row, dim3(std::max(1, (left0 + kCholRowCols - 1) / kCholRowCols)), dim3(kCholThreads), 0, ctx->stream, G2, npa2, nN,
                            0, (const double*)s.gdiag, s.st, s.Dfac);
     }
     for (int kb = 0; kb + 1 < nsteps; ++kb) {
-        const int left = np2 - (kb + 1) * kCholNB;
+        const int left = npa2 - (kb + 1) * kCholNB;
         const int left2 = left - kCholNB;
         const int Tt = (left + kGramTile - 1) / kGramTile;
         const int ntrail = left > kCholNB ? Tt * (Tt + 1) / 2 : 0;
         const int nrow = std::max(1, (left2 + kCholRowCols - 1) / kCholRowCols);
-        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, s.Gm, np2, nN, kb, (const double*)s.gdiag, s.st,
+        hipLaunchKernelGGL(k_chol_step, dim3(nrow + ntrail), dim3(kCholThreads), 0, ctx->stream, G2, npa2, nN, kb, (const double*)s.gdiag, s.st,
                            nrow, s.Dfac, np2);
     }
     HIPCHECK(hipGetLastError());
-    hipLaunchKernelGGL(k_gram_export_b, dim3((unsigned)(((int64_t)n * nN + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gm, np2, nF, nN,
+    hipLaunchKernelGGL(k_gram_export_b, dim3((unsigned)(((int64_t)n * nN + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)G2, npa2, nF, nN,
                        (const int*)s.cands, (const double*)s.Wb, ldw, s.R, s.kcap, s.z, s.sel, s.st, (const double*)s.Dfac);
     HIPCHECK(hipGetLastError());
     s.tt_pending = false;
@@ -482,7 +491,21 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     s.keep_np = np;
     s.keep_valid = true;
     s.jh = std::min(s.kcap, n);
-    CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    if (aug2) {
+        hipLaunchKernelGGL(k_tt_gemv, dim3((nN + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(G2 + (size_t)np2 * npa2), npa2, (const double*)(s.z + nF),
+                           (const DevState*)s.st, nN, s.coef + nF, n);
+        hipLaunchKernelGGL(k_wx, dim3((nF + 63) / 64), dim3(256), 0, ctx->stream, (const double*)s.Wb, ldw, nF, nN, (const double*)s.z,
+                           (const double*)(s.coef + nF), (const DevState*)s.st, n, s.ytmp);
+        hipLaunchKernelGGL(k_tt_gemv, dim3((nF + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(s.Gm + (size_t)s.tt_col0 * s.tt_ld), s.tt_ld,
+                           (const double*)s.ytmp, (const DevState*)s.st, nF, s.coef, n);
+        const int ne = std::max(n, s.outcap);
+        hipLaunchKernelGGL(k_trsv_emit, dim3((ne + 255) / 256), dim3(256), (size_t)(s.kcap + 4) * sizeof(int), ctx->stream,
+                           (const double*)s.coef, (const int*)s.sel, (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap,
+                           (int*)nullptr);
+        HIPCHECK(hipGetLastError());
+    } else {
+        CHECK(launch_finish(ctx, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap));
+    }
     const int nch = (n + kResChunk - 1) / kResChunk;
     hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nch), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
                        (const int*)s.cands, (const double*)s.coef, n, s.rpart);
@@ -606,7 +629,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     s.jh = std::min(s.kcap, n);
     if (aug) {  // x = R^-1 z through the explicit inverse beside R: one product instead of the back substitution's chain
         hipLaunchKernelGGL(k_tt_gemv, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(s.Gm + (size_t)np * npa), npa, (const double*)s.z,
-                           (const DevState*)s.st, n, s.coef);
+                           (const DevState*)s.st, n, s.coef, n);
         const int ne = std::max(n, s.outcap);
         hipLaunchKernelGGL(k_trsv_emit, dim3((ne + 255) / 256), dim3(256), (size_t)(s.kcap + 4) * sizeof(int), ctx->stream,
                            (const double*)s.coef, (const int*)s.sel, (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap,
@@ -709,10 +732,16 @@ static int sp_job_select(SpJob& j, bool scr) {
     int* top = (int*)pv;
     int* pnt = top + k;
     pnt[1] = 0;
+    // Several solves in flight (csmp_sp_batch): the sweeps of different solves run ONE AFTER THE OTHER.  Two HBM-bound sweeps side
+    // by side finish no sooner than back to back, and while they share the memory system nothing is left for the others to hide
+    // their latency chains under; queued behind one another, every sweep has the chains of the other solves beside it.
+    if (ctx->gate) HIPCHECK(hipStreamWaitEvent(ctx->stream, *ctx->gate, 0));
     if (scr) {
         CHECK(sp_select_screened(ctx, k));
+        if (ctx->gate) HIPCHECK(hipEventRecord(*ctx->gate, ctx->stream));
     } else {
         CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
+        if (ctx->gate) HIPCHECK(hipEventRecord(*ctx->gate, ctx->stream));
         CHECK(launch_topS(ctx, k));
     }
     hipLaunchKernelGGL(k_land_sel, dim3((k + 255) / 256), dim3(256), 0, ctx->stream, (const int*)s.cands, (const int*)s.ncands, k,
@@ -928,6 +957,8 @@ extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t 
         if (T == 1) CHECK(screened_ensure(ctx));
         for (int t = 1; t < T; ++t) CHECK(screened_ensure_pair(ctx, cc[t]));
     }
+    if (!ctx->ev_gate) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_gate, hipEventDisableTiming));
+    for (int t = 0; t < T; ++t) cc[t]->gate = T > 1 ? &ctx->ev_gate : nullptr;
     const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
     int64_t sig_of[4] = {-1, -1, -1, -1}, next = 0, finished = 0;
     int rc = CSMP_OK;
@@ -969,6 +1000,7 @@ extern "C" int csmp_sp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t 
         }
     }
     for (int t = 0; t < T; ++t) (void)hipStreamSynchronize(cc[t]->stream);
+    for (int t = 0; t < T; ++t) cc[t]->gate = nullptr;
     for (int t = 1; t < T; ++t) {  // (the twins' screened-selection counters belong to this context's statistics)
         ctx->scr_solves += cc[t]->scr_solves;
         ctx->scr_fallbacks += cc[t]->scr_fallbacks;

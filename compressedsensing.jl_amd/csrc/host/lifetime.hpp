@@ -77,7 +77,7 @@ static void solver_free(Solver& s) {
     dfree(s.rho2); dfree(s.dvec);
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
-    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
+    dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin); dfree(s.Gm2); dfree(s.ytmp); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);
     s = Solver();
 }
 
@@ -111,7 +111,7 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
     if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
     if (ctx->spjob.ev) (void)hipEventDestroy(ctx->spjob.ev);
     if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
-    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_off})
+    for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_off, ctx->ev_gate})
         if (e) (void)hipEventDestroy(e);
     dict_release(ctx);
     for (auto& e : ctx->ev) (void)hipEventDestroy(e);
