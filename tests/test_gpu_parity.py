@@ -2419,6 +2419,44 @@ def test_batched_certificate_against_adversarial_residuals(cs, oracle, image_nam
     d.close()
 
 
+@pytest.mark.parametrize("image_name", ["bf16", "f16"])
+def test_screened_sweep_certificate_against_adversarial_residuals(cs, oracle, image_name):
+    """The same construction against the opt-in screened SINGLE-SIGNAL sweep (CSMP_OPT_SCREENED_SWEEP: the sweep reads an image of
+    A, the pick is certified, an uncertified solve is repeated exactly).  Under the rigorous certificate every first pick and every
+    k = 6 support must be the oracle's, whatever the image; the statistical certificate is run on the same signals and its
+    outcome reported."""
+    M, N, nadv, k = 4096, 2048, 12, 6
+    rng = np.random.default_rng(4048)
+    A = rng.standard_normal((M, N))
+    A /= np.linalg.norm(A, axis=0)
+    A = np.asfortranarray(A.astype(np.float32))
+    image, bits, opt = (_bf16_image, 8, 1) if image_name == "bf16" else (_f16_image, 11, 3)
+    sig = []
+    for i1, i2 in rng.permutation(N)[:8 * nadv].reshape(-1, 2):
+        b = _adversarial_signal(A, int(i1), int(i2), image, bits)
+        if b is not None and len(sig) < nadv:
+            sig.append(b)
+    assert len(sig) == nadv
+    refs = [oracle.omp(A, b, k, EPS32) for b in sig]
+    d = cs.Dictionary(A)
+    d.ctx.set_option("screened_sweep", opt)
+    for cert in (1, 0):
+        d.ctx.set_option("batch_cert", cert)
+        d.ctx.screened_stats(reset=True)
+        wrong = []
+        for s, b in enumerate(sig):
+            for kk in (1, k):
+                g = d.ctx.omp(b, kk, EPS32)
+                ok = int(g[2][0]) == int(refs[s][2][0]) if kk == 1 else (np.array_equal(g[0], refs[s][0]) and close(g[1], refs[s][1], tight=False))
+                if not ok:
+                    wrong.append((s, kk))
+        st = d.ctx.screened_stats()
+        print("adversarial screened sweep [%s] %s certificate: wrong %s, %s" % (image_name, "rigorous" if cert else "statistical (opt-in)", wrong, st))
+        if cert == 1:
+            assert wrong == [], (wrong, st)
+    d.close()
+
+
 def test_omp_sharded_in_library_rccl(cs, oracle, D):
     """csmp_comm_id / csmp_comm_init / csmp_omp_sharded: the signal-sharded solve with the ONE collective (ncclAllGather) inside the
     library.  One GPU can only hold a group of one rank (RCCL refuses two ranks on a device), which still runs every line: the
