@@ -914,6 +914,7 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     if (2 * k > ctx->M) return fail(ctx, CSMP_ERANGE, "2k > length(b) is invalid for Subspace Pursuit");  // src/twostage.jl:55
     if (k > ctx->N) return fail(ctx, CSMP_ERANGE, "sp: k > number of atoms");
     SpJob& j = ctx->spjob;
+    ctx->gate = nullptr;  // (one solve: nothing to queue behind)
     int rc = sp_job_begin(j, ctx, b, b_dtype, k, delta, maxiter);
     while (rc == CSMP_OK && j.phase != SpJob::DONE) {
         // a phase lasts 0.1-1 ms and the solve resumes on this thread: poll (the wake-up of a blocking wait would sit on the chain
