@@ -661,25 +661,30 @@ __global__ __launch_bounds__(256) void k_schur_reduce(const double* __restrict__
     G2[row + (int64_t)col * npa2] = s;
 }
 
-// y = z_F - W x_N (the coupling of the bordered extension's back substitution: x_F = R_F^-1 y); rows in 64s, four column
-// phases per row summed through LDS in a fixed order
+// y = z_F - W x_N (the coupling of the bordered extension's back substitution: x_F = R_F^-1 y); 16 rows per workgroup (128-byte
+// segments of W's columns), sixteen column phases per row summed through LDS in a fixed order
 __global__ __launch_bounds__(256) void k_wx(const double* __restrict__ Wb, int ldw, int nF, int nN, const double* __restrict__ z,
                                             const double* __restrict__ xN, const DevState* st, int nsel, double* __restrict__ y) {
     if (st->nsel != nsel) return;
-    __shared__ double part[4][64];
-    const int r = threadIdx.x & 63, g = threadIdx.x >> 6, i = blockIdx.x * 64 + r;
+    __shared__ double part[16][17];
+    const int r = threadIdx.x & 15, g = threadIdx.x >> 4, i = blockIdx.x * 16 + r;
     double a0 = 0.0, a1 = 0.0;
     if (i < nF) {
         int j = g;
-        for (; j + 4 < nN; j += 8) {
+        for (; j + 16 < nN; j += 32) {
             a0 = fma(Wb[i + (int64_t)j * ldw], xN[j], a0);
-            a1 = fma(Wb[i + (int64_t)(j + 4) * ldw], xN[j + 4], a1);
+            a1 = fma(Wb[i + (int64_t)(j + 16) * ldw], xN[j + 16], a1);
         }
         if (j < nN) a0 = fma(Wb[i + (int64_t)j * ldw], xN[j], a0);
     }
     part[g][r] = a0 + a1;
     __syncthreads();
-    if (g == 0 && i < nF) y[i] = z[i] - (((part[0][r] + part[1][r]) + part[2][r]) + part[3][r]);
+    if (g == 0 && i < nF) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][r];
+        y[i] = z[i] - t;
+    }
 }
 
 // R_T's new blocks into the solver slot: W (rows of F, columns of N), R_C, z_N, the new atoms; count = nF + nN.

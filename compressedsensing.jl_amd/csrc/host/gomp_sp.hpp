@@ -494,7 +494,7 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     if (aug2) {
         hipLaunchKernelGGL(k_tt_gemv, dim3((nN + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(G2 + (size_t)np2 * npa2), npa2, (const double*)(s.z + nF),
                            (const DevState*)s.st, nN, s.coef + nF, n);
-        hipLaunchKernelGGL(k_wx, dim3((nF + 63) / 64), dim3(256), 0, ctx->stream, (const double*)s.Wb, ldw, nF, nN, (const double*)s.z,
+        hipLaunchKernelGGL(k_wx, dim3((nF + 15) / 16), dim3(256), 0, ctx->stream, (const double*)s.Wb, ldw, nF, nN, (const double*)s.z,
                            (const double*)(s.coef + nF), (const DevState*)s.st, n, s.ytmp);
         hipLaunchKernelGGL(k_tt_gemv, dim3((nF + 3) / 4), dim3(256), 0, ctx->stream, (const double*)(s.Gm + (size_t)s.tt_col0 * s.tt_ld), s.tt_ld,
                            (const double*)s.ytmp, (const DevState*)s.st, nF, s.coef, n);
