@@ -65,12 +65,22 @@ def library_collective(cs, dist, D, use_dist, share_gpu):
     device) and a box whose RCCL cannot be bound keep the host-side all_gather of the same packed rows."""
     if not use_dist or share_gpu or dist.get_backend() != "nccl":
         return False
+    import torch
+    ok = 1
     try:
         cs.library_comm(D.ctx)
-        return True
     except Exception as e:  # noqa: BLE001
+        ok = 0
         print(f"bench.py: csmp_comm_init failed ({e!r}); the gather falls back to torch.distributed", file=sys.stderr, flush=True)
+    # every rank must take the same path: one that could not bind RCCL or join the communicator sends everybody to the host-side gather
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if ok:
+            D.ctx.comm_free()
+            D.ctx._comm_key = None
         return False
+    return True
 
 
 def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
