@@ -593,10 +593,12 @@ def test_streamed_dictionary_and_dictionary_files(cs, oracle, shape, tmp_path):
         gs = d.ctx.sp(b, min(k, n // 2), 1e-9)
         assert np.array_equal(gs[0], refs[0]) and close(gs[1], refs[1]), name
         idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+        sb = d.ctx.sp_batch(B, min(k, n // 2), 1e-9)  # (several solves in flight: clones of the context share the mapped dictionary)
         if base is None:
-            base = (idx, val, nnz)
+            base = (idx, val, nnz, sb)
         else:  # bit for bit the resident dictionary's results
             assert np.array_equal(idx, base[0]) and np.array_equal(nnz, base[2]) and np.array_equal(val, base[1]), name
+            assert all(np.array_equal(u, v) for u, v in zip(sb, base[3])), name
     for d in variants.values():
         d.close()
     with pytest.raises(cs.CsmpError):
