@@ -267,7 +267,7 @@ hipError_t launch_screen(hipStream_t stream, int mode, const __bf16* Ab, const _
     return hipGetLastError();
 }
 const char* screen_kernel_name(int mode) {
-    if (mode == 0) return "none (M > 8192: csmp_omp_batch's exact sweeps)";
+    if (mode == 0) return "none (M > 8192 or a support capacity beyond the per-signal kernels' LDS: csmp_omp_batch's exact sweeps)";
     if (mode == kScreen256i8)
         return "csmp::k_b_screen256p<i8> (v_mfma_i32_16x16x64_i8 on int8 images, 256x256 tiles, eight-phase schedule, exact integer "
                "accumulation; fused top-4 epilogue)";

@@ -277,9 +277,11 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     if (nsig > (1 << 20)) return fail(ctx, CSMP_ERANGE, "omp_batch_mfma: too many signals in one call");
     HIPCHECK(hipSetDevice(ctx->dev));
-    if (ctx->Mv > kBatchMaxRows) {
-        // The per-signal kernels of this path keep a signal's column slice in registers and its residual in LDS (8 M bytes):
-        // beyond 8192 rows the contract -- csmp_omp_batch's results -- is met by csmp_omp_batch itself (exact sweeps, three signals
+    const int kc0 = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    if (ctx->Mv > kBatchMaxRows || b_append_lds_bytes(ctx->Mv, ctx->dtype == CSMP_F32 ? 4 : 2, kc0) > (size_t)160 * 1024 - 1024) {
+        // The per-signal kernels of this path keep a signal's column slice in registers, its residual (8 M bytes) and three
+        // support-length vectors in LDS: beyond 8192 rows, or with a support capacity those vectors do not fit (k ~ 5000 at
+        // M = 4096), the contract -- csmp_omp_batch's results -- is met by csmp_omp_batch itself (exact sweeps, three signals
         // in flight).  The statistics say so: no screening kernel, nothing re-solved.
         Batch& b0 = ctx->bt;
         b0.last_mode = 0;

@@ -625,6 +625,23 @@ def test_batched_mfma_beyond_8192_rows_runs_the_exact_batch(cs, oracle, D):
     d.close()
 
 
+def test_batched_mfma_at_the_reference_default_capacity(cs, oracle, D):
+    """omp(A, b) defaults to k = size(A, 1) (src/matchingpursuit.jl:89): the batched path must take that capacity -- through its own
+    kernels where the per-signal vectors fit the LDS (k = M = 2048), through csmp_omp_batch's exact sweeps where they do not
+    (k = M = 5632) -- and stop by eps after the planted atoms either way."""
+    for n, m, mode in ((2048, 2304, "screen"), (5632, 5760, "none")):
+        A, x, b = cs.sparse_data(n=n, m=m, k=5, rng=n, dtype=np.float32)
+        d = D(A)
+        rng = np.random.default_rng(n + 1)
+        B = np.asfortranarray(np.stack([A.astype(np.float64) @ cs.sparse_vector(m, 5, rng=rng).to_dense() for _ in range(3)], axis=1))
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, n, 1e-5)
+        assert d.ctx.batch_screen_kernel().startswith("none") == (mode == "none")
+        for s in range(3):
+            ref = oracle.omp(A, B[:, s], n, 1e-5)
+            assert nnz[s] == len(ref[0]) == 5 and np.array_equal(idx[:5, s], ref[0]) and close(val[:5, s], ref[1])
+        d.close()
+
+
 def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
     # noiseless 3-sparse signals, k = 8: every signal stops after 3 atoms (eps-stop inside k_b_step)
     A, x, b = cs.sparse_data(n=96, m=400, k=3, rng=1, dtype=np.float32)
