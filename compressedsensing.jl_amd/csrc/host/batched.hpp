@@ -268,8 +268,76 @@ static hipError_t b_step_dispatch(csmp_ctx* ctx, hipStream_t stream, int sig0, i
 #undef CSMP_BSTEP
 }
 
+// HBM bytes of the batched path's per-signal state (batch_ensure) at support capacity kc
+static size_t batch_bytes_per_signal(const csmp_ctx* ctx, int kc) {
+    const Batch& b = ctx->bt;
+    const size_t Mr = (size_t)((ctx->M + 3) / 4) * 4;
+    return (size_t)b.Mk * 2 + 2 * Mr * 8 + 2 * (size_t)kc * kc * 8 + (size_t)kc * 12 + sizeof(BState) + sizeof(BPick) +
+           (size_t)b.n_atiles * kTileCand * 8 + (size_t)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256) + 4;
+}
+
+static int omp_batch_mfma_chunk(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                                double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc);
+
+// The entry point: argument checks, then the batch in as many pieces as the free HBM asks for.  The per-signal state is dominated
+// by the two k x k Float64 factors (T = R^-1 and its transpose): 1024 signals at k = 128 hold 0.27 GB, at k = 2048 69 GB.  A batch
+// whose state does not fit beside what the GPU already holds is solved in chunks of whole 256-signal tiles, one after the other
+// (same results; csmp_batch_stats adds the chunks up); if not even one tile fits, csmp_omp_batch's exact sweeps take the batch.
 extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                                    double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
+    if (!B || nsig < 1 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch_mfma: bad arguments");
+    if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    HIPCHECK(hipSetDevice(ctx->dev));
+    Batch& b = ctx->bt;
+    const int kc = (int)std::max<int64_t>(1, std::min<int64_t>(k, ctx->M));
+    const int64_t Bpad = ((nsig + 2 * kBT - 1) / (2 * kBT)) * (2 * kBT);
+    if (ctx->Mv <= kBatchMaxRows && !(b.Bcap >= Bpad && b.kcap >= kc)) {  // (state of that size is not there yet)
+        CHECK(batch_meta(ctx));  // (Mk, n_atiles: the image's geometry)
+        size_t free_b = 0, total_b = 0;
+        HIPCHECK(hipMemGetInfo(&free_b, &total_b));
+        const size_t held = (size_t)b.Bcap * batch_bytes_per_signal(ctx, b.kcap);
+        const size_t margin = (size_t)2 << 30;  // (the operand images, temporaries of the re-solves)
+        const size_t budget = free_b + held > margin ? free_b + held - margin : 0;
+        const size_t per = batch_bytes_per_signal(ctx, std::max(kc, b.kcap));
+        if ((size_t)std::max<int64_t>(Bpad, b.Bcap) * per > budget) {
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            batch_free(b, true);  // (whatever an earlier, differently shaped batch left: the budget counted it as free)
+            const int64_t fit = (int64_t)(budget / batch_bytes_per_signal(ctx, kc)) / (2 * kBT) * (2 * kBT);
+            if (fit < 2 * kBT) {
+                b.last_mode = 0;
+                b.last_streams = 1;
+                b.last_screen_signals = 0;
+                b.last_signals = nsig;
+                b.last_resolved = b.last_uncertain = b.last_illcond = 0;
+                return csmp_omp_batch(ctx, B, b_dtype, ldB, nsig, b_loc, k, eps, idx, val, nnz, out_loc);
+            }
+            if (fit < Bpad) {
+                const size_t es = b_dtype == CSMP_F32 ? 4 : 8;
+                int64_t tot_res = 0, tot_unc = 0, tot_ill = 0;
+                for (int64_t off = 0; off < nsig; off += fit) {
+                    const int64_t n = std::min<int64_t>(fit, nsig - off);
+                    CHECK(omp_batch_mfma_chunk(ctx, (const char*)B + (size_t)off * (size_t)ldB * es, b_dtype, ldB, n, b_loc, k, eps, idx + off * k,
+                                               val + off * k, nnz + off, out_loc));
+                    tot_res += b.last_resolved;
+                    tot_unc += b.last_uncertain;
+                    tot_ill += b.last_illcond;
+                }
+                b.last_signals = nsig;
+                b.last_resolved = tot_res;
+                b.last_uncertain = tot_unc;
+                b.last_illcond = tot_ill;
+                return CSMP_OK;
+            }
+        }
+    }
+    return omp_batch_mfma_chunk(ctx, B, b_dtype, ldB, nsig, b_loc, k, eps, idx, val, nnz, out_loc);
+}
+
+static int omp_batch_mfma_chunk(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
+                                double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
     if (!B || nsig < 1 || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "omp_batch_mfma: bad arguments");

@@ -210,7 +210,8 @@ int csmp_sp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
  * before returning, so a certified result equals csmp_omp_batch's.  The error bound behind the certificate is
  * chosen by CSMP_OPT_BATCH_CERT (below).  Dictionaries of more than 8192 rows, and support capacities min(k, M) whose per-signal
  * vectors exceed the LDS (about 5000 columns at M = 4096), are solved by csmp_omp_batch's exact sweeps (same results;
- * csmp_batch_screen_kernel then reports "none").  With out_loc == CSMP_DEVICE this call still
+ * csmp_batch_screen_kernel then reports "none").  The per-signal state is two k x k Float64 factors: a batch
+ * whose state does not fit the free HBM is solved in chunks of whole 256-signal tiles (csmp_batch_stats adds them up).  With out_loc == CSMP_DEVICE this call still
  * synchronises once (to read the per-signal certificates). */
 int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                         double eps, int64_t *idx, double *val, int64_t *nnz, int out_loc);

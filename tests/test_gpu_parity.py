@@ -642,6 +642,39 @@ def test_batched_mfma_at_the_reference_default_capacity(cs, oracle, D):
         d.close()
 
 
+def test_batched_mfma_solves_in_chunks_when_hbm_is_short(cs, oracle, D):
+    """The per-signal state of the batched path grows with k^2 (two k x k Float64 factors per signal): a batch that does not fit
+    the free HBM is solved in chunks of whole 256-signal tiles, with csmp_omp_batch's results.  The GPU's memory is filled up to
+    a few GB here so that a small batch meets the situation a 288 GB device meets at k in the thousands."""
+    import torch
+    n, m, k, nsig = 512, 2048, 512, 600
+    A, x, b = cs.sparse_data(n=n, m=m, k=6, rng=9, dtype=np.float32)
+    d = D(A)
+    rng = np.random.default_rng(10)
+    B = np.asfortranarray(np.stack([cs.perturb(A.astype(np.float64) @ cs.sparse_vector(m, 6, rng=rng).to_dense(), 5e-3, rng=rng)
+                                    for _ in range(nsig)], axis=1))
+    eps = 5e-2  # (stops after the planted atoms: the CAPACITY k = 512 is what sizes the state)
+    i0, v0, n0 = d.ctx.omp_batch(B, k, eps)
+    d.ctx.omp_batch_mfma(B[:, :8], 4, eps)  # (the operand image exists before the memory is measured)
+    per = 2 * k * k * 8
+    free, total = torch.cuda.mem_get_info()
+    want_free = (2 << 30) + 300 * per  # the library's margin + room for one 256-signal tile, not for two
+    filler = torch.empty(max(0, free - want_free), dtype=torch.uint8, device="cuda") if free > want_free else None
+    try:
+        idx, val, nnz = d.ctx.omp_batch_mfma(B, k, eps)
+        st = d.ctx.batch_stats()
+    finally:
+        del filler
+        torch.cuda.empty_cache()
+    assert st["signals"] == nsig and d.ctx.batch_screen_kernel().startswith("csmp::k_b_screen")
+    assert np.array_equal(nnz, n0) and np.array_equal(idx, i0) and np.allclose(val, v0, rtol=1e-9, atol=1e-12)
+    assert d.ctx.batch_layout()["screen_signals"] == 256  # signal columns of the last screening launch: one tile, i.e. the batch went in pieces
+    for s in (0, 255, 256, 511, 512, nsig - 1):
+        ref = oracle.omp(A, B[:, s], k, eps)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]) and close(val[:nnz[s], s], ref[1])
+    d.close()
+
+
 def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
     # noiseless 3-sparse signals, k = 8: every signal stops after 3 atoms (eps-stop inside k_b_step)
     A, x, b = cs.sparse_data(n=96, m=400, k=3, rng=1, dtype=np.float32)
