@@ -46,6 +46,32 @@ struct DevState {
     float rstep;    // int8 screened sweep: the quantisation step of the residual image of the last sweep
 };
 
+// up to eight pieces of device memory -> one page-locked landing area (host memory mapped into the device), in one launch
+constexpr int kLandMax = 8;
+struct LandSegs {
+    const void* src[kLandMax];
+    unsigned off[kLandMax], words[kLandMax];
+    int n;
+};
+__global__ __launch_bounds__(256) void k_land_multi(const LandSegs g, char* __restrict__ dst) {
+    for (int q = 0; q < g.n; ++q) {
+        const int* s_ = reinterpret_cast<const int*>(g.src[q]);
+        int* d_ = reinterpret_cast<int*>(dst + g.off[q]);
+        for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < g.words[q]; i += gridDim.x * 256) d_[i] = s_[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_put_ints(const int* __restrict__ src, int n, int* __restrict__ dst) {
+    const int t = (int)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) dst[t] = src[t];
+}
+// two ints from kernel arguments (a candidate list of one: the host knows the atom)
+__global__ void k_set_pair(int* __restrict__ a, int va, int* __restrict__ b, int vb) {
+    if (threadIdx.x == 0) {
+        *a = va;
+        *b = vb;
+    }
+}
+
 using f32x4 = float __attribute__((ext_vector_type(4)));
 using f64x2 = double __attribute__((ext_vector_type(2)));
 template <typename TA> struct Vec;

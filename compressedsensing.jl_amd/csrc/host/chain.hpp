@@ -95,15 +95,16 @@ static int solver_fit_for_removal(csmp_ctx* ctx, int kcap) {
     return CSMP_OK;
 }
 
-// Small results coming back on a latency chain: every piece is copied into the page-locked slot (truly asynchronous, back
-// to back), ONE wait, then the pieces are handed to their host destinations.  (A copy straight into pageable memory -- a stack
-// variable, a std::vector -- is staged by the runtime and blocks the host once per piece.)
+// Small results coming back on a latency chain: the pieces land in the page-locked slot (a copy straight into pageable memory --
+// a stack variable, a std::vector -- is staged by the runtime and blocks the host once per piece).
 struct PinFetch {
     csmp_ctx* ctx;
     char* base = nullptr;
     size_t used = 0;
-    struct Out { void* dst; size_t off, bytes; } outs[8];
+    struct Out { void* dst; size_t off, bytes; } outs[kLandMax];
     int nout = 0;
+    LandSegs segs{};
+    unsigned maxwords = 0;
     explicit PinFetch(csmp_ctx* c) : ctx(c) {}
     int begin(size_t total) {
         void* pv = nullptr;
@@ -111,16 +112,34 @@ struct PinFetch {
         base = (char*)pv;
         used = 0;
         nout = 0;
+        segs.n = 0;
+        maxwords = 0;
         return CSMP_OK;
     }
     int add(void* dst, const void* dev, size_t bytes) {
+        if (nout == kLandMax) return fail(ctx, CSMP_EINVAL, "PinFetch: too many pieces");
         const size_t off = (used + 7) / 8 * 8;
-        HIPCHECK(hipMemcpyAsync(base + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        if ((bytes & 3) || ((uintptr_t)dev & 3)) {  // (never in this library: every piece is whole, aligned 4-byte words)
+            HIPCHECK(hipMemcpyAsync(base + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            segs.src[segs.n] = dev;
+            segs.off[segs.n] = (unsigned)off;
+            segs.words[segs.n] = (unsigned)(bytes / 4);
+            maxwords = std::max(maxwords, (unsigned)(bytes / 4));
+            segs.n += 1;
+        }
         outs[nout++] = {dst, off, bytes};
         used = off + bytes;
         return CSMP_OK;
     }
+    // ONE kernel writes all pieces into the page-locked landing area over the host link (a small hipMemcpyAsync is a blit kernel
+    // of its own: 5 us on the chain for every piece), ONE wait, then the pieces are handed to their host destinations
     int wait() {
+        if (segs.n > 0) {
+            const int grid = (int)std::max(1u, std::min(64u, (maxwords + 255u) / 256u));
+            hipLaunchKernelGGL(k_land_multi, dim3(grid), dim3(256), 0, ctx->stream, segs, base);
+            HIPCHECK(hipGetLastError());
+        }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         for (int q = 0; q < nout; ++q) memcpy(outs[q].dst, base + outs[q].off, outs[q].bytes);
         return CSMP_OK;

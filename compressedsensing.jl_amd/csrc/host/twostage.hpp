@@ -79,7 +79,13 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
         DevState hs;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool scr = screened && attempt == 0;
-            HIPCHECK(hipMemcpyAsync(s.cands, cur.data(), cur.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            {  // the support goes up through a kernel that reads the page-locked staging buffer (no staged copy from pageable memory)
+                void* pcv = nullptr;
+                CHECK(pin_get(ctx, 2, cur.size() * 4 + 16, &pcv));
+                memcpy(pcv, cur.data(), cur.size() * 4);
+                hipLaunchKernelGGL(k_put_ints, dim3(((int)cur.size() + 255) / 256), dim3(256), 0, ctx->stream, (const int*)pcv, (int)cur.size(), s.cands);
+                HIPCHECK(hipGetLastError());
+            }
             if (scr) {
                 CHECK(ompr_sweep_screened(ctx, s.cands, (int)k));
             } else {
@@ -144,8 +150,8 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
                     else
                         CHECK(launch_delete_atom(ctx, leaving));
                     const int one = 1, ci = (int)cand;
-                    HIPCHECK(hipMemcpyAsync(s.cands, &ci, 4, hipMemcpyHostToDevice, ctx->stream));
-                    HIPCHECK(hipMemcpyAsync(s.ncands, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+                    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(64), 0, ctx->stream, s.cands, (int)ci, s.ncands, (int)one);
+                    HIPCHECK(hipGetLastError());
                     CHECK(launch_append(ctx, 2, 0, 0));
                     if (tmode) CHECK(launch_tinv_append(ctx));
                 } else {
