@@ -240,7 +240,8 @@ static int dict_file_open(const char* path, FILE** out, DictFileHeader* h) {
     if (!f) return CSMP_EIO;
     if (fread(h, sizeof *h, 1, f) != 1 || memcmp(h->magic, "CSMPDICT", 8) != 0 || h->version != 1 ||
         (h->dtype != (uint32_t)CSMP_F32 && h->dtype != (uint32_t)CSMP_F64) || h->M < 1 || h->N < 1 || h->ld < h->M ||
-        (h->ld * (h->dtype == (uint32_t)CSMP_F32 ? 4 : 8)) % 16 != 0) {
+        h->ld != ((h->M + (h->dtype == (uint32_t)CSMP_F32 ? 3 : 1)) / (h->dtype == (uint32_t)CSMP_F32 ? 4 : 2)) * (h->dtype == (uint32_t)CSMP_F32 ? 4 : 2)) {
+        // (ld is M rounded up to 16 bytes, nothing else: the kernels read the padding rows as part of the columns)
         fclose(f);
         return CSMP_EIO;
     }
