@@ -318,24 +318,37 @@ __global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T
 // meta[0] < 0 nothing is removed and T2 / R2 receive copies.
 template <typename LD, typename ST>
 __device__ __forceinline__ double rot_chain(int p, int last, const double* __restrict__ G, LD ld, ST stv) {
+    // (the rotations (c_i, s_i) are requested a block ahead like the data: a load of them inside the dependent chain -- the same
+    // address in every lane, but a trip to the L2 all the same -- was what a step cost)
     double carry = ld(p);
     double pre[kQPre], nxt[kQPre];
+    f64x2 gpre[kQPre], gnxt[kQPre];
+    const f64x2* G2 = reinterpret_cast<const f64x2*>(G);
 #pragma unroll
-    for (int u = 0; u < kQPre; ++u) pre[u] = ld(p + 1 + u);
+    for (int u = 0; u < kQPre; ++u) {
+        pre[u] = ld(p + 1 + u);
+        gpre[u] = (p + u <= last) ? G2[p + u] : f64x2{1.0, 0.0};
+    }
     for (int ib = p; ib <= last; ib += kQPre) {
 #pragma unroll
-        for (int u = 0; u < kQPre; ++u) nxt[u] = ld(ib + kQPre + 1 + u);
+        for (int u = 0; u < kQPre; ++u) {
+            nxt[u] = ld(ib + kQPre + 1 + u);
+            gnxt[u] = (ib + kQPre + u <= last) ? G2[ib + kQPre + u] : f64x2{1.0, 0.0};
+        }
 #pragma unroll
         for (int u = 0; u < kQPre; ++u) {
             const int i = ib + u;
             if (i <= last) {
-                const double cs = G[2 * i], sn = G[2 * i + 1], x = pre[u];
+                const double cs = gpre[u].x, sn = gpre[u].y, x = pre[u];
                 stv(i, fma(cs, carry, sn * x));
                 carry = fma(cs, x, -sn * carry);
             }
         }
 #pragma unroll
-        for (int u = 0; u < kQPre; ++u) pre[u] = nxt[u];
+        for (int u = 0; u < kQPre; ++u) {
+            pre[u] = nxt[u];
+            gpre[u] = gnxt[u];
+        }
     }
     return carry;
 }
