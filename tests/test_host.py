@@ -115,3 +115,18 @@ def test_dictionary_file_format_round_trip(cs, tmp_path):
     bad.write_bytes(b"not a dictionary" * 8)
     with pytest.raises(cs.CsmpError):
         cs.dictionary_file_info(str(bad))
+
+
+def test_dictionary_file_golden_bytes(cs, tmp_path):
+    """The on-disk format is pinned by two committed files (tests/golden/dict_*.csmp, written by csmp_dictionary_file_write and
+    checked by hand against include/csmp.h's layout): today's writer must reproduce them byte for byte and the reader must
+    return their shapes."""
+    import os
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    A32 = np.asfortranarray((np.arange(15, dtype=np.float32).reshape(3, 5).T - 7) / 4)   # 5 x 3
+    A64 = np.asfortranarray((np.arange(12, dtype=np.float64).reshape(4, 3).T - 5) / 8)   # 3 x 4
+    for name, A in (("dict_5x3_f32.csmp", A32), ("dict_3x4_f64.csmp", A64)):
+        path = str(tmp_path / name)
+        cs.write_dictionary_file(path, A)
+        assert open(path, "rb").read() == open(os.path.join(gold, name), "rb").read(), name
+        assert cs.dictionary_file_info(os.path.join(gold, name)) == (A.shape[0], A.shape[1], A.dtype.type)
