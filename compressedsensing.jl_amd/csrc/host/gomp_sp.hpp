@@ -361,12 +361,13 @@ static inline void mark_put(csmp_ctx* ctx, int atom, int pos) {
 }
 static inline int mark_get(const csmp_ctx* ctx, int atom) { return ctx->s.hstamp[(size_t)atom] == ctx->s.hgen ? ctx->s.hpos[(size_t)atom] : -1; }
 
-static int gram_split_for(const csmp_ctx* ctx, int np) {
-    // pieces of k_gram on or above the diagonal; the rows are split so that ONE round of workgroups (two per CU) covers them:
-    // a second, partly filled round would cost as much as a full one
+static int gram_split_for(const csmp_ctx* ctx, int np, int jtile0 = 0) {
+    // pieces of k_gram on or above the diagonal (from column tile jtile0 on: the bordered extension computes the new columns'
+    // tiles only); the rows are split so that ONE round of workgroups (two per CU) covers them: a second, partly filled round
+    // would cost as much as a full one
     const int TJ = np / kGramWgJ;
     int pieces = 0;
-    for (int J = 0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
+    for (int J = jtile0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
     const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
     int nsplit = std::max(1, slots / std::max(1, pieces));
     nsplit = std::min<int>(nsplit, std::max<int>(1, (int)(ctx->M / 64)));  // at least four 16-row blocks each
@@ -418,7 +419,7 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int np2 = ((nN + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int ldw = ((nF + 15) / 16) * 16;
-    const int nsplit = gram_split_for(ctx, np);
+    const int nsplit = std::min(gram_split_for(ctx, np, nF / kGramWgJ), s.gram_split);  // (the new columns' tiles fill the round)
     // (gram_ensure has run: the caller checked the buffers' sizes before it decided for this path)
     CHECK(solver_restart(ctx));  // r = b, control block reset; R, z, sel of F stay where they are
     void* pcv = nullptr;
@@ -525,7 +526,10 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     // AUGMENTED by the unit vectors (csmp_gram.hpp, k_gram_reduce): (R^-1)' comes out beside R, for free on this chain.
     const bool aug = n >= 64 && 2 * n <= s.kcap;
     const int npa = aug ? ((np + n + kGramTile - 1) / kGramTile) * kGramTile : np;
-    CHECK(gram_ensure(ctx, npa, nsplit));  // (a reallocation drops fac_valid and keep_valid)
+    // (a set that may be an extension of the slot's factor splits its rows finer: fewer tiles to spread over the same round)
+    const int nsplit_ext = (s.fac_valid && s.fac_cols.size() >= 64 && (int)s.fac_cols.size() < n)
+                               ? gram_split_for(ctx, np, (int)s.fac_cols.size() / kGramWgJ) : nsplit;
+    CHECK(gram_ensure(ctx, npa, std::max(nsplit, nsplit_ext)));  // (a reallocation drops fac_valid and keep_valid)
     const bool can_extend = s.fac_valid;
     s.fac_valid = false;  // whatever happens below rewrites the slot; the caller confirms the new factor once it has seen it succeed
     s.fac_pending.assign(cols.begin(), cols.end());  // the factor order of this solve
