@@ -572,7 +572,7 @@ __global__ __launch_bounds__(256) void k_top_merge(const double* __restrict__ lv
 // SETTLED: the later histogram launches (enqueued blindly by the host, which never reads anything back) return at once,
 // k_rs_collect gathers the keys above the bucket and the bucket itself, and k_rs_finish picks the `remaining` best of the
 // bucket exactly.  The scan of a pass is done by the LAST workgroup of its histogram launch (ticket counter): one launch per
-// pass.  Typical cost at N = 131072, S = 1024: 2 live passes + 4 empty launches + collect + finish, ~60 us (it was 19
+// pass.  Typical cost at N = 131072, S = 1024: 2 live passes + the tail launch (k_rs_tail: the remaining passes, a no-op once settled) + collect + finish, ~55 us (it was 19
 // launches, ~200 us, with 8-bit digits and a single-workgroup rank sort).
 constexpr int kRsDigit = 11, kRsBins = 1 << kRsDigit, kRsPasses = 6;
 struct RsState {
@@ -607,10 +607,8 @@ __global__ __launch_bounds__(256) void k_rs_init(RsState* rs, int S) {
 
 // One pass: histogram of the current digit over the keys that match the prefix; the last workgroup to finish walks the
 // histogram from the largest digit down, extends the prefix and decides whether the selection is settled.
-__global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec, int64_t N, RsState* rs, int settle) {
-    __shared__ unsigned int h[kRsBins];
-    __shared__ unsigned int part[256];
-    __shared__ unsigned int last;
+__device__ __forceinline__ void rs_hist_body(const double* __restrict__ cvec, int64_t N, RsState* rs, int settle, unsigned int* h,
+                                             unsigned int* part, unsigned int& last) {
     const int tid = threadIdx.x;
     if (rs->settled || rs->pass >= kRsPasses) return;
     const int pass = rs->pass;
@@ -666,6 +664,25 @@ __global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec
     }
     for (int b = tid; b < kRsBins; b += 256) rs->hist[b] = 0;
     if (tid == 0) rs->ticket = 0;
+}
+__global__ __launch_bounds__(256) void k_rs_hist(const double* __restrict__ cvec, int64_t N, RsState* rs, int settle) {
+    __shared__ unsigned int h[kRsBins];
+    __shared__ unsigned int part[256];
+    __shared__ unsigned int last;
+    rs_hist_body(cvec, N, rs, settle, h, part, last);
+}
+// The passes after the first two, in ONE launch of ONE workgroup: for anything but massively tied data the selection is settled
+// by then and this returns at once (it used to be four empty launches on the chain); a selection that is not settled is carried
+// through its remaining digits here, a pass at a time over all N keys (slow, rare, exact).
+__global__ __launch_bounds__(256) void k_rs_tail(const double* __restrict__ cvec, int64_t N, RsState* rs, int settle) {
+    __shared__ unsigned int h[kRsBins];
+    __shared__ unsigned int part[256];
+    __shared__ unsigned int last;
+    for (int it = 2; it < kRsPasses; ++it) {
+        rs_hist_body(cvec, N, rs, settle, h, part, last);
+        __threadfence();   // (the state the next pass reads was written by threads of this workgroup)
+        __syncthreads();
+    }
 }
 
 // keys above the prefix bucket -> gt_idx, keys inside it -> eq_idx (at most eq_cap are kept; more than that only when the

@@ -88,8 +88,9 @@ static int launch_topS(csmp_ctx* ctx, int S) {
     // (few, fat workgroups: every workgroup flushes its non-empty bins with global atomics, and pass 0 -- the exponent -- puts
     // all keys into a dozen bins)
     const int hgrid = (int)std::min<int64_t>((ctx->N + 2047) / 2048, (int64_t)ctx->prop.multiProcessorCount);
-    for (int pass = 0; pass < kRsPasses; ++pass)  // (a settled selection turns the remaining launches into no-ops)
+    for (int pass = 0; pass < 2; ++pass)  // the exponent, the leading 11 mantissa bits
         hipLaunchKernelGGL(k_rs_hist, dim3(hgrid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, kRsSettle);
+    hipLaunchKernelGGL(k_rs_tail, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, kRsSettle);  // (a no-op once settled)
     hipLaunchKernelGGL(k_rs_collect, dim3(grid), dim3(256), 0, ctx->stream, (const double*)s.cvec, ctx->N, s.rs, s.rs_gt, s.rs_eq, kRsEqCap);
     const int pairs = S_eff <= 4096 ? S_eff : 0;  // (value, index) pairs of the final rank sort staged in LDS
     const size_t lds = (size_t)pairs * 12 + 16 + (size_t)kRsEqCap * 12 + 16;
