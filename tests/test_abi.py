@@ -82,3 +82,21 @@ def test_option_keys_match_the_header(cs):
     src = open(os.path.join(ROOT, "include", "csmp.h")).read()
     keys = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define CSMP_OPT_([A-Z_]+)\s+(\d+)", src)}
     assert keys == lib.OPTIONS and len(keys) == 7
+
+
+def build_c_example(cs, out):
+    """tests/c_abi_example.c -> an executable linked against the in-tree libcsmp.so (strict C99: the header is C, not C++)"""
+    import subprocess
+    libdir = os.path.dirname(cs.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), "-o", out,
+           os.path.join(ROOT, "tests", "c_abi_example.c"), "-L", libdir, "-lcsmp", "-lm", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return out
+
+
+def test_header_is_plain_c_and_links(cs, tmp_path):
+    """include/csmp.h compiles as strict C99 and a C program that uses the drivers, the batch form and the dictionary files links
+    against libcsmp.so with nothing else (no C++ runtime named on the command line, no torch): the boundary is a C ABI."""
+    exe = build_c_example(cs, str(tmp_path / "c_abi_example"))
+    assert os.path.exists(exe)

@@ -675,6 +675,16 @@ def test_batched_mfma_solves_in_chunks_when_hbm_is_short(cs, oracle, D):
     d.close()
 
 
+def test_c_program_through_the_abi(cs, tmp_path):
+    """tests/c_abi_example.c (plain C99 on include/csmp.h): omp, gomp, omp_batch and a dictionary file round trip, with the
+    supports the numpy oracle gives for its dictionary hard-coded inside.  Exit code 0 = every check held."""
+    import subprocess
+    from test_abi import build_c_example
+    exe = build_c_example(cs, str(tmp_path / "c_abi_example"))
+    r = subprocess.run([exe, str(tmp_path / "c_example.csmp")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
     # noiseless 3-sparse signals, k = 8: every signal stops after 3 atoms (eps-stop inside k_b_step)
     A, x, b = cs.sparse_data(n=96, m=400, k=3, rng=1, dtype=np.float32)
