@@ -319,6 +319,8 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
 extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                               double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
+    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
+        return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
     if (screened_on(ctx) && nsig > 0) {
         if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
         if (!B || !idx || !val || !nnz || k < 1 || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "batch: bad arguments");
@@ -334,6 +336,8 @@ extern "C" int csmp_omp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t
 extern "C" int csmp_fr_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
                              double max_eps, double min_delta, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
+    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
+        return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
     if (max_eps != max_eps || min_delta != min_delta) return fail(ctx, CSMP_EINVAL, "fr_batch: max_eps / min_delta is NaN");
     return batch_impl(ctx, CSMP_ALGO_FR, B, b_dtype, ldB, nsig, b_loc, k, max_eps, min_delta * min_delta, idx, val, nnz, out_loc);
 }

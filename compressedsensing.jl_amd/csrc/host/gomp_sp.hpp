@@ -210,6 +210,8 @@ static int gomp_enqueue(csmp_ctx* c, const void* col_dev, int b_dtype, int64_t l
 extern "C" int csmp_gomp_batch(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t l, int64_t k,
                                double eps, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
+    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
+        return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
     if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");  // src/matchingpursuit.jl:127
     if (!B || nsig < 0 || k < 1 || l < 1 || l > k || ldB < ctx->M) return fail(ctx, CSMP_EINVAL, "gomp_batch: bad arguments (needs 1 <= l <= k)");
     if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) return fail(ctx, CSMP_EINVAL, "b_dtype must be CSMP_F32 or CSMP_F64");

@@ -160,6 +160,9 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
                                 int method, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->comm) return fail(ctx, CSMP_ESTATE, "omp_sharded: no communicator (csmp_comm_init)");
+    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
+        return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
+
     if (nsig < 0 || k < 1 || !idx || !val || !nnz || (method != 0 && method != 1)) return fail(ctx, CSMP_EINVAL, "omp_sharded: bad arguments");
     if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
     if (nsig == 0) return CSMP_OK;

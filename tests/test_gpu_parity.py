@@ -698,6 +698,16 @@ def test_batched_mfma_eps_stop_and_padding(cs, oracle, D):
         assert np.all(idx[3:, s] == -1)
     with pytest.raises(cs.CsmpError):
         d.ctx.omp_batch_mfma(B, 8, -1.0)
+    # a location code that is not CSMP_HOST / CSMP_DEVICE is refused, not dereferenced (CSMP_HOST_STREAMED belongs to dictionaries)
+    import ctypes as C
+    Bf = np.asfortranarray(B)
+    idx = np.zeros((8, 7), np.int64, order="F")
+    val = np.zeros((8, 7), np.float64, order="F")
+    nn = np.zeros(7, np.int64)
+    for name in ("csmp_omp_batch", "csmp_omp_batch_mfma"):
+        with pytest.raises(cs.CsmpError):
+            d.ctx.call(name, Bf.ctypes.data_as(C.c_void_p), 1, C.c_int64(96), C.c_int64(7), 2, C.c_int64(8), C.c_double(1e-6),
+                       idx.ctypes.data_as(C.c_void_p), val.ctypes.data_as(C.c_void_p), nn.ctypes.data_as(C.c_void_p), 0)
 
 
 def test_oblivious_and_acquisitions(cs, oracle, D):
