@@ -135,6 +135,8 @@ struct SpJob {
     double delta = 0.0, resnorm = 0.0, oldnorm = 0.0;
     std::vector<int64_t> xi;  // the support (sorted) and its coefficients
     std::vector<double> xv;
+    std::vector<int64_t> prev_xi;  // ... as they were before the current acquisition
+    std::vector<double> prev_xv;
     std::vector<int> cols;    // the set whose least squares is in flight
     enum Phase { IDLE, SELECT, LS_FIRST, LS_UNION, LS_PRUNED, DONE } phase = IDLE;
     bool screened = false, sel_screened = false, want_norm = false, gram_inflight = false;

@@ -832,6 +832,8 @@ static int sp_job_selected(SpJob& j, SpJob::Phase next) {
         }
     }
     const int nt = *pnt;
+    j.prev_xi = j.xi;  // the support this acquisition starts from and its solution: if the prune hands the same set back, that IS the result
+    j.prev_xv = j.xv;
     std::vector<int> mine(j.xi.begin(), j.xi.end()), fresh(top, top + nt);  // (the support comes sorted; the k best atoms by value)
     std::sort(fresh.begin(), fresh.end());
     fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
@@ -892,6 +894,16 @@ static int sp_job_advance(SpJob& j) {
                 for (size_t t = 0; t < j.xi.size(); ++t)
                     if (!kill[t]) keep.push_back(j.xi[t]);
                 j.xi.swap(keep);
+            }
+            if (j.oldnorm >= 0.0 && j.xi == j.prev_xi) {
+                // The prune returned the support the iteration started from.  solve! on it (:82) is the very computation that
+                // produced x and r before the acquisition -- the reference gets the same numbers again, bit for bit, and stops by
+                // oldnorm <= resnorm (:96).  So do we, without running it a second time.
+                j.xv = j.prev_xv;
+                j.resnorm = j.oldnorm;
+                ++j.it;
+                j.phase = SpJob::DONE;
+                return CSMP_OK;
             }
             j.cols.clear();
             for (auto i : j.xi) j.cols.push_back((int)i);
