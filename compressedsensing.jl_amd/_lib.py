@@ -70,8 +70,6 @@ SIGNATURES = {
     "csmp_gomp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, i64, C.c_double, vp, vp, vp, C.c_int]),
     "csmp_sp_batch": (C.c_int, [vp, vp, C.c_int, i64, i64, i64, C.c_double, i64, vp, vp, vp, vp]),
     "csmp_omp_batch_mfma": (C.c_int, [vp, vp, C.c_int, i64, i64, C.c_int, i64, C.c_double, vp, vp, vp, C.c_int]),
-    "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
-    "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64), C.POINTER(i64),
                                    C.POINTER(C.c_double)]),
     "csmp_screened_stats": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64), C.c_int]),
@@ -83,11 +81,20 @@ SIGNATURES = {
     "csmp_solver_state": (C.c_int, [vp, vp, vp, C.POINTER(i64), C.POINTER(C.c_double), vp, C.POINTER(C.c_int)]),
     "csmp_sweep": (C.c_int, [vp, vp, vp, i64, vp, vp]),
     "csmp_lstsq": (C.c_int, [vp, vp, i64, vp, C.c_int, vp]),
+}
+
+
+# measurement and test hooks: include/csmp_internal.h (not part of the drop-in boundary)
+INTERNAL_SIGNATURES = {
     "csmp_profile_enable": (C.c_int, [vp, C.c_int]),
     "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64)]),
+    "csmp_tune": (C.c_int, [vp, C.c_int, i64]),
+    "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
+    "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-
+TUNE = {"sweep_kernel": 1, "sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
 
@@ -141,7 +148,7 @@ def lib():
             raise CsmpError(ESTATE, f"{LIB_PATH} is missing -- build it with `make -C {os.path.dirname(LIB_PATH)}`; "
                                     "there is no CPU fallback")
         L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(INTERNAL_SIGNATURES.items()):
             f = getattr(L, name)  # AttributeError if the ABI and the header disagree
             f.restype = res
             f.argtypes = args
@@ -684,6 +691,17 @@ class Context:
         ms = C.c_double(0)
         self.call("csmp_bench_sweep", int(variant), int(reps), C.byref(ms))
         return ms.value
+
+    def sweep_config(self):
+        """what configure_sweep chose for the resident dictionary (csmp_internal.h)"""
+        kind, unit, ph, wg, lds = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), i64(0)
+        self.call("csmp_sweep_config", C.byref(kind), C.byref(unit), C.byref(ph), C.byref(wg), C.byref(lds))
+        return {"kernel": "k_sweep_gen" if kind.value else "k_sweep_pf", "unit_loads": unit.value, "phases": ph.value,
+                "workgroups": wg.value, "lds_bytes": int(lds.value)}
+
+    def tune(self, key, value):
+        """measurement override (csmp_internal.h): key in TUNE"""
+        self.call("csmp_tune", int(TUNE[key]), i64(int(value)))
 
 
 # ---- signal sharding: the wire layout of the ONE exchange (host memory, no ctx)

@@ -5,6 +5,7 @@
 // The host code is cut by solver family into host/*.hpp, included below IN ORDER (helpers are file-local
 // functions defined before their users); this file and csmp_screen.hip are the library's two translation units.
 #include "../../include/csmp.h"
+#include "../../include/csmp_internal.h"
 #include "csmp_kernels.hpp"
 #include "csmp_batched.hpp"
 #include "csmp_screened.hpp"

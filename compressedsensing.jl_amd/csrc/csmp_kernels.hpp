@@ -118,167 +118,13 @@ __device__ __forceinline__ int r_slot(int m) {  // index in doubles
 }
 
 // ---------------------------------------------------------------------------------------------
-// Sweep: c = A' r (Float64), fused |.| + arg-max partials.  One wave owns kCPW whole columns at a
-// time (16 KiB contiguous each at M = 4096 f32), lanes stride the rows with 16-B loads, r lives
-// in LDS.  Grid-stride over column groups; one (max |c|, first index) pair per workgroup.
-//   U     row chunks (64 lanes x 16 B) whose loads are issued together: U*kCPW loads in flight
-//   FULL  Mv is a multiple of U*64*VEC rows (no row predicate in the hot loop)
-//   NT    non-temporal dictionary loads (A is streamed once per sweep and exceeds every cache)
-//   TACC  double = product; float exists only as a bandwidth probe (csmp_bench_sweep)
-// dynamic LDS: r image (nchunk*64*VEC doubles) + 64 doubles of reduction scratch
-template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW>
-__device__ __forceinline__ void sweep_body(
-    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
-    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask, const int bid, const int nblk, double* lds) {
-    using VT = typename Vec<TA>::type;
-    constexpr int VEC = Vec<TA>::n;
-    constexpr int ROWS = kWave * VEC;  // rows per chunk
-    constexpr int NW = kSweepThreads / kWave;
-    if (st->done & skipmask) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nchunk = (Mv + ROWS - 1) / ROWS;
-    const int Mlds = nchunk * ROWS;
-    double* red = lds + Mlds;                           // [4]
-    double* redv = red + 8;                             // [16]
-    int* redi = reinterpret_cast<int*>(redv + 4 * NW);  // [16]
-
-    // prologue: r -> LDS (zero beyond Mv), ||r||^2 in a fixed order (identical in every workgroup)
-    double n2 = 0.0;
-    for (int m = tid; m < Mlds; m += kSweepThreads) {
-        const double v = (m < Mv) ? r[m] : 0.0;
-        lds[r_slot<VEC>(m)] = v;
-        n2 = fma(v, v, n2);
-    }
-    n2 = block_sum256(n2, red);
-    if (bid == 0 && tid == 0) st->rnorm2 = n2;
-    if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
-        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-        return;
-    }
-
-    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
-    double bestv = -1.0;
-    int besti = 0x7fffffff;
-    const int64_t stride = (int64_t)nblk * NW * CPW;
-    for (int64_t cg = ((int64_t)bid * NW + wave) * CPW; cg < N; cg += stride) {
-        const VT* p[CPW];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) {
-            const int64_t col = (cg + c < N) ? cg + c : N - 1;
-            p[c] = reinterpret_cast<const VT*>(A + col * ld) + lane;
-        }
-        TACC acc[CPW];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) acc[c] = (TACC)0;
-
-        for (int t = 0; t < nchunk; t += U) {
-            VT a[U][CPW];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int c = 0; c < CPW; ++c) {
-                    if constexpr (FULL) {
-                        if constexpr (NT)
-                            a[u][c] = __builtin_nontemporal_load(p[c] + (t + u) * kWave);
-                        else
-                            a[u][c] = p[c][(t + u) * kWave];
-                    } else {
-                        const int row = (t + u) * ROWS + lane * VEC;
-                        a[u][c] = (VT)0;
-                        if (row < Mv) a[u][c] = p[c][(t + u) * kWave];
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                if constexpr (VEC == 4) {
-                    const f64x2 r01 = rs[((t + u) * 2 + 0) * kWave + lane];
-                    const f64x2 r23 = rs[((t + u) * 2 + 1) * kWave + lane];
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c) {
-                        acc[c] = fma((TACC)a[u][c].x, (TACC)r01.x, acc[c]);
-                        acc[c] = fma((TACC)a[u][c].y, (TACC)r01.y, acc[c]);
-                        acc[c] = fma((TACC)a[u][c].z, (TACC)r23.x, acc[c]);
-                        acc[c] = fma((TACC)a[u][c].w, (TACC)r23.y, acc[c]);
-                    }
-                } else {
-                    const f64x2 r01 = rs[(t + u) * kWave + lane];
-#pragma unroll
-                    for (int c = 0; c < CPW; ++c) {
-                        acc[c] = fma((TACC)a[u][c].x, (TACC)r01.x, acc[c]);
-                        acc[c] = fma((TACC)a[u][c].y, (TACC)r01.y, acc[c]);
-                    }
-                }
-            }
-        }
-        // transposing butterfly: CPW accumulators x 64 lanes -> each (64/CPW)-lane group holds one column
-        double s0;
-        if constexpr (CPW == 4) {
-            double s1;
-            {
-                const bool hi = lane & 32;
-                const double k0 = hi ? (double)acc[2] : (double)acc[0], k1 = hi ? (double)acc[3] : (double)acc[1];
-                const double g0 = hi ? (double)acc[0] : (double)acc[2], g1 = hi ? (double)acc[1] : (double)acc[3];
-                s0 = k0 + shx(g0, 32);
-                s1 = k1 + shx(g1, 32);
-            }
-            {
-                const bool hi = lane & 16;
-                const double k = hi ? s1 : s0, g = hi ? s0 : s1;
-                s0 = k + shx(g, 16);
-            }
-        } else if constexpr (CPW == 2) {
-            const bool hi = lane & 32;
-            const double k = hi ? (double)acc[1] : (double)acc[0], g = hi ? (double)acc[0] : (double)acc[1];
-            s0 = k + shx(g, 32);
-            s0 += shx(s0, 16);
-        } else {
-            s0 = (double)acc[0];
-            s0 += shx(s0, 32);
-            s0 += shx(s0, 16);
-        }
-        s0 += shx(s0, 8);
-        s0 += shx(s0, 4);
-        s0 += shx(s0, 2);
-        s0 += shx(s0, 1);
-        constexpr int GL = kWave / CPW;  // lanes per column group
-        const int64_t col = cg + lane / GL;
-        if (col < N) {
-            if ((lane & (GL - 1)) == 0) cvec[col] = s0;
-            const double av = fabs(s0);
-            if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
-                bestv = av;
-                besti = (int)col;
-            }
-        }
-    }
-    if ((lane & 15) == 0) {  // (with CPW < 4 several 16-lane groups carry the same pair: harmless)
-        redv[wave * 4 + (lane >> 4)] = bestv;
-        redi[wave * 4 + (lane >> 4)] = besti;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double bv = redv[0];
-        int bi = redi[0];
-        for (int q = 1; q < 4 * NW; ++q)
-            if (better(redv[q], redi[q], bv, bi)) {
-                bv = redv[q];
-                bi = redi[q];
-            }
-        pval[bid] = bv;
-        pidx[bid] = bi;
-    }
-}
-template <typename TA, typename TACC, int U, bool FULL, bool NT, int CPW = kCPW>
-__global__ __launch_bounds__(kSweepThreads) void k_sweep(
-    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
-    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    sweep_body<TA, TACC, U, FULL, NT, CPW>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask,
-                                           (int)blockIdx.x, (int)gridDim.x, lds);
-}
+// Sweep: c = A' r (Float64), fused |.| + arg-max partials (argmaxinner!(P), src/matchingpursuit.jl:181-185).  One wave owns ONE
+// whole column at a time (16 KiB contiguous at M = 4096 f32), lanes stride the rows with 16-byte non-temporal loads (A is streamed
+// once per sweep and exceeds every cache), r lives in the LDS.  Grid-stride over columns; one (max |c|, first index) pair per
+// workgroup.  Two bodies: sweep_body_pf for columns of whole 8- or 16-chunk load blocks (the benchmark's shapes), sweep_body_gen
+// for every other shape.
+// dynamic LDS: the r image + 32 doubles of reduction scratch
+//
 // Software-pipelined form of the product sweep (one column per wave, full chunks, Float64): the NEXT
 // column's U loads are issued before the current column is converted, multiplied and reduced, so a
 // wave always has U..2U KiB in flight instead of draining to zero once per column.  Fewer waves
@@ -426,6 +272,200 @@ inline size_t sweep_lds_bytes(int Mv, int vec) {
     const int nchunk = (Mv + rows - 1) / rows;
     return (size_t)(nchunk * rows + 8 + 16 + 8) * sizeof(double);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The shape-general form of the pipelined product sweep (argmaxinner!(P), src/matchingpursuit.jl:181-185, for ANY size(A):
+// the reference allocates zeros(T, n) and calls mul! whatever n is, :54-60): ragged M, and a residual larger than the LDS.
+//   unit    U consecutive 64-lane loads (U KiB) of ONE column: the grain of the pipeline.  One wave owns one column at a time.
+//   ring    NB units in flight per wave, consumed oldest first; a consumed buffer is refilled at once with the unit NB ahead.
+//           In the steady loop every load is unconditional (no branch around a load), so the wait the compiler places in front
+//           of a unit's arithmetic is s_waitcnt vmcnt((NB-1)*U): the wave never drains below (NB-1)*U KiB in flight.
+//   ragged  a lane whose rows lie past the column's end CLAMPS its vector index to the column's last vector -- a load of valid
+//           memory, no predicate, no extra DRAM line -- and multiplies it with a zero of the residual image.
+//   phases  (PH) a residual that exceeds the LDS is staged KP rows at a time; the workgroup runs ALL its columns against one
+//           stage before the next one is loaded (two barriers per stage and launch, not per column), and a column's partial sum
+//           waits in c[col]: written by lane 0, re-read at agent scope (L2) by the same wave after the stage barrier.
+//           c[col] = ((stage 0) + stage 1) + ... -- a fixed order, like everything else on the selection path.
+// KP: rows of the residual image (a multiple of U*64*VEC; !PH: >= Mv).  dynamic LDS: KP doubles + 32 doubles of scratch.
+template <typename TA, int U, int NB, bool PH>
+__device__ __forceinline__ void sweep_body_gen(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, const int KP, double* lds) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    constexpr int UR = U * ROWS;  // rows per unit
+    constexpr int NW = kSweepThreads / kWave;
+    static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
+    if (st->done & skipmask) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nvec = Mv / VEC;  // 16-byte vectors per column (Mv is a multiple of VEC: the leading dimension is padded to 16 bytes)
+    const int nph = PH ? (Mv + KP - 1) / KP : 1;
+    double* red = lds + KP;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+
+    const int64_t col0 = (int64_t)bid * NW + wave, stride = (int64_t)nblk * NW;
+    const int64_t ncol = col0 < N ? (N - 1 - col0) / stride + 1 : 0;
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+
+    for (int ph = 0; ph < nph; ++ph) {
+        const int k0 = ph * KP;
+        const int rows_here = (Mv - k0) < KP ? (Mv - k0) : KP;
+        const int nunit = (rows_here + UR - 1) / UR;  // units per column in this stage
+        const int Mst = nunit * UR;                   // rows of the image in use (zero beyond Mv)
+        if (ph > 0) __syncthreads();                  // (everyone is done with the previous image; c[col] stores are acknowledged)
+        if (ph == 0) {
+            // image of the first stage, and ||r||^2 over ALL rows in a fixed per-thread order (identical in every workgroup).
+            // The loads go out 16 at a time (a rolled loop waits for each in turn: ~6 us of a 150 us kernel at M = 4096).
+            const int Mall = (PH && Mv > Mst) ? Mv : Mst;
+            constexpr int RP = 16;
+            double n2 = 0.0;
+            for (int m0 = tid; m0 < Mall; m0 += RP * kSweepThreads) {
+                double rv[RP];
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const int m = m0 + q * kSweepThreads;
+                    rv[q] = m < Mv ? r[m] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const int m = m0 + q * kSweepThreads;
+                    if (m < Mst) lds[r_slot<VEC>(m)] = rv[q];
+                    n2 = fma(rv[q], rv[q], n2);
+                }
+            }
+            for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+            __syncthreads();
+            if (lane == 0) red[wave] = n2;
+            __syncthreads();
+            n2 = (red[0] + red[1]) + (red[2] + red[3]);
+            if (bid == 0 && tid == 0) st->rnorm2 = n2;
+            if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+                if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+                return;
+            }
+        } else {
+            for (int m = tid; m < Mst; m += kSweepThreads) lds[r_slot<VEC>(m)] = (k0 + m < Mv) ? r[k0 + m] : 0.0;
+            __syncthreads();
+        }
+        const bool lastph = !PH || ph + 1 == nph;
+        const int k0v = k0 / VEC;
+
+        VT buf[NB][U];
+        double prev[NB];
+        int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
+        int ib = 0, cb = 0;
+        const int64_t T = ncol * nunit;
+        int64_t ileft = T, cleft = T;
+        double acc = 0.0;
+        auto issue = [&](VT(&b)[U], double& pv) {
+            const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
+            const int vb = k0v + ib * (U * kWave) + lane;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int v = vb + u * kWave;
+                b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
+            }
+            if constexpr (PH) pv = __hip_atomic_load(cvec + icol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (++ib == nunit) {
+                ib = 0;
+                icol += stride;
+            }
+            --ileft;
+        };
+        auto consume = [&](const VT(&b)[U], const double pv) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = cb * U + u;
+                if constexpr (VEC == 4) {
+                    const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                    const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                    acc = fma((double)b[u].x, r01.x, acc);
+                    acc = fma((double)b[u].y, r01.y, acc);
+                    acc = fma((double)b[u].z, r23.x, acc);
+                    acc = fma((double)b[u].w, r23.y, acc);
+                } else {
+                    const f64x2 r01 = rs[t * kWave + lane];
+                    acc = fma((double)b[u].x, r01.x, acc);
+                    acc = fma((double)b[u].y, r01.y, acc);
+                }
+            }
+            if (++cb == nunit) {  // the column's last unit of this stage
+                for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+                if constexpr (PH) {
+                    if (ph > 0) acc = pv + acc;
+                }
+                if (lane == 0) cvec[ccol] = acc;
+                if (lastph) {
+                    const double av = fabs(acc);
+                    if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
+                        bestv = av;
+                        besti = (int)ccol;
+                    }
+                }
+                acc = 0.0;
+                cb = 0;
+                ccol += stride;
+            }
+            --cleft;
+        };
+        if (T >= 2 * NB) {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) issue(buf[d], prev[d]);
+            const int64_t groups = T / NB - 1;
+            for (int64_t g = 0; g < groups; ++g) {
+#pragma unroll
+                for (int d = 0; d < NB; ++d) {
+                    consume(buf[d], prev[d]);
+                    issue(buf[d], prev[d]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int d = 0; d < NB; ++d)
+                if (d < T) issue(buf[d], prev[d]);
+        }
+        while (cleft > 0) {  // the last NB .. 2 NB - 1 units of the wave (or all of them, when there are fewer)
+#pragma unroll
+            for (int d = 0; d < NB; ++d) {
+                if (cleft == 0) break;
+                consume(buf[d], prev[d]);
+                if (ileft > 0) issue(buf[d], prev[d]);
+            }
+        }
+    }
+    if ((lane & 15) == 0) {
+        redv[wave * 4 + (lane >> 4)] = bestv;
+        redi[wave * 4 + (lane >> 4)] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int q = 1; q < 4 * NW; ++q)
+            if (better(redv[q], redi[q], bv, bi)) {
+                bv = redv[q];
+                bi = redi[q];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+template <typename TA, int U, int NB, bool PH>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_gen(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, int KP) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body_gen<TA, U, NB, PH>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x,
+                                  (int)gridDim.x, KP, lds);
+}
+inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * sizeof(double); }
 
 // ---------------------------------------------------------------------------------------------
 // block-wide lexicographic arg-max over (v, i) pairs held one per thread (256 threads)
@@ -1379,6 +1419,7 @@ struct TickSweep {
     const TA* A; int64_t ld; int Mv; int64_t N;
     const double* r; double* cvec; double* pval; int* pidx; DevState* st;
     double eps; int check_eps, skipmask, nblk, active;
+    int KP;  // k_sweep_gen's residual image rows (sweep kinds 1 and 2)
 };
 template <typename TA>
 struct TickQr1 {
@@ -1396,14 +1437,15 @@ struct TickQr2 {
     int kcap, jpad, force_reorth, jh, optimistic, active;
 };
 
+// KIND: the sweep body -- 0 sweep_body_pf (U = 16 / 8), 1 sweep_body_gen in one image (U = 16 / 8 / 4), 2 sweep_body_gen in phases (U = 8).
 // STEADY only names the kernel: the launches in which all three stages are live (every tick of a batch except the
 // 2 + 2 that fill and drain the pipeline of a signal triple) get a symbol of their own, so that a kernel trace
 // (rocprofv3 --kernel-trace --stats) reports the sweep-carrying ticks as one clean row.
-template <typename TA, int U, bool PF, bool STEADY = false>
+template <typename TA, int U, int KIND, bool STEADY = false>
 __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
                                                         const int G, const int sweep_first) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    // Workgroups are dispatched in index order.  sweep_first (CSMP_TICK_ORDER): the persistent sweep
+    // Workgroups are dispatched in index order.  sweep_first: the persistent sweep
     // workgroups take their CUs at t = 0 and the short append stages fill what is left, instead of the sweep
     // tail starting only when the stages have drained.
     int bid = (int)blockIdx.x;
@@ -1419,12 +1461,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, 
                          bid - G, lds);
     } else {
         if (sw.active) {
-            if constexpr (PF && U >= 8)
+            if constexpr (KIND == 0)
                 sweep_body_pf<TA, U, true>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
                                            sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
             else
-                sweep_body<TA, double, U, true, true, 1>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st,
-                                                         sw.eps, sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
+                sweep_body_gen<TA, U, 32 / U, KIND == 2>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
+                                                         sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
         }
     }
 }

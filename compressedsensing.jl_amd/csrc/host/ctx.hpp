@@ -173,8 +173,14 @@ struct csmp_ctx {
     int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
     int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
     int sweep_grid = 0, sweep_U = 1;
-    int tick_U = 1;  // load-block size of the sweep inside the tick kernel (8 where it tiles, else sweep_U)
     bool sweep_full = false, sweep_nt = false;
+    // which product sweep serves this dictionary (configure_sweep): 0 = k_sweep_pf (columns of whole 8- or 16-chunk blocks, residual in
+    // the LDS: the shape the benchmark is quoted on), 1 = k_sweep_gen (any shape: ragged rows, a residual staged in phases)
+    int sweep_kind = 0;
+    int sweep_gU = 16;      // k_sweep_gen: loads per unit (16 / 8 / 4; the ring holds 32 loads)
+    bool sweep_ph = false;  // k_sweep_gen: the residual is staged in phases of sweep_KP rows
+    int sweep_KP = 0;       // rows of the residual image in the LDS
+    int tune_sweep_kind = 0, tune_sweep_grid = 0, tune_sweep_U = 0;  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic
     // options (csmp_set_option, include/csmp.h)
     void* comm = nullptr;          // ncclComm_t of the signal-sharded solve (csmp_comm_init, host/rccl.hpp); this rank and the group's size
     int comm_rank = 0, comm_world = 1;
@@ -194,8 +200,6 @@ struct csmp_ctx {
     Solver park[3];  // parked slots (park[active] is unused): three signals are pipelined in csmp_omp_batch
     int active = 0;
     bool pipeline = true;
-    int tick_wg_per_cu = 2;  // sweep workgroups per CU inside the tick kernel (CSMP_TICK_WGS)
-    bool tick_pf = true;     // software-pipelined sweep inside the tick kernel (CSMP_TICK_PF)
     int tick_nblk = 0;       // absolute override of the sweep workgroup count (CSMP_TICK_NBLK), 0 = per-CU rule
     bool tick_sweep_first = false;  // dispatch the sweep workgroups ahead of the append stages (CSMP_TICK_ORDER=1)
     Batch bt;

@@ -29,13 +29,10 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
     return CSMP_OK;
 }
 
-// experimental column-per-wave variants (f32 dictionary, full chunks only): cpw in {1,2}, U in {4,8,16}
-
-// variant = U + 8*nt + 16*f32acc + 256*workgroups_per_CU (0 = product configuration)
-// variant >= 1<<20: experimental: (variant>>20) = cpw, bits 0-7 = U, bits 8-15 = workgroups per CU
 extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
     if (!ctx || reps < 1) return CSMP_EINVAL;
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (variant != 0) return fail(ctx, CSMP_ESTATE, "bench_sweep: variant 0 (the product kernel) is the only one");
     HIPCHECK(hipSetDevice(ctx->dev));
     CHECK(solver_ensure(ctx, 1, 1, false));
     ctx->s.begun = false;
@@ -46,28 +43,53 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
         v = ((double)(sd >> 11) / 9007199254740992.0) - 0.5;
     }
     CHECK(upload_b(ctx, r.data(), CSMP_F64));
-    int U = ctx->sweep_U, grid = ctx->sweep_grid;
-    bool nt = ctx->sweep_nt, f32acc = false;
-    if (variant != 0) return fail(ctx, CSMP_ESTATE, "bench_sweep: variant 0 (the product kernel) is the only one");
     const bool was = ctx->prof;
     ctx->prof = false;
-    if (variant == 0) {
-        for (int i = 0; i < 3; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
-        hipEvent_t e0, e1;
-        HIPCHECK(hipEventCreate(&e0));
-        HIPCHECK(hipEventCreate(&e1));
-        HIPCHECK(hipEventRecord(e0, ctx->stream));
-        for (int i = 0; i < reps; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
-        HIPCHECK(hipEventRecord(e1, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        float ms0 = 0.f;
-        HIPCHECK(hipEventElapsedTime(&ms0, e0, e1));
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        ctx->prof = was;
-        if (avg_ms) *avg_ms = (double)ms0 / reps;
-        return CSMP_OK;
+    for (int i = 0; i < 3; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0));
+    HIPCHECK(hipEventCreate(&e1));
+    HIPCHECK(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; ++i) CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, 0));
+    HIPCHECK(hipEventRecord(e1, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    float ms0 = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms0, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    ctx->prof = was;
+    if (avg_ms) *avg_ms = (double)ms0 / reps;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* kind, int* unit_loads, int* phases, int* workgroups, int64_t* lds_bytes) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!ctx->dA) return CSMP_ESTATE;
+    if (kind) *kind = ctx->sweep_kind;
+    if (unit_loads) *unit_loads = ctx->sweep_U;
+    if (phases) *phases = ctx->sweep_ph ? (ctx->Mv + ctx->sweep_KP - 1) / ctx->sweep_KP : 1;
+    if (workgroups) *workgroups = ctx->sweep_grid;
+    if (lds_bytes) *lds_bytes = (int64_t)ctx->sweep_lds;
+    return CSMP_OK;
+}
+
+extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
+    if (!ctx) return CSMP_EINVAL;
+    if (value < 0 || value > (1 << 20)) return fail(ctx, CSMP_EINVAL, "csmp_tune: value out of range");
+    switch (key) {
+        case CSMP_TUNE_SWEEP_KERNEL: ctx->tune_sweep_kind = value ? 1 : 0; break;
+        case CSMP_TUNE_SWEEP_GRID: ctx->tune_sweep_grid = (int)value; break;
+        case CSMP_TUNE_SWEEP_UNIT:
+            if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, CSMP_EINVAL, "csmp_tune: unit loads must be 0, 4, 8 or 16");
+            ctx->tune_sweep_U = (int)value;
+            break;
+        case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;
+        default: return fail(ctx, CSMP_EINVAL, "csmp_tune: unknown key");
     }
-    (void)U; (void)grid; (void)nt; (void)f32acc;
+    if (ctx->dA) {
+        HIPCHECK(hipSetDevice(ctx->dev));
+        HIPCHECK(sync_all(ctx));
+        CHECK(configure_sweep(ctx));
+    }
     return CSMP_OK;
 }

@@ -210,7 +210,7 @@ int csmp_sp_batch(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_
  * before returning, so a certified result equals csmp_omp_batch's.  The error bound behind the certificate is
  * chosen by CSMP_OPT_BATCH_CERT (below).  Dictionaries of more than 8192 rows, and support capacities min(k, M) whose per-signal
  * vectors exceed the LDS (about 5000 columns at M = 4096), are solved by csmp_omp_batch's exact sweeps (same results;
- * csmp_batch_screen_kernel then reports "none").  The per-signal state is two k x k Float64 factors: a batch
+ * the internal csmp_batch_screen_kernel then reports "none").  The per-signal state is two k x k Float64 factors: a batch
  * whose state does not fit the free HBM is solved in chunks of whole 256-signal tiles (csmp_batch_stats adds them up).  With out_loc == CSMP_DEVICE this call still
  * synchronises once (to read the per-signal certificates). */
 int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k,
@@ -219,13 +219,6 @@ int csmp_omp_batch_mfma(csmp_ctx *ctx, const void *B, int b_dtype, int64_t ldB, 
  * why), and -- when profiling is enabled -- the number and total duration (ms) of screening GEMMs */
 int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly, int64_t *uncertain, int64_t *illcond,
                      int64_t *screen_launches, double *screen_ms);
-/* layout of the last csmp_omp_batch_mfma call (measurement only): signal columns of one screening launch (the batch
- * padded to whole 256-signal tiles) and the number of streams used (1: the screening GEMM and the per-signal
- * kernels alternate on the context's stream) */
-int csmp_batch_layout(const csmp_ctx *ctx, int64_t *screen_signals, int *streams);
-/* name of the screening kernel the last csmp_omp_batch_mfma call ran (measurement only) */
-const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
-
 /* ------------------------------------------------------------------ options
  * The reference passes every behavioural choice as an argument (src/matchingpursuit.jl:88-91,145-148;
  * src/twostage.jl:87); those are arguments here too.  The choices that exist only on this side of the boundary are
@@ -356,16 +349,6 @@ int csmp_sweep(csmp_ctx *ctx, const double *r, double *abs_corr, int64_t topk, i
 /* A[:, cols] \ b by the on-device QR: the UpdatableQR solve pinned by test/forward.jl:23-28
  * ("P.AiQR \ y ~ A[:, nzind] \ y").  cols in any order; coef aligned with cols. */
 int csmp_lstsq(csmp_ctx *ctx, const int64_t *cols, int64_t ncols, const void *b, int b_dtype, double *coef);
-
-/* ------------------------------------------------------------------ measurement
- * on = 1: every sweep launch is bracketed by HIP events on the ctx stream; on = n > 1: every
- * n-th launch only (an event pair costs a few microseconds of stream time); 0 = off. */
-int csmp_profile_enable(csmp_ctx *ctx, int on);
-/* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
-int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);
-/* one-off sweep bandwidth probe: runs `reps` sweeps on a random residual, returns avg ms.
- * variant: 0 = product kernel; others = experimental variants */
-int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
 
 #ifdef __cplusplus
 }

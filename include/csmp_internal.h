@@ -1,0 +1,41 @@
+/*
+ * csmp_internal.h -- measurement and test hooks of libcsmp.so.  NOT part of the drop-in boundary: nothing a host of the
+ * reference's API (mp / omp / gomp / sp, the Update functors) needs is declared here, and the Julia wrapper binds none of it.
+ * bench.py, tools/ and tests/ bind these through compressedsensing.jl_amd/_lib.py (INTERNAL_SIGNATURES).
+ */
+#ifndef CSMP_INTERNAL_H
+#define CSMP_INTERNAL_H
+#include "csmp.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* on = 1: every sweep launch is bracketed by HIP events on the ctx stream; on = n > 1: every
+ * n-th launch only (an event pair costs a few microseconds of stream time); 0 = off. */
+int csmp_profile_enable(csmp_ctx *ctx, int on);
+/* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
+int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);
+/* sweep bandwidth probe: `reps` product sweeps (argmaxinner!(P), src/matchingpursuit.jl:181-185) of a random residual,
+ * bracketed by one HIP event pair on the ctx stream; returns the average ms per sweep.  variant must be 0. */
+int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
+/* what configure_sweep chose for the resident dictionary: kind 0 = k_sweep_pf, 1 = k_sweep_gen; loads per unit; phases the
+ * residual is staged in (1: one LDS image); workgroups; dynamic LDS bytes.  Any pointer may be NULL. */
+int csmp_sweep_config(const csmp_ctx *ctx, int *kind, int *unit_loads, int *phases, int *workgroups, int64_t *lds_bytes);
+/* measurement overrides of that choice, applied to the resident dictionary at once and to later ones: 0 = automatic */
+#define CSMP_TUNE_SWEEP_KERNEL 1 /* 1: k_sweep_gen for every shape */
+#define CSMP_TUNE_SWEEP_GRID 2   /* workgroups of the product sweep */
+#define CSMP_TUNE_SWEEP_UNIT 3   /* k_sweep_gen: loads per unit (16, 8 or 4) */
+#define CSMP_TUNE_TICK_GRID 4    /* sweep workgroups inside the tick kernel of csmp_omp_batch */
+int csmp_tune(csmp_ctx *ctx, int key, int64_t value);
+
+/* layout of the last csmp_omp_batch_mfma call: signal columns of one screening launch (the batch
+ * padded to whole 256-signal tiles) and the number of streams used (1: the screening GEMM and the per-signal
+ * kernels alternate on the context's stream) */
+int csmp_batch_layout(const csmp_ctx *ctx, int64_t *screen_signals, int *streams);
+/* name of the screening kernel the last csmp_omp_batch_mfma call ran ("none": the exact sweeps served it) */
+const char *csmp_batch_screen_kernel(const csmp_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

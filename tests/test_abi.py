@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    src = open(os.path.join(ROOT, "include", "csmp.h")).read()
+def header_symbols(name="csmp.h"):
+    src = open(os.path.join(ROOT, "include", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(csmp_[a-z_0-9]+)\s*\(", src)))
 
@@ -20,8 +20,8 @@ def test_library_exports_every_declared_symbol(cs):
     L = ctypes.CDLL(cs.LIB_PATH)
     syms = header_symbols()
     assert len(syms) >= 20
-    for s in syms:
-        assert hasattr(L, s), f"{s} declared in include/csmp.h but not exported"
+    for s in syms + header_symbols("csmp_internal.h"):
+        assert hasattr(L, s), f"{s} declared in include/*.h but not exported"
     L.csmp_version.restype = ctypes.c_int
     assert L.csmp_version() >= 100
 
@@ -30,6 +30,11 @@ def test_binding_table_matches_header(cs):
     from csmp_pkg import load
     lib = load()._lib
     assert sorted(lib.SIGNATURES) == header_symbols()
+    assert sorted(lib.INTERNAL_SIGNATURES) == header_symbols("csmp_internal.h")
+    # the measurement hooks are not part of the boundary: the public header and the Julia wrapper name none of them
+    jl = open(os.path.join(ROOT, "compressedsensing.jl_amd", "julia", "CompressedSensingAMD.jl")).read()
+    for name in lib.INTERNAL_SIGNATURES:
+        assert name not in header_symbols() and (":" + name) not in jl, name
 
 
 def test_product_does_not_link_the_oracle(cs):
