@@ -171,7 +171,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="rigorous", help="--workload batched: CSMP_OPT_BATCH_CERT (rigorous is the library's default)")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
-    p.add_argument("--workload", choices=["omp", "screened", "streamed", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
+    p.add_argument("--tune", type=str, default="", help="measurement overrides of the sweep configuration (csmp_internal.h), e.g. tick_grid=224,sweep_grid=192")
+    p.add_argument("--workload", choices=["omp", "shapes", "screened", "streamed", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
                         "k=128, bf16 MFMA screening GEMM + Float64 rescoring (a step = one batch); gomp / sp = configs[4]: "
                         "A 8192x131072, k=512, GOMP with S=4 atoms per sweep / Subspace Pursuit (a step = one solve)")
@@ -612,7 +613,7 @@ def measure_config5(workload, K, W, cs, torch, dev, D5=None, At5=None, delta=1e-
                       "signals_in_flight": (min(3, D5.ctx.get_option("solves_in_flight")) if screened else 2) if workload == "gomp"
                       else (D5.ctx.get_option("solves_in_flight") if workload == "sp" else 1)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_pf<float,16,true>",
+                        "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None, "kernel": "csmp::k_sweep_gen<float,16,2,false>",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     if isg:  # the whole solve against the same roofline: one dictionary pass per S atoms is all the algorithm needs
         out["roofline"]["whole_solve"] = {"achieved": alg / S * atoms / dt / 1e9, "frac": alg / S * atoms / dt / 1e9 / HBM_PEAK_GBS,
@@ -731,7 +732,7 @@ def run_twostage(args, cs, torch, dev, At, D, show=True):
                       "iterations": int(iters), "iterations_per_s": iters / dt, "sweeps_timed": int(sweeps)},
            "roofline": {"bound": "hbm", "achieved": alg / avg / 1e9 if sweeps else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (alg / avg / 1e9 / HBM_PEAK_GBS) if sweeps else 0.0, "traffic": None,
-                        "kernel": ("csmp::k_sweep_i8<2,3,true>" if image == 2 else "csmp::k_sweep_bf16<2,3,true>" if image == 1 else "csmp::k_sweep_f16<2,3,true>" if image == 3 else "csmp::k_sweep_pf<float,16,true>")
+                        "kernel": ("csmp::k_sweep_i8<2,3,true>" if image == 2 else "csmp::k_sweep_bf16<2,3,true>" if image == 1 else "csmp::k_sweep_f16<2,3,true>" if image == 3 else "csmp::k_sweep_gen<float,16,2,false>")
                         if args.workload == "ompr" else "csmp::k_fr_sweep<float,16,true,NQ> (NQ = 2 in the loop, 1 / -1 at the start)",
                         "launches_timed": int(sweeps), "avg_launch_us": avg * 1e6, "algorithmic_bytes_per_launch": alg}}
     D.ctx.profile_enable(False)
@@ -886,6 +887,36 @@ def run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen
     return out
 
 
+def run_shapes(args, cs, torch, np, dev):
+    """The product sweep c = A'r over dictionaries of ~1 GiB with M = 1000 .. 32768 rows, Float32 and Float64 (the reference is
+    generic over shape and element type, src/matchingpursuit.jl:54-60; its own tests are Float64): every row checked against torch's
+    Float64 product, timed with HIP events (csmp_bench_sweep, median of five runs), priced against 8 TB/s.  Writes the table to
+    profiles/r05_sweep_shapes.json when run from the repository (tools/sweep_shapes.py holds the loop)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import sweep_shapes
+    rows = sweep_shapes.table(torch, np, cs, dev, reps=max(5, min(args.steps, 20)))
+    worst = min(rows, key=lambda r: r["frac"])
+    out = {"metric": "product sweep A'r: worst fraction of the HBM roofline over 14 shapes (M = 1000..32768, f32 and f64, ~1 GiB each)",
+           "value": worst["frac"], "unit": "fraction of 8 TB/s", "n_gpus": 1, "steps": len(rows), "warmup": 0,
+           "ms_per_step": sum(r["us"] for r in rows) / len(rows) / 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "shape table of the A'r sweep (verdict round 4, item 1)"},
+           "roofline": {"bound": "hbm", "achieved": worst["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": worst["frac"], "traffic": None,
+                        "kernel": "csmp::k_sweep_gen (worst row: M = %d %s)" % (worst["M"], worst["dtype"])},
+           "all_correct": all(r["argmax_ok"] and r["max_rel_err"] < 1e-12 for r in rows), "rows": rows}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_sweep_shapes.json"), "w") as f:
+            json.dump(rows, f, indent=1)
+    except OSError:
+        pass
+    return out
+
+
+def tick_kernel_name(D):
+    """the symbol of the steady-state tick for this dictionary, as rocprofv3 prints it"""
+    c = D.ctx.sweep_config()
+    return "k_tick<float, %d, %s, true>" % (c["unit_loads"], "true" if c["phases"] > 1 else "false")
+
+
 def rank_census(torch, dist, dev, use_dist, world):
     """ranks_seen = the process group's own world size; devices = every rank's GPU as IT names it, gathered."""
     name = torch.cuda.get_device_name(dev) + f" (cuda:{dev.index})"
@@ -950,8 +981,14 @@ def main():
                                  screened={"f16": 3, "bf16": 1, "int8": 2}[args.screen_image] if args.screened else 0))
             D5.close()
         return finish()
+    if args.workload == "shapes":
+        if rank == 0:
+            emit(run_shapes(args, cs, torch, np, dev))
+        return finish()
     At = make_dictionary(torch, dev)
     D = cs.Dictionary(At, device=local)  # borrowed, zero-copy
+    for kv in filter(None, args.tune.split(",")):
+        D.ctx.tune(kv.split("=")[0], int(kv.split("=")[1]))
     if args.workload in ("fr", "ompr", "srr"):
         if args.steps == 18 and args.warmup == 3:
             args.steps, args.warmup = (9, 3) if args.workload == "fr" else (6, 1)
@@ -1048,12 +1085,13 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "csmp::k_tick<float,8,true,true> = the steady-state tick of the pipelined batch: software-pipelined sweep of one "
-                          "signal (one column per wave, 8-16 KiB of nt loads in flight per wave, one workgroup per CU) fused with the two "
-                          "short append stages of two other signals; csmp::k_sweep_pf<float,16,true> when a signal runs alone",
+                "kernel": "csmp::" + tick_kernel_name(D) + " = the steady-state tick of the pipelined batch: the product sweep of one "
+                          "signal (one column per wave, a ring of 32 nt loads = up to 32 KiB in flight per wave) fused with the two "
+                          "short append stages of two other signals; csmp::k_sweep_gen<float,16,2,false> when a signal runs alone",
+                "sweep_config": D.ctx.sweep_config(),
                 "launches_timed": int(sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
                 "timer": "HIP events on the library's stream around every %d-th steady-state tick of the timed region" % args.profile_every}
-        rp = rocprof_row("k_tick<float, 8, true, true>")
+        rp = rocprof_row(tick_kernel_name(D), pattern="r05_bench_kernel_stats.csv")
         if rp:
             roof["committed_profile"] = rp
         out = {

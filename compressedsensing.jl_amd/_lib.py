@@ -94,7 +94,7 @@ INTERNAL_SIGNATURES = {
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-TUNE = {"sweep_kernel": 1, "sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4}  # CSMP_TUNE_* (include/csmp_internal.h)
+TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
 
@@ -694,10 +694,10 @@ class Context:
 
     def sweep_config(self):
         """what configure_sweep chose for the resident dictionary (csmp_internal.h)"""
-        kind, unit, ph, wg, lds = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), i64(0)
-        self.call("csmp_sweep_config", C.byref(kind), C.byref(unit), C.byref(ph), C.byref(wg), C.byref(lds))
-        return {"kernel": "k_sweep_gen" if kind.value else "k_sweep_pf", "unit_loads": unit.value, "phases": ph.value,
-                "workgroups": wg.value, "lds_bytes": int(lds.value)}
+        unit, ph, wg, twg, lds = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), i64(0)
+        self.call("csmp_sweep_config", C.byref(unit), C.byref(ph), C.byref(wg), C.byref(twg), C.byref(lds))
+        return {"unit_loads": unit.value, "phases": ph.value, "workgroups": wg.value, "tick_workgroups": twg.value,
+                "lds_bytes": int(lds.value)}
 
     def tune(self, key, value):
         """measurement override (csmp_internal.h): key in TUNE"""

@@ -121,161 +121,9 @@ __device__ __forceinline__ int r_slot(int m) {  // index in doubles
 // Sweep: c = A' r (Float64), fused |.| + arg-max partials (argmaxinner!(P), src/matchingpursuit.jl:181-185).  One wave owns ONE
 // whole column at a time (16 KiB contiguous at M = 4096 f32), lanes stride the rows with 16-byte non-temporal loads (A is streamed
 // once per sweep and exceeds every cache), r lives in the LDS.  Grid-stride over columns; one (max |c|, first index) pair per
-// workgroup.  Two bodies: sweep_body_pf for columns of whole 8- or 16-chunk load blocks (the benchmark's shapes), sweep_body_gen
-// for every other shape.
-// dynamic LDS: the r image + 32 doubles of reduction scratch
-//
-// Software-pipelined form of the product sweep (one column per wave, full chunks, Float64): the NEXT
-// column's U loads are issued before the current column is converted, multiplied and reduced, so a
-// wave always has U..2U KiB in flight instead of draining to zero once per column.  Fewer waves
-// then saturate HBM, and fewer concurrent DRAM streams reach a higher bandwidth.
-template <typename TA, int U, bool NT>
-__device__ __forceinline__ void sweep_body_pf(
-    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
-    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask, const int bid, const int nblk, double* lds) {
-    using VT = typename Vec<TA>::type;
-    constexpr int VEC = Vec<TA>::n;
-    constexpr int ROWS = kWave * VEC;
-    constexpr int NW = kSweepThreads / kWave;
-    if (st->done & skipmask) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nchunk = Mv / ROWS;  // exact (FULL) and a multiple of U
-    const int Mlds = nchunk * ROWS;
-    double* red = lds + Mlds;
-    double* redv = red + 8;
-    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
-
-    const int64_t stride = (int64_t)nblk * NW;
-    const int nblocks = nchunk / U;  // load blocks per column
-    auto ldv = [&](const VT* p) -> VT {
-        if constexpr (NT) return __builtin_nontemporal_load(p);
-        else return *p;
-    };
-    // The residual's loads go out first and ALL AT ONCE (the rolled loop waited for each of its Mlds / 256 loads in turn:
-    // ~6 us of a 150 us kernel, tools/probes/sweep_probe.hip), the first column's loads right behind them -- loads return in
-    // order, so the prologue does not wait for the column -- and the workgroup sum uses barriers that order LDS only (a
-    // __syncthreads would drain the column's loads).  The arithmetic (per-thread order of the norm's terms, the order of
-    // the workgroup sum) is unchanged.
-    constexpr int RP = 16;  // residual elements per thread and pass (one pass up to M = 4096)
-    double rv[RP];
-#pragma unroll
-    for (int q = 0; q < RP; ++q) {
-        const int m = tid + q * kSweepThreads;
-        rv[q] = m < Mlds ? r[m] : 0.0;
-    }
-    int64_t col = (int64_t)bid * NW + wave;
-    if (col >= N) col = -1;
-    VT cur[U], nxt[U];
-    if (col >= 0) {
-        const VT* p = reinterpret_cast<const VT*>(A + col * ld) + lane;
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = ldv(p + u * kWave);
-    }
-    double n2 = 0.0;
-#pragma unroll
-    for (int q = 0; q < RP; ++q) {
-        const int m = tid + q * kSweepThreads;
-        if (m < Mlds) {
-            lds[r_slot<VEC>(m)] = rv[q];
-            n2 = fma(rv[q], rv[q], n2);
-        }
-    }
-    for (int m = tid + RP * kSweepThreads; m < Mlds; m += kSweepThreads) {  // (M > 4096)
-        const double v = r[m];
-        lds[r_slot<VEC>(m)] = v;
-        n2 = fma(v, v, n2);
-    }
-    for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);  // block_sum256 with LDS-only barriers
-    lds_barrier();
-    if (lane == 0) red[wave] = n2;
-    lds_barrier();
-    n2 = (red[0] + red[1]) + (red[2] + red[3]);
-    if (bid == 0 && tid == 0) st->rnorm2 = n2;
-    if (check_eps && !(sqrt(n2) >= eps)) {
-        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-        return;
-    }
-    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
-    double bestv = -1.0;
-    int besti = 0x7fffffff;
-    while (col >= 0) {
-        double acc = 0.0;
-        for (int blk = 0; blk < nblocks; ++blk) {
-            // request the following block: next block of this column, or the first of the next column
-            const bool last = blk + 1 == nblocks;
-            const int64_t ncol = last ? col + stride : col;
-            const bool have = !last || ncol < N;
-            if (have) {
-                const VT* p = reinterpret_cast<const VT*>(A + ncol * ld) + lane + (last ? 0 : (blk + 1) * U * kWave);
-#pragma unroll
-                for (int u = 0; u < U; ++u) nxt[u] = ldv(p + u * kWave);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = blk * U + u;
-                if constexpr (VEC == 4) {
-                    const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
-                    const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
-                    acc = fma((double)cur[u].x, r01.x, acc);
-                    acc = fma((double)cur[u].y, r01.y, acc);
-                    acc = fma((double)cur[u].z, r23.x, acc);
-                    acc = fma((double)cur[u].w, r23.y, acc);
-                } else {
-                    const f64x2 r01 = rs[t * kWave + lane];
-                    acc = fma((double)cur[u].x, r01.x, acc);
-                    acc = fma((double)cur[u].y, r01.y, acc);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) cur[u] = nxt[u];
-        }
-        for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
-        if (lane == 0) cvec[col] = acc;
-        const double av = fabs(acc);
-        if (av > bestv) {
-            bestv = av;
-            besti = (int)col;
-        }
-        col += stride;
-        if (col >= N) col = -1;
-    }
-    if ((lane & 15) == 0) {
-        redv[wave * 4 + (lane >> 4)] = bestv;
-        redi[wave * 4 + (lane >> 4)] = besti;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double bv = redv[0];
-        int bi = redi[0];
-        for (int q = 1; q < 4 * NW; ++q)
-            if (better(redv[q], redi[q], bv, bi)) {
-                bv = redv[q];
-                bi = redi[q];
-            }
-        pval[bid] = bv;
-        pidx[bid] = bi;
-    }
-}
-template <typename TA, int U, bool NT>
-__global__ __launch_bounds__(kSweepThreads) void k_sweep_pf(
-    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
-    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    sweep_body_pf<TA, U, NT>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x,
-                             (int)gridDim.x, lds);
-}
-
-inline size_t sweep_lds_bytes(int Mv, int vec) {
-    const int rows = kWave * vec;
-    const int nchunk = (Mv + rows - 1) / rows;
-    return (size_t)(nchunk * rows + 8 + 16 + 8) * sizeof(double);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The shape-general form of the pipelined product sweep (argmaxinner!(P), src/matchingpursuit.jl:181-185, for ANY size(A):
-// the reference allocates zeros(T, n) and calls mul! whatever n is, :54-60): ragged M, and a residual larger than the LDS.
+// workgroup.  dynamic LDS: the r image + 32 doubles of reduction scratch.
+// The pipelined product sweep for ANY size(A) (the reference allocates zeros(T, n) and calls mul! whatever n is, :54-60):
+// ragged M, and a residual larger than the LDS.
 //   unit    U consecutive 64-lane loads (U KiB) of ONE column: the grain of the pipeline.  One wave owns one column at a time.
 //   ring    NB units in flight per wave, consumed oldest first; a consumed buffer is refilled at once with the unit NB ahead.
 //           In the steady loop every load is unconditional (no branch around a load), so the wait the compiler places in front
@@ -1419,7 +1267,7 @@ struct TickSweep {
     const TA* A; int64_t ld; int Mv; int64_t N;
     const double* r; double* cvec; double* pval; int* pidx; DevState* st;
     double eps; int check_eps, skipmask, nblk, active;
-    int KP;  // k_sweep_gen's residual image rows (sweep kinds 1 and 2)
+    int KP;  // rows of the residual image
 };
 template <typename TA>
 struct TickQr1 {
@@ -1437,11 +1285,11 @@ struct TickQr2 {
     int kcap, jpad, force_reorth, jh, optimistic, active;
 };
 
-// KIND: the sweep body -- 0 sweep_body_pf (U = 16 / 8), 1 sweep_body_gen in one image (U = 16 / 8 / 4), 2 sweep_body_gen in phases (U = 8).
+// U, PH: the sweep body's unit size (16 / 8 / 4 loads) and whether the residual is staged in phases (sweep_body_gen).
 // STEADY only names the kernel: the launches in which all three stages are live (every tick of a batch except the
 // 2 + 2 that fill and drain the pipeline of a signal triple) get a symbol of their own, so that a kernel trace
 // (rocprofv3 --kernel-trace --stats) reports the sweep-carrying ticks as one clean row.
-template <typename TA, int U, int KIND, bool STEADY = false>
+template <typename TA, int U, bool PH, bool STEADY = false>
 __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
                                                         const int G, const int sweep_first) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1461,12 +1309,8 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, 
                          bid - G, lds);
     } else {
         if (sw.active) {
-            if constexpr (KIND == 0)
-                sweep_body_pf<TA, U, true>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
-                                           sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, lds);
-            else
-                sweep_body_gen<TA, U, 32 / U, KIND == 2>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
-                                                         sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
+            sweep_body_gen<TA, U, 32 / U, PH>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
+                                              sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
         }
     }
 }

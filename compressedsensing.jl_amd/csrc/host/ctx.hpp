@@ -173,14 +173,11 @@ struct csmp_ctx {
     int64_t col_offset = 0;  // global index of local column 0 (column-sharded OMP; 0 otherwise)
     int Mv = 0;  // M rounded up to the 16-byte vector (zero rows in our own copy)
     int sweep_grid = 0, sweep_U = 1;
-    bool sweep_full = false, sweep_nt = false;
-    // which product sweep serves this dictionary (configure_sweep): 0 = k_sweep_pf (columns of whole 8- or 16-chunk blocks, residual in
-    // the LDS: the shape the benchmark is quoted on), 1 = k_sweep_gen (any shape: ragged rows, a residual staged in phases)
-    int sweep_kind = 0;
-    int sweep_gU = 16;      // k_sweep_gen: loads per unit (16 / 8 / 4; the ring holds 32 loads)
-    bool sweep_ph = false;  // k_sweep_gen: the residual is staged in phases of sweep_KP rows
+    // the product sweep's configuration for this dictionary (configure_sweep): sweep_U loads per unit (16 / 8 / 4; the ring holds 32)
+    bool sweep_ph = false;  // the residual is staged in phases of sweep_KP rows (it exceeds the LDS)
     int sweep_KP = 0;       // rows of the residual image in the LDS
-    int tune_sweep_kind = 0, tune_sweep_grid = 0, tune_sweep_U = 0;  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic
+    int tick_grid = 0;      // sweep workgroups inside the tick kernel
+    int tune_sweep_grid = 0, tune_sweep_U = 0;  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic
     // options (csmp_set_option, include/csmp.h)
     void* comm = nullptr;          // ncclComm_t of the signal-sharded solve (csmp_comm_init, host/rccl.hpp); this rank and the group's size
     int comm_rank = 0, comm_world = 1;

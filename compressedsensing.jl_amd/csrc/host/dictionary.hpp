@@ -1,47 +1,27 @@
 // host/dictionary.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
 // sweep configuration and launch; the resident dictionary.
 // ------------------------------------------------------------------------------------------ sweep launch
-// the shape-general sweep (k_sweep_gen): U loads per unit, a ring of 32 loads, the residual in one image or staged in phases
+// the product sweep (k_sweep_gen): U loads per unit, a ring of 32 loads, the residual in one image or staged in phases
 template <typename TA, int U, int NB, bool PH>
-static hipError_t sweep_gen_launch_t(csmp_ctx* ctx, int grid, size_t lds, const double* r, double eps, int check_eps, int skipmask) {
+static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
     auto kern = k_sweep_gen<TA, U, NB, PH>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (ctx->sweep_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
         if (e != hipSuccess) return e;
     }
     Solver& s = ctx->s;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
                        ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
     return hipGetLastError();
 }
 template <typename TA>
-static hipError_t sweep_gen(csmp_ctx* ctx, int grid, size_t lds, const double* r, double eps, int check_eps, int skipmask) {
-    if (ctx->sweep_ph) return sweep_gen_launch_t<TA, 8, 4, true>(ctx, grid, lds, r, eps, check_eps, skipmask);
-    switch (ctx->sweep_gU) {
-        case 16: return sweep_gen_launch_t<TA, 16, 2, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-        case 8: return sweep_gen_launch_t<TA, 8, 4, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
-        default: return sweep_gen_launch_t<TA, 4, 8, false>(ctx, grid, lds, r, eps, check_eps, skipmask);
+static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
+    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask);
+    switch (ctx->sweep_U) {
+        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask);
+        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask);
+        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask);
     }
-}
-
-// product configuration: one column per wave at a time, software-pipelined across columns
-template <typename TA>
-static hipError_t sweep_product(csmp_ctx* ctx, int U, int grid, size_t lds, const double* r, double eps,
-                                int check_eps, int skipmask) {
-    if (ctx->sweep_kind == 1) return sweep_gen<TA>(ctx, grid, lds, r, eps, check_eps, skipmask);
-    Solver& s = ctx->s;
-    if (lds > 64 * 1024) {
-        hipError_t e = U == 16 ? hipFuncSetAttribute((const void*)k_sweep_pf<TA, 16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                               : hipFuncSetAttribute((const void*)k_sweep_pf<TA, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    if (U == 16)
-        hipLaunchKernelGGL((k_sweep_pf<TA, 16, true>), dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld,
-                           ctx->Mv, ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask);
-    else
-        hipLaunchKernelGGL((k_sweep_pf<TA, 8, true>), dim3(grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld,
-                           ctx->Mv, ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask);
-    return hipGetLastError();
 }
 
 // true when this sweep launch is one of the sampled ones
@@ -65,45 +45,52 @@ static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_ep
     const bool timed = prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
     hipError_t e = ctx->dtype == CSMP_F32
-                       ? sweep_product<float>(ctx, ctx->sweep_U, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask)
-                       : sweep_product<double>(ctx, ctx->sweep_U, ctx->sweep_grid, ctx->sweep_lds, r, eps, check_eps, skipmask);
+                       ? sweep_product<float>(ctx, r, eps, check_eps, skipmask)
+                       : sweep_product<double>(ctx, r, eps, check_eps, skipmask);
     HIPCHECK(e);
     if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;
 }
 
 // ------------------------------------------------------------------------------------------ dictionary
+// Workgroups of a sweep: `base` (a multiple of the CU count), moved within +-1/8 to the count that splits the columns over the
+// waves most evenly -- only where a wave carries few columns (N = 4096 on 768 waves: most carry 5, some 6; on 820: 5 each).
+static int balanced_grid(int64_t N, int64_t base) {
+    const int64_t groups = (N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
+    if (groups <= base) return (int)std::max<int64_t>(1, groups);
+    int64_t grid = base;
+    if (N / (4 * base) < 32) {
+        double best = 0.0;
+        for (int64_t g = base + base / 8; g >= base - base / 8; --g) {
+            const int64_t per_wave = (N + 4 * g - 1) / (4 * g);
+            const double eff = (double)N / (double)(per_wave * 4 * g);
+            if (eff > best + 5e-3) {
+                best = eff;
+                grid = g;
+            }
+        }
+    }
+    return (int)grid;
+}
+
+// k_sweep_gen for every shape (the reference sweeps whatever size(A) is: zeros(T, n), mul!, src/matchingpursuit.jl:54-60,183).
+// One image when the residual fits the LDS: the unit size (16 / 8 / 4 loads) that pads the column's chunks least, the larger one
+// on a tie.  Else phases of KP rows, 8-load units (a column has >= 10 of them there: at most one in ten is padding).
+// Workgroups, measured on MI355X with 1 GiB dictionaries of M = 1000 .. 32768 rows, f32 and f64 (profiles/r05_sweep_shapes.json):
+// 3/4 of the CUs (192) wherever a column is 8 KiB or longer -- every wave keeps 32 KiB in flight, and FEWER concurrent DRAM streams
+// reach a higher bandwidth (256 workgroups: -3..5 %) --, three per CU for shorter columns (the per-column reduction then weighs in
+// and more waves hide it).
 static int configure_sweep(csmp_ctx* ctx) {
     const int vec = ctx->dtype == CSMP_F32 ? 4 : 2;
     const int rows = kWave * vec;
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     const int cus = ctx->prop.multiProcessorCount;
-    const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     const size_t lds_cap = 160 * 1024 - 512;
-    ctx->sweep_full = (ctx->Mv % rows) == 0;
-    ctx->sweep_nt = true;
-    ctx->sweep_kind = 1;
-    ctx->sweep_ph = false;
-    // k_sweep_pf: columns of whole 16- or 8-chunk load blocks with the residual in the LDS -- the shape the benchmark is quoted on.
-    // Measured on MI355X at 4096 x 65536 f32: ONE column per wave at a time, non-temporal loads, the next column's 16 KiB requested
-    // before the current one is reduced, and only 192 workgroups (3/4 of the CUs): 154.5 us = 6.95 TB/s.  More workgroups, or several
-    // columns per wave, mean more concurrent DRAM streams and LESS bandwidth (768 workgroups: 6.6 TB/s; 4 columns per wave: 6.1 TB/s).
-    if (ctx->sweep_full && nchunk % 8 == 0 && sweep_lds_bytes(ctx->Mv, vec) <= lds_cap && ctx->tune_sweep_kind == 0) {
-        ctx->sweep_kind = 0;
-        ctx->sweep_U = nchunk % 16 == 0 ? 16 : 8;
-        ctx->sweep_KP = nchunk * rows;
-        ctx->sweep_lds = sweep_lds_bytes(ctx->Mv, vec);
-        int64_t grid = ctx->sweep_U == 16 ? (int64_t)cus * 3 / 4 : (int64_t)cus;
-        if (ctx->tune_sweep_grid > 0) grid = ctx->tune_sweep_grid;
-        ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(grid, groups));
-        return CSMP_OK;
-    }
-    // k_sweep_gen, every other shape (the reference sweeps whatever size(A) is: zeros(T, n), mul!, src/matchingpursuit.jl:54-60,183).
-    // One image when the residual fits the LDS: the unit size (16 / 8 / 4 loads) that pads the column's chunks least, the larger one
-    // on a tie.  Else phases of KP rows, 8-load units (a column has >= 10 of them there: at most one in ten is padding).
     const int kp_cap = (int)(lds_cap / sizeof(double)) - 32;  // rows the LDS holds beside the reduction scratch
+    ctx->sweep_ph = false;
     int bestU = 0, best_pad = 0;
     for (int u : {16, 8, 4}) {
+        if (ctx->tune_sweep_U > 0 && u != ctx->tune_sweep_U) continue;
         const int pad = ((nchunk + u - 1) / u) * u;
         if (pad * rows > kp_cap) continue;
         if (!bestU || pad < best_pad) {
@@ -111,42 +98,28 @@ static int configure_sweep(csmp_ctx* ctx) {
             best_pad = pad;
         }
     }
-    if (ctx->tune_sweep_U > 0 && ((nchunk + ctx->tune_sweep_U - 1) / ctx->tune_sweep_U) * ctx->tune_sweep_U * rows <= kp_cap) {
-        bestU = ctx->tune_sweep_U;
-        best_pad = ((nchunk + bestU - 1) / bestU) * bestU;
-    }
     if (bestU) {
-        ctx->sweep_gU = bestU;
+        ctx->sweep_U = bestU;
         ctx->sweep_KP = best_pad * rows;
     } else {
         const int ur = 8 * rows;
         const int kp_max = (kp_cap / ur) * ur;
         const int nph = (ctx->Mv + kp_max - 1) / kp_max;
         const int per = (ctx->Mv + nph - 1) / nph;
-        ctx->sweep_gU = 8;
+        ctx->sweep_U = 8;
         ctx->sweep_ph = true;
         ctx->sweep_KP = ((per + ur - 1) / ur) * ur;
     }
-    ctx->sweep_U = ctx->sweep_gU;
     ctx->sweep_lds = sweep_gen_lds_bytes(ctx->sweep_KP);
-    // One workgroup per CU (32 KiB in flight per wave); with few columns per wave the grid is trimmed to the count that splits them
-    // most evenly (N = 4096 on 1024 waves: 4 each; on 768 waves some waves would carry 6 and most 5).
-    int64_t gmax = cus;
-    int64_t grid = gmax;
-    if (groups < gmax) grid = groups;
-    else {
-        double best_eff = 0.0;
-        for (int64_t g = gmax; g >= gmax * 3 / 4; --g) {
-            const int64_t per_wave = (ctx->N + 4 * g - 1) / (4 * g);
-            const double eff = (double)ctx->N / (double)(per_wave * 4 * g);
-            if (eff > best_eff + 1e-9) {
-                best_eff = eff;
-                grid = g;
-            }
-        }
+    const size_t col_bytes = (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8);
+    const int64_t base = col_bytes >= 8192 ? (int64_t)cus * 3 / 4 : (int64_t)cus * 3;
+    ctx->sweep_grid = ctx->tune_sweep_grid > 0 ? balanced_grid(ctx->N, ctx->tune_sweep_grid) : balanced_grid(ctx->N, base);
+    if (ctx->tune_sweep_grid > 0 && ctx->tune_sweep_grid < ctx->sweep_grid + ctx->sweep_grid / 4) {
+        const int64_t groups = (ctx->N + 3) / 4;
+        ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tune_sweep_grid, groups));  // (an override is taken literally)
     }
-    if (ctx->tune_sweep_grid > 0) grid = std::min<int64_t>(ctx->tune_sweep_grid, groups);
-    ctx->sweep_grid = (int)std::max<int64_t>(1, grid);
+    // inside the tick kernel (csmp_omp_batch) the sweep shares the CUs with the append stages of two other signals
+    ctx->tick_grid = balanced_grid(ctx->N, col_bytes >= 8192 ? (int64_t)cus * 11 / 16 : (int64_t)cus * 3);
     return CSMP_OK;
 }
 

@@ -256,7 +256,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     const bool opt = true;
     // (the tick kernel carries the LDS form of the append stages: supports beyond qr_max_cols() go one signal at a time through
     // launch_append, whose spill kernels have no such bound)
-    bool pipe = ctx->pipeline && nsig >= 2 && ctx->sweep_full && kc <= qr_max_cols();
+    bool pipe = ctx->pipeline && nsig >= 2 && kc <= qr_max_cols();
     if (isfr) {  // the tick kernel exists for the exact-tiling FR sweeps only
         int U, g; bool full; size_t l;
         fr_config(ctx, 1, U, full, l, g);

@@ -62,13 +62,13 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     return CSMP_OK;
 }
 
-extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* kind, int* unit_loads, int* phases, int* workgroups, int64_t* lds_bytes) {
+extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phases, int* workgroups, int* tick_workgroups, int64_t* lds_bytes) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->dA) return CSMP_ESTATE;
-    if (kind) *kind = ctx->sweep_kind;
     if (unit_loads) *unit_loads = ctx->sweep_U;
     if (phases) *phases = ctx->sweep_ph ? (ctx->Mv + ctx->sweep_KP - 1) / ctx->sweep_KP : 1;
     if (workgroups) *workgroups = ctx->sweep_grid;
+    if (tick_workgroups) *tick_workgroups = ctx->tick_nblk > 0 ? ctx->tick_nblk : ctx->tick_grid;
     if (lds_bytes) *lds_bytes = (int64_t)ctx->sweep_lds;
     return CSMP_OK;
 }
@@ -77,7 +77,6 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
     if (!ctx) return CSMP_EINVAL;
     if (value < 0 || value > (1 << 20)) return fail(ctx, CSMP_EINVAL, "csmp_tune: value out of range");
     switch (key) {
-        case CSMP_TUNE_SWEEP_KERNEL: ctx->tune_sweep_kind = value ? 1 : 0; break;
         case CSMP_TUNE_SWEEP_GRID: ctx->tune_sweep_grid = (int)value; break;
         case CSMP_TUNE_SWEEP_UNIT:
             if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, CSMP_EINVAL, "csmp_tune: unit loads must be 0, 4, 8 or 16");

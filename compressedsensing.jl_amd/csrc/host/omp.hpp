@@ -30,9 +30,9 @@ static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optim
     return p;
 }
 
-template <typename TA, int U, int KIND, bool STEADY = false>
+template <typename TA, int U, bool PH, bool STEADY = false>
 static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
-    auto kern = k_tick<TA, U, KIND, STEADY>;
+    auto kern = k_tick<TA, U, PH, STEADY>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -41,19 +41,17 @@ static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const Ti
     return hipGetLastError();
 }
 // steady: all three stages of this tick are live (the launches the bench's roofline is quoted on)
-template <typename TA, int U, int KIND>
+template <typename TA, int U, bool PH>
 static hipError_t tick_launch_s(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
-    return steady ? tick_launch_t<TA, U, KIND, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, U, KIND, false>(ctx, sw, q1, q2, G, lds);
+    return steady ? tick_launch_t<TA, U, PH, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, U, PH, false>(ctx, sw, q1, q2, G, lds);
 }
 template <typename TA>
 static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
-    if (ctx->sweep_kind == 0)  // (columns of whole 8-chunk blocks: 16-chunk shapes run 8-chunk blocks here, see omp_ticks)
-        return tick_launch_s<TA, 8, 0>(ctx, sw, q1, q2, G, lds, steady);
-    if (ctx->sweep_ph) return tick_launch_s<TA, 8, 2>(ctx, sw, q1, q2, G, lds, steady);
-    switch (ctx->sweep_gU) {
-        case 16: return tick_launch_s<TA, 16, 1>(ctx, sw, q1, q2, G, lds, steady);
-        case 8: return tick_launch_s<TA, 8, 1>(ctx, sw, q1, q2, G, lds, steady);
-        default: return tick_launch_s<TA, 4, 1>(ctx, sw, q1, q2, G, lds, steady);
+    if (ctx->sweep_ph) return tick_launch_s<TA, 8, true>(ctx, sw, q1, q2, G, lds, steady);
+    switch (ctx->sweep_U) {
+        case 16: return tick_launch_s<TA, 16, false>(ctx, sw, q1, q2, G, lds, steady);
+        case 8: return tick_launch_s<TA, 8, false>(ctx, sw, q1, q2, G, lds, steady);
+        default: return tick_launch_s<TA, 4, false>(ctx, sw, q1, q2, G, lds, steady);
     }
 }
 
@@ -70,8 +68,7 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
     // Measured at 4096 x 65536 f32: 8-chunk load blocks on ONE workgroup per CU (the append stages of the other two
     // signals share those CUs) 160.4 us per tick; 16-chunk blocks on 176 workgroups (11/12 of the stand-alone sweep's
     // optimum of 192) 162.6 us.
-    // the shape-general sweep keeps the grid configure_sweep balanced its columns on
-    const int64_t auto_nblk = ctx->sweep_kind == 0 ? (int64_t)ctx->prop.multiProcessorCount : (int64_t)ctx->sweep_grid;
+    const int64_t auto_nblk = (int64_t)ctx->tick_grid;  // (configure_sweep)
     const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
     const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
     for (int64_t n = 0; n < 3 * k + 2; ++n) {

@@ -18,13 +18,13 @@ int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, 
 /* sweep bandwidth probe: `reps` product sweeps (argmaxinner!(P), src/matchingpursuit.jl:181-185) of a random residual,
  * bracketed by one HIP event pair on the ctx stream; returns the average ms per sweep.  variant must be 0. */
 int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
-/* what configure_sweep chose for the resident dictionary: kind 0 = k_sweep_pf, 1 = k_sweep_gen; loads per unit; phases the
- * residual is staged in (1: one LDS image); workgroups; dynamic LDS bytes.  Any pointer may be NULL. */
-int csmp_sweep_config(const csmp_ctx *ctx, int *kind, int *unit_loads, int *phases, int *workgroups, int64_t *lds_bytes);
+/* what configure_sweep chose for the resident dictionary: loads per unit of k_sweep_gen (16 / 8 / 4); phases the residual is
+ * staged in (1: one LDS image); workgroups of a stand-alone sweep and of the sweep inside the tick kernel; dynamic LDS bytes.
+ * Any pointer may be NULL. */
+int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *workgroups, int *tick_workgroups, int64_t *lds_bytes);
 /* measurement overrides of that choice, applied to the resident dictionary at once and to later ones: 0 = automatic */
-#define CSMP_TUNE_SWEEP_KERNEL 1 /* 1: k_sweep_gen for every shape */
 #define CSMP_TUNE_SWEEP_GRID 2   /* workgroups of the product sweep */
-#define CSMP_TUNE_SWEEP_UNIT 3   /* k_sweep_gen: loads per unit (16, 8 or 4) */
+#define CSMP_TUNE_SWEEP_UNIT 3   /* loads per unit (16, 8 or 4) */
 #define CSMP_TUNE_TICK_GRID 4    /* sweep workgroups inside the tick kernel of csmp_omp_batch */
 int csmp_tune(csmp_ctx *ctx, int key, int64_t value);
 

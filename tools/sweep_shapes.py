@@ -4,7 +4,6 @@ around `reps` launches).  bench.py --workload shapes runs table(); the options b
 
     python tools/sweep_shapes.py                         # the table, automatic configuration
     python tools/sweep_shapes.py --grids 192,256,384     # ... and the same sweeps under other workgroup counts
-    python tools/sweep_shapes.py --force-gen             # k_sweep_gen on the shapes k_sweep_pf serves
 """
 import argparse
 import json
@@ -54,7 +53,7 @@ def check_sweep(torch, np, D, At, seed=3):
     return err, ok_arg
 
 
-def measure(torch, np, cs, dev, M, dtype, reps, total_bytes=1 << 30, grids=(), force_gen=False, unit=0, check=True):
+def measure(torch, np, cs, dev, M, dtype, reps, total_bytes=1 << 30, grids=(), unit=0, check=True):
     es = 4 if dtype == torch.float32 else 8
     N = max(8, (total_bytes // (M * es)) // 4 * 4)
     At = make_dictionary(torch, dev, M, N, dtype)
@@ -63,12 +62,12 @@ def measure(torch, np, cs, dev, M, dtype, reps, total_bytes=1 << 30, grids=(), f
     try:
         variants = [None] + [g for g in grids]
         for g in variants:
-            D.ctx.tune("sweep_kernel", 1 if force_gen else 0)
             D.ctx.tune("sweep_unit", unit)
             D.ctx.tune("sweep_grid", 0 if g is None else g)
             cfg = D.ctx.sweep_config()
             err, ok = check_sweep(torch, np, D, At) if check else (None, None)
-            ms = D.ctx.bench_sweep(0, reps)
+            D.ctx.bench_sweep(0, reps)  # (clocks and caches settle; the first timed run after a fresh allocation reads ~30 % slow)
+            ms = sorted(D.ctx.bench_sweep(0, reps) for _ in range(5))[2]  # median of five runs of `reps` launches
             nbytes = M * N * es
             rows.append({"M": M, "N": N, "dtype": "f32" if es == 4 else "f64", "bytes": nbytes, "us": round(ms * 1e3, 2),
                          "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1), "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4),
@@ -95,7 +94,6 @@ def main():
     p.add_argument("--dtypes", type=str, default="f32,f64")
     p.add_argument("--grids", type=str, default="")
     p.add_argument("--unit", type=int, default=0)
-    p.add_argument("--force-gen", action="store_true")
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--out", type=str, default="")
     a = p.parse_args()
@@ -107,9 +105,9 @@ def main():
     Ms = tuple(int(x) for x in a.M.split(",")) if a.M else SHAPES_M
     dts = tuple({"f32": torch.float32, "f64": torch.float64}[x] for x in a.dtypes.split(","))
     grids = tuple(int(x) for x in a.grids.split(",")) if a.grids else ()
-    rows = table(torch, np, cs, dev, a.reps, Ms, dts, grids=grids, force_gen=a.force_gen, unit=a.unit, check=not a.no_check)
+    rows = table(torch, np, cs, dev, a.reps, Ms, dts, grids=grids, unit=a.unit, check=not a.no_check)
     for r in rows:
-        print(json.dumps(r))
+        print(json.dumps(r), flush=True)
     if a.out:
         with open(a.out, "w") as f:
             json.dump(rows, f, indent=1)
