@@ -89,6 +89,7 @@ INTERNAL_SIGNATURES = {
     "csmp_profile_enable": (C.c_int, [vp, C.c_int]),
     "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "csmp_profile_overhead": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
     "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64)]),
     "csmp_tune": (C.c_int, [vp, C.c_int, i64]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
@@ -686,6 +687,12 @@ class Context:
         ms = C.c_double(0)
         self.call("csmp_profile_read", C.byref(n), C.byref(ms), int(bool(reset)))
         return n.value, ms.value
+
+    def profile_overhead(self, reps=64):
+        """average reading (ms) of an empty HIP-event pair on this context's stream"""
+        ms = C.c_double(0)
+        self.call("csmp_profile_overhead", int(reps), C.byref(ms))
+        return ms.value
 
     def bench_sweep(self, variant=0, reps=20):
         ms = C.c_double(0)

@@ -37,14 +37,6 @@ __device__ __forceinline__ int rf_slot(int m) {  // index in floats
     return ((((t << 1) + (e >> 2)) << 6) + l) * 4 + (e & 3);
 }
 
-#ifdef CSMP_SWEEP_TRACE  // tools/probes/sweep_probe.hip: wall-clock stamps (100 MHz) of workgroup phases
-__device__ unsigned long long g_sweep_trace[4096 * 8];
-#define CSMP_TRACE(slot) \
-    if (threadIdx.x == 0) g_sweep_trace[blockIdx.x * 8 + (slot)] = wall_clock64()
-#else
-#define CSMP_TRACE(slot)
-#endif
-
 constexpr int kScrPartWgs = 8;        // workgroups that share a ticket counter
 constexpr int kScrTicketStride = 64;  // words between two counters (a 256-byte line each)
 constexpr int kScrCols = 4;  // columns a wave multiplies side by side (they share the residual registers and one reduction)
@@ -104,9 +96,7 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     constexpr int CH = kWave * EV;         // rows per chunk
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = (int)blockIdx.x, nblk = (int)gridDim.x;
-    CSMP_TRACE(0);
     if (st->done & skipmask) return;
-    CSMP_TRACE(1);
     const int nchunk = (Mk + CH - 1) / CH;
     const int Ml = nchunk * CH;
     const int64_t RB = (int64_t)Mk * (I8 ? 1 : 2);  // bytes per image row
@@ -201,7 +191,6 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
             }
         }
     }
-    CSMP_TRACE(5);
     // sum over the workgroup in a fixed order; barriers that order LDS only (a __syncthreads would drain the prefetch)
     for (int sft = 32; sft >= 1; sft >>= 1) n2 += __shfl_xor(n2, sft, kWave);
     if constexpr (I8)
@@ -210,7 +199,6 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
         red[wave] = n2;
         if constexpr (I8) reinterpret_cast<float*>(red + 4)[wave] = amax;
     }
-    CSMP_TRACE(6);
     lds_barrier();
     n2 = (red[0] + red[1]) + (red[2] + red[3]);
     float scale = 1.0f;
@@ -239,7 +227,6 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
         if (bid == 0 && tid == 0) st->done |= STOP_EPS;
         return;
     }
-    CSMP_TRACE(2);
     const f32x4* rs = reinterpret_cast<const f32x4*>(rimgf);
     const i32x4* rs8 = reinterpret_cast<const i32x4*>(rimg8);
     float tv[LC];
@@ -358,7 +345,6 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
             }
         }
     }
-    CSMP_TRACE(3);
     if ((lane & 15) == 0) {
         const int l = wave * (kWave / 16) + (lane >> 4);
 #pragma unroll
@@ -388,7 +374,6 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
             cand_idx[bid * LC + rank] = i;
         }
     }
-    CSMP_TRACE(4);
 }
 template <int U, int D, bool FULL, int C = kScrCols, int LC = kScrCand>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_bf16(const __bf16* __restrict__ Ab, int Mk, int64_t N,
@@ -691,9 +676,6 @@ __global__ __launch_bounds__(NT) void k_pickS(const TA* __restrict__ A, int64_t 
         }
         if (rank == Seff - 1 && !(nall <= kwin && (cb < 0.0 || (nw >= S && v > cb)))) {
             st->uncertain += 1;
-#ifdef CSMP_PICK_DEBUG
-            printf("pickS uncertain: nsel %d nall %d kwin %d nw %d S %d vS %.9g cb %.9g mS %.9g dabs %.9g rstep %g n2 %g\n", st->nsel, nall, kwin, nw, S, v, cb, (double)mS, dabs, (double)st->rstep, n2);
-#endif
         }
     }
     if (tid == 0) {

@@ -29,6 +29,26 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
     return CSMP_OK;
 }
 
+// what an event pair reads with NOTHING between its two records (the marker packets themselves): csmp_profile_read's sums carry one
+// of these per timed launch, and a caller that wants launch durations subtracts it
+extern "C" int csmp_profile_overhead(csmp_ctx* ctx, int reps, double* avg_ms) {
+    if (!ctx || reps < 1 || !avg_ms) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    std::vector<hipEvent_t> ev((size_t)reps * 2);
+    for (auto& e : ev) HIPCHECK(hipEventCreate(&e));
+    for (auto& e : ev) HIPCHECK(hipEventRecord(e, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    double sum = 0.0;
+    for (int i = 0; i < reps; ++i) {
+        float ms = 0.f;
+        HIPCHECK(hipEventElapsedTime(&ms, ev[(size_t)i * 2], ev[(size_t)i * 2 + 1]));
+        sum += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    *avg_ms = sum / reps;
+    return CSMP_OK;
+}
+
 extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
     if (!ctx || reps < 1) return CSMP_EINVAL;
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");

@@ -59,13 +59,16 @@ int rccl_fail(csmp_ctx* ctx, const char* what, ncclResult_t r) {
 }  // namespace
 
 // rows of 2k+1 Float64 [idx | val | nnz] from the batch drivers' device outputs (idx, val: k x nloc, nnz: nloc); rows >= nloc: zeros
+// status < 0 (this rank's block could not be solved): the block carries no results and the nnz slot of its row 0 carries the status --
+// a count is never negative, so the slot tells every receiver that the rank failed, and with what code (csmp_omp_sharded)
 __global__ void k_pack_rows(const int64_t* __restrict__ idx, const double* __restrict__ val, const int64_t* __restrict__ nnz, int64_t k,
-                            int64_t nloc, int64_t rows, double* __restrict__ packed) {
+                            int64_t nloc, int64_t rows, double* __restrict__ packed, int status) {
     const int64_t w = 2 * k + 1, n = rows * w;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t s = i / w, t = i % w;
         double v = 0.0;
-        if (s < nloc) v = t < k ? (double)idx[s * k + t] : t < 2 * k ? val[s * k + (t - k)] : (double)nnz[s];
+        if (status < 0) v = (s == 0 && t == 2 * k) ? (double)status : 0.0;
+        else if (s < nloc) v = t < k ? (double)idx[s * k + t] : t < 2 * k ? val[s * k + (t - k)] : (double)nnz[s];
         packed[i] = v;
     }
 }
@@ -95,7 +98,7 @@ extern "C" int csmp_pack_block_device(csmp_ctx* ctx, const int64_t* idx, const d
     HIPCHECK(hipSetDevice(ctx->dev));
     const int64_t w = 2 * k + 1;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows * w + 255) / 256));
-    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, idx, val, nnz, k, nloc, rows, packed);
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, idx, val, nnz, k, nloc, rows, packed, 0);
     HIPCHECK(hipGetLastError());
     return CSMP_OK;
 }
@@ -156,13 +159,18 @@ extern "C" int csmp_comm_init(csmp_ctx* ctx, const void* id, int rank, int world
     return CSMP_OK;
 }
 
+// The call is COLLECTIVE: every rank must reach the ncclAllGather, or the ranks that did wait for ever.  So nothing rank-specific
+// returns before it: arguments that are the same on all ranks are checked first (a failure there fails everywhere), the gather's
+// own two buffers are allocated next (the one failure that cannot be reported: without them this rank cannot take part), and from
+// then on a failure of THIS rank -- its B missing, its temporaries, its block's solves (CSMP_EDIM, CSMP_ENOMEM, CSMP_ERANGE ...)
+// -- is carried through the collective as a status in the block (k_pack_rows) and returned AFTER it, on every rank: the failing
+// rank gets its own code and message, the others the same code and the failing rank's number.  No rank's outputs are valid then.
 extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
                                 int method, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->comm) return fail(ctx, CSMP_ESTATE, "omp_sharded: no communicator (csmp_comm_init)");
     if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
         return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
-
     if (nsig < 0 || k < 1 || !idx || !val || !nnz || (method != 0 && method != 1)) return fail(ctx, CSMP_EINVAL, "omp_sharded: bad arguments");
     if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
     if (nsig == 0) return CSMP_OK;
@@ -171,40 +179,65 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
     int64_t lo = 0, hi = 0;
     CHECK(csmp_shard_range(nsig, rank, world, &lo, &hi));
     const int64_t nloc = hi - lo, rows = (nsig + world - 1) / world, w = 2 * k + 1;
-    if (nloc > 0 && !B) return fail(ctx, CSMP_EINVAL, "omp_sharded: B == NULL");
-    // the block's solves: results stay in device memory
     DevTmp tIdx, tVal, tNnz, tPack, tAll, oIdx, oVal, oNnz;
-    HIPCHECK(tIdx.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8));
-    HIPCHECK(tVal.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8));
-    HIPCHECK(tNnz.alloc((size_t)std::max<int64_t>(1, nloc) * 8));
     HIPCHECK(tPack.alloc((size_t)(rows * w) * 8));
     HIPCHECK(tAll.alloc((size_t)(world * rows * w) * 8));
-    if (nloc > 0) {
-        const int rc = method == 1
-            ? csmp_omp_batch_mfma(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE)
-            : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE);
-        if (rc != CSMP_OK) return rc;
+    // ---- this rank's part: a failure is remembered, not returned
+    int local = CSMP_OK;
+    std::string local_msg;
+    auto note = [&](int rc) {
+        if (rc != CSMP_OK && local == CSMP_OK) {
+            local = rc;
+            local_msg = ctx->err;
+        }
+    };
+    if (nloc > 0 && !B) note(fail(ctx, CSMP_EINVAL, "omp_sharded: B == NULL"));
+    if (local == CSMP_OK && (tIdx.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8) != hipSuccess || tVal.alloc((size_t)std::max<int64_t>(1, k * nloc) * 8) != hipSuccess ||
+                             tNnz.alloc((size_t)std::max<int64_t>(1, nloc) * 8) != hipSuccess)) {
+        (void)hipGetLastError();
+        note(fail(ctx, CSMP_ENOMEM, "omp_sharded: no device memory for this rank's results"));
     }
-    CHECK(csmp_pack_block_device(ctx, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k, nloc, rows, (double*)tPack.p));
-    // THE collective: every rank's packed block, device memory to device memory, ordered on the context's stream
-    const ncclResult_t r = g_rccl.AllGather(tPack.p, tAll.p, (size_t)(rows * w), ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
-    if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
     int64_t *d_idx = idx, *d_nnz = nnz;
     double* d_val = val;
-    if (out_loc == CSMP_HOST) {
-        HIPCHECK(oIdx.alloc((size_t)(k * nsig) * 8));
-        HIPCHECK(oVal.alloc((size_t)(k * nsig) * 8));
-        HIPCHECK(oNnz.alloc((size_t)nsig * 8));
+    if (local == CSMP_OK && out_loc == CSMP_HOST) {
+        if (oIdx.alloc((size_t)(k * nsig) * 8) != hipSuccess || oVal.alloc((size_t)(k * nsig) * 8) != hipSuccess || oNnz.alloc((size_t)nsig * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            note(fail(ctx, CSMP_ENOMEM, "omp_sharded: no device memory for the gathered results"));
+        }
         d_idx = (int64_t*)oIdx.p;
         d_val = (double*)oVal.p;
         d_nnz = (int64_t*)oNnz.p;
     }
-    CHECK(csmp_unpack_gathered_device(ctx, (const double*)tAll.p, k, nsig, world, d_idx, d_val, d_nnz));
-    if (out_loc == CSMP_HOST) {
-        HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (local == CSMP_OK && nloc > 0)  // the block's solves: results stay in device memory
+        note(method == 1
+                 ? csmp_omp_batch_mfma(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE)
+                 : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE));
+    {
+        const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows * w + 255) / 256));
+        hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k,
+                           local == CSMP_OK ? nloc : 0, rows, (double*)tPack.p, local);
+        HIPCHECK(hipGetLastError());
+    }
+    // ---- THE collective: every rank's packed block, device memory to device memory, ordered on the context's stream
+    const ncclResult_t r = g_rccl.AllGather(tPack.p, tAll.p, (size_t)(rows * w), ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+    if (r != ncclSuccess) return rccl_fail(ctx, "ncclAllGather", r);
+    // every rank's status word (the nnz slot of its row 0) comes down beside the results
+    std::vector<double> status((size_t)world, 0.0);
+    HIPCHECK(hipMemcpy2DAsync(status.data(), sizeof(double), (const double*)tAll.p + 2 * k, (size_t)(rows * w) * sizeof(double), sizeof(double), (size_t)world,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    if (local == CSMP_OK) {
+        CHECK(csmp_unpack_gathered_device(ctx, (const double*)tAll.p, k, nsig, world, d_idx, d_val, d_nnz));
+        if (out_loc == CSMP_HOST) {
+            HIPCHECK(hipMemcpyAsync(idx, d_idx, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(val, d_val, (size_t)(k * nsig) * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipMemcpyAsync(nnz, d_nnz, (size_t)nsig * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     HIPCHECK(hipStreamSynchronize(ctx->stream));  // (the temporaries are released on return)
+    if (local != CSMP_OK) return fail(ctx, local, local_msg);
+    for (int q = 0; q < world; ++q)
+        if (status[(size_t)q] < 0.0)
+            return fail(ctx, (int)status[(size_t)q], "omp_sharded: rank " + std::to_string(q) + " could not solve its block (status " +
+                                                          std::to_string((int)status[(size_t)q]) + "); no rank's results are valid");
     return CSMP_OK;
 }

@@ -50,15 +50,30 @@ def pack_t(idx, val, nnz):
     return torch.cat([idx.to(torch.float64), val, nnz[:, None].to(torch.float64)], dim=1).contiguous()
 
 
-def gather_packed(packed, nsig, group=None):
+class ShardedSolveError(RuntimeError):
+    """A rank could not solve its block of a signal-sharded call; raised on EVERY rank after the one collective (csmp_omp_sharded
+    returns the failing rank's code on every rank the same way)."""
+
+    def __init__(self, failed, status):
+        super().__init__(f"signal-sharded solve: rank(s) {failed} could not solve their block (status {status}); no rank's results are valid")
+        self.failed, self.status = failed, status
+
+
+def gather_packed(packed, nsig, group=None, status=0):
     """ONE all_gather of every rank's packed block (padded to the largest block, ceil(nsig / world) rows);
-    returns the (nsig, 2k+1) tensor of all signals in global order, on `packed`'s device."""
+    returns the (nsig, 2k+1) tensor of all signals in global order, on `packed`'s device.
+    status < 0: THIS rank could not solve its block.  It still takes part -- a rank that left before the collective would leave
+    the others waiting for ever -- with an empty block whose row 0 carries the status in its nnz slot (a count is never negative:
+    libcsmp's k_pack_rows writes the same word); every rank then raises ShardedSolveError."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     maxn = -(-int(nsig) // world)
     mine = packed
-    if packed.shape[0] != maxn:
+    if status < 0:
+        mine = torch.zeros((maxn, packed.shape[1]), dtype=packed.dtype, device=packed.device)
+        mine[0, -1] = float(status)
+    elif packed.shape[0] != maxn:
         mine = torch.zeros((maxn, packed.shape[1]), dtype=packed.dtype, device=packed.device)
         mine[:packed.shape[0]] = packed
     if mine.is_cuda and dist.get_backend(group) == "gloo":
@@ -70,6 +85,9 @@ def gather_packed(packed, nsig, group=None):
     else:
         out = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(out, mine, group=group)  # the single collective of the path
+    failed = [r for r in range(world) if float(out[r][0, -1]) < 0.0]
+    if failed:
+        raise ShardedSolveError(failed, int(float(out[failed[0]][0, -1])))
     parts = []
     for r in range(world):
         rlo, rhi = shard_range(nsig, r, world)
@@ -90,10 +108,33 @@ def library_comm(ctx, group=None):
     key = (id(group), rank, world)
     if getattr(ctx, "_comm_key", None) == key:
         return
+    import torch
     from . import _lib
-    ids = [_lib.comm_id() if rank == 0 else None]
+    # every rank runs the same sequence of collectives whatever fails where: rank 0 broadcasts the id OR a failure marker, and the
+    # ranks agree on the outcome of csmp_comm_init before any of them uses (or gives up on) the communicator
+    err = None
+    ident = None
+    if rank == 0:
+        try:
+            ident = _lib.comm_id()
+        except Exception as e:  # noqa: BLE001  (RCCL cannot be bound, ncclGetUniqueId failed)
+            err = e
+    ids = [ident]
     dist.broadcast_object_list(ids, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    ctx.comm_init(ids[0], rank, world)
+    if ids[0] is None:
+        raise _lib.CsmpError(_lib.ERCCL, "rank 0 could not draw a communicator id" + (f": {err}" if err else ""))
+    ok = 1
+    try:
+        ctx.comm_init(ids[0], rank, world)
+    except Exception as e:  # noqa: BLE001
+        ok, err = 0, e
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if ok:
+            ctx.comm_free()
+        raise _lib.CsmpError(_lib.ERCCL, "csmp_comm_init failed on " + ("this rank: " + str(err) if not ok else "another rank"))
     ctx._comm_key = key
 
 
@@ -136,17 +177,32 @@ def omp_sharded(D, B, k, eps=None, group=None, solver=None, device=None, method=
         val = torch.zeros((n, k), dtype=torch.float64, device=dev)
         nnz = torch.zeros(n, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
-        if n:
-            (D.ctx.omp_batch_mfma_device if method == "mfma" else D.ctx.omp_batch_device)(Bl, k, eps, idx, val, nnz)
-        D.ctx.sync()
+        status, err = 0, None
+        try:
+            if n:
+                (D.ctx.omp_batch_mfma_device if method == "mfma" else D.ctx.omp_batch_device)(Bl, k, eps, idx, val, nnz)
+            D.ctx.sync()
+        except Exception as e:  # noqa: BLE001  (this rank still joins the collective: see gather_packed)
+            status, err = min(-1, int(getattr(e, "code", -1))), e
         packed = pack_t(idx, val, nnz)
     else:
         if solver is None:
             eps = D.eps if eps is None else eps
             solver = D.ctx.omp_batch_mfma if method == "mfma" else D.ctx.omp_batch
-        idx, val, nnz = solver(np.asfortranarray(B[:, lo:hi]), k, eps)
-        packed = torch.from_numpy(pack(idx, val, nnz)).to(dev)
-    return unpack_t(gather_packed(packed, nsig, group), k)
+        status, err = 0, None
+        try:
+            idx, val, nnz = solver(np.asfortranarray(B[:, lo:hi]), k, eps)
+            packed = torch.from_numpy(pack(idx, val, nnz)).to(dev)
+        except Exception as e:  # noqa: BLE001
+            status, err = min(-1, int(getattr(e, "code", -1))), e
+            packed = torch.zeros((0, 2 * int(k) + 1), dtype=torch.float64, device=dev)
+    try:
+        full = gather_packed(packed, nsig, group, status=status)
+    except ShardedSolveError as e:
+        if err is not None:
+            raise e from err  # (the failing rank keeps its own exception as the cause)
+        raise
+    return unpack_t(full, k)
 
 
 def sharded_solve(B, cap, one, group=None, device=None):

@@ -15,6 +15,9 @@ extern "C" {
 int csmp_profile_enable(csmp_ctx *ctx, int on);
 /* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
 int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);
+/* average reading (ms) of an event pair with nothing between its two records: the share of a timed launch's bracket that is the
+ * bracket itself */
+int csmp_profile_overhead(csmp_ctx *ctx, int reps, double *avg_ms);
 /* sweep bandwidth probe: `reps` product sweeps (argmaxinner!(P), src/matchingpursuit.jl:181-185) of a random residual,
  * bracketed by one HIP event pair on the ctx stream; returns the average ms per sweep.  variant must be 0. */
 int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);

@@ -59,3 +59,22 @@ def test_headline_survives_errors_and_missing_blocks():
     o = json.loads(bench.headline({"metric": "m", "value": 1.0, "unit": "atoms/s", "cpu_baseline": {"value": None, "error": "x" * 5000},
                                    "secondary": {"a": {"error": "boom"}, "b": {"value": 2.5}}, "roofline": {"bound": "hbm", "kernel": "k = " + "y" * 900}}))
     assert o["secondary"] == {"a": None, "b": 2.5} and len(o["cpu_baseline"]["error"]) <= 160 and o["roofline"]["kernel"] == "k"
+
+
+def test_headline_carries_both_ceilings_of_the_batched_step_and_the_device_resident_single_signal():
+    """batched_c3 priced against the MFMA-only ceiling AND the serial composite (MFMA flop at 2.5 PF + the
+    per-signal kernels' bytes at 8 TB/s); a one-signal figure with b and the results resident in HBM; the roofline's launch
+    duration net of the event pair's own reading."""
+    comp = bench.composite_roofline(flops=2.0 * 4096 * 65536 * 1024, peak_tf=bench.MFMA_PEAK_TF, hbm_bytes=2.27e9, ms_per_omp_step=0.795, nsig=1024)
+    assert abs(comp["mfma_floor_us"] - 219.9) < 0.5 and abs(comp["hbm_floor_us"] - 283.75) < 0.5
+    assert abs(comp["frac"] - (219.9 + 283.75) / 795.0) < 2e-3 and 1.9e6 < comp["ceiling_atoms_per_s"] < 2.1e6
+    sec = {"batched_c3": {"value": 1.29e6, "roofline": {"whole_step": {"frac": 0.277}}, "roofline_composite": comp},
+           "lone_omp_c2_device": {"value": 5900.0}, "lone_omp_c2": {"value": 5750.0}}
+    o = json.loads(bench.headline({"metric": "m", "value": 1.0, "unit": "atoms/s", "secondary": sec,
+                                   "roofline": {"bound": "hbm", "avg_launch_us": 160.0, "event_pair_us": 2.1, "kernel": "k"}}))
+    assert o["secondary"]["batched_c3_frac_of_mfma_only_ceiling"] == 0.277
+    assert abs(o["secondary"]["batched_c3_frac_of_composite_ceiling"] - comp["frac"]) < 1e-5
+    assert o["secondary"]["lone_omp_c2_device"] == 5900.0
+    assert all(v is None or isinstance(v, (int, float)) for v in o["secondary"].values())
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "profile_overhead" in src and "statistical_int8" not in src.split("def main()")[1].split("for name, cert, gram, scr in")[1][:400]

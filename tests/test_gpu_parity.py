@@ -2564,6 +2564,24 @@ def test_omp_sharded_in_library_rccl(cs, oracle, D):
     with pytest.raises(cs.CsmpError):
         d.ctx.omp_sharded(B, nsig, k, EPS32)
     d.ctx.comm_init(cs.comm_id(), 0, 1)  # a second communicator on the same context; freed by csmp_destroy
+    # a rank whose LOCAL solve fails must not leave before the collective (the others would wait in the
+    # all-gather for ever): it sends a block that carries its status, and every rank returns that status after the gather.  Injected
+    # here with a leading dimension below M (csmp_omp_batch: CSMP_EDIM) -- the call comes back, with the local code and message, and
+    # the communicator is as usable as before.
+    import ctypes as C
+    from csmp_pkg import load
+    L = load()._lib
+    idx = np.zeros((k, nsig), np.int64, order="F")
+    val = np.zeros((k, nsig), np.float64, order="F")
+    nnz = np.zeros(nsig, np.int64)
+    with pytest.raises(cs.CsmpError) as e:
+        d.ctx.call("csmp_omp_sharded", L.ptr(B), L.F64, L.i64(M - 1), L.i64(nsig), L.HOST, L.i64(k), C.c_double(EPS32), 0, L.ptr(idx), L.ptr(val), L.ptr(nnz), L.HOST)
+    assert e.value.code == L.EDIM
+    with pytest.raises(cs.CsmpError) as e:  # ... and with a missing block
+        d.ctx.call("csmp_omp_sharded", None, L.F64, L.i64(M), L.i64(nsig), L.HOST, L.i64(k), C.c_double(EPS32), 0, L.ptr(idx), L.ptr(val), L.ptr(nnz), L.HOST)
+    assert e.value.code == L.EINVAL and "B == NULL" in str(e.value)
+    idx, val, nnz = d.ctx.omp_sharded(B, nsig, k, EPS32)
+    assert np.array_equal(nnz, n2) and np.array_equal(idx, i2)
 
 
 @pytest.mark.parametrize("cfg", [(2304, 4608, 1100, 2, 4), (4096, 8192, 2048, 1, 2)])
