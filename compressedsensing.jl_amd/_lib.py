@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libcsmp.so")
 OK, EINVAL, EDIM, ERANGE, EHIP, ESTATE, ENOMEM, ERCCL, EIO = 0, -1, -2, -3, -4, -5, -6, -7, -8
 F32, F64 = 0, 1
 HOST, DEVICE, HOST_STREAMED = 0, 1, 2
-ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR = 0, 1, 2, 3
+ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR, ALGO_SP, ALGO_OMPR = 0, 1, 2, 3, 4, 5
 STOP_EPS, STOP_STAG, STOP_FULL = 1, 2, 4
 # csmp_set_option keys (include/csmp.h)
 OPT_BATCH_CERT, OPT_BATCH_GRAM, OPT_BATCH_WINDOW, OPT_PIPELINE, OPT_SOLVES_IN_FLIGHT, OPT_SCREENED_SWEEP, OPT_BATCH_SCREEN = 1, 2, 3, 4, 9, 10, 11
@@ -77,6 +77,7 @@ SIGNATURES = {
     "csmp_get_option": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
     "csmp_solver_begin": (C.c_int, [vp, C.c_int, vp, C.c_int, i64, vp, vp, i64]),
     "csmp_solver_step": (C.c_int, [vp, i64]),
+    "csmp_solver_acquire": (C.c_int, [vp, i64]),
     "csmp_solver_remove": (C.c_int, [vp, i64]),
     "csmp_solver_state": (C.c_int, [vp, vp, vp, C.POINTER(i64), C.POINTER(C.c_double), vp, C.POINTER(C.c_int)]),
     "csmp_sweep": (C.c_int, [vp, vp, vp, i64, vp, vp]),
@@ -616,6 +617,10 @@ class Context:
 
     def solver_step(self, l=1):
         self.call("csmp_solver_step", i64(int(l)))
+
+    def solver_acquire(self, k):
+        """sp_acquisition!(P, x, k) (SP) / oblivious_acquisition!(P, x, k) (OMPR, OMP, GOMP)"""
+        self.call("csmp_solver_acquire", i64(int(k)))
 
     def solver_remove(self, atom):
         self.call("csmp_solver_remove", i64(int(atom)))

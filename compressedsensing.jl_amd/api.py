@@ -516,6 +516,106 @@ class MP(_DevicePursuit):
         return x
 
 
+class _TwoStage(_Update):
+    """SP and OMPR: functors whose x the reference's caller owns and passes back in (update!(P, x)).  The device solver holds the x
+    it produced last; an x that is not that one -- other atoms or other values -- restarts the solver from it where the reference
+    allows that (SP: the acquisition starts from residual!(P, x) whatever x is, src/twostage.jl:68)."""
+    ALGO = None
+
+    def __init__(self, A, b, k):
+        self.D, self._tmp = _dict(A)
+        self.A, self.b, self.k = A, np.asarray(b), int(k)
+        self.ctx = self.D.ctx.clone()
+        self.ctx.solver_begin(self.ALGO, self.b, self.k)
+        self._x = spzeros(self.D.shape[1])
+
+    def _sync_x(self, x):
+        idx, val, res, order, stop = self.ctx.solver_state(max(2 * self.k, 1))
+        self._x = SparseVector(self.D.shape[1], idx, val)
+        self.resnorm = res
+        if x is None:
+            return self._x.copy()
+        x.nzind, x.nzval = idx.copy(), val.copy()
+        return x
+
+    def _is_mine(self, x):
+        return x is None or (x.nnz == self._x.nnz and np.array_equal(x.nzind, self._x.nzind) and np.array_equal(x.nzval, self._x.nzval))
+
+    def _check_nnz(self, x):
+        n = self._x.nnz if x is None else x.nnz
+        if n != self.k:  # the reference throws this String (src/twostage.jl:76,135)
+            raise ValueError(f"nnz(x) = {n} \u2260 {self.k} = k")
+
+    def residual_norm(self):
+        return self.ctx.solver_state(max(2 * self.k, 1))[2]
+
+    def close(self):
+        self.ctx.close()
+        if self._tmp:
+            self.D.close()
+
+
+class SP(_TwoStage):
+    """SP(A, b, k) = SubspacePursuit (src/twostage.jl:42-61): sp_acquisition!(P, x, k=P.k) (:67-72) and update!(P, x) (:75-83) one
+    call at a time on the device -- the phases csmp_sp strings together (sweep + top-k, least squares on the union, prune, least
+    squares on the k kept)."""
+    ALGO = _lib.ALGO_SP
+
+    def __init__(self, A, b, k):
+        M = A.shape[0]
+        if 2 * k > M:  # error(...) at :55
+            raise ValueError(f"2k = {2 * k} > {M} = length(b) is invalid for Subspace Pursuit")
+        super().__init__(A, b, k)
+
+    def _load(self, x):
+        if not self._is_mine(x):  # a foreign x: the solver restarts from it (its values too: the residual is b - A x)
+            self.ctx.solver_begin(self.ALGO, self.b, self.k, x.nzind, x.nzval)
+            self._x = x.copy()
+
+    def acquisition_(self, x=None, k=None):
+        self._load(x)
+        self.ctx.solver_acquire(self.k if k is None else int(k))
+        return self._sync_x(x)
+
+    def update_(self, x=None):
+        self._check_nnz(x)
+        self._load(x)
+        self.ctx.solver_step(1)
+        return self._sync_x(x)
+
+
+SubspacePursuit = SP
+
+
+class OMPR(_TwoStage):
+    """OMPR(A, b, k) (src/twostage.jl:110-132): oblivious_acquisition!(P, x, k) fills the empty x (src/matchingpursuit.jl:207-216;
+    how ompr starts, src/twostage.jl:190), update!(P, x) (:134-180, eta = 1) swaps one atom.  The updatable QR (with its Givens
+    down-date) lives on the device, tied to the x this object returned last."""
+    ALGO = _lib.ALGO_OMPR
+
+    def acquisition_(self, x=None, k=None):
+        if x is not None and x.nnz:
+            raise ValueError("oblivious_acquisition!(P::OMPR, x, k): x must be empty (OMPR(A, b, k) starts from an empty factorisation)")
+        if self._x.nnz:  # a fresh start of the same object
+            self.ctx.solver_begin(self.ALGO, self.b, self.k)
+        self.ctx.solver_acquire(self.k if k is None else int(k))
+        return self._sync_x(x)
+
+    def update_(self, x=None, eta=1.0):
+        if eta != 1.0:
+            raise NotImplementedError("update!(P::OMPR, x, eta): only eta = 1 (the value every driver of the reference uses) runs on the device")
+        self._check_nnz(x)
+        if not self._is_mine(x):
+            raise ValueError("update!(P::OMPR, x): x is not the vector this OMPR object's QR was built for")
+        self.ctx.solver_step(1)
+        return self._sync_x(x)
+
+
+def sp_acquisition(P, x=None, k=None):
+    """sp_acquisition!(P::SP, x, k = P.k): src/twostage.jl:67-72"""
+    return P.acquisition_(x, k)
+
+
 # ------------------------------------------------------------------------------------ oblivious
 def oblivious(A, b, k):
     """oblivious(A, b, k): src/oblivious.jl:3-8 -- the k atoms most correlated with b
@@ -532,10 +632,22 @@ def oblivious(A, b, k):
             D.close()
 
 
-def oblivious_acquisition(A, b, x, k):
+def oblivious_acquisition(A, b, x=None, k=None):
     """oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216 -- residual of the current x,
     the k atoms best correlated with it are added (x[ind] = NaN placeholders in the reference), then
-    least squares on the enlarged support.  x is updated in place and returned."""
+    least squares on the enlarged support.  x is updated in place and returned.
+    Two call forms: (A, b, x, k) on a matrix / Dictionary, and (P, x, k) on a functor that keeps an updatable QR
+    (OMPR, OMP, GOMP: csmp_solver_acquire)."""
+    if isinstance(A, (_TwoStage, _DevicePursuit)):  # (P, x, k)
+        P, x, k = A, b, (x if k is None else k)
+        if isinstance(P, OMPR):
+            return P.acquisition_(x, k)
+        if not isinstance(P, (OMP, GOMP)):
+            raise TypeError("oblivious_acquisition!(P, x, k): P must keep an updatable QR (OMP, GOMP, OMPR)")
+        if not P._same(x):
+            raise ValueError("oblivious_acquisition!(P, x, k): x is not the support this object's QR was built for")
+        P.ctx.solver_acquire(int(k))
+        return P._sync_x(x)
     D, tmp = _dict(A)
     try:
         b = np.asarray(b, dtype=np.float64)

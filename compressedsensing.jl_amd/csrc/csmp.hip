@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>  // (std::this_thread::yield in csmp_sp_batch's polling loop; the library starts no threads)
@@ -40,6 +41,7 @@ using namespace csmp;
 #include "host/removal.hpp"
 #include "host/gomp_sp.hpp"
 #include "host/twostage.hpp"
+#include "host/steps_twostage.hpp"
 #include "host/batched.hpp"
 #include "host/screened.hpp"
 #include "host/measure.hpp"

@@ -146,7 +146,8 @@ struct SpJob {
 
 
 struct csmp_ctx {
-    SpJob spjob;  // the Subspace Pursuit solve this context is carrying (csmp_sp, csmp_sp_batch)
+    SpJob spjob;  // the Subspace Pursuit solve this context is carrying (csmp_sp, csmp_sp_batch, the SP functor)
+    std::shared_ptr<void> omprjob;  // the OMPR object of csmp_ompr / the OMPR functor (OmprJob, host/twostage.hpp), made on first use
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;

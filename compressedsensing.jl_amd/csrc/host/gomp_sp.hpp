@@ -925,6 +925,18 @@ static int sp_job_advance(SpJob& j) {
     }
 }
 
+// the pending phase of a job, waited for on the calling thread: a phase lasts 0.1-1 ms and the solve resumes on this thread, so poll
+// (the wake-up of a blocking wait would sit on the chain five times per solve); something that takes far longer than a phase is
+// waited for the ordinary way
+static int sp_job_wait(SpJob& j) {
+    csmp_ctx* ctx = j.c;
+    hipError_t q = hipErrorNotReady;
+    for (int spin = 0; spin < 50000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(j.ev);
+    if (q == hipErrorNotReady) q = hipEventSynchronize(j.ev);
+    HIPCHECK(q);
+    return CSMP_OK;
+}
+
 extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
                        double* val, int64_t* nnz, int64_t* iters) {
     if (!ctx) return CSMP_EINVAL;
@@ -936,12 +948,7 @@ extern "C" int csmp_sp(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, dou
     ctx->gate = nullptr;  // (one solve: nothing to queue behind)
     int rc = sp_job_begin(j, ctx, b, b_dtype, k, delta, maxiter);
     while (rc == CSMP_OK && j.phase != SpJob::DONE) {
-        // a phase lasts 0.1-1 ms and the solve resumes on this thread: poll (the wake-up of a blocking wait would sit on the chain
-        // five times per solve); something that takes far longer than a phase is waited for the ordinary way
-        hipError_t q = hipErrorNotReady;
-        for (int spin = 0; spin < 50000 && q == hipErrorNotReady; ++spin) q = hipEventQuery(j.ev);
-        if (q == hipErrorNotReady) q = hipEventSynchronize(j.ev);
-        HIPCHECK(q);
+        CHECK(sp_job_wait(j));
         rc = sp_job_advance(j);
     }
     if (rc != CSMP_OK) return rc;

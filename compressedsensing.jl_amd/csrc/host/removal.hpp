@@ -148,6 +148,7 @@ extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
     if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_remove: no solver begun");
     if (ctx->s.algo == CSMP_ALGO_MP) return fail(ctx, CSMP_EINVAL, "solver_remove: MP keeps no factorisation");
     if (ctx->s.algo == CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_remove: use csmp_srr / the backward step for FR");
+    if (ctx->s.algo == CSMP_ALGO_SP || ctx->s.algo == CSMP_ALGO_OMPR) return fail(ctx, CSMP_EINVAL, "solver_remove: SP and OMPR choose the atoms that leave themselves (update!)");
     HIPCHECK(hipSetDevice(ctx->dev));
     if (ctx->s.kcap > kDelMaxCols)  // (the functor's down-date walks R with one thread per column in one workgroup: k_qrdel_r)
         return fail(ctx, CSMP_ERANGE, "solver_remove: the step-level solver's column removal supports a capacity of at most 1023 columns");
@@ -170,6 +171,7 @@ extern "C" int csmp_solver_state(csmp_ctx* ctx, int64_t* idx, double* val, int64
     if (!ctx->s.begun) return fail(ctx, CSMP_ESTATE, "solver_state: no solver begun");
     HIPCHECK(hipSetDevice(ctx->dev));
     Solver& s = ctx->s;
+    if (s.algo == CSMP_ALGO_SP || s.algo == CSMP_ALGO_OMPR) return twostage_functor_state(ctx, idx, val, nnz, resnorm, order, stop);
     if (resnorm) {
         hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
         HIPCHECK(hipGetLastError());

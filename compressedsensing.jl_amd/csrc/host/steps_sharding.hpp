@@ -1,13 +1,28 @@
 // host/steps_sharding.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
 // step-level API (the Update functors), csmp_clone, column-sharded OMP, signal-sharding helpers.
 // ------------------------------------------------------------------------------------------ step-level API
+// (the two-stage functors SP and OMPR: host/steps_twostage.hpp)
+static int sp_functor_begin(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, const int64_t* idx0, const double* val0, int64_t nnz0);
+static int sp_functor_update(csmp_ctx* ctx);
+static int ompr_functor_begin(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, int64_t nnz0);
+static int ompr_functor_update(csmp_ctx* ctx);
+static int twostage_functor_state(csmp_ctx* ctx, int64_t* idx, double* val, int64_t* nnz, double* resnorm, int64_t* order, int* stop);
+
 extern "C" int csmp_solver_begin(csmp_ctx* ctx, int algo, const void* b, int b_dtype, int64_t kcap, const int64_t* idx0,
                                  const double* val0, int64_t nnz0) {
     if (!ctx) return CSMP_EINVAL;
     if (!b || kcap < 1) return fail(ctx, CSMP_EINVAL, "solver_begin: bad arguments");
-    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP && algo != CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
+    if (algo != CSMP_ALGO_MP && algo != CSMP_ALGO_OMP && algo != CSMP_ALGO_GOMP && algo != CSMP_ALGO_FR && algo != CSMP_ALGO_SP && algo != CSMP_ALGO_OMPR)
+        return fail(ctx, CSMP_EINVAL, "solver_begin: unknown algo");
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
     HIPCHECK(hipSetDevice(ctx->dev));
+    if (algo == CSMP_ALGO_SP || algo == CSMP_ALGO_OMPR) {  // kcap is the k of SP(A, b, k) / OMPR(A, b, k)
+        ctx->s.begun = false;
+        CHECK(algo == CSMP_ALGO_SP ? sp_functor_begin(ctx, b, b_dtype, kcap, idx0, val0, nnz0) : ompr_functor_begin(ctx, b, b_dtype, kcap, nnz0));
+        ctx->s.algo = algo;
+        ctx->s.begun = true;
+        return CSMP_OK;
+    }
     const int kc = algo == CSMP_ALGO_MP ? (int)kcap : (int)std::min<int64_t>(kcap, ctx->M);
     CHECK(solver_ensure(ctx, kc, kc, algo != CSMP_ALGO_MP));
     if (algo == CSMP_ALGO_FR) CHECK(fr_ensure(ctx));
@@ -30,6 +45,8 @@ extern "C" int csmp_solver_step(csmp_ctx* ctx, int64_t l) {
     int rc = CSMP_OK;
     switch (ctx->s.algo) {
         case CSMP_ALGO_MP: return mp_step(ctx);
+        case CSMP_ALGO_SP: return sp_functor_update(ctx);
+        case CSMP_ALGO_OMPR: return ompr_functor_update(ctx);
         case CSMP_ALGO_OMP: {
             // update!(P::OMP, x) alone: no eps logic (that belongs to the omp driver)
             CHECK(launch_sweep(ctx, ctx->s.r, 0.0, 0, STOP_FULL));

@@ -1,42 +1,48 @@
 // host/twostage.hpp -- part of the host side of libcsmp.so (included by csmp.hip, in order; ONE translation unit):
 // OMP with replacement, the stepwise-regression object, srr, rmp, foba, br.
 // ------------------------------------------------------------------------------------------ OMP with replacement
-// ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202, x starting empty.  The support is filled by
-// oblivious_acquisition! (src/matchingpursuit.jl:207-216); every update! (:134-180) is one sweep +
-// arg-max on the device, the tiny "which entry leaves" decision on k+1 numbers on the host, and --
-// when the support changes -- remove_column! as a Givens down-date of the on-device QR
-// (csmp_downdate.hpp) followed by the usual append (k > 1023: a fresh panel factorisation instead).
-extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
-                         double* val, int64_t* nnz, int64_t* iters) {
-    if (!ctx) return CSMP_EINVAL;
-    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "ompr: b == NULL or k < 1");
-    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
-    if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
-    if (maxiter < 0) maxiter = ctx->M;  // :185
-    HIPCHECK(hipSetDevice(ctx->dev));
-    const bool want_downdate = k <= kTMaxCols;
-    if (want_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
-    CHECK(solver_ensure(ctx, (int)k, (int)k));
-    ctx->s.begun = false;
-    Solver& s = ctx->s;
-    const bool use_downdate = k <= kTMaxCols;  // (beyond: refactorise instead)
-    const bool tmode = use_downdate;  // explicit inverse next to R (csmp_tinv.hpp)
-    if (use_downdate) CHECK(del_ensure(ctx));
-    if (tmode) CHECK(tinv_ensure(ctx));
-    CHECK(upload_b(ctx, b, b_dtype));
-    // CSMP_OPT_SCREENED_SWEEP: the sweeps read the image; the oblivious acquisition's top-k set and every update!'s arg-max are
-    // certified (host/screened.hpp), the correlations on the support are computed exactly beside them; a sweep whose
-    // selection could not be certified is repeated exactly on the spot (the host reads the state after every sweep anyway)
-    const bool screened = screened_on(ctx) && k <= 4096;
-    if (screened) CHECK(screened_ensure(ctx));
-    ctx->scr_lone = true;
-    struct LoneReset {
-        csmp_ctx* c;
-        ~LoneReset() { c->scr_lone = false; }
-    } lone_reset{ctx};
-    // oblivious_acquisition!(P, x, k): the k atoms best correlated with b, least squares on them
-    std::vector<int> top((size_t)k);
-    {
+// The OMPR object (struct OMPR, src/twostage.jl:110-132) as the host keeps it: the support x (sorted, with its values), the residual
+// norm, and the on-device QR + explicit inverse that belong to it.  csmp_ompr drives one through begin / acquire / update; the
+// step-level functor (csmp_solver_begin(CSMP_ALGO_OMPR), host/steps_twostage.hpp) hands the same three calls to the host language.
+struct OmprJob {
+    csmp_ctx* ctx = nullptr;
+    int64_t k = 0;
+    std::vector<int64_t> xi;
+    std::vector<double> xv;
+    double resnorm = 0.0;
+    bool use_downdate = false, tmode = false, screened = false;
+    int unc_seen = 0;  // DevState::uncertain seen so far (the screened sweeps count up in it)
+    std::vector<double> cs, call;
+
+    // OMPR(A, b, k) (:124-132): buffers, b on the device, empty support, r = b
+    int begin(csmp_ctx* c, const void* b, int b_dtype, int64_t kk) {
+        ctx = c;
+        k = kk;
+        use_downdate = k <= kTMaxCols;  // (beyond: refactorise instead)
+        tmode = use_downdate;           // explicit inverse next to R (csmp_tinv.hpp)
+        if (use_downdate) CHECK(solver_fit_for_removal(ctx, (int)k));
+        CHECK(solver_ensure(ctx, (int)k, (int)k));
+        ctx->s.begun = false;
+        if (use_downdate) CHECK(del_ensure(ctx));
+        if (tmode) CHECK(tinv_ensure(ctx));
+        CHECK(upload_b(ctx, b, b_dtype));
+        // CSMP_OPT_SCREENED_SWEEP: the sweeps read the image; the oblivious acquisition's top-k set and every update!'s arg-max are
+        // certified (host/screened.hpp), the correlations on the support are computed exactly beside them; a sweep whose
+        // selection could not be certified is repeated exactly on the spot (the host reads the state after every sweep anyway)
+        screened = screened_on(ctx) && k <= 4096;
+        if (screened) CHECK(screened_ensure(ctx));
+        xi.clear();
+        xv.clear();
+        cs.assign((size_t)k, 0.0);
+        unc_seen = 0;
+        resnorm = 0.0;
+        return CSMP_OK;
+    }
+    // oblivious_acquisition!(P, x, k) on an empty x (src/matchingpursuit.jl:207-216, called at src/twostage.jl:190): the k atoms best
+    // correlated with b, least squares on them; then norm(residual!(P, x)) (:192)
+    int acquire() {
+        Solver& s = ctx->s;
+        std::vector<int> top((size_t)k);
         bool scr = screened;
         for (int attempt = 0; attempt < 2; ++attempt) {
             int flag = 0;
@@ -55,26 +61,21 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
             ctx->scr_fallbacks += 1;
             scr = false;
         }
+        std::sort(top.begin(), top.end());
+        CHECK(ls_on_columns(ctx, top));
+        if (tmode) {
+            CHECK(launch_tinv_build(ctx));
+            CHECK(fetch_sorted_t(ctx, xi, xv));
+        } else {
+            CHECK(fetch_sorted(ctx, xi, xv));
+        }
+        return residual_norm(ctx, &resnorm);
     }
-    std::sort(top.begin(), top.end());
-    CHECK(ls_on_columns(ctx, top));
-    std::vector<int64_t> xi;
-    std::vector<double> xv;
-    if (tmode) {
-        CHECK(launch_tinv_build(ctx));
-        CHECK(fetch_sorted_t(ctx, xi, xv));
-    } else {
-        CHECK(fetch_sorted(ctx, xi, xv));
-    }
-    double resnorm = 0.0;
-    CHECK(residual_norm(ctx, &resnorm));  // :192
-    int64_t it = 0;
-    std::vector<double> cs((size_t)k), call;
-    int unc_seen = 0;  // DevState::uncertain seen so far (the screened sweeps count up in it)
-    while (it < maxiter) {  // :193
-        const double oldnorm = resnorm;
+    // update!(P::OMPR, x) with eta = 1 (:134-180) and the norm(residual!(P, x)) the driver takes after it (:196)
+    int update() {
+        Solver& s = ctx->s;
         bool have_norm = false;
-        // update!(P, x): Ar = x + A'r (eta = 1), arg-max over atoms outside the support
+        // Ar = x + A'r, arg-max over atoms outside the support
         std::vector<int> cur(xi.begin(), xi.end());
         DevState hs;
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -128,7 +129,6 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
         } else if (!(std::fabs(ccand) > 0.0)) {
             cand = -1;
         }
-        ++it;
         if (cand >= 0) {
             // x[i] = NaN; x.nzval = Ar[x.nzind]; drop the first entry of smallest magnitude (:158-169)
             const size_t pos = (size_t)(std::lower_bound(xi.begin(), xi.end(), cand) - xi.begin());
@@ -171,13 +171,49 @@ extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, d
             }
         }
         if (!have_norm) CHECK(residual_norm(ctx, &resnorm));  // :196
-        if (resnorm <= delta || oldnorm <= resnorm) break;   // :197
+        return CSMP_OK;
     }
-    for (size_t t = 0; t < xi.size(); ++t) {
-        if (idx) idx[t] = xi[t];
-        if (val) val[t] = xv[t];
+};
+
+// (the context owns its OMPR object through a type-erased pointer: csmp_ctx is declared before this file)
+static OmprJob& ompr_job(csmp_ctx* ctx) {
+    if (!ctx->omprjob) ctx->omprjob = std::shared_ptr<void>(new OmprJob, [](void* p) { delete (OmprJob*)p; });
+    return *(OmprJob*)ctx->omprjob.get();
+}
+
+// ompr(A,b,k,delta;maxiter): src/twostage.jl:110-202, x starting empty.  The support is filled by
+// oblivious_acquisition! (src/matchingpursuit.jl:207-216); every update! (:134-180) is one sweep +
+// arg-max on the device, the tiny "which entry leaves" decision on k+1 numbers on the host, and --
+// when the support changes -- remove_column! as a Givens down-date of the on-device QR
+// (csmp_downdate.hpp) followed by the usual append (k > 4095: a fresh panel factorisation instead).
+extern "C" int csmp_ompr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double delta, int64_t maxiter, int64_t* idx,
+                         double* val, int64_t* nnz, int64_t* iters) {
+    if (!ctx) return CSMP_EINVAL;
+    if (!b || k < 1) return fail(ctx, CSMP_EINVAL, "ompr: b == NULL or k < 1");
+    if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
+    if (k > ctx->N || k > ctx->M) return fail(ctx, CSMP_ERANGE, "ompr: k exceeds size(A)");
+    if (maxiter < 0) maxiter = ctx->M;  // :185
+    HIPCHECK(hipSetDevice(ctx->dev));
+    OmprJob& j = ompr_job(ctx);
+    CHECK(j.begin(ctx, b, b_dtype, k));
+    ctx->scr_lone = true;
+    struct LoneReset {
+        csmp_ctx* c;
+        ~LoneReset() { c->scr_lone = false; }
+    } lone_reset{ctx};
+    CHECK(j.acquire());
+    int64_t it = 0;
+    while (it < maxiter) {  // :193
+        const double oldnorm = j.resnorm;
+        CHECK(j.update());
+        ++it;
+        if (j.resnorm <= delta || oldnorm <= j.resnorm) break;  // :197
     }
-    if (nnz) *nnz = (int64_t)xi.size();
+    for (size_t t = 0; t < j.xi.size(); ++t) {
+        if (idx) idx[t] = j.xi[t];
+        if (val) val[t] = j.xv[t];
+    }
+    if (nnz) *nnz = (int64_t)j.xi.size();
     if (iters) *iters = it;
     return CSMP_OK;
 }

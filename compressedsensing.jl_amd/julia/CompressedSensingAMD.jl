@@ -18,7 +18,7 @@ const libcsmp = get(ENV, "LIBCSMP", joinpath(@__DIR__, "..", "csrc", "libcsmp.so
 
 const CSMP_F32, CSMP_F64 = Cint(0), Cint(1)
 const CSMP_HOST, CSMP_DEVICE, CSMP_HOST_STREAMED = Cint(0), Cint(1), Cint(2)
-const ALGO_MP, ALGO_OMP, ALGO_GOMP = Cint(0), Cint(1), Cint(2)
+const ALGO_MP, ALGO_OMP, ALGO_GOMP, ALGO_FR, ALGO_SP, ALGO_OMPR = Cint(0), Cint(1), Cint(2), Cint(3), Cint(4), Cint(5)
 
 dtype_code(::Type{Float32}) = CSMP_F32
 dtype_code(::Type{Float64}) = CSMP_F64
@@ -297,12 +297,13 @@ mutable struct DevicePursuit{T} <: Update{T}
     algo::Cint
     l::Int
     kcap::Int
+    b::Any               # the signal (the reference's P.b): a two-stage functor restarts from a foreign x with it
 end
 function begin_solver(A::MatOrDict{T}, b, algo, kcap, l = 1) where {T}
     D = dict(A)
     ref = Ref{Ptr{Cvoid}}(C_NULL)
     check(D, ccall((:csmp_clone, libcsmp), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), D.ctx, ref))
-    P = DevicePursuit{T}(D, ref[], algo, l, kcap)
+    P = DevicePursuit{T}(D, ref[], algo, l, kcap, b)
     finalizer(p -> ccall((:csmp_destroy, libcsmp), Cint, (Ptr{Cvoid},), p.ctx), P)
     bb, bt = bvec(b)
     GC.@preserve bb pcheck(P, ccall((:csmp_solver_begin, libcsmp), Cint,
@@ -318,6 +319,7 @@ GOMP(A, b, l::Int, k::Integer = size(A, 1)) = begin_solver(A, b, ALGO_GOMP, min(
 
 # update!(P, x): one greedy step on the device, then x <- the device's current solution
 function update!(P::DevicePursuit, x::SparseVector = spzeros(size(P.D, 2)), l::Int = P.l)
+    (P.algo == ALGO_SP || P.algo == ALGO_OMPR) && return update_twostage!(P, x)
     pcheck(P, ccall((:csmp_solver_step, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.ctx, l))
     idx, val, nnz = zeros(Int64, P.kcap), zeros(Float64, P.kcap), Ref{Int64}(0)
     GC.@preserve idx val pcheck(P, ccall((:csmp_solver_state, libcsmp), Cint,
@@ -327,6 +329,68 @@ function update!(P::DevicePursuit, x::SparseVector = spzeros(size(P.D, 2)), l::I
     resize!(x.nzind, nnz[]); resize!(x.nzval, nnz[])
     copyto!(x.nzind, y.nzind); copyto!(x.nzval, y.nzval)
     return x
+end
+
+# ---- the two-stage functors: SP (src/twostage.jl:42-83) and OMPR (:110-180).  The device solver owns the x it produced last; the x
+# handed to update! is checked against it: SP restarts from a foreign x (the reference recomputes the residual from whatever x it
+# is given, :68), OMPR refuses one (its factorisation belongs to the x it built).
+function SP(A::MatOrDict, b::AbstractVector, k::Integer)
+    2k > length(b) && error("2k = $(2k) > $(length(b)) = length(b) is invalid for Subspace Pursuit")  # :55
+    begin_solver(A, b, ALGO_SP, Int(k))
+end
+const SubspacePursuit = SP
+OMPR(A::MatOrDict, b::AbstractVector, k::Int) = begin_solver(A, b, ALGO_OMPR, k)  # :124-132
+mutable struct TwoStageX  # the x a two-stage functor returned last (per functor; keyed by the clone's handle)
+    nzind::Vector{Int}
+    nzval::Vector{Float64}
+end
+const LAST_X = Dict{Ptr{Cvoid},TwoStageX}()
+function fetch_x!(P::DevicePursuit, x::SparseVector)
+    cap = 2 * P.kcap
+    idx, val, nnz = zeros(Int64, cap), zeros(Float64, cap), Ref{Int64}(0)
+    GC.@preserve idx val pcheck(P, ccall((:csmp_solver_state, libcsmp), Cint,
+        (Ptr{Cvoid}, Ptr{Int64}, Ptr{Cdouble}, Ref{Int64}, Ptr{Cdouble}, Ptr{Int64}, Ptr{Cint}),
+        P.ctx, idx, val, nnz, C_NULL, C_NULL, C_NULL))
+    y = to_sparse(size(P.D, 2), idx, val, nnz[])
+    resize!(x.nzind, nnz[]); resize!(x.nzval, nnz[])
+    copyto!(x.nzind, y.nzind); copyto!(x.nzval, y.nzval)
+    LAST_X[P.ctx] = TwoStageX(copy(x.nzind), copy(x.nzval))
+    return x
+end
+is_mine(P::DevicePursuit, x::SparseVector) = (l = get(LAST_X, P.ctx, TwoStageX(Int[], Float64[])); x.nzind == l.nzind && x.nzval == l.nzval)
+# a foreign x restarts the SP solver from it (csmp_solver_begin with the x's entries, 0-based)
+function load_x!(P::DevicePursuit, x::SparseVector)
+    is_mine(P, x) && return
+    bb, bt = bvec(P.b)
+    i0, v0 = x.nzind .- 1, Vector{Float64}(x.nzval)
+    GC.@preserve bb i0 v0 pcheck(P, ccall((:csmp_solver_begin, libcsmp), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint, Int64, Ptr{Int64}, Ptr{Cdouble}, Int64),
+        P.ctx, P.algo, bb, bt, P.kcap, i0, v0, length(i0)))
+    LAST_X[P.ctx] = TwoStageX(copy(x.nzind), copy(x.nzval))
+end
+# sp_acquisition!(P, x, k = P.k): :67-72
+function sp_acquisition!(P::DevicePursuit, x::SparseVector, k::Int = P.kcap)
+    P.algo == ALGO_SP || throw("sp_acquisition!: P is not an SP")
+    load_x!(P, x)
+    pcheck(P, ccall((:csmp_solver_acquire, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.ctx, k))
+    fetch_x!(P, x)
+end
+# oblivious_acquisition!(P, x, k): src/matchingpursuit.jl:207-216, for the functors that keep an updatable QR (OMPR, OMP, GOMP)
+function oblivious_acquisition!(P::DevicePursuit, x::SparseVector, k::Int)
+    P.algo in (ALGO_OMPR, ALGO_OMP, ALGO_GOMP) || throw("oblivious_acquisition!: P keeps no updatable QR")
+    pcheck(P, ccall((:csmp_solver_acquire, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.ctx, k))
+    fetch_x!(P, x)
+end
+# update!(P::SP, x) (:75-83) and update!(P::OMPR, x) (:134-180, eta = 1): nnz(x) == k or the reference's String is thrown (:76, :135)
+function update_twostage!(P::DevicePursuit, x::SparseVector)
+    nnz(x) == P.kcap || throw("nnz(x) = $(nnz(x)) ≠ $(P.kcap) = k")
+    if P.algo == ALGO_SP
+        load_x!(P, x)
+    else
+        is_mine(P, x) || throw("update!(P::OMPR, x): x is not the vector this OMPR object's QR was built for")
+    end
+    pcheck(P, ccall((:csmp_solver_step, libcsmp), Cint, (Ptr{Cvoid}, Int64), P.ctx, 1))
+    fetch_x!(P, x)
 end
 
 # ---------------------------------------------------------------------------------- many signals

@@ -49,6 +49,8 @@ extern "C" {
 #define CSMP_ALGO_OMP 1
 #define CSMP_ALGO_GOMP 2
 #define CSMP_ALGO_FR 3 /* update!(P::FR, x): src/forward.jl:88-95 */
+#define CSMP_ALGO_SP 4   /* SP(A,b,k), update!(P::SP, x): src/twostage.jl:42-83 */
+#define CSMP_ALGO_OMPR 5 /* OMPR(A,b,k), update!(P::OMPR, x) with eta = 1: src/twostage.jl:110-180 */
 
 /* why a solve stopped early (csmp_solver_state: *stop) */
 #define CSMP_STOP_NONE 0
@@ -280,8 +282,16 @@ int csmp_screened_stats(csmp_ctx *ctx, int64_t *solves, int64_t *fallbacks, int 
  * (residual, on-device QR, support) lives in the ctx. */
 int csmp_solver_begin(csmp_ctx *ctx, int algo, const void *b, int b_dtype, int64_t kcap,
                       const int64_t *idx0, const double *val0, int64_t nnz0);
-/* one update!: MP/OMP ignore l; GOMP adds the l best atoms */
+/* CSMP_ALGO_SP / CSMP_ALGO_OMPR: kcap is the k of SP(A,b,k) (2k <= M or CSMP_ERANGE: src/twostage.jl:55) / OMPR(A,b,k).  The
+ * solver owns x.  SP: (idx0, val0) is the x the host would hand to update! -- any vector of at most 2k atoms; its values count (the
+ * acquisition starts from residual!(P, x), :68).  OMPR: x starts empty (nnz0 = 0): its factorisation does (:124-129).
+ * one update!: MP/OMP ignore l; GOMP adds the l best atoms; SP / OMPR: update!(P, x) (:75-83 / :134-180, eta = 1), which requires
+ * nnz(x) == k -- otherwise CSMP_ESTATE with the reference's message "nnz(x) = .. != .. = k" (:76, :135) */
 int csmp_solver_step(csmp_ctx *ctx, int64_t l);
+/* SP: sp_acquisition!(P, x, k) (src/twostage.jl:67-72) -- the k atoms best correlated with the residual of x join it, least squares
+ * on the union.  OMPR / OMP / GOMP: oblivious_acquisition!(P, x, k) (src/matchingpursuit.jl:207-216) -- the same with the
+ * updatable QR (OMPR: on the empty x, k = the k of OMPR(A,b,k): how ompr fills the support, src/twostage.jl:190). */
+int csmp_solver_acquire(csmp_ctx *ctx, int64_t k);
 /* dropindex!(x, AiQR, i) (src/util.jl:137-161): atom leaves the support of an OMP/GOMP solver -- Givens
  * down-date of the on-device QR (remove_column!), residual and coefficients follow.  No-op if absent. */
 int csmp_solver_remove(csmp_ctx *ctx, int64_t atom);

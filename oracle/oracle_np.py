@@ -112,6 +112,28 @@ def mp(A, b, k, x0=None):
     return idx, np.array([x[i] for i in idx])
 
 
+def sp_acquisition(A, b, idx, val, k):
+    """sp_acquisition!(P, x, k): src/twostage.jl:67-72 -- (idx, val) -> the union with the k atoms best correlated with the
+    residual of x, and the least-squares solution on it"""
+    A, b = _f64(A, b)
+    idx, val = np.asarray(idx, np.int64), np.asarray(val, np.float64)
+    r = _residual(A, b, idx, val)
+    idx = np.union1d(idx, _topk(_abs_corr(A, r), k)).astype(np.int64)
+    return idx, _ls(A, idx, b)
+
+
+def sp_update(A, b, idx, val, k):
+    """update!(P::SP, x): src/twostage.jl:75-83 (nnz(x) == k is the caller's to hold, :76)"""
+    A, b = _f64(A, b)
+    idx, val = sp_acquisition(A, b, idx, val, k)  # :77
+    drop = len(idx) - k
+    if drop > 0:  # :78-81
+        kill = np.lexsort((np.arange(len(val)), np.abs(val)))[:drop]
+        keep = np.setdiff1d(np.arange(len(idx)), kill)
+        idx = idx[keep]
+    return idx, _ls(A, idx, b)  # :82
+
+
 def sp(A, b, k, delta=1e-12, maxiter=None):
     A, b = _f64(A, b)
     M, N = A.shape
@@ -119,29 +141,45 @@ def sp(A, b, k, delta=1e-12, maxiter=None):
         raise ValueError("2k > length(b) is invalid for Subspace Pursuit")  # twostage.jl:55
     if maxiter is None:
         maxiter = 16 * k
-
-    def acquire(idx, val):  # :67-72
-        r = _residual(A, b, idx, val)
-        idx = np.union1d(idx, _topk(_abs_corr(A, r), k)).astype(np.int64)
-        return idx, _ls(A, idx, b)
-
-    idx, val = acquire(np.zeros(0, np.int64), np.zeros(0))  # :90
+    idx, val = sp_acquisition(A, b, np.zeros(0, np.int64), np.zeros(0), k)  # :90
     resnorm = np.linalg.norm(_residual(A, b, idx, val))
     iters = 0
     for _ in range(maxiter):  # :92
         oldnorm = resnorm
-        idx, val = acquire(idx, val)  # :77
-        drop = len(idx) - k
-        if drop > 0:  # :78-81
-            kill = np.lexsort((np.arange(len(val)), np.abs(val)))[:drop]
-            keep = np.setdiff1d(np.arange(len(idx)), kill)
-            idx = idx[keep]
-        val = _ls(A, idx, b)  # :82
+        idx, val = sp_update(A, b, idx, val, k)
         iters += 1
         resnorm = np.linalg.norm(_residual(A, b, idx, val))
         if resnorm <= delta or oldnorm <= resnorm:  # :96
             break
     return idx, val, iters
+
+
+def oblivious_acquisition(A, b, k):
+    """oblivious_acquisition!(P, x, k) on an empty x: src/matchingpursuit.jl:207-216"""
+    A, b = _f64(A, b)
+    idx = np.sort(_topk(_abs_corr(A, b), k)).astype(np.int64)
+    return idx, _ls(A, idx, b)
+
+
+def ompr_update(A, b, idx, val):
+    """update!(P::OMPR, x) with eta = 1: src/twostage.jl:134-180"""
+    A, b = _f64(A, b)
+    idx, val = np.asarray(idx, np.int64), np.asarray(val, np.float64)
+    N = A.shape[1]
+    r = _residual(A, b, idx, val)
+    Ar = A.T @ r  # eta = 1
+    Ar[idx] += val  # copy!(P.Ar, x); mul!(P.Ar, A', r, eta, 1)
+    mask = np.ones(N, bool)
+    mask[idx] = False
+    cand = np.abs(Ar) * mask
+    if cand.max() > 0:
+        i = int(np.argmax(cand))  # first maximum among atoms outside the support
+        idx2 = np.sort(np.append(idx, i))
+        v2 = Ar[idx2]
+        j = int(np.argmin(np.abs(v2)))  # first minimum
+        idx = np.delete(idx2, j)
+        val = _ls(A, idx, b)
+    return idx, val
 
 
 def ompr(A, b, k, delta, maxiter=None):
@@ -150,26 +188,13 @@ def ompr(A, b, k, delta, maxiter=None):
     M, N = A.shape
     if maxiter is None:
         maxiter = M  # :185
-    idx = np.sort(_topk(_abs_corr(A, b), k)).astype(np.int64)  # oblivious_acquisition! (matchingpursuit.jl:207-216)
-    val = _ls(A, idx, b)
+    idx, val = oblivious_acquisition(A, b, k)
     resnorm = np.linalg.norm(_residual(A, b, idx, val))
     iters = 0
     for _ in range(maxiter):
         oldnorm = resnorm
-        r = _residual(A, b, idx, val)
-        Ar = A.T @ r  # eta = 1
-        Ar[idx] += val  # copy!(P.Ar, x); mul!(P.Ar, A', r, eta, 1)
-        mask = np.ones(N, bool)
-        mask[idx] = False
-        cand = np.abs(Ar) * mask
+        idx, val = ompr_update(A, b, idx, val)
         iters += 1
-        if cand.max() > 0:
-            i = int(np.argmax(cand))  # first maximum among atoms outside the support
-            idx2 = np.sort(np.append(idx, i))
-            v2 = Ar[idx2]
-            j = int(np.argmin(np.abs(v2)))  # first minimum
-            idx = np.delete(idx2, j)
-            val = _ls(A, idx, b)
         resnorm = np.linalg.norm(_residual(A, b, idx, val))
         if resnorm <= delta or oldnorm <= resnorm:
             break

@@ -123,3 +123,118 @@ def test_float64_dictionary_at_the_benchmark_row_count(cs, oracle):
     got = d.ctx.omp(y, k, EPS64)
     assert np.array_equal(got[2], ref[2]) and close(got[1], ref[1])
     d.close()
+
+
+# ------------------------------------------------------------------------------------------ step-level SP and OMPR (verdict round 4, item 4)
+def test_step_level_sp_functor(cs, oracle):
+    """P = SP(A, b, k); sp_acquisition!(P, x); update!(P, x) one call at a time (src/twostage.jl:54-83): x after EVERY call against
+    the oracle's iterate -- the numpy twin's step functions, and the C oracle's sp stopped after the same number of update! calls --,
+    the residual norm the functor reports, and the reference's errors (2k > length(b), :55; nnz(x) != k, :76)."""
+    from oracle import oracle_np
+    for (M, N, k, dtype, seed) in [(64, 256, 6, np.float64, 3), (256, 1024, 20, np.float32, 4), (1000, 3000, 24, np.float32, 5)]:
+        A = gaussian(M, N, dtype, seed)
+        y = planted(A, k, seed, noise=0.05)
+        d = cs.Dictionary(A)
+        P = cs.SP(d, y, k)
+        x = cs.spzeros(N)
+        with pytest.raises(ValueError, match="nnz\\(x\\) = 0"):
+            P(x)  # update! on the empty x throws (:76)
+        with pytest.raises(cs.CsmpError, match="nnz\\(x\\) = 0 \u2260 %d = k" % k):
+            P.ctx.solver_step(1)  # ... and so does the C ABI underneath the host mirror (CSMP_ESTATE, the reference's string)
+        cs.sp_acquisition(P, x)
+        ri, rv = oracle_np.sp_acquisition(A, y, [], [], k)
+        assert np.array_equal(x.nzind, ri) and close(x.nzval, rv)
+        for t in range(1, 6):
+            P(x)  # (U::Update)(x) = update!(U, x)
+            ri, rv = oracle_np.sp_update(A, y, ri, rv, k)
+            assert x.nnz == k and np.array_equal(x.nzind, ri), (t, x.nzind, ri)
+            assert close(x.nzval, rv)
+            rn = np.linalg.norm(oracle.residual(A, x.nzind, x.nzval, y))
+            assert abs(P.resnorm - rn) <= 1e-9 * max(rn, 1e-30)
+            ci, cv, cit = oracle.sp(A, y, k, 0.0, maxiter=t)
+            if cit == t:  # (the driver had not stopped by oldnorm <= resnorm before: its x after t calls)
+                assert np.array_equal(x.nzind, ci) and close(x.nzval, cv)
+        # a FOREIGN x (the reference recomputes the residual from whatever x it is handed, :68): other atoms, other values
+        g = np.random.default_rng(seed)
+        fx = cs.SparseVector(N, np.sort(g.choice(N, k, replace=False)), g.standard_normal(k))
+        ri, rv = oracle_np.sp_update(A, y, fx.nzind, fx.nzval, k)
+        P(fx)
+        assert np.array_equal(fx.nzind, ri) and close(fx.nzval, rv)
+        # the whole driver, rebuilt from the functor: sp(A, b, k, delta) (:87-101)
+        P2 = cs.SP(d, y, k)
+        x2 = cs.sp_acquisition(P2)
+        resnorm, it = P2.resnorm, 0
+        for it in range(1, 16 * k + 1):
+            old = resnorm
+            x2 = P2(x2)
+            resnorm = P2.resnorm
+            if resnorm <= 1e-12 or old <= resnorm:
+                break
+        ci, cv, cit = oracle.sp(A, y, k, 1e-12)
+        assert it == cit and np.array_equal(x2.nzind, ci) and close(x2.nzval, cv)
+        P.close()
+        P2.close()
+        d.close()
+    with pytest.raises(ValueError, match="invalid for Subspace Pursuit"):
+        cs.SP(gaussian(16, 40, np.float64, 1), np.ones(16), 9)
+
+
+def test_step_level_ompr_functor(cs, oracle):
+    """P = OMPR(A, b, k); oblivious_acquisition!(P, x, k); update!(P, x) (src/twostage.jl:124-180, src/matchingpursuit.jl:207-216):
+    every iterate against the oracle's, the driver rebuilt from the functor against oracle.ompr, and the nnz(x) != k error (:135)."""
+    from oracle import oracle_np
+    for (M, N, k, dtype, seed) in [(64, 256, 6, np.float64, 7), (256, 1024, 20, np.float32, 8), (512, 2048, 40, np.float32, 9)]:
+        A = gaussian(M, N, dtype, seed)
+        y = planted(A, k + 3, seed, noise=0.3)  # more planted atoms than k and heavy noise: the oblivious start is wrong, swaps follow
+        d = cs.Dictionary(A)
+        P = cs.OMPR(d, y, k)
+        x = cs.spzeros(N)
+        with pytest.raises(ValueError, match="nnz\\(x\\) = 0"):
+            P(x)
+        cs.oblivious_acquisition(P, x, k)
+        ri, rv = oracle_np.oblivious_acquisition(A, y, k)
+        assert np.array_equal(x.nzind, ri) and close(x.nzval, rv)
+        swaps = 0
+        for t in range(1, 9):
+            before = x.nzind.copy()
+            P(x)
+            ri, rv = oracle_np.ompr_update(A, y, ri, rv)
+            assert x.nnz == k and np.array_equal(x.nzind, ri), (t, x.nzind, ri)
+            assert close(x.nzval, rv)
+            swaps += int(not np.array_equal(before, x.nzind))
+            rn = np.linalg.norm(oracle.residual(A, x.nzind, x.nzval, y))
+            assert abs(P.resnorm - rn) <= 1e-9 * max(rn, 1e-30)
+        assert swaps >= 1, "the test data must make OMPR replace at least one atom"
+        P2 = cs.OMPR(d, y, k)
+        x2 = cs.oblivious_acquisition(P2, None, k)
+        resnorm, it = P2.resnorm, 0
+        for it in range(1, M + 1):
+            old = resnorm
+            x2 = P2(x2)
+            resnorm = P2.resnorm
+            if resnorm <= 1e-9 or old <= resnorm:
+                break
+        ci, cv, cit = oracle.ompr(A, y, k, 1e-9)
+        assert it == cit and np.array_equal(x2.nzind, ci) and close(x2.nzval, cv)
+        P.close()
+        P2.close()
+        d.close()
+
+
+def test_oblivious_acquisition_on_the_omp_functor(cs, oracle):
+    """oblivious_acquisition!(P, x, k) for a P that keeps an updatable QR (src/matchingpursuit.jl:207-216): residual of x, the k best
+    atoms join (one already there is skipped, src/util.jl:128-134), one solve -- then update! continues from it"""
+    from oracle import oracle_np
+    A = gaussian(128, 512, np.float64, 21)
+    y = planted(A, 8, 2)
+    d = cs.Dictionary(A)
+    P = cs.OMP(d, y, 16)
+    x = cs.oblivious_acquisition(P, None, 5)
+    ri, rv = oracle_np.oblivious_acquisition(A, y, 5)
+    assert np.array_equal(x.nzind, ri) and close(x.nzval, rv)
+    x = P(x)
+    r = y - A[:, ri] @ rv
+    nxt = int(np.argmax(np.abs(A.T @ r)))
+    assert x.nnz == 6 and nxt in x.nzind and close(x.nzval, oracle.lstsq_cols(A, x.nzind, y))
+    P.close()
+    d.close()
