@@ -150,8 +150,16 @@ extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
     if (ctx->s.algo == CSMP_ALGO_FR) return fail(ctx, CSMP_EINVAL, "solver_remove: use csmp_srr / the backward step for FR");
     if (ctx->s.algo == CSMP_ALGO_SP || ctx->s.algo == CSMP_ALGO_OMPR) return fail(ctx, CSMP_EINVAL, "solver_remove: SP and OMPR choose the atoms that leave themselves (update!)");
     HIPCHECK(hipSetDevice(ctx->dev));
-    if (ctx->s.kcap > kDelMaxCols)  // (the functor's down-date walks R with one thread per column in one workgroup: k_qrdel_r)
-        return fail(ctx, CSMP_ERANGE, "solver_remove: the step-level solver's column removal supports a capacity of at most 1023 columns");
+    if (ctx->s.kcap > kDelMaxCols) {
+        // k_qrdel_r walks R with one thread per column in one workgroup (1023 columns).  Beyond that the down-date takes its
+        // rotations from the explicit inverse T = R^-1, as the two-stage solvers do (csmp_tinv.hpp: up to 4095 columns); the
+        // functor's appends do not maintain T, so it is rebuilt from R here (one launch, O(j^3 / 64) per lane: a step primitive)
+        if (ctx->s.kcap > kTMaxCols)
+            return fail(ctx, CSMP_ERANGE, "solver_remove: column removal supports a capacity of at most 4095 columns");
+        CHECK(tinv_ensure(ctx));
+        CHECK(launch_tinv_build(ctx));
+        return launch_delete_atom_t(ctx, (int)atom);
+    }
     CHECK(del_ensure(ctx));
     return launch_delete_atom(ctx, (int)atom);
 }

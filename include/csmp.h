@@ -293,7 +293,8 @@ int csmp_solver_step(csmp_ctx *ctx, int64_t l);
  * updatable QR (OMPR: on the empty x, k = the k of OMPR(A,b,k): how ompr fills the support, src/twostage.jl:190). */
 int csmp_solver_acquire(csmp_ctx *ctx, int64_t k);
 /* dropindex!(x, AiQR, i) (src/util.jl:137-161): atom leaves the support of an OMP/GOMP solver -- Givens
- * down-date of the on-device QR (remove_column!), residual and coefficients follow.  No-op if absent. */
+ * down-date of the on-device QR (remove_column!), residual and coefficients follow.  No-op if absent.
+ * Capacities (kcap of csmp_solver_begin) up to 4095 columns; beyond: CSMP_ERANGE. */
 int csmp_solver_remove(csmp_ctx *ctx, int64_t atom);
 /* current x (sorted), ||b - A x||_2, selection order, stop reason.  Any pointer may be NULL. */
 int csmp_solver_state(csmp_ctx *ctx, int64_t *idx, double *val, int64_t *nnz, double *resnorm,

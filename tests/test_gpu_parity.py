@@ -1066,6 +1066,51 @@ def test_qr_column_removal(cs, D, cfg):
     assert len(idx) == 0 and np.isclose(res, np.linalg.norm(y), rtol=1e-10)
 
 
+def test_qr_column_removal_beyond_1023_columns(cs, D):
+    """dropindex! has no column cap in the reference (src/util.jl:137-161); rounds 1-4 stopped the step-level csmp_solver_remove at
+    1023 columns (one thread per column in k_qrdel_r).  A 2048-column support (built by oblivious_acquisition!, then update!s):
+    removals at the first / a middle / the last / the second insertion position, each checked against a dense least-squares solve,
+    insertion order preserved, appends on top of the down-dated factorisation, an absent atom a no-op."""
+    M, N, k = 4096, 6000, 2048
+    g = np.random.default_rng(2048)
+    A = g.standard_normal((M, N))
+    A /= np.linalg.norm(A, axis=0, keepdims=True)
+    A = np.asfortranarray(A.astype(np.float32))
+    A64 = A.astype(np.float64)
+    y = A64[:, g.choice(N, 64, replace=False)] @ g.standard_normal(64) + 0.05 * g.standard_normal(M)
+    d = D(A)
+    d.ctx.solver_begin(cs._lib.ALGO_OMP, y, k + 8)
+    d.ctx.solver_acquire(k - 2)
+    for _ in range(2):
+        d.ctx.solver_step(1)
+    idx, val, res, order, stop = d.ctx.solver_state(k + 8)
+    assert len(idx) == k
+
+    def check(expect_support):
+        idx, val, res, order, stop = d.ctx.solver_state(k + 8)
+        S = np.array(sorted(expect_support))
+        assert np.array_equal(idx, S)
+        coef = np.linalg.lstsq(A64[:, S], y, rcond=None)[0]
+        assert np.allclose(val, coef, rtol=1e-7, atol=1e-9 * np.abs(coef).max())
+        assert np.isclose(res, np.linalg.norm(y - A64[:, S] @ coef), rtol=1e-8, atol=1e-12)
+        return order
+
+    supp = list(order)
+    for pos in (0, len(supp) // 2, -1, 1):
+        atom = supp[pos]
+        d.ctx.solver_remove(atom)
+        supp.remove(atom)
+        order = check(supp)
+        assert list(order) == supp
+    d.ctx.solver_remove(10 ** 6)
+    check(supp)
+    for _ in range(2):
+        d.ctx.solver_step(1)
+    idx, val, res, order, stop = d.ctx.solver_state(k + 8)
+    assert len(idx) == k - 2
+    check(list(order))
+
+
 # ------------------------------------------------------------------------------------------------
 # stepwise regression with replacement (srr, src/twostage.jl:3-33): forward steps + backward steps
 @pytest.mark.parametrize("cfg", [(32, 64, 3, 1, np.float64), (32, 64, 3, 3, np.float64), (128, 512, 12, 1, np.float32),
