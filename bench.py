@@ -175,6 +175,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch-cert", choices=["statistical", "rigorous"], default="rigorous", help="--workload batched: CSMP_OPT_BATCH_CERT (rigorous is the library's default)")
     p.add_argument("--batch-gram", action="store_true", help="--workload batched: CSMP_OPT_BATCH_GRAM (resident G = A'A, 32 GiB)")
+    p.add_argument("--no-in-flight", action="store_true", help="--workload ompr / srr: skip the three-solves-in-flight part (a kernel trace of the one-solve-at-a-time loop alone)")
     p.add_argument("--tune", type=str, default="", help="measurement overrides of the sweep configuration (csmp_internal.h), e.g. tick_grid=224,sweep_grid=192")
     p.add_argument("--workload", choices=["omp", "shapes", "screened", "streamed", "batched", "gomp", "gomp_single", "sp", "sp_single", "fr", "ompr", "srr", "colsharded"], default="omp",
                    help="omp = configs[1] (default, the headline metric); batched = configs[2]/[3]: 1024 signals per GPU, "
@@ -839,13 +840,14 @@ def run_twostage(args, cs, torch, dev, At, D, show=True):
     # signal's long latency-bound chain (rank-one exchanges, selections, host decisions) under the others' sweeps
     def one(c, b):
         return c.ompr(b, K_ATOMS, 1e-6)[2] if args.workload == "ompr" else c.srr(b, K_ATOMS, 1e-12, -1, 1, 1)[2]
-    many = [sigs[W + (i % K)] for i in range(3 * K)]
-    cs.solve_in_flight(D, many[:3], one, in_flight=3)  # (the clones' first call allocates their solver slots)
-    t0 = time.perf_counter()
-    its = cs.solve_in_flight(D, many, one, in_flight=3)
-    dt3 = time.perf_counter() - t0
-    out["three_in_flight"] = {"solves": len(many), "ms_per_solve": dt3 / len(many) * 1e3, "solves_per_s": len(many) / dt3,
-                              "iterations_equal_single": bool(sum(its[:K]) == iters)}
+    if not getattr(args, "no_in_flight", False):
+        many = [sigs[W + (i % K)] for i in range(3 * K)]
+        cs.solve_in_flight(D, many[:3], one, in_flight=3)  # (the clones' first call allocates their solver slots)
+        t0 = time.perf_counter()
+        its = cs.solve_in_flight(D, many, one, in_flight=3)
+        dt3 = time.perf_counter() - t0
+        out["three_in_flight"] = {"solves": len(many), "ms_per_solve": dt3 / len(many) * 1e3, "solves_per_s": len(many) / dt3,
+                                  "iterations_equal_single": bool(sum(its[:K]) == iters)}
     if show:
         emit(out)
     return out

@@ -94,8 +94,16 @@ __global__ __launch_bounds__(256) void k_b_convert_f16(const TA* __restrict__ A,
     }
     *reinterpret_cast<f16x8v*>(out + n * Mk + c * 8) = v;
 }
-// power of two that scales a largest magnitude vmax into [2^14, 2^15) (1 for vmax == 0)
-__host__ __device__ __forceinline__ float f16_scale(float vmax) { return vmax > 0.0f ? ldexpf(1.0f, 14 - ilogbf(vmax)) : 1.0f; }
+// power of two that scales a largest magnitude vmax into [2^14, 2^15) (1 for vmax == 0).  The exponent is clamped to +-100 so that
+// the scale AND its reciprocal stay finite normal floats whatever vmax is: a residual of 1e-35 (a Float32 subnormal, or a Float64
+// far below FLT_MIN) used to give 2^127+ = inf and an image of NaNs; an infinite vmax overflowed the integer exponent.  A
+// clamped image underflows to zeros instead, which the certificate charges as a flush to zero (the signal is then re-solved exactly).
+__host__ __device__ __forceinline__ float f16_scale(float vmax) {
+    if (!(vmax > 0.0f) || !(vmax <= 3.4028234e38f)) return 1.0f;
+    int e = 14 - ilogbf(vmax);
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return ldexpf(1.0f, e);
+}
 
 // dictionary -> int8 [Npad][Mk8] with ONE step for the whole dictionary (astep = max|A| / 127; inv = 1 / astep), zero padded:
 // the int8 screen's operand (k_b_screen256p<true>).  A common step makes the absolute rounding error of every entry the

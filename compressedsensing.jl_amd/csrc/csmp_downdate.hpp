@@ -124,6 +124,7 @@ __global__ __launch_bounds__(1024) void k_qrdel_r(const double* __restrict__ Rol
 // rotated-out column q_drop (needed by the forward-regression rescaling, csmp_forward.hpp) and
 // restores the residual r += zeta * q_drop.  One wave per 64-row slab, kQPre columns in flight.
 constexpr int kQPre = 32;
+constexpr int kRotBlk = 16, kRotBuf = 3;  // rot_chain (csmp_tinv.hpp): a ring of three 16-element blocks
 __global__ __launch_bounds__(64) void k_qrdel_q(double* __restrict__ Q, int64_t ldq, const double* __restrict__ G,
                                                 const double* __restrict__ scal, const int* __restrict__ meta,
                                                 double* __restrict__ r, double* __restrict__ qdrop,

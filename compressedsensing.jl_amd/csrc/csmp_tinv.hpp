@@ -203,12 +203,26 @@ __global__ __launch_bounds__(256) void k_tinv_fin(double* __restrict__ T, int kc
     if (threadIdx.x == 0) tmeta[0] = j + 1;
 }
 
-// (index, coefficient) pairs in ascending index order from coefficients in insertion order (the tail of k_finish)
+// (index, coefficient) pairs in ascending index order from coefficients in insertion order (the tail of k_finish).
+// r != NULL: ||r||^2 into *n2out as well (k_norm2's arithmetic: the two used to be two launches on a latency chain).
 __global__ __launch_bounds__(256) void k_emit_sorted(const double* __restrict__ coef, const int* __restrict__ sel,
                                                      const DevState* st, int64_t* __restrict__ out_idx,
                                                      double* __restrict__ out_val, int64_t* __restrict__ out_nnz,
-                                                     int64_t* __restrict__ out_order, int outcap) {
+                                                     int64_t* __restrict__ out_order, int outcap,
+                                                     const double* __restrict__ r = nullptr, int M = 0, double* __restrict__ n2out = nullptr) {
     const int tid = threadIdx.x, j = st->nsel;
+    if (r) {
+        __shared__ double sred[256];
+        double acc = 0.0;
+        for (int i = tid; i < M; i += 256) acc = fma(r[i], r[i], acc);
+        sred[tid] = acc;
+        __syncthreads();
+        for (int k = 128; k >= 1; k >>= 1) {
+            if (tid < k) sred[tid] += sred[tid + k];
+            __syncthreads();
+        }
+        if (tid == 0) *n2out = sred[0];
+    }
     for (int t = tid; t < outcap; t += 256) {
         out_idx[t] = -1;
         out_val[t] = 0.0;
@@ -223,6 +237,47 @@ __global__ __launch_bounds__(256) void k_emit_sorted(const double* __restrict__ 
         out_val[rank] = coef[t];
     }
     if (tid == 0) *out_nnz = j;
+}
+
+// OMPR's update!, between the sweep and the host's decision (one workgroup): the arg-max over the sweep's partials (k_select, mode 0:
+// no guards) and c[i] for the atoms of the support in INDEX order (the sorted list the last k_emit_sorted left on the device) --
+// the numbers "x.nzval = P.Ar[x.nzind]" needs (src/twostage.jl:166).  It was three launches: the support going up, k_select, k_gather.
+__global__ __launch_bounds__(256) void k_ompr_pick(const double* __restrict__ pval, const int* __restrict__ pidx, int nblk,
+                                                   const double* __restrict__ cvec, DevState* st, const int64_t* __restrict__ sorted_idx,
+                                                   int k, double* __restrict__ cs) {
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    const int tid = threadIdx.x;
+    double bv = -1.0;
+    int bi = 0x7fffffff;
+    for (int q = tid; q < nblk; q += 256)
+        if (better(pval[q], pidx[q], bv, bi)) {
+            bv = pval[q];
+            bi = pidx[q];
+        }
+    block_argmax(bv, bi, sv, si);
+    for (int t = tid; t < k; t += 256) cs[t] = cvec[sorted_idx[t]];
+    if (tid == 0) {
+        st->cand = bi;
+        st->cval = cvec[bi];
+        st->j = st->nsel;
+        st->go = 1;
+    }
+}
+// ... and after it: the atom that leaves -> its insertion position (k_find_pos), the atom that joins -> the append's candidate list
+__global__ __launch_bounds__(256) void k_swap_prep(const int* __restrict__ sel, const DevState* st, int leaving, int joining,
+                                                   int* __restrict__ delpos, int* __restrict__ cands, int* __restrict__ ncands) {
+    __shared__ int pos;
+    if (threadIdx.x == 0) pos = -1;
+    __syncthreads();
+    for (int t = threadIdx.x; t < st->nsel; t += 256)
+        if (sel[t] == leaving) pos = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *delpos = pos;
+        cands[0] = joining;
+        *ncands = 1;
+    }
 }
 
 // Removal, step 1 (one workgroup of 1024 threads; thread c <-> the CPT consecutive columns c CPT .. c CPT + CPT - 1, CPT = 1 up to
@@ -312,55 +367,83 @@ __global__ __launch_bounds__(1024) void k_tdel_prep(const double* __restrict__ T
 }
 
 // Removal, step 2: every row of Q and of T, every column of R, and z take the rotations -- one thread
-// per vector, kQPre elements requested ahead.  Workgroups (64 threads): [0, GQ) rows of Q (in place;
+// per vector, a ring of blocks requested ahead (rot_chain).  Workgroups (64 threads): [0, GQ) rows of Q (in place;
 // also q_drop, the pre-rotation last column, and r += zeta q_drop); then NB blocks of T rows (into
-// T2, row p dropped); NB blocks of R columns (into R2, column p dropped); one block for z.  With
-// meta[0] < 0 nothing is removed and T2 / R2 receive copies.
+// T2, row p dropped: the part from column p on); NB blocks of R columns (into R2, column p dropped; skipR: not at all); one
+// block for z; then kcap / 4 copy blocks (T's columns left of p, unchanged).  With meta[0] < 0 nothing is removed and T2 / R2
+// receive copies.
+// ld(i) is a PLAIN load from a clamped address -- no branch around it and no select on its value (either one makes the compiler wait
+// for the load on the spot, and the chain then pays a memory latency per element instead of one per block of kQPre).  Elements past
+// `last` + 1 may therefore be anything, NaN included: they meet the identity rotation, their outputs are not stored and the carry
+// is not advanced past `last`.
 template <typename LD, typename ST>
 __device__ __forceinline__ double rot_chain(int p, int last, const double* __restrict__ G, LD ld, ST stv) {
-    // (the rotations (c_i, s_i) are requested a block ahead like the data: a load of them inside the dependent chain -- the same
-    // address in every lane, but a trip to the L2 all the same -- was what a step cost)
+    // A ring of kRotBuf blocks of kRotBlk elements: a block is consumed, then refilled at once with the block kRotBuf ahead, so
+    // 2-3 blocks of loads are in flight all the time (one pre-fetched block drained once per block: a memory latency per 32
+    // elements was most of the chain).  The rotations (c_i, s_i) -- the same address in every lane -- travel with the data.
+    constexpr int RB = kRotBlk, NBUF = kRotBuf;
     double carry = ld(p);
-    double pre[kQPre], nxt[kQPre];
-    f64x2 gpre[kQPre], gnxt[kQPre];
+    double x[NBUF][RB];
+    f64x2 g[NBUF][RB];
     const f64x2* G2 = reinterpret_cast<const f64x2*>(G);
+    const int glast = last > p ? last : p;
+    auto fill = [&](double(&xb)[RB], f64x2(&gb)[RB], int base) {  // elements base+1 .. base+RB, rotations base .. base+RB-1
 #pragma unroll
-    for (int u = 0; u < kQPre; ++u) {
-        pre[u] = ld(p + 1 + u);
-        gpre[u] = (p + u <= last) ? G2[p + u] : f64x2{1.0, 0.0};
-    }
-    for (int ib = p; ib <= last; ib += kQPre) {
-#pragma unroll
-        for (int u = 0; u < kQPre; ++u) {
-            nxt[u] = ld(ib + kQPre + 1 + u);
-            gnxt[u] = (ib + kQPre + u <= last) ? G2[ib + kQPre + u] : f64x2{1.0, 0.0};
+        for (int u = 0; u < RB; ++u) {
+            xb[u] = ld(base + 1 + u);
+            const f64x2 gv = G2[base + u <= glast ? base + u : glast];
+            gb[u] = (base + u <= last) ? gv : f64x2{1.0, 0.0};
         }
+    };
+    auto eat_full = [&](const double(&xb)[RB], const f64x2(&gb)[RB], int base) {  // a whole block: no test per element
 #pragma unroll
-        for (int u = 0; u < kQPre; ++u) {
-            const int i = ib + u;
-            if (i <= last) {
-                const double cs = gpre[u].x, sn = gpre[u].y, x = pre[u];
-                stv(i, fma(cs, carry, sn * x));
-                carry = fma(cs, x, -sn * carry);
+        for (int u = 0; u < RB; ++u) {
+            const double cs = gb[u].x, sn = gb[u].y, xv = xb[u];
+            stv(base + u, fma(cs, carry, sn * xv));
+            carry = fma(-sn, carry, cs * xv);  // (cs * x is off the chain: ONE dependent fma per rotation)
+        }
+    };
+    auto eat_part = [&](const double(&xb)[RB], const f64x2(&gb)[RB], int base) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const double cs = gb[u].x, sn = gb[u].y, xv = xb[u];
+            const double out = fma(cs, carry, sn * xv);
+            if (base + u <= last) {
+                stv(base + u, out);
+                carry = fma(-sn, carry, cs * xv);
             }
         }
+    };
 #pragma unroll
-        for (int u = 0; u < kQPre; ++u) {
-            pre[u] = nxt[u];
-            gpre[u] = gnxt[u];
+    for (int d = 0; d < NBUF; ++d) fill(x[d], g[d], p + d * RB);
+    int ib = p;
+    // whole rounds of the ring: nothing conditional between a block's loads and their use, so the compiler waits for that block's
+    // loads only (a load under a branch costs a wait for everything in flight)
+    for (; ib + NBUF * RB - 1 <= last; ib += NBUF * RB) {
+#pragma unroll
+        for (int d = 0; d < NBUF; ++d) {
+            eat_full(x[d], g[d], ib + d * RB);
+            fill(x[d], g[d], ib + d * RB + NBUF * RB);
         }
     }
+#pragma unroll
+    for (int d = 0; d < NBUF; ++d)  // the last, partial round (the ring is aligned at block 0 again)
+        if (ib + d * RB <= last) eat_part(x[d], g[d], ib + d * RB);
     return carry;
 }
 
+template <int PART = 0>  // 0: everything; 1 / 2 / 3: the Q / T / R-and-z blocks only (a diagnostic split: one row each in a kernel trace)
 __global__ __launch_bounds__(64) void k_tdel_apply(double* __restrict__ Q, int64_t ldq, int GQ, const double* __restrict__ T,
                                                    double* __restrict__ T2, const double* __restrict__ R,
                                                    double* __restrict__ R2, int kcap, int NB, double* __restrict__ z,
                                                    const double* __restrict__ G, const double* __restrict__ scal,
                                                    const int* __restrict__ meta, double* __restrict__ r,
-                                                   double* __restrict__ qdrop, double* __restrict__ qsave) {
+                                                   double* __restrict__ qdrop, double* __restrict__ qsave, int skipR) {
     const int p = meta[0], n = meta[1];
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (skipR && b >= GQ + NB && b < GQ + 2 * NB) return;  // (the two-stage solvers never read R's old columns: see launch_delete_t)
+    if (PART != 0 && (PART == 1) != (b < GQ)) return;
+    if (PART != 0 && b >= GQ && (PART == 2) != (b < GQ + NB || b > GQ + 2 * NB)) return;
     if (b < GQ) {  // rows of Q
         const int64_t row = (int64_t)b * 64 + lane;
         if (p < 0) {
@@ -370,7 +453,7 @@ __global__ __launch_bounds__(64) void k_tdel_apply(double* __restrict__ Q, int64
         double* q = Q + row;
         qsave[row] = q[(int64_t)(n - 1) * ldq];
         const double carry = rot_chain(
-            p, n - 2, G, [&](int i) { return i <= n - 1 ? q[(int64_t)i * ldq] : 0.0; },
+            p, n - 2, G, [&](int i) { return q[(int64_t)(i < kcap ? i : kcap - 1) * ldq]; },
             [&](int i, double v) { q[(int64_t)i * ldq] = v; });
         q[(int64_t)(n - 1) * ldq] = 0.0;
         qdrop[row] = carry;
@@ -385,9 +468,8 @@ __global__ __launch_bounds__(64) void k_tdel_apply(double* __restrict__ Q, int64
         }
         if (t >= n || t == p) return;
         const int tn = t - (t > p ? 1 : 0);
-        for (int i = t; i < p; ++i) T2[(int64_t)i * kcap + tn] = T[(int64_t)i * kcap + t];  // columns left of p (t < p only)
         rot_chain(
-            p, n - 2, G, [&](int i) { return (i >= t && i <= n - 1) ? T[(int64_t)i * kcap + t] : 0.0; },
+            p, n - 2, G, [&](int i) { return T[(int64_t)(i < kcap ? i : kcap - 1) * kcap + t]; },  // (entries i < t: the zero lower triangle, tinv_ensure)
             [&](int i, double v) {
                 if (i >= tn) T2[(int64_t)i * kcap + tn] = v;
             });
@@ -409,12 +491,38 @@ __global__ __launch_bounds__(64) void k_tdel_apply(double* __restrict__ Q, int64
         double* dst = R2 + (int64_t)(c - 1) * kcap;
         for (int i = 0; i < p; ++i) dst[i] = src[i];
         rot_chain(
-            p, c - 1, G, [&](int i) { return i <= c ? src[i] : 0.0; }, [&](int i, double v) { dst[i] = v; });
+            p, c - 1, G, [&](int i) { return i <= c ? src[i] : 0.0; }, [&](int i, double v) { dst[i] = v; });  // (the functor's path only: conditional loads)
+        return;
+    }
+    if (b > GQ + 2 * NB) {
+        // copy blocks: the columns left of p keep their entries (rows <= column < p, unchanged position) -- four columns per block,
+        // rows along the lanes, all loads of a block of rows requested together (walking them one row per lane inside the T blocks
+        // was as long as the rotation chain itself)
+        if (p <= 0) return;
+        const int c0 = (b - GQ - 2 * NB - 1) * 4;
+        if (c0 >= p) return;
+        for (int r0 = 0; r0 < p; r0 += 4 * 64) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int i = c0 + u, rr = r0 + w * 64 + lane;
+                    v[u][w] = T[(int64_t)(i < kcap ? i : kcap - 1) * kcap + (rr < kcap ? rr : kcap - 1)];
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int i = c0 + u, rr = r0 + w * 64 + lane;
+                    if (i < p && rr <= i) T2[(int64_t)i * kcap + rr] = v[u][w];
+                }
+        }
         return;
     }
     if (lane == 0 && p >= 0) {  // z
         rot_chain(
-            p, n - 2, G, [&](int i) { return i <= n - 1 ? z[i] : 0.0; }, [&](int i, double v) { z[i] = v; });
+            p, n - 2, G, [&](int i) { return z[i < kcap ? i : kcap - 1]; }, [&](int i, double v) { z[i] = v; });
         z[n - 1] = 0.0;
     }
 }

@@ -302,7 +302,8 @@ extern "C" int csmp_omp_batch_mfma(csmp_ctx* ctx, const void* B, int b_dtype, in
         HIPCHECK(hipMemGetInfo(&free_b, &total_b));
         const size_t held = (size_t)b.Bcap * batch_bytes_per_signal(ctx, b.kcap);
         const size_t margin = (size_t)2 << 30;  // (the operand images, temporaries of the re-solves)
-        const size_t budget = free_b + held > margin ? free_b + held - margin : 0;
+        size_t budget = free_b + held > margin ? free_b + held - margin : 0;
+        if (ctx->tune_batch_budget_mib > 0) budget = std::min(budget, (size_t)ctx->tune_batch_budget_mib << 20);  // (csmp_tune: a test's stand-in for a full device)
         const size_t per = batch_bytes_per_signal(ctx, std::max(kc, b.kcap));
         if ((size_t)std::max<int64_t>(Bpad, b.Bcap) * per > budget) {
             HIPCHECK(hipStreamSynchronize(ctx->stream));

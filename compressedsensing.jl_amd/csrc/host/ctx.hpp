@@ -178,7 +178,9 @@ struct csmp_ctx {
     bool sweep_ph = false;  // the residual is staged in phases of sweep_KP rows (it exceeds the LDS)
     int sweep_KP = 0;       // rows of the residual image in the LDS
     int tick_grid = 0;      // sweep workgroups inside the tick kernel
-    int tune_sweep_grid = 0, tune_sweep_U = 0;  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic
+    int tune_sweep_grid = 0, tune_sweep_U = 0;
+    int tune_diag_split = 0;  // csmp_tune: fused kernels run as one launch per part (a kernel trace then shows the parts)
+    int64_t tune_batch_budget_mib = 0;  // csmp_tune: HBM the batched path's per-signal state may take (MiB), 0 = what is free  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic
     // options (csmp_set_option, include/csmp.h)
     void* comm = nullptr;          // ncclComm_t of the signal-sharded solve (csmp_comm_init, host/rccl.hpp); this rank and the group's size
     int comm_rank = 0, comm_world = 1;

@@ -141,6 +141,20 @@ static int dict_forget(csmp_ctx* ctx) {
     return CSMP_OK;
 }
 
+// A call that fails after the previous dictionary has been let go leaves the context with NO dictionary (dA == NULL, M = N = 0) --
+// never with the new dimensions over nothing: the entry points that test dA then say "no dictionary set".
+static int dict_failed(csmp_ctx* ctx, int rc) {
+    if (rc != CSMP_OK) {
+        const std::string keep = ctx->err;
+        (void)hipGetLastError();
+        dict_release(ctx);
+        ctx->M = ctx->N = ctx->ld = 0;
+        ctx->Mv = 0;
+        ctx->err = keep;
+    }
+    return rc;
+}
+static int set_dictionary_impl(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc);
 extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!A || M < 1 || N < 1 || ldA < M) return fail(ctx, CSMP_EDIM, "set_dictionary: need A != NULL, M,N >= 1, ldA >= M");
@@ -148,6 +162,9 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
     if (M > (int64_t)1 << 30 || N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary: M or N too large");
     if (loc != CSMP_HOST && loc != CSMP_DEVICE && loc != CSMP_HOST_STREAMED)
         return fail(ctx, CSMP_EINVAL, "set_dictionary: loc must be CSMP_HOST, CSMP_DEVICE or CSMP_HOST_STREAMED");
+    return dict_failed(ctx, set_dictionary_impl(ctx, A, M, N, ldA, dtype, loc));
+}
+static int set_dictionary_impl(csmp_ctx* ctx, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc) {
     CHECK(dict_forget(ctx));
     const size_t es = dtype == CSMP_F32 ? 4 : 8;
     const int vec = 16 / (int)es;
@@ -166,7 +183,8 @@ extern "C" int csmp_set_dictionary(csmp_ctx* ctx, const void* A, int64_t M, int6
         int kind = 2;
         int64_t ld = ldA;
         if (aligned) {
-            const hipError_t e = hipHostRegister(hostp, (size_t)ldA * (size_t)N * es, hipHostRegisterMapped | hipHostRegisterPortable);
+            // (a column-major view with ldA > M owns ldA (N - 1) + M elements, not ldA N: registering more could run past the allocation)
+            const hipError_t e = hipHostRegister(hostp, ((size_t)ldA * (size_t)(N - 1) + (size_t)M) * es, hipHostRegisterMapped | hipHostRegisterPortable);
             if (e == hipErrorHostMemoryAlreadyRegistered) {
                 (void)hipGetLastError();
                 kind = -1;  // (page-locked by the caller already -- hipHostMalloc, or registered: nothing to undo later)
@@ -280,6 +298,7 @@ extern "C" int csmp_dictionary_file_info(const char* path, int64_t* M, int64_t* 
     return CSMP_OK;
 }
 
+static int set_dictionary_file_impl(csmp_ctx* ctx, FILE* f, const DictFileHeader& h, int loc);
 extern "C" int csmp_set_dictionary_file(csmp_ctx* ctx, const char* path, int loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!path) return fail(ctx, CSMP_EINVAL, "set_dictionary_file: path == NULL");
@@ -293,6 +312,9 @@ extern "C" int csmp_set_dictionary_file(csmp_ctx* ctx, const char* path, int loc
         ~Closer() { if (f) fclose(f); }
     } closer{f};
     if (h.M > (int64_t)1 << 30 || h.N > (int64_t)1 << 31) return fail(ctx, CSMP_ERANGE, "set_dictionary_file: M or N too large");
+    return dict_failed(ctx, set_dictionary_file_impl(ctx, f, h, loc));  // (a short file, no memory: the context ends with no dictionary)
+}
+static int set_dictionary_file_impl(csmp_ctx* ctx, FILE* f, const DictFileHeader& h, int loc) {
     const size_t es = h.dtype == (uint32_t)CSMP_F32 ? 4 : 8;
     const size_t total = (size_t)h.ld * (size_t)h.N * es;
     CHECK(dict_forget(ctx));

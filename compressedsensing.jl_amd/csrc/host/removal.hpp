@@ -46,6 +46,10 @@ static int tinv_ensure(csmp_ctx* ctx) {
     const size_t nch = (size_t)(s.kcap + kTChunk - 1) / kTChunk;
     CHECK(dmalloc(ctx, &s.T, (size_t)s.kcap * s.kcap));
     CHECK(dmalloc(ctx, &s.T2, (size_t)s.kcap * s.kcap));
+    // the strictly lower triangles stay ZERO for the life of the buffers (every writer writes entries on and above the diagonal
+    // only): the removal's rotation chains read whole rows without a bounds test (k_tdel_apply)
+    HIPCHECK(hipMemsetAsync(s.T, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
+    HIPCHECK(hipMemsetAsync(s.T2, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
     CHECK(dmalloc(ctx, &s.tpd, nch * s.kcap));
     CHECK(dmalloc(ctx, &s.tpn, nch * s.kcap));
     CHECK(dmalloc(ctx, &s.tmeta, 2));
@@ -84,8 +88,11 @@ static int launch_tinv_mv(csmp_ctx* ctx, int mode) {
 static int launch_tinv_append(csmp_ctx* ctx) { return launch_tinv_mv(ctx, 1); }
 // x = T z (insertion order, s.bwd_coef) and the backward scores x^2 / gamma (s.bwd)
 static int launch_tinv_solve(csmp_ctx* ctx) { return launch_tinv_mv(ctx, 0); }
-// remove_column!(AiQR, *delpos) with the rotations taken from T
-static int launch_delete_t(csmp_ctx* ctx) {
+// remove_column!(AiQR, *delpos) with the rotations taken from T.  keep_R == false (the two-stage solvers ompr / srr / rmp / foba / br,
+// which take every coefficient from T z): R is NOT down-dated -- nothing of theirs reads an old column of R again (an append
+// writes the new column and k_tinv_fin reads only that one), and walking 64 columns of R per workgroup with one column per lane
+// was a third of the kernel.  The step-level csmp_solver_remove keeps R: its functor goes on with plain appends and back-solves.
+static int launch_delete_t(csmp_ctx* ctx, bool keep_R = false) {
     Solver& s = ctx->s;
     if (s.kcap <= 1023) {
         const int threads = std::min(1024, ((s.kcap + 1 + 63) / 64) * 64);
@@ -97,31 +104,37 @@ static int launch_delete_t(csmp_ctx* ctx) {
     }
     HIPCHECK(hipGetLastError());
     const int NB = (s.kcap + 63) / 64;
-    hipLaunchKernelGGL(k_tdel_apply, dim3(s.G + 2 * NB + 1), dim3(64), 0, ctx->stream, s.Q, s.ldq, s.G, (const double*)s.T, s.T2,
-                       (const double*)s.R, s.R2, s.kcap, NB, s.z, (const double*)s.Gdel, (const double*)s.scal,
-                       (const int*)s.delmeta, s.r, s.qdrop, s.qsave);
+#define TDEL_APPLY(PART)                                                                                                          \
+    hipLaunchKernelGGL(k_tdel_apply<PART>, dim3(s.G + 2 * NB + 1 + (s.kcap + 3) / 4), dim3(64), 0, ctx->stream, s.Q, s.ldq, s.G, (const double*)s.T, s.T2, \
+                       (const double*)s.R, s.R2, s.kcap, NB, s.z, (const double*)s.Gdel, (const double*)s.scal,                   \
+                       (const int*)s.delmeta, s.r, s.qdrop, s.qsave, keep_R ? 0 : 1)
+    if (ctx->tune_diag_split) {
+        TDEL_APPLY(1);
+        TDEL_APPLY(2);
+        TDEL_APPLY(3);
+    } else {
+        TDEL_APPLY(0);
+    }
+#undef TDEL_APPLY
     HIPCHECK(hipGetLastError());
     std::swap(s.T, s.T2);
-    std::swap(s.R, s.R2);
+    if (keep_R) std::swap(s.R, s.R2);
     return CSMP_OK;
 }
-static int launch_delete_atom_t(csmp_ctx* ctx, int atom) {
+static int launch_delete_atom_t(csmp_ctx* ctx, int atom, bool keep_R = false) {
     Solver& s = ctx->s;
     hipLaunchKernelGGL(k_find_pos, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, atom, s.delpos);
     HIPCHECK(hipGetLastError());
-    return launch_delete_t(ctx);
+    return launch_delete_t(ctx, keep_R);
 }
 // fetch_sorted in explicit-inverse mode: coefficients from T z, emitted in index order
 // (resnorm != NULL: the residual norm travels in the same synchronisation)
 static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<double>& val, double* resnorm = nullptr) {
     Solver& s = ctx->s;
-    if (resnorm) {
-        hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal + 1);
-        HIPCHECK(hipGetLastError());
-    }
     CHECK(launch_tinv_solve(ctx));
     hipLaunchKernelGGL(k_emit_sorted, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd_coef, (const int*)s.sel,
-                       (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap);
+                       (const DevState*)s.st, s.out_idx, s.out_val, s.out_nnz, s.out_order, s.outcap,
+                       resnorm ? (const double*)s.r : (const double*)nullptr, (int)ctx->M, s.scal + 1);  // (||r||^2 in the same launch)
     HIPCHECK(hipGetLastError());
     idx.assign((size_t)s.outcap, 0);
     val.assign((size_t)s.outcap, 0.0);
@@ -158,7 +171,7 @@ extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
             return fail(ctx, CSMP_ERANGE, "solver_remove: column removal supports a capacity of at most 4095 columns");
         CHECK(tinv_ensure(ctx));
         CHECK(launch_tinv_build(ctx));
-        return launch_delete_atom_t(ctx, (int)atom);
+        return launch_delete_atom_t(ctx, (int)atom, /*keep_R*/ true);
     }
     CHECK(del_ensure(ctx));
     return launch_delete_atom(ctx, (int)atom);

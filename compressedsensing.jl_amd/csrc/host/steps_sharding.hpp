@@ -79,6 +79,9 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->opt_batch_window = src->opt_batch_window;
     dst->opt_batch_screen = src->opt_batch_screen;
     dst->opt_screened = src->opt_screened;
+    dst->tune_sweep_grid = src->tune_sweep_grid;  // (measurement overrides, csmp_tune: the twins of the batch drivers sweep like their parent)
+    dst->tune_sweep_U = src->tune_sweep_U;
+    dst->tick_nblk = src->tick_nblk;
 }
 extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     if (!src || !out) return CSMP_EINVAL;

@@ -80,19 +80,20 @@ struct OmprJob {
         DevState hs;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool scr = screened && attempt == 0;
-            {  // the support goes up through a kernel that reads the page-locked staging buffer (no staged copy from pageable memory)
-                void* pcv = nullptr;
-                CHECK(pin_get(ctx, 2, cur.size() * 4 + 16, &pcv));
-                memcpy(pcv, cur.data(), cur.size() * 4);
-                hipLaunchKernelGGL(k_put_ints, dim3(((int)cur.size() + 255) / 256), dim3(256), 0, ctx->stream, (const int*)pcv, (int)cur.size(), s.cands);
-                HIPCHECK(hipGetLastError());
-            }
             if (scr) {
+                {  // the support goes up through a kernel that reads the page-locked staging buffer (no staged copy from pageable memory)
+                    void* pcv = nullptr;
+                    CHECK(pin_get(ctx, 2, cur.size() * 4 + 16, &pcv));
+                    memcpy(pcv, cur.data(), cur.size() * 4);
+                    hipLaunchKernelGGL(k_put_ints, dim3(((int)cur.size() + 255) / 256), dim3(256), 0, ctx->stream, (const int*)pcv, (int)cur.size(), s.cands);
+                    HIPCHECK(hipGetLastError());
+                }
                 CHECK(ompr_sweep_screened(ctx, s.cands, (int)k));
             } else {
+                // (the sorted support is on the device already: the index list the last k_emit_sorted wrote)
                 CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
-                CHECK(launch_select(ctx, 0, 0));
-                hipLaunchKernelGGL(k_gather, dim3(((int)k + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.cvec, (const int*)s.cands, (int)k, s.coef);
+                hipLaunchKernelGGL(k_ompr_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid,
+                                   (const double*)s.cvec, s.st, (const int64_t*)s.out_idx, (int)k, s.coef);
                 HIPCHECK(hipGetLastError());
             }
             {
@@ -145,13 +146,14 @@ struct OmprJob {
                 const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
                 if (use_downdate) {
                     // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
-                    if (tmode)
-                        CHECK(launch_delete_atom_t(ctx, leaving));
-                    else
-                        CHECK(launch_delete_atom(ctx, leaving));
-                    const int one = 1, ci = (int)cand;
-                    hipLaunchKernelGGL(k_set_pair, dim3(1), dim3(64), 0, ctx->stream, s.cands, (int)ci, s.ncands, (int)one);
+                    // (one launch names both atoms: the one that leaves -> its position, the one that joins -> the append's list)
+                    hipLaunchKernelGGL(k_swap_prep, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, leaving, (int)cand,
+                                       s.delpos, s.cands, s.ncands);
                     HIPCHECK(hipGetLastError());
+                    if (tmode)
+                        CHECK(launch_delete_t(ctx));
+                    else
+                        CHECK(launch_delete(ctx));
                     CHECK(launch_append(ctx, 2, 0, 0));
                     if (tmode) CHECK(launch_tinv_append(ctx));
                 } else {
