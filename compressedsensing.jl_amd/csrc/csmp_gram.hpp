@@ -75,7 +75,8 @@ constexpr int kGramWgJ = 64;   // G columns per workgroup
 // one wave per SIMD cannot issue Float64 MFMAs back to back (measured: 35 TFLOP/s with one, 47 with two waves per SIMD).
 template <typename TA>
 __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const TA* __restrict__ Ac, int64_t ldo, int np,
-                                                                         int rows_per_split, double* __restrict__ Gpart, int jtile0 = 0) {
+                                                                         int rows_per_split, double* __restrict__ Gpart, int jtile0 = 0,
+                                                                         int jtile1 = 1 << 30) {
     constexpr int RPL = kGramRpl, BLK = 4 * RPL;
     struct alignas(sizeof(TA) * RPL) Frag { TA v[RPL]; };
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
@@ -83,6 +84,8 @@ __global__ __launch_bounds__(256, (sizeof(TA) == 4 ? 3 : 2)) void k_gram(const T
     const int I = blockIdx.y, J = blockIdx.x, ks = blockIdx.z;
     if (I * kGramWgI > J * kGramWgJ + kGramWgJ - 1) return;  // entirely below the diagonal
     if (J < jtile0) return;  // (bordered extension: only the new columns' tiles are needed, k_ext_reduce)
+    if (J >= jtile1) return;  // (column tiles that hold nothing but the bordered column and padding: the reduce kernels take that column
+                              // from the gather pass's sums -- at n = 512, np = 576 they were 5 of the 25 pieces)
     const int k0 = ks * rows_per_split, k1 = (int)min((int64_t)ldo, (int64_t)k0 + rows_per_split);
     const int i0 = I * kGramWgI + wi * 64, j0 = J * kGramWgJ + wj * 32;
     const TA *ci[4], *cj[2];

@@ -364,11 +364,12 @@ static inline void mark_put(csmp_ctx* ctx, int atom, int pos) {
 }
 static inline int mark_get(const csmp_ctx* ctx, int atom) { return ctx->s.hstamp[(size_t)atom] == ctx->s.hgen ? ctx->s.hpos[(size_t)atom] : -1; }
 
-static int gram_split_for(const csmp_ctx* ctx, int np, int jtile0 = 0) {
+static int gram_split_for(const csmp_ctx* ctx, int np, int jtile0 = 0, int ncols = -1) {
     // pieces of k_gram on or above the diagonal (from column tile jtile0 on: the bordered extension computes the new columns'
     // tiles only); the rows are split so that ONE round of workgroups (two per CU) covers them: a second, partly filled round
     // would cost as much as a full one
-    const int TJ = np / kGramWgJ;
+    int TJ = np / kGramWgJ;
+    if (ncols >= 0) TJ = std::min(TJ, (ncols + kGramWgJ - 1) / kGramWgJ);  // (tiles past the set's own columns are not computed: k_gram's jtile1)
     int pieces = 0;
     for (int J = jtile0; J < TJ; ++J) pieces += (J * kGramWgJ + kGramWgJ - 1) / kGramWgI + 1;
     const int slots = (ctx->dtype == CSMP_F32 ? 3 : 2) * ctx->prop.multiProcessorCount;  // k_gram's workgroups per CU
@@ -422,7 +423,7 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int np2 = ((nN + 1 + kGramTile - 1) / kGramTile) * kGramTile;
     const int ldw = ((nF + 15) / 16) * 16;
-    const int nsplit = std::min(gram_split_for(ctx, np, nF / kGramWgJ), s.gram_split);  // (the new columns' tiles fill the round)
+    const int nsplit = std::min(gram_split_for(ctx, np, nF / kGramWgJ, n), s.gram_split);  // (the new columns' tiles fill the round)
     // (gram_ensure has run: the caller checked the buffers' sizes before it decided for this path)
     CHECK(solver_restart(ctx));  // r = b, control block reset; R, z, sel of F stay where they are
     void* pcv = nullptr;
@@ -440,7 +441,7 @@ static int ls_gram_extend_t(csmp_ctx* ctx, const std::vector<int>& order, int nF
     hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)nchunk, np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
                        (const int*)s.cands, n, (TA*)s.Acomp, ldo, (const double*)s.b, np, s.rhs_part);
     hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
-                       rps, s.Gpart, nF / kGramWgJ);
+                       rps, s.Gpart, nF / kGramWgJ, (n + kGramWgJ - 1) / kGramWgJ);
     HIPCHECK(hipGetLastError());
     const int64_t nel = std::max<int64_t>((int64_t)np * np, (int64_t)ldw * np2);
     hipLaunchKernelGGL(k_ext_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, nF, n, np,
@@ -524,14 +525,14 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
     Solver& s = ctx->s;
     const int n = (int)cols.size(), M = (int)ctx->M;
     const int np = ((n + 1 + kGramTile - 1) / kGramTile) * kGramTile;
-    const int nsplit = gram_split_for(ctx, np);
+    const int nsplit = gram_split_for(ctx, np, 0, n);
     // A set that k further columns may extend (Subspace Pursuit: the k atoms of the support before an acquisition) is factorised
     // AUGMENTED by the unit vectors (csmp_gram.hpp, k_gram_reduce): (R^-1)' comes out beside R, for free on this chain.
     const bool aug = n >= 64 && 2 * n <= s.kcap;
     const int npa = aug ? ((np + n + kGramTile - 1) / kGramTile) * kGramTile : np;
     // (a set that may be an extension of the slot's factor splits its rows finer: fewer tiles to spread over the same round)
     const int nsplit_ext = (s.fac_valid && s.fac_cols.size() >= 64 && (int)s.fac_cols.size() < n)
-                               ? gram_split_for(ctx, np, (int)s.fac_cols.size() / kGramWgJ) : nsplit;
+                               ? gram_split_for(ctx, np, (int)s.fac_cols.size() / kGramWgJ, n) : nsplit;
     CHECK(gram_ensure(ctx, npa, std::max(nsplit, nsplit_ext)));  // (a reallocation drops fac_valid and keep_valid)
     const bool can_extend = s.fac_valid;
     s.fac_valid = false;  // whatever happens below rewrites the slot; the caller confirms the new factor once it has seen it succeed
@@ -597,7 +598,7 @@ static int ls_gram_t(csmp_ctx* ctx, const std::vector<int>& cols) {
         hipLaunchKernelGGL(k_gather_cols<TA>, dim3((unsigned)nchunk, np), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M,
                            (const int*)s.cands, n, (TA*)s.Acomp, ldo, (const double*)s.b, np, s.rhs_part);
         hipLaunchKernelGGL(k_gram<TA>, dim3(np / kGramWgJ, (np + kGramWgI - 1) / kGramWgI, nsplit), dim3(256), 0, ctx->stream, (const TA*)s.Acomp, ldo, np,
-                           rps, s.Gpart);
+                           rps, s.Gpart, 0, (n + kGramWgJ - 1) / kGramWgJ);
         HIPCHECK(hipGetLastError());
         const int64_t nel = (int64_t)np * np + (int64_t)(npa - np) * npa;
         hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((nel + 255) / 256)), dim3(256), 0, ctx->stream, (const double*)s.Gpart, nsplit, n, np,
