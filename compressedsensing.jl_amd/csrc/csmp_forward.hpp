@@ -333,6 +333,76 @@ __global__ __launch_bounds__(256) void k_fr_rebuild(const TA* __restrict__ A, in
     }
 }
 
+// ---- dictionaries whose columns do not fit the LDS images of k_fr_sweep (8 (1 + NQ) M bytes: M beyond ~10 000 with one direction,
+// ~6 800 with two): the same pass as separate launches -- c = A'r and g = A'q by the product sweep (k_sweep_gen: any M, the
+// residual staged in phases), |a_j|^2 by k_fr_colnorm2 on a solve's first step, then k_fr_combine does what the fused kernel does
+// per column: the rho2 correction, the score, the marks, the arg-max partials.  Two or three passes over the dictionary instead
+// of one: the price of a shape the reference serves (src/forward.jl:99-114 forms Q'A whatever size(A) is) and the fused kernel cannot.
+template <typename TA>
+__global__ __launch_bounds__(256) void k_fr_colnorm2(const TA* __restrict__ A, int64_t ld, int M, int64_t N, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t col = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= N) return;
+    const TA* a = A + col * ld;
+    double acc = 0.0;
+    for (int m = lane; m < M; m += 64) {
+        const double v = (double)a[m];
+        acc = fma(v, v, acc);
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+    if (lane == 0) out[col] = acc;
+}
+// the Q column appended last -> a vector of its own (a sweep takes it as its "residual"); zeros while the support is empty
+__global__ __launch_bounds__(256) void k_fr_lastq(const double* __restrict__ Q, int64_t ldq, const DevState* st, int Mpad, int M,
+                                                  double* __restrict__ out) {
+    const int nsel = st->nsel;
+    for (int m = blockIdx.x * 256 + threadIdx.x; m < Mpad; m += gridDim.x * 256)
+        out[m] = (nsel > 0 && m < M) ? Q[(int64_t)(nsel - 1) * ldq + m] : 0.0;
+}
+// per column what fr_sweep_body does after its reduction (same NQ meanings); c, g1, g2: the sweeps' outputs (g1 = |a_j|^2 for NQ = -1)
+template <int NQ>
+__global__ __launch_bounds__(256) void k_fr_combine(int64_t N, const double* __restrict__ c, const double* __restrict__ g1, double s1,
+                                                    const double* __restrict__ g2, double s2, const int* __restrict__ unmark, int update_only,
+                                                    double* __restrict__ rho2, double* __restrict__ dvec, double* __restrict__ pval,
+                                                    int* __restrict__ pidx, const int* __restrict__ sel, DevState* st, double max_eps, int skipmask) {
+    __shared__ double sv[256];
+    __shared__ int si[256];
+    if (st->done & skipmask) return;
+    constexpr bool FIRST = NQ < 0;
+    const int tid = threadIdx.x;
+    if (!update_only && !(sqrt(st->rnorm2) > max_eps)) {  // normr > max_eps || return false   (src/forward.jl:60-61)
+        __syncthreads();  // (every thread has read the flag word above before one of them changes it)
+        if (blockIdx.x == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const int nsel = st->nsel;
+    const int lastsel = (!FIRST && nsel > 0) ? sel[nsel - 1] : -1;
+    const int unsel = (NQ >= 1 && unmark) ? *unmark : -1;
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + tid; j < N; j += (int64_t)gridDim.x * 256) {
+        double rho = FIRST ? g1[j] : rho2[j];
+        if constexpr (NQ >= 1) rho = fma(s1 * g1[j], g1[j], rho);
+        if constexpr (NQ == 2) rho = fma(s2 * g2[j], g2[j], rho);
+        if ((int)j == lastsel) rho = __builtin_inf();
+        if constexpr (NQ >= 1)
+            if ((int)j == unsel) rho = NQ == 2 ? g2[j] * g2[j] : g1[j] * g1[j];
+        const double d2 = c[j] * c[j] / rho;
+        if constexpr (NQ != 0) rho2[j] = rho;
+        else if ((int)j == lastsel) rho2[j] = rho;
+        if (!update_only) dvec[j] = d2;
+        if (d2 > bestv) {  // (ascending j per thread: '>' keeps the first maximum)
+            bestv = d2;
+            besti = (int)j;
+        }
+    }
+    block_argmax(bestv, besti, sv, si);
+    if (tid == 0) {
+        pval[blockIdx.x] = bestv;
+        pidx[blockIdx.x] = besti;
+    }
+}
+
 // rho2 = +Inf for every atom of the support (bulk form of the per-step marking in k_fr_sweep)
 __global__ __launch_bounds__(256) void k_mark_inf(double* __restrict__ rho2, const int* __restrict__ sel, const DevState* st) {
     for (int t = threadIdx.x; t < st->nsel; t += 256) rho2[sel[t]] = __builtin_inf();

@@ -44,6 +44,7 @@ struct Solver {
     int* sigflags = nullptr;  // per-signal stop flags of a batch (optimistic-chain verification)
     double *rho2 = nullptr, *dvec = nullptr;  // forward regression: OLS rescaling and δ² scores (N each), allocated on first use
     int fr_grid = 0;
+    double *frg1 = nullptr, *frg2 = nullptr, *frq = nullptr;  // tall dictionaries (launch_fr_pass_tall): g = A'q per direction, the last Q column
     // column removal (csmp_downdate.hpp), allocated on first use
     double *R2 = nullptr, *Gdel = nullptr, *qdrop = nullptr, *qsave = nullptr, *bwd = nullptr, *bwd_coef = nullptr, *bwd_info = nullptr;
     int *delmeta = nullptr, *delpos = nullptr;

@@ -3,7 +3,7 @@
 // ------------------------------------------------------------------------------------------ sweep launch
 // the product sweep (k_sweep_gen): U loads per unit, a ring of 32 loads, the residual in one image or staged in phases
 template <typename TA, int U, int NB, bool PH>
-static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
+static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
     auto kern = k_sweep_gen<TA, U, NB, PH>;
     if (ctx->sweep_lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
@@ -11,16 +11,16 @@ static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int
     }
     Solver& s = ctx->s;
     hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, r, s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
+                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
     return hipGetLastError();
 }
 template <typename TA>
-static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
-    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask);
+static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
+    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask, cout);
     switch (ctx->sweep_U) {
-        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask);
-        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask);
-        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask);
+        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask, cout);
+        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask, cout);
+        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask, cout);
     }
 }
 
@@ -41,12 +41,13 @@ static int prof_mark(csmp_ctx* ctx) {
 }
 
 
-static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask) {
+// cout: where c = A'r goes (default: the solver slot's correlation vector)
+static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout = nullptr) {
     const bool timed = prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
     hipError_t e = ctx->dtype == CSMP_F32
-                       ? sweep_product<float>(ctx, r, eps, check_eps, skipmask)
-                       : sweep_product<double>(ctx, r, eps, check_eps, skipmask);
+                       ? sweep_product<float>(ctx, r, eps, check_eps, skipmask, cout)
+                       : sweep_product<double>(ctx, r, eps, check_eps, skipmask, cout);
     HIPCHECK(e);
     if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;

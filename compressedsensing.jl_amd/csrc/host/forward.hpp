@@ -70,21 +70,75 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(g, groups));
 }
 
+// A column whose LDS images (the residual and up to two directions: 24 M bytes) exceed the LDS takes the tall path: the same pass
+// as separate launches (csmp_forward.hpp, k_fr_combine)
+static bool fr_tall(const csmp_ctx* ctx, int nq) {
+    int U, grid; bool full; size_t lds;
+    fr_config(ctx, nq, U, full, lds, grid);
+    return lds > 160 * 1024 - 512;
+}
+static int fr_combine_grid(const csmp_ctx* ctx) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (ctx->N + 255) / 256)); }
+
 static int fr_ensure(csmp_ctx* ctx) {
     Solver& s = ctx->s;
     int U; bool full; size_t lds;
     fr_config(ctx, 1, U, full, lds, s.fr_grid);
-    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "fr: M too large (r and q must both fit the 160 KiB LDS)");
+    if (fr_tall(ctx, 2)) {  // (some pass of some solver on this dictionary will take the tall path: srr's two directions at the latest)
+        if (!s.frg1) CHECK(dmalloc(ctx, &s.frg1, (size_t)ctx->N));
+        if (!s.frg2) CHECK(dmalloc(ctx, &s.frg2, (size_t)ctx->N));
+        if (!s.frq) CHECK(dmalloc(ctx, &s.frq, (size_t)s.Mpad));
+    }
     if (!s.rho2) CHECK(dmalloc(ctx, &s.rho2, (size_t)ctx->N));
     if (!s.dvec) CHECK(dmalloc(ctx, &s.dvec, (size_t)ctx->N));
     return CSMP_OK;
 }
 
+// forward_δ! on a tall dictionary: g = A'q per direction and c = A'r by the product sweep, then k_fr_combine
+static int launch_fr_pass_tall(csmp_ctx* ctx, const FrPass& ps, double max_eps, int skipmask) {
+    Solver& s = ctx->s;
+    const int M = (int)ctx->M;
+    if (ps.nq >= 1) {
+        const double* q1 = ps.q1;
+        if (!q1) {
+            hipLaunchKernelGGL(k_fr_lastq, dim3((s.Mpad + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.Q, s.ldq, (const DevState*)s.st, s.Mpad, M, s.frq);
+            HIPCHECK(hipGetLastError());
+            q1 = s.frq;
+        }
+        CHECK(launch_sweep(ctx, q1, 0.0, 0, skipmask, s.frg1));
+    }
+    if (ps.nq == 2) CHECK(launch_sweep(ctx, ps.q2, 0.0, 0, skipmask, s.frg2));
+    if (ps.nq < 0) {
+        const unsigned grid = (unsigned)((ctx->N + 3) / 4);
+        if (ctx->dtype == CSMP_F32)
+            hipLaunchKernelGGL(k_fr_colnorm2<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld, M, ctx->N, s.frg1);
+        else
+            hipLaunchKernelGGL(k_fr_colnorm2<double>, dim3(grid), dim3(256), 0, ctx->stream, (const double*)ctx->dA, ctx->ld, M, ctx->N, s.frg1);
+        HIPCHECK(hipGetLastError());
+    }
+    CHECK(launch_sweep(ctx, s.r, 0.0, 0, skipmask));  // (last: the sweep's prologue leaves ||r||^2 in the control block)
+    const dim3 grid((unsigned)fr_combine_grid(ctx));
+    s.fr_grid = (int)grid.x;  // (the arg-max partials the append reads are k_fr_combine's)
+#define FR_COMBINE(NQ)                                                                                                                      \
+    hipLaunchKernelGGL(k_fr_combine<NQ>, grid, dim3(256), 0, ctx->stream, ctx->N, (const double*)s.cvec, (const double*)s.frg1, ps.s1,       \
+                       (const double*)s.frg2, ps.s2, ps.unmark, ps.update_only, s.rho2, s.dvec, s.pval, s.pidx, (const int*)s.sel, s.st, max_eps, \
+                       skipmask)
+    switch (ps.nq) {
+        case -1: FR_COMBINE(-1); break;
+        case 0: FR_COMBINE(0); break;
+        case 1: FR_COMBINE(1); break;
+        default: FR_COMBINE(2); break;
+    }
+#undef FR_COMBINE
+    HIPCHECK(hipGetLastError());
+    return CSMP_OK;
+}
+
 // forward_δ! + the residual-norm guard of forward_step! (src/forward.jl:59-61,75-82)
 static int launch_fr_pass(csmp_ctx* ctx, const FrPass& ps, double max_eps, int skipmask) {
+    if (fr_tall(ctx, ps.nq)) return launch_fr_pass_tall(ctx, ps, max_eps, skipmask);
     int U, grid; bool full; size_t lds;
     fr_config(ctx, ps.nq, U, full, lds, grid);
-    if (lds > 160 * 1024 - 512) return fail(ctx, CSMP_ERANGE, "forward-regression sweep: M too large for the LDS images");
+    ctx->s.fr_grid = grid;  // (the partials of THIS pass: a dictionary near the LDS limit mixes fused and tall passes)
     const bool timed = !ps.update_only && prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
     hipError_t e = ctx->dtype == CSMP_F32 ? fr_sweep_launch<float>(ctx, ps, U, full, grid, lds, max_eps, skipmask)
@@ -260,7 +314,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     if (isfr) {  // the tick kernel exists for the exact-tiling FR sweeps only
         int U, g; bool full; size_t l;
         fr_config(ctx, 1, U, full, l, g);
-        pipe = pipe && full;
+        pipe = pipe && full && !fr_tall(ctx, 1);
     }
     auto init_sig = [&](int64_t sgn) -> int {
         const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;

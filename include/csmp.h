@@ -132,7 +132,7 @@ int csmp_ompr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double delta
  * src/forward.jl:44-54 (forward_step! :56-73, forward_δ! :75-82, ols_rescaling! :99-114), with x
  * starting empty.  Each step adds the atom maximising <a_j,r>^2 / (|a_j|^2 - |Q_S' a_j|^2); stops
  * when norm(r) <= max_eps, when the best score does not exceed min_delta^2, or at k atoms / nnz = M.
- * Capacity k.  Requires 16*M bytes of LDS (M <= ~10000). */
+ * Capacity k.  (Any M: columns whose two LDS images, 16 M bytes, exceed the LDS -- M beyond ~10 000 -- are swept once per image.) */
 int csmp_fr(csmp_ctx *ctx, const void *b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t *idx,
             double *val, int64_t *nnz, int64_t *order);
 /* P.δ² of the most recent forward-regression step (src/forward.jl:11,75-82; foba reads its maximum,

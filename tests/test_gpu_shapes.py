@@ -238,3 +238,45 @@ def test_oblivious_acquisition_on_the_omp_functor(cs, oracle):
     assert x.nnz == 6 and nxt in x.nzind and close(x.nzval, oracle.lstsq_cols(A, x.nzind, y))
     P.close()
     d.close()
+
+
+@pytest.mark.parametrize("case", [(12000, 700, np.float32), (8000, 600, np.float64), (32768, 400, np.float32), (20500, 300, np.float64)])
+def test_forward_regression_family_on_tall_dictionaries(cs, oracle, case):
+    """fr / ols and the stepwise solvers built on forward_step! (srr, rmp, foba) where the fused OLS sweep's LDS images (8 (1 + NQ) M
+    bytes) do not fit -- M beyond ~10 000 with one direction, ~6 800 with srr's two: rounds 1-4 returned CSMP_ERANGE there.  The
+    pass then runs as separate sweeps + k_fr_combine; the (8000, .) case mixes fused passes (fr) and tall ones (srr) on one
+    dictionary.  Selection order, supports, coefficients and iteration counts against the oracle."""
+    M, N, dtype = case
+    A = gaussian(M, N, dtype, 3 * M + N)
+    d = cs.Dictionary(A)
+    k = 12
+    for seed in range(2):
+        y = planted(A, k, seed, noise=0.05)
+        ref = oracle.fr(A, y, k)
+        got = d.ctx.fr(y, k, 0.0, 0.0)
+        assert np.array_equal(got[2], ref[2]), "fr selection order"
+        assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1])
+        ys = planted(A, k + 2, 10 + seed, noise=0.2)  # two atoms more than srr may keep: the replacement loop works
+        for init in (1, 2):
+            rs = oracle.srr(A, ys, k, 1e-12, -1, init, 1)
+            gs = d.ctx.srr(ys, k, 1e-12, -1, init, 1)
+            assert np.array_equal(gs[0], rs[0]) and close(gs[1], rs[1]) and gs[2] == rs[2], (init, gs[2], rs[2])
+        rr = oracle.rmp(A, y, 0.02, 2)
+        gr = d.ctx.rmp(y, 0.02, 2)
+        assert np.array_equal(gr[0], rr[0]) and close(gr[1], rr[1])
+        rf = oracle.foba(A, y, 0.02)
+        gf = d.ctx.foba(y, 0.02)
+        assert np.array_equal(gf[0], rf[0]) and close(gf[1], rf[1])
+    # the FR functor (update!(P::FR, x), src/forward.jl:88-95) and the batch driver (one signal at a time here: the pipelined tick needs the LDS form)
+    P = cs.FR(d, y, k)
+    x = cs.spzeros(N)
+    for t in range(4):
+        P(x)
+    assert np.array_equal(np.sort(ref[2][:4]), x.nzind)
+    P.close()
+    Y = np.asfortranarray(np.stack([planted(A, k, 20 + s, noise=0.05) for s in range(3)], axis=1))
+    bi, bv, bn = d.ctx.fr_batch(Y, k, 0.0, 0.0)
+    for s in range(3):
+        r3 = oracle.fr(A, Y[:, s], k)
+        assert bn[s] == len(r3[0]) and np.array_equal(bi[:bn[s], s], r3[0]) and close(bv[:bn[s], s], r3[1])
+    d.close()
