@@ -44,7 +44,10 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 // (dictionary step) x (the signal's residual step), see csmp_batched.hpp.
 using i32x4s = __attribute__((ext_vector_type(4))) int;
 using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
-template <int OP>
+// DIAG (tools/probes/screen_epilogue_probe.hip only; the library instantiates 0): 1 = no epilogue (one accumulator sum per lane is
+// stored, so that the K-loop stays alive): the epilogue's share of the launch; 2 = the full kernel + clock stamps around the K-loop
+// (s_memtime / s_memrealtime per workgroup into cand_idx's tail): the clock the chip holds under this loop.
+template <int OP, int DIAG = 0>
 __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__ Ab, const __bf16* __restrict__ Rb, int Mk,
                                                       int n_at2, int n_st2, int64_t N, int n_atiles128,
                                                       float* __restrict__ cand_val, int* __restrict__ cand_idx,
@@ -141,6 +144,11 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
         __builtin_amdgcn_s_setprio(0);                                                                           \
         __builtin_amdgcn_s_barrier();                                                                            \
     }
+    unsigned long long diag_t0 = 0, diag_r0 = 0;
+    if constexpr (DIAG == 2) {
+        diag_t0 = __builtin_amdgcn_s_memtime();
+        diag_r0 = __builtin_amdgcn_s_memrealtime();
+    }
     // prologue: units 0 .. 3 (K-tile 0); units 0, 1 must have landed
 #pragma unroll
     for (int u = 0; u < 4; ++u) issue(u);
@@ -172,6 +180,22 @@ __global__ __launch_bounds__(512) void k_b_screen256p(const __bf16* __restrict__
     }
 #undef CSMP_PH
     if (wr == 0) __builtin_amdgcn_s_barrier();  // (barrier counts of the two wave rows match again)
+    if constexpr (DIAG == 2) {
+        if (tid == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(cand_idx + (int64_t)n_st2 * kBT2 * n_atiles128 * kTileCand) + 2 * (int64_t)blockIdx.x;
+            o[0] = __builtin_amdgcn_s_memtime() - diag_t0;
+            o[1] = __builtin_amdgcn_s_memrealtime() - diag_r0;
+        }
+    }
+    if constexpr (DIAG == 1) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) sum += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+        cand_val[(int64_t)blockIdx.x * 512 + tid] = sum;
+        return;
+    }
     // epilogue: per signal the 4 largest |c| over this wave's 128 atoms, on packed keys -- the upper 23 bits of |c| (f32, sign
     // cleared, low 8 mantissa bits dropped) over 8 bits of (128 - atom-in-tile), so that one unsigned max orders by value and then by
     // LOWER atom index; the value handed on is the key with its low byte set: an upper bound of |c| that is 2^-15 relative wide

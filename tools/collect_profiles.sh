@@ -30,13 +30,22 @@ cd /tmp
 stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
 stats bench_batched --workload batched --steps 2 --warmup 1
 stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
-stats bench_batched_statistical_int8 --workload batched --steps 2 --warmup 1 --batch-cert statistical --batch-screen int8
 stats bench_sp --workload sp --steps 9 --warmup 3
 stats bench_sp_single --workload sp_single --steps 3 --warmup 1
 stats bench_gomp --workload gomp --steps 6 --warmup 2
 stats bench_gomp_single --workload gomp_single --steps 2 --warmup 1
 stats bench_screened_f16 --workload screened --steps 6 --warmup 2
 stats bench_gomp_single_screened_f16 --workload gomp_single --steps 2 --warmup 1 --screened
+stats bench_ompr --workload ompr --steps 3 --warmup 1 --no-in-flight
+stats bench_srr --workload srr --steps 3 --warmup 1 --no-in-flight
+stats bench_fr --workload fr --steps 6 --warmup 3
+# the shape table of the product sweep (M = 1000 .. 32768, f32 and f64): per-shape rows from the kernel trace
+rm -rf /tmp/prof_shapes /tmp/w_shapes; mkdir -p /tmp/w_shapes; cd /tmp/w_shapes
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_shapes -- python3 $R/bench.py --workload shapes --steps 10 > $OUT/shapes_stdout.txt 2> $OUT/shapes.err
+tail -1 $OUT/shapes_stdout.txt > $OUT/bench_shapes_line.json; rm -f $OUT/shapes_stdout.txt
+cp $R/profiles/r05_sweep_shapes.json $OUT/sweep_shapes.json
+python3 $R/tools/shape_profile.py /tmp/prof_shapes $OUT/sweep_shapes.json > $OUT/sweep_shapes_kernel_stats.csv
+cd /tmp
 # HBM traffic of the steady-state tick (two passes: the TCC block cannot hold both counters)
 d1=$(pmc fetch FETCH_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
 d2=$(pmc write WRITE_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)

@@ -16,7 +16,7 @@ HBM_PEAK = 8.0e12
 
 def main():
     prof, table = sys.argv[1], json.load(open(sys.argv[2]))
-    groups = {}
+    disp = []
     for f in glob.glob(os.path.join(prof, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
@@ -24,28 +24,36 @@ def main():
                 continue
             wg = int(row.get("Workgroup_Size_X", row.get("Workgroup_Size", 256)) or 256)
             grid = int(row.get("Grid_Size_X", row.get("Grid_Size", 0)) or 0) // max(wg, 1)
-            lds = int(row.get("LDS_Block_Size", row.get("LDS_Block_Size_v", 0)) or 0)
-            dur = int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
-            groups.setdefault((name.split("(")[0], grid, lds), []).append(dur)
+            disp.append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]), name.split("(")[0], grid))
+    disp.sort()
+    # one segment per dictionary: the sweeps of a shape run back to back, the next dictionary's generation (seconds of other
+    # kernels) lies between two shapes.  (The profiler reports a dynamic LDS allocation as 0 and several shapes share a template
+    # instance and a grid: neither tells them apart.)
+    segs = []
+    for st, en, name, grid in disp:
+        if not segs or st - segs[-1]["end"] > 20_000_000 or segs[-1]["name"] != name:
+            segs.append({"name": name, "grid": set(), "durs": [], "end": en})
+        segs[-1]["durs"].append(en - st)
+        segs[-1]["grid"].add(grid)
+        segs[-1]["end"] = en
     w = csv.writer(sys.stdout)
-    w.writerow(["M", "N", "dtype", "Name", "Workgroups", "LDS_Block_Size", "Calls", "AverageNs", "MinNs", "MaxNs", "algorithmic_bytes", "frac_of_8TBps"])
-    used = set()
-    for r in table:
-        tname = "float" if r["dtype"] == "f32" else "double"
-        want = "k_sweep_gen<%s, %d, %d, %s>" % (tname, r["unit_loads"], 32 // r["unit_loads"], "true" if r["phases"] > 1 else "false")
-        hits = [k for k in groups if want in k[0] and k[1] == r["workgroups"] and k not in used]
-        if not hits:
-            continue
-        key = min(hits, key=lambda k: abs(k[2] - r["lds_bytes"]))  # (the profiler reports the LDS allocation in its own granules)
-        used.add(key)
-        durs = sorted(groups[key])
+    w.writerow(["M", "N", "dtype", "Name", "Workgroups", "Calls", "AverageNs", "MinNs", "MaxNs", "algorithmic_bytes", "frac_of_8TBps"])
+    ok = len(segs) == len(table)
+    for i, seg in enumerate(segs):
+        r = table[i] if ok else None
+        if r is not None:
+            tname = "float" if r["dtype"] == "f32" else "double"
+            want = "k_sweep_gen<%s, %d, %d, %s>" % (tname, r["unit_loads"], 32 // r["unit_loads"], "true" if r["phases"] > 1 else "false")
+            if want not in seg["name"]:
+                ok, r = False, None
+        durs = sorted(seg["durs"])
         avg = sum(durs) / len(durs)
-        w.writerow([r["M"], r["N"], r["dtype"], key[0], key[1], key[2], len(durs), round(avg, 1), durs[0], durs[-1], r["bytes"],
-                    round(r["bytes"] / (avg * 1e-9) / HBM_PEAK, 4)])
-    for key in sorted(groups):
-        if key not in used:  # (dispatches no row of the table claimed: the check sweeps of another grid, if any)
-            durs = sorted(groups[key])
-            w.writerow(["", "", "", key[0], key[1], key[2], len(durs), round(sum(durs) / len(durs), 1), durs[0], durs[-1], "", ""])
+        grids = "/".join(str(g) for g in sorted(seg["grid"]))
+        if r is not None:
+            w.writerow([r["M"], r["N"], r["dtype"], seg["name"], grids, len(durs), round(avg, 1), durs[0], durs[-1], r["bytes"],
+                        round(r["bytes"] / (avg * 1e-9) / HBM_PEAK, 4)])
+        else:
+            w.writerow(["", "", "", seg["name"], grids, len(durs), round(avg, 1), durs[0], durs[-1], "", ""])
 
 
 if __name__ == "__main__":
