@@ -15,6 +15,7 @@
 #include "csmp_tinv.hpp"
 #include "csmp_shard.hpp"
 #include "csmp_gram.hpp"
+#include "csmp_swap.hpp"
 
 #include <algorithm>
 #include <iterator>

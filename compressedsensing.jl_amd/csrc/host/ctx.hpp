@@ -51,6 +51,8 @@ struct Solver {
     // explicit inverse factor of the two-stage solvers (csmp_tinv.hpp)
     double *T = nullptr, *T2 = nullptr, *tpd = nullptr, *tpn = nullptr;
     int* tmeta = nullptr;
+    double *swapH = nullptr, *swapv = nullptr;  // OMPR's exchanges on the inverse Gram matrix (csmp_swap.hpp): H (kcap x kcap) and its vectors
+    size_t swapv_cap = 0;
     int sigcap = 0;
     // whole-set least squares (csmp_gram.hpp), allocated on first use
     double *Gm = nullptr, *Gpart = nullptr, *gdiag = nullptr, *rpart = nullptr, *Dfac = nullptr, *Gm2 = nullptr, *ytmp = nullptr;

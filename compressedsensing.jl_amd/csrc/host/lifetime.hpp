@@ -74,7 +74,7 @@ static void solver_free(Solver& s) {
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
     dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags); dfree(s.scr_val); dfree(s.scr_idx); dfree(s.scr_tickets); dfree(s.scr_cb); dfree(s.scr_flag);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
-    dfree(s.rho2); dfree(s.dvec); dfree(s.frg1); dfree(s.frg2); dfree(s.frq);
+    dfree(s.rho2); dfree(s.dvec); dfree(s.frg1); dfree(s.frg2); dfree(s.frq); dfree(s.swapH); dfree(s.swapv); s.swapv_cap = 0;
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);
     dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta); dfree(s.extcol);
     dfree(s.Gm); dfree(s.Dfac); dfree(s.Gpart); dfree(s.gdiag); dfree(s.rpart); dfree(s.Acomp); dfree(s.Gkeep); dfree(s.gdkeep); dfree(s.Gkeep2); dfree(s.gdkeep2); dfree(s.Wb); dfree(s.Gin); dfree(s.Gm2); dfree(s.ytmp); dfree(s.kpos); dfree(s.rhs_part); dfree(s.rn2part);

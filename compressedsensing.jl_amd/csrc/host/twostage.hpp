@@ -13,6 +13,94 @@ struct OmprJob {
     bool use_downdate = false, tmode = false, screened = false;
     int unc_seen = 0;  // DevState::uncertain seen so far (the screened sweeps count up in it)
     std::vector<double> cs, call;
+    // exchanges on the inverse Gram matrix (csmp_swap.hpp): on from the acquisition until an exchange fails its guard
+    bool gram = false;
+    std::vector<int> slot;  // the atom in every slot of H (device: s.sel)
+    double *dG = nullptr, *dUpart = nullptr, *dU = nullptr, *dHp = nullptr, *dC = nullptr, *dInfo = nullptr, *dRpart = nullptr, *dN2 = nullptr;
+    int nchk = 0, nchm = 0, nshare = 0;
+
+    // H = (A_S'A_S)^-1 = T T' from the explicit inverse factor the acquisition built, c = A_S'b, x in slot order (s.bwd_coef)
+    template <typename TA>
+    int gram_begin_t() {
+        Solver& s = ctx->s;
+        const int kk = (int)k, M = (int)ctx->M;
+        nchk = (kk + kSwapChunk - 1) / kSwapChunk;
+        nchm = (kk + kResChunk - 1) / kResChunk;
+        nshare = (M + 255) / 256;
+        const size_t need = (size_t)(kk + 2) + (size_t)nchk * kk + 3 * (size_t)kk + 8 + (size_t)nchm * M + (size_t)nshare;
+        if (!s.swapH) CHECK(dmalloc(ctx, &s.swapH, (size_t)s.kcap * s.kcap));
+        if (s.swapv_cap < need) {
+            dfree(s.swapv);
+            CHECK(dmalloc(ctx, &s.swapv, need));
+            s.swapv_cap = need;
+        }
+        dG = s.swapv;
+        dUpart = dG + kk + 2;
+        dU = dUpart + (size_t)nchk * kk;
+        dHp = dU + kk;
+        dC = dHp + kk;
+        dInfo = dC + kk;
+        dRpart = dInfo + 8;
+        dN2 = dRpart + (size_t)nchm * M;
+        hipLaunchKernelGGL(k_swap_init, dim3((kk * kk + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.T, s.kcap, kk, s.swapH);
+        hipLaunchKernelGGL((k_swap_dots<TA, double>), dim3((kk + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, kk,
+                           (const double*)s.b, (const double*)s.b, 0, dC);
+        HIPCHECK(hipGetLastError());
+        slot.assign((size_t)kk, 0);
+        HIPCHECK(hipMemcpyAsync(slot.data(), s.sel, (size_t)kk * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        gram = true;
+        return CSMP_OK;
+    }
+    // one exchange: `leaving` out, `joining` in; *refused: the guard did not hold and nothing was changed
+    template <typename TA>
+    int gram_swap_t(int leaving, int joining, bool* refused) {
+        Solver& s = ctx->s;
+        const int kk = (int)k, M = (int)ctx->M;
+        const int p = (int)(std::find(slot.begin(), slot.end(), leaving) - slot.begin());
+        if (p >= kk) return fail(ctx, CSMP_ESTATE, "ompr: the leaving atom is not in the support");
+        hipLaunchKernelGGL((k_swap_dots<TA, TA>), dim3((kk + 2 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, kk,
+                           (const TA*)ctx->dA + (int64_t)joining * ctx->ld, (const double*)s.b, 2, dG);
+        hipLaunchKernelGGL(k_swap_upart, dim3((kk + 63) / 64, nchk), dim3(64), 0, ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, dUpart);
+        hipLaunchKernelGGL(k_swap_fin, dim3(1), dim3(256), (size_t)kk * sizeof(int), ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, (const double*)dUpart, nchk,
+                           dU, s.bwd_coef, dC, s.sel, joining, dHp, dInfo, s.out_idx, s.out_val, s.out_nnz);
+        hipLaunchKernelGGL(k_swap_commit, dim3((kk * kk + 255) / 256), dim3(256), 0, ctx->stream, s.swapH, s.kcap, kk, p, (const double*)dU, (const double*)dHp,
+                           (const double*)dInfo);
+        hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nchm), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel,
+                           (const double*)s.bwd_coef, kk, dRpart);
+        hipLaunchKernelGGL(k_swap_rsum, dim3(nshare), dim3(256), 0, ctx->stream, (const double*)dRpart, nchm, M, (const double*)s.b, s.r, (const double*)dInfo, dN2);
+        HIPCHECK(hipGetLastError());
+        std::vector<int64_t> hi((size_t)kk);
+        std::vector<double> hv((size_t)kk), n2((size_t)nshare);
+        double info[4] = {0, 0, 0, 0};
+        {
+            PinFetch f(ctx);
+            CHECK(f.begin((size_t)kk * 16 + (size_t)nshare * 8 + 64));
+            CHECK(f.add(hi.data(), s.out_idx, (size_t)kk * 8));
+            CHECK(f.add(hv.data(), s.out_val, (size_t)kk * 8));
+            CHECK(f.add(n2.data(), dN2, (size_t)nshare * 8));
+            CHECK(f.add(info, dInfo, 32));
+            CHECK(f.wait());
+        }
+        *refused = info[2] != 0.0;
+        if (*refused) return CSMP_OK;
+        slot[(size_t)p] = joining;
+        xi.assign(hi.begin(), hi.end());
+        xv.assign(hv.begin(), hv.end());
+        double t = 0.0;
+        for (double v : n2) t += v;
+        resnorm = std::sqrt(t);
+        return CSMP_OK;
+    }
+    // the guard refused an exchange: back to the factorisation of the CURRENT support (as the acquisition builds it); the
+    // rotation path takes over for the rest of the solve
+    int gram_leave() {
+        gram = false;
+        std::vector<int> cols(xi.begin(), xi.end());
+        CHECK(ls_on_columns(ctx, cols));
+        CHECK(launch_tinv_build(ctx));
+        return fetch_sorted_t(ctx, xi, xv);
+    }
 
     // OMPR(A, b, k) (:124-132): buffers, b on the device, empty support, r = b
     int begin(csmp_ctx* c, const void* b, int b_dtype, int64_t kk) {
@@ -36,6 +124,7 @@ struct OmprJob {
         cs.assign((size_t)k, 0.0);
         unc_seen = 0;
         resnorm = 0.0;
+        gram = false;
         return CSMP_OK;
     }
     // oblivious_acquisition!(P, x, k) on an empty x (src/matchingpursuit.jl:207-216, called at src/twostage.jl:190): the k atoms best
@@ -66,6 +155,8 @@ struct OmprJob {
         if (tmode) {
             CHECK(launch_tinv_build(ctx));
             CHECK(fetch_sorted_t(ctx, xi, xv));
+            if ((int64_t)xi.size() == k)  // (a full support: the exchanges run on the inverse Gram matrix from here on)
+                CHECK(ctx->dtype == CSMP_F32 ? gram_begin_t<float>() : gram_begin_t<double>());
         } else {
             CHECK(fetch_sorted(ctx, xi, xv));
         }
@@ -144,6 +235,12 @@ struct OmprJob {
             }
             if (jmin != pos) {  // qr_i != j (:171): the support really changes
                 const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
+                if (gram) {
+                    bool refused = false;
+                    CHECK(ctx->dtype == CSMP_F32 ? gram_swap_t<float>(leaving, (int)cand, &refused) : gram_swap_t<double>(leaving, (int)cand, &refused));
+                    if (!refused) return CSMP_OK;  // (x, r and ||r|| are the exchange's)
+                    CHECK(gram_leave());
+                }
                 if (use_downdate) {
                     // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
                     // (one launch names both atoms: the one that leaves -> its position, the one that joins -> the append's list)
