@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_swap_fin(const double* __restrict__ H, 
                                                   const double* __restrict__ part, int nch, double* __restrict__ u, double* __restrict__ x,
                                                   double* __restrict__ c, int* __restrict__ sel, int anew, double* __restrict__ hp,
                                                   double* __restrict__ info, int64_t* __restrict__ out_idx, double* __restrict__ out_val,
-                                                  int64_t* __restrict__ out_nnz) {
+                                                  int64_t* __restrict__ out_nnz, double guard) {
     __shared__ double red[8];
     __shared__ double sh_xa;
     const int tid = threadIdx.x;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_swap_fin(const double* __restrict__ H, 
     const double sigma = gamma - gu;
     // the guard: the joining atom must keep a real component outside the span of the others (sigma = its squared distance);
     // the append chain's DGKS test re-orthogonalises below 1/2, here there is no second pass: a small ratio hands the solve back
-    const bool bad = !(sigma > 1e-6 * gamma) || !(hpp > 0.0);
+    const bool bad = !(sigma > guard * gamma) || !(hpp > 0.0);  // (guard: 1e-6; a test hook passes 2 -- sigma <= gamma always -- to walk the fallback)
     if (tid == 0) {
         info[0] = sigma;
         info[1] = hpp;

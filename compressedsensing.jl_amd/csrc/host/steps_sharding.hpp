@@ -82,6 +82,7 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tune_sweep_grid = src->tune_sweep_grid;  // (measurement overrides, csmp_tune: the twins of the batch drivers sweep like their parent)
     dst->tune_sweep_U = src->tune_sweep_U;
     dst->tick_nblk = src->tick_nblk;
+    dst->tune_swap_refuse = src->tune_swap_refuse;
 }
 extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     if (!src || !out) return CSMP_EINVAL;

@@ -63,7 +63,7 @@ struct OmprJob {
                            (const TA*)ctx->dA + (int64_t)joining * ctx->ld, (const double*)s.b, 2, dG);
         hipLaunchKernelGGL(k_swap_upart, dim3((kk + 63) / 64, nchk), dim3(64), 0, ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, dUpart);
         hipLaunchKernelGGL(k_swap_fin, dim3(1), dim3(256), (size_t)kk * sizeof(int), ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, (const double*)dUpart, nchk,
-                           dU, s.bwd_coef, dC, s.sel, joining, dHp, dInfo, s.out_idx, s.out_val, s.out_nnz);
+                           dU, s.bwd_coef, dC, s.sel, joining, dHp, dInfo, s.out_idx, s.out_val, s.out_nnz, ctx->tune_swap_refuse ? 2.0 : 1e-6);
         hipLaunchKernelGGL(k_swap_commit, dim3((kk * kk + 255) / 256), dim3(256), 0, ctx->stream, s.swapH, s.kcap, kk, p, (const double*)dU, (const double*)dHp,
                            (const double*)dInfo);
         hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nchm), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel,
@@ -165,7 +165,7 @@ struct OmprJob {
     // update!(P::OMPR, x) with eta = 1 (:134-180) and the norm(residual!(P, x)) the driver takes after it (:196)
     int update() {
         Solver& s = ctx->s;
-        bool have_norm = false;
+        bool have_norm = false, changed = false;
         // Ar = x + A'r, arg-max over atoms outside the support
         std::vector<int> cur(xi.begin(), xi.end());
         DevState hs;
@@ -234,6 +234,7 @@ struct OmprJob {
                 }
             }
             if (jmin != pos) {  // qr_i != j (:171): the support really changes
+                changed = true;
                 const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
                 if (gram) {
                     bool refused = false;
@@ -269,7 +270,10 @@ struct OmprJob {
                 }
             }
         }
-        if (!have_norm) CHECK(residual_norm(ctx, &resnorm));  // :196
+        // :196.  An update! that changed nothing leaves x, hence residual!(P, x) and its norm, exactly where they were (the
+        // reference recomputes the same number bit for bit): the norm held is the norm -- re-measuring it by another kernel's
+        // summation order could differ in the last place and keep `oldnorm <= resnorm` from ending the loop where it ends there
+        if (!have_norm && changed) CHECK(residual_norm(ctx, &resnorm));
         return CSMP_OK;
     }
 };

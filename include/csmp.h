@@ -233,10 +233,12 @@ int csmp_batch_stats(csmp_ctx *ctx, int64_t *signals, int64_t *resolved_exactly,
                                       operands' images, Float32 accumulation, key truncation) with the largest column norm: a
                                       passed certificate PROVES the pick; no residual, however constructed, can slip through
                                       (tests: test_batched_certificate_against_adversarial_residuals).
-                                      0 (opt-in): statistical -- 8 standard deviations of independent roundings + a coherent
-                                      term; narrower windows (fewer rescored candidates, int8 operands allowed), holds for generic
-                                      data, NOT a proof: a residual aligned with the rounding errors of a near-tied atom passes
-                                      the certificate with the wrong atom */
+                                      0 (opt-in, UNSAFE): statistical -- 8 standard deviations of independent roundings + a
+                                      coherent term; narrower windows (fewer rescored candidates, int8 operands allowed), holds
+                                      for generic data, NOT a proof: a residual aligned with the rounding errors of a near-tied
+                                      atom passes the certificate with the WRONG atom and nothing reports it (the library's own
+                                      adversarial test constructs 24 such signals out of 24).  Not measured in the default bench
+                                      line; use it only where a wrong pick on a crafted input is acceptable */
 #define CSMP_OPT_BATCH_GRAM 2      /* 1: csmp_omp_batch_mfma keeps G = A'A resident (Float64, 8 N^2 bytes: 32 GiB at N = 65536;
                                       built on first use, 2 M N^2 / 2 flops on the Float64 matrix cores) and takes A_S'a from it
                                       instead of streaming the support's columns: half the append traffic.  0 (default) frees it */

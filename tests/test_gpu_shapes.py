@@ -280,3 +280,23 @@ def test_forward_regression_family_on_tall_dictionaries(cs, oracle, case):
         r3 = oracle.fr(A, Y[:, s], k)
         assert bn[s] == len(r3[0]) and np.array_equal(bi[:bn[s], s], r3[0]) and close(bv[:bn[s], s], r3[1])
     d.close()
+
+
+def test_ompr_exchange_guard_falls_back_to_the_qr_path(cs, oracle):
+    """csmp_ompr exchanges atoms on the inverse Gram matrix (csmp_swap.hpp); an exchange whose Schur complement fails the guard is not
+    applied: the QR state is rebuilt from the current support and the rotation path (k_tdel_apply) carries the solve on.  The test
+    hook makes the guard fail on the first exchange: the results must still be the oracle's -- as they are with the guard at rest."""
+    A = gaussian(256, 1024, np.float32, 77)
+    d = cs.Dictionary(A)
+    for seed in range(3):
+        y = planted(A, 23, seed, noise=0.3)
+        ref = oracle.ompr(A, y, 20, 1e-9)
+        got = d.ctx.ompr(y, 20, 1e-9)
+        assert np.array_equal(got[0], ref[0]) and close(got[1], ref[1]) and got[2] == ref[2]
+        d.ctx.tune("swap_refuse", 1)
+        try:
+            fb = d.ctx.ompr(y, 20, 1e-9)
+        finally:
+            d.ctx.tune("swap_refuse", 0)
+        assert np.array_equal(fb[0], ref[0]) and close(fb[1], ref[1]) and fb[2] == ref[2]
+    d.close()
