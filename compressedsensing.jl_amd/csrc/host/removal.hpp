@@ -155,6 +155,7 @@ static int fetch_sorted_t(csmp_ctx* ctx, std::vector<int64_t>& idx, std::vector<
     return CSMP_OK;
 }
 
+static int ls_on_columns(csmp_ctx* ctx, const std::vector<int>& cols);  // (host/gomp_sp.hpp)
 // dropindex!(x, AiQR, i) on the step-level solver (src/util.jl:137-161): atom leaves the support
 extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
     if (!ctx) return CSMP_EINVAL;
@@ -167,8 +168,23 @@ extern "C" int csmp_solver_remove(csmp_ctx* ctx, int64_t atom) {
         // k_qrdel_r walks R with one thread per column in one workgroup (1023 columns).  Beyond that the down-date takes its
         // rotations from the explicit inverse T = R^-1, as the two-stage solvers do (csmp_tinv.hpp: up to 4095 columns); the
         // functor's appends do not maintain T, so it is rebuilt from R here (one launch, O(j^3 / 64) per lane: a step primitive)
-        if (ctx->s.kcap > kTMaxCols)
-            return fail(ctx, CSMP_ERANGE, "solver_remove: column removal supports a capacity of at most 4095 columns");
+        if (ctx->s.kcap > kTMaxCols) {
+            // Beyond the 4095 columns the rotation kernels scan in one workgroup (GOMP's default capacity size(A,1) at M = 8192):
+            // the atom leaves the list and the factorisation is rebuilt from the columns that stay, in their insertion order
+            // (panel appends, O(M j^2)) -- dropindex! has no cap in the reference (src/util.jl:137-161), so neither has this.
+            Solver& s = ctx->s;
+            DevState hs;
+            HIPCHECK(hipMemcpyAsync(&hs, s.st, sizeof hs, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            std::vector<int> cols((size_t)std::max(hs.nsel, 0));
+            if (hs.nsel > 0) HIPCHECK(hipMemcpy(cols.data(), s.sel, (size_t)hs.nsel * sizeof(int), hipMemcpyDeviceToHost));
+            auto it = std::find(cols.begin(), cols.end(), (int)atom);
+            if (it == cols.end()) return CSMP_OK;  // (absent: a no-op, as below)
+            cols.erase(it);
+            CHECK(ls_on_columns(ctx, cols));
+            s.jh = (int)cols.size();
+            return CSMP_OK;
+        }
         CHECK(tinv_ensure(ctx));
         CHECK(launch_tinv_build(ctx));
         return launch_delete_atom_t(ctx, (int)atom, /*keep_R*/ true);

@@ -296,7 +296,8 @@ int csmp_solver_step(csmp_ctx *ctx, int64_t l);
 int csmp_solver_acquire(csmp_ctx *ctx, int64_t k);
 /* dropindex!(x, AiQR, i) (src/util.jl:137-161): atom leaves the support of an OMP/GOMP solver -- Givens
  * down-date of the on-device QR (remove_column!), residual and coefficients follow.  No-op if absent.
- * Capacities (kcap of csmp_solver_begin) up to 4095 columns; beyond: CSMP_ERANGE. */
+ * Any capacity: up to 1023 columns one workgroup walks R, up to 4095 the rotations come from the explicit inverse, beyond that the
+ * factorisation is rebuilt from the columns that stay. */
 int csmp_solver_remove(csmp_ctx *ctx, int64_t atom);
 /* current x (sorted), ||b - A x||_2, selection order, stop reason.  Any pointer may be NULL. */
 int csmp_solver_state(csmp_ctx *ctx, int64_t *idx, double *val, int64_t *nnz, double *resnorm,

@@ -1108,6 +1108,40 @@ def test_qr_column_removal_beyond_1023_columns(cs, D):
     check(list(order))
 
 
+def test_qr_column_removal_at_the_reference_default_capacity(cs, D):
+    """GOMP(A, b, l) defaults its capacity to size(A, 1) (src/matchingpursuit.jl:108): at M = 4608 that is beyond the 4095 columns the
+    rotation kernels scan, and dropindex! must still work (src/util.jl:137-161 has no cap): the factorisation is rebuilt without
+    the atom.  Removals, then appends on top, each state against a dense least-squares solve."""
+    M, N = 4608, 5000
+    g = np.random.default_rng(4608)
+    A = g.standard_normal((M, N))
+    A /= np.linalg.norm(A, axis=0, keepdims=True)
+    A = np.asfortranarray(A.astype(np.float32))
+    A64 = A.astype(np.float64)
+    y = A64[:, g.choice(N, 20, replace=False)] @ g.standard_normal(20) + 0.05 * g.standard_normal(M)
+    d = D(A)
+    d.ctx.solver_begin(cs._lib.ALGO_GOMP, y, M)  # the reference's default capacity
+    for _ in range(6):
+        d.ctx.solver_step(4)
+    idx, val, res, order, stop = d.ctx.solver_state(M)
+    supp = list(order)
+    assert len(supp) == 24
+    for pos in (0, 11, -1):
+        atom = supp[pos]
+        d.ctx.solver_remove(atom)
+        supp.remove(atom)
+        idx, val, res, order, stop = d.ctx.solver_state(M)
+        assert list(order) == supp and np.array_equal(idx, np.array(sorted(supp)))
+        coef = np.linalg.lstsq(A64[:, idx], y, rcond=None)[0]
+        assert np.allclose(val, coef, rtol=1e-8, atol=1e-10) and np.isclose(res, np.linalg.norm(y - A64[:, idx] @ coef), rtol=1e-8)
+    d.ctx.solver_remove(10 ** 6)
+    d.ctx.solver_step(4)
+    idx, val, res, order, stop = d.ctx.solver_state(M)
+    assert len(idx) == 25 and list(order)[:21] == supp
+    coef = np.linalg.lstsq(A64[:, idx], y, rcond=None)[0]
+    assert np.allclose(val, coef, rtol=1e-8, atol=1e-10)
+
+
 # ------------------------------------------------------------------------------------------------
 # stepwise regression with replacement (srr, src/twostage.jl:3-33): forward steps + backward steps
 @pytest.mark.parametrize("cfg", [(32, 64, 3, 1, np.float64), (32, 64, 3, 3, np.float64), (128, 512, 12, 1, np.float32),
