@@ -230,6 +230,49 @@ stepwise_case("lace_ref_32x32_delta", "lace", A, y, [BIG, 1e-2, 0], lambda o: o.
 for nm in ("br_ref_32x32_k3", "br_ref_32x32_eps", "lace_ref_32x32_delta"):
     assert np.array_equal(out[nm + ".idx"], x.nzind)
 
+
+# round 5: OMP with replacement (the driver) and the step-level functors SP / OMPR: x after the acquisition and after each of
+# `steps` update! calls is what a host that steps sees; the fixture holds the LAST iterate (the numpy twin's step functions),
+# cross-checked against the C oracle's driver where the driver has not stopped earlier.  params = [k, steps]
+def ompr_case(name, A, b, k, delta):
+    r = oc.ompr(A, b, k, delta)
+    r2 = on.ompr(A, b, k, delta)
+    agree(r[:2], r2[:2], name)
+    assert r[2] == r2[2]
+    add(name, "ompr", A, b, [k, delta, r[2]], r[:2])
+
+
+def sp_steps_case(name, A, b, k, steps):
+    idx, val = on.sp_acquisition(A, b, [], [], k)
+    for t in range(steps):
+        idx, val = on.sp_update(A, b, idx, val, k)
+    c = oc.sp(A, b, k, 0.0, maxiter=steps)
+    if c[2] == steps:
+        agree((idx, val), c[:2], name)
+    add(name, "sp_steps", A, b, [k, steps], (idx, val))
+
+
+def ompr_steps_case(name, A, b, k, steps):
+    idx, val = on.oblivious_acquisition(A, b, k)
+    for t in range(steps):
+        idx, val = on.ompr_update(A, b, idx, val)
+    c = oc.ompr(A, b, k, 0.0, maxiter=steps)
+    if c[2] == steps:
+        agree((idx, val), c[:2], name)
+    add(name, "ompr_steps", A, b, [k, steps], (idx, val))
+
+
+A, x, b = cs.sparse_data(n=32, m=64, k=3, rng=111)  # test/twostage.jl's shape
+y = cs.perturb(b, 5e-3, rng=112)
+ompr_case("ompr_ref_32x64", A, y, 3, 1e-2)
+sp_steps_case("sp_steps_ref_32x64", A, y, 3, 2)
+ompr_steps_case("ompr_steps_ref_32x64", A, y, 3, 2)
+A, x, b = cs.sparse_data(n=64, m=256, k=10, rng=113, dtype=np.float32)
+y = cs.perturb(b, 0.3, rng=114)  # heavy noise, two atoms fewer than planted: the exchanges have work to do
+ompr_case("ompr_f32_64x256_k8", A, y, 8, 1e-6)
+sp_steps_case("sp_steps_f32_64x256_k8", A, y, 8, 3)
+ompr_steps_case("ompr_steps_f32_64x256_k8", A, y, 8, 4)
+
 out["names"] = np.array(names)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_small.npz")
 np.savez_compressed(path, **out)

@@ -2,7 +2,7 @@
 #
 # The build image has no Julia, so tests/golden/golden_small.npz was produced by the C oracle (make_golden.py) and
 # the project's parity claim is capped at "partial" until someone runs this script.  It loads the real package,
-# replays the 38 committed golden INPUTS (A, b, parameters) through the reference's own drivers and writes the
+# replays the 44 committed golden INPUTS (A, b, parameters) through the reference's own drivers and writes the
 # reference-produced outputs in the same npz layout:
 #
 #     julia --project=/path/to/CompressedSensing.jl tests/golden/make_golden_reference.jl \
@@ -59,6 +59,18 @@ for name in names
         CS.rmp(A, b, p[1], Int(p[2]))                    # :5-26
     elseif algo == "foba"
         CS.foba(A, b, p[1])                              # :47-56
+    elseif algo == "ompr"
+        CS.ompr(A, b, Int(p[1]), p[2])                   # src/twostage.jl:184-202  params = [k, delta, iterations]
+    elseif algo == "sp_steps"                            # the functor, call by call: params = [k, steps]
+        P = CS.SP(A, b, Int(p[1])); xs = spzeros(size(A, 2))
+        CS.sp_acquisition!(P, xs, P.k)                   # src/twostage.jl:67-72
+        for _ in 1:Int(p[2]); CS.update!(P, xs); end     # :75-83
+        xs
+    elseif algo == "ompr_steps"
+        P = CS.OMPR(A, b, Int(p[1])); xs = spzeros(size(A, 2))
+        CS.oblivious_acquisition!(P, xs, P.k)            # src/matchingpursuit.jl:207-216
+        for _ in 1:Int(p[2]); CS.update!(P, xs); end     # src/twostage.jl:134-180
+        xs
     elseif algo == "br"
         CS.br(A, b, p[1], p[2], Int(p[3]))               # src/backward.jl:27-35
     elseif algo == "lace"

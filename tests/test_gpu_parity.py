@@ -84,6 +84,16 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         elif c["algo"] == "fr":
             idx, val, order = d.ctx.fr(b, int(p[0]), float(p[1]), float(p[2]))
             assert np.array_equal(order, c["order"]), (name, order, c["order"])
+        elif c["algo"] == "ompr":
+            idx, val, iters = d.ctx.ompr(b, int(p[0]), float(p[1]))
+            assert iters == int(p[2]), name
+        elif c["algo"] in ("sp_steps", "ompr_steps"):  # the step-level functors: acquisition + `steps` update! calls
+            P = (cs.SP if c["algo"] == "sp_steps" else cs.OMPR)(d, b, int(p[0]))
+            xv = cs.sp_acquisition(P) if c["algo"] == "sp_steps" else cs.oblivious_acquisition(P, None, int(p[0]))
+            for _ in range(int(p[1])):
+                xv = P(xv)
+            idx, val = xv.nzind, xv.nzval
+            P.close()
         else:
             idx, val, iters = d.ctx.sp(b, int(p[0]), float(p[1]))
             assert iters == int(p[2]), name
@@ -93,7 +103,7 @@ def test_golden_vectors_through_the_abi(cs, golden, D):
         else:  # gomp_dupcols: an atom AND its exact copy are both selected -> singular least squares;
             pass  # the reference's own coefficients are NaN/Inf there, only the support is defined
         ran += 1
-    assert ran == len(golden) >= 38
+    assert ran == len(golden) >= 44
 
 
 @pytest.mark.parametrize("shape", [(32, 48, 3), (64, 256, 8), (37, 101, 5), (256, 1024, 32), (130, 700, 20), (512, 4096, 40)])

@@ -32,19 +32,33 @@ def run_case(oracle, c):
         return oracle.srr(A, b, int(p[0]), float(p[1]), -1, int(p[2]), int(p[3]))
     if c["algo"] == "fr":
         return oracle.fr(A, b, int(p[0]), float(p[1]), float(p[2]))
+    if c["algo"] == "ompr":
+        return oracle.ompr(A, b, int(p[0]), float(p[1]))
+    if c["algo"] in ("sp_steps", "ompr_steps"):  # the functor's iterate after `steps` update! calls: the numpy twin's step functions
+        from oracle import oracle_np
+        k, steps = int(p[0]), int(p[1])
+        if c["algo"] == "sp_steps":
+            idx, val = oracle_np.sp_acquisition(A, b, [], [], k)
+            for _ in range(steps):
+                idx, val = oracle_np.sp_update(A, b, idx, val, k)
+        else:
+            idx, val = oracle_np.oblivious_acquisition(A, b, k)
+            for _ in range(steps):
+                idx, val = oracle_np.ompr_update(A, b, idx, val)
+        return idx, val
     raise AssertionError(c["algo"])
 
 
 def test_golden_vectors(oracle, golden):
-    assert len(golden) >= 38
+    assert len(golden) >= 44
     for name, c in golden.items():
         r = run_case(oracle, c)
         assert np.array_equal(r[0], c["idx"]), name
         if np.all(np.isfinite(c["val"])):  # (gomp_dupcols is a singular LS problem: support only)
-            np.testing.assert_allclose(r[1], c["val"], rtol=1e-12, atol=1e-15, err_msg=name)
+            np.testing.assert_allclose(r[1], c["val"], rtol=1e-10 if c["algo"].endswith("_steps") else 1e-12, atol=1e-15, err_msg=name)
         if c["algo"] in ("omp", "gomp", "fr"):
             assert np.array_equal(r[2], c["order"]), name
-        if c["algo"] == "sp":
+        if c["algo"] in ("sp", "ompr"):
             assert r[2] == int(c["params"][2]), name
         if c["algo"] == "srr":
             assert r[2] == int(c["params"][4]), name
