@@ -333,6 +333,147 @@ __global__ __launch_bounds__(256) void k_fr_rebuild(const TA* __restrict__ A, in
     }
 }
 
+// The same product with the directions staged through the LDS: the 128 x 64 block of Q a row block needs is fetched ONCE per
+// workgroup (coalesced 16-byte loads into registers while the matrix cores work on the block before, then written to the other
+// LDS buffer), instead of once per wave from L2 behind a uniform branch per direction tile -- which is what k_fr_rebuild waits
+// for: 16 loads, their latency, 32 MFMAs, and again.  Directions are LDS rows of 64 doubles + 16 bytes: the 16 lanes of a
+// quarter read 16 different rows at a 528-byte stride, i.e. all 64 banks once per ds_read_b128.  Every steady row block is loaded
+// unguarded (all its rows exist); the last one clamps its row indices and masks what lies beyond M.
+constexpr int kRbDirs = 128, kRbRows = 64, kRbStride = kRbRows + 2;
+__host__ __device__ constexpr size_t fr_rebuild_lds_bytes() { return (size_t)2 * kRbDirs * kRbStride * sizeof(double); }
+
+template <typename TA, bool VEC>
+__global__ __launch_bounds__(256) void k_fr_rebuild_lds(const TA* __restrict__ A, int64_t ld, int M, int64_t N,
+                                                        const double* __restrict__ Q, int64_t ldq, int d0, int nd,
+                                                        double* __restrict__ rho2) {
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    typedef TA ta4 __attribute__((ext_vector_type(16 / sizeof(TA))));
+    constexpr int NA = 2, NT = kRbDirs / 16, PERV = 16 / (int)sizeof(TA), NV = 16 / PERV;
+    extern __shared__ double qlds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t a0 = ((int64_t)blockIdx.x * 4 + wave) * (16 * NA);
+    const TA* acol[NA];
+#pragma unroll
+    for (int h = 0; h < NA; ++h) {
+        const int64_t atom = a0 + h * 16 + fr < N ? a0 + h * 16 + fr : N - 1;
+        acol[h] = A + atom * ld + fq * 16;
+    }
+    // loader: thread -> row pair tid % 32 of direction tid / 32 + 8 j (32 threads cover the 512 contiguous bytes of a direction)
+    const int lrp = tid & 31, ldir = tid >> 5;
+    const double* qsrc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int dir = ldir + 8 * j;
+        qsrc[j] = Q + (int64_t)(d0 + (dir < nd ? dir : 0)) * ldq + lrp * 2;
+    }
+    d2 stage[16];
+    TA raw[NA][16];
+    d4 acc[NA][NT];
+#pragma unroll
+    for (int h = 0; h < NA; ++h)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[h][t] = d4{0.0, 0.0, 0.0, 0.0};
+    const int nrb = (M + kRbRows - 1) / kRbRows;
+
+    auto fetch_q = [&](int rb) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) stage[j] = *reinterpret_cast<const d2*>(qsrc[j] + (int64_t)rb * kRbRows);
+    };
+    auto store_q = [&](int buf) {
+        double* dst = qlds + (size_t)buf * kRbDirs * kRbStride + lrp * 2;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int dir = ldir + 8 * j;
+            *reinterpret_cast<d2*>(dst + dir * kRbStride) = dir < nd ? stage[j] : d2{0.0, 0.0};
+        }
+    };
+    auto fetch_a_full = [&](int rb) {
+#pragma unroll
+        for (int h = 0; h < NA; ++h) {
+            if (VEC) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const ta4 x = __builtin_nontemporal_load(reinterpret_cast<const ta4*>(acol[h] + (int64_t)rb * kRbRows) + v);
+#pragma unroll
+                    for (int c = 0; c < PERV; ++c) raw[h][v * PERV + c] = x[c];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) raw[h][e] = acol[h][(int64_t)rb * kRbRows + e];
+            }
+        }
+    };
+    auto fetch_a_last = [&](int rb) {  // row indices clamped into the column; to_operand masks them
+        const int r0 = rb * kRbRows + fq * 16;
+#pragma unroll
+        for (int h = 0; h < NA; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = r0 + e < M ? r0 + e : M - 1;
+                raw[h][e] = acol[h][row - fq * 16];
+            }
+    };
+    auto compute = [&](int buf, const double (&bv)[NA][16]) {
+        const double* src = qlds + (size_t)buf * kRbDirs * kRbStride + fq * 16;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double qv[16];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const d2 x = *reinterpret_cast<const d2*>(src + (t * 16 + fr) * kRbStride + 2 * e);
+                qv[2 * e] = x[0];
+                qv[2 * e + 1] = x[1];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+#pragma unroll
+                for (int h = 0; h < NA; ++h) acc[h][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(qv[kk], bv[h][kk], acc[h][t], 0, 0, 0);
+        }
+    };
+
+    fetch_q(0);
+    if (nrb > 1) fetch_a_full(0); else fetch_a_last(0);
+    store_q(0);
+    __syncthreads();
+    int buf = 0;
+    for (int rb = 0; rb + 1 < nrb; ++rb) {
+        double bv[NA][16];
+#pragma unroll
+        for (int h = 0; h < NA; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[h][e] = (double)raw[h][e];
+        fetch_q(rb + 1);
+        if (rb + 2 < nrb) fetch_a_full(rb + 1); else fetch_a_last(rb + 1);
+        compute(buf, bv);
+        store_q(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    {
+        double bv[NA][16];
+        const int r0 = (nrb - 1) * kRbRows + fq * 16;
+#pragma unroll
+        for (int h = 0; h < NA; ++h)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) bv[h][e] = r0 + e < M ? (double)raw[h][e] : 0.0;
+        compute(buf, bv);
+    }
+    if (a0 >= N) return;
+#pragma unroll
+    for (int h = 0; h < NA; ++h) {
+        double ssum = 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ssum = fma(acc[h][t][reg], acc[h][t][reg], ssum);
+        ssum += shx(ssum, 16);
+        ssum += shx(ssum, 32);
+        if (fq == 0 && a0 + h * 16 + fr < N) rho2[a0 + h * 16 + fr] -= ssum;
+    }
+}
+
 // ---- dictionaries whose columns do not fit the LDS images of k_fr_sweep (8 (1 + NQ) M bytes: M beyond ~10 000 with one direction,
 // ~6 800 with two): the same pass as separate launches -- c = A'r and g = A'q by the product sweep (k_sweep_gen: any M, the
 // residual staged in phases), |a_j|^2 by k_fr_colnorm2 on a solve's first step, then k_fr_combine does what the fused kernel does

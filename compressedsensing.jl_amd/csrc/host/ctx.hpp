@@ -182,6 +182,7 @@ struct csmp_ctx {
     int sweep_KP = 0;       // rows of the residual image in the LDS
     int tick_grid = 0;      // sweep workgroups inside the tick kernel
     int tune_sweep_grid = 0, tune_sweep_U = 0;
+    int tune_rebuild_direct = 0;  // csmp_tune: the oblivious start's Q'A pass reads its directions from L2 (k_fr_rebuild) instead of the LDS
     int tune_swap_refuse = 0;  // csmp_tune: OMPR's inverse-Gram exchanges fail their guard (tests walk the fallback to the QR path)
     int tune_diag_split = 0;  // csmp_tune: fused kernels run as one launch per part (a kernel trace then shows the parts)
     int64_t tune_batch_budget_mib = 0;  // csmp_tune: HBM the batched path's per-signal state may take (MiB), 0 = what is free  // csmp_tune (include/csmp_internal.h): measurement overrides, 0 = automatic

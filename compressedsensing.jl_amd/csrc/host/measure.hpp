@@ -103,6 +103,7 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_sweep_U = (int)value;
             break;
         case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;
+        case CSMP_TUNE_REBUILD_DIRECT: ctx->tune_rebuild_direct = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_SWAP_REFUSE: ctx->tune_swap_refuse = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_DIAG_SPLIT: ctx->tune_diag_split = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_BATCH_BUDGET_MIB: ctx->tune_batch_budget_mib = value; return CSMP_OK;

@@ -83,6 +83,7 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tune_sweep_U = src->tune_sweep_U;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;
+    dst->tune_rebuild_direct = src->tune_rebuild_direct;
 }
 extern "C" int csmp_clone(csmp_ctx* src, csmp_ctx** out) {
     if (!src || !out) return CSMP_EINVAL;

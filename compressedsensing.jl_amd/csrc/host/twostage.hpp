@@ -460,6 +460,27 @@ struct Stepwise {
     }
 };
 
+template <typename TA, bool VEC>
+static hipError_t fr_rebuild_lds_t(csmp_ctx* ctx, int d0, int nd) {
+    Solver& s = ctx->s;
+    auto kern = k_fr_rebuild_lds<TA, VEC>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fr_rebuild_lds_bytes());
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((ctx->N + 127) / 128)), dim3(256), fr_rebuild_lds_bytes(), ctx->stream, (const TA*)ctx->dA, ctx->ld,
+                       (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, d0, nd, s.rho2);
+    return hipGetLastError();
+}
+static int launch_fr_rebuild_lds(csmp_ctx* ctx, int d0, int nd) {
+    // 16-byte loads of a column's rows need the column starts on 16-byte boundaries
+    const size_t esz = ctx->dtype == CSMP_F32 ? 4 : 8;
+    const bool vec = ((uintptr_t)ctx->dA % 16 == 0) && ((size_t)ctx->ld * esz) % 16 == 0;
+    hipError_t e;
+    if (ctx->dtype == CSMP_F32) e = vec ? fr_rebuild_lds_t<float, true>(ctx, d0, nd) : fr_rebuild_lds_t<float, false>(ctx, d0, nd);
+    else e = vec ? fr_rebuild_lds_t<double, true>(ctx, d0, nd) : fr_rebuild_lds_t<double, false>(ctx, d0, nd);
+    HIPCHECK(e);
+    return CSMP_OK;
+}
+
 static int stepwise_args(csmp_ctx* ctx, const void* b, const char* who) {
     if (!ctx) return CSMP_EINVAL;
     if (!b) return fail(ctx, CSMP_EINVAL, (std::string(who) + ": b == NULL").c_str());
@@ -506,6 +527,10 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
             const int grid = (int)((ctx->N + 127) / 128);  // 4 waves x 32 atoms
             for (int64_t t = 0; t < k; t += 128) {
                 const int nd = (int)std::min<int64_t>(128, k - t);
+                if (nd > 64 && !ctx->tune_rebuild_direct) {  // most of a 128-direction pass is real work: stage the directions in the LDS
+                    CHECK(launch_fr_rebuild_lds(ctx, (int)t, nd));
+                    continue;
+                }
                 if (ctx->dtype == CSMP_F32)
                     hipLaunchKernelGGL(k_fr_rebuild<float>, dim3(grid), dim3(256), 0, ctx->stream, (const float*)ctx->dA, ctx->ld,
                                        (int)ctx->M, ctx->N, (const double*)s.Q, s.ldq, (int)t, nd, s.rho2);

@@ -29,6 +29,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_SWEEP_GRID 2   /* workgroups of the product sweep */
 #define CSMP_TUNE_SWEEP_UNIT 3   /* loads per unit (16, 8 or 4) */
 #define CSMP_TUNE_TICK_GRID 4    /* sweep workgroups inside the tick kernel of csmp_omp_batch */
+#define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */
 #define CSMP_TUNE_BATCH_BUDGET_MIB 5 /* csmp_omp_batch_mfma: HBM (MiB) its per-signal state may take -- a test's stand-in for a full device */

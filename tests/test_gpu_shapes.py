@@ -300,3 +300,25 @@ def test_ompr_exchange_guard_falls_back_to_the_qr_path(cs, oracle):
             d.ctx.tune("swap_refuse", 0)
         assert np.array_equal(fb[0], ref[0]) and close(fb[1], ref[1]) and fb[2] == ref[2]
     d.close()
+
+
+@pytest.mark.parametrize("case", [(1000, 1500, 80, np.float32), (1001, 900, 130, np.float32), (1003, 700, 70, np.float64),
+                                  (4096, 2048, 200, np.float32), (640, 1000, 128, np.float64)])
+def test_srr_oblivious_start_beyond_64_atoms(cs, oracle, case):
+    """srr(initialization = 1) with k > 64 (src/twostage.jl:11-13: oblivious_acquisition!, then the stepwise loop on the factorised
+    set): rho2_j = |a_j|^2 - |Q'a_j|^2 for all N columns is a 128-direction Float64 MFMA pass with Q staged in the LDS
+    (k_fr_rebuild_lds); ragged row counts and column starts off the 16-byte grid take its scalar-load form.  Against the oracle,
+    and against the same solve with the directions read from L2 per wave (csmp_tune rebuild_direct), which must agree bit for bit."""
+    M, N, k, dtype = case
+    A = gaussian(M, N, dtype, M + N + k)
+    d = cs.Dictionary(A)
+    y = planted(A, k + 2, 9, noise=0.2)
+    ref = oracle.srr(A, y, k, 1e-12, 6, 1, 1)
+    got = d.ctx.srr(y, k, 1e-12, 6, 1, 1)
+    assert np.array_equal(got[0], ref[0]), (got[0][:8], ref[0][:8])
+    assert close(got[1], ref[1], 1e-7) and got[2] == ref[2]
+    d.ctx.tune("rebuild_direct", 1)
+    alt = d.ctx.srr(y, k, 1e-12, 6, 1, 1)
+    d.ctx.tune("rebuild_direct", 0)
+    assert np.array_equal(alt[0], got[0]) and np.array_equal(alt[1], got[1]) and alt[2] == got[2]
+    d.close()
