@@ -340,11 +340,12 @@ struct Stepwise {
     int last_added = -1, last_removed = -1;  // atoms moved by the last successful forward / backward step
     DevState hs;
 
-    int read_state(int* also_int = nullptr, const int* also_dev = nullptr) {
+    int read_state(int* also_int = nullptr, const int* also_dev = nullptr, double* also_dbl = nullptr, const double* dbl_dev = nullptr) {
         Solver& s = ctx->s;
         PinFetch f(ctx);
-        CHECK(f.begin(sizeof hs + 16));
+        CHECK(f.begin(sizeof hs + 32));
         if (also_int) CHECK(f.add(also_int, also_dev, sizeof(int)));
+        if (also_dbl) CHECK(f.add(also_dbl, dbl_dev, sizeof(double)));
         CHECK(f.add(&hs, s.st, sizeof hs));
         return f.wait();
     }
@@ -424,7 +425,8 @@ struct Stepwise {
         return CSMP_OK;
     }
     // backward_step!(P, x, max_eps, max_delta); lace: LACE's candidate rule (least |x_i|)
-    int backward(double max_eps, double max_d2, bool* ok, bool lace = false) {
+    // norm2: ||r||^2 after the step rides in the same landing (srr measures it once per iteration, right after its last removal)
+    int backward(double max_eps, double max_d2, bool* ok, bool lace = false, double* norm2 = nullptr) {
         Solver& s = ctx->s;
         *ok = false;
         if (n <= 0) return CSMP_OK;
@@ -437,7 +439,11 @@ struct Stepwise {
                            lace ? (const double*)s.bwd_coef : (const double*)nullptr);
         HIPCHECK(hipGetLastError());
         CHECK(launch_delete_t(ctx));
-        CHECK(read_state(&last_removed, s.delmeta + 2));
+        if (norm2) {
+            hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+            HIPCHECK(hipGetLastError());
+        }
+        CHECK(read_state(&last_removed, s.delmeta + 2, norm2, s.scal));
         if (hs.nsel == n) return CSMP_OK;  // the thresholds (or the lack of a finite score) kept every atom
         for (Pend& e : pend)
             if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_tdel_apply kept a copy
@@ -573,9 +579,11 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
             if (!ok) break;
             added.push_back(P.last_added);
         }
+        double n2 = -1.0;  // ||r||^2 as the last removal left it (k_norm2 in that step's own landing), if there was one
         while (P.n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
             bool ok;
-            CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok));
+            n2 = -1.0;
+            CHECK(P.backward((double)HUGE_VAL, (double)HUGE_VAL, &ok, false, P.n == k + 1 ? &n2 : nullptr));
             if (!ok) break;
             removed.push_back(P.last_removed);
         }
@@ -585,6 +593,8 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
         // old one (:27-28 then stops).  Measuring it instead would compare two roundings of the same number.
         if (added == removed)
             resnorm = oldnorm;
+        else if (n2 >= 0.0 && P.n == k)
+            resnorm = std::sqrt(n2);  // :27
         else
             CHECK(residual_norm(ctx, &resnorm));  // :27
         ++it;
