@@ -139,6 +139,10 @@ def headline(out):
         o["cpu_baseline"] = {k: (c[k][:160] if isinstance(c[k], str) else c[k]) for k in ("value", "unit", "cores", "kind", "sample", "selection_order_matches_gpu", "error") if k in c}
     if isinstance(o.get("secondary"), dict):
         o["secondary"] = {name: (blk.get("value") if isinstance(blk, dict) and "error" not in blk else None) for name, blk in out["secondary"].items()}
+        for nm in ("ompr_8f2", "srr_8f2"):  # the same solves three in flight (the headline itself is three signals pipelined)
+            blk = out["secondary"].get(nm)
+            if isinstance(blk, dict) and isinstance(blk.get("three_in_flight"), dict):
+                o["secondary"][nm + "_three_in_flight"] = blk["three_in_flight"]["solves_per_s"]
         b3 = out["secondary"].get("batched_c3")
         if isinstance(b3, dict) and "roofline_composite" in b3:  # the batched step against BOTH of its ceilings (verdict round 4, item 7)
             o["secondary"]["batched_c3_frac_of_mfma_only_ceiling"] = b3["roofline"]["whole_step"]["frac"]

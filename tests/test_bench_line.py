@@ -34,7 +34,8 @@ def test_headline_is_compact_and_complete():
     for k in ("value", "unit", "cores", "kind", "sample", "selection_order_matches_gpu"):
         assert k in o["cpu_baseline"], k
     # one scalar per secondary workload, no nested blocks, no prose
-    assert set(o["secondary"]) == set(out["secondary"])
+    derived = {k for k in o["secondary"] if k.endswith("_three_in_flight") or k.startswith("batched_c3_frac_of_")}
+    assert set(o["secondary"]) - derived == set(out["secondary"])
     assert all(v is None or isinstance(v, (int, float)) for v in o["secondary"].values())
     assert "note" not in line
 
@@ -69,12 +70,14 @@ def test_headline_carries_both_ceilings_of_the_batched_step_and_the_device_resid
     assert abs(comp["mfma_floor_us"] - 219.9) < 0.5 and abs(comp["hbm_floor_us"] - 283.75) < 0.5
     assert abs(comp["frac"] - (219.9 + 283.75) / 795.0) < 2e-3 and 1.9e6 < comp["ceiling_atoms_per_s"] < 2.1e6
     sec = {"batched_c3": {"value": 1.29e6, "roofline": {"whole_step": {"frac": 0.277}}, "roofline_composite": comp},
-           "lone_omp_c2_device": {"value": 5900.0}, "lone_omp_c2": {"value": 5750.0}}
+           "lone_omp_c2_device": {"value": 5900.0}, "lone_omp_c2": {"value": 5750.0},
+           "srr_8f2": {"value": 45.0, "three_in_flight": {"solves": 9, "solves_per_s": 62.5}}, "ompr_8f2": {"value": 66.0}}
     o = json.loads(bench.headline({"metric": "m", "value": 1.0, "unit": "atoms/s", "secondary": sec,
                                    "roofline": {"bound": "hbm", "avg_launch_us": 160.0, "event_pair_us": 2.1, "kernel": "k"}}))
     assert o["secondary"]["batched_c3_frac_of_mfma_only_ceiling"] == 0.277
     assert abs(o["secondary"]["batched_c3_frac_of_composite_ceiling"] - comp["frac"]) < 1e-5
     assert o["secondary"]["lone_omp_c2_device"] == 5900.0
+    assert o["secondary"]["srr_8f2"] == 45.0 and o["secondary"]["srr_8f2_three_in_flight"] == 62.5 and "ompr_8f2_three_in_flight" not in o["secondary"]
     assert all(v is None or isinstance(v, (int, float)) for v in o["secondary"].values())
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "profile_overhead" in src and "statistical_int8" not in src.split("def main()")[1].split("for name, cert, gram, scr in")[1][:400]
