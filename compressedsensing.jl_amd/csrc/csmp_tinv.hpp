@@ -244,9 +244,11 @@ __global__ __launch_bounds__(256) void k_emit_sorted(const double* __restrict__ 
 // the numbers "x.nzval = P.Ar[x.nzind]" needs (src/twostage.jl:166).  It was three launches: the support going up, k_select, k_gather.
 __global__ __launch_bounds__(256) void k_ompr_pick(const double* __restrict__ pval, const int* __restrict__ pidx, int nblk,
                                                    const double* __restrict__ cvec, DevState* st, const int64_t* __restrict__ sorted_idx,
-                                                   int k, double* __restrict__ cs) {
+                                                   int k, double* __restrict__ cs, const double* __restrict__ sorted_val,
+                                                   const int* __restrict__ sel, int* __restrict__ meta) {
     __shared__ double sv[256];
     __shared__ int si[256];
+    __shared__ int cnt[2];
     const int tid = threadIdx.x;
     double bv = -1.0;
     int bi = 0x7fffffff;
@@ -262,6 +264,62 @@ __global__ __launch_bounds__(256) void k_ompr_pick(const double* __restrict__ pv
         st->cval = cvec[bi];
         st->j = st->nsel;
         st->go = 1;
+    }
+    if (!meta) return;
+    // ... and the decision itself (src/twostage.jl:158-171), so that the exchange can be queued behind this kernel without a trip
+    // to the host: x[i] = NaN; x.nzval = Ar[x.nzind]; the FIRST entry of smallest magnitude leaves.
+    //   meta[0] = 1 exchange (meta[1] leaves, meta[2] joins, meta[3] = the leaving atom's slot in sel), 0 nothing changes (no
+    //   candidate, or the candidate itself is the smallest), 2 the arg-max lies inside the support (the host scans: :139-155)
+    const double ccand = cvec[bi];
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+    int below = 0, inside = 0;
+    for (int t = tid; t < k; t += 256) {
+        const int64_t a = sorted_idx[t];
+        below += a < bi;
+        inside += a == bi;
+    }
+    if (below) atomicAdd(&cnt[0], below);
+    if (inside) atomicAdd(&cnt[1], inside);
+    __syncthreads();
+    const int pos = cnt[0];
+    if (cnt[1] || !(fabs(ccand) > 0.0)) {
+        if (tid == 0) meta[0] = cnt[1] ? 2 : 0;
+        return;
+    }
+    // merged order: support entry t sits at t + (t >= pos), the candidate at pos; ties go to the lower merged index
+    double mv = -__builtin_inf();
+    int mi = 0x7fffffff;
+    for (int t = tid; t <= k; t += 256) {
+        double v;
+        int at;
+        if (t == k) {
+            v = ccand;
+            at = pos;
+        } else {
+            v = sorted_val[t] + cvec[sorted_idx[t]];
+            at = t + (t >= pos);
+        }
+        if (better(-fabs(v), at, mv, mi)) {
+            mv = -fabs(v);
+            mi = at;
+        }
+    }
+    block_argmax(mv, mi, sv, si);
+    // (the host loop starts from entry 0 whatever it is: a NaN there is never displaced)
+    const double v0 = pos == 0 ? ccand : sorted_val[0] + cvec[sorted_idx[0]];
+    if (v0 != v0) mi = 0;
+    if (mi == pos) {
+        if (tid == 0) meta[0] = 0;
+        return;
+    }
+    const int leaving = (int)sorted_idx[mi < pos ? mi : mi - 1];
+    for (int t = tid; t < k; t += 256)
+        if (sel[t] == leaving) meta[3] = t;
+    if (tid == 0) {
+        meta[0] = 1;
+        meta[1] = leaving;
+        meta[2] = bi;
     }
 }
 // ... and after it: the atom that leaves -> its insertion position (k_find_pos), the atom that joins -> the append's candidate list

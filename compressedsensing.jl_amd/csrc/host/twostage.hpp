@@ -17,6 +17,8 @@ struct OmprJob {
     bool gram = false;
     std::vector<int> slot;  // the atom in every slot of H (device: s.sel)
     double *dG = nullptr, *dUpart = nullptr, *dU = nullptr, *dHp = nullptr, *dC = nullptr, *dInfo = nullptr, *dRpart = nullptr, *dN2 = nullptr;
+    int* dMeta = nullptr;         // the exchange the chain performs: (1, leaving, joining, slot), csmp_swap.hpp
+    unsigned* dCounter = nullptr; // k_swap_ufin's workgroup count (zero between launches)
     int nchk = 0, nchm = 0, nshare = 0;
 
     // H = (A_S'A_S)^-1 = T T' from the explicit inverse factor the acquisition built, c = A_S'b, x in slot order (s.bwd_coef)
@@ -42,9 +44,12 @@ struct OmprJob {
         dInfo = dC + kk;
         dRpart = dInfo + 8;
         dN2 = dRpart + (size_t)nchm * M;
+        dMeta = reinterpret_cast<int*>(dInfo + 4);          // (info uses three of its eight doubles)
+        dCounter = reinterpret_cast<unsigned*>(dInfo + 6);
+        HIPCHECK(hipMemsetAsync(dInfo, 0, 8 * sizeof(double), ctx->stream));
         hipLaunchKernelGGL(k_swap_init, dim3((kk * kk + 255) / 256), dim3(256), 0, ctx->stream, (const double*)s.T, s.kcap, kk, s.swapH);
         hipLaunchKernelGGL((k_swap_dots<TA, double>), dim3((kk + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, kk,
-                           (const double*)s.b, (const double*)s.b, 0, dC);
+                           (const double*)s.b, (const double*)s.b, 0, dC, (const int*)nullptr);
         HIPCHECK(hipGetLastError());
         slot.assign((size_t)kk, 0);
         HIPCHECK(hipMemcpyAsync(slot.data(), s.sel, (size_t)kk * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -52,44 +57,77 @@ struct OmprJob {
         gram = true;
         return CSMP_OK;
     }
-    // one exchange: `leaving` out, `joining` in; *refused: the guard did not hold and nothing was changed
+    // the exchange dMeta names, queued on the stream (every kernel of it returns at once unless dMeta[0] == 1)
     template <typename TA>
-    int gram_swap_t(int leaving, int joining, bool* refused) {
+    int gram_chain_t() {
         Solver& s = ctx->s;
         const int kk = (int)k, M = (int)ctx->M;
+        const int ncommit = (kk * kk + 255) / 256, nrb = (M + 255) / 256;
+        hipLaunchKernelGGL((k_swap_dots<TA, TA>), dim3((kk + 2 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, kk,
+                           (const TA*)ctx->dA, (const double*)s.b, 2, dG, (const int*)dMeta);
+        hipLaunchKernelGGL(k_swap_ufin, dim3(nchk), dim3(256), (size_t)kk * sizeof(int), ctx->stream, (const double*)s.swapH, s.kcap, kk, (const int*)dMeta,
+                           (const double*)dG, dUpart, nchk, dCounter, dU, s.bwd_coef, dC, s.sel, dHp, dInfo, s.out_idx, s.out_val, s.out_nnz,
+                           ctx->tune_swap_refuse ? 2.0 : 1e-6);
+        hipLaunchKernelGGL(k_swap_commit_res<TA>, dim3(ncommit + nrb * nchm), dim3(256), 0, ctx->stream, s.swapH, s.kcap, kk, (const int*)dMeta, (const double*)dU,
+                           (const double*)dHp, (const double*)dInfo, ncommit, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, (const double*)s.bwd_coef, nrb,
+                           dRpart);
+        hipLaunchKernelGGL(k_swap_rsum, dim3(nshare), dim3(256), 0, ctx->stream, (const double*)dRpart, nchm, M, (const double*)s.b, s.r, (const double*)dInfo, dN2,
+                           (const int*)dMeta);
+        HIPCHECK(hipGetLastError());
+        return CSMP_OK;
+    }
+    int gram_chain() { return ctx->dtype == CSMP_F32 ? gram_chain_t<float>() : gram_chain_t<double>(); }
+    // what the chain left: the pieces of one landing
+    struct SwapLanding {
+        std::vector<int64_t> hi;
+        std::vector<double> hv, n2;
+        double info[4] = {0, 0, 0, 0};
+        int meta[4] = {0, 0, 0, 0};
+    };
+    int gram_land_add(PinFetch& f, SwapLanding& L) {
+        Solver& s = ctx->s;
+        const int kk = (int)k;
+        L.hi.assign((size_t)kk, 0);
+        L.hv.assign((size_t)kk, 0.0);
+        L.n2.assign((size_t)nshare, 0.0);
+        CHECK(f.add(L.hi.data(), s.out_idx, (size_t)kk * 8));
+        CHECK(f.add(L.hv.data(), s.out_val, (size_t)kk * 8));
+        CHECK(f.add(L.n2.data(), dN2, (size_t)nshare * 8));
+        CHECK(f.add(L.info, dInfo, 32));
+        CHECK(f.add(L.meta, dMeta, 16));
+        return CSMP_OK;
+    }
+    size_t gram_land_bytes() const { return (size_t)k * 16 + (size_t)nshare * 8 + 128; }
+    // the exchange went through: x, the slot's owner and ||r|| are the exchange's
+    void gram_accept(const SwapLanding& L) {
+        slot[(size_t)L.meta[3]] = L.meta[2];
+        xi.assign(L.hi.begin(), L.hi.end());
+        xv.assign(L.hv.begin(), L.hv.end());
+        double t = 0.0;
+        for (double v : L.n2) t += v;
+        resnorm = std::sqrt(t);
+    }
+    // one exchange named by the host: `leaving` out, `joining` in; *refused: the guard did not hold and nothing was changed
+    int gram_swap(int leaving, int joining, bool* refused) {
+        const int kk = (int)k;
         const int p = (int)(std::find(slot.begin(), slot.end(), leaving) - slot.begin());
         if (p >= kk) return fail(ctx, CSMP_ESTATE, "ompr: the leaving atom is not in the support");
-        hipLaunchKernelGGL((k_swap_dots<TA, TA>), dim3((kk + 2 + 3) / 4), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel, kk,
-                           (const TA*)ctx->dA + (int64_t)joining * ctx->ld, (const double*)s.b, 2, dG);
-        hipLaunchKernelGGL(k_swap_upart, dim3((kk + 63) / 64, nchk), dim3(64), 0, ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, dUpart);
-        hipLaunchKernelGGL(k_swap_fin, dim3(1), dim3(256), (size_t)kk * sizeof(int), ctx->stream, (const double*)s.swapH, s.kcap, kk, p, (const double*)dG, (const double*)dUpart, nchk,
-                           dU, s.bwd_coef, dC, s.sel, joining, dHp, dInfo, s.out_idx, s.out_val, s.out_nnz, ctx->tune_swap_refuse ? 2.0 : 1e-6);
-        hipLaunchKernelGGL(k_swap_commit, dim3((kk * kk + 255) / 256), dim3(256), 0, ctx->stream, s.swapH, s.kcap, kk, p, (const double*)dU, (const double*)dHp,
-                           (const double*)dInfo);
-        hipLaunchKernelGGL(k_residual_part<TA>, dim3((M + 255) / 256, nchm), dim3(256), 0, ctx->stream, (const TA*)ctx->dA, ctx->ld, M, (const int*)s.sel,
-                           (const double*)s.bwd_coef, kk, dRpart);
-        hipLaunchKernelGGL(k_swap_rsum, dim3(nshare), dim3(256), 0, ctx->stream, (const double*)dRpart, nchm, M, (const double*)s.b, s.r, (const double*)dInfo, dN2);
+        void* pv = nullptr;
+        CHECK(pin_get(ctx, 2, 16, &pv));
+        int* m = (int*)pv;
+        m[0] = 1; m[1] = leaving; m[2] = joining; m[3] = p;
+        hipLaunchKernelGGL(k_put_ints, dim3(1), dim3(256), 0, ctx->stream, (const int*)m, 4, dMeta);
         HIPCHECK(hipGetLastError());
-        std::vector<int64_t> hi((size_t)kk);
-        std::vector<double> hv((size_t)kk), n2((size_t)nshare);
-        double info[4] = {0, 0, 0, 0};
+        CHECK(gram_chain());
+        SwapLanding L;
         {
             PinFetch f(ctx);
-            CHECK(f.begin((size_t)kk * 16 + (size_t)nshare * 8 + 64));
-            CHECK(f.add(hi.data(), s.out_idx, (size_t)kk * 8));
-            CHECK(f.add(hv.data(), s.out_val, (size_t)kk * 8));
-            CHECK(f.add(n2.data(), dN2, (size_t)nshare * 8));
-            CHECK(f.add(info, dInfo, 32));
+            CHECK(f.begin(gram_land_bytes()));
+            CHECK(gram_land_add(f, L));
             CHECK(f.wait());
         }
-        *refused = info[2] != 0.0;
-        if (*refused) return CSMP_OK;
-        slot[(size_t)p] = joining;
-        xi.assign(hi.begin(), hi.end());
-        xv.assign(hv.begin(), hv.end());
-        double t = 0.0;
-        for (double v : n2) t += v;
-        resnorm = std::sqrt(t);
+        *refused = L.info[2] != 0.0;
+        if (!*refused) gram_accept(L);
         return CSMP_OK;
     }
     // the guard refused an exchange: back to the factorisation of the CURRENT support (as the acquisition builds it); the
@@ -162,6 +200,37 @@ struct OmprJob {
         }
         return residual_norm(ctx, &resnorm);
     }
+    // the exchange on the factorisation (the rotation path, or a fresh factorisation beyond its capacity); x and, in explicit-
+    // inverse mode, ||r|| come back in one synchronisation
+    int exchange_on_factor(int leaving, int cand, bool* have_norm) {
+        Solver& s = ctx->s;
+        if (use_downdate) {
+            // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
+            // (one launch names both atoms: the one that leaves -> its position, the one that joins -> the append's list)
+            hipLaunchKernelGGL(k_swap_prep, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, leaving, cand,
+                               s.delpos, s.cands, s.ncands);
+            HIPCHECK(hipGetLastError());
+            if (tmode)
+                CHECK(launch_delete_t(ctx));
+            else
+                CHECK(launch_delete(ctx));
+            CHECK(launch_append(ctx, 2, 0, 0));
+            if (tmode) CHECK(launch_tinv_append(ctx));
+        } else {
+            std::vector<int> cols;
+            for (int64_t a : xi)
+                if (a != leaving) cols.push_back((int)a);
+            cols.insert(std::lower_bound(cols.begin(), cols.end(), cand), cand);
+            CHECK(ls_on_columns(ctx, cols));  // :178
+        }
+        if (tmode) {
+            CHECK(fetch_sorted_t(ctx, xi, xv, &resnorm));  // :178 and :196 in one synchronisation
+            *have_norm = true;
+        } else {
+            CHECK(fetch_sorted(ctx, xi, xv));
+        }
+        return CSMP_OK;
+    }
     // update!(P::OMPR, x) with eta = 1 (:134-180) and the norm(residual!(P, x)) the driver takes after it (:196)
     int update() {
         Solver& s = ctx->s;
@@ -169,6 +238,10 @@ struct OmprJob {
         // Ar = x + A'r, arg-max over atoms outside the support
         std::vector<int> cur(xi.begin(), xi.end());
         DevState hs;
+        // On the inverse Gram matrix with exact sweeps the "which entry leaves" decision is taken on the device too (k_ompr_pick) and
+        // the exchange is queued behind it: ONE landing per update! carries the decision and its outcome.
+        const bool fast = gram && !screened;
+        SwapLanding L;
         for (int attempt = 0; attempt < 2; ++attempt) {
             const bool scr = screened && attempt == 0;
             if (scr) {
@@ -184,14 +257,17 @@ struct OmprJob {
                 // (the sorted support is on the device already: the index list the last k_emit_sorted wrote)
                 CHECK(launch_sweep(ctx, s.r, 0.0, 0, 0));
                 hipLaunchKernelGGL(k_ompr_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.pval, (const int*)s.pidx, ctx->sweep_grid,
-                                   (const double*)s.cvec, s.st, (const int64_t*)s.out_idx, (int)k, s.coef);
+                                   (const double*)s.cvec, s.st, (const int64_t*)s.out_idx, (int)k, s.coef, (const double*)s.out_val, (const int*)s.sel,
+                                   fast ? dMeta : (int*)nullptr);
                 HIPCHECK(hipGetLastError());
+                if (fast) CHECK(gram_chain());
             }
             {
                 PinFetch f(ctx);
-                CHECK(f.begin((size_t)k * 8 + sizeof hs + 16));
+                CHECK(f.begin((size_t)k * 8 + sizeof hs + 16 + (fast ? gram_land_bytes() : 0)));
                 CHECK(f.add(cs.data(), s.coef, (size_t)k * 8));
                 CHECK(f.add(&hs, s.st, sizeof hs));
+                if (fast) CHECK(gram_land_add(f, L));
                 CHECK(f.wait());
             }
             if (!scr) break;
@@ -201,6 +277,19 @@ struct OmprJob {
             if (hs.uncertain != unc_seen) ctx->scr_fallbacks += 1;
             unc_seen = hs.uncertain;  // (repeat with the exact sweep: it also leaves the correlation vector the degenerate case scans)
         }
+        if (fast && L.meta[0] == 0) return CSMP_OK;  // no candidate, or the candidate itself was the smallest entry: nothing changed (:171)
+        if (fast && L.meta[0] == 1) {
+            if (L.info[2] == 0.0) {
+                gram_accept(L);
+                return CSMP_OK;
+            }
+            // the guard refused: the same exchange on the factorisation of the current support, which carries the rest of the solve
+            CHECK(gram_leave());
+            CHECK(exchange_on_factor(L.meta[1], L.meta[2], &have_norm));
+            if (!have_norm) CHECK(residual_norm(ctx, &resnorm));
+            return CSMP_OK;
+        }
+        // (fast with L.meta[0] == 2: the arg-max lies inside the support -- nothing was queued; the host scans below)
         int64_t cand = hs.cand;
         double ccand = hs.cval;
         if (std::binary_search(xi.begin(), xi.end(), cand)) {
@@ -238,36 +327,11 @@ struct OmprJob {
                 const int leaving = (int)(jmin < pos ? xi[jmin] : xi[jmin - 1]);
                 if (gram) {
                     bool refused = false;
-                    CHECK(ctx->dtype == CSMP_F32 ? gram_swap_t<float>(leaving, (int)cand, &refused) : gram_swap_t<double>(leaving, (int)cand, &refused));
+                    CHECK(gram_swap(leaving, (int)cand, &refused));
                     if (!refused) return CSMP_OK;  // (x, r and ||r|| are the exchange's)
                     CHECK(gram_leave());
                 }
-                if (use_downdate) {
-                    // remove_column! + add_column! (:172-176) as a Givens down-date and a Gram-Schmidt append
-                    // (one launch names both atoms: the one that leaves -> its position, the one that joins -> the append's list)
-                    hipLaunchKernelGGL(k_swap_prep, dim3(1), dim3(256), 0, ctx->stream, (const int*)s.sel, (const DevState*)s.st, leaving, (int)cand,
-                                       s.delpos, s.cands, s.ncands);
-                    HIPCHECK(hipGetLastError());
-                    if (tmode)
-                        CHECK(launch_delete_t(ctx));
-                    else
-                        CHECK(launch_delete(ctx));
-                    CHECK(launch_append(ctx, 2, 0, 0));
-                    if (tmode) CHECK(launch_tinv_append(ctx));
-                } else {
-                    std::vector<int> cols;
-                    for (size_t t = 0; t <= xi.size(); ++t) {
-                        if (t == jmin) continue;
-                        cols.push_back(t == pos ? (int)cand : (int)(t < pos ? xi[t] : xi[t - 1]));
-                    }
-                    CHECK(ls_on_columns(ctx, cols));  // :178
-                }
-                if (tmode) {
-                    CHECK(fetch_sorted_t(ctx, xi, xv, &resnorm));  // :178 and :196 in one synchronisation
-                    have_norm = true;
-                } else {
-                    CHECK(fetch_sorted(ctx, xi, xv));
-                }
+                CHECK(exchange_on_factor(leaving, (int)cand, &have_norm));
             }
         }
         // :196.  An update! that changed nothing leaves x, hence residual!(P, x) and its norm, exactly where they were (the
