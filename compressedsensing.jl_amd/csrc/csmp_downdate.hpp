@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_bwd_pick(const double* __restrict__ sc,
                                                   const DevState* st, const double* __restrict__ r, int M,
                                                   double max_eps, double max_d2, int* __restrict__ delpos,
                                                   double* __restrict__ info /* [0]=min δ², [1]=|r|^2 */,
-                                                  const double* __restrict__ coef = nullptr) {
+                                                  const double* __restrict__ coef = nullptr, int skipmask = 0, int need_n = -1) {
     __shared__ double sv[256];
     __shared__ int si[256], sp[256];
     __shared__ double red[4];
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256) void k_bwd_pick(const double* __restrict__ sc,
     }
     if (tid == 0) {
         const double mn = (coef && sp[0] >= 0) ? sc[sp[0]] : sv[0];
-        const bool drop = n > 0 && sp[0] >= 0 && sqrt(mn + n2) < max_eps && mn < max_d2;
+        // (skipmask, need_n: a backward step queued behind a forward step the host has not seen yet drops nothing unless that step
+        // went through -- no stop flag, the support one atom larger)
+        const bool gated = (st->done & skipmask) || (need_n >= 0 && n != need_n);
+        const bool drop = !gated && n > 0 && sp[0] >= 0 && sqrt(mn + n2) < max_eps && mn < max_d2;
         *delpos = drop ? sp[0] : -1;
         info[0] = mn;
         info[1] = n2;

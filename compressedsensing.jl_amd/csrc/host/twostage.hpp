@@ -480,6 +480,55 @@ struct Stepwise {
         *ok = true;
         return CSMP_OK;
     }
+    // forward_step!(P, x, 0, 0) and, if it went through, backward_step!(P, x, Inf, Inf) right behind it -- srr's iteration with
+    // l = 1 (src/twostage.jl:21-26) -- as ONE queue of launches and ONE landing: the backward step is gated on the device
+    // (k_bwd_pick: no stop flag of the forward step, n0 + 1 atoms), so the host does not have to see the forward step's outcome
+    // before it queues it.  *norm2: ||r||^2 after the removal.
+    int forward_backward(bool* fok, bool* bok, double* norm2) {
+        Solver& s = ctx->s;
+        const int skipF = STOP_EPS | STOP_STAG | STOP_FULL;
+        const int n0 = n;
+        *fok = *bok = false;
+        CHECK(launch_fr_pass(ctx, pass_of(0), 0.0, skipF));
+        CHECK(launch_append(ctx, 3, 0, skipF, false, 0.0, s.fr_grid));
+        CHECK(launch_tinv_append(ctx));
+        // (a forward step that went through leaves {the last column} pending: no q_drop among it, nothing to flush)
+        CHECK(launch_tinv_solve(ctx));
+        hipLaunchKernelGGL(k_bwd_pick, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.bwd, (const int*)s.sel,
+                           (const DevState*)s.st, (const double*)s.r, (int)ctx->M, (double)HUGE_VAL, (double)HUGE_VAL, s.delpos, s.bwd_info,
+                           (const double*)nullptr, skipF, n0 + 1);
+        HIPCHECK(hipGetLastError());
+        CHECK(launch_delete_t(ctx));
+        hipLaunchKernelGGL(k_norm2, dim3(1), dim3(256), 0, ctx->stream, (const double*)s.r, (int)ctx->M, s.scal);
+        HIPCHECK(hipGetLastError());
+        CHECK(read_state(&last_removed, s.delmeta + 2, norm2, s.scal));
+        if (hs.done & skipF) {  // the forward step failed (as in forward()); nothing was removed
+            if (!(hs.done & STOP_EPS)) {
+                pend.clear();
+                unmark = false;
+                rho_ready = true;
+                last_max_d2 = hs.cval;
+            }
+            CHECK(clear_flags());
+            return CSMP_OK;
+        }
+        *fok = true;
+        last_max_d2 = hs.cval;
+        last_added = hs.cand;
+        rho_ready = true;
+        pend.clear();
+        unmark = false;
+        pend.push_back({nullptr, -1.0});
+        n = n0 + 1;
+        if (hs.nsel == n) return CSMP_OK;  // (no finite score: every atom stays)
+        for (Pend& e : pend)
+            if (!e.q) e.q = s.qsave;  // the appended column has been rotated; k_tdel_apply kept a copy
+        pend.push_back({s.qdrop, 1.0});
+        unmark = true;
+        n = hs.nsel;
+        *bok = true;
+        return CSMP_OK;
+    }
     // applies the pending corrections now (needed before a second removal reuses the q_drop buffer)
     int flush() {
         if (pend.empty() && !unmark) return CSMP_OK;
@@ -637,13 +686,21 @@ static int srr_impl(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double
     while (it < maxiter) {  // :19
         const double oldnorm = resnorm;
         std::vector<int> added, removed;
-        for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
-            bool ok;
-            CHECK(P.forward(0.0, 0.0, true, &ok));
-            if (!ok) break;
-            added.push_back(P.last_added);
-        }
         double n2 = -1.0;  // ||r||^2 as the last removal left it (k_norm2 in that step's own landing), if there was one
+        if (l == 1 && P.n == k) {  // the usual iteration: one atom in, one out, queued together
+            bool fok, bok;
+            CHECK(P.forward_backward(&fok, &bok, &n2));
+            if (fok) added.push_back(P.last_added);
+            if (bok) removed.push_back(P.last_removed);
+            else n2 = -1.0;
+        } else {
+            for (int64_t f = 0; f < l; ++f) {  // :21-23  forward_step!(P, x, 0, 0) || break
+                bool ok;
+                CHECK(P.forward(0.0, 0.0, true, &ok));
+                if (!ok) break;
+                added.push_back(P.last_added);
+            }
+        }
         while (P.n > k) {  // :24-26  backward_step!(P, x, Inf, Inf)
             bool ok;
             n2 = -1.0;
