@@ -198,7 +198,21 @@ __device__ __forceinline__ void sweep_body_gen(
                 return;
             }
         } else {
-            for (int m = tid; m < Mst; m += kSweepThreads) lds[r_slot<VEC>(m)] = (k0 + m < Mv) ? r[k0 + m] : 0.0;
+            // (16 loads at a time, as above: one by one a stage of 16 384 rows is 64 dependent trips per thread)
+            constexpr int RP = 16;
+            for (int m0 = tid; m0 < Mst; m0 += RP * kSweepThreads) {
+                double rv[RP];
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const int m = m0 + q * kSweepThreads;
+                    rv[q] = k0 + m < Mv ? r[k0 + m] : 0.0;
+                }
+#pragma unroll
+                for (int q = 0; q < RP; ++q) {
+                    const int m = m0 + q * kSweepThreads;
+                    if (m < Mst) lds[r_slot<VEC>(m)] = rv[q];
+                }
+            }
             __syncthreads();
         }
         const bool lastph = !PH || ph + 1 == nph;
