@@ -1016,7 +1016,7 @@ def run_shapes(args, cs, torch, np, dev):
 def tick_kernel_name(D):
     """the symbol of the steady-state tick for this dictionary, as rocprofv3 prints it"""
     c = D.ctx.sweep_config()
-    return "k_tick<float, %d, %s, true>" % (c["unit_loads"], "true" if c["phases"] > 1 else "false")
+    return "k_tick<float, %d, %s, true, %s>" % (c["unit_loads"], "true" if c["phases"] > 1 else "false", "true" if c.get("dynamic") else "false")
 
 
 def rank_census(torch, dist, dev, use_dist, world):

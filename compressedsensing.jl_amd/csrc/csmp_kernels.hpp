@@ -330,6 +330,237 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_gen(
 inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * sizeof(double); }
 
 // ---------------------------------------------------------------------------------------------
+// The same sweep with its columns handed out AT RUN TIME (one residual image: !PH).  With a static split the workgroups of one
+// 1-GiB launch finish between 139 and 160 us (which ones are slow changes from launch to launch), so the
+// launch lasts 3.5-6 % longer than its average workgroup.  Round 5 measured what does NOT work: claims made by the streaming
+// waves themselves (an atomic's answer returns in order with the loads of the same wave: +29 us) and one counter for the chip
+// (~7 ns per claim).  Here a FIFTH wave per workgroup does the claiming and nothing else:
+//   pools    the full groups of four neighbouring columns are dealt over kClaimPools counters (group g' belongs to pool
+//            g' mod 8, so all pools walk the dictionary at the same pace); a workgroup claims from the pool of its XCD
+//            (s_getreg HW_REG_XCC_ID: placement is for speed only) and, once that is empty, from the others in turn.
+//            The N mod 4 last columns go to workgroup 0 up front.
+//   claimer  two claims in flight (agent-scope atomic adds: ~1.1-1.3 us each beside the stream), each published as ONE column
+//            per streaming wave into that wave's ring of kClaimQ slots in the LDS -- single producer, single consumer, no LDS
+//            atomics; a slot is EMPTY, a column index, or END.
+//   stream   waves 0..3 run sweep_body_gen's ring of NB units; at a column's first unit the wave takes its next column from its
+//            slot ring (a broadcast ds_read; it frees the slot at once).  Every buffer of the ring carries its column and unit
+//            index, so consuming needs no queue.  After END the ring is refilled with loads of ONE 16-byte vector (all lanes the
+//            same address) that nobody consumes: no load sits under a branch and the compiler's counted waits stay exact.
+// Every column's sum is formed by one wave in the same lane order as in the static body, and the maxima are compared
+// lexicographically (value, then lower index): the results do not depend on who swept which column -- bit-identical.
+// The counters: two sets per solver slot; a launch claims from one and workgroup 0 zeroes the other for the slot's next sweep
+// (kernel boundary in between).  dynamic LDS: KP + 48 doubles.
+constexpr int kClaimPools = 8;    // one per XCD
+constexpr int kClaimStride = 32;  // words between two counters (a 128-byte line each)
+constexpr int kClaimWords = kClaimPools * kClaimStride;
+constexpr int kClaimQ = 8;        // slots per streaming wave (a power of two)
+constexpr int kClEmpty = -2, kClEnd = -1;
+constexpr int kSweepDynThreads = kSweepThreads + kWave;
+inline size_t sweep_dyn_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8 + 16) * sizeof(double); }
+using lds_int_ptr = __attribute__((address_space(3))) int*;
+__device__ __forceinline__ int q_load(lds_int_ptr p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void q_store(lds_int_ptr p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <typename TA, int U, int NB>
+__device__ __forceinline__ void sweep_body_dyn(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, const int bid, const int KP, unsigned* __restrict__ claim,
+    unsigned* __restrict__ claim_next, double* lds) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    constexpr int UR = U * ROWS;
+    constexpr int NW = kSweepThreads / kWave;
+    constexpr int Q = kClaimQ;
+    static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (bid == 0 && wave == NW && lane < kClaimPools) claim_next[lane * kClaimStride] = 0u;  // (before any way out)
+    if (st->done & skipmask) return;
+    const int nvec = Mv / VEC;
+    double* red = lds + KP;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+    lds_int_ptr q = (lds_int_ptr)(redi + 16);
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    const int nunit = (Mv + UR - 1) / UR;
+    const int Mst = nunit * UR;
+    if (tid < NW * Q) q_store(q + tid, kClEmpty);
+    {
+        constexpr int RP = 16;
+        double n2 = 0.0;
+        if (wave < NW) {
+            for (int m0 = tid; m0 < Mst; m0 += RP * kSweepThreads) {
+                double rv[RP];
+#pragma unroll
+                for (int qq = 0; qq < RP; ++qq) {
+                    const int m = m0 + qq * kSweepThreads;
+                    rv[qq] = m < Mv ? r[m] : 0.0;
+                }
+#pragma unroll
+                for (int qq = 0; qq < RP; ++qq) {
+                    const int m = m0 + qq * kSweepThreads;
+                    if (m < Mst) lds[r_slot<VEC>(m)] = rv[qq];
+                    n2 = fma(rv[qq], rv[qq], n2);
+                }
+            }
+            for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        }
+        __syncthreads();
+        if (lane == 0 && wave < NW) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return;
+        }
+    }
+    if (wave == NW) {
+        // ---- the claimer: lane w < 4 serves streaming wave w
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const int64_t NG = N >> 2;  // full groups of four columns
+        int wpos = 0;
+        auto publish = [&](int col) {  // (lanes < NW: each its own slot ring)
+            lds_int_ptr slot = q + lane * Q + (wpos & (Q - 1));
+            while (q_load(slot) != kClEmpty) __builtin_amdgcn_s_sleep(2);
+            q_store(slot, col);
+            ++wpos;
+        };
+        if (bid == 0 && lane < (int)(N & 3)) publish((int)(NG * 4 + lane));
+        int pcur = (int)(xcc & (kClaimPools - 1)), tried = 0;
+        unsigned g0 = 0, g1 = 0;
+        int p0, p1;
+        auto ask = [&](unsigned& g, int& pp) {
+            pp = pcur;
+            if (lane == 0) g = __hip_atomic_fetch_add(claim + pcur * kClaimStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        auto take = [&](unsigned& g, int& pp) {  // the answer of the older claim; then the next claim goes out in its place
+            const unsigned gg = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+            const int64_t cnt = NG > pp ? (NG - pp + kClaimPools - 1) / kClaimPools : 0;
+            if ((int64_t)gg < cnt) {
+                if (lane < NW) publish((int)((((int64_t)gg * kClaimPools + pp) << 2) + lane));
+            } else if (pp == pcur) {
+                ++tried;
+                pcur = (pcur + 1) & (kClaimPools - 1);
+            }
+            if (tried < kClaimPools) ask(g, pp);
+        };
+        ask(g0, p0);
+        ask(g1, p1);
+        while (tried < kClaimPools) {
+            take(g0, p0);
+            if (tried < kClaimPools) take(g1, p1);
+        }
+        if (lane < NW) publish(kClEnd);
+        return;
+    }
+    // ---- the streaming waves
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+    VT buf[NB][U];
+    int bc[NB], bu[NB];
+    int icol = 0, ib = 0, ipos = 0;
+    bool live = true;
+    double acc = 0.0;
+    lds_int_ptr myq = q + wave * Q;
+    auto issue = [&](VT(&b)[U], int& c_, int& u_) {
+        if (ib == 0 && live) {
+            lds_int_ptr slot = myq + (ipos & (Q - 1));
+            int c = q_load(slot);
+            while (c == kClEmpty) {
+                __builtin_amdgcn_s_sleep(1);
+                c = q_load(slot);
+            }
+            c = __builtin_amdgcn_readfirstlane(c);
+            if (c == kClEnd) {
+                live = false;
+            } else {
+                if (lane == 0) q_store(slot, kClEmpty);
+                ++ipos;
+                icol = c;
+            }
+        }
+        const VT* pc = reinterpret_cast<const VT*>(A + (live ? (int64_t)icol * ld : 0));
+        const int vb = ib * (U * kWave) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb + u * kWave;
+            b[u] = __builtin_nontemporal_load(pc + (live ? (v < nvec ? v : nvec - 1) : 0));
+        }
+        c_ = live ? icol : -1;
+        u_ = ib;
+        if (++ib == nunit) ib = 0;
+    };
+    auto consume = [&](const VT(&b)[U], const int c_, const int u_) {
+        if (c_ < 0) return;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = u_ * U + u;
+            if constexpr (VEC == 4) {
+                const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                acc = fma((double)b[u].x, r01.x, acc);
+                acc = fma((double)b[u].y, r01.y, acc);
+                acc = fma((double)b[u].z, r23.x, acc);
+                acc = fma((double)b[u].w, r23.y, acc);
+            } else {
+                const f64x2 r01 = rs[t * kWave + lane];
+                acc = fma((double)b[u].x, r01.x, acc);
+                acc = fma((double)b[u].y, r01.y, acc);
+            }
+        }
+        if (u_ == nunit - 1) {  // the column's last unit
+            for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+            if (lane == 0) cvec[c_] = acc;
+            const double av = fabs(acc);
+            if (better(av, c_, bestv, besti)) {
+                bestv = av;
+                besti = c_;
+            }
+            acc = 0.0;
+        }
+    };
+#pragma unroll
+    for (int d = 0; d < NB; ++d) issue(buf[d], bc[d], bu[d]);
+    while (live) {
+#pragma unroll
+        for (int d = 0; d < NB; ++d) {
+            consume(buf[d], bc[d], bu[d]);
+            issue(buf[d], bc[d], bu[d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < NB; ++d) consume(buf[d], bc[d], bu[d]);
+    if (lane == 0) {
+        redv[wave] = bestv;
+        redi[wave] = besti;
+    }
+    lds_barrier();  // (the claimer has left: a barrier counts the waves that are still running)
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int qq = 1; qq < NW; ++qq)
+            if (better(redv[qq], redi[qq], bv, bi)) {
+                bv = redv[qq];
+                bi = redi[qq];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+template <typename TA, int U, int NB>
+__global__ __launch_bounds__(kSweepDynThreads) void k_sweep_dyn(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, int KP, unsigned* __restrict__ claim, unsigned* __restrict__ claim_next) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body_dyn<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, KP, claim, claim_next, lds);
+}
+
+// ---------------------------------------------------------------------------------------------
 // block-wide lexicographic arg-max over (v, i) pairs held one per thread (256 threads)
 __device__ __forceinline__ void block_argmax(double& v, int& i, double* sv, int* si) {
     const int tid = threadIdx.x;
@@ -1282,6 +1513,7 @@ struct TickSweep {
     const double* r; double* cvec; double* pval; int* pidx; DevState* st;
     double eps; int check_eps, skipmask, nblk, active;
     int KP;  // rows of the residual image
+    unsigned *claim, *claim_next;  // DYN: the column pools of this sweep, and the set to zero for the slot's next one (sweep_body_dyn)
 };
 template <typename TA>
 struct TickQr1 {
@@ -1303,8 +1535,10 @@ struct TickQr2 {
 // STEADY only names the kernel: the launches in which all three stages are live (every tick of a batch except the
 // 2 + 2 that fill and drain the pipeline of a signal triple) get a symbol of their own, so that a kernel trace
 // (rocprofv3 --kernel-trace --stats) reports the sweep-carrying ticks as one clean row.
-template <typename TA, int U, bool PH, bool STEADY = false>
-__global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
+// DYN: the sweep's columns are handed out at run time (sweep_body_dyn: a fifth wave per workgroup claims; in the append stages'
+// workgroups that wave leaves at once).
+template <typename TA, int U, bool PH, bool STEADY = false, bool DYN = false>
+__global__ __launch_bounds__(DYN ? kSweepDynThreads : kSweepThreads) void k_tick(const TickSweep<TA> sw, const TickQr1<TA> q1, const TickQr2 q2,
                                                         const int G, const int sweep_first) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     // Workgroups are dispatched in index order.  sweep_first: the persistent sweep
@@ -1312,6 +1546,9 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, 
     // tail starting only when the stages have drained.
     int bid = (int)blockIdx.x;
     if (sweep_first) bid = bid < sw.nblk ? bid + 2 * G : bid - sw.nblk;
+    if constexpr (DYN) {
+        if (bid < 2 * G && threadIdx.x >= kSweepThreads) return;
+    }
     if (bid < G) {
         if (q2.active)
             qr2_body<8>(q2.Q, q2.ldq, q2.st, q2.avec, q2.r, q2.P1, q2.P1s, q2.G, q2.W1, q2.vvec, q2.P2, q2.P2s, q2.R, q2.z,
@@ -1323,8 +1560,12 @@ __global__ __launch_bounds__(kSweepThreads) void k_tick(const TickSweep<TA> sw, 
                          bid - G, lds);
     } else {
         if (sw.active) {
-            sweep_body_gen<TA, U, 32 / U, PH>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
-                                              sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
+            if constexpr (DYN)
+                sweep_body_dyn<TA, U, 32 / U>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps, sw.check_eps,
+                                              sw.skipmask, bid - 2 * G, sw.KP, sw.claim, sw.claim_next, lds);
+            else
+                sweep_body_gen<TA, U, 32 / U, PH>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
+                                                  sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
         }
     }
 }

@@ -14,8 +14,36 @@ static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int
                        ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
     return hipGetLastError();
 }
+// the two sets of column-pool counters of a solver slot (sweep_body_dyn): this launch's, and the one it zeroes for the slot's next sweep
+static void claim_sets(Solver& s, unsigned*& cur, unsigned*& next) {
+    cur = s.claim + (size_t)s.claim_par * kClaimWords;
+    s.claim_par ^= 1;
+    next = s.claim + (size_t)s.claim_par * kClaimWords;
+}
+// the sweep with its columns handed out at run time (k_sweep_dyn): one residual image only
+template <typename TA, int U, int NB>
+static hipError_t sweep_launch_dyn(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
+    auto kern = k_sweep_dyn<TA, U, NB>;
+    if (ctx->sweep_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
+        if (e != hipSuccess) return e;
+    }
+    Solver& s = ctx->s;
+    unsigned *cur, *next;
+    claim_sets(s, cur, next);
+    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepDynThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next);
+    return hipGetLastError();
+}
 template <typename TA>
 static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
+    if (ctx->sweep_dyn) {
+        switch (ctx->sweep_U) {
+            case 16: return sweep_launch_dyn<TA, 16, 2>(ctx, r, eps, check_eps, skipmask, cout);
+            case 8: return sweep_launch_dyn<TA, 8, 4>(ctx, r, eps, check_eps, skipmask, cout);
+            default: return sweep_launch_dyn<TA, 4, 8>(ctx, r, eps, check_eps, skipmask, cout);
+        }
+    }
     if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask, cout);
     switch (ctx->sweep_U) {
         case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask, cout);
@@ -87,7 +115,7 @@ static int configure_sweep(csmp_ctx* ctx) {
     const int nchunk = (ctx->Mv + rows - 1) / rows;
     const int cus = ctx->prop.multiProcessorCount;
     const size_t lds_cap = 160 * 1024 - 512;
-    const int kp_cap = (int)(lds_cap / sizeof(double)) - 32;  // rows the LDS holds beside the reduction scratch
+    const int kp_cap = (int)(lds_cap / sizeof(double)) - 48;  // rows the LDS holds beside the reduction scratch and the claim rings
     ctx->sweep_ph = false;
     int bestU = 0, best_pad = 0;
     for (int u : {16, 8, 4}) {
@@ -111,7 +139,9 @@ static int configure_sweep(csmp_ctx* ctx) {
         ctx->sweep_ph = true;
         ctx->sweep_KP = ((per + ur - 1) / ur) * ur;
     }
-    ctx->sweep_lds = sweep_gen_lds_bytes(ctx->sweep_KP);
+    // columns handed out at run time (sweep_body_dyn) wherever one image holds the residual; csmp_tune(CSMP_TUNE_SWEEP_DYN): 1 = never
+    ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn != 1;
+    ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
     const size_t col_bytes = (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8);
     const int64_t base = col_bytes >= 8192 ? (int64_t)cus * 3 / 4 : (int64_t)cus * 3;
     ctx->sweep_grid = ctx->tune_sweep_grid > 0 ? balanced_grid(ctx->N, ctx->tune_sweep_grid) : balanced_grid(ctx->N, base);

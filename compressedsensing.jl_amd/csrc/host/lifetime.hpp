@@ -72,7 +72,7 @@ static void solver_free(Solver& s) {
     dfree(s.W1); dfree(s.P1); dfree(s.P2); dfree(s.P2s); dfree(s.P1s); dfree(s.avec); dfree(s.vvec); dfree(s.coef);
     dfree(s.scal); dfree(s.sel); dfree(s.cands); dfree(s.ncands); dfree(s.st); dfree(s.bstage);
     dfree(s.top_lv); dfree(s.cvals); dfree(s.top_li); dfree(s.rs_gt); dfree(s.rs_eq); dfree(s.rs_work); dfree(s.rs);
-    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags); dfree(s.scr_val); dfree(s.scr_idx); dfree(s.scr_tickets); dfree(s.scr_cb); dfree(s.scr_flag);
+    dfree(s.out_idx); dfree(s.out_order); dfree(s.out_nnz); dfree(s.out_val); dfree(s.sigflags); dfree(s.scr_val); dfree(s.scr_idx); dfree(s.scr_tickets); dfree(s.claim); dfree(s.scr_cb); dfree(s.scr_flag);
     dfree(s.Apan); dfree(s.Vpan); dfree(s.PB1); dfree(s.W1b); dfree(s.PG); dfree(s.Gsum); dfree(s.pan_atoms);
     dfree(s.rho2); dfree(s.dvec); dfree(s.frg1); dfree(s.frg2); dfree(s.frq); dfree(s.swapH); dfree(s.swapv); s.swapv_cap = 0;
     dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.qsave); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.delpos);

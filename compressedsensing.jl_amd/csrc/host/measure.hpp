@@ -82,7 +82,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     return CSMP_OK;
 }
 
-extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phases, int* workgroups, int* tick_workgroups, int64_t* lds_bytes) {
+extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phases, int* workgroups, int* tick_workgroups, int64_t* lds_bytes, int* dynamic) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->dA) return CSMP_ESTATE;
     if (unit_loads) *unit_loads = ctx->sweep_U;
@@ -90,6 +90,7 @@ extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phas
     if (workgroups) *workgroups = ctx->sweep_grid;
     if (tick_workgroups) *tick_workgroups = ctx->tick_nblk > 0 ? ctx->tick_nblk : ctx->tick_grid;
     if (lds_bytes) *lds_bytes = (int64_t)ctx->sweep_lds;
+    if (dynamic) *dynamic = ctx->sweep_dyn ? 1 : 0;
     return CSMP_OK;
 }
 
@@ -103,6 +104,8 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_sweep_U = (int)value;
             break;
         case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;
+        case CSMP_TUNE_SWEEP_DYN: ctx->tune_sweep_dyn = value ? 1 : 0; break;
+        case CSMP_TUNE_TICK_ORDER: ctx->tick_sweep_first = value != 0; return CSMP_OK;
         case CSMP_TUNE_REBUILD_DIRECT: ctx->tune_rebuild_direct = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_SWAP_REFUSE: ctx->tune_swap_refuse = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_DIAG_SPLIT: ctx->tune_diag_split = value ? 1 : 0; return CSMP_OK;

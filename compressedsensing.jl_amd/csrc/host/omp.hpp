@@ -2,8 +2,10 @@
 // the tick pipeline (three signals in flight) and the omp driver.
 // ------------------------------------------------------------------------------------------ tick kernel (3 signals in flight)
 template <typename TA>
-static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, const Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
+static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
     TickSweep<TA> p;
+    p.claim = p.claim_next = nullptr;
+    if (active && ctx->sweep_dyn) claim_sets(s, p.claim, p.claim_next);
     p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
     p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;
     p.eps = eps; p.check_eps = check_eps; p.skipmask = skipmask; p.nblk = nblk; p.active = active; p.KP = ctx->sweep_KP;
@@ -30,24 +32,31 @@ static TickQr2 tick_qr2_params(csmp_ctx* ctx, const Solver& s, int jh, int optim
     return p;
 }
 
-template <typename TA, int U, bool PH, bool STEADY = false>
+template <typename TA, int U, bool PH, bool STEADY = false, bool DYN = false>
 static hipError_t tick_launch_t(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds) {
-    auto kern = k_tick<TA, U, PH, STEADY>;
+    auto kern = k_tick<TA, U, PH, STEADY, DYN>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, ctx->tick_sweep_first ? 1 : 0);
+    hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(DYN ? kSweepDynThreads : kSweepThreads), lds, ctx->stream, sw, q1, q2, G, ctx->tick_sweep_first ? 1 : 0);
     return hipGetLastError();
 }
 // steady: all three stages of this tick are live (the launches the bench's roofline is quoted on)
-template <typename TA, int U, bool PH>
+template <typename TA, int U, bool PH, bool DYN = false>
 static hipError_t tick_launch_s(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
-    return steady ? tick_launch_t<TA, U, PH, true>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, U, PH, false>(ctx, sw, q1, q2, G, lds);
+    return steady ? tick_launch_t<TA, U, PH, true, DYN>(ctx, sw, q1, q2, G, lds) : tick_launch_t<TA, U, PH, false, DYN>(ctx, sw, q1, q2, G, lds);
 }
 template <typename TA>
 static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const TickQr1<TA>& q1, const TickQr2& q2, int G, size_t lds, bool steady) {
     if (ctx->sweep_ph) return tick_launch_s<TA, 8, true>(ctx, sw, q1, q2, G, lds, steady);
+    if (ctx->sweep_dyn) {
+        switch (ctx->sweep_U) {
+            case 16: return tick_launch_s<TA, 16, false, true>(ctx, sw, q1, q2, G, lds, steady);
+            case 8: return tick_launch_s<TA, 8, false, true>(ctx, sw, q1, q2, G, lds, steady);
+            default: return tick_launch_s<TA, 4, false, true>(ctx, sw, q1, q2, G, lds, steady);
+        }
+    }
     switch (ctx->sweep_U) {
         case 16: return tick_launch_s<TA, 16, false>(ctx, sw, q1, q2, G, lds, steady);
         case 8: return tick_launch_s<TA, 8, false>(ctx, sw, q1, q2, G, lds, steady);

@@ -81,6 +81,8 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->opt_screened = src->opt_screened;
     dst->tune_sweep_grid = src->tune_sweep_grid;  // (measurement overrides, csmp_tune: the twins of the batch drivers sweep like their parent)
     dst->tune_sweep_U = src->tune_sweep_U;
+    dst->tune_sweep_dyn = src->tune_sweep_dyn;
+    dst->tick_sweep_first = src->tick_sweep_first;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;
     dst->tune_rebuild_direct = src->tune_rebuild_direct;

@@ -22,13 +22,15 @@ int csmp_profile_overhead(csmp_ctx *ctx, int reps, double *avg_ms);
  * bracketed by one HIP event pair on the ctx stream; returns the average ms per sweep.  variant must be 0. */
 int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
 /* what configure_sweep chose for the resident dictionary: loads per unit of k_sweep_gen (16 / 8 / 4); phases the residual is
- * staged in (1: one LDS image); workgroups of a stand-alone sweep and of the sweep inside the tick kernel; dynamic LDS bytes.
- * Any pointer may be NULL. */
-int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *workgroups, int *tick_workgroups, int64_t *lds_bytes);
+ * staged in (1: one LDS image); workgroups of a stand-alone sweep and of the sweep inside the tick kernel; dynamic LDS bytes;
+ * dynamic = 1: the columns are handed out at run time (k_sweep_dyn and the DYN tick), 0: split statically.  Any pointer may be NULL. */
+int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *workgroups, int *tick_workgroups, int64_t *lds_bytes, int *dynamic);
 /* measurement overrides of that choice, applied to the resident dictionary at once and to later ones: 0 = automatic */
 #define CSMP_TUNE_SWEEP_GRID 2   /* workgroups of the product sweep */
 #define CSMP_TUNE_SWEEP_UNIT 3   /* loads per unit (16, 8 or 4) */
 #define CSMP_TUNE_TICK_GRID 4    /* sweep workgroups inside the tick kernel of csmp_omp_batch */
+#define CSMP_TUNE_SWEEP_DYN 9     /* 1: the product sweep splits its columns statically over the workgroups (default 0: handed out at run time wherever one LDS image holds the residual) */
+#define CSMP_TUNE_TICK_ORDER 10   /* 1: the tick kernel's sweep workgroups are dispatched ahead of its append stages' */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */
