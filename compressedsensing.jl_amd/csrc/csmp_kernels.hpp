@@ -335,10 +335,14 @@ inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * s
 // launch lasts 3.5-6 % longer than its average workgroup.  Round 5 measured what does NOT work: claims made by the streaming
 // waves themselves (an atomic's answer returns in order with the loads of the same wave: +29 us) and one counter for the chip
 // (~7 ns per claim).  Here a FIFTH wave per workgroup does the claiming and nothing else:
-//   pools    the full groups of four neighbouring columns are dealt over kClaimPools counters (group g' belongs to pool
-//            g' mod 8, so all pools walk the dictionary at the same pace); a workgroup claims from the pool of its XCD
-//            (s_getreg HW_REG_XCC_ID: placement is for speed only) and, once that is empty, from the others in turn.
-//            The N mod 4 last columns go to workgroup 0 up front.
+//   pools    every workgroup owns the groups of four neighbouring columns that the static split would give it (group g' belongs to
+//            workgroup g' mod grid) and a counter over them, on a line of its own kClaimStride words from the next one: an
+//            agent-scope atomic is a read-modify-write at the memory side, ~90 ns of ONE channel beside the stream -- 8 counters
+//            for the chip made the launch 181-205 us, 22 made it 161-165 (the static split: 155); one per workgroup spreads
+//            the ~93 claims of a workgroup's share over as many channels.  A workgroup claims from its own counter and, once
+//            that is empty, STEALS from the following workgroups' (b + 1, b + 2, ...: eight consecutive block ids sit on eight
+//            XCDs under the round-robin dispatch, and the XCDs differ by several percent in speed) until npools - 1 of them in
+//            a row had nothing left.  The N mod 4 last columns go to workgroup 0 up front.
 //   claimer  two claims in flight (agent-scope atomic adds: ~1.1-1.3 us each beside the stream), each published as ONE column
 //            per streaming wave into that wave's ring of kClaimQ slots in the LDS -- single producer, single consumer, no LDS
 //            atomics; a slot is EMPTY, a column index, or END.
@@ -350,9 +354,8 @@ inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * s
 // lexicographically (value, then lower index): the results do not depend on who swept which column -- bit-identical.
 // The counters: two sets per solver slot; a launch claims from one and workgroup 0 zeroes the other for the slot's next sweep
 // (kernel boundary in between).  dynamic LDS: KP + 48 doubles.
-constexpr int kClaimPools = 8;    // one per XCD
-constexpr int kClaimStride = 32;  // words between two counters (a 128-byte line each)
-constexpr int kClaimWords = kClaimPools * kClaimStride;
+constexpr int kClaimStride = 1088;  // words between two counters: 4 KiB + 256 B, so that neighbours differ in every plausible channel-interleave bit
+constexpr int kClaimMaxWgs = 512;   // largest grid the dynamic sweep is launched on (a solver slot holds two sets of that many counters)
 constexpr int kClaimQ = 8;        // slots per streaming wave (a power of two)
 constexpr int kClEmpty = -2, kClEnd = -1;
 constexpr int kSweepDynThreads = kSweepThreads + kWave;
@@ -365,8 +368,8 @@ template <typename TA, int U, int NB>
 __device__ __forceinline__ void sweep_body_dyn(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask, const int bid, const int KP, unsigned* __restrict__ claim,
-    unsigned* __restrict__ claim_next, double* lds) {
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, const int KP, unsigned* __restrict__ claim,
+    unsigned* __restrict__ claim_next, const int npools, double* lds) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
@@ -376,7 +379,9 @@ __device__ __forceinline__ void sweep_body_dyn(
     static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    if (bid == 0 && wave == NW && lane < kClaimPools) claim_next[lane * kClaimStride] = 0u;  // (before any way out)
+    const int P = nblk;  // pools: one per workgroup
+    if (bid == 0 && wave == NW)  // (before any way out)
+        for (int p = lane; p < P; p += kWave) claim_next[p * kClaimStride] = 0u;
     if (st->done & skipmask) return;
     const int nvec = Mv / VEC;
     double* red = lds + KP;
@@ -419,8 +424,6 @@ __device__ __forceinline__ void sweep_body_dyn(
     }
     if (wave == NW) {
         // ---- the claimer: lane w < 4 serves streaming wave w
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         const int64_t NG = N >> 2;  // full groups of four columns
         int wpos = 0;
         auto publish = [&](int col) {  // (lanes < NW: each its own slot ring)
@@ -430,7 +433,8 @@ __device__ __forceinline__ void sweep_body_dyn(
             ++wpos;
         };
         if (bid == 0 && lane < (int)(N & 3)) publish((int)(NG * 4 + lane));
-        int pcur = (int)(xcc & (kClaimPools - 1)), tried = 0;
+        const int ntry = npools < P ? npools : P;  // empty counters in a row that end the search
+        int pcur = bid, tried = 0;
         unsigned g0 = 0, g1 = 0;
         int p0, p1;
         auto ask = [&](unsigned& g, int& pp) {
@@ -439,20 +443,21 @@ __device__ __forceinline__ void sweep_body_dyn(
         };
         auto take = [&](unsigned& g, int& pp) {  // the answer of the older claim; then the next claim goes out in its place
             const unsigned gg = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
-            const int64_t cnt = NG > pp ? (NG - pp + kClaimPools - 1) / kClaimPools : 0;
+            const int64_t cnt = NG > pp ? (NG - pp + P - 1) / P : 0;
             if ((int64_t)gg < cnt) {
-                if (lane < NW) publish((int)((((int64_t)gg * kClaimPools + pp) << 2) + lane));
+                if (lane < NW) publish((int)((((int64_t)gg * P + pp) << 2) + lane));
+                if (pp == pcur) tried = 0;
             } else if (pp == pcur) {
                 ++tried;
-                pcur = (pcur + 1) & (kClaimPools - 1);
+                pcur = pcur + 1 == P ? 0 : pcur + 1;
             }
-            if (tried < kClaimPools) ask(g, pp);
+            if (tried < ntry) ask(g, pp);
         };
         ask(g0, p0);
         ask(g1, p1);
-        while (tried < kClaimPools) {
+        while (tried < ntry) {
             take(g0, p0);
-            if (tried < kClaimPools) take(g1, p1);
+            if (tried < ntry) take(g1, p1);
         }
         if (lane < NW) publish(kClEnd);
         return;
@@ -555,9 +560,10 @@ template <typename TA, int U, int NB>
 __global__ __launch_bounds__(kSweepDynThreads) void k_sweep_dyn(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask, int KP, unsigned* __restrict__ claim, unsigned* __restrict__ claim_next) {
+    double eps, int check_eps, int skipmask, int KP, unsigned* __restrict__ claim, unsigned* __restrict__ claim_next, int npools) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    sweep_body_dyn<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, KP, claim, claim_next, lds);
+    sweep_body_dyn<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, KP, claim,
+                              claim_next, npools, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1513,6 +1519,7 @@ struct TickSweep {
     const double* r; double* cvec; double* pval; int* pidx; DevState* st;
     double eps; int check_eps, skipmask, nblk, active;
     int KP;  // rows of the residual image
+    int npools;                    // DYN: pools a workgroup may claim from (its XCD's first)
     unsigned *claim, *claim_next;  // DYN: the column pools of this sweep, and the set to zero for the slot's next one (sweep_body_dyn)
 };
 template <typename TA>
@@ -1562,7 +1569,7 @@ __global__ __launch_bounds__(DYN ? kSweepDynThreads : kSweepThreads) void k_tick
         if (sw.active) {
             if constexpr (DYN)
                 sweep_body_dyn<TA, U, 32 / U>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps, sw.check_eps,
-                                              sw.skipmask, bid - 2 * G, sw.KP, sw.claim, sw.claim_next, lds);
+                                              sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, sw.claim, sw.claim_next, sw.npools, lds);
             else
                 sweep_body_gen<TA, U, 32 / U, PH>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
                                                   sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);

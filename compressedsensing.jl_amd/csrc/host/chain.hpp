@@ -27,8 +27,9 @@ static int solver_alloc(csmp_ctx* ctx, Solver& s, int kcap, int outcap, int qcap
     CHECK(dmalloc(ctx, &s.scr_flag, 2));
     CHECK(dmalloc(ctx, &s.scr_tickets, (size_t)(maxgrid / kScrPartWgs + 2) * kScrTicketStride));
     HIPCHECK(hipMemsetAsync(s.scr_tickets, 0, (size_t)(maxgrid / kScrPartWgs + 2) * kScrTicketStride * sizeof(unsigned), ctx->stream));
-    CHECK(dmalloc(ctx, &s.claim, (size_t)2 * kClaimWords));
-    HIPCHECK(hipMemsetAsync(s.claim, 0, (size_t)2 * kClaimWords * sizeof(unsigned), ctx->stream));
+    s.claim_words = (size_t)(kClaimMaxWgs + 1) * kClaimStride;
+    CHECK(dmalloc(ctx, &s.claim, 2 * s.claim_words));
+    HIPCHECK(hipMemsetAsync(s.claim, 0, 2 * s.claim_words * sizeof(unsigned), ctx->stream));
     s.claim_par = 0;
     CHECK(dmalloc(ctx, &s.pidx, maxgrid));
     CHECK(dmalloc(ctx, &s.Q, (size_t)s.ldq * qcap));

@@ -33,8 +33,9 @@ struct Solver {
     int* scr_idx = nullptr;
     unsigned long long* scr_cb = nullptr;  // sp_select_screened: the bound of everything that was not rescored (bits of a double)
     int* scr_flag = nullptr;               // ... and 1 when the selection could not be certified
-    unsigned* claim = nullptr;  // sweep_body_dyn's column pools: two sets of kClaimWords words, used in turn (claim_par: the next launch's)
+    unsigned* claim = nullptr;  // sweep_body_dyn's column pools: two sets of claim_words words, used in turn (claim_par: the next launch's)
     int claim_par = 0;
+    size_t claim_words = 0;
     unsigned* scr_tickets = nullptr;  // k_sweep_bf16's ticket counters, one per partition of workgroups, kScrTicketStride words apart
     double* spill = nullptr;  // supports beyond the LDS append kernels' ~3900 columns: their five support-length vectors per workgroup (launch_append)
     size_t spill_cap = 0;
@@ -185,7 +186,9 @@ struct csmp_ctx {
     int tick_grid = 0;      // sweep workgroups inside the tick kernel
     int tune_sweep_grid = 0, tune_sweep_U = 0;
     bool sweep_dyn = false;  // the product sweep hands its columns out at run time (k_sweep_dyn, the DYN tick)
-    int tune_sweep_dyn = 0;  // csmp_tune: 1 = the static split everywhere
+    int tune_sweep_dyn = 0;  // csmp_tune: 1 = the columns handed out at run time where one image holds the residual (measured slower: DESIGN.md section 0)
+    int tune_pipelines = 0;  // csmp_tune: 1 = csmp_omp_batch keeps ONE pipeline of three signals (default: two side by side from six signals on)
+    int claim_pools = 8;     // counters a workgroup of the dynamic sweep finds empty in a row before it stops (its own, then the following workgroups')
     int tune_rebuild_direct = 0;  // csmp_tune: the oblivious start's Q'A pass reads its directions from L2 (k_fr_rebuild) instead of the LDS
     int tune_swap_refuse = 0;  // csmp_tune: OMPR's inverse-Gram exchanges fail their guard (tests walk the fallback to the QR path)
     int tune_diag_split = 0;  // csmp_tune: fused kernels run as one launch per part (a kernel trace then shows the parts)

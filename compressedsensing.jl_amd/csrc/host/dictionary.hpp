@@ -3,7 +3,7 @@
 // ------------------------------------------------------------------------------------------ sweep launch
 // the product sweep (k_sweep_gen): U loads per unit, a ring of 32 loads, the residual in one image or staged in phases
 template <typename TA, int U, int NB, bool PH>
-static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
+static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols = 0) {
     auto kern = k_sweep_gen<TA, U, NB, PH>;
     if (ctx->sweep_lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
@@ -11,14 +11,14 @@ static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int
     }
     Solver& s = ctx->s;
     hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
+                       ncols > 0 ? ncols : ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
     return hipGetLastError();
 }
 // the two sets of column-pool counters of a solver slot (sweep_body_dyn): this launch's, and the one it zeroes for the slot's next sweep
 static void claim_sets(Solver& s, unsigned*& cur, unsigned*& next) {
-    cur = s.claim + (size_t)s.claim_par * kClaimWords;
+    cur = s.claim + (size_t)s.claim_par * s.claim_words;
     s.claim_par ^= 1;
-    next = s.claim + (size_t)s.claim_par * kClaimWords;
+    next = s.claim + (size_t)s.claim_par * s.claim_words;
 }
 // the sweep with its columns handed out at run time (k_sweep_dyn): one residual image only
 template <typename TA, int U, int NB>
@@ -32,23 +32,23 @@ static hipError_t sweep_launch_dyn(csmp_ctx* ctx, const double* r, double eps, i
     unsigned *cur, *next;
     claim_sets(s, cur, next);
     hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepDynThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next);
+                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next, ctx->claim_pools);
     return hipGetLastError();
 }
 template <typename TA>
-static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout) {
-    if (ctx->sweep_dyn) {
+static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols = 0) {
+    if (ctx->sweep_dyn && ncols == 0) {
         switch (ctx->sweep_U) {
             case 16: return sweep_launch_dyn<TA, 16, 2>(ctx, r, eps, check_eps, skipmask, cout);
             case 8: return sweep_launch_dyn<TA, 8, 4>(ctx, r, eps, check_eps, skipmask, cout);
             default: return sweep_launch_dyn<TA, 4, 8>(ctx, r, eps, check_eps, skipmask, cout);
         }
     }
-    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask, cout);
+    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     switch (ctx->sweep_U) {
-        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask, cout);
-        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask, cout);
-        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask, cout);
+        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     }
 }
 
@@ -69,13 +69,13 @@ static int prof_mark(csmp_ctx* ctx) {
 }
 
 
-// cout: where c = A'r goes (default: the solver slot's correlation vector)
-static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout = nullptr) {
-    const bool timed = prof_pick(ctx);
+// cout: where c = A'r goes (default: the solver slot's correlation vector); ncols > 0: the first ncols columns only
+static int launch_sweep(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout = nullptr, int64_t ncols = 0) {
+    const bool timed = ncols == 0 && prof_pick(ctx);
     if (timed) CHECK(prof_mark(ctx));
     hipError_t e = ctx->dtype == CSMP_F32
-                       ? sweep_product<float>(ctx, r, eps, check_eps, skipmask, cout)
-                       : sweep_product<double>(ctx, r, eps, check_eps, skipmask, cout);
+                       ? sweep_product<float>(ctx, r, eps, check_eps, skipmask, cout, ncols)
+                       : sweep_product<double>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     HIPCHECK(e);
     if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;
@@ -139,9 +139,8 @@ static int configure_sweep(csmp_ctx* ctx) {
         ctx->sweep_ph = true;
         ctx->sweep_KP = ((per + ur - 1) / ur) * ur;
     }
-    // columns handed out at run time (sweep_body_dyn) wherever one image holds the residual; csmp_tune(CSMP_TUNE_SWEEP_DYN): 1 = never
-    ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn != 1;
-    ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
+    // columns handed out at run time (sweep_body_dyn): only on csmp_tune(CSMP_TUNE_SWEEP_DYN, 1) -- measured 1-3 % slower than the static split
+    ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn == 1;
     const size_t col_bytes = (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8);
     const int64_t base = col_bytes >= 8192 ? (int64_t)cus * 3 / 4 : (int64_t)cus * 3;
     ctx->sweep_grid = ctx->tune_sweep_grid > 0 ? balanced_grid(ctx->N, ctx->tune_sweep_grid) : balanced_grid(ctx->N, base);
@@ -151,6 +150,12 @@ static int configure_sweep(csmp_ctx* ctx) {
     }
     // inside the tick kernel (csmp_omp_batch) the sweep shares the CUs with the append stages of two other signals
     ctx->tick_grid = balanced_grid(ctx->N, col_bytes >= 8192 ? (int64_t)cus * 11 / 16 : (int64_t)cus * 3);
+    // (the per-workgroup partials pval / pidx and the claim counters of a solver slot are sized for cus * 8 + 8 workgroups: solver_alloc)
+    const int maxgrid = cus * 8 + 8;
+    ctx->sweep_grid = std::min(ctx->sweep_grid, maxgrid);
+    ctx->tick_grid = std::min(ctx->tick_grid, maxgrid);
+    if (ctx->sweep_grid > kClaimMaxWgs || std::max(ctx->tick_grid, ctx->tick_nblk) > kClaimMaxWgs) ctx->sweep_dyn = false;  // (one counter per workgroup)
+    ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
     return CSMP_OK;
 }
 

@@ -80,7 +80,9 @@ static bool fr_tall(const csmp_ctx* ctx, int nq) {
     fr_config(ctx, nq, U, full, lds, grid);
     return lds > 160 * 1024 - 512;
 }
-static int fr_combine_grid(const csmp_ctx* ctx) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (ctx->N + 255) / 256)); }
+static int fr_combine_grid(const csmp_ctx* ctx) {  // (its partials land in pval / pidx: cus * 8 + 8 entries, solver_alloc)
+    return (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(2048, ctx->prop.multiProcessorCount * 8 + 8), (ctx->N + 255) / 256));
+}
 
 static int fr_ensure(csmp_ctx* ctx) {
     Solver& s = ctx->s;
@@ -319,12 +321,28 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         fr_config(ctx, 1, U, full, l, g);
         pipe = pipe && full && !fr_tall(ctx, 1);
     }
-    auto init_sig = [&](int64_t sgn) -> int {
-        const char* col = (const char*)dB + (size_t)sgn * (size_t)ldB * es;
-        return b_dtype == CSMP_F32 ? init_from_device_t<float>(ctx, (const float*)col)
-                                   : init_from_device_t<double>(ctx, (const double*)col);
-    };
     int64_t sgn = 0;
+    // TWO pipelines (omp only): the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair).
+    // From six signals on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one.
+    csmp_ctx* tw = nullptr;
+    if (pipe && !isfr && nsig >= 6 && ctx->tune_pipelines != 1) {
+        rc = twins_ensure(ctx, 1);
+        if (rc == CSMP_OK) {
+            tw = ctx->twins[0];
+            for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
+                activate_slot(tw, q);
+                rc = solver_ensure(tw, kc, (int)k);
+            }
+            activate_slot(tw, 0);
+            if (rc != CSMP_OK) ctx->err = tw->err;
+        }
+        if (rc == CSMP_OK && !ctx->ev_twin) HIPCHECK(hipEventCreateWithFlags(&ctx->ev_twin, hipEventDisableTiming));
+        if (rc == CSMP_OK && !tw->ev_twin) HIPCHECK(hipEventCreateWithFlags(&tw->ev_twin, hipEventDisableTiming));
+        if (rc == CSMP_OK) {  // (the twin starts behind everything this context's stream holds: the caller's buffers, the slots' allocation)
+            HIPCHECK(hipEventRecord(ctx->ev_twin, ctx->stream));
+            HIPCHECK(hipStreamWaitEvent(tw->stream, ctx->ev_twin, 0));
+        }
+    }
     if (pipe) {
         for (int q = 1; q < 3 && rc == CSMP_OK; ++q) {
             activate_slot(ctx, q);
@@ -332,23 +350,77 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             if (rc == CSMP_OK && isfr) rc = fr_ensure(ctx);
         }
         activate_slot(ctx, 0);
+        auto init_triple = [&](csmp_ctx* c, int64_t first, int64_t end, bool present[3]) -> int {
+            int r2 = CSMP_OK;
+            for (int q = 0; q < 3 && r2 == CSMP_OK; ++q) {
+                present[q] = first + q < end;
+                if (!present[q]) continue;
+                activate_slot(c, q);
+                const char* col = (const char*)dB + (size_t)(first + q) * (size_t)ldB * es;
+                r2 = b_dtype == CSMP_F32 ? init_from_device_t<float>(c, (const float*)col) : init_from_device_t<double>(c, (const double*)col);
+            }
+            if (r2 != CSMP_OK && c != ctx) ctx->err = c->err;
+            return r2;
+        };
+        auto finish_triple = [&](csmp_ctx* c, int64_t first, const bool present[3]) -> int {
+            int r2 = CSMP_OK;
+            for (int q = 0; q < 3 && r2 == CSMP_OK; ++q) {
+                if (!present[q]) continue;
+                activate_slot(c, q);
+                r2 = launch_finish(c, d_idx + (first + q) * k, d_val + (first + q) * k, d_nnz + first + q, nullptr, (int)k, sigflags + first + q);
+            }
+            activate_slot(c, 0);
+            if (r2 != CSMP_OK && c != ctx) ctx->err = c->err;
+            return r2;
+        };
+        if (tw && rc == CSMP_OK) {
+            // this context takes the triples of the first half of the signals, the twin the rest; round j runs triple j of each
+            const int64_t ntrip = (nsig + 2) / 3;
+            const int64_t nA = std::min<int64_t>(nsig, 3 * ((ntrip + 1) / 2));
+            for (int64_t j = 0; 3 * j < nA && rc == CSMP_OK; ++j) {
+                bool pa[3], pb[3];
+                const int64_t fa = 3 * j, fb = nA + 3 * j;
+                rc = init_triple(ctx, fa, nA, pa);
+                const bool hasb = fb < nsig;
+                if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, nsig, pb);
+                if (rc != CSMP_OK) break;
+                if (hasb && j == 0 && ctx->N >= 8) {
+                    // the twin's pipeline starts HALF a tick behind: a throw-away sweep of half the dictionary on its stream (into the
+                    // slot's own correlation vector, which the first real sweep rewrites; no stop test, nothing else written).  Two
+                    // pipelines of equal ticks that start together stay in step, and their tails and launch boundaries would coincide.
+                    activate_slot(tw, 0);
+                    rc = launch_sweep(tw, tw->s.r, 0.0, 0, 0, nullptr, ctx->N / 2);
+                    if (rc != CSMP_OK) {
+                        ctx->err = tw->err;
+                        break;
+                    }
+                }
+                if (hasb)
+                    rc = ctx->dtype == CSMP_F32 ? omp_ticks_pair<float>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid)
+                                                : omp_ticks_pair<double>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid);
+                else
+                    rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, pa, k, eps, opt) : omp_ticks<double>(ctx, pa, k, eps, opt);
+                if (rc == CSMP_OK) rc = finish_triple(ctx, fa, pa);
+                if (rc == CSMP_OK && hasb) rc = finish_triple(tw, fb, pb);
+            }
+            sgn = nsig;
+            // this context's stream goes on behind the twin's last launch (a failed enqueue: drain both before anything is released)
+            if (rc == CSMP_OK) {
+                HIPCHECK(hipEventRecord(tw->ev_twin, tw->stream));
+                HIPCHECK(hipStreamWaitEvent(ctx->stream, tw->ev_twin, 0));
+            } else {
+                (void)hipStreamSynchronize(tw->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+            }
+        }
         for (; sgn < nsig && rc == CSMP_OK; sgn += 3) {
             bool present[3];
-            for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
-                present[q] = sgn + q < nsig;
-                if (!present[q]) continue;
-                activate_slot(ctx, q);
-                rc = init_sig(sgn + q);
-            }
+            rc = init_triple(ctx, sgn, nsig, present);
             if (rc == CSMP_OK && isfr)
                 rc = ctx->dtype == CSMP_F32 ? fr_ticks<float>(ctx, present, k, eps, p2, opt) : fr_ticks<double>(ctx, present, k, eps, p2, opt);
             else if (rc == CSMP_OK)
                 rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, present, k, eps, opt) : omp_ticks<double>(ctx, present, k, eps, opt);
-            for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
-                if (!present[q]) continue;
-                activate_slot(ctx, q);
-                rc = launch_finish(ctx, d_idx + (sgn + q) * k, d_val + (sgn + q) * k, d_nnz + sgn + q, nullptr, (int)k, sigflags + sgn + q);
-            }
+            if (rc == CSMP_OK) rc = finish_triple(ctx, sgn, present);
         }
         activate_slot(ctx, 0);
     }

@@ -103,8 +103,13 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             if (value != 0 && value != 4 && value != 8 && value != 16) return fail(ctx, CSMP_EINVAL, "csmp_tune: unit loads must be 0, 4, 8 or 16");
             ctx->tune_sweep_U = (int)value;
             break;
-        case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;
+        case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;  // (configure_sweep below: the dynamic sweep's grid limit)
         case CSMP_TUNE_SWEEP_DYN: ctx->tune_sweep_dyn = value ? 1 : 0; break;
+        case CSMP_TUNE_CLAIM_POOLS:
+            if (value < 1 || value > 4096) return fail(ctx, CSMP_EINVAL, "csmp_tune: claim pools must be 1..4096");
+            ctx->claim_pools = (int)value;
+            return CSMP_OK;
+        case CSMP_TUNE_PIPELINES: ctx->tune_pipelines = value == 1 ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_TICK_ORDER: ctx->tick_sweep_first = value != 0; return CSMP_OK;
         case CSMP_TUNE_REBUILD_DIRECT: ctx->tune_rebuild_direct = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_SWAP_REFUSE: ctx->tune_swap_refuse = value ? 1 : 0; return CSMP_OK;

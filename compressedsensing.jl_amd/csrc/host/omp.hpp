@@ -5,6 +5,7 @@ template <typename TA>
 static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
     TickSweep<TA> p;
     p.claim = p.claim_next = nullptr;
+    p.npools = ctx->claim_pools;
     if (active && ctx->sweep_dyn) claim_sets(s, p.claim, p.claim_next);
     p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
     p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;
@@ -67,40 +68,78 @@ static hipError_t tick_launch(csmp_ctx* ctx, const TickSweep<TA>& sw, const Tick
 // OMP for up to three signals (solver slots 0..2, already initialised with their b) advanced
 // together: at tick n slot n%3 sweeps, slot (n-1)%3 runs its k_qr1 stage, slot (n-2)%3 its k_qr2
 // stage.  k steps per signal = 3k+2 ticks.  present[q] == false leaves slot q idle.
-template <typename TA>
-static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps, bool optimistic) {
-    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+// One pipeline's schedule: which slots are live at tick n, and the launch of that tick.
+struct TickPipe {
+    csmp_ctx* ctx = nullptr;
+    bool present[3] = {false, false, false};
+    int nblk = 0;
+    size_t lds = 0;
+};
+static void tick_pipe_begin(TickPipe& tp, csmp_ctx* ctx, const bool present[3], int64_t k, int grid_override) {
+    tp.ctx = ctx;
+    for (int q = 0; q < 3; ++q) tp.present[q] = present[q];
     activate_slot(ctx, 0);
-    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
-    const int G = sl[0]->G;
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     // Measured at 4096 x 65536 f32: 8-chunk load blocks on ONE workgroup per CU (the append stages of the other two
     // signals share those CUs) 160.4 us per tick; 16-chunk blocks on 176 workgroups (11/12 of the stand-alone sweep's
     // optimum of 192) 162.6 us.
-    const int64_t auto_nblk = (int64_t)ctx->tick_grid;  // (configure_sweep)
-    const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups));
-    const size_t lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));  // (jh never exceeds k here)
+    const int64_t auto_nblk = grid_override > 0 ? (int64_t)grid_override : (int64_t)ctx->tick_grid;  // (configure_sweep)
+    tp.nblk = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(ctx->tick_nblk > 0 ? ctx->tick_nblk : auto_nblk, groups),
+                                                         ctx->prop.multiProcessorCount * 8 + 8));  // (pval / pidx: solver_alloc)
+    tp.lds = std::max(ctx->sweep_lds, qr_lds_bytes((int)std::min<int64_t>(k, ctx->s.kcap)));  // (jh never exceeds k here)
+}
+template <typename TA>
+static int tick_pipe_launch(TickPipe& tp, int64_t n, int64_t k, double eps, bool optimistic) {
+    csmp_ctx* ctx = tp.ctx;
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};  // (slot 0 is the active one: tick_pipe_begin)
+    const int G = sl[0]->G;
+    const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
+    const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
+    const bool az = tp.present[zs] && n >= zs && tz < k;
+    const bool ay = tp.present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
+    const bool ax = tp.present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
+    if (!az && !ay && !ax) return CSMP_OK;
+    int jh1 = 0;
+    if (ay) {
+        jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
+        sl[ys]->jh_last = jh1;
+        if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
+    }
+    const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, tp.nblk, az ? 1 : 0);
+    const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, tp.nblk, jh1, ay ? 1 : 0);
+    const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
+    const bool steady = az && ay && ax;
+    const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
+    if (timed) CHECK(prof_mark(ctx));
+    HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, tp.lds, steady));
+    if (timed) CHECK(prof_mark(ctx));
+    return CSMP_OK;
+}
+template <typename TA>
+static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps, bool optimistic) {
+    TickPipe tp;
+    tick_pipe_begin(tp, ctx, present, k, 0);
+    for (int64_t n = 0; n < 3 * k + 2; ++n) CHECK(tick_pipe_launch<TA>(tp, n, k, eps, optimistic));
+    return CSMP_OK;
+}
+constexpr int kPairTickGrid = 192;  // sweep workgroups of each of two pipelines side by side (measured: 176 -> 6.41e3, 192 -> 6.46e3, 224 -> 6.45e3, 256 -> 6.41e3 atoms/s)
+// TWO pipelines side by side: a second triple of signals on a twin context (its own stream), the launches of the two enqueued
+// alternately.  The sweeps of the two then share the HBM, out of step with one another: the last workgroups of one tick, its
+// launch boundary and the staging of its residual image fall under the other pipeline's stream instead of leaving the memory
+// system idle (6.03e3 -> 6.46e3 atoms/s with 192 sweep workgroups each).
+template <typename TA>
+static int omp_ticks_pair(csmp_ctx* a, const bool pa[3], csmp_ctx* b, const bool pb[3], int64_t k, double eps, bool optimistic, int grid) {
+    TickPipe ta, tb;
+    tick_pipe_begin(ta, a, pa, k, grid);
+    tick_pipe_begin(tb, b, pb, k, grid);
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
-        const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);  // sweep, qr1, qr2 slots
-        const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
-        const bool az = present[zs] && n >= zs && tz < k;
-        const bool ay = present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
-        const bool ax = present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
-        if (!az && !ay && !ax) continue;
-        int jh1 = 0;
-        if (ay) {
-            jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
-            sl[ys]->jh_last = jh1;
-            if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
+        CHECK(tick_pipe_launch<TA>(ta, n, k, eps, optimistic));
+        const int rc = tick_pipe_launch<TA>(tb, n, k, eps, optimistic);
+        if (rc != CSMP_OK) {
+            a->err = b->err;
+            return rc;
         }
-        const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, nblk, az ? 1 : 0);
-        const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
-        const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
-        const bool steady = az && ay && ax;
-        const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
-        if (timed) CHECK(prof_mark(ctx));
-        HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, lds, steady));
-        if (timed) CHECK(prof_mark(ctx));
     }
     return CSMP_OK;
 }

@@ -83,6 +83,8 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tune_sweep_U = src->tune_sweep_U;
     dst->tune_sweep_dyn = src->tune_sweep_dyn;
     dst->tick_sweep_first = src->tick_sweep_first;
+    dst->claim_pools = src->claim_pools;
+    dst->tune_pipelines = src->tune_pipelines;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;
     dst->tune_rebuild_direct = src->tune_rebuild_direct;
