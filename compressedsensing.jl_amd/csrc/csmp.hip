@@ -32,6 +32,7 @@
 
 using namespace csmp;
 
+#include "host/hostonly.hpp"
 #include "host/ctx.hpp"
 #include "host/lifetime.hpp"
 #include "host/dictionary.hpp"

@@ -276,64 +276,7 @@ static int set_dictionary_impl(csmp_ctx* ctx, const void* A, int64_t M, int64_t 
 // csmp_set_dictionary_file reads it straight to where it will live: HBM (CSMP_DEVICE: through two page-locked staging buffers,
 // the read of one chunk under the upload of the other) or page-locked host memory mapped into the device (CSMP_HOST_STREAMED:
 // every sweep then crosses the host link -- ~50 GB/s against HBM's 6.6 TB/s; the mode for a dictionary that does not fit).
-struct DictFileHeader {
-    char magic[8];
-    uint32_t version, dtype;
-    int64_t M, N, ld;
-    char pad[24];
-};
-static_assert(sizeof(DictFileHeader) == 64, "header layout");
-
-extern "C" int csmp_dictionary_file_write(const char* path, const void* A, int64_t M, int64_t N, int64_t ldA, int dtype) {
-    if (!path || !A || M < 1 || N < 1 || ldA < M || (dtype != CSMP_F32 && dtype != CSMP_F64)) return CSMP_EINVAL;
-    const size_t es = dtype == CSMP_F32 ? 4 : 8;
-    const int64_t vec = 16 / (int64_t)es, ld = ((M + vec - 1) / vec) * vec;
-    FILE* f = fopen(path, "wb");
-    if (!f) return CSMP_EIO;
-    DictFileHeader h{};
-    memcpy(h.magic, "CSMPDICT", 8);
-    h.version = 1;
-    h.dtype = (uint32_t)dtype;
-    h.M = M;
-    h.N = N;
-    h.ld = ld;
-    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
-    const char zeros[16] = {0};
-    for (int64_t c = 0; c < N && ok; ++c) {
-        ok = fwrite((const char*)A + (size_t)c * (size_t)ldA * es, es, (size_t)M, f) == (size_t)M;
-        if (ok && ld > M) ok = fwrite(zeros, es, (size_t)(ld - M), f) == (size_t)(ld - M);
-    }
-    ok = (fclose(f) == 0) && ok;
-    return ok ? CSMP_OK : CSMP_EIO;
-}
-
-static int dict_file_open(const char* path, FILE** out, DictFileHeader* h) {
-    FILE* f = fopen(path, "rb");
-    if (!f) return CSMP_EIO;
-    if (fread(h, sizeof *h, 1, f) != 1 || memcmp(h->magic, "CSMPDICT", 8) != 0 || h->version != 1 ||
-        (h->dtype != (uint32_t)CSMP_F32 && h->dtype != (uint32_t)CSMP_F64) || h->M < 1 || h->N < 1 || h->ld < h->M ||
-        h->ld != ((h->M + (h->dtype == (uint32_t)CSMP_F32 ? 3 : 1)) / (h->dtype == (uint32_t)CSMP_F32 ? 4 : 2)) * (h->dtype == (uint32_t)CSMP_F32 ? 4 : 2)) {
-        // (ld is M rounded up to 16 bytes, nothing else: the kernels read the padding rows as part of the columns)
-        fclose(f);
-        return CSMP_EIO;
-    }
-    *out = f;
-    return CSMP_OK;
-}
-
-extern "C" int csmp_dictionary_file_info(const char* path, int64_t* M, int64_t* N, int* dtype) {
-    if (!path) return CSMP_EINVAL;
-    FILE* f = nullptr;
-    DictFileHeader h;
-    const int rc = dict_file_open(path, &f, &h);
-    if (rc != CSMP_OK) return rc;
-    fclose(f);
-    if (M) *M = h.M;
-    if (N) *N = h.N;
-    if (dtype) *dtype = (int)h.dtype;
-    return CSMP_OK;
-}
-
+// (DictFileHeader, csmp_dictionary_file_write / _info and dict_file_open: host/hostonly.hpp -- no context, no HIP)
 static int set_dictionary_file_impl(csmp_ctx* ctx, FILE* f, const DictFileHeader& h, int loc);
 extern "C" int csmp_set_dictionary_file(csmp_ctx* ctx, const char* path, int loc) {
     if (!ctx) return CSMP_EINVAL;

@@ -190,34 +190,4 @@ extern "C" int csmp_shard_append(csmp_ctx* ctx, const void* recs_dev, int nrec) 
 // three host-side helpers fix its layout so that any host language can run it over its own collective
 // (torch.distributed / RCCL here, MPI.jl from Julia): contiguous blocks of signals per rank, and per signal one row
 // of 2k + 1 Float64 = [idx_0 .. idx_{k-1} | val_0 .. val_{k-1} | nnz] (indices are exact in Float64 below 2^53).
-extern "C" int csmp_shard_range(int64_t nsig, int rank, int world, int64_t* lo, int64_t* hi) {
-    if (nsig < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return CSMP_EINVAL;
-    const int64_t base = nsig / world, extra = nsig % world;  // block sizes differ by at most one
-    *lo = rank * base + std::min<int64_t>(rank, extra);
-    *hi = *lo + base + (rank < extra ? 1 : 0);
-    return CSMP_OK;
-}
-extern "C" int csmp_pack_results(const int64_t* idx, const double* val, const int64_t* nnz, int64_t k, int64_t nsig, double* packed) {
-    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
-    const int64_t w = 2 * k + 1;
-    for (int64_t s = 0; s < nsig; ++s) {
-        for (int64_t t = 0; t < k; ++t) {
-            packed[s * w + t] = (double)idx[s * k + t];
-            packed[s * w + k + t] = val[s * k + t];
-        }
-        packed[s * w + 2 * k] = (double)nnz[s];
-    }
-    return CSMP_OK;
-}
-extern "C" int csmp_unpack_results(const double* packed, int64_t k, int64_t nsig, int64_t* idx, double* val, int64_t* nnz) {
-    if (!idx || !val || !nnz || !packed || k < 0 || nsig < 0) return CSMP_EINVAL;
-    const int64_t w = 2 * k + 1;
-    for (int64_t s = 0; s < nsig; ++s) {
-        for (int64_t t = 0; t < k; ++t) {
-            idx[s * k + t] = (int64_t)packed[s * w + t];
-            val[s * k + t] = packed[s * w + k + t];
-        }
-        nnz[s] = (int64_t)packed[s * w + 2 * k];
-    }
-    return CSMP_OK;
-}
+// (csmp_shard_range, csmp_pack_results, csmp_unpack_results: host/hostonly.hpp -- no context, no HIP)

@@ -28,9 +28,11 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libcsmp_oracle.so")
-        if not os.path.exists(so):
-            build()
+        so = os.environ.get("CSMP_ORACLE_SO")  # tools/sanitize_cpu.sh: the same source built with gcc's sanitizers
+        if not so:
+            so = os.path.join(_HERE, "libcsmp_oracle.so")
+            if not os.path.exists(so):
+                build()
         _LIB = C.CDLL(so)
         _LIB.cso_sweep_abs.restype = i64
     return _LIB
