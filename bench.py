@@ -105,7 +105,7 @@ def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
 LINE_BUDGET = 3000  # bytes: the driver keeps ~8 KB of stdout tail; round 3's 30 KB line was cut and the record did not parse
 DETAIL_FILE = "bench_secondary.json"
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_timed", "avg_launch_us",
-              "algorithmic_bytes_per_launch", "flops_per_launch")
+              "algorithmic_bytes_per_launch", "flops_per_launch", "launch_duration_us", "launches_in_flight")
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "signals_per_sec", "config", "roofline", "cpu_baseline", "secondary", "secondary_file", "gather_check",
              "ranks_seen", "devices", "matches_exact_path_on_sample", "batch_stats", "equals_unsharded_omp", "ranks_agree_on_first_support", "error")
@@ -990,23 +990,23 @@ def run_colsharded(args, cs, torch, dist, dev, rank, world, use_dist, ranks_seen
 
 
 def run_shapes(args, cs, torch, np, dev):
-    """The product sweep c = A'r over dictionaries of ~1 GiB with M = 1000 .. 32768 rows, Float32 and Float64 (the reference is
+    """The product sweep c = A'r over dictionaries of ~1 GiB with M = 256 .. 32768 rows, Float32 and Float64 (the reference is
     generic over shape and element type, src/matchingpursuit.jl:54-60; its own tests are Float64): every row checked against torch's
     Float64 product, timed with HIP events (csmp_bench_sweep, median of five runs), priced against 8 TB/s.  Writes the table to
-    profiles/r05_sweep_shapes.json when run from the repository (tools/sweep_shapes.py holds the loop)."""
+    profiles/r06_sweep_shapes.json when run from the repository (tools/sweep_shapes.py holds the loop)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import sweep_shapes
     rows = sweep_shapes.table(torch, np, cs, dev, reps=max(5, min(args.steps, 20)))
     worst = min(rows, key=lambda r: r["frac"])
-    out = {"metric": "product sweep A'r: worst fraction of the HBM roofline over 14 shapes (M = 1000..32768, f32 and f64, ~1 GiB each)",
+    out = {"metric": "product sweep A'r: worst fraction of the HBM roofline over %d shapes (M = 256..32768, f32 and f64, ~1 GiB each)" % len(rows),
            "value": worst["frac"], "unit": "fraction of 8 TB/s", "n_gpus": 1, "steps": len(rows), "warmup": 0,
            "ms_per_step": sum(r["us"] for r in rows) / len(rows) / 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f64", "data": "synthetic", "config": {"workload": "shape table of the A'r sweep (verdict round 4, item 1)"},
+           "dtype": "f64", "data": "synthetic", "config": {"workload": "shape table of the A'r sweep (verdict round 4 item 1, round 5 item 2)"},
            "roofline": {"bound": "hbm", "achieved": worst["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": worst["frac"], "traffic": None,
                         "kernel": "csmp::k_sweep_gen (worst row: M = %d %s)" % (worst["M"], worst["dtype"])},
            "all_correct": all(r["argmax_ok"] and r["max_rel_err"] < 1e-12 for r in rows), "rows": rows}
     try:
-        with open(os.path.join(ROOT, "profiles", "r05_sweep_shapes.json"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", "r06_sweep_shapes.json"), "w") as f:
             json.dump(rows, f, indent=1)
     except OSError:
         pass
@@ -1167,6 +1167,7 @@ def main():
             gathered = exchange_results(idx[W:], val[W:], nnz[W:])
     barrier()
     dt = time.perf_counter() - t0
+    window = D.ctx.profile_window()  # (before profile_read, which consumes the events)
     sweeps, sweep_ms = D.ctx.profile_read(reset=True)
     D.ctx.profile_enable(False)
 
@@ -1181,7 +1182,16 @@ def main():
         alg_bytes = M * N * 4  # bytes/atom = M*N*sizeof(Float32), A streamed once
         # a timed launch's bracket reads the launch plus the event pair itself: the empty-pair reading is measured and subtracted
         bracket_ms = D.ctx.profile_overhead(64)
-        avg_sweep_s = max(sweep_ms / max(sweeps, 1) - bracket_ms, 0.0) / 1e3
+        duration_s = max(sweep_ms / max(sweeps, 1) - bracket_ms, 0.0) / 1e3  # one launch, start to end
+        two = window["streams"] == 2 and window["launches"] > 0
+        if two:
+            # Two pipelines side by side (csmp_omp_batch from six signals on): the sweep launches of the two streams OVERLAP -- while one
+            # launch runs, the other pipeline's launch moves its bytes too, so bytes / (one launch's duration) is not a bandwidth.
+            # The launches are priced as one window instead: all sweep launches from the first to the last timed one on each stream,
+            # over the time from the earliest start event to the latest end event (HIP events on both streams, one clock).
+            avg_sweep_s = window["window_ms"] / 1e3 / window["launches"]
+        else:
+            avg_sweep_s = duration_s
         achieved = alg_bytes / avg_sweep_s / 1e9 if sweeps else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "sweep_traffic.json")
@@ -1189,25 +1199,33 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "csmp::" + tick_kernel_name(D) + " = the steady-state tick of the pipelined batch: the product sweep of one "
+                "kernel": "csmp::" + tick_kernel_name(D) + (" = the sweep launch of a tick: the product sweep of one signal (one column per wave, a ring of "
+                          "32 nt loads = up to 32 KiB in flight per wave), one workgroup per CU; two pipelines of three signals run side by side on "
+                          "two streams, so two such launches overlap and a CU that a workgroup of one leaves goes to the next workgroup of the other"
+                          if two else " = the steady-state tick of the pipelined batch: the product sweep of one "
                           "signal (one column per wave, a ring of 32 nt loads = up to 32 KiB in flight per wave) fused with the two "
-                          "short append stages of two other signals; csmp::k_sweep_gen<float,16,2,false> when a signal runs alone",
+                          "short append stages of two other signals") + "; csmp::k_sweep_gen<float,16,2,false> when a signal runs alone",
                 "sweep_config": D.ctx.sweep_config(),
-                "launches_timed": int(sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
-                "timer": "HIP events on the library's stream around every %d-th steady-state tick of the timed region, minus the reading of "
-                         "an empty event pair (%.2f us)" % (args.profile_every, bracket_ms * 1e3), "event_pair_us": bracket_ms * 1e3}
-        rp = rocprof_row(tick_kernel_name(D), pattern="r05_bench_kernel_stats.csv")
+                "launches_timed": int(window["launches"] if two else sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
+                "launch_duration_us": duration_s * 1e6, "launches_in_flight": 2 if two else 1,
+                "timer": ("HIP events on BOTH pipelines' streams around every %d-th sweep launch of the timed region: avg_launch_us = (latest end - "
+                          "earliest start) / (the %d launches from the first to the last timed one on each stream) -- the launches of the two streams "
+                          "overlap, each lasting launch_duration_us (mean of the timed ones minus the reading of an empty event pair, %.2f us; the "
+                          "rocprofv3 row's AverageNs is THIS number)" % (args.profile_every, window["launches"], bracket_ms * 1e3)) if two else
+                         ("HIP events on the library's stream around every %d-th steady-state tick of the timed region, minus the reading of "
+                          "an empty event pair (%.2f us)" % (args.profile_every, bracket_ms * 1e3)), "event_pair_us": bracket_ms * 1e3}
+        rp = rocprof_row(tick_kernel_name(D), pattern="r06_bench_kernel_stats.csv")
         if rp:
             roof["committed_profile"] = rp
         out = {
-            "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps, 3 signals pipelined)",
+            "metric": "OMP atoms selected/sec at m=4096,n=65536,k=256 (single-signal sweeps, 2 x 3 signals pipelined)",
             "value": atoms / tmax, "unit": "atoms/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "signals_per_sec": K * world / tmax,
             "config": {"workload": "configs[1]: single-signal OMP, A 4096x65536 Float32 Gaussian unit-norm, "
                                    "k=256, planted +-1 256-sparse x0 + noise 5e-3, eps=eps(Float32)",
-                       "signals_per_gpu": K, "signals_in_flight": 3,
+                       "signals_per_gpu": K, "signals_in_flight": 6 if two else 3,
                        "sharding": f"signals over {world} GPU(s), A replicated, one all_gather",
                        "collective": "ncclAllGather inside csmp_omp_sharded" if lib_gather else ("torch.distributed all_gather" if use_dist else "none (one rank)")},
             "ranks_seen": ranks_seen, "devices": devices,

@@ -91,12 +91,13 @@ INTERNAL_SIGNATURES = {
     "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "csmp_profile_overhead": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
+    "csmp_profile_window": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_tune": (C.c_int, [vp, C.c_int, i64]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12}  # CSMP_TUNE_* (include/csmp_internal.h)
+TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
 
@@ -692,6 +693,12 @@ class Context:
         ms = C.c_double(0)
         self.call("csmp_profile_read", C.byref(n), C.byref(ms), int(bool(reset)))
         return n.value, ms.value
+
+    def profile_window(self):
+        """the timed launches of this context and its twin as one window (csmp_internal.h); call before profile_read"""
+        n, w, d, st = i64(0), C.c_double(0), C.c_double(0), C.c_int(0)
+        self.call("csmp_profile_window", C.byref(n), C.byref(w), C.byref(d), C.byref(st))
+        return {"launches": int(n.value), "window_ms": w.value, "mean_launch_ms": d.value, "streams": st.value}
 
     def profile_overhead(self, reps=64):
         """average reading (ms) of an empty HIP-event pair on this context's stream"""

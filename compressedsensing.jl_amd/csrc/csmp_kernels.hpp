@@ -88,6 +88,35 @@ __device__ __forceinline__ double block_sum256(double v, double* scratch4) {
 }
 
 __device__ __forceinline__ double shx(double v, int m) { return __shfl_xor(v, m, kWave); }
+// The wave-wide butterfly sum v += xor 32, 16, 8, 4, 2, 1 (every lane ends with the total) WITHOUT LDS trips: __shfl_xor is a
+// ds_bpermute -- six dependent LDS round trips per column of the sweep, during which the wave's ring is one unit short.
+// gfx950's v_permlane32_swap / v_permlane16_swap exchange the halves / the odd and even rows of two registers; handed the same
+// value twice they leave (own, partner) or (partner, own) in the pair, and own + partner is the butterfly step either way.  The
+// four in-row steps are DPP moves (row_ror:8; row_shl:4 / row_shr:4 under bank masks; two quad permutations).  The same pairs in
+// the same order as the shuffle form and commutative additions: bit-identical to it (tools/probes/xsum_probe.hip).
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ double dpp_mov_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_xsum(double v) {
+    {
+        const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);  // xor 32
+    }
+    {
+        const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);  // xor 16
+    }
+    v += dpp_mov_f64<0x128>(v, v);                                    // xor 8: row_ror:8
+    v += dpp_mov_f64<0x114, 0xa>(dpp_mov_f64<0x104, 0x5>(v, v), v);   // xor 4: lanes with bit 2 clear read lane + 4 (row_shl:4), the others lane - 4 (row_shr:4)
+    v += dpp_mov_f64<0x4E>(v, v);                                     // xor 2: quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0xB1>(v, v);                                     // xor 1: quad_perm [1,0,3,2]
+    return v;
+}
 // value of lane `src` (uniform) in every lane: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double readlane_f64(double v, int src) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
@@ -258,7 +287,7 @@ __device__ __forceinline__ void sweep_body_gen(
                 }
             }
             if (++cb == nunit) {  // the column's last unit of this stage
-                for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+                acc = wave_xsum(acc);
                 if constexpr (PH) {
                     if (ph > 0) acc = pv + acc;
                 }
@@ -518,7 +547,7 @@ __device__ __forceinline__ void sweep_body_dyn(
             }
         }
         if (u_ == nunit - 1) {  // the column's last unit
-            for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+            acc = wave_xsum(acc);
             if (lane == 0) cvec[c_] = acc;
             const double av = fabs(acc);
             if (better(av, c_, bestv, besti)) {

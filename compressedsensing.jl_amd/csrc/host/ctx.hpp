@@ -187,6 +187,8 @@ struct csmp_ctx {
     int tune_sweep_grid = 0, tune_sweep_U = 0;
     bool sweep_dyn = false;  // the product sweep hands its columns out at run time (k_sweep_dyn, the DYN tick)
     int tune_sweep_dyn = 0;  // csmp_tune: 1 = the columns handed out at run time where one image holds the residual (measured slower: DESIGN.md section 0)
+    int tune_pair_lds_kib = 0;  // csmp_tune: dynamic LDS (KiB) of the ticks of two pipelines side by side, 0 = kPairLdsKiB (one workgroup per CU)
+    int tune_pair_split = 0;    // csmp_tune: 1 = two pipelines side by side keep the fused tick (one launch), default: append stages and sweep in two launches
     int tune_pipelines = 0;  // csmp_tune: 1 = csmp_omp_batch keeps ONE pipeline of three signals (default: two side by side from six signals on)
     int claim_pools = 8;     // counters a workgroup of the dynamic sweep finds empty in a row before it stops (its own, then the following workgroups')
     int tune_rebuild_direct = 0;  // csmp_tune: the oblivious start's Q'A pass reads its directions from L2 (k_fr_rebuild) instead of the LDS
@@ -219,6 +221,8 @@ struct csmp_ctx {
     bool prof = false;
     int prof_every = 1;       // time every n-th sweep launch only (an event pair costs a few us of stream time)
     int64_t prof_count = 0;
+    int64_t prof_first = -1, prof_last = -1;  // launch numbers of the first and the last sampled launch since the events were last read
+    hipEvent_t prof_ref = nullptr;            // recorded by csmp_profile_enable: the origin of csmp_profile_window's clock
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     int64_t prof_n = 0;

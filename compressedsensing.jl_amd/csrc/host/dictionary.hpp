@@ -55,7 +55,13 @@ static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int 
 // true when this sweep launch is one of the sampled ones
 static bool prof_pick(csmp_ctx* ctx) {
     if (!ctx->prof) return false;
-    return (ctx->prof_count++ % ctx->prof_every) == 0;
+    const bool pick = (ctx->prof_count % ctx->prof_every) == 0;
+    if (pick) {  // (csmp_profile_window: the launches between the first and the last sampled one)
+        if (ctx->prof_first < 0) ctx->prof_first = ctx->prof_count;
+        ctx->prof_last = ctx->prof_count;
+    }
+    ctx->prof_count += 1;
+    return pick;
 }
 
 static int prof_mark(csmp_ctx* ctx) {

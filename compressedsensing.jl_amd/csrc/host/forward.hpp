@@ -329,6 +329,8 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         rc = twins_ensure(ctx, 1);
         if (rc == CSMP_OK) {
             tw = ctx->twins[0];
+            tw->prof = ctx->prof;  // (csmp_profile_*: the second pipeline's launches are sampled like the first's)
+            tw->prof_every = ctx->prof_every;
             for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
                 activate_slot(tw, q);
                 rc = solver_ensure(tw, kc, (int)k);

@@ -109,6 +109,7 @@ extern "C" int csmp_destroy(csmp_ctx* ctx) {
         t = nullptr;
     }
     if (ctx->ev_twin) (void)hipEventDestroy(ctx->ev_twin);
+    if (ctx->prof_ref) (void)hipEventDestroy(ctx->prof_ref);
     if (ctx->spjob.ev) (void)hipEventDestroy(ctx->spjob.ev);
     if (ctx->stream_b) (void)hipStreamDestroy(ctx->stream_b);
     for (hipEvent_t e : {ctx->ev_fork, ctx->ev_join, ctx->ev_off, ctx->ev_gate})

@@ -6,6 +6,51 @@ extern "C" int csmp_profile_enable(csmp_ctx* ctx, int on) {
     ctx->prof = on != 0;
     ctx->prof_every = on > 1 ? on : 1;  // on = n > 1: time every n-th sweep launch
     ctx->prof_count = 0;
+    ctx->prof_first = ctx->prof_last = -1;
+    if (ctx->prof) {
+        HIPCHECK(hipSetDevice(ctx->dev));
+        if (!ctx->prof_ref) HIPCHECK(hipEventCreate(&ctx->prof_ref));
+        HIPCHECK(hipEventRecord(ctx->prof_ref, ctx->stream));
+    }
+    return CSMP_OK;
+}
+
+// The timed launches as ONE window.  csmp_omp_batch runs two pipelines side by side from six signals on (host/omp.hpp): their
+// sweep launches overlap, so a launch's own duration says nothing about the bandwidth -- the bytes of BOTH streams' launches move
+// during it.  This call reports, over this context and its twin: the launches from the first to the last sampled one on each stream
+// (all of them, sampled or not), the time from the earliest of their start events to the latest of their end events (one clock:
+// HIP events on the two streams, measured from the event csmp_profile_enable recorded), and the mean duration of a sampled launch.
+// Launches outside a stream's first .. last sampled one are not counted although part of their traffic may fall into the window:
+// bytes / window never overstates.  Call it BEFORE csmp_profile_read (which consumes the events).
+extern "C" int csmp_profile_window(csmp_ctx* ctx, int64_t* launches, double* window_ms, double* mean_launch_ms, int* streams) {
+    if (!ctx) return CSMP_EINVAL;
+    HIPCHECK(hipSetDevice(ctx->dev));
+    HIPCHECK(sync_all(ctx));
+    csmp_ctx* cc[2] = {ctx, ctx->twins[0]};
+    int64_t n = 0, pairs = 0;
+    double t0 = 0.0, t1 = 0.0, dur = 0.0;
+    int ns = 0;
+    for (csmp_ctx* c : cc) {
+        if (!c || c->ev_used < 2 || c->prof_first < 0 || !ctx->prof_ref) continue;
+        if (c != ctx) HIPCHECK(hipStreamSynchronize(c->stream));
+        float s = 0.f, e = 0.f;
+        HIPCHECK(hipEventElapsedTime(&s, ctx->prof_ref, c->ev[0]));
+        HIPCHECK(hipEventElapsedTime(&e, ctx->prof_ref, c->ev[c->ev_used - 1]));
+        if (ns == 0 || s < t0) t0 = s;
+        if (ns == 0 || e > t1) t1 = e;
+        n += c->prof_last - c->prof_first + 1;
+        for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+            dur += ms;
+            pairs += 1;
+        }
+        ns += 1;
+    }
+    if (launches) *launches = n;
+    if (window_ms) *window_ms = ns ? t1 - t0 : 0.0;
+    if (mean_launch_ms) *mean_launch_ms = pairs ? dur / (double)pairs : 0.0;
+    if (streams) *streams = ns;
     return CSMP_OK;
 }
 
@@ -20,6 +65,18 @@ extern "C" int csmp_profile_read(csmp_ctx* ctx, int64_t* sweep_launches, double*
         ctx->prof_n += 1;
     }
     ctx->ev_used = 0;
+    ctx->prof_first = ctx->prof_last = -1;
+    if (csmp_ctx* tw = ctx->twins[0]) {  // (the second pipeline of csmp_omp_batch: its sampled launches count like this context's)
+        if (tw->ev_used >= 2) HIPCHECK(hipStreamSynchronize(tw->stream));
+        for (size_t i = 0; i + 1 < tw->ev_used; i += 2) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, tw->ev[i], tw->ev[i + 1]));
+            ctx->prof_ms += ms;
+            ctx->prof_n += 1;
+        }
+        tw->ev_used = 0;
+        tw->prof_first = tw->prof_last = -1;
+    }
     if (sweep_launches) *sweep_launches = ctx->prof_n;
     if (sweep_ms) *sweep_ms = ctx->prof_ms;
     if (reset) {
@@ -109,7 +166,15 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             if (value < 1 || value > 4096) return fail(ctx, CSMP_EINVAL, "csmp_tune: claim pools must be 1..4096");
             ctx->claim_pools = (int)value;
             return CSMP_OK;
-        case CSMP_TUNE_PIPELINES: ctx->tune_pipelines = value == 1 ? 1 : 0; return CSMP_OK;
+        case CSMP_TUNE_PAIR_LDS_KIB:
+            if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");
+            ctx->tune_pair_lds_kib = (int)value;
+            return CSMP_OK;
+        case CSMP_TUNE_PAIR_SPLIT: ctx->tune_pair_split = value == 1 ? 1 : 0; return CSMP_OK;
+        case CSMP_TUNE_PIPELINES:
+            if (value > 2) return fail(ctx, CSMP_EINVAL, "csmp_tune: pipelines must be 0 (automatic), 1 or 2");
+            ctx->tune_pipelines = (int)value;
+            return CSMP_OK;
         case CSMP_TUNE_TICK_ORDER: ctx->tick_sweep_first = value != 0; return CSMP_OK;
         case CSMP_TUNE_REBUILD_DIRECT: ctx->tune_rebuild_direct = value ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_SWAP_REFUSE: ctx->tune_swap_refuse = value ? 1 : 0; return CSMP_OK;

@@ -74,6 +74,7 @@ struct TickPipe {
     bool present[3] = {false, false, false};
     int nblk = 0;
     size_t lds = 0;
+    size_t lds_sweep = 0;  // > 0: a tick is TWO launches -- the append stages alone (lds), then the sweep alone under this LDS request
 };
 static void tick_pipe_begin(TickPipe& tp, csmp_ctx* ctx, const bool present[3], int64_t k, int grid_override) {
     tp.ctx = ctx;
@@ -111,6 +112,26 @@ static int tick_pipe_launch(TickPipe& tp, int64_t n, int64_t k, double eps, bool
     const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
     const bool steady = az && ay && ax;
     const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
+    if (tp.lds_sweep > 0) {
+        // the append stages first, in a launch of their own that asks for what they need (it shares the CUs with the OTHER pipeline's
+        // sweep), then the sweep alone with the large LDS request that keeps its workgroups one to a CU (omp_ticks_pair)
+        if (ay || ax) {
+            auto sw0 = sw;
+            sw0.active = 0;
+            sw0.nblk = 0;
+            HIPCHECK(tick_launch<TA>(ctx, sw0, q1, q2, G, tp.lds, false));
+        }
+        if (az) {
+            auto q10 = q1;
+            auto q20 = q2;
+            q10.active = 0;
+            q20.active = 0;
+            if (timed) CHECK(prof_mark(ctx));
+            HIPCHECK(tick_launch<TA>(ctx, sw, q10, q20, 0, tp.lds_sweep, steady));
+            if (timed) CHECK(prof_mark(ctx));
+        }
+        return CSMP_OK;
+    }
     if (timed) CHECK(prof_mark(ctx));
     HIPCHECK(tick_launch<TA>(ctx, sw, q1, q2, G, tp.lds, steady));
     if (timed) CHECK(prof_mark(ctx));
@@ -123,6 +144,7 @@ static int omp_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double eps
     for (int64_t n = 0; n < 3 * k + 2; ++n) CHECK(tick_pipe_launch<TA>(tp, n, k, eps, optimistic));
     return CSMP_OK;
 }
+constexpr int kPairLdsKiB = 81;     // dynamic LDS of a tick of two pipelines side by side: more than half a CU's 160 KiB = one workgroup per CU
 constexpr int kPairTickGrid = 192;  // sweep workgroups of each of two pipelines side by side (measured: 176 -> 6.41e3, 192 -> 6.46e3, 224 -> 6.45e3, 256 -> 6.41e3 atoms/s)
 // TWO pipelines side by side: a second triple of signals on a twin context (its own stream), the launches of the two enqueued
 // alternately.  The sweeps of the two then share the HBM, out of step with one another: the last workgroups of one tick, its
@@ -133,6 +155,20 @@ static int omp_ticks_pair(csmp_ctx* a, const bool pa[3], csmp_ctx* b, const bool
     TickPipe ta, tb;
     tick_pipe_begin(ta, a, pa, k, grid);
     tick_pipe_begin(tb, b, pb, k, grid);
+    // ONE workgroup per CU (an LDS request above half of the 160 KiB): the workgroups of the two pipelines' launches then QUEUE for the
+    // CUs instead of all being resident at once, and the dispatcher hands a CU that a workgroup of one tick has left to the next
+    // workgroup in line -- of the other pipeline's tick, whose sweep does not depend on this one.  The chip is never waiting for the
+    // slowest workgroups of a launch (they finish 139 ... 160 us into a 157-us sweep), for a launch boundary or for a residual image.
+    const size_t excl = (size_t)(a->tune_pair_lds_kib > 0 ? a->tune_pair_lds_kib : kPairLdsKiB) * 1024;
+    if (a->tune_pair_split == 1) {  // (measurement: the fused tick under the large request)
+        ta.lds = std::max(ta.lds, excl);
+        tb.lds = std::max(tb.lds, excl);
+    } else {
+        ta.lds_sweep = std::max(a->sweep_lds, excl);
+        tb.lds_sweep = std::max(b->sweep_lds, excl);
+        ta.lds = qr_lds_bytes((int)std::min<int64_t>(k, a->s.kcap));  // (the append stages' launch asks for what IT needs)
+        tb.lds = qr_lds_bytes((int)std::min<int64_t>(k, b->s.kcap));
+    }
     for (int64_t n = 0; n < 3 * k + 2; ++n) {
         CHECK(tick_pipe_launch<TA>(ta, n, k, eps, optimistic));
         const int rc = tick_pipe_launch<TA>(tb, n, k, eps, optimistic);

@@ -85,6 +85,8 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tick_sweep_first = src->tick_sweep_first;
     dst->claim_pools = src->claim_pools;
     dst->tune_pipelines = src->tune_pipelines;
+    dst->tune_pair_lds_kib = src->tune_pair_lds_kib;
+    dst->tune_pair_split = src->tune_pair_split;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;
     dst->tune_rebuild_direct = src->tune_rebuild_direct;

@@ -15,6 +15,10 @@ extern "C" {
 int csmp_profile_enable(csmp_ctx *ctx, int on);
 /* number of sweep launches timed and the sum of their durations (ms); reset != 0 clears */
 int csmp_profile_read(csmp_ctx *ctx, int64_t *sweep_launches, double *sweep_ms, int reset);
+/* the timed launches of this context and of the second pipeline of csmp_omp_batch (its twin) as ONE window: launches from the first
+ * to the last sampled one on each stream, the time from the earliest start event to the latest end event, the mean duration of a
+ * sampled launch, the number of streams that carried timed launches.  Before csmp_profile_read, which consumes the events. */
+int csmp_profile_window(csmp_ctx *ctx, int64_t *launches, double *window_ms, double *mean_launch_ms, int *streams);
 /* average reading (ms) of an event pair with nothing between its two records: the share of a timed launch's bracket that is the
  * bracket itself */
 int csmp_profile_overhead(csmp_ctx *ctx, int reps, double *avg_ms);
@@ -33,6 +37,8 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_PIPELINES 12    /* 1: csmp_omp_batch keeps one pipeline of three signals; default 0: two pipelines side by side from six signals on */
 #define CSMP_TUNE_TICK_ORDER 10   /* 1: the tick kernel's sweep workgroups are dispatched ahead of its append stages' */
 #define CSMP_TUNE_CLAIM_POOLS 11  /* the dynamic sweep: column pools a workgroup may claim from (its own first) */
+#define CSMP_TUNE_PAIR_LDS_KIB 13 /* dynamic LDS (KiB) requested by the ticks of two pipelines side by side: above 80 = one workgroup per CU (default 81), 1 = what the kernels need */
+#define CSMP_TUNE_PAIR_SPLIT 14   /* 1: two pipelines side by side keep the fused tick (append stages + sweep in ONE launch under the large LDS request); default 0: two launches per tick */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */

@@ -1,8 +1,10 @@
 #!/bin/bash
-# round 6: the headline bench with two pipelines side by side (default) against one (csmp_tune pipelines=1)
+# round 6: the headline bench with two pipelines side by side against one, over the LDS request (residency) and the sweep grid; ONE box
 show() { python -c "
-import json,sys;d=json.load(open(sys.argv[1]));print(sys.argv[1],d['value'],d['roofline']['avg_launch_us'],d['roofline']['launches_timed'])" "$1"; }
+import json,sys;d=json.load(open(sys.argv[1]));print(sys.argv[2],round(d['value'],1),round(d['roofline']['avg_launch_us'],2),d['roofline']['launches_timed'])" "$1" "$2"; }
 mkdir -p gpurun_out
-for i in 1 2; do python bench.py --no-secondary --cpu-seconds 1 > gpurun_out/bench_pair_$i.json 2> /dev/null; show gpurun_out/bench_pair_$i.json; done
-python bench.py --no-secondary --cpu-seconds 1 --tune pipelines=1 > gpurun_out/bench_one.json 2>/dev/null; show gpurun_out/bench_one.json
-python bench.py --no-secondary --cpu-seconds 1 --steps 36 --warmup 6 > gpurun_out/bench_pair_36.json 2>/dev/null; show gpurun_out/bench_pair_36.json
+run() { python bench.py --no-secondary --cpu-seconds 1 --tune "$1" > gpurun_out/bench_tmp.json 2>/dev/null; show gpurun_out/bench_tmp.json "$1"; }
+run pipelines=1
+for split in 1 0; do for grid in 176 208 224 240 256; do run pipelines=2,pair_split=$split,tick_grid=$grid; done; done
+run pipelines=1
+run pipelines=2

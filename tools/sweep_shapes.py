@@ -13,7 +13,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 HBM_PEAK = 8.0e12  # bytes/s (MI355X_MICROARCH.md)
-SHAPES_M = (1000, 3000, 4096, 4352, 8192, 12288, 32768)
+SHAPES_M = (256, 512, 1000, 3000, 4096, 4352, 8192, 12288, 32768)  # (round 6: 256 and 512 -- configs[0] is 256 x 1024, the reference's tests 32 x 48)
 
 
 def make_dictionary(torch, dev, M, N, dtype, seed=7):
