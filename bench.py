@@ -1077,6 +1077,8 @@ def main():
             args.steps, args.warmup = (9, 3) if args.workload in ("gomp", "sp") else (3, 1)
         if rank == 0:
             At5, D5 = make_dictionary5(cs, torch, dev)
+            for kv in filter(None, args.tune.split(",")):
+                D5.ctx.tune(kv.split("=")[0], int(kv.split("=")[1]))
             if args.in_flight:
                 D5.ctx.set_option("solves_in_flight", args.in_flight)
             emit(measure_config5(args.workload, args.steps, args.warmup, cs, torch, dev, D5, At5,

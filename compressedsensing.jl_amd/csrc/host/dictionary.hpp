@@ -5,12 +5,15 @@
 template <typename TA, int U, int NB, bool PH>
 static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols = 0) {
     auto kern = k_sweep_gen<TA, U, NB, PH>;
-    if (ctx->sweep_lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
+    // the LDS REQUEST may exceed what the kernel uses (configure_sweep: sweep_lds_req): it sets how many workgroups share a CU, and with
+    // more workgroups than fit the rest QUEUE -- a CU that a workgroup leaves goes to the next one in line
+    const size_t lds = std::max(ctx->sweep_lds, ctx->sweep_lds_req);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     Solver& s = ctx->s;
-    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
                        ncols > 0 ? ncols : ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP);
     return hipGetLastError();
 }
@@ -162,6 +165,7 @@ static int configure_sweep(csmp_ctx* ctx) {
     ctx->tick_grid = std::min(ctx->tick_grid, maxgrid);
     if (ctx->sweep_grid > kClaimMaxWgs || std::max(ctx->tick_grid, ctx->tick_nblk) > kClaimMaxWgs) ctx->sweep_dyn = false;  // (one counter per workgroup)
     ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
+    ctx->sweep_lds_req = (size_t)ctx->tune_sweep_lds_kib * 1024;
     return CSMP_OK;
 }
 

@@ -161,6 +161,10 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_sweep_U = (int)value;
             break;
         case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;  // (configure_sweep below: the dynamic sweep's grid limit)
+        case CSMP_TUNE_SWEEP_LDS_KIB:
+            if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");
+            ctx->tune_sweep_lds_kib = (int)value;
+            break;
         case CSMP_TUNE_SWEEP_DYN: ctx->tune_sweep_dyn = value ? 1 : 0; break;
         case CSMP_TUNE_CLAIM_POOLS:
             if (value < 1 || value > 4096) return fail(ctx, CSMP_EINVAL, "csmp_tune: claim pools must be 1..4096");

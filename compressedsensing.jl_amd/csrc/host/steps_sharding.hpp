@@ -87,6 +87,8 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tune_pipelines = src->tune_pipelines;
     dst->tune_pair_lds_kib = src->tune_pair_lds_kib;
     dst->tune_pair_split = src->tune_pair_split;
+    dst->tune_sweep_lds_kib = src->tune_sweep_lds_kib;
+    dst->sweep_lds_req = src->sweep_lds_req;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;
     dst->tune_rebuild_direct = src->tune_rebuild_direct;

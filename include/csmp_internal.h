@@ -39,6 +39,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_CLAIM_POOLS 11  /* the dynamic sweep: column pools a workgroup may claim from (its own first) */
 #define CSMP_TUNE_PAIR_LDS_KIB 13 /* dynamic LDS (KiB) requested by the ticks of two pipelines side by side: above 80 = one workgroup per CU (default 81), 1 = what the kernels need */
 #define CSMP_TUNE_PAIR_SPLIT 14   /* 1: two pipelines side by side keep the fused tick (append stages + sweep in ONE launch under the large LDS request); default 0: two launches per tick */
+#define CSMP_TUNE_SWEEP_LDS_KIB 15 /* dynamic LDS (KiB) the stand-alone product sweep REQUESTS when that is more than it uses: above 80 = one workgroup per CU, 54 = two */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */
