@@ -92,12 +92,12 @@ INTERNAL_SIGNATURES = {
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "csmp_profile_overhead": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
     "csmp_profile_window": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
-    "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(C.c_int)]),
+    "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "csmp_tune": (C.c_int, [vp, C.c_int, i64]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15}  # CSMP_TUNE_* (include/csmp_internal.h)
+TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15, "sweep_short": 16}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
 
@@ -713,10 +713,10 @@ class Context:
 
     def sweep_config(self):
         """what configure_sweep chose for the resident dictionary (csmp_internal.h)"""
-        unit, ph, wg, twg, lds, dyn = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), i64(0), C.c_int(0)
-        self.call("csmp_sweep_config", C.byref(unit), C.byref(ph), C.byref(wg), C.byref(twg), C.byref(lds), C.byref(dyn))
+        unit, ph, wg, twg, lds, dyn, cpu = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0), i64(0), C.c_int(0), C.c_int(0)
+        self.call("csmp_sweep_config", C.byref(unit), C.byref(ph), C.byref(wg), C.byref(twg), C.byref(lds), C.byref(dyn), C.byref(cpu))
         return {"unit_loads": unit.value, "phases": ph.value, "workgroups": wg.value, "tick_workgroups": twg.value,
-                "lds_bytes": int(lds.value), "dynamic": dyn.value}
+                "lds_bytes": int(lds.value), "dynamic": dyn.value, "columns_per_unit": cpu.value}
 
     def tune(self, key, value):
         """measurement override (csmp_internal.h): key in TUNE"""

@@ -100,22 +100,31 @@ __device__ __forceinline__ double dpp_mov_f64(double old, double v) {
     const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_xsum(double v) {
-    {
-        const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);  // xor 32
-    }
-    {
-        const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);  // xor 16
-    }
+// one butterfly step across the wave's halves (xor 32) / across neighbouring rows (xor 16) on TWO inputs: x + its partner where the
+// result keeps x's column, y + its partner where it keeps y's -- lanes 0..31 (rows 0 and 2) end with x's pair sums, lanes 32..63
+// (rows 1 and 3) with y's.  x == y is the plain step.  (swap: X' = [X_lo | Y_lo], Y' = [X_hi | Y_hi]; X' + Y' pairs lane i with i + 32.)
+__device__ __forceinline__ double xs32(double x, double y) {
+    const auto a = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+__device__ __forceinline__ double xs16(double x, double y) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+    return __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+}
+// the four steps inside a row of 16 lanes (xor 8, 4, 2, 1)
+__device__ __forceinline__ double row_xsum(double v) {
     v += dpp_mov_f64<0x128>(v, v);                                    // xor 8: row_ror:8
     v += dpp_mov_f64<0x114, 0xa>(dpp_mov_f64<0x104, 0x5>(v, v), v);   // xor 4: lanes with bit 2 clear read lane + 4 (row_shl:4), the others lane - 4 (row_shr:4)
     v += dpp_mov_f64<0x4E>(v, v);                                     // xor 2: quad_perm [2,3,0,1]
     v += dpp_mov_f64<0xB1>(v, v);                                     // xor 1: quad_perm [1,0,3,2]
     return v;
+}
+__device__ __forceinline__ double wave_xsum(double v) {
+    v = xs32(v, v);
+    v = xs16(v, v);
+    return row_xsum(v);
 }
 // value of lane `src` (uniform) in every lane: two v_readlane_b32, no LDS round trip
 __device__ __forceinline__ double readlane_f64(double v, int src) {
@@ -249,6 +258,12 @@ __device__ __forceinline__ void sweep_body_gen(
 
         VT buf[NB][U];
         double prev[NB];
+        // c values are STAGED: lane s keeps the total of the wave's s-th finished column and the wave writes 64 of them with one
+        // store instruction.  A store per column sits in the wave's in-order memory queue among the ring's loads: measured 1.5-3 us of
+        // a 155-us sweep at 16-KiB columns, 5-7 % at 8-KiB Float64 columns, 13 us of 170 with one store per 4 KiB (short columns).
+        double cst = 0.0;
+        int64_t ccst = -1;
+        int cslot = 0;
         int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
         int ib = 0, cb = 0;
         const int64_t T = ncol * nunit;
@@ -291,7 +306,15 @@ __device__ __forceinline__ void sweep_body_gen(
                 if constexpr (PH) {
                     if (ph > 0) acc = pv + acc;
                 }
-                if (lane == 0) cvec[ccol] = acc;
+                if (lane == cslot) {
+                    cst = acc;
+                    ccst = ccol;
+                }
+                if (++cslot == kWave) {
+                    if (ccst >= 0) cvec[ccst] = cst;
+                    ccst = -1;
+                    cslot = 0;
+                }
                 if (lastph) {
                     const double av = fabs(acc);
                     if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
@@ -329,6 +352,7 @@ __device__ __forceinline__ void sweep_body_gen(
                 if (ileft > 0) issue(buf[d], prev[d]);
             }
         }
+        if (ccst >= 0) cvec[ccst] = cst;  // (the columns staged since the last full store: before the next stage's barrier)
     }
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
@@ -357,6 +381,193 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_gen(
                                   (int)gridDim.x, KP, lds);
 }
 inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * sizeof(double); }
+
+// ---------------------------------------------------------------------------------------------
+// SHORT columns (the reference sweeps whatever size(A) is: its own tests are 32 x 48, configs[0] is 256 x 1024): when a column is
+// one or two 1-KiB wave loads, one column per unit leaves the ring's loads clamped duplicates and pays a reduction per KiB.  Here a
+// unit of eight loads covers 8 / NCH NEIGHBOURING columns of NCH chunks each; the lanes keep one partial sum per column and ONE
+// transposing butterfly reduces CPU of them together (two such sets where a unit holds eight columns): the xor-32 step keeps columns 0 / 1 in the wave's lower half and 2 / 3 in the upper
+// (CPU = 2: column 0 below, 1 above), the xor-16 step leaves column q in row q, the four in-row steps finish all of them at once --
+// the pairs and their order are those of wave_xsum for every column, so c[col] has the bits of the one-column body.
+// Lane 16 q (CPU = 2: lane 32 q) writes column q; every lane tracks the maximum of ITS column sequence (increasing indices).
+// One residual image (NCH chunks); a wave owns the column groups g0, g0 + stride, ...; a ragged last group clamps its column
+// addresses into the dictionary and neither writes nor ranks the surplus.  KP = NCH * 64 * VEC.
+// Measured, 1 GiB dictionaries (fraction of 8 TB/s, one column per unit -> this body): M = 256 f32 0.52 -> 0.79+, f64 0.75 -> 0.81;
+// M = 512 f32 0.72 -> 0.80+; M = 1000 f32 0.78 -> 0.83; M = 64 f32 0.17 -> 0.45.
+template <typename TA, int NCH, int CPU>
+__device__ __forceinline__ void sweep_body_short(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, const int KP, double* lds) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int U = 8, NB = 32 / U;       // units of eight loads, a ring of four
+    constexpr int CU_ = U / NCH;            // columns per unit
+    constexpr int SETS = CU_ / CPU;         // ... reduced CPU at a time
+    constexpr int NW = kSweepThreads / kWave;
+    static_assert(CPU == 2 || CPU == 4, "two or four columns per transposing reduction");
+    static_assert(U % NCH == 0 && CU_ % CPU == 0 && SETS >= 1, "whole columns per unit, whole sets per unit");
+    if (st->done & skipmask) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nvec = Mv / VEC;
+    double* red = lds + KP;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    {
+        double n2 = 0.0;
+        for (int m = tid; m < KP; m += kSweepThreads) {
+            const double rv = m < Mv ? r[m] : 0.0;
+            lds[r_slot<VEC>(m)] = rv;
+            n2 = fma(rv, rv, n2);
+        }
+        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        __syncthreads();
+        if (lane == 0) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return;
+        }
+    }
+    const int64_t ngrp = (N + CU_ - 1) / CU_;
+    const int64_t g0 = (int64_t)bid * NW + wave, stride = (int64_t)nblk * NW;
+    const int64_t T = g0 < ngrp ? (ngrp - 1 - g0) / stride + 1 : 0;
+    const int q = CPU == 4 ? (lane >> 4) : (lane >> 5);  // the column of its group this lane ends up holding
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+    VT buf[NB][U];
+    constexpr int LW = kWave / CPU, SLOTS = LW / SETS;
+    double cst = 0.0;
+    int64_t ccst = -1;
+    int cslot = 0;
+    int64_t ig = g0, cg = g0;
+    int64_t ileft = T, cleft = T;
+    auto issue = [&](VT(&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t col = ig * CU_ + u / NCH;
+            const VT* pc = reinterpret_cast<const VT*>(A + (col < N ? col : N - 1) * ld);
+            const int v = (u % NCH) * kWave + lane;
+            b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
+        }
+        ig += stride;
+        --ileft;
+    };
+    auto consume = [&](const VT(&b)[U]) {
+        double a[CU_];
+#pragma unroll
+        for (int c = 0; c < CU_; ++c) a[c] = 0.0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = u / NCH, t = u % NCH;
+            if constexpr (VEC == 4) {
+                const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                a[c] = fma((double)b[u].x, r01.x, a[c]);
+                a[c] = fma((double)b[u].y, r01.y, a[c]);
+                a[c] = fma((double)b[u].z, r23.x, a[c]);
+                a[c] = fma((double)b[u].w, r23.y, a[c]);
+            } else {
+                const f64x2 r01 = rs[t * kWave + lane];
+                a[c] = fma((double)b[u].x, r01.x, a[c]);
+                a[c] = fma((double)b[u].y, r01.y, a[c]);
+            }
+        }
+        double vs[SETS];
+#pragma unroll
+        for (int set = 0; set < SETS; ++set) {
+            double v;
+            if constexpr (CPU == 4) {
+                v = xs16(xs32(a[set * 4 + 0], a[set * 4 + 2]), xs32(a[set * 4 + 1], a[set * 4 + 3]));
+            } else {
+                v = xs32(a[set * 2 + 0], a[set * 2 + 1]);
+                v = xs16(v, v);
+            }
+            v = row_xsum(v);
+            vs[set] = v;
+            const int64_t col = cg * CU_ + set * CPU + q;
+            if (col < N) {
+                const double av = fabs(v);
+                if (av > bestv) {  // a lane's columns arrive in increasing order: '>' keeps the first maximum
+                    bestv = av;
+                    besti = (int)col;
+                }
+            }
+        }
+        // the c values are staged (see sweep_body_gen): the LW = 64 / CPU lanes that hold a column's total are SETS x SLOTS; lane
+        // (q, set, slot) keeps column set * CPU + q of the unit whose number is slot mod SLOTS, and every SLOTS units all 64 lanes store
+        {
+            const int set = (lane & (LW - 1)) / SLOTS, slot = (lane & (LW - 1)) % SLOTS;
+            if (slot == cslot) {
+                double v = vs[0];
+                if constexpr (SETS == 2) v = set == 1 ? vs[1] : vs[0];
+                const int64_t col = cg * CU_ + set * CPU + q;
+                cst = v;
+                ccst = col < N ? col : -1;
+            }
+            if (++cslot == SLOTS) {
+                if (ccst >= 0) cvec[ccst] = cst;
+                ccst = -1;
+                cslot = 0;
+            }
+        }
+        cg += stride;
+        --cleft;
+    };
+    if (T >= 2 * NB) {
+#pragma unroll
+        for (int d = 0; d < NB; ++d) issue(buf[d]);
+        const int64_t groups = T / NB - 1;
+        for (int64_t g = 0; g < groups; ++g) {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) {
+                consume(buf[d]);
+                issue(buf[d]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int d = 0; d < NB; ++d)
+            if (d < T) issue(buf[d]);
+    }
+    while (cleft > 0) {
+#pragma unroll
+        for (int d = 0; d < NB; ++d) {
+            if (cleft == 0) break;
+            consume(buf[d]);
+            if (ileft > 0) issue(buf[d]);
+        }
+    }
+    if (ccst >= 0) cvec[ccst] = cst;
+    if ((lane & 15) == 0) {
+        redv[wave * 4 + (lane >> 4)] = bestv;
+        redi[wave * 4 + (lane >> 4)] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int qq = 1; qq < 4 * NW; ++qq)
+            if (better(redv[qq], redi[qq], bv, bi)) {
+                bv = redv[qq];
+                bi = redi[qq];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+template <typename TA, int NCH, int CPU>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_short(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, int KP) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body_short<TA, NCH, CPU>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, KP, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // The same sweep with its columns handed out AT RUN TIME (one residual image: !PH).  With a static split the workgroups of one

@@ -210,6 +210,9 @@ struct csmp_ctx {
     int opt_screened = 0;         // CSMP_OPT_SCREENED_SWEEP: csmp_omp / csmp_omp_batch / csmp_gomp sweep the bf16 image and certify (csmp_screened.hpp)
     int opt_batch_screen = 3;     // CSMP_OPT_BATCH_SCREEN: 3 (default) binary16 operands, 0 bf16, 1 int8, 2 int8 where the dictionary is flat (int8: statistical certificate only)
     size_t sweep_lds = 0;
+    int short_cpu = 0, short_nch = 0, short_KP = 0;  // k_sweep_short (stand-alone sweep of short columns): columns per reduction, chunks per column, image rows; 0 = the one-column body
+    size_t short_lds = 0;
+    int tune_sweep_short = 0;  // csmp_tune: 1 = the one-column body for every shape
     size_t sweep_lds_req = 0;    // the stand-alone sweep's LDS request when larger than sweep_lds (residency control)
     int tune_sweep_lds_kib = 0;  // csmp_tune
     Solver s;        // the ACTIVE solver slot (see activate_slot)

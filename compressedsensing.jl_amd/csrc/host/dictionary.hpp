@@ -38,8 +38,20 @@ static hipError_t sweep_launch_dyn(csmp_ctx* ctx, const double* r, double eps, i
                        ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next, ctx->claim_pools);
     return hipGetLastError();
 }
+// short columns (k_sweep_short): U loads = CPU neighbouring columns of U / CPU chunks, one transposing reduction per unit
+template <typename TA, int NCH, int CPU>
+static hipError_t sweep_launch_short(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols) {
+    auto kern = k_sweep_short<TA, NCH, CPU>;
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->short_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                       ncols > 0 ? ncols : ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->short_KP);
+    return hipGetLastError();
+}
 template <typename TA>
 static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols = 0) {
+    if (ctx->short_cpu > 0 && ctx->short_nch == 1) return sweep_launch_short<TA, 1, 4>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+    if (ctx->short_cpu > 0 && ctx->short_nch == 2) return sweep_launch_short<TA, 2, 4>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+    if (ctx->short_cpu > 0) return sweep_launch_short<TA, 4, 2>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     if (ctx->sweep_dyn && ncols == 0) {
         switch (ctx->sweep_U) {
             case 16: return sweep_launch_dyn<TA, 16, 2>(ctx, r, eps, check_eps, skipmask, cout);
@@ -166,6 +178,16 @@ static int configure_sweep(csmp_ctx* ctx) {
     if (ctx->sweep_grid > kClaimMaxWgs || std::max(ctx->tick_grid, ctx->tick_nblk) > kClaimMaxWgs) ctx->sweep_dyn = false;  // (one counter per workgroup)
     ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
     ctx->sweep_lds_req = (size_t)ctx->tune_sweep_lds_kib * 1024;
+    // short columns: the stand-alone sweep takes several columns per unit (k_sweep_short); the tick kernel keeps the one-column body
+    // (the same bits).  Units of eight loads: eight columns of one chunk (two sets of four), four of two chunks, two of three or four
+    // chunks.  csmp_tune(CSMP_TUNE_SWEEP_SHORT, 1): never.
+    ctx->short_cpu = ctx->short_nch = 0;
+    if (ctx->tune_sweep_short != 1 && nchunk <= 4 && ctx->N >= 8) {
+        ctx->short_nch = nchunk <= 2 ? nchunk : 4;
+        ctx->short_cpu = nchunk <= 2 ? 4 : 2;
+        ctx->short_KP = ctx->short_nch * rows;
+        ctx->short_lds = sweep_gen_lds_bytes(ctx->short_KP);
+    }
     return CSMP_OK;
 }
 

@@ -139,7 +139,7 @@ extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* av
     return CSMP_OK;
 }
 
-extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phases, int* workgroups, int* tick_workgroups, int64_t* lds_bytes, int* dynamic) {
+extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phases, int* workgroups, int* tick_workgroups, int64_t* lds_bytes, int* dynamic, int* columns_per_unit) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->dA) return CSMP_ESTATE;
     if (unit_loads) *unit_loads = ctx->sweep_U;
@@ -148,6 +148,7 @@ extern "C" int csmp_sweep_config(const csmp_ctx* ctx, int* unit_loads, int* phas
     if (tick_workgroups) *tick_workgroups = ctx->tick_nblk > 0 ? ctx->tick_nblk : ctx->tick_grid;
     if (lds_bytes) *lds_bytes = (int64_t)ctx->sweep_lds;
     if (dynamic) *dynamic = ctx->sweep_dyn ? 1 : 0;
+    if (columns_per_unit) *columns_per_unit = ctx->short_cpu > 0 ? 8 / ctx->short_nch : 1;
     return CSMP_OK;
 }
 
@@ -161,6 +162,7 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_sweep_U = (int)value;
             break;
         case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;  // (configure_sweep below: the dynamic sweep's grid limit)
+        case CSMP_TUNE_SWEEP_SHORT: ctx->tune_sweep_short = value == 1 ? 1 : 0; break;
         case CSMP_TUNE_SWEEP_LDS_KIB:
             if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");
             ctx->tune_sweep_lds_kib = (int)value;

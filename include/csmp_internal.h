@@ -27,8 +27,10 @@ int csmp_profile_overhead(csmp_ctx *ctx, int reps, double *avg_ms);
 int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
 /* what configure_sweep chose for the resident dictionary: loads per unit of k_sweep_gen (16 / 8 / 4); phases the residual is
  * staged in (1: one LDS image); workgroups of a stand-alone sweep and of the sweep inside the tick kernel; dynamic LDS bytes;
- * dynamic = 1: the columns are handed out at run time (k_sweep_dyn and the DYN tick), 0: split statically.  Any pointer may be NULL. */
-int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *workgroups, int *tick_workgroups, int64_t *lds_bytes, int *dynamic);
+ * dynamic = 1: the columns are handed out at run time (k_sweep_dyn and the DYN tick), 0: split statically; columns_per_unit: 2 or 4
+ * where the stand-alone sweep takes short columns several at a time (k_sweep_short), else 1.  Any pointer may be NULL. */
+int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *workgroups, int *tick_workgroups, int64_t *lds_bytes, int *dynamic,
+                      int *columns_per_unit);
 /* measurement overrides of that choice, applied to the resident dictionary at once and to later ones: 0 = automatic */
 #define CSMP_TUNE_SWEEP_GRID 2   /* workgroups of the product sweep */
 #define CSMP_TUNE_SWEEP_UNIT 3   /* loads per unit (16, 8 or 4) */
@@ -40,6 +42,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_PAIR_LDS_KIB 13 /* dynamic LDS (KiB) requested by the ticks of two pipelines side by side: above 80 = one workgroup per CU (default 81), 1 = what the kernels need */
 #define CSMP_TUNE_PAIR_SPLIT 14   /* 1: two pipelines side by side keep the fused tick (append stages + sweep in ONE launch under the large LDS request); default 0: two launches per tick */
 #define CSMP_TUNE_SWEEP_LDS_KIB 15 /* dynamic LDS (KiB) the stand-alone product sweep REQUESTS when that is more than it uses: above 80 = one workgroup per CU, 54 = two */
+#define CSMP_TUNE_SWEEP_SHORT 16  /* 1: the stand-alone sweep keeps one column per unit for every shape (default 0: columns of up to four 1-KiB chunks go two or four to a unit, k_sweep_short) */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */

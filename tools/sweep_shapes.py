@@ -53,13 +53,15 @@ def check_sweep(torch, np, D, At, seed=3):
     return err, ok_arg
 
 
-def measure(torch, np, cs, dev, M, dtype, reps, total_bytes=1 << 30, grids=(), unit=0, check=True):
+def measure(torch, np, cs, dev, M, dtype, reps, total_bytes=1 << 30, grids=(), unit=0, check=True, tune=()):
     es = 4 if dtype == torch.float32 else 8
     N = max(8, (total_bytes // (M * es)) // 4 * 4)
     At = make_dictionary(torch, dev, M, N, dtype)
     D = cs.Dictionary(At)
     rows = []
     try:
+        for key, value in tune:
+            D.ctx.tune(key, value)
         variants = [None] + [g for g in grids]
         for g in variants:
             D.ctx.tune("sweep_unit", unit)
@@ -96,6 +98,7 @@ def main():
     p.add_argument("--unit", type=int, default=0)
     p.add_argument("--no-check", action="store_true")
     p.add_argument("--out", type=str, default="")
+    p.add_argument("--tune", type=str, default="", help="csmp_tune overrides, e.g. sweep_short=1")
     a = p.parse_args()
     import numpy as np
     import torch
@@ -105,7 +108,8 @@ def main():
     Ms = tuple(int(x) for x in a.M.split(",")) if a.M else SHAPES_M
     dts = tuple({"f32": torch.float32, "f64": torch.float64}[x] for x in a.dtypes.split(","))
     grids = tuple(int(x) for x in a.grids.split(",")) if a.grids else ()
-    rows = table(torch, np, cs, dev, a.reps, Ms, dts, grids=grids, unit=a.unit, check=not a.no_check)
+    tune = tuple((kv.split("=")[0], int(kv.split("=")[1])) for kv in a.tune.split(",") if kv)
+    rows = table(torch, np, cs, dev, a.reps, Ms, dts, grids=grids, unit=a.unit, check=not a.no_check, tune=tune)
     for r in rows:
         print(json.dumps(r), flush=True)
     if a.out:
