@@ -160,20 +160,16 @@ __device__ __forceinline__ int r_slot(int m) {  // index in doubles
 // whole column at a time (16 KiB contiguous at M = 4096 f32), lanes stride the rows with 16-byte non-temporal loads (A is streamed
 // once per sweep and exceeds every cache), r lives in the LDS.  Grid-stride over columns; one (max |c|, first index) pair per
 // workgroup.  dynamic LDS: the r image + 32 doubles of reduction scratch.
-// The pipelined product sweep for ANY size(A) (the reference allocates zeros(T, n) and calls mul! whatever n is, :54-60):
-// ragged M, and a residual larger than the LDS.
+// The pipelined product sweep for any size(A) whose residual one LDS image holds (the reference allocates zeros(T, n) and calls
+// mul! whatever n is, :54-60); longer residuals: sweep_body_ph, columns of up to four chunks: sweep_body_short.
 //   unit    U consecutive 64-lane loads (U KiB) of ONE column: the grain of the pipeline.  One wave owns one column at a time.
 //   ring    NB units in flight per wave, consumed oldest first; a consumed buffer is refilled at once with the unit NB ahead.
 //           In the steady loop every load is unconditional (no branch around a load), so the wait the compiler places in front
 //           of a unit's arithmetic is s_waitcnt vmcnt((NB-1)*U): the wave never drains below (NB-1)*U KiB in flight.
 //   ragged  a lane whose rows lie past the column's end CLAMPS its vector index to the column's last vector -- a load of valid
 //           memory, no predicate, no extra DRAM line -- and multiplies it with a zero of the residual image.
-//   phases  (PH) a residual that exceeds the LDS is staged KP rows at a time; the workgroup runs ALL its columns against one
-//           stage before the next one is loaded (two barriers per stage and launch, not per column), and a column's partial sum
-//           waits in c[col]: written by lane 0, re-read at agent scope (L2) by the same wave after the stage barrier.
-//           c[col] = ((stage 0) + stage 1) + ... -- a fixed order, like everything else on the selection path.
-// KP: rows of the residual image (a multiple of U*64*VEC; !PH: >= Mv).  dynamic LDS: KP doubles + 32 doubles of scratch.
-template <typename TA, int U, int NB, bool PH>
+// KP: rows of the residual image (a multiple of U*64*VEC, >= Mv).  dynamic LDS: KP doubles + 32 doubles of scratch.
+template <typename TA, int U, int NB>
 __device__ __forceinline__ void sweep_body_gen(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
@@ -188,7 +184,6 @@ __device__ __forceinline__ void sweep_body_gen(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nvec = Mv / VEC;  // 16-byte vectors per column (Mv is a multiple of VEC: the leading dimension is padded to 16 bytes)
-    const int nph = PH ? (Mv + KP - 1) / KP : 1;
     double* red = lds + KP;
     double* redv = red + 8;
     int* redi = reinterpret_cast<int*>(redv + 4 * NW);
@@ -198,162 +193,128 @@ __device__ __forceinline__ void sweep_body_gen(
     const int64_t ncol = col0 < N ? (N - 1 - col0) / stride + 1 : 0;
     double bestv = -1.0;
     int besti = 0x7fffffff;
-
-    for (int ph = 0; ph < nph; ++ph) {
-        const int k0 = ph * KP;
-        const int rows_here = (Mv - k0) < KP ? (Mv - k0) : KP;
-        const int nunit = (rows_here + UR - 1) / UR;  // units per column in this stage
-        const int Mst = nunit * UR;                   // rows of the image in use (zero beyond Mv)
-        if (ph > 0) __syncthreads();                  // (everyone is done with the previous image; c[col] stores are acknowledged)
-        if (ph == 0) {
-            // image of the first stage, and ||r||^2 over ALL rows in a fixed per-thread order (identical in every workgroup).
-            // The loads go out 16 at a time (a rolled loop waits for each in turn: ~6 us of a 150 us kernel at M = 4096).
-            const int Mall = (PH && Mv > Mst) ? Mv : Mst;
-            constexpr int RP = 16;
-            double n2 = 0.0;
-            for (int m0 = tid; m0 < Mall; m0 += RP * kSweepThreads) {
-                double rv[RP];
+    const int nunit = (Mv + UR - 1) / UR;  // units per column
+    const int Mst = nunit * UR;            // rows of the image in use (zero beyond Mv)
+    {
+        // the residual image, and ||r||^2 in a fixed per-thread order (identical in every workgroup).
+        // The loads go out 16 at a time (a rolled loop waits for each in turn: ~6 us of a 150 us kernel at M = 4096).
+        constexpr int RP = 16;
+        double n2 = 0.0;
+        for (int m0 = tid; m0 < Mst; m0 += RP * kSweepThreads) {
+            double rv[RP];
 #pragma unroll
-                for (int q = 0; q < RP; ++q) {
-                    const int m = m0 + q * kSweepThreads;
-                    rv[q] = m < Mv ? r[m] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < RP; ++q) {
-                    const int m = m0 + q * kSweepThreads;
-                    if (m < Mst) lds[r_slot<VEC>(m)] = rv[q];
-                    n2 = fma(rv[q], rv[q], n2);
-                }
+            for (int q = 0; q < RP; ++q) {
+                const int m = m0 + q * kSweepThreads;
+                rv[q] = m < Mv ? r[m] : 0.0;
             }
-            for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
-            __syncthreads();
-            if (lane == 0) red[wave] = n2;
-            __syncthreads();
-            n2 = (red[0] + red[1]) + (red[2] + red[3]);
-            if (bid == 0 && tid == 0) st->rnorm2 = n2;
-            if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
-                if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-                return;
-            }
-        } else {
-            // (16 loads at a time, as above: one by one a stage of 16 384 rows is 64 dependent trips per thread)
-            constexpr int RP = 16;
-            for (int m0 = tid; m0 < Mst; m0 += RP * kSweepThreads) {
-                double rv[RP];
 #pragma unroll
-                for (int q = 0; q < RP; ++q) {
-                    const int m = m0 + q * kSweepThreads;
-                    rv[q] = k0 + m < Mv ? r[k0 + m] : 0.0;
-                }
-#pragma unroll
-                for (int q = 0; q < RP; ++q) {
-                    const int m = m0 + q * kSweepThreads;
-                    if (m < Mst) lds[r_slot<VEC>(m)] = rv[q];
-                }
+            for (int q = 0; q < RP; ++q) {
+                const int m = m0 + q * kSweepThreads;
+                if (m < Mst) lds[r_slot<VEC>(m)] = rv[q];
+                n2 = fma(rv[q], rv[q], n2);
             }
-            __syncthreads();
         }
-        const bool lastph = !PH || ph + 1 == nph;
-        const int k0v = k0 / VEC;
-
-        VT buf[NB][U];
-        double prev[NB];
-        // c values are STAGED: lane s keeps the total of the wave's s-th finished column and the wave writes 64 of them with one
-        // store instruction.  A store per column sits in the wave's in-order memory queue among the ring's loads: measured 1.5-3 us of
-        // a 155-us sweep at 16-KiB columns, 5-7 % at 8-KiB Float64 columns, 13 us of 170 with one store per 4 KiB (short columns).
-        double cst = 0.0;
-        int64_t ccst = -1;
-        int cslot = 0;
-        int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
-        int ib = 0, cb = 0;
-        const int64_t T = ncol * nunit;
-        int64_t ileft = T, cleft = T;
-        double acc = 0.0;
-        auto issue = [&](VT(&b)[U], double& pv) {
-            const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
-            const int vb = k0v + ib * (U * kWave) + lane;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int v = vb + u * kWave;
-                b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
-            }
-            if constexpr (PH) pv = __hip_atomic_load(cvec + icol, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (++ib == nunit) {
-                ib = 0;
-                icol += stride;
-            }
-            --ileft;
-        };
-        auto consume = [&](const VT(&b)[U], const double pv) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int t = cb * U + u;
-                if constexpr (VEC == 4) {
-                    const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
-                    const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
-                    acc = fma((double)b[u].x, r01.x, acc);
-                    acc = fma((double)b[u].y, r01.y, acc);
-                    acc = fma((double)b[u].z, r23.x, acc);
-                    acc = fma((double)b[u].w, r23.y, acc);
-                } else {
-                    const f64x2 r01 = rs[t * kWave + lane];
-                    acc = fma((double)b[u].x, r01.x, acc);
-                    acc = fma((double)b[u].y, r01.y, acc);
-                }
-            }
-            if (++cb == nunit) {  // the column's last unit of this stage
-                acc = wave_xsum(acc);
-                if constexpr (PH) {
-                    if (ph > 0) acc = pv + acc;
-                }
-                if (lane == cslot) {
-                    cst = acc;
-                    ccst = ccol;
-                }
-                if (++cslot == kWave) {
-                    if (ccst >= 0) cvec[ccst] = cst;
-                    ccst = -1;
-                    cslot = 0;
-                }
-                if (lastph) {
-                    const double av = fabs(acc);
-                    if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
-                        bestv = av;
-                        besti = (int)ccol;
-                    }
-                }
-                acc = 0.0;
-                cb = 0;
-                ccol += stride;
-            }
-            --cleft;
-        };
-        if (T >= 2 * NB) {
-#pragma unroll
-            for (int d = 0; d < NB; ++d) issue(buf[d], prev[d]);
-            const int64_t groups = T / NB - 1;
-            for (int64_t g = 0; g < groups; ++g) {
-#pragma unroll
-                for (int d = 0; d < NB; ++d) {
-                    consume(buf[d], prev[d]);
-                    issue(buf[d], prev[d]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int d = 0; d < NB; ++d)
-                if (d < T) issue(buf[d], prev[d]);
+        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        __syncthreads();
+        if (lane == 0) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return;
         }
-        while (cleft > 0) {  // the last NB .. 2 NB - 1 units of the wave (or all of them, when there are fewer)
+    }
+    VT buf[NB][U];
+    // c values are STAGED: lane s keeps the total of the wave's s-th finished column and the wave writes 64 of them with one
+    // store instruction.  A store per column sits in the wave's in-order memory queue among the ring's loads: measured 1.5-3 us of
+    // a 155-us sweep at 16-KiB columns, 5-7 % at 8-KiB Float64 columns, 13 us of 170 with one store per 4 KiB (short columns).
+    double cst = 0.0;
+    int64_t ccst = -1;
+    int cslot = 0;
+    int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
+    int ib = 0, cb = 0;
+    const int64_t T = ncol * nunit;
+    int64_t ileft = T, cleft = T;
+    double acc = 0.0;
+    auto issue = [&](VT(&b)[U]) {
+        const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
+        const int vb = ib * (U * kWave) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb + u * kWave;
+            b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
+        }
+        if (++ib == nunit) {
+            ib = 0;
+            icol += stride;
+        }
+        --ileft;
+    };
+    auto consume = [&](const VT(&b)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = cb * U + u;
+            if constexpr (VEC == 4) {
+                const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                acc = fma((double)b[u].x, r01.x, acc);
+                acc = fma((double)b[u].y, r01.y, acc);
+                acc = fma((double)b[u].z, r23.x, acc);
+                acc = fma((double)b[u].w, r23.y, acc);
+            } else {
+                const f64x2 r01 = rs[t * kWave + lane];
+                acc = fma((double)b[u].x, r01.x, acc);
+                acc = fma((double)b[u].y, r01.y, acc);
+            }
+        }
+        if (++cb == nunit) {  // the column's last unit
+            acc = wave_xsum(acc);
+            if (lane == cslot) {
+                cst = acc;
+                ccst = ccol;
+            }
+            if (++cslot == kWave) {
+                if (ccst >= 0) cvec[ccst] = cst;
+                ccst = -1;
+                cslot = 0;
+            }
+            const double av = fabs(acc);
+            if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
+                bestv = av;
+                besti = (int)ccol;
+            }
+            acc = 0.0;
+            cb = 0;
+            ccol += stride;
+        }
+        --cleft;
+    };
+    if (T >= 2 * NB) {
+#pragma unroll
+        for (int d = 0; d < NB; ++d) issue(buf[d]);
+        const int64_t groups = T / NB - 1;
+        for (int64_t g = 0; g < groups; ++g) {
 #pragma unroll
             for (int d = 0; d < NB; ++d) {
-                if (cleft == 0) break;
-                consume(buf[d], prev[d]);
-                if (ileft > 0) issue(buf[d], prev[d]);
+                consume(buf[d]);
+                issue(buf[d]);
             }
         }
-        if (ccst >= 0) cvec[ccst] = cst;  // (the columns staged since the last full store: before the next stage's barrier)
+    } else {
+#pragma unroll
+        for (int d = 0; d < NB; ++d)
+            if (d < T) issue(buf[d]);
     }
+    while (cleft > 0) {  // the last NB .. 2 NB - 1 units of the wave (or all of them, when there are fewer)
+#pragma unroll
+        for (int d = 0; d < NB; ++d) {
+            if (cleft == 0) break;
+            consume(buf[d]);
+            if (ileft > 0) issue(buf[d]);
+        }
+    }
+    if (ccst >= 0) cvec[ccst] = cst;  // (the columns staged since the last full store)
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;
@@ -371,16 +332,230 @@ __device__ __forceinline__ void sweep_body_gen(
         pidx[bid] = bi;
     }
 }
-template <typename TA, int U, int NB, bool PH>
+template <typename TA, int U, int NB>
 __global__ __launch_bounds__(kSweepThreads) void k_sweep_gen(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
     double eps, int check_eps, int skipmask, int KP) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    sweep_body_gen<TA, U, NB, PH>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x,
-                                  (int)gridDim.x, KP, lds);
+    sweep_body_gen<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, KP, lds);
 }
 inline size_t sweep_gen_lds_bytes(int KP) { return (size_t)(KP + 8 + 16 + 8) * sizeof(double); }
+
+// ---------------------------------------------------------------------------------------------
+// A residual LONGER than the LDS (8 M bytes > 160 KiB, M beyond ~20 000): the image is staged KP rows at a time and the workgroup
+// runs ALL its columns against one stage before the next is loaded.  Round 5 did this inside sweep_body_gen with every stage a
+// pipeline of its own (the ring drained before the stage's barrier and refilled after the reload) and the columns' partial sums
+// parked in c[col]: 0.765-0.78 of the roofline at M = 32 768.  Here the dictionary stream does not stop at a stage boundary:
+//   issue     ONE stream of units over (stage, column, unit), NB units ahead of the arithmetic whatever stage that is in: while the
+//             wave multiplies the last units of stage p its ring already holds the first units of stage p + 1, and they stay in
+//             flight across the barrier and the reload of the image (lds_barrier: no drain).  Every ring buffer carries its column
+//             ordinal and unit number; each stage's unit count is padded to a multiple of NB with loads of ONE vector that nobody
+//             consumes (after the last stage too), so every stage starts on buffer 0, no load sits under a branch, and the
+//             compiler's counted waits stay exact.
+//   partials  a column's sum over the stages so far waits in the LDS (pcap doubles per wave, the wave's columns in order), not in
+//             c[col]: nothing is read back from memory, and c is written once, 64 columns to a store instruction.
+//             c[col] = ((stage 0) + stage 1) + ... as before: the same bits.
+// dynamic LDS: KP + 40 + 4 pcap doubles.  Every wave joins every barrier (a wave without columns too).
+inline size_t sweep_ph_lds_bytes(int KP, int pcap) { return (size_t)(KP + 8 + 16 + 8 + 8 + 4 * (size_t)pcap) * sizeof(double); }
+template <typename TA, int U, int NB>
+__device__ __forceinline__ void sweep_body_ph(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, const int bid, const int nblk, const int KP, const int pcap, double* lds) {
+    using VT = typename Vec<TA>::type;
+    constexpr int VEC = Vec<TA>::n;
+    constexpr int ROWS = kWave * VEC;
+    constexpr int UR = U * ROWS;
+    constexpr int NW = kSweepThreads / kWave;
+    static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
+    if (st->done & skipmask) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nvec = Mv / VEC;
+    const int nph = (Mv + KP - 1) / KP;
+    double* red = lds + KP;
+    double* redv = red + 8;
+    int* redi = reinterpret_cast<int*>(redv + 4 * NW);
+    double* part = redv + 4 * NW + 8 + 8 + (size_t)wave * pcap;
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    const int64_t col0 = (int64_t)bid * NW + wave, stride = (int64_t)nblk * NW;
+    const int ncol = col0 < N ? (int)((N - 1 - col0) / stride + 1) : 0;  // (<= pcap: the host sized the partials for it)
+    auto units_of = [&](int ph) {  // units per column in stage ph
+        const int rows_here = (Mv - ph * KP) < KP ? (Mv - ph * KP) : KP;
+        return (rows_here + UR - 1) / UR;
+    };
+    // the image of stage ph: pairs of rows (16-byte loads; a pair is one 16-byte LDS slot in either layout), 16 loads in flight per
+    // thread -- one by one a stage of 16 384 rows is 64 dependent trips per thread, and the stage's barrier waits for all of them
+    auto stage_image = [&](int ph, double& n2) {
+        const int k0 = ph * KP, Mst = units_of(ph) * UR;
+        const int Mend = (ph == 0 && Mv > Mst) ? Mv : Mst;  // (stage 0 also sums ||r||^2 over ALL rows, in a fixed per-thread order)
+        constexpr int RP = 16;
+        for (int m0 = 2 * tid; m0 < Mend; m0 += RP * 2 * kSweepThreads) {
+            f64x2 rv[RP];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const int m = k0 + m0 + q * 2 * kSweepThreads;  // (even: Mv, KP and k0 are)
+                rv[q] = m + 1 < Mv ? *reinterpret_cast<const f64x2*>(r + m) : f64x2{m < Mv ? r[m] : 0.0, 0.0};
+            }
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const int m = m0 + q * 2 * kSweepThreads;
+                if (m < Mst) *reinterpret_cast<f64x2*>(lds + r_slot<VEC>(m)) = rv[q];
+                n2 = fma(rv[q].x, rv[q].x, n2);
+                n2 = fma(rv[q].y, rv[q].y, n2);
+            }
+        }
+    };
+    {
+        double n2 = 0.0;
+        stage_image(0, n2);
+        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        __syncthreads();
+        if (lane == 0) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return;
+        }
+    }
+    double bestv = -1.0;
+    int besti = 0x7fffffff;
+    VT buf[NB][U];
+    int ms[NB], mb[NB];  // column ordinal of the unit in the buffer (-1: nobody consumes it) and its number within the column
+    // the issue stream: irem real units and then ipad padding units left in its stage; (icol, ib) always names a valid unit -- a
+    // padding unit re-reads it (one vector per lane from lines the wave has just had) and nobody consumes it
+    int iph = 0, is = 0, ib = 0;
+    int inunit = units_of(0);
+    int64_t irem = (int64_t)ncol * inunit;
+    int ipad = (int)((NB - irem % NB) % NB);
+    int64_t icol = col0 < N ? col0 : N - 1;
+    int ik0v = 0;
+    auto issue = [&](VT(&b)[U], int& s_, int& b_) {
+        const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
+        const int vb = ik0v + ib * (U * kWave) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb + u * kWave;
+            b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
+        }
+        const bool real = irem > 0;
+        s_ = real ? is : -1;
+        b_ = ib;
+        if (real) {
+            --irem;
+            if (++ib == inunit) {
+                ib = 0;
+                ++is;
+                if (irem > 0) icol += stride;
+            }
+        } else if (ipad > 0) {
+            --ipad;
+        }
+        if (irem == 0 && ipad == 0 && iph + 1 < nph) {  // on to the next stage's units
+            ++iph;
+            inunit = units_of(iph);
+            irem = (int64_t)ncol * inunit;
+            ipad = (int)((NB - irem % NB) % NB);
+            is = 0;
+            ib = 0;
+            icol = col0 < N ? col0 : N - 1;
+            ik0v = (iph * KP) / VEC;
+        }
+    };
+    double acc = 0.0;
+    double cst = 0.0;  // c values staged 64 to a store instruction (see sweep_body_gen)
+    int64_t ccst = -1;
+    int cslot = 0;
+#pragma unroll
+    for (int d = 0; d < NB; ++d) issue(buf[d], ms[d], mb[d]);
+    for (int ph = 0; ph < nph; ++ph) {
+        if (ph > 0) {
+            lds_barrier();  // everyone is done with the previous image (the ring's loads stay in flight)
+            double dummy = 0.0;
+            stage_image(ph, dummy);
+            __syncthreads();
+        }
+        const int nunit = units_of(ph);
+        const bool lastph = ph + 1 == nph;
+        const int64_t Tpad = ((int64_t)ncol * nunit + NB - 1) / NB * NB;
+        for (int64_t g = 0; g < Tpad / NB; ++g) {
+#pragma unroll
+            for (int d = 0; d < NB; ++d) {
+                if (ms[d] >= 0) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int t = mb[d] * U + u;
+                        if constexpr (VEC == 4) {
+                            const f64x2 r01 = rs[(t * 2 + 0) * kWave + lane];
+                            const f64x2 r23 = rs[(t * 2 + 1) * kWave + lane];
+                            acc = fma((double)buf[d][u].x, r01.x, acc);
+                            acc = fma((double)buf[d][u].y, r01.y, acc);
+                            acc = fma((double)buf[d][u].z, r23.x, acc);
+                            acc = fma((double)buf[d][u].w, r23.y, acc);
+                        } else {
+                            const f64x2 r01 = rs[t * kWave + lane];
+                            acc = fma((double)buf[d][u].x, r01.x, acc);
+                            acc = fma((double)buf[d][u].y, r01.y, acc);
+                        }
+                    }
+                    if (mb[d] == nunit - 1) {  // the column's last unit of this stage
+                        acc = wave_xsum(acc);
+                        if (ph > 0) acc = part[ms[d]] + acc;
+                        if (!lastph) {
+                            if (lane == 0) part[ms[d]] = acc;
+                        } else {
+                            const int64_t col = col0 + (int64_t)ms[d] * stride;
+                            if (lane == cslot) {
+                                cst = acc;
+                                ccst = col;
+                            }
+                            if (++cslot == kWave) {
+                                if (ccst >= 0) cvec[ccst] = cst;
+                                ccst = -1;
+                                cslot = 0;
+                            }
+                            const double av = fabs(acc);
+                            if (av > bestv) {  // columns arrive in increasing order: '>' keeps the first maximum
+                                bestv = av;
+                                besti = (int)col;
+                            }
+                        }
+                        acc = 0.0;
+                    }
+                }
+                issue(buf[d], ms[d], mb[d]);
+            }
+        }
+    }
+    if (ccst >= 0) cvec[ccst] = cst;
+    if ((lane & 15) == 0) {
+        redv[wave * 4 + (lane >> 4)] = bestv;
+        redi[wave * 4 + (lane >> 4)] = besti;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double bv = redv[0];
+        int bi = redi[0];
+        for (int q = 1; q < 4 * NW; ++q)
+            if (better(redv[q], redi[q], bv, bi)) {
+                bv = redv[q];
+                bi = redi[q];
+            }
+        pval[bid] = bv;
+        pidx[bid] = bi;
+    }
+}
+template <typename TA, int U, int NB>
+__global__ __launch_bounds__(kSweepThreads) void k_sweep_ph(
+    const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
+    double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
+    double eps, int check_eps, int skipmask, int KP, int pcap) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    sweep_body_ph<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, KP, pcap, lds);
+}
 
 // ---------------------------------------------------------------------------------------------
 // SHORT columns (the reference sweeps whatever size(A) is: its own tests are 32 x 48, configs[0] is 256 x 1024): when a column is
@@ -1758,7 +1933,8 @@ struct TickSweep {
     const TA* A; int64_t ld; int Mv; int64_t N;
     const double* r; double* cvec; double* pval; int* pidx; DevState* st;
     double eps; int check_eps, skipmask, nblk, active;
-    int KP;  // rows of the residual image
+    int KP;    // rows of the residual image
+    int pcap;  // PH: columns per wave the LDS holds partial sums for (sweep_body_ph)
     int npools;                    // DYN: pools a workgroup may claim from (its XCD's first)
     unsigned *claim, *claim_next;  // DYN: the column pools of this sweep, and the set to zero for the slot's next one (sweep_body_dyn)
 };
@@ -1810,9 +1986,12 @@ __global__ __launch_bounds__(DYN ? kSweepDynThreads : kSweepThreads) void k_tick
             if constexpr (DYN)
                 sweep_body_dyn<TA, U, 32 / U>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps, sw.check_eps,
                                               sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, sw.claim, sw.claim_next, sw.npools, lds);
+            else if constexpr (PH)
+                sweep_body_ph<TA, U, 32 / U>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps, sw.check_eps,
+                                             sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, sw.pcap, lds);
             else
-                sweep_body_gen<TA, U, 32 / U, PH>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps,
-                                                  sw.check_eps, sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
+                sweep_body_gen<TA, U, 32 / U>(sw.A, sw.ld, sw.Mv, sw.N, sw.r, sw.cvec, sw.pval, sw.pidx, sw.st, sw.eps, sw.check_eps,
+                                              sw.skipmask, bid - 2 * G, sw.nblk, sw.KP, lds);
         }
     }
 }

@@ -183,6 +183,7 @@ struct csmp_ctx {
     // the product sweep's configuration for this dictionary (configure_sweep): sweep_U loads per unit (16 / 8 / 4; the ring holds 32)
     bool sweep_ph = false;  // the residual is staged in phases of sweep_KP rows (it exceeds the LDS)
     int sweep_KP = 0;       // rows of the residual image in the LDS
+    int sweep_pcap = 0;     // phases: columns per wave whose partial sums the LDS holds (sweep_body_ph)
     int tick_grid = 0;      // sweep workgroups inside the tick kernel
     int tune_sweep_grid = 0, tune_sweep_U = 0;
     bool sweep_dyn = false;  // the product sweep hands its columns out at run time (k_sweep_dyn, the DYN tick)
@@ -212,6 +213,7 @@ struct csmp_ctx {
     size_t sweep_lds = 0;
     int short_cpu = 0, short_nch = 0, short_KP = 0;  // k_sweep_short (stand-alone sweep of short columns): columns per reduction, chunks per column, image rows; 0 = the one-column body
     size_t short_lds = 0;
+    int tune_phase_rows = 0;   // csmp_tune: most rows of a stage of the phased sweep (0: what the LDS holds)
     int tune_sweep_short = 0;  // csmp_tune: 1 = the one-column body for every shape
     size_t sweep_lds_req = 0;    // the stand-alone sweep's LDS request when larger than sweep_lds (residency control)
     int tune_sweep_lds_kib = 0;  // csmp_tune

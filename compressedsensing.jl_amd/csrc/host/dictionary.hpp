@@ -2,9 +2,9 @@
 // sweep configuration and launch; the resident dictionary.
 // ------------------------------------------------------------------------------------------ sweep launch
 // the product sweep (k_sweep_gen): U loads per unit, a ring of 32 loads, the residual in one image or staged in phases
-template <typename TA, int U, int NB, bool PH>
+template <typename TA, int U, int NB>
 static hipError_t sweep_launch_t(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols = 0) {
-    auto kern = k_sweep_gen<TA, U, NB, PH>;
+    auto kern = k_sweep_gen<TA, U, NB>;
     // the LDS REQUEST may exceed what the kernel uses (configure_sweep: sweep_lds_req): it sets how many workgroups share a CU, and with
     // more workgroups than fit the rest QUEUE -- a CU that a workgroup leaves goes to the next one in line
     const size_t lds = std::max(ctx->sweep_lds, ctx->sweep_lds_req);
@@ -38,6 +38,19 @@ static hipError_t sweep_launch_dyn(csmp_ctx* ctx, const double* r, double eps, i
                        ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next, ctx->claim_pools);
     return hipGetLastError();
 }
+// a residual longer than the LDS, staged in phases (k_sweep_ph)
+template <typename TA>
+static hipError_t sweep_launch_ph(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols) {
+    auto kern = k_sweep_ph<TA, 8, 4>;
+    if (ctx->sweep_lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->sweep_lds);
+        if (e != hipSuccess) return e;
+    }
+    Solver& s = ctx->s;
+    hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
+                       ncols > 0 ? ncols : ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, ctx->sweep_pcap);
+    return hipGetLastError();
+}
 // short columns (k_sweep_short): U loads = CPU neighbouring columns of U / CPU chunks, one transposing reduction per unit
 template <typename TA, int NCH, int CPU>
 static hipError_t sweep_launch_short(csmp_ctx* ctx, const double* r, double eps, int check_eps, int skipmask, double* cout, int64_t ncols) {
@@ -59,11 +72,11 @@ static hipError_t sweep_product(csmp_ctx* ctx, const double* r, double eps, int 
             default: return sweep_launch_dyn<TA, 4, 8>(ctx, r, eps, check_eps, skipmask, cout);
         }
     }
-    if (ctx->sweep_ph) return sweep_launch_t<TA, 8, 4, true>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+    if (ctx->sweep_ph) return sweep_launch_ph<TA>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     switch (ctx->sweep_U) {
-        case 16: return sweep_launch_t<TA, 16, 2, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
-        case 8: return sweep_launch_t<TA, 8, 4, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
-        default: return sweep_launch_t<TA, 4, 8, false>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+        case 16: return sweep_launch_t<TA, 16, 2>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+        case 8: return sweep_launch_t<TA, 8, 4>(ctx, r, eps, check_eps, skipmask, cout, ncols);
+        default: return sweep_launch_t<TA, 4, 8>(ctx, r, eps, check_eps, skipmask, cout, ncols);
     }
 }
 
@@ -148,12 +161,34 @@ static int configure_sweep(csmp_ctx* ctx) {
             best_pad = pad;
         }
     }
+    const size_t col_bytes = (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8);
+    const int64_t base = col_bytes >= 8192 ? (int64_t)cus * 3 / 4 : (int64_t)cus * 3;
+    const int maxgrid = cus * 8 + 8;  // (the per-workgroup partials pval / pidx of a solver slot are sized for it: solver_alloc)
+    ctx->sweep_grid = ctx->tune_sweep_grid > 0 ? balanced_grid(ctx->N, ctx->tune_sweep_grid) : balanced_grid(ctx->N, base);
+    if (ctx->tune_sweep_grid > 0 && ctx->tune_sweep_grid < ctx->sweep_grid + ctx->sweep_grid / 4) {
+        const int64_t groups = (ctx->N + 3) / 4;
+        ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tune_sweep_grid, groups));  // (an override is taken literally)
+    }
+    // inside the tick kernel (csmp_omp_batch) the sweep shares the CUs with the append stages of two other signals
+    ctx->tick_grid = balanced_grid(ctx->N, col_bytes >= 8192 ? (int64_t)cus * 11 / 16 : (int64_t)cus * 3);
+    ctx->sweep_grid = std::min(ctx->sweep_grid, maxgrid);
+    ctx->tick_grid = std::min(ctx->tick_grid, maxgrid);
+    ctx->sweep_pcap = 0;
     if (bestU) {
         ctx->sweep_U = bestU;
         ctx->sweep_KP = best_pad * rows;
     } else {
+        // phases: beside the image the LDS holds the partial sums of every wave's columns (sweep_body_ph), sized for the smallest
+        // grid the sweep is launched on (the tick kernel's, or an override's)
+        int ming = std::min(ctx->sweep_grid, ctx->tick_grid);
+        if (ctx->tick_nblk > 0) ming = std::min(ming, ctx->tick_nblk);
+        const int64_t pcap64 = (ctx->N + (int64_t)ming * 4 - 1) / ((int64_t)ming * 4);
+        const int64_t spare = (int64_t)(lds_cap / sizeof(double)) - 48 - 4 * pcap64;
         const int ur = 8 * rows;
-        const int kp_max = (kp_cap / ur) * ur;
+        if (spare < ur) return fail(ctx, CSMP_ERANGE, "set_dictionary: too many columns per sweep workgroup for a residual staged in phases");
+        ctx->sweep_pcap = (int)pcap64;
+        int kp_max = (int)(spare / ur) * ur;
+        if (ctx->tune_phase_rows > 0) kp_max = std::max(ur, std::min(kp_max, (ctx->tune_phase_rows / ur) * ur));
         const int nph = (ctx->Mv + kp_max - 1) / kp_max;
         const int per = (ctx->Mv + nph - 1) / nph;
         ctx->sweep_U = 8;
@@ -162,21 +197,9 @@ static int configure_sweep(csmp_ctx* ctx) {
     }
     // columns handed out at run time (sweep_body_dyn): only on csmp_tune(CSMP_TUNE_SWEEP_DYN, 1) -- measured 1-3 % slower than the static split
     ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn == 1;
-    const size_t col_bytes = (size_t)ctx->Mv * (ctx->dtype == CSMP_F32 ? 4 : 8);
-    const int64_t base = col_bytes >= 8192 ? (int64_t)cus * 3 / 4 : (int64_t)cus * 3;
-    ctx->sweep_grid = ctx->tune_sweep_grid > 0 ? balanced_grid(ctx->N, ctx->tune_sweep_grid) : balanced_grid(ctx->N, base);
-    if (ctx->tune_sweep_grid > 0 && ctx->tune_sweep_grid < ctx->sweep_grid + ctx->sweep_grid / 4) {
-        const int64_t groups = (ctx->N + 3) / 4;
-        ctx->sweep_grid = (int)std::max<int64_t>(1, std::min<int64_t>(ctx->tune_sweep_grid, groups));  // (an override is taken literally)
-    }
-    // inside the tick kernel (csmp_omp_batch) the sweep shares the CUs with the append stages of two other signals
-    ctx->tick_grid = balanced_grid(ctx->N, col_bytes >= 8192 ? (int64_t)cus * 11 / 16 : (int64_t)cus * 3);
-    // (the per-workgroup partials pval / pidx and the claim counters of a solver slot are sized for cus * 8 + 8 workgroups: solver_alloc)
-    const int maxgrid = cus * 8 + 8;
-    ctx->sweep_grid = std::min(ctx->sweep_grid, maxgrid);
-    ctx->tick_grid = std::min(ctx->tick_grid, maxgrid);
     if (ctx->sweep_grid > kClaimMaxWgs || std::max(ctx->tick_grid, ctx->tick_nblk) > kClaimMaxWgs) ctx->sweep_dyn = false;  // (one counter per workgroup)
-    ctx->sweep_lds = ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
+    ctx->sweep_lds = ctx->sweep_ph ? sweep_ph_lds_bytes(ctx->sweep_KP, ctx->sweep_pcap)
+                                   : ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);
     ctx->sweep_lds_req = (size_t)ctx->tune_sweep_lds_kib * 1024;
     // short columns: the stand-alone sweep takes several columns per unit (k_sweep_short); the tick kernel keeps the one-column body
     // (the same bits).  Units of eight loads: eight columns of one chunk (two sets of four), four of two chunks, two of three or four

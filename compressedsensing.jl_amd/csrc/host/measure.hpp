@@ -162,6 +162,7 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_sweep_U = (int)value;
             break;
         case CSMP_TUNE_TICK_GRID: ctx->tick_nblk = (int)value; break;  // (configure_sweep below: the dynamic sweep's grid limit)
+        case CSMP_TUNE_PHASE_ROWS: ctx->tune_phase_rows = (int)value; break;
         case CSMP_TUNE_SWEEP_SHORT: ctx->tune_sweep_short = value == 1 ? 1 : 0; break;
         case CSMP_TUNE_SWEEP_LDS_KIB:
             if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");

@@ -10,6 +10,7 @@ static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, Solver& s, double eps, int
     p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
     p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;
     p.eps = eps; p.check_eps = check_eps; p.skipmask = skipmask; p.nblk = nblk; p.active = active; p.KP = ctx->sweep_KP;
+    p.pcap = ctx->sweep_pcap;
     return p;
 }
 template <typename TA>
