@@ -9,7 +9,7 @@ from .data import sparse_vector, sparse_data, gaussian_data, perturb, samesuppor
 from ._lib import CsmpError, Context, LIB_PATH, comm_id, write_dictionary_file, dictionary_file_info
 from .api import (Dictionary, mp, omp, gomp, sp, ompr, srr, rmp, foba, br, fbr, lace, fr, ols, oomp, ormp, FR, OLS, omp_batch, omp_batch_mfma, gomp_batch, sp_batch, solve_in_flight, fr_batch, MP, OMP, GOMP, SP, SubspacePursuit, OMPR, sp_acquisition, update_, argmaxinner,
                   oblivious, oblivious_acquisition, random_acquisition)
-from .sharded import omp_sharded, shard_range, sharded_solve, fr_sharded, omp_colsharded, HipColumnShard, column_range, pack_t, gather_packed, unpack_t, library_comm
+from .sharded import omp_sharded, shard_range, sharded_solve, fr_sharded, omp_colsharded, HipColumnShard, column_range, pack_t, gather_packed, unpack_t, library_comm, ShardedSolveError, ShardedArgumentError
 
 __all__ = [
     "SparseVector", "spzeros", "sparse_vector", "sparse_data", "gaussian_data", "perturb", "samesupport", "structured_dictionary",

@@ -91,15 +91,25 @@ INTERNAL_SIGNATURES = {
     "csmp_profile_read": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.c_int]),
     "csmp_bench_sweep": (C.c_int, [vp, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "csmp_profile_overhead": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
+    "csmp_live_resources": (C.c_int, [C.POINTER(i64)] * 6),
     "csmp_profile_window": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "csmp_sweep_config": (C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(i64), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "csmp_tune": (C.c_int, [vp, C.c_int, i64]),
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15, "sweep_short": 16, "phase_rows": 17}  # CSMP_TUNE_* (include/csmp_internal.h)
+TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15, "sweep_short": 16, "phase_rows": 17, "fail_alloc": 18}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
+
+
+def live_resources():
+    """what the library holds right now, process-wide (csmp_internal.h): all zero when no context exists"""
+    v = [i64(0) for _ in range(6)]
+    rc = lib().csmp_live_resources(*[C.byref(x) for x in v])
+    if rc != OK:
+        raise CsmpError(rc, "csmp_live_resources")
+    return dict(zip(("device_bytes", "device_blocks", "pinned_bytes", "registered_ranges", "events", "streams"), (int(x.value) for x in v)))
 
 
 def comm_id():

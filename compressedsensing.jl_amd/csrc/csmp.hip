@@ -33,6 +33,7 @@
 using namespace csmp;
 
 #include "host/hostonly.hpp"
+#include "host/track.hpp"
 #include "host/ctx.hpp"
 #include "host/lifetime.hpp"
 #include "host/dictionary.hpp"

@@ -161,22 +161,32 @@ static int batch_ensure(csmp_ctx* ctx, int nsig, int kcap) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     const int nb = std::max(Bpad, b.Bcap), nk = std::max(kcap, b.kcap);
     batch_free(b, true);
+    b.Mr = (int)(((ctx->M + 3) / 4) * 4);
+    // all of it or none: a capacity is recorded only over a complete set of buffers (a half-built set under nb x nk would let the
+    // next call launch on null pointers)
+    auto all = [&]() -> int {
+        CHECK(dmalloc(ctx, &b.Rb, (size_t)nb * b.Mk));
+        CHECK(dmalloc(ctx, &b.r, (size_t)nb * b.Mr));
+        CHECK(dmalloc(ctx, &b.b, (size_t)nb * b.Mr));
+        CHECK(dmalloc(ctx, &b.T, (size_t)nb * nk * nk));
+        CHECK(dmalloc(ctx, &b.Tt, (size_t)nb * nk * nk));
+        CHECK(dmalloc(ctx, &b.z, (size_t)nb * nk));
+        CHECK(dmalloc(ctx, &b.sel, (size_t)nb * nk));
+        CHECK(dmalloc(ctx, &b.bs, (size_t)nb));
+        CHECK(dmalloc(ctx, &b.pick, (size_t)nb));
+        CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
+        CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
+        CHECK(dmalloc(ctx, &b.R8, (size_t)nb * (size_t)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256)));
+        CHECK(dmalloc(ctx, &b.sigscale, (size_t)nb));
+        return CSMP_OK;
+    };
+    const int rc = all();
+    if (rc != CSMP_OK) {
+        batch_free(b, true);
+        return rc;
+    }
     b.Bcap = nb;
     b.kcap = nk;
-    b.Mr = (int)(((ctx->M + 3) / 4) * 4);
-    CHECK(dmalloc(ctx, &b.Rb, (size_t)nb * b.Mk));
-    CHECK(dmalloc(ctx, &b.r, (size_t)nb * b.Mr));
-    CHECK(dmalloc(ctx, &b.b, (size_t)nb * b.Mr));
-    CHECK(dmalloc(ctx, &b.T, (size_t)nb * nk * nk));
-    CHECK(dmalloc(ctx, &b.Tt, (size_t)nb * nk * nk));
-    CHECK(dmalloc(ctx, &b.z, (size_t)nb * nk));
-    CHECK(dmalloc(ctx, &b.sel, (size_t)nb * nk));
-    CHECK(dmalloc(ctx, &b.bs, (size_t)nb));
-    CHECK(dmalloc(ctx, &b.pick, (size_t)nb));
-    CHECK(dmalloc(ctx, &b.cand_val, (size_t)nb * b.n_atiles * kTileCand));
-    CHECK(dmalloc(ctx, &b.cand_idx, (size_t)nb * b.n_atiles * kTileCand));
-    CHECK(dmalloc(ctx, &b.R8, (size_t)nb * (size_t)std::max<int64_t>(512, ((ctx->M + 255) / 256) * 256)));
-    CHECK(dmalloc(ctx, &b.sigscale, (size_t)nb));
     return CSMP_OK;
 }
 

@@ -190,6 +190,7 @@ struct csmp_ctx {
     int tune_sweep_dyn = 0;  // csmp_tune: 1 = the columns handed out at run time where one image holds the residual (measured slower: DESIGN.md section 0)
     int tune_pair_lds_kib = 0;  // csmp_tune: dynamic LDS (KiB) of the ticks of two pipelines side by side, 0 = kPairLdsKiB (one workgroup per CU)
     int tune_pair_split = 0;    // csmp_tune: 1 = two pipelines side by side keep the fused tick (one launch), default: append stages and sweep in two launches
+    int tune_fail_alloc = 0;    // csmp_tune (test hook): the n-th device allocation of a solver slot from now fails (dmalloc)
     int tune_pipelines = 0;  // csmp_tune: 1 = csmp_omp_batch keeps ONE pipeline of three signals (default: two side by side from six signals on)
     int claim_pools = 8;     // counters a workgroup of the dynamic sweep finds empty in a row before it stops (its own, then the following workgroups')
     int tune_rebuild_direct = 0;  // csmp_tune: the oblivious start's Q'A pass reads its directions from L2 (k_fr_rebuild) instead of the LDS
@@ -245,6 +246,7 @@ struct csmp_ctx {
     do {                                                                                        \
         hipError_t e_ = (expr);                                                                 \
         if (e_ != hipSuccess) {                                                                 \
+            (void)hipGetLastError(); /* reported HERE: left pending, the next launch's check would report it again, as its own */ \
             char buf_[512];                                                                     \
             snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
                      __FILE__, __LINE__);                                                       \
@@ -262,13 +264,18 @@ struct csmp_ctx {
 // The library reads no environment variable: every behavioural choice is an argument or a csmp_set_option key (include/csmp.h).
 static int fail(csmp_ctx* ctx, int code, const char* msg) {
     if (ctx) ctx->err = msg;
+    if (code == CSMP_EHIP || code == CSMP_ENOMEM) (void)hipGetLastError();  // (a HIP failure is reported once: not again by the next launch's check)
     return code;
 }
 static int fail(csmp_ctx* ctx, int code, const std::string& msg) { return fail(ctx, code, msg.c_str()); }
 
 template <typename T>
 static int dmalloc(csmp_ctx* ctx, T** p, size_t n) {
-    HIPCHECK(hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+    size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    // test hook (csmp_tune, CSMP_TUNE_FAIL_ALLOC = n): the n-th allocation from now asks for an impossible size -- a REAL hipMalloc
+    // failure, with hipErrorOutOfMemory left pending for the next hipGetLastError, as a full device would produce it
+    if (ctx->tune_fail_alloc > 0 && --ctx->tune_fail_alloc == 0) bytes = (size_t)1 << 60;
+    HIPCHECK(hipMalloc((void**)p, bytes));
     return CSMP_OK;
 }
 template <typename T>

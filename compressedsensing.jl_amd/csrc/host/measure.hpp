@@ -106,6 +106,23 @@ extern "C" int csmp_profile_overhead(csmp_ctx* ctx, int reps, double* avg_ms) {
     return CSMP_OK;
 }
 
+// what the library holds right now, process-wide (host/track.hpp): bytes and blocks of device memory, bytes of page-locked host memory,
+// host ranges registered with the device, events, streams
+extern "C" int csmp_live_resources(int64_t* device_bytes, int64_t* device_blocks, int64_t* pinned_bytes, int64_t* registered_ranges, int64_t* events,
+                                   int64_t* streams) {
+    std::lock_guard<std::mutex> g(csmp_track::mu);
+    int64_t db = 0, pb = 0;
+    for (const auto& kv : csmp_track::dev) db += (int64_t)kv.second;
+    for (const auto& kv : csmp_track::pinned) pb += (int64_t)kv.second;
+    if (device_bytes) *device_bytes = db;
+    if (device_blocks) *device_blocks = (int64_t)csmp_track::dev.size();
+    if (pinned_bytes) *pinned_bytes = pb;
+    if (registered_ranges) *registered_ranges = (int64_t)csmp_track::registered.load();
+    if (events) *events = (int64_t)csmp_track::events.load();
+    if (streams) *streams = (int64_t)csmp_track::streams.load();
+    return CSMP_OK;
+}
+
 extern "C" int csmp_bench_sweep(csmp_ctx* ctx, int variant, int reps, double* avg_ms) {
     if (!ctx || reps < 1) return CSMP_EINVAL;
     if (!ctx->dA) return fail(ctx, CSMP_ESTATE, "no dictionary set (csmp_set_dictionary)");
@@ -178,6 +195,7 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             ctx->tune_pair_lds_kib = (int)value;
             return CSMP_OK;
         case CSMP_TUNE_PAIR_SPLIT: ctx->tune_pair_split = value == 1 ? 1 : 0; return CSMP_OK;
+        case CSMP_TUNE_FAIL_ALLOC: ctx->tune_fail_alloc = (int)value; return CSMP_OK;
         case CSMP_TUNE_PIPELINES:
             if (value > 2) return fail(ctx, CSMP_EINVAL, "csmp_tune: pipelines must be 0 (automatic), 1 or 2");
             ctx->tune_pipelines = (int)value;

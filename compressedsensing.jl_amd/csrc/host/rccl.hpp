@@ -159,23 +159,57 @@ extern "C" int csmp_comm_init(csmp_ctx* ctx, const void* id, int rank, int world
     return CSMP_OK;
 }
 
-// The call is COLLECTIVE: every rank must reach the ncclAllGather, or the ranks that did wait for ever.  So nothing rank-specific
-// returns before it: arguments that are the same on all ranks are checked first (a failure there fails everywhere), the gather's
-// own two buffers are allocated next (the one failure that cannot be reported: without them this rank cannot take part), and from
-// then on a failure of THIS rank -- its B missing, its temporaries, its block's solves (CSMP_EDIM, CSMP_ENOMEM, CSMP_ERANGE ...)
-// -- is carried through the collective as a status in the block (k_pack_rows) and returned AFTER it, on every rank: the failing
-// rank gets its own code and message, the others the same code and the failing rank's number.  No rank's outputs are valid then.
+// The call is COLLECTIVE: every rank must reach the same collectives with the same counts, or the ranks that did wait for ever.
+// So nothing that can differ between the ranks returns before a collective has carried it to all of them:
+//   1. AGREEMENT.  The arguments that size the gather -- nsig, k, the element type of B, the method, eps -- and this rank's
+//      verdict on its own arguments travel first, in an all-gather of kHdr doubles per rank (a count no argument can change).  Ranks
+//      that were called with different arguments, or any rank with invalid ones, make EVERY rank return CSMP_EINVAL here, before any
+//      solve and before the gather whose counts would not have matched.  (Only a missing communicator and a NULL context return
+//      earlier: such a rank cannot take part in anything.)
+//   2. The gather's own two buffers (and the header's) are the one failure that cannot be reported: without them this rank cannot
+//      take part.  From then on a failure of THIS rank -- its B missing, its temporaries, its block's solves (CSMP_EDIM,
+//      CSMP_ENOMEM, CSMP_ERANGE, a HIP error ...) -- is REMEMBERED, carried through the gather as a status in the block
+//      (k_pack_rows) and returned AFTER it, on every rank: the failing rank gets its own code and message, the others the same
+//      code and the failing rank's number.  No rank's outputs are valid then.  A HIP error left pending by the failed part is
+//      cleared on the spot (hipGetLastError): read later, it would make this rank leave in front of the gather.
+constexpr int kHdr = 8;
 extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64_t ldB, int64_t nsig, int b_loc, int64_t k, double eps,
                                 int method, int64_t* idx, double* val, int64_t* nnz, int out_loc) {
     if (!ctx) return CSMP_EINVAL;
     if (!ctx->comm) return fail(ctx, CSMP_ESTATE, "omp_sharded: no communicator (csmp_comm_init)");
-    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE))
-        return fail(ctx, CSMP_EINVAL, "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE");
-    if (nsig < 0 || k < 1 || !idx || !val || !nnz || (method != 0 && method != 1)) return fail(ctx, CSMP_EINVAL, "omp_sharded: bad arguments");
-    if (!(eps >= 0.0)) return fail(ctx, CSMP_EINVAL, "eps has to be non-negative");
-    if (nsig == 0) return CSMP_OK;
     HIPCHECK(hipSetDevice(ctx->dev));
     const int world = ctx->comm_world, rank = ctx->comm_rank;
+    // ---- 1. agreement
+    const char* argerr = nullptr;
+    if ((b_loc != CSMP_HOST && b_loc != CSMP_DEVICE) || (out_loc != CSMP_HOST && out_loc != CSMP_DEVICE)) argerr = "b_loc / out_loc must be CSMP_HOST or CSMP_DEVICE";
+    else if (nsig < 0 || k < 1 || !idx || !val || !nnz || (method != 0 && method != 1)) argerr = "omp_sharded: bad arguments";
+    else if (b_dtype != CSMP_F32 && b_dtype != CSMP_F64) argerr = "b_dtype must be CSMP_F32 or CSMP_F64";
+    else if (!(eps >= 0.0)) argerr = "eps has to be non-negative";  // src/matchingpursuit.jl:74
+    {
+        DevTmp tHdr, tHdrAll;
+        HIPCHECK(tHdr.alloc(kHdr * sizeof(double)));
+        HIPCHECK(tHdrAll.alloc((size_t)world * kHdr * sizeof(double)));
+        double h[kHdr] = {(double)nsig, (double)k, (double)b_dtype, (double)method, eps == eps ? eps : -1.0, argerr ? 1.0 : 0.0, 0.0, 0.0};
+        HIPCHECK(hipMemcpyAsync(tHdr.p, h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+        const ncclResult_t rh = g_rccl.AllGather(tHdr.p, tHdrAll.p, (size_t)kHdr, ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);
+        if (rh != ncclSuccess) return rccl_fail(ctx, "ncclAllGather (agreement)", rh);
+        std::vector<double> all((size_t)world * kHdr);
+        HIPCHECK(hipMemcpyAsync(all.data(), tHdrAll.p, all.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (argerr) return fail(ctx, CSMP_EINVAL, argerr);
+        for (int q = 0; q < world; ++q) {
+            const double* hq = all.data() + (size_t)q * kHdr;
+            if (hq[5] != 0.0)
+                return fail(ctx, CSMP_EINVAL, "omp_sharded: rank " + std::to_string(q) + " was called with invalid arguments; no rank solves anything");
+            if (memcmp(hq, h, 5 * sizeof(double)) != 0)
+                return fail(ctx, CSMP_EINVAL, "omp_sharded: the ranks disagree on (nsig, k, b_dtype, method, eps): rank " + std::to_string(q) + " has (" +
+                                                  std::to_string((int64_t)hq[0]) + ", " + std::to_string((int64_t)hq[1]) + ", " + std::to_string((int)hq[2]) + ", " +
+                                                  std::to_string((int)hq[3]) + ", " + std::to_string(hq[4]) + "), rank " + std::to_string(rank) + " (" +
+                                                  std::to_string(nsig) + ", " + std::to_string(k) + ", " + std::to_string(b_dtype) + ", " + std::to_string(method) +
+                                                  ", " + std::to_string(eps) + "); no rank solves anything");
+        }
+    }
+    if (nsig == 0) return CSMP_OK;  // (on every rank: they agree)
     int64_t lo = 0, hi = 0;
     CHECK(csmp_shard_range(nsig, rank, world, &lo, &hi));
     const int64_t nloc = hi - lo, rows = (nsig + world - 1) / world, w = 2 * k + 1;
@@ -212,11 +246,18 @@ extern "C" int csmp_omp_sharded(csmp_ctx* ctx, const void* B, int b_dtype, int64
         note(method == 1
                  ? csmp_omp_batch_mfma(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE)
                  : csmp_omp_batch(ctx, B, b_dtype, ldB, nloc, b_loc, k, eps, (int64_t*)tIdx.p, (double*)tVal.p, (int64_t*)tNnz.p, CSMP_DEVICE));
+    if (local != CSMP_OK) {
+        // whatever the failed part left behind must not reach the gather: a pending HIP error (an allocation that failed inside the
+        // block's solves leaves hipErrorOutOfMemory for the next hipGetLastError) and work still queued on the stream
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+    }
     {
         const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (rows * w + 255) / 256));
         hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, ctx->stream, (const int64_t*)tIdx.p, (const double*)tVal.p, (const int64_t*)tNnz.p, k,
                            local == CSMP_OK ? nloc : 0, rows, (double*)tPack.p, local);
-        HIPCHECK(hipGetLastError());
+        const hipError_t pe = hipGetLastError();  // (remembered like every other failure of this rank: the gather comes first)
+        if (pe != hipSuccess) note(fail(ctx, CSMP_EHIP, std::string("omp_sharded: packing this rank's block: ") + hipGetErrorString(pe)));
     }
     // ---- THE collective: every rank's packed block, device memory to device memory, ordered on the context's stream
     const ncclResult_t r = g_rccl.AllGather(tPack.p, tAll.p, (size_t)(rows * w), ncclDouble, (ncclComm_t)ctx->comm, ctx->stream);

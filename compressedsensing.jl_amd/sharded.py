@@ -59,16 +59,44 @@ class ShardedSolveError(RuntimeError):
         self.failed, self.status = failed, status
 
 
+class ShardedArgumentError(ValueError):
+    """The ranks of a signal-sharded call were given different (nsig, k): raised on EVERY rank by the agreement exchange, before any
+    collective whose counts would not have matched (csmp_omp_sharded returns CSMP_EINVAL on every rank the same way)."""
+
+    def __init__(self, rows):
+        super().__init__(f"signal-sharded solve: the ranks disagree on (nsig, row width): {rows}; no rank's results are valid")
+        self.rows = rows
+
+
+def agree(values, group=None, device=None):
+    """All ranks exchange a fixed-size header (a count no argument can change) and compare: different values on any two ranks raise
+    ShardedArgumentError on every rank.  The collective in front of the gather, whose counts depend on exactly these values."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    on_host = device is None or device.type != "cuda" or dist.get_backend(group) == "gloo"
+    mine = torch.tensor([float(v) for v in values], dtype=torch.float64, device=torch.device("cpu") if on_host else device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    rows = [tuple(o.cpu().tolist()) for o in out]
+    if any(r != rows[0] for r in rows):
+        raise ShardedArgumentError(rows)
+
+
 def gather_packed(packed, nsig, group=None, status=0):
-    """ONE all_gather of every rank's packed block (padded to the largest block, ceil(nsig / world) rows);
-    returns the (nsig, 2k+1) tensor of all signals in global order, on `packed`'s device.
+    """ONE all_gather of every rank's packed block (padded to the largest block, ceil(nsig / world) rows), behind the fixed-size
+    agreement exchange on (nsig, 2k+1); returns the (nsig, 2k+1) tensor of all signals in global order, on `packed`'s device.
     status < 0: THIS rank could not solve its block.  It still takes part -- a rank that left before the collective would leave
     the others waiting for ever -- with an empty block whose row 0 carries the status in its nnz slot (a count is never negative:
     libcsmp's k_pack_rows writes the same word); every rank then raises ShardedSolveError."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
+    # the gather's counts follow from (nsig, row width): ranks that disagree on them would post mismatched all_gathers and hang
+    agree((int(nsig), int(packed.shape[1])), group, packed.device)
     maxn = -(-int(nsig) // world)
+    if maxn == 0:  # an empty batch (on every rank: they agree): nothing to gather, nothing that could have failed
+        return torch.zeros((0, packed.shape[1]), dtype=packed.dtype, device=packed.device)
     mine = packed
     if status < 0:
         mine = torch.zeros((maxn, packed.shape[1]), dtype=packed.dtype, device=packed.device)

@@ -22,6 +22,10 @@ int csmp_profile_window(csmp_ctx *ctx, int64_t *launches, double *window_ms, dou
 /* average reading (ms) of an event pair with nothing between its two records: the share of a timed launch's bracket that is the
  * bracket itself */
 int csmp_profile_overhead(csmp_ctx *ctx, int reps, double *avg_ms);
+/* what the library holds at this moment, process-wide: bytes and blocks of device memory, bytes of page-locked host memory, host ranges
+ * registered with the device, events, streams.  Every one is zero when no context exists (tests/test_gpu_leaks.py).  Any pointer may be NULL. */
+int csmp_live_resources(int64_t *device_bytes, int64_t *device_blocks, int64_t *pinned_bytes, int64_t *registered_ranges, int64_t *events,
+                        int64_t *streams);
 /* sweep bandwidth probe: `reps` product sweeps (argmaxinner!(P), src/matchingpursuit.jl:181-185) of a random residual,
  * bracketed by one HIP event pair on the ctx stream; returns the average ms per sweep.  variant must be 0. */
 int csmp_bench_sweep(csmp_ctx *ctx, int variant, int reps, double *avg_ms);
@@ -44,6 +48,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_SWEEP_LDS_KIB 15 /* dynamic LDS (KiB) the stand-alone product sweep REQUESTS when that is more than it uses: above 80 = one workgroup per CU, 54 = two */
 #define CSMP_TUNE_SWEEP_SHORT 16  /* 1: the stand-alone sweep keeps one column per unit for every shape (default 0: columns of up to four 1-KiB chunks go two or four to a unit, k_sweep_short) */
 #define CSMP_TUNE_PHASE_ROWS 17   /* the phased sweep (a residual longer than the LDS): most rows of one stage; 0 = as many as the LDS holds */
+#define CSMP_TUNE_FAIL_ALLOC 18   /* test hook: the n-th device allocation of solver state from now fails for real (hipMalloc of an impossible size: hipErrorOutOfMemory stays pending); 0 = off */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
 #define CSMP_TUNE_DIAG_SPLIT 6   /* 1: kernels that fuse independent parts run one launch per part (same results; a kernel trace shows the parts) */

