@@ -5,16 +5,24 @@ static int del_ensure(csmp_ctx* ctx) {
     Solver& s = ctx->s;
     if (s.kcap > kTMaxCols) return fail(ctx, CSMP_ERANGE, "column removal supports at most 4095 columns");
     if (s.R2) return CSMP_OK;
-    CHECK(dmalloc(ctx, &s.R2, (size_t)s.kcap * s.kcap));
-    CHECK(dmalloc(ctx, &s.Gdel, (size_t)2 * s.kcap + 2));
-    CHECK(dmalloc(ctx, &s.qdrop, s.Mpad));
-    CHECK(dmalloc(ctx, &s.bwd, s.kcap));
-    CHECK(dmalloc(ctx, &s.bwd_coef, s.kcap));
-    CHECK(dmalloc(ctx, &s.bwd_info, 2));
-    CHECK(dmalloc(ctx, &s.delmeta, 4));
-    CHECK(dmalloc(ctx, &s.qsave, s.Mpad));
-    CHECK(dmalloc(ctx, &s.delpos, 1));
-    return CSMP_OK;
+    // all of the group or none of it: R2 alone would tell the next call that the group exists
+    auto all = [&]() -> int {
+        CHECK(dmalloc(ctx, &s.Gdel, (size_t)2 * s.kcap + 2));
+        CHECK(dmalloc(ctx, &s.qdrop, s.Mpad));
+        CHECK(dmalloc(ctx, &s.bwd, s.kcap));
+        CHECK(dmalloc(ctx, &s.bwd_coef, s.kcap));
+        CHECK(dmalloc(ctx, &s.bwd_info, 2));
+        CHECK(dmalloc(ctx, &s.delmeta, 4));
+        CHECK(dmalloc(ctx, &s.qsave, s.Mpad));
+        CHECK(dmalloc(ctx, &s.delpos, 1));
+        CHECK(dmalloc(ctx, &s.R2, (size_t)s.kcap * s.kcap));
+        return CSMP_OK;
+    };
+    const int rc = all();
+    if (rc != CSMP_OK) {
+        dfree(s.R2); dfree(s.Gdel); dfree(s.qdrop); dfree(s.bwd); dfree(s.bwd_coef); dfree(s.bwd_info); dfree(s.delmeta); dfree(s.qsave); dfree(s.delpos);
+    }
+    return rc;
 }
 
 // remove_column!(AiQR, *delpos) -- the insertion position is read from device memory (-1: nothing happens)
@@ -44,16 +52,23 @@ static int tinv_ensure(csmp_ctx* ctx) {
     CHECK(del_ensure(ctx));
     if (s.T) return CSMP_OK;
     const size_t nch = (size_t)(s.kcap + kTChunk - 1) / kTChunk;
-    CHECK(dmalloc(ctx, &s.T, (size_t)s.kcap * s.kcap));
-    CHECK(dmalloc(ctx, &s.T2, (size_t)s.kcap * s.kcap));
-    // the strictly lower triangles stay ZERO for the life of the buffers (every writer writes entries on and above the diagonal
-    // only): the removal's rotation chains read whole rows without a bounds test (k_tdel_apply)
-    HIPCHECK(hipMemsetAsync(s.T, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
-    HIPCHECK(hipMemsetAsync(s.T2, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
-    CHECK(dmalloc(ctx, &s.tpd, nch * s.kcap));
-    CHECK(dmalloc(ctx, &s.tpn, nch * s.kcap));
-    CHECK(dmalloc(ctx, &s.tmeta, 2));
-    return CSMP_OK;
+    auto all = [&]() -> int {  // (all of the group or none of it, as del_ensure)
+        CHECK(dmalloc(ctx, &s.T2, (size_t)s.kcap * s.kcap));
+        CHECK(dmalloc(ctx, &s.tpd, nch * s.kcap));
+        CHECK(dmalloc(ctx, &s.tpn, nch * s.kcap));
+        CHECK(dmalloc(ctx, &s.tmeta, 2));
+        CHECK(dmalloc(ctx, &s.T, (size_t)s.kcap * s.kcap));
+        // the strictly lower triangles stay ZERO for the life of the buffers (every writer writes entries on and above the diagonal
+        // only): the removal's rotation chains read whole rows without a bounds test (k_tdel_apply)
+        HIPCHECK(hipMemsetAsync(s.T, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
+        HIPCHECK(hipMemsetAsync(s.T2, 0, (size_t)s.kcap * s.kcap * sizeof(double), ctx->stream));
+        return CSMP_OK;
+    };
+    const int rc = all();
+    if (rc != CSMP_OK) {
+        dfree(s.T); dfree(s.T2); dfree(s.tpd); dfree(s.tpn); dfree(s.tmeta);
+    }
+    return rc;
 }
 // T = R^-1 for the columns factorised so far
 static int launch_tinv_build(csmp_ctx* ctx) {

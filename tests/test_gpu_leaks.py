@@ -9,6 +9,7 @@
   context's result bit for bit.
 The reference has no such state (Julia's GC owns its arrays: src/matchingpursuit.jl:44-60); this is the price of the C ABI."""
 import gc
+import os
 
 import numpy as np
 import pytest
@@ -74,9 +75,9 @@ def test_no_resource_leaks(cs, tmp_path):
     for name, A in (("a32", A32), ("a64", A64)):
         paths[name] = str(tmp_path / (name + ".csmp"))
         L.write_dictionary_file(paths[name], A)
-    bad_file = str(tmp_path / "garbage.csmp")
+    bad_file = str(tmp_path / "truncated.csmp")  # a good header over too few bytes: the read fails AFTER the context let its dictionary go
     with open(bad_file, "wb") as f:
-        f.write(b"CSMPDICT" + bytes(100))
+        f.write(open(paths["a32"], "rb").read()[:64 + 1000])
     # one warm cycle: what the process keeps for good (the runtime's pools, RCCL's first communicator) is not a leak of a cycle
     d = cs.Dictionary(A32)
     d.ctx.comm_init(cs.comm_id(), 0, 1)
@@ -107,9 +108,10 @@ def test_no_resource_leaks(cs, tmp_path):
         which = c % 5
         if which == 0:
             with pytest.raises(cs.CsmpError):
-                ctx.set_dictionary_file(bad_file)                    # leaves NO dictionary behind
-            with pytest.raises(cs.CsmpError):
-                ctx.omp(y, 3, eps)
+                ctx.call("csmp_set_dictionary_file", os.fsencode(bad_file), L.DEVICE if c % 2 else L.HOST_STREAMED)
+            with pytest.raises(cs.CsmpError):                        # the failed call leaves NO dictionary behind
+                ctx.call("csmp_omp", L.ptr(y), L.F64, L.i64(3), L.C.c_double(eps), L.ptr(np.zeros(3, np.int64)), L.ptr(np.zeros(3)),
+                         L.C.byref(L.i64(0)), None)
         elif which == 1:
             with pytest.raises(cs.CsmpError):
                 ctx.omp(y[:-1], 3, eps)                              # length(b) != size(A, 1)
