@@ -15,6 +15,8 @@ struct OmprJob {
     std::vector<double> cs, call;
     // exchanges on the inverse Gram matrix (csmp_swap.hpp): on from the acquisition until an exchange fails its guard
     bool gram = false;
+    int64_t gram_exchanges = 0;              // accepted since the solve began
+    static constexpr int kSwapRefresh = 32;  // ... and every so many of them H, c, x are rebuilt from the factorisation
     std::vector<int> slot;  // the atom in every slot of H (device: s.sel)
     double *dG = nullptr, *dUpart = nullptr, *dU = nullptr, *dHp = nullptr, *dC = nullptr, *dInfo = nullptr, *dRpart = nullptr, *dN2 = nullptr;
     int* dMeta = nullptr;         // the exchange the chain performs: (1, leaving, joining, slot), csmp_swap.hpp
@@ -106,6 +108,19 @@ struct OmprJob {
         double t = 0.0;
         for (double v : L.n2) t += v;
         resnorm = std::sqrt(t);
+        gram_exchanges += 1;
+    }
+    // H, c and x are UPDATED by every exchange (rank-one corrections), never re-derived: rounding accumulates over many exchanges on
+    // an ill-conditioned support, and the per-exchange guard (sigma > 1e-6 a'a) sees a near-dependent atom, not drift.  The
+    // reference solves against b afresh after every exchange (ldiv!!, src/twostage.jl:176).  So every kSwapRefresh accepted
+    // exchanges the support is factorised from its columns again and H, c, x, r rebuilt from that (about one iteration's time).
+    // The residual norm the stop rule compares is the one the exchanges carried: the refresh changes no decision by itself.
+    int gram_refresh_if_due() {
+        if (!gram || gram_exchanges == 0 || gram_exchanges % kSwapRefresh != 0) return CSMP_OK;
+        const double keep = resnorm;
+        CHECK(gram_leave());
+        resnorm = keep;
+        return ctx->dtype == CSMP_F32 ? gram_begin_t<float>() : gram_begin_t<double>();
     }
     // one exchange named by the host: `leaving` out, `joining` in; *refused: the guard did not hold and nothing was changed
     int gram_swap(int leaving, int joining, bool* refused) {
@@ -127,7 +142,10 @@ struct OmprJob {
             CHECK(f.wait());
         }
         *refused = L.info[2] != 0.0;
-        if (!*refused) gram_accept(L);
+        if (!*refused) {
+            gram_accept(L);
+            CHECK(gram_refresh_if_due());
+        }
         return CSMP_OK;
     }
     // the guard refused an exchange: back to the factorisation of the CURRENT support (as the acquisition builds it); the
@@ -163,6 +181,7 @@ struct OmprJob {
         unc_seen = 0;
         resnorm = 0.0;
         gram = false;
+        gram_exchanges = 0;
         return CSMP_OK;
     }
     // oblivious_acquisition!(P, x, k) on an empty x (src/matchingpursuit.jl:207-216, called at src/twostage.jl:190): the k atoms best
@@ -281,7 +300,7 @@ struct OmprJob {
         if (fast && L.meta[0] == 1) {
             if (L.info[2] == 0.0) {
                 gram_accept(L);
-                return CSMP_OK;
+                return gram_refresh_if_due();
             }
             // the guard refused: the same exchange on the factorisation of the current support, which carries the rest of the solve
             CHECK(gram_leave());

@@ -74,7 +74,11 @@ int csmp_device_info(csmp_ctx *ctx, char *name, int name_len, int *compute_units
 /* ------------------------------------------------------------------ dictionary
  * Replaces the `A` field of MP/OMP/GOMP/SP (src/matchingpursuit.jl:10-24,44-60,95-114;
  * src/twostage.jl:42-61).  Uploaded once, stays resident in HBM.  A CSMP_DEVICE pointer that is
- * 16-byte aligned with M and ldA multiples of 16 bytes is borrowed without a copy. */
+ * 16-byte aligned with M and ldA multiples of 16 bytes is borrowed without a copy.
+ * The entries must be FINITE.  The sweeps pad a column's last load by re-reading its own last 16 bytes against zeros of the
+ * residual image (no predicate in the load stream): an Inf or NaN there gives 0 * Inf = NaN for THAT column's product, where
+ * the reference's mul! would leave an Inf -- no other column is touched, and a column with a non-finite entry has no
+ * meaningful correlation in the reference either. */
 int csmp_set_dictionary(csmp_ctx *ctx, const void *A, int64_t M, int64_t N, int64_t ldA, int dtype, int loc);
 /* A dictionary LARGER THAN HBM (not in the reference, whose A is whatever the host's memory holds):
  * loc = CSMP_HOST_STREAMED leaves A in HOST memory, page-locked and mapped into the device's address space, and every kernel that

@@ -140,3 +140,30 @@ def test_profile_window_counts_both_pipelines(cs):
         # every launch lies inside the window: the window is at least as long as launches / streams back to back would be short of
         assert w["window_ms"] * streams >= 0.5 * w["launches"] * w["mean_launch_ms"] / max(streams, 1)
     d.close()
+
+
+@pytest.mark.parametrize("cfg", [(512, 4096, 160, 0.7, 2.0, 5), (384, 3000, 150, 0.8, 3.0, 6)])
+def test_ompr_many_exchanges_on_a_coherent_dictionary(cs, oracle, cfg):
+    """OMPR's fast path exchanges atoms on H = (A_S'A_S)^-1 by rank-one corrections (csmp_swap.hpp) and never re-derived H, c, x: the
+    advisor's round-5 finding.  Every 32 accepted exchanges they are now rebuilt from the factorisation of the support
+    (OmprJob::gram_refresh_if_due).  A coherent dictionary (a shared component in every atom, cond(A_S) ~ 20) under heavy noise runs
+    54-69 exchanges: the supports and iteration counts are the oracle's (which solves against b afresh after every exchange, as the
+    reference does: src/twostage.jl:176), and the coefficients are THE least-squares solution on the final support."""
+    M, N, k, mix, noise, seed = cfg
+    g = np.random.default_rng(seed)
+    sh = g.standard_normal((M, 1))
+    A = g.standard_normal((M, N)) + mix * np.sqrt(M) * sh / np.linalg.norm(sh)
+    A /= np.linalg.norm(A, axis=0, keepdims=True)
+    A = np.asfortranarray(A.astype(np.float32))
+    xs = cs.sparse_vector(N, k, rng=g)
+    y = cs.perturb(A[:, xs.nzind].astype(np.float64) @ xs.nzval, noise, rng=g)
+    d = cs.Dictionary(A)
+    got = d.ctx.ompr(y, k, 0.0, 400)
+    ref = oracle.ompr(A, y, k, 0.0, 400)
+    assert got[2] >= 50 and got[2] == ref[2], (got[2], ref[2])
+    assert np.array_equal(got[0], ref[0])
+    S = A[:, got[0]].astype(np.float64)
+    xls = np.linalg.lstsq(S, y, rcond=None)[0]
+    assert np.allclose(got[1], xls, rtol=1e-9, atol=1e-10 * np.abs(xls).max()), np.abs(got[1] - xls).max()
+    assert close(got[1], ref[1])
+    d.close()
