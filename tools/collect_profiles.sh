@@ -28,6 +28,9 @@ python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_default_stdout.t
 tail -1 $OUT/bench_default_stdout.txt > $OUT/bench_default_line.json; cp bench_secondary.json $OUT/bench_default_detail.json; rm -f $OUT/bench_default_stdout.txt
 cd /tmp
 stats bench --steps 18 --warmup 3 --no-cpu-baseline --no-secondary
+# two pipelines side by side: the sweep launches of the two streams overlap -- the bandwidth the kernel trace itself supports
+python3 $R/tools/trace_union.py /tmp/prof_bench "k_tick<float, 16, false, true" 1073741824 > $OUT/bench_kernel_union.json 2> $OUT/bench_kernel_union.err
+stats bench_one_pipeline --steps 18 --warmup 3 --no-cpu-baseline --no-secondary --tune pipelines=1
 stats bench_batched --workload batched --steps 2 --warmup 1
 stats bench_batched_gram --workload batched --steps 2 --warmup 1 --batch-gram
 stats bench_sp --workload sp --steps 9 --warmup 3
@@ -39,17 +42,18 @@ stats bench_gomp_single_screened_f16 --workload gomp_single --steps 2 --warmup 1
 stats bench_ompr --workload ompr --steps 3 --warmup 1 --no-in-flight
 stats bench_srr --workload srr --steps 3 --warmup 1 --no-in-flight
 stats bench_fr --workload fr --steps 6 --warmup 3
-# the shape table of the product sweep (M = 1000 .. 32768, f32 and f64): per-shape rows from the kernel trace
+# the shape table of the product sweep (M = 256 .. 32768, f32 and f64): per-shape rows from the kernel trace
 rm -rf /tmp/prof_shapes /tmp/w_shapes; mkdir -p /tmp/w_shapes; cd /tmp/w_shapes
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_shapes -- python3 $R/bench.py --workload shapes --steps 10 > $OUT/shapes_stdout.txt 2> $OUT/shapes.err
 tail -1 $OUT/shapes_stdout.txt > $OUT/bench_shapes_line.json; rm -f $OUT/shapes_stdout.txt
-cp $R/profiles/r05_sweep_shapes.json $OUT/sweep_shapes.json
+cp $R/profiles/r06_sweep_shapes.json $OUT/sweep_shapes.json
 python3 $R/tools/shape_profile.py /tmp/prof_shapes $OUT/sweep_shapes.json > $OUT/sweep_shapes_kernel_stats.csv
 cd /tmp
 # HBM traffic of the steady-state tick (two passes: the TCC block cannot hold both counters)
-d1=$(pmc fetch FETCH_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
-d2=$(pmc write WRITE_SIZE --steps 3 --warmup 0 --no-cpu-baseline --no-secondary)
-python3 $R/tools/pmc_traffic.py $d1 $d2 > $OUT/sweep_traffic.json
+# (six signals: two pipelines, the tick's sweep a launch of its own -- the steady-state symbol names exactly those launches)
+d1=$(pmc fetch FETCH_SIZE --steps 6 --warmup 0 --no-cpu-baseline --no-secondary)
+d2=$(pmc write WRITE_SIZE --steps 6 --warmup 0 --no-cpu-baseline --no-secondary)
+python3 $R/tools/pmc_traffic.py --kernel "k_tick<float, 16, false, true" $d1 $d2 > $OUT/sweep_traffic.json
 # HBM fetch bytes of the binary16-image sweep
 d5=$(pmc scr FETCH_SIZE --workload screened --steps 2 --warmup 1)
 python3 $R/tools/pmc_traffic.py --kernel k_sweep_f16 $d5 > $OUT/screened_f16_traffic.json

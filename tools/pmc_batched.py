@@ -16,12 +16,18 @@ M, N, B, K = 4096, 65536, 1024, 128
 gram = len(sys.argv) > 3 and sys.argv[3] == "gram"
 
 
+KEYS = ("k_b_screen256p", "k_b_pick", "k_b_append")
+seen_names, seen_files = set(), []
+
+
 def collect(d):
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        seen_files.append(f)
         for row in csv.DictReader(open(f)):
             kn = row.get("Kernel_Name", "")
-            for key in ("k_b_screen256p", "k_b_pick", "k_b_append"):
+            seen_names.add(kn.split("(")[0][:80])
+            for key in KEYS:
                 if key in kn:
                     acc.setdefault((key, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
     return acc
@@ -53,4 +59,10 @@ for key in ("k_b_screen256p", "k_b_pick", "k_b_append"):
     if key == "k_b_pick":
         out[key]["note"] = "algorithmic = candidates + residual only; the rest is the window's rescored columns (16 KiB each)"
         out[key]["rescored_columns_per_signal_and_step"] = max(0.0, (fb + wb - alg[key]) / B / (M * 4))
+missing = [key for key in KEYS if key not in out]
+if missing:
+    # (round 5 committed a file with no kernel rows at all: an empty collection must not look like a result)
+    sys.stderr.write("pmc_batched.py: no FETCH_SIZE rows for %s in %s (%d counter file(s); kernels seen: %s)\n"
+                     % (", ".join(missing), sys.argv[1], len(seen_files), ", ".join(sorted(seen_names)[:12]) or "none"))
+    sys.exit(2)
 print(json.dumps(out, indent=1))

@@ -3,7 +3,7 @@ kernel symbol, grid and dynamic LDS (which together identify the shape: tools/sw
 their count and average duration, and the fraction of the 8 TB/s HBM peak that duration is for the shape's M*N*sizeof(T) bytes.
 The --stats summary merges shapes that share a template instance; this keeps them apart.
 
-    python tools/shape_profile.py <rocprof output dir> <shapes.json>  >  profiles/r05_sweep_shapes_kernel_stats.csv
+    python tools/shape_profile.py <rocprof output dir> <shapes.json>  >  profiles/r06_sweep_shapes_kernel_stats.csv
 """
 import csv
 import glob
@@ -20,7 +20,7 @@ def main():
     for f in glob.glob(os.path.join(prof, "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             name = row.get("Kernel_Name", "")
-            if "k_sweep_gen" not in name:
+            if not any(k in name for k in ("k_sweep_gen", "k_sweep_short", "k_sweep_ph")):
                 continue
             wg = int(row.get("Workgroup_Size_X", row.get("Workgroup_Size", 256)) or 256)
             grid = int(row.get("Grid_Size_X", row.get("Grid_Size", 0)) or 0) // max(wg, 1)
@@ -53,7 +53,13 @@ def main():
         r = table[i] if ok else None
         if r is not None:
             tname = "float" if r["dtype"] == "f32" else "double"
-            want = "k_sweep_gen<%s, %d, %d, %s>" % (tname, r["unit_loads"], 32 // r["unit_loads"], "true" if r["phases"] > 1 else "false")
+            if r["phases"] > 1:  # a residual longer than the LDS (round 6: its own kernel)
+                want = "k_sweep_ph<%s, 8, 4>" % tname
+            elif r.get("columns_per_unit", 1) > 1:  # short columns, several to a unit: <element type, chunks per column, columns per reduction>
+                cpu = r["columns_per_unit"]
+                want = "k_sweep_short<%s, %d, %d>" % (tname, 8 // cpu, 4 if cpu >= 4 else 2)
+            else:
+                want = "k_sweep_gen<%s, %d, %d>" % (tname, r["unit_loads"], 32 // r["unit_loads"])
             if want not in seg["name"]:
                 ok, r = False, None
         durs = sorted(seg["durs"])
