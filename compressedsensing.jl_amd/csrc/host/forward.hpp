@@ -178,50 +178,66 @@ static hipError_t tick_fr_launch_t(csmp_ctx* ctx, const TickFr<TA>& sw, const Ti
     hipLaunchKernelGGL(kern, dim3(2 * G + sw.nblk), dim3(kSweepThreads), lds, ctx->stream, sw, q1, q2, G, min_d2);
     return hipGetLastError();
 }
-template <typename TA>
-static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_eps, double min_d2, bool optimistic) {
-    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+// One pipeline's schedule (the TickPipe of host/omp.hpp with the OLS sweep)
+struct FrPipe {
+    csmp_ctx* ctx = nullptr;
+    bool present[3] = {false, false, false};
+    int nblk = 0, U = 8;
+    size_t lds = 0;
+};
+static void fr_pipe_begin(FrPipe& fp, csmp_ctx* ctx, const bool present[3], int64_t k) {
+    fp.ctx = ctx;
+    for (int q = 0; q < 3; ++q) fp.present[q] = present[q];
     activate_slot(ctx, 0);
-    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};
+    int grid; bool full; size_t flds;
+    fr_config(ctx, 1, fp.U, full, flds, grid);
+    fp.nblk = grid;
+    fp.lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, ctx->s.kcap)));
+}
+template <typename TA>
+static int fr_pipe_launch(FrPipe& fp, int64_t n, int64_t k, double max_eps, double min_d2, bool optimistic) {
+    csmp_ctx* ctx = fp.ctx;
+    const int skip = STOP_EPS | STOP_STAG | STOP_FULL | STOP_REORTH;
+    Solver* sl[3] = {&ctx->s, &ctx->park[1], &ctx->park[2]};  // (slot 0 is the active one: fr_pipe_begin)
     const int G = sl[0]->G;
-    int U, grid; bool full; size_t flds;
-    fr_config(ctx, 1, U, full, flds, grid);
-    int nblk = grid;
-    const size_t lds = std::max(flds, qr_lds_bytes((int)std::min<int64_t>(k, sl[0]->kcap)));
-    for (int64_t n = 0; n < 3 * k + 2; ++n) {
-        const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
-        const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
-        const bool az = present[zs] && n >= zs && tz < k;
-        const bool ay = present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
-        const bool ax = present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
-        if (!az && !ay && !ax) continue;
-        int jh1 = 0;
-        if (ay) {
-            jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
-            sl[ys]->jh_last = jh1;
-            if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
-        }
-        const Solver& z = *sl[zs];
-        TickFr<TA> sw;
-        sw.A = (const TA*)ctx->dA; sw.ld = ctx->ld; sw.Mv = ctx->Mv; sw.N = ctx->N;
-        sw.r = z.r; sw.Q = z.Q; sw.ldq = z.ldq; sw.rho2 = z.rho2; sw.dvec = z.dvec; sw.pval = z.pval; sw.pidx = z.pidx;
-        sw.sel = z.sel; sw.st = z.st; sw.max_eps = max_eps; sw.skipmask = skip; sw.nblk = nblk; sw.active = az ? 1 : 0;
-        auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, nblk, jh1, ay ? 1 : 0);
-        q1.mode = 3;
-        const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
-        const bool timed = az && ay && ax && prof_pick(ctx);
-        if (timed) CHECK(prof_mark(ctx));
-        hipError_t e;
-        if (U == 16)
-            e = tz == 0 ? tick_fr_launch_t<TA, 16, -1>(ctx, sw, q1, q2, G, lds, min_d2) : tick_fr_launch_t<TA, 16, 1>(ctx, sw, q1, q2, G, lds, min_d2);
-        else
-            e = tz == 0 ? tick_fr_launch_t<TA, 8, -1>(ctx, sw, q1, q2, G, lds, min_d2) : tick_fr_launch_t<TA, 8, 1>(ctx, sw, q1, q2, G, lds, min_d2);
-        HIPCHECK(e);
-        if (timed) CHECK(prof_mark(ctx));
+    const int zs = (int)(n % 3), ys = (int)((n + 2) % 3), xs = (int)((n + 1) % 3);
+    const int64_t tz = (n - zs) / 3, ty = (n - 1 - ys) / 3, tx = (n - 2 - xs) / 3;
+    const bool az = fp.present[zs] && n >= zs && tz < k;
+    const bool ay = fp.present[ys] && n >= 1 + ys && ty < k && (n - 1 - ys) % 3 == 0;
+    const bool ax = fp.present[xs] && n >= 2 + xs && tx < k && (n - 2 - xs) % 3 == 0;
+    if (!az && !ay && !ax) return CSMP_OK;
+    int jh1 = 0;
+    if (ay) {
+        jh1 = std::min(sl[ys]->jh, sl[ys]->kcap);
+        sl[ys]->jh_last = jh1;
+        if (sl[ys]->jh < sl[ys]->kcap) sl[ys]->jh += 1;
     }
+    const Solver& z = *sl[zs];
+    TickFr<TA> sw;
+    sw.A = (const TA*)ctx->dA; sw.ld = ctx->ld; sw.Mv = ctx->Mv; sw.N = ctx->N;
+    sw.r = z.r; sw.Q = z.Q; sw.ldq = z.ldq; sw.rho2 = z.rho2; sw.dvec = z.dvec; sw.pval = z.pval; sw.pidx = z.pidx;
+    sw.sel = z.sel; sw.st = z.st; sw.max_eps = max_eps; sw.skipmask = skip; sw.nblk = fp.nblk; sw.active = az ? 1 : 0;
+    auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, fp.nblk, jh1, ay ? 1 : 0);
+    q1.mode = 3;
+    auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
+    auto launch = [&](const TickFr<TA>& s_, const TickQr1<TA>& a_, const TickQr2& b_, int g_, size_t lds_) -> hipError_t {
+        if (fp.U == 16)
+            return tz == 0 ? tick_fr_launch_t<TA, 16, -1>(ctx, s_, a_, b_, g_, lds_, min_d2) : tick_fr_launch_t<TA, 16, 1>(ctx, s_, a_, b_, g_, lds_, min_d2);
+        return tz == 0 ? tick_fr_launch_t<TA, 8, -1>(ctx, s_, a_, b_, g_, lds_, min_d2) : tick_fr_launch_t<TA, 8, 1>(ctx, s_, a_, b_, g_, lds_, min_d2);
+    };
+    const bool timed = az && ay && ax && prof_pick(ctx);
+    if (timed) CHECK(prof_mark(ctx));
+    HIPCHECK(launch(sw, q1, q2, G, fp.lds));
+    if (timed) CHECK(prof_mark(ctx));
     return CSMP_OK;
 }
-
+template <typename TA>
+static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_eps, double min_d2, bool optimistic) {
+    FrPipe fp;
+    fr_pipe_begin(fp, ctx, present, k);
+    for (int64_t n = 0; n < 3 * k + 2; ++n) CHECK(fr_pipe_launch<TA>(fp, n, k, max_eps, min_d2, optimistic));
+    return CSMP_OK;
+}
 // fr(A, b, max_ε, min_δ, k) = ols = oomp = ormp, x starting empty: src/forward.jl:44-54
 extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t* idx,
                        double* val, int64_t* nnz, int64_t* order) {
@@ -325,6 +341,8 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     // TWO pipelines (omp only): the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair).
     // From six signals on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one.
     csmp_ctx* tw = nullptr;
+    // (omp only.  Forward regression's sweep holds two or three LDS images -- one workgroup per CU as it is -- and two pipelines of
+    // k_tick_fr measured no gain: 5.99e3 against 5.96e3 atoms/s)
     if (pipe && !isfr && nsig >= 6 && ctx->tune_pipelines != 1) {
         rc = twins_ensure(ctx, 1);
         if (rc == CSMP_OK) {
@@ -376,27 +394,28 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             return r2;
         };
         if (tw && rc == CSMP_OK) {
-            // this context takes the triples of the first half of the signals, the twin the rest; round j runs triple j of each
-            const int64_t ntrip = (nsig + 2) / 3;
-            const int64_t nA = std::min<int64_t>(nsig, 3 * ((ntrip + 1) / 2));
-            for (int64_t j = 0; 3 * j < nA && rc == CSMP_OK; ++j) {
-                bool pa[3], pb[3];
-                const int64_t fa = 3 * j, fb = nA + 3 * j;
-                rc = init_triple(ctx, fa, nA, pa);
-                const bool hasb = fb < nsig;
-                if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, nsig, pb);
-                if (rc != CSMP_OK) break;
-                if (hasb && j == 0 && ctx->N >= 8) {
-                    // the twin's pipeline starts HALF a tick behind: a throw-away sweep of half the dictionary on its stream (into the
-                    // slot's own correlation vector, which the first real sweep rewrites; no stop test, nothing else written).  Two
-                    // pipelines of equal ticks that start together stay in step, and their tails and launch boundaries would coincide.
-                    activate_slot(tw, 0);
-                    rc = launch_sweep(tw, tw->s.r, 0.0, 0, 0, nullptr, ctx->N / 2);
-                    if (rc != CSMP_OK) {
-                        ctx->err = tw->err;
-                        break;
-                    }
+            // this context takes the first half of the signals, the twin the second; each half goes through its pipeline in groups of
+            // three or two (10 signals: 3 + 3 + 2 + 2 -- never a lone signal beside a full triple), round j runs group j of each
+            const int64_t nA = (nsig + 1) / 2, nB = nsig - nA;
+            auto groups_of = [](int64_t lo, int64_t n) {
+                std::vector<std::pair<int64_t, int>> g;
+                if (n <= 0) return g;
+                const int64_t r = (n + 2) / 3, base = n / r, extra = n % r;
+                for (int64_t q = 0, at = lo; q < r; ++q) {
+                    const int c = (int)(base + (q < extra ? 1 : 0));
+                    g.push_back({at, c});
+                    at += c;
                 }
+                return g;
+            };
+            const auto gA = groups_of(0, nA), gB = groups_of(nA, nB);
+            for (size_t j = 0; j < gA.size() && rc == CSMP_OK; ++j) {
+                bool pa[3], pb[3];
+                const int64_t fa = gA[j].first, fb = j < gB.size() ? gB[j].first : 0;
+                rc = init_triple(ctx, fa, fa + gA[j].second, pa);
+                const bool hasb = j < gB.size();
+                if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, fb + gB[j].second, pb);
+                if (rc != CSMP_OK) break;
                 if (hasb)
                     rc = ctx->dtype == CSMP_F32 ? omp_ticks_pair<float>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid)
                                                 : omp_ticks_pair<double>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid);

@@ -111,8 +111,10 @@ static int tick_pipe_launch(TickPipe& tp, int64_t n, int64_t k, double eps, bool
     const auto sw = tick_sweep_params<TA>(ctx, *sl[zs], eps, tz > 0 ? 1 : 0, skip, tp.nblk, az ? 1 : 0);
     const auto q1 = tick_qr1_params<TA>(ctx, *sl[ys], skip, tp.nblk, jh1, ay ? 1 : 0);
     const auto q2 = tick_qr2_params(ctx, *sl[xs], sl[xs]->jh_last, optimistic ? 1 : 0, ax ? 1 : 0);
-    const bool steady = az && ay && ax;
-    const bool timed = steady && prof_pick(ctx);  // steady-state ticks only
+    // steady: all three stages live (one pipeline: the launches the roofline is quoted on).  Two pipelines: a tick's sweep is a
+    // launch of its own, the same work whatever the other stages do -- every one of them counts, the fill and drain ticks' too
+    const bool steady = tp.lds_sweep > 0 ? az : (az && ay && ax);
+    const bool timed = steady && prof_pick(ctx);
     if (tp.lds_sweep > 0) {
         // the append stages first, in a launch of their own that asks for what they need (it shares the CUs with the OTHER pipeline's
         // sweep), then the sweep alone with the large LDS request that keeps its workgroups one to a CU (omp_ticks_pair)

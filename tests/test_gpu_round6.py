@@ -132,7 +132,9 @@ def test_profile_window_counts_both_pipelines(cs):
         w = d.ctx.profile_window()
         launches, ms = d.ctx.profile_read(reset=True)
         d.ctx.profile_enable(False)
-        steady = (nsig // 3) * (3 * k + 2 - 4)  # ticks with all three stages live: all but the two that fill and the two that drain a triple
+        # one pipeline: the ticks with all three stages live (all but the two that fill and the two that drain a triple); two pipelines:
+        # a tick's sweep is a launch of its own and every one counts -- k per signal
+        steady = (nsig // 3) * (3 * k + 2 - 4) if streams == 1 else nsig * k
         assert w["streams"] == streams, w
         assert steady - 2 * streams * 2 <= w["launches"] <= steady, (w, steady)  # (first .. last SAMPLED launch on each stream)
         assert launches >= w["launches"] // 2 - 2 and ms > 0.0

@@ -35,7 +35,9 @@ def planted(A, k, seed, noise=5e-3):
 
 # (M, N): one-image shapes with ragged tails under every unit size, a residual just past the LDS (two phases, the second nearly
 # empty), two full phases, three ragged phases
-SWEEP_SHAPES = [(1000, 700), (1001, 300), (3000, 515), (4352, 260), (4097, 130), (20500, 150), (32768, 96), (40002, 70)]
+# round 6: short columns (k_sweep_short: 8 / 4 / 2 columns to a unit), configs[0]'s 256 rows, fewer rows than a wave has lanes
+SWEEP_SHAPES = [(1000, 700), (1001, 300), (3000, 515), (4352, 260), (4097, 130), (20500, 150), (32768, 96), (40002, 70),
+                (256, 4096), (512, 2048), (64, 300), (200, 1021), (130, 77), (32, 48)]
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
