@@ -15,6 +15,7 @@
 // deliver it, so Float64 selection costs no bandwidth ("sweep").
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 
 namespace csmp {
@@ -136,6 +137,13 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // global load and store (s_waitcnt vmcnt(0)), which would serialise a latency chain with the
 // look-ahead loads it is supposed to overlap
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// tools/probes/ph_trace.hip: wall-clock stamps (100 MHz) of a sweep workgroup's waves; nothing in the product build
+#ifdef CSMP_PH_TRACE
+__device__ unsigned long long* g_ph_trace;
+#define PH_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_ph_trace[((size_t)bid * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define PH_STAMP(slot) do { } while (0)
+#endif
 
 // lexicographic "better": larger value wins, ties go to the LOWER index (Julia argmax = first max)
 __device__ __forceinline__ bool better(double v, int i, double bv, int bi) {
@@ -181,6 +189,7 @@ __device__ __forceinline__ void sweep_body_gen(
     constexpr int NW = kSweepThreads / kWave;
     static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
     if (st->done & skipmask) return;
+    PH_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nvec = Mv / VEC;  // 16-byte vectors per column (Mv is a multiple of VEC: the leading dimension is padded to 16 bytes)
@@ -195,6 +204,43 @@ __device__ __forceinline__ void sweep_body_gen(
     int besti = 0x7fffffff;
     const int nunit = (Mv + UR - 1) / UR;  // units per column
     const int Mst = nunit * UR;            // rows of the image in use (zero beyond Mv)
+    VT buf[NB][U];
+    // c values are STAGED: lane s keeps the total of the wave's s-th finished column and the wave writes 64 of them with one
+    // store instruction.  A store per column sits in the wave's in-order memory queue among the ring's loads: measured 1.5-3 us of
+    // a 155-us sweep at 16-KiB columns, 5-7 % at 8-KiB Float64 columns, 13 us of 170 with one store per 4 KiB (short columns).
+    double cst = 0.0;
+    int64_t ccst = -1;
+    int cslot = 0;
+    int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
+    int ib = 0, cb = 0;
+    const int64_t T = ncol * nunit;
+    int64_t ileft = T, cleft = T;
+    double acc = 0.0;
+    auto issue = [&](VT(&b)[U]) {
+        const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
+        const int vb = ib * (U * kWave) + lane;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int v = vb + u * kWave;
+            b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
+        }
+        if (++ib == nunit) {
+            ib = 0;
+            icol += stride;
+        }
+        --ileft;
+    };
+    // the ring's first loads go out BEFORE the residual image is staged: they do not depend on it, and the trip to HBM and the
+    // image's trip to L2 then overlap (tools/probes/ph_trace.hip: the image and ||r||^2 take 6.5-9.7 us of a long column's launch)
+    // (a wave with fewer than NB units re-reads its last column -- or column N - 1 -- for the rest: no load sits under a branch)
+#pragma unroll
+    for (int d = 0; d < NB; ++d) {
+        if (ileft <= 0) {
+            icol = (ncol > 0 ? col0 + (ncol - 1) * stride : N - 1);
+            ib = 0;
+        }
+        issue(buf[d]);
+    }
     {
         // the residual image, and ||r||^2 in a fixed per-thread order (identical in every workgroup).
         // The loads go out 16 at a time (a rolled loop waits for each in turn: ~6 us of a 150 us kernel at M = 4096).
@@ -225,32 +271,7 @@ __device__ __forceinline__ void sweep_body_gen(
             return;
         }
     }
-    VT buf[NB][U];
-    // c values are STAGED: lane s keeps the total of the wave's s-th finished column and the wave writes 64 of them with one
-    // store instruction.  A store per column sits in the wave's in-order memory queue among the ring's loads: measured 1.5-3 us of
-    // a 155-us sweep at 16-KiB columns, 5-7 % at 8-KiB Float64 columns, 13 us of 170 with one store per 4 KiB (short columns).
-    double cst = 0.0;
-    int64_t ccst = -1;
-    int cslot = 0;
-    int64_t icol = col0, ccol = col0;  // issue / consume pointers: (column, unit within the column)
-    int ib = 0, cb = 0;
-    const int64_t T = ncol * nunit;
-    int64_t ileft = T, cleft = T;
-    double acc = 0.0;
-    auto issue = [&](VT(&b)[U]) {
-        const VT* pc = reinterpret_cast<const VT*>(A + icol * ld);
-        const int vb = ib * (U * kWave) + lane;
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int v = vb + u * kWave;
-            b[u] = __builtin_nontemporal_load(pc + (v < nvec ? v : nvec - 1));
-        }
-        if (++ib == nunit) {
-            ib = 0;
-            icol += stride;
-        }
-        --ileft;
-    };
+    PH_STAMP(1);
     auto consume = [&](const VT(&b)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -291,8 +312,6 @@ __device__ __forceinline__ void sweep_body_gen(
         --cleft;
     };
     if (T >= 2 * NB) {
-#pragma unroll
-        for (int d = 0; d < NB; ++d) issue(buf[d]);
         const int64_t groups = T / NB - 1;
         for (int64_t g = 0; g < groups; ++g) {
 #pragma unroll
@@ -301,10 +320,6 @@ __device__ __forceinline__ void sweep_body_gen(
                 issue(buf[d]);
             }
         }
-    } else {
-#pragma unroll
-        for (int d = 0; d < NB; ++d)
-            if (d < T) issue(buf[d]);
     }
     while (cleft > 0) {  // the last NB .. 2 NB - 1 units of the wave (or all of them, when there are fewer)
 #pragma unroll
@@ -315,6 +330,7 @@ __device__ __forceinline__ void sweep_body_gen(
         }
     }
     if (ccst >= 0) cvec[ccst] = cst;  // (the columns staged since the last full store)
+    PH_STAMP(5);
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;
@@ -370,6 +386,7 @@ __device__ __forceinline__ void sweep_body_ph(
     constexpr int NW = kSweepThreads / kWave;
     static_assert((NB - 1) * U < 64, "the ring must fit the 6-bit vmcnt");
     if (st->done & skipmask) return;
+    PH_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nvec = Mv / VEC;
@@ -387,16 +404,17 @@ __device__ __forceinline__ void sweep_body_ph(
     };
     // the image of stage ph: pairs of rows (16-byte loads; a pair is one 16-byte LDS slot in either layout), 16 loads in flight per
     // thread -- one by one a stage of 16 384 rows is 64 dependent trips per thread, and the stage's barrier waits for all of them
-    auto stage_image = [&](int ph, double& n2) {
+    auto stage_image = [&](int ph, double& n2, auto rp) {
         const int k0 = ph * KP, Mst = units_of(ph) * UR;
-        const int Mend = (ph == 0 && Mv > Mst) ? Mv : Mst;  // (stage 0 also sums ||r||^2 over ALL rows, in a fixed per-thread order)
-        constexpr int RP = 16;
+        const int Mend = Mst;  // (||r||^2 grows stage by stage: thread t adds the pairs of rows with (m / 2) mod 256 = t in increasing order)
+        constexpr int RP = decltype(rp)::value;
         for (int m0 = 2 * tid; m0 < Mend; m0 += RP * 2 * kSweepThreads) {
             f64x2 rv[RP];
 #pragma unroll
             for (int q = 0; q < RP; ++q) {
                 const int m = k0 + m0 + q * 2 * kSweepThreads;  // (even: Mv, KP and k0 are)
-                rv[q] = m + 1 < Mv ? *reinterpret_cast<const f64x2*>(r + m) : f64x2{m < Mv ? r[m] : 0.0, 0.0};
+                const f64x2 x = *reinterpret_cast<const f64x2*>(r + (m < Mv ? m : Mv - 2));  // (no load under a branch: they all go out together)
+                rv[q] = m < Mv ? x : f64x2{0.0, 0.0};
             }
 #pragma unroll
             for (int q = 0; q < RP; ++q) {
@@ -407,20 +425,6 @@ __device__ __forceinline__ void sweep_body_ph(
             }
         }
     };
-    {
-        double n2 = 0.0;
-        stage_image(0, n2);
-        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
-        __syncthreads();
-        if (lane == 0) red[wave] = n2;
-        __syncthreads();
-        n2 = (red[0] + red[1]) + (red[2] + red[3]);
-        if (bid == 0 && tid == 0) st->rnorm2 = n2;
-        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
-            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-            return;
-        }
-    }
     double bestv = -1.0;
     int besti = 0x7fffffff;
     VT buf[NB][U];
@@ -469,14 +473,44 @@ __device__ __forceinline__ void sweep_body_ph(
     double cst = 0.0;  // c values staged 64 to a store instruction (see sweep_body_gen)
     int64_t ccst = -1;
     int cslot = 0;
+    // the ring's first loads go out before the first image is staged (see sweep_body_gen)
 #pragma unroll
     for (int d = 0; d < NB; ++d) issue(buf[d], ms[d], mb[d]);
+    // ||r||^2 is complete when the LAST stage's image has been read (every stage adds its rows: no stage reads rows it does not
+    // keep -- the whole residual in the first stage was 2 of its 4 trips, ~4.5 us of a 165-us launch at M = 32768); the eps test
+    // waits for it.  A sweep that turns out not to be wanted has then run all but its last stage: nobody looks at its results.
+    double n2 = 0.0;
+    auto norm_done = [&]() -> bool {  // (after the image's stores, before the barrier that publishes it)
+        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        if (lane == 0) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return true;
+        }
+        return false;
+    };
+    stage_image(0, n2, std::integral_constant<int, 16>());
+    if (nph == 1) {
+        if (norm_done()) return;
+    } else {
+        __syncthreads();
+    }
+    PH_STAMP(1);
     for (int ph = 0; ph < nph; ++ph) {
         if (ph > 0) {
+            PH_STAMP(2);
             lds_barrier();  // everyone is done with the previous image (the ring's loads stay in flight)
-            double dummy = 0.0;
-            stage_image(ph, dummy);
-            __syncthreads();
+            PH_STAMP(3);
+            stage_image(ph, n2, std::integral_constant<int, 16>());
+            if (ph + 1 == nph) {
+                if (norm_done()) return;
+            } else {
+                __syncthreads();
+            }
+            PH_STAMP(4);
         }
         const int nunit = units_of(ph);
         const bool lastph = ph + 1 == nph;
@@ -531,6 +565,7 @@ __device__ __forceinline__ void sweep_body_ph(
         }
     }
     if (ccst >= 0) cvec[ccst] = cst;
+    PH_STAMP(5);
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;

@@ -60,10 +60,12 @@ def test_sweep_any_shape(cs, shape, dtype):
     d.close()
 
 
-def test_sweep_stops_on_a_small_residual_in_every_phase_layout(cs, oracle):
-    """the driver's residual test norm(r) >= eps (src/matchingpursuit.jl:79) is evaluated by the sweep's prologue over ALL rows, also
-    when only the first phase's rows sit in the LDS: an eps above / below ||b|| stops at once / runs"""
-    M, N = 32768, 64
+@pytest.mark.parametrize("M", [32768, 40002, 20500])
+def test_sweep_stops_on_a_small_residual_in_every_phase_layout(cs, oracle, M):
+    """the driver's residual test norm(r) >= eps (src/matchingpursuit.jl:79) is the sweep's, over ALL rows, also when the residual is
+    staged in phases (||r||^2 is then complete with the last stage's image): an eps above / below ||b|| stops at once / runs.
+    Two full stages, three ragged ones, a second stage that is nearly empty."""
+    N = 64
     A = gaussian(M, N, np.float32, 11)
     b = planted(A, 4, 3)
     d = cs.Dictionary(A)
