@@ -625,24 +625,6 @@ __device__ __forceinline__ void sweep_body_short(
     double* redv = red + 8;
     int* redi = reinterpret_cast<int*>(redv + 4 * NW);
     const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
-    {
-        double n2 = 0.0;
-        for (int m = tid; m < KP; m += kSweepThreads) {
-            const double rv = m < Mv ? r[m] : 0.0;
-            lds[r_slot<VEC>(m)] = rv;
-            n2 = fma(rv, rv, n2);
-        }
-        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
-        __syncthreads();
-        if (lane == 0) red[wave] = n2;
-        __syncthreads();
-        n2 = (red[0] + red[1]) + (red[2] + red[3]);
-        if (bid == 0 && tid == 0) st->rnorm2 = n2;
-        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
-            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-            return;
-        }
-    }
     const int64_t ngrp = (N + CU_ - 1) / CU_;
     const int64_t g0 = (int64_t)bid * NW + wave, stride = (int64_t)nblk * NW;
     const int64_t T = g0 < ngrp ? (ngrp - 1 - g0) / stride + 1 : 0;
@@ -667,6 +649,28 @@ __device__ __forceinline__ void sweep_body_short(
         ig += stride;
         --ileft;
     };
+    // the ring's first loads go out before the residual image is staged (see sweep_body_gen; past the wave's last group `issue`
+    // re-reads column N - 1: no load sits under a branch)
+#pragma unroll
+    for (int d = 0; d < NB; ++d) issue(buf[d]);
+    {
+        double n2 = 0.0;
+        for (int m = tid; m < KP; m += kSweepThreads) {
+            const double rv = m < Mv ? r[m] : 0.0;
+            lds[r_slot<VEC>(m)] = rv;
+            n2 = fma(rv, rv, n2);
+        }
+        for (int s = 32; s >= 1; s >>= 1) n2 += __shfl_xor(n2, s, kWave);
+        __syncthreads();
+        if (lane == 0) red[wave] = n2;
+        __syncthreads();
+        n2 = (red[0] + red[1]) + (red[2] + red[3]);
+        if (bid == 0 && tid == 0) st->rnorm2 = n2;
+        if (check_eps && !(sqrt(n2) >= eps)) {  // norm(residual!) >= eps || break  (:79,:132)
+            if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+            return;
+        }
+    }
     auto consume = [&](const VT(&b)[U]) {
         double a[CU_];
 #pragma unroll
@@ -729,8 +733,6 @@ __device__ __forceinline__ void sweep_body_short(
         --cleft;
     };
     if (T >= 2 * NB) {
-#pragma unroll
-        for (int d = 0; d < NB; ++d) issue(buf[d]);
         const int64_t groups = T / NB - 1;
         for (int64_t g = 0; g < groups; ++g) {
 #pragma unroll
@@ -739,10 +741,6 @@ __device__ __forceinline__ void sweep_body_short(
                 issue(buf[d]);
             }
         }
-    } else {
-#pragma unroll
-        for (int d = 0; d < NB; ++d)
-            if (d < T) issue(buf[d]);
     }
     while (cleft > 0) {
 #pragma unroll

@@ -1,6 +1,6 @@
 set -u
 L=compressedsensing.jl_amd/csrc
-O=gpurun_out/r06/ab_last.txt
+O=gpurun_out/r06/ab_blocked.txt
 mkdir -p gpurun_out/r06
 cp $L/libcsmp.so /tmp/new.so
 : > $O
@@ -15,7 +15,7 @@ for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('bench', d['value'], d['roofline']['frac'], d['roofline'].get('avg_launch_us'), d['roofline'].get('launch_duration_us'))
 " >> $O 2>&1
-    python tools/sweep_shapes.py --M 20480,24576,32768,49152 --no-check 2>/dev/null | python -c "
+    python tools/sweep_shapes.py --M 256,512,1000 --no-check 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     l=l.strip()
