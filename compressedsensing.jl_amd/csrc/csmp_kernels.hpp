@@ -138,6 +138,9 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 // look-ahead loads it is supposed to overlap
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // tools/probes/ph_trace.hip: wall-clock stamps (100 MHz) of a sweep workgroup's waves; nothing in the product build
+#ifndef CSMP_C_INDEX
+#define CSMP_C_INDEX(c) (c)  // (tools/probes/ph_trace.hip redirects the short body's c stores)
+#endif
 #ifdef CSMP_PH_TRACE
 __device__ unsigned long long* g_ph_trace;
 #define PH_STAMP(slot) do { if ((threadIdx.x & 63) == 0) g_ph_trace[((size_t)bid * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); } while (0)
@@ -618,6 +621,7 @@ __device__ __forceinline__ void sweep_body_short(
     static_assert(CPU == 2 || CPU == 4, "two or four columns per transposing reduction");
     static_assert(U % NCH == 0 && CU_ % CPU == 0 && SETS >= 1, "whole columns per unit, whole sets per unit");
     if (st->done & skipmask) return;
+    PH_STAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nvec = Mv / VEC;
@@ -633,9 +637,23 @@ __device__ __forceinline__ void sweep_body_short(
     int besti = 0x7fffffff;
     VT buf[NB][U];
     constexpr int LW = kWave / CPU, SLOTS = LW / SETS;
-    double cst = 0.0;
-    int64_t ccst = -1;
-    int cslot = 0;
+    constexpr int KS = 6;  // registers of staged c values per lane: the wave stores every 64 KS columns (see `flush` below)
+    double cst[KS];
+    int ccst[KS];
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+        cst[k] = 0.0;
+        ccst[k] = -1;
+    }
+    int cslot = 0, kslot = 0;
+    auto flush = [&]() {
+#pragma unroll
+        for (int k = 0; k < KS; ++k) {
+            if (ccst[k] >= 0) cvec[CSMP_C_INDEX(ccst[k])] = cst[k];
+            ccst[k] = -1;
+        }
+        kslot = 0;
+    };
     int64_t ig = g0, cg = g0;
     int64_t ileft = T, cleft = T;
     auto issue = [&](VT(&b)[U]) {
@@ -671,6 +689,7 @@ __device__ __forceinline__ void sweep_body_short(
             return;
         }
     }
+    PH_STAMP(1);
     auto consume = [&](const VT(&b)[U]) {
         double a[CU_];
 #pragma unroll
@@ -720,13 +739,19 @@ __device__ __forceinline__ void sweep_body_short(
                 double v = vs[0];
                 if constexpr (SETS == 2) v = set == 1 ? vs[1] : vs[0];
                 const int64_t col = cg * CU_ + set * CPU + q;
-                cst = v;
-                ccst = col < N ? col : -1;
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    if (k == kslot) {
+                        cst[k] = v;
+                        ccst[k] = col < N ? (int)col : -1;
+                    }
             }
+            // 64 KS columns per lane set, then KS stores back to back: c writes that trickle out among the reads cost the DRAM far
+            // more than their bytes (M = 256 Float32, 8 MiB of c beside 1 GiB of A: 168 us, 159 us with the stores aimed at one
+            // L2-resident line -- tools/probes/ph_trace.hip); a wave of the 1-GiB table keeps ALL its columns until its end
             if (++cslot == SLOTS) {
-                if (ccst >= 0) cvec[ccst] = cst;
-                ccst = -1;
                 cslot = 0;
+                if (++kslot == KS) flush();
             }
         }
         cg += stride;
@@ -750,7 +775,8 @@ __device__ __forceinline__ void sweep_body_short(
             if (ileft > 0) issue(buf[d]);
         }
     }
-    if (ccst >= 0) cvec[ccst] = cst;
+    flush();
+    PH_STAMP(5);
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;

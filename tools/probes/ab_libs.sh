@@ -1,6 +1,6 @@
 set -u
 L=compressedsensing.jl_amd/csrc
-O=gpurun_out/r06/ab_blocked.txt
+O=gpurun_out/r06/ab_defer.txt
 mkdir -p gpurun_out/r06
 cp $L/libcsmp.so /tmp/new.so
 : > $O

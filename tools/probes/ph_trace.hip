@@ -41,7 +41,7 @@ int main() {
     int* pidx;
     DevState* st;
     unsigned long long* tr;
-    const int maxw = 4096;
+    const int maxw = 8192;
     CK(hipMalloc(&A, bytes));
     CK(hipMalloc(&r, 65536 * 8));
     CK(hipMalloc(&c, 1 << 20));
@@ -99,6 +99,27 @@ int main() {
         CK(hipMemcpy(t.data(), tr, (size_t)maxw * 64, hipMemcpyDeviceToHost));
         printf("k_sweep_gen<float, 16, 2> M = 18432, N = 14560, 206 workgroups, one image: %.1f us (events)\n", ms * 1e3);
         report("one image", t, grid * 4, {0, 1, 5});
+        diffs("image + norm (0 -> 1)", t, grid * 4, 0, 1);
+        diffs("stream (1 -> 5)", t, grid * 4, 1, 5);
+    }
+    {
+        const int M = 256, N = 1048576, grid = 768, KP = 256;
+        auto kern = k_sweep_short<float, 1, 4>;
+        const size_t lds = sweep_gen_lds_bytes(KP);
+        float ms = 0;
+        double* cbig;
+        CK(hipMalloc(&cbig, (size_t)N * 8));
+        for (int it = 0; it < 6; ++it) {
+            CK(hipMemset(tr, 0, (size_t)maxw * 64));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, A, (int64_t)M, M, (int64_t)N, r, cbig, pval, pidx, st, 0.0, 0, 0, KP);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        CK(hipMemcpy(t.data(), tr, (size_t)maxw * 64, hipMemcpyDeviceToHost));
+        printf("k_sweep_short<float, 1, 4> M = 256, N = 1048576, 768 workgroups: %.1f us (events)\n", ms * 1e3);
+        report("short columns", t, grid * 4, {0, 1, 5});
         diffs("image + norm (0 -> 1)", t, grid * 4, 0, 1);
         diffs("stream (1 -> 5)", t, grid * 4, 1, 5);
     }
