@@ -843,7 +843,7 @@ __device__ __forceinline__ void sweep_body_dyn(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
     double eps, int check_eps, int skipmask, const int bid, const int nblk, const int KP, unsigned* __restrict__ claim,
-    unsigned* __restrict__ claim_next, const int npools, double* lds) {
+    unsigned* __restrict__ claim_next, const int npools_div, double* lds) {
     using VT = typename Vec<TA>::type;
     constexpr int VEC = Vec<TA>::n;
     constexpr int ROWS = kWave * VEC;
@@ -854,6 +854,7 @@ __device__ __forceinline__ void sweep_body_dyn(
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = nblk;  // pools: one per workgroup
+    const int npools = npools_div & 0xffff, dyn_div = npools_div >> 16;  // (dyn_div >= 2: only the last 1 / dyn_div of a pool is claimed)
     if (bid == 0 && wave == NW)  // (before any way out)
         for (int p = lane; p < P; p += kWave) claim_next[p * kClaimStride] = 0u;
     if (st->done & skipmask) return;
@@ -911,15 +912,28 @@ __device__ __forceinline__ void sweep_body_dyn(
         int pcur = bid, tried = 0;
         unsigned g0 = 0, g1 = 0;
         int p0, p1;
+        // the STATIC head of a pool: its first groups go to the pool's own workgroup without a claim (no atomics, the columns the
+        // static split would give it); only the last 1 / dyn_div of every pool -- at least two groups -- is claimed and can be stolen
+        auto head_of = [&](int pp) -> int64_t {
+            const int64_t cnt = NG > pp ? (NG - pp + P - 1) / P : 0;
+            if (dyn_div < 2) return 0;
+            const int64_t tail = cnt / dyn_div > 2 ? cnt / dyn_div : 2;
+            return cnt > tail ? cnt - tail : 0;
+        };
+        {
+            const int64_t head = head_of(bid);
+            for (int64_t gg = 0; gg < head; ++gg)
+                if (lane < NW) publish((int)(((gg * P + bid) << 2) + lane));
+        }
         auto ask = [&](unsigned& g, int& pp) {
             pp = pcur;
             if (lane == 0) g = __hip_atomic_fetch_add(claim + pcur * kClaimStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         };
         auto take = [&](unsigned& g, int& pp) {  // the answer of the older claim; then the next claim goes out in its place
-            const unsigned gg = (unsigned)__builtin_amdgcn_readfirstlane((int)g);
+            const int64_t gg = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)g) + head_of(pp);
             const int64_t cnt = NG > pp ? (NG - pp + P - 1) / P : 0;
-            if ((int64_t)gg < cnt) {
-                if (lane < NW) publish((int)((((int64_t)gg * P + pp) << 2) + lane));
+            if (gg < cnt) {
+                if (lane < NW) publish((int)(((gg * P + pp) << 2) + lane));
                 if (pp == pcur) tried = 0;
             } else if (pp == pcur) {
                 ++tried;
@@ -944,6 +958,8 @@ __device__ __forceinline__ void sweep_body_dyn(
     int icol = 0, ib = 0, ipos = 0;
     bool live = true;
     double acc = 0.0;
+    double cst = 0.0;  // c values staged 64 to a store instruction (see sweep_body_gen)
+    int ccst = -1, cslot = 0;
     lds_int_ptr myq = q + wave * Q;
     auto issue = [&](VT(&b)[U], int& c_, int& u_) {
         if (ib == 0 && live) {
@@ -993,7 +1009,15 @@ __device__ __forceinline__ void sweep_body_dyn(
         }
         if (u_ == nunit - 1) {  // the column's last unit
             acc = wave_xsum(acc);
-            if (lane == 0) cvec[c_] = acc;
+            if (lane == cslot) {
+                cst = acc;
+                ccst = c_;
+            }
+            if (++cslot == kWave) {
+                if (ccst >= 0) cvec[ccst] = cst;
+                ccst = -1;
+                cslot = 0;
+            }
             const double av = fabs(acc);
             if (better(av, c_, bestv, besti)) {
                 bestv = av;
@@ -1013,6 +1037,7 @@ __device__ __forceinline__ void sweep_body_dyn(
     }
 #pragma unroll
     for (int d = 0; d < NB; ++d) consume(buf[d], bc[d], bu[d]);
+    if (ccst >= 0) cvec[ccst] = cst;
     if (lane == 0) {
         redv[wave] = bestv;
         redi[wave] = besti;
@@ -1034,10 +1059,10 @@ template <typename TA, int U, int NB>
 __global__ __launch_bounds__(kSweepDynThreads) void k_sweep_dyn(
     const TA* __restrict__ A, int64_t ld, int Mv, int64_t N, const double* __restrict__ r,
     double* __restrict__ cvec, double* __restrict__ pval, int* __restrict__ pidx, DevState* st,
-    double eps, int check_eps, int skipmask, int KP, unsigned* __restrict__ claim, unsigned* __restrict__ claim_next, int npools) {
+    double eps, int check_eps, int skipmask, int KP, unsigned* __restrict__ claim, unsigned* __restrict__ claim_next, int npools_div) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     sweep_body_dyn<TA, U, NB>(A, ld, Mv, N, r, cvec, pval, pidx, st, eps, check_eps, skipmask, (int)blockIdx.x, (int)gridDim.x, KP, claim,
-                              claim_next, npools, lds);
+                              claim_next, npools_div, lds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1994,7 +2019,7 @@ struct TickSweep {
     double eps; int check_eps, skipmask, nblk, active;
     int KP;    // rows of the residual image
     int pcap;  // PH: columns per wave the LDS holds partial sums for (sweep_body_ph)
-    int npools;                    // DYN: pools a workgroup may claim from (its XCD's first)
+    int npools;                    // DYN: empty pools in a row that end a workgroup's search, | (dyn_div << 16): 1 / dyn_div of a pool is claimed
     unsigned *claim, *claim_next;  // DYN: the column pools of this sweep, and the set to zero for the slot's next one (sweep_body_dyn)
 };
 template <typename TA>

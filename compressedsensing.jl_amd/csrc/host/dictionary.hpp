@@ -35,7 +35,7 @@ static hipError_t sweep_launch_dyn(csmp_ctx* ctx, const double* r, double eps, i
     unsigned *cur, *next;
     claim_sets(s, cur, next);
     hipLaunchKernelGGL(kern, dim3(ctx->sweep_grid), dim3(kSweepDynThreads), ctx->sweep_lds, ctx->stream, (const TA*)ctx->dA, ctx->ld, ctx->Mv,
-                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next, ctx->claim_pools);
+                       ctx->N, r, cout ? cout : s.cvec, s.pval, s.pidx, s.st, eps, check_eps, skipmask, ctx->sweep_KP, cur, next, ctx->claim_pools | (ctx->tune_sweep_dyn << 16));
     return hipGetLastError();
 }
 // a residual longer than the LDS, staged in phases (k_sweep_ph)
@@ -196,7 +196,7 @@ static int configure_sweep(csmp_ctx* ctx) {
         ctx->sweep_KP = ((per + ur - 1) / ur) * ur;
     }
     // columns handed out at run time (sweep_body_dyn): only on csmp_tune(CSMP_TUNE_SWEEP_DYN, 1) -- measured 1-3 % slower than the static split
-    ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn == 1;
+    ctx->sweep_dyn = !ctx->sweep_ph && ctx->tune_sweep_dyn >= 1;
     if (ctx->sweep_grid > kClaimMaxWgs || std::max(ctx->tick_grid, ctx->tick_nblk) > kClaimMaxWgs) ctx->sweep_dyn = false;  // (one counter per workgroup)
     ctx->sweep_lds = ctx->sweep_ph ? sweep_ph_lds_bytes(ctx->sweep_KP, ctx->sweep_pcap)
                                    : ctx->sweep_dyn ? sweep_dyn_lds_bytes(ctx->sweep_KP) : sweep_gen_lds_bytes(ctx->sweep_KP);

@@ -185,7 +185,10 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");
             ctx->tune_sweep_lds_kib = (int)value;
             break;
-        case CSMP_TUNE_SWEEP_DYN: ctx->tune_sweep_dyn = value ? 1 : 0; break;
+        case CSMP_TUNE_SWEEP_DYN:
+            if (value < 0 || value > 64) return fail(ctx, CSMP_EINVAL, "csmp_tune: sweep_dyn must be 0 (static), 1 (every column claimed) or 2..64 (the last 1 / n of a workgroup's columns claimed)");
+            ctx->tune_sweep_dyn = (int)value;
+            break;
         case CSMP_TUNE_CLAIM_POOLS:
             if (value < 1 || value > 4096) return fail(ctx, CSMP_EINVAL, "csmp_tune: claim pools must be 1..4096");
             ctx->claim_pools = (int)value;

@@ -5,7 +5,7 @@ template <typename TA>
 static TickSweep<TA> tick_sweep_params(csmp_ctx* ctx, Solver& s, double eps, int check_eps, int skipmask, int nblk, int active) {
     TickSweep<TA> p;
     p.claim = p.claim_next = nullptr;
-    p.npools = ctx->claim_pools;
+    p.npools = ctx->claim_pools | (ctx->tune_sweep_dyn << 16);
     if (active && ctx->sweep_dyn) claim_sets(s, p.claim, p.claim_next);
     p.A = (const TA*)ctx->dA; p.ld = ctx->ld; p.Mv = ctx->Mv; p.N = ctx->N;
     p.r = s.r; p.cvec = s.cvec; p.pval = s.pval; p.pidx = s.pidx; p.st = s.st;

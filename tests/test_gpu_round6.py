@@ -79,8 +79,9 @@ def test_two_pipelines_device_buffers_and_repeated_calls(cs, oracle):
                                    (64, 3, np.float32), (4096, 130, np.float64), (12288, 205, np.float32)])
 def test_dynamic_sweep_gives_the_bits_of_the_static_one(cs, oracle, shape):
     """csmp_tune(sweep_dyn): a fifth wave per workgroup claims groups of four columns from per-workgroup counters and steals from its
-    neighbours' (csmp_kernels.hpp: sweep_body_dyn).  Opt-in (it measured 1-3 % slower than the static split); its c = A'r, arg-max
-    and whole solves are the static split's bit for bit.  N mod 4 != 0, fewer columns than waves, ragged M."""
+    neighbours' (csmp_kernels.hpp: sweep_body_dyn) -- all of them (1) or only the last 1 / n of every pool after a static head (n >= 2).
+    Opt-in (measured 0-3 % slower than the static split); its c = A'r, arg-max and whole solves are the static split's bit for bit.
+    N mod 4 != 0, fewer columns than waves, ragged M."""
     M, N, dtype = shape
     g = np.random.default_rng(M + N)
     A = g.standard_normal((M, N))
@@ -91,20 +92,18 @@ def test_dynamic_sweep_gives_the_bits_of_the_static_one(cs, oracle, shape):
     B = np.asfortranarray(g.standard_normal((M, 4)))
     eps = 1e-12
     res = {}
-    for mode in (0, 1):
+    for mode in (0, 1, 8):  # the static split; every column claimed; a static head and the last eighth of every pool claimed
         d.ctx.tune("sweep_dyn", mode)
         cfg = d.ctx.sweep_config()
-        assert cfg["dynamic"] == (mode if cfg["workgroups"] <= 512 and cfg["tick_workgroups"] <= 512 else 0), cfg
+        assert cfg["dynamic"] == ((1 if mode else 0) if cfg["workgroups"] <= 512 and cfg["tick_workgroups"] <= 512 else 0), cfg
         sw = [d.ctx.sweep(B[:, 0], topk=1) for _ in range(3)]  # (three launches: the two counter sets take turns)
         for t in sw[1:]:
             assert all(np.array_equal(a, b) for a, b in zip(sw[0], t))
         res[mode] = (sw[0], d.ctx.omp_batch(B, k, eps), d.ctx.omp(B[:, 1], k, eps))
-    for a, b in zip(res[0][0], res[1][0]):
-        assert np.array_equal(a, b)
-    for a, b in zip(res[0][1], res[1][1]):
-        assert np.array_equal(a, b)
-    for a, b in zip(res[0][2], res[1][2]):
-        assert np.array_equal(a, b)
+    for mode in (1, 8):
+        for part in range(3):
+            for a, b in zip(res[0][part], res[mode][part]):
+                assert np.array_equal(a, b), (mode, part)
     ref = np.abs(A.astype(np.float64).T @ B[:, 0])
     assert np.allclose(res[1][0][0], ref, rtol=0, atol=4e-14 * np.linalg.norm(B[:, 0]))
     assert int(res[1][0][1][0]) == int(np.argmax(ref))

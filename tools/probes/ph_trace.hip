@@ -123,5 +123,24 @@ int main() {
         diffs("image + norm (0 -> 1)", t, grid * 4, 0, 1);
         diffs("stream (1 -> 5)", t, grid * 4, 1, 5);
     }
+    for (int grid : {192, 176, 256}) {
+        const int M = 4096, N = 65536, KP = 4096;
+        auto kern = k_sweep_gen<float, 16, 2>;
+        const size_t lds = sweep_gen_lds_bytes(KP);
+        float ms = 0;
+        for (int it = 0; it < 6; ++it) {
+            CK(hipMemset(tr, 0, (size_t)maxw * 64));
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, 0, A, (int64_t)M, M, (int64_t)N, r, c, pval, pidx, st, 0.0, 0, 0, KP);
+            CK(hipEventRecord(e1));
+            CK(hipDeviceSynchronize());
+            CK(hipEventElapsedTime(&ms, e0, e1));
+        }
+        CK(hipMemcpy(t.data(), tr, (size_t)maxw * 64, hipMemcpyDeviceToHost));
+        printf("k_sweep_gen<float, 16, 2> M = 4096, N = 65536 (the headline's sweep), %d workgroups: %.1f us (events)\n", grid, ms * 1e3);
+        report("headline shape", t, grid * 4, {0, 1, 5});
+        diffs("image + norm (0 -> 1)", t, grid * 4, 0, 1);
+        diffs("stream (1 -> 5)", t, grid * 4, 1, 5);
+    }
     return 0;
 }
