@@ -1187,7 +1187,7 @@ def main():
         duration_s = max(sweep_ms / max(sweeps, 1) - bracket_ms, 0.0) / 1e3  # one launch, start to end
         two = window["streams"] == 2 and window["launches"] > 0
         if two:
-            # Two pipelines side by side (csmp_omp_batch from six signals on): the sweep launches of the two streams OVERLAP -- while one
+            # Two pipelines side by side (csmp_omp_batch from two signals on): the sweep launches of the two streams OVERLAP -- while one
             # launch runs, the other pipeline's launch moves its bytes too, so bytes / (one launch's duration) is not a bandwidth.
             # The launches are priced as one window instead: all sweep launches from the first to the last timed one on each stream,
             # over the time from the earliest start event to the latest end event (HIP events on both streams, one clock).

@@ -191,7 +191,7 @@ struct csmp_ctx {
     int tune_pair_lds_kib = 0;  // csmp_tune: dynamic LDS (KiB) of the ticks of two pipelines side by side, 0 = kPairLdsKiB (one workgroup per CU)
     int tune_pair_split = 0;    // csmp_tune: 1 = two pipelines side by side keep the fused tick (one launch), default: append stages and sweep in two launches
     int tune_fail_alloc = 0;    // csmp_tune (test hook): the n-th device allocation of a solver slot from now fails (dmalloc)
-    int tune_pipelines = 0;  // csmp_tune: 1 = csmp_omp_batch keeps ONE pipeline of three signals (default: two side by side from six signals on)
+    int tune_pipelines = 0;  // csmp_tune: 1 = csmp_omp_batch keeps ONE pipeline of three signals (default: two side by side from two signals on)
     int claim_pools = 8;     // counters a workgroup of the dynamic sweep finds empty in a row before it stops (its own, then the following workgroups')
     int tune_rebuild_direct = 0;  // csmp_tune: the oblivious start's Q'A pass reads its directions from L2 (k_fr_rebuild) instead of the LDS
     int tune_swap_refuse = 0;  // csmp_tune: OMPR's inverse-Gram exchanges fail their guard (tests walk the fallback to the QR path)

@@ -339,11 +339,12 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     }
     int64_t sgn = 0;
     // TWO pipelines (omp only): the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair).
-    // From six signals on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one.
+    // From two signals on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one.
+    constexpr int64_t kPairMinSignals = 2;
     csmp_ctx* tw = nullptr;
     // (omp only.  Forward regression's sweep holds two or three LDS images -- one workgroup per CU as it is -- and two pipelines of
     // k_tick_fr measured no gain: 5.99e3 against 5.96e3 atoms/s)
-    if (pipe && !isfr && nsig >= 6 && ctx->tune_pipelines != 1) {
+    if (pipe && !isfr && nsig >= kPairMinSignals && ctx->tune_pipelines != 1) {
         rc = twins_ensure(ctx, 1);
         if (rc == CSMP_OK) {
             tw = ctx->twins[0];
@@ -394,27 +395,25 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             return r2;
         };
         if (tw && rc == CSMP_OK) {
-            // this context takes the first half of the signals, the twin the second; each half goes through its pipeline in groups of
-            // three or two (10 signals: 3 + 3 + 2 + 2 -- never a lone signal beside a full triple), round j runs group j of each
-            const int64_t nA = (nsig + 1) / 2, nB = nsig - nA;
-            auto groups_of = [](int64_t lo, int64_t n) {
-                std::vector<std::pair<int64_t, int>> g;
-                if (n <= 0) return g;
-                const int64_t r = (n + 2) / 3, base = n / r, extra = n % r;
-                for (int64_t q = 0, at = lo; q < r; ++q) {
-                    const int c = (int)(base + (q < extra ? 1 : 0));
-                    g.push_back({at, c});
-                    at += c;
-                }
-                return g;
-            };
-            const auto gA = groups_of(0, nA), gB = groups_of(nA, nB);
-            for (size_t j = 0; j < gA.size() && rc == CSMP_OK; ++j) {
+            // rounds of 3 + 3 signals (this context's pipeline + the twin's), then the remainder in rounds of 1 + 1 and a last lone
+            // signal: measured on the 1-GiB dictionary, atoms/s of a whole batch -- 3 + 3: 6680, 1 + 1: 6690, 2 + 2: 6486, and the
+            // rounds whose pipelines hold different numbers 3 + 2: 6340, 2 + 1: 6332 (one pipeline of three: 6306, a lone signal:
+            // 5830; tools/probes/few_signals.sh).  Two streams with a sweep ready each keep the HBM busy; what costs is a round in
+            // which one stream's ticks have sweeps the other's have not.
+            struct Round { int64_t fa; int ca; int64_t fb; int cb; };
+            std::vector<Round> rounds;
+            {
+                int64_t at = 0;
+                for (; nsig - at >= 6; at += 6) rounds.push_back({at, 3, at + 3, 3});
+                for (; nsig - at >= 2; at += 2) rounds.push_back({at, 1, at + 1, 1});
+                if (at < nsig) rounds.push_back({at, 1, 0, 0});
+            }
+            for (size_t j = 0; j < rounds.size() && rc == CSMP_OK; ++j) {
                 bool pa[3], pb[3];
-                const int64_t fa = gA[j].first, fb = j < gB.size() ? gB[j].first : 0;
-                rc = init_triple(ctx, fa, fa + gA[j].second, pa);
-                const bool hasb = j < gB.size();
-                if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, fb + gB[j].second, pb);
+                const int64_t fa = rounds[j].fa, fb = rounds[j].fb;
+                const bool hasb = rounds[j].cb > 0;
+                rc = init_triple(ctx, fa, fa + rounds[j].ca, pa);
+                if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, fb + rounds[j].cb, pb);
                 if (rc != CSMP_OK) break;
                 if (hasb)
                     rc = ctx->dtype == CSMP_F32 ? omp_ticks_pair<float>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid)

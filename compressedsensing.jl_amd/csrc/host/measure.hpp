@@ -15,7 +15,7 @@ extern "C" int csmp_profile_enable(csmp_ctx* ctx, int on) {
     return CSMP_OK;
 }
 
-// The timed launches as ONE window.  csmp_omp_batch runs two pipelines side by side from six signals on (host/omp.hpp): their
+// The timed launches as ONE window.  csmp_omp_batch runs two pipelines side by side from two signals on (host/forward.hpp, host/omp.hpp): their
 // sweep launches overlap, so a launch's own duration says nothing about the bandwidth -- the bytes of BOTH streams' launches move
 // during it.  This call reports, over this context and its twin: the launches from the first to the last sampled one on each stream
 // (all of them, sampled or not), the time from the earliest of their start events to the latest of their end events (one clock:

@@ -26,15 +26,16 @@ def signals(cs, A, k, nsig, seed):
 @pytest.mark.parametrize("cfg", [(256, 1024, 12, 6, np.float64), (256, 1024, 12, 7, np.float64), (1000, 3000, 9, 13, np.float32),
                                  (4096, 2500, 10, 12, np.float32), (2048, 1500, 8, 8, np.float64), (300, 700, 5, 17, np.float32)])
 def test_two_pipelines_give_the_bits_of_one(cs, oracle, cfg):
-    """From six signals on csmp_omp_batch runs the second half of the triples on a twin context beside the first (host/omp.hpp:
-    omp_ticks_pair).  Group sizes: both pipelines full (6, 12), a lone signal on the twin (7), a ragged last round (8, 13, 17)."""
+    """csmp_omp_batch runs two pipelines side by side, the second on a twin context (host/omp.hpp: omp_ticks_pair), in rounds of 3 + 3
+    signals, then 1 + 1, then a lone one (host/forward.hpp).  Whole rounds only (6, 12), a lone last signal (7, 13), rounds of 1 + 1
+    (8), both (17)."""
     n, m, k, nsig, dtype = cfg
     eps = float(np.finfo(dtype).eps)
     A, _, _ = cs.sparse_data(n=n, m=m, k=k, rng=n + m + nsig, dtype=dtype)
     d = cs.Dictionary(A)
     B = signals(cs, A, k, nsig, nsig)
     out = {}
-    for mode in (1, 2, 0):  # one pipeline; two; the automatic choice (two from six signals on)
+    for mode in (1, 2, 0):  # one pipeline; two; the automatic choice (two)
         d.ctx.tune("pipelines", mode)
         out[mode] = d.ctx.omp_batch(B, k, eps)
     d.ctx.tune("pair_split", 1)  # two pipelines with the fused tick (one launch per tick under the large LDS request)

@@ -1,7 +1,7 @@
 """Bandwidth of OVERLAPPING launches from a rocprofv3 kernel trace (the per-dispatch start / end timestamps of
 `rocprofv3 --kernel-trace --output-format csv`): for the dispatches whose kernel name contains <substr>, the number of launches, the
 mean duration of one, the time during which AT LEAST ONE of them runs (the union of their intervals), and algorithmic bytes per
-launch x launches / that time.  csmp_omp_batch runs two pipelines side by side from six signals on: two sweep launches overlap,
+launch x launches / that time.  csmp_omp_batch runs two pipelines side by side from two signals on: two sweep launches overlap,
 and `bytes / mean duration` of the stats table is then no bandwidth -- this is the figure the kernel trace itself supports, and the
 one bench.py's `roofline.achieved` (HIP events on both streams, csmp_profile_window) must agree with.
 
