@@ -137,7 +137,7 @@ while time.time() - t0 < budget:
                             cmp("sp_" + name, Ds.ctx.sp(B[:, 0], k, 1e-12), sref[0], cfg)
                     finally:
                         Ds.close()
-        cols = np.sort(rng.choice(N, min(3 * k, M // 2), replace=False))
+        cols = np.sort(rng.choice(N, min(3 * k, M // 2, N), replace=False))
         got = D.ctx.lstsq(cols, B[:, 0])
         ref = oc.lstsq_cols(A, cols, B[:, 0])
         cmp("lstsq", (cols, got), (cols, ref), cfg)
