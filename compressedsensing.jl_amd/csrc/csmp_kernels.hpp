@@ -817,6 +817,10 @@ __global__ __launch_bounds__(kSweepThreads) void k_sweep_short(
 //            that is empty, STEALS from the following workgroups' (b + 1, b + 2, ...: eight consecutive block ids sit on eight
 //            XCDs under the round-robin dispatch, and the XCDs differ by several percent in speed) until npools - 1 of them in
 //            a row had nothing left.  The N mod 4 last columns go to workgroup 0 up front.
+//            With dyn_div >= 2 (csmp_tune sweep_dyn = n) a pool has a STATIC head: its first groups go to its own workgroup
+//            without a claim, only the last 1 / dyn_div of it (at least two groups) is claimed and can be stolen.  Measured level
+//            with the static split at 1/16 (the claims then cost nothing, and the launch is no shorter: its tail is the memory
+//            system draining, not work a free wave could take over -- DESIGN.md section 0.1).
 //   claimer  two claims in flight (agent-scope atomic adds: ~1.1-1.3 us each beside the stream), each published as ONE column
 //            per streaming wave into that wave's ring of kClaimQ slots in the LDS -- single producer, single consumer, no LDS
 //            atomics; a slot is EMPTY, a column index, or END.
