@@ -271,8 +271,7 @@ __device__ __forceinline__ double wave_col_dot(const TA* __restrict__ col, int M
         }
     }
     double acc = acc0 + acc1;
-    for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
-    return acc;
+    return wave_xsum(acc);  // (the shuffle butterfly's pairs in its order, without the LDS trips)
 }
 
 // dynamic LDS: the residual image, nchunk * 64 * VEC Float64 (32 KiB at M = 4096: four workgroups per CU)
@@ -557,11 +556,16 @@ __global__ __launch_bounds__(256, (b_wgs<TA, NI>())) void k_b_append(
                         }
                     }
                     if (++tc == nchunk) {
+                        {
+                            // ONE transposing butterfly for the four columns (csmp_kernels.hpp, k_sweep_short): after the xor-32 and
+                            // xor-16 steps row q of the wave holds column q's partial sums, the in-row steps finish all four -- per
+                            // column the pairs and their order are the plain butterfly's, so g has the same bits
+                            double v = xs16(xs32(acc[0], acc[2]), xs32(acc[1], acc[3]));
+                            v = row_xsum(v);
+                            const int c = lane >> 4;
+                            if ((lane & 15) == 0 && c0c + c < j) gv[c0c + c] = v;
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            for (int sft = 32; sft >= 1; sft >>= 1) acc[c] += shx(acc[c], sft);
-                            if (lane == 0 && c0c + c < j) gv[c0c + c] = acc[c];
-                            acc[c] = 0.0;
+                            for (int cc = 0; cc < 4; ++cc) acc[cc] = 0.0;
                         }
                         tc = 0;
                         c0c += 16;

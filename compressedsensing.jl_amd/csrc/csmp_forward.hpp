@@ -67,25 +67,6 @@ __device__ __forceinline__ void fr_sweep_body(
     const int unsel = (NQ >= 1 && unmark) ? *unmark : -1;
     const double* q1 = nullptr;
     if constexpr (NQ >= 1) q1 = q1in ? q1in : (nsel > 0 ? Q + (int64_t)(nsel - 1) * ldq : nullptr);
-    double n2 = 0.0;
-    for (int m = tid; m < Mlds; m += kSweepThreads) {
-        const double v = (m < Mv) ? r[m] : 0.0;
-        lds[r_slot<VEC>(m)] = v;
-        n2 = fma(v, v, n2);
-        if constexpr (NQ >= 1) qim[r_slot<VEC>(m)] = (q1 && m < Mv) ? q1[m] : 0.0;
-        if constexpr (NQ == 2) qim2[r_slot<VEC>(m)] = (q2in && m < Mv) ? q2in[m] : 0.0;
-    }
-    n2 = block_sum256(n2, red);
-    if (bid == 0 && tid == 0) st->rnorm2 = n2;
-    if (!update_only && !(sqrt(n2) > max_eps)) {  // normr > max_ε || return false   (src/forward.jl:60-61)
-        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
-        return;
-    }
-    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
-    const f64x2* qs = reinterpret_cast<const f64x2*>(qim);
-    const f64x2* qs2 = reinterpret_cast<const f64x2*>(qim2);
-    double bestv = -1.0;  // a NaN score never wins a comparison
-    int besti = 0x7fffffff;
     const int64_t stride = (int64_t)nblk * NW;
     auto load_block = [&](VT* dst, int64_t c, int blk) {
         const VT* p = reinterpret_cast<const VT*>(A + c * ld) + lane + (int64_t)blk * U * kWave;
@@ -102,7 +83,58 @@ __device__ __forceinline__ void fr_sweep_body(
     int64_t col = (int64_t)bid * NW + wave;
     if (col >= N) col = -1;
     VT cur[U], nxt[U];
-    if (col >= 0) load_block(cur, col, 0);
+    if (col >= 0) load_block(cur, col, 0);  // (ahead of the images: the first trip to HBM and the images' trips to the L2 overlap)
+    // the images, eight rows per thread and image at a time (a rolled loop waits for every load in turn); ||r||^2 in the same
+    // per-thread order as before (rows tid, tid + 256, ...)
+    double n2 = 0.0;
+    {
+        constexpr int RP = 8;
+        for (int m0 = tid; m0 < Mlds; m0 += RP * kSweepThreads) {
+            double rv[RP], qv[NQ >= 1 ? RP : 1], qv2[NQ == 2 ? RP : 1];
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const int m = m0 + q * kSweepThreads;
+                const int mc = m < Mv ? m : Mv - 1;  // (no load under a branch)
+                rv[q] = r[mc];
+                if constexpr (NQ >= 1) qv[q] = q1 ? q1[mc] : 0.0;
+                if constexpr (NQ == 2) qv2[q] = q2in ? q2in[mc] : 0.0;
+            }
+#pragma unroll
+            for (int q = 0; q < RP; ++q) {
+                const int m = m0 + q * kSweepThreads;
+                if (m < Mlds) {
+                    const bool in = m < Mv;
+                    const double v = in ? rv[q] : 0.0;
+                    lds[r_slot<VEC>(m)] = v;
+                    n2 = fma(v, v, n2);
+                    if constexpr (NQ >= 1) qim[r_slot<VEC>(m)] = in ? qv[q] : 0.0;
+                    if constexpr (NQ == 2) qim2[r_slot<VEC>(m)] = in ? qv2[q] : 0.0;
+                }
+            }
+        }
+    }
+    n2 = block_sum256(n2, red);
+    if (bid == 0 && tid == 0) st->rnorm2 = n2;
+    if (!update_only && !(sqrt(n2) > max_eps)) {  // normr > max_ε || return false   (src/forward.jl:60-61)
+        if (bid == 0 && tid == 0) st->done |= STOP_EPS;
+        return;
+    }
+    const f64x2* rs = reinterpret_cast<const f64x2*>(lds);
+    const f64x2* qs = reinterpret_cast<const f64x2*>(qim);
+    const f64x2* qs2 = reinterpret_cast<const f64x2*>(qim2);
+    double bestv = -1.0;  // a NaN score never wins a comparison
+    int besti = 0x7fffffff;
+    // rho2 / d2 are STAGED like the product sweep's c: lane s keeps the wave's s-th finished column, 64 columns to a store
+    double srho = 0.0, sd2 = 0.0;
+    int scol = -1, cslot = 0;
+    auto flush = [&]() {
+        if (scol >= 0) {
+            if (NQ != 0 || scol == lastsel) rho2[scol] = srho;
+            if (!update_only) dvec[scol] = sd2;
+        }
+        scol = -1;
+        cslot = 0;
+    };
     while (col >= 0) {
         double rho_old = 0.0;
         if constexpr (!FIRST) rho_old = rho2[col];  // requested before the column's loads are consumed
@@ -168,11 +200,9 @@ __device__ __forceinline__ void fr_sweep_body(
 #pragma unroll
             for (int u = 0; u < U; ++u) cur[u] = nxt[u];
         }
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            acc += shx(acc, sft);
-            if constexpr (NQ != 0) acg += shx(acg, sft);
-            if constexpr (NQ == 2) acg2 += shx(acg2, sft);
-        }
+        acc = wave_xsum(acc);  // (the butterfly without LDS trips: the same pairs in the same order as the shuffle form)
+        if constexpr (NQ != 0) acg = wave_xsum(acg);
+        if constexpr (NQ == 2) acg2 = wave_xsum(acg2);
         // rescaling_j (src/forward.jl:108-113), one more row of Q'A per step; atoms of the support get
         // +Inf once, which makes their score c^2 / Inf = 0 for good (δ²[x.nzind] = 0, :80)
         double rho = rho_old;
@@ -183,11 +213,12 @@ __device__ __forceinline__ void fr_sweep_body(
         if constexpr (NQ >= 1)
             if ((int)col == unsel) rho = NQ == 2 ? acg2 * acg2 : acg * acg;
         const double d2 = acc * acc / rho;
-        if (lane == 0) {
-            if constexpr (NQ != 0) rho2[col] = rho;
-            else if ((int)col == lastsel) rho2[col] = rho;
-            if (!update_only) dvec[col] = d2;
+        if (lane == cslot) {
+            srho = rho;
+            sd2 = d2;
+            scol = (int)col;
         }
+        if (++cslot == kWave) flush();
         if (d2 > bestv) {
             bestv = d2;
             besti = (int)col;
@@ -195,6 +226,7 @@ __device__ __forceinline__ void fr_sweep_body(
         col += stride;
         if (col >= N) col = -1;
     }
+    flush();
     if ((lane & 15) == 0) {
         redv[wave * 4 + (lane >> 4)] = bestv;
         redi[wave * 4 + (lane >> 4)] = besti;
@@ -490,7 +522,7 @@ __global__ __launch_bounds__(256) void k_fr_colnorm2(const TA* __restrict__ A, i
         const double v = (double)a[m];
         acc = fma(v, v, acc);
     }
-    for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+    acc = wave_xsum(acc);
     if (lane == 0) out[col] = acc;
 }
 // the Q column appended last -> a vector of its own (a sweep takes it as its "residual"); zeros while the support is empty

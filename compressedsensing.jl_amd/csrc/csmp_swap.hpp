@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_swap_dots(const TA* __restrict__ A, int
     } else {
         for (int m = lane; m < M; m += 64) acc = fma((double)v[m], j == k ? (double)v[m] : b[m], acc);
     }
-    for (int sft = 32; sft >= 1; sft >>= 1) acc += shx(acc, sft);
+    acc = wave_xsum(acc);
     if (lane == 0) out[j] = acc;
 }
 
