@@ -58,7 +58,7 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
         // With TWO directions the three images leave room for one workgroup per CU only: four waves, and what hides the DRAM latency
         // is the loads each of them keeps in flight -- 16-chunk blocks on 15/16 of the CUs 175 us, 8-chunk blocks on all of them 187
         // (16 on all: 184, on 7/8: 176, on 3/4: 194; profiles/r05_bench_srr_kernel_stats.csv).
-        const int umax = nq == 2 ? 16 : 8;
+        const int umax = ctx->tune_sweep_U == 16 ? 16 : ctx->tune_sweep_U == 8 ? 8 : nq == 2 ? 16 : 8;  // (csmp_tune: measurement override)
         for (int u : {16, 8})
             if (u <= umax && nchunk % u == 0) {
                 U = u;
@@ -69,6 +69,7 @@ static void fr_config(const csmp_ctx* ctx, int nq, int& U, bool& full, size_t& l
     lds = fr_sweep_lds_bytes(ctx->Mv, vec, U, nq);
     const int cus = ctx->prop.multiProcessorCount;
     int64_t g = U == 16 ? (int64_t)cus * (nq == 2 ? 15 : 12) / 16 : (int64_t)cus;  // (nq < 2 with 16-chunk blocks: as the OMP sweep, configure_sweep)
+    if (ctx->tune_sweep_grid > 0) g = std::min<int64_t>(ctx->tune_sweep_grid, (int64_t)cus * 8);
     const int64_t groups = (ctx->N + (kSweepThreads / kWave) - 1) / (kSweepThreads / kWave);
     grid = (int)std::max<int64_t>(1, std::min<int64_t>(g, groups));
 }
