@@ -340,12 +340,16 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     }
     int64_t sgn = 0;
     // TWO pipelines (omp only): the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair).
-    // From two signals on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one.
+    // From two signals on and dictionaries of 4 MiB on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one, 2 takes two whatever the size.
     constexpr int64_t kPairMinSignals = 2;
+    constexpr size_t kPairMinBytes = (size_t)4 << 20;  // two pipelines: 1 MiB -10 %, 8 MiB +35 %, 32 MiB +40 %, 64 MiB ... 1 GiB +5 ... +16 %
     csmp_ctx* tw = nullptr;
     // (omp only.  Forward regression's sweep holds two or three LDS images -- one workgroup per CU as it is -- and two pipelines of
     // k_tick_fr measured no gain: 5.99e3 against 5.96e3 atoms/s)
-    if (pipe && !isfr && nsig >= kPairMinSignals && ctx->tune_pipelines != 1) {
+    // ... and where a sweep is long enough for its tail to matter: dictionaries of kPairMinBytes and more (measured: tools/probes/
+    // pair_sizes.py); csmp_tune(CSMP_TUNE_PIPELINES, 2) takes two pipelines whatever the size
+    const size_t dict_bytes = (size_t)ctx->Mv * (size_t)ctx->N * (ctx->dtype == CSMP_F32 ? 4 : 8);
+    if (pipe && !isfr && nsig >= kPairMinSignals && ctx->tune_pipelines != 1 && (ctx->tune_pipelines == 2 || dict_bytes >= kPairMinBytes)) {
         rc = twins_ensure(ctx, 1);
         if (rc == CSMP_OK) {
             tw = ctx->twins[0];

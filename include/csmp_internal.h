@@ -40,7 +40,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_SWEEP_UNIT 3   /* loads per unit (16, 8 or 4) */
 #define CSMP_TUNE_TICK_GRID 4    /* sweep workgroups inside the tick kernel of csmp_omp_batch */
 #define CSMP_TUNE_SWEEP_DYN 9     /* 1: the product sweep hands its columns out at run time (k_sweep_dyn; one LDS image, grids up to 512 workgroups); n = 2..64: only the last 1 / n of a workgroup's columns, after a static head; default 0: the static split */
-#define CSMP_TUNE_PIPELINES 12    /* 1: csmp_omp_batch keeps one pipeline of three signals; default 0: two pipelines side by side from two signals on (rounds of 3 + 3 signals, the remainder 1 + 1) */
+#define CSMP_TUNE_PIPELINES 12    /* 1: csmp_omp_batch keeps one pipeline of three signals; 2: two pipelines side by side whatever the sizes; default 0: two from two signals and a 4-MiB dictionary on (rounds of 3 + 3 signals, the remainder 1 + 1) */
 #define CSMP_TUNE_TICK_ORDER 10   /* 1: the tick kernel's sweep workgroups are dispatched ahead of its append stages' */
 #define CSMP_TUNE_CLAIM_POOLS 11  /* the dynamic sweep: column pools a workgroup may claim from (its own first) */
 #define CSMP_TUNE_PAIR_LDS_KIB 13 /* dynamic LDS (KiB) requested by the ticks of two pipelines side by side: above 80 = one workgroup per CU (default 81), 1 = what the kernels need */

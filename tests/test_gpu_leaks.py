@@ -101,6 +101,7 @@ def test_no_resource_leaks(cs, tmp_path):
             ctx.set_dictionary_file(paths["a32" if c % 2 == 0 else "a64"])
             d = None
         ctx = d.ctx if d is not None else ctx
+        ctx.tune("pipelines", 2)                                     # (two pipelines for these small dictionaries too: the twin context and its stream)
         names = sorted(fam)
         for name in names[c % 4::4] if c >= 8 else names:           # (every family in the first cycles, a rotating quarter afterwards)
             fam[name](ctx)
@@ -161,12 +162,14 @@ def test_every_allocation_may_fail(cs, dtype):
     base = L.live_resources()
     for name, f in sorted(fam.items()):
         clean = cs.Dictionary(A)
+        clean.ctx.tune("pipelines", 2)  # (the twin context's allocations are among those that fail in turn)
         want = f(clean.ctx)
         clean.close()
         n, seen_ok = 0, 0
         while seen_ok < 2 and n < 200:  # (two successes in a row: n is past every allocation of the call)
             n += 1
             d = cs.Dictionary(A)
+            d.ctx.tune("pipelines", 2)
             d.ctx.tune("fail_alloc", n)
             try:
                 got = f(d.ctx)
