@@ -37,8 +37,10 @@ def close(v, ref, tight=True):
     return np.allclose(v, ref, rtol=tol, atol=tol * max(1e-300, float(np.max(np.abs(ref))) if len(ref) else 0.0))
 
 
-@pytest.fixture(scope="module")
+@pytest.fixture
 def D(cs):
+    """dictionaries of ONE test, closed when it ends (a module-wide list kept some three hundred contexts -- each with its stream, and
+    since round 6 a twin context with another -- alive at once for no reason)"""
     made = []
 
     def make(A):
