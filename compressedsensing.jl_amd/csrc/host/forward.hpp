@@ -239,6 +239,26 @@ static int fr_ticks(csmp_ctx* ctx, const bool present[3], int64_t k, double max_
     for (int64_t n = 0; n < 3 * k + 2; ++n) CHECK(fr_pipe_launch<TA>(fp, n, k, max_eps, min_d2, optimistic));
     return CSMP_OK;
 }
+// Two such pipelines side by side (the omp_ticks_pair of host/omp.hpp with the OLS sweep): the ticks of both ask for lds_req bytes of
+// LDS -- above half a CU's, one workgroup per CU -- so that the two streams' workgroups queue for the CUs
+template <typename TA>
+static int fr_ticks_pair(csmp_ctx* ca, const bool pa[3], csmp_ctx* cb, const bool pb[3], int64_t k, double max_eps, double min_d2,
+                         bool optimistic, size_t lds_req) {
+    FrPipe fa, fb;
+    fr_pipe_begin(fa, ca, pa, k);
+    fr_pipe_begin(fb, cb, pb, k);
+    fa.lds = std::max(fa.lds, lds_req);
+    fb.lds = std::max(fb.lds, lds_req);
+    for (int64_t n = 0; n < 3 * k + 2; ++n) {
+        CHECK(fr_pipe_launch<TA>(fa, n, k, max_eps, min_d2, optimistic));
+        const int rb = fr_pipe_launch<TA>(fb, n, k, max_eps, min_d2, optimistic);
+        if (rb != CSMP_OK) {
+            ca->err = cb->err;
+            return rb;
+        }
+    }
+    return CSMP_OK;
+}
 // fr(A, b, max_ε, min_δ, k) = ols = oomp = ormp, x starting empty: src/forward.jl:44-54
 extern "C" int csmp_fr(csmp_ctx* ctx, const void* b, int b_dtype, int64_t k, double max_eps, double min_delta, int64_t* idx,
                        double* val, int64_t* nnz, int64_t* order) {
@@ -339,17 +359,17 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
         pipe = pipe && full && !fr_tall(ctx, 1);
     }
     int64_t sgn = 0;
-    // TWO pipelines (omp only): the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair).
+    // TWO pipelines: the second half of the triples runs on a twin context and stream beside the first (omp_ticks_pair, fr_ticks_pair).
     // From two signals on and dictionaries of 4 MiB on; csmp_tune(CSMP_TUNE_PIPELINES, 1) keeps one, 2 takes two whatever the size.
     constexpr int64_t kPairMinSignals = 2;
     constexpr size_t kPairMinBytes = (size_t)4 << 20;  // two pipelines: 1 MiB -10 %, 8 MiB +35 %, 32 MiB +40 %, 64 MiB ... 1 GiB +5 ... +16 %
     csmp_ctx* tw = nullptr;
-    // (omp only.  Forward regression's sweep holds two or three LDS images -- one workgroup per CU as it is -- and two pipelines of
-    // k_tick_fr measured no gain: 5.99e3 against 5.96e3 atoms/s)
+    // (forward regression too: its ticks under the same LDS request -- one workgroup per CU -- 6.28e3 -> 6.57e3 atoms/s at the benchmark
+    // shape; without the request 6.47e3.  An earlier measurement that found nothing, 5.99e3 against 5.96e3, was made without it.)
     // ... and where a sweep is long enough for its tail to matter: dictionaries of kPairMinBytes and more (measured: tools/probes/
     // pair_sizes.py); csmp_tune(CSMP_TUNE_PIPELINES, 2) takes two pipelines whatever the size
     const size_t dict_bytes = (size_t)ctx->Mv * (size_t)ctx->N * (ctx->dtype == CSMP_F32 ? 4 : 8);
-    if (pipe && !isfr && nsig >= kPairMinSignals && ctx->tune_pipelines != 1 && (ctx->tune_pipelines == 2 || dict_bytes >= kPairMinBytes)) {
+    if (pipe && nsig >= kPairMinSignals && ctx->tune_pipelines != 1 && (ctx->tune_pipelines == 2 || dict_bytes >= kPairMinBytes)) {
         rc = twins_ensure(ctx, 1);
         if (rc == CSMP_OK) {
             tw = ctx->twins[0];
@@ -358,6 +378,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             for (int q = 0; q < 3 && rc == CSMP_OK; ++q) {
                 activate_slot(tw, q);
                 rc = solver_ensure(tw, kc, (int)k);
+                if (rc == CSMP_OK && isfr) rc = fr_ensure(tw);
             }
             activate_slot(tw, 0);
             if (rc != CSMP_OK) ctx->err = tw->err;
@@ -405,6 +426,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
             // rounds whose pipelines hold different numbers 3 + 2: 6340, 2 + 1: 6332 (one pipeline of three: 6306, a lone signal:
             // 5830; tools/probes/few_signals.sh).  Two streams with a sweep ready each keep the HBM busy; what costs is a round in
             // which one stream's ticks have sweeps the other's have not.
+            const size_t fr_pair_lds = (size_t)(ctx->tune_pair_lds_kib > 0 ? ctx->tune_pair_lds_kib : kPairLdsKiB) * 1024;
             struct Round { int64_t fa; int ca; int64_t fb; int cb; };
             std::vector<Round> rounds;
             {
@@ -420,9 +442,14 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
                 rc = init_triple(ctx, fa, fa + rounds[j].ca, pa);
                 if (rc == CSMP_OK && hasb) rc = init_triple(tw, fb, fb + rounds[j].cb, pb);
                 if (rc != CSMP_OK) break;
-                if (hasb)
+                if (hasb && isfr)
+                    rc = ctx->dtype == CSMP_F32 ? fr_ticks_pair<float>(ctx, pa, tw, pb, k, eps, p2, opt, fr_pair_lds)
+                                                : fr_ticks_pair<double>(ctx, pa, tw, pb, k, eps, p2, opt, fr_pair_lds);
+                else if (hasb)
                     rc = ctx->dtype == CSMP_F32 ? omp_ticks_pair<float>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid)
                                                 : omp_ticks_pair<double>(ctx, pa, tw, pb, k, eps, opt, kPairTickGrid);
+                else if (isfr)
+                    rc = ctx->dtype == CSMP_F32 ? fr_ticks<float>(ctx, pa, k, eps, p2, opt) : fr_ticks<double>(ctx, pa, k, eps, p2, opt);
                 else
                     rc = ctx->dtype == CSMP_F32 ? omp_ticks<float>(ctx, pa, k, eps, opt) : omp_ticks<double>(ctx, pa, k, eps, opt);
                 if (rc == CSMP_OK) rc = finish_triple(ctx, fa, pa);

@@ -52,6 +52,29 @@ def test_two_pipelines_give_the_bits_of_one(cs, oracle, cfg):
     d.close()
 
 
+@pytest.mark.parametrize("cfg", [(256, 1024, 10, 6, np.float64), (1024, 3000, 9, 7, np.float32), (512, 2048, 8, 11, np.float32), (256, 700, 6, 2, np.float64)])
+def test_two_pipelines_of_forward_regression_give_the_bits_of_one(cs, oracle, cfg):
+    """csmp_fr_batch side by side on a twin context (host/forward.hpp: fr_ticks_pair, the ticks under the one-workgroup-per-CU LDS
+    request): rounds of 3 + 3, 1 + 1 and a lone signal; supports, coefficients and counts of one pipeline bit for bit, and the oracle's
+    forward regression (src/forward.jl:44-72)."""
+    n, m, k, nsig, dtype = cfg
+    A, _, _ = cs.sparse_data(n=n, m=m, k=k, rng=n + m + nsig, dtype=dtype)
+    d = cs.Dictionary(A)
+    B = signals(cs, A, k, nsig, 3 * nsig)
+    out = {}
+    for mode in (1, 2):
+        d.ctx.tune("pipelines", mode)
+        out[mode] = d.ctx.fr_batch(B, k, 0.0, 0.0)
+    for a, b in zip(out[1], out[2]):
+        assert np.array_equal(a, b)
+    idx, val, nnz = out[2]
+    for s in range(nsig):
+        ref = oracle.fr(A, B[:, s], k, 0.0, 0.0)
+        assert nnz[s] == len(ref[0]) and np.array_equal(idx[:nnz[s], s], ref[0]), s
+        assert close(val[:nnz[s], s], ref[1]), s
+    d.close()
+
+
 def test_two_pipelines_device_buffers_and_repeated_calls(cs, oracle):
     """device-resident signals and results (the bench's form), the same context called again with another batch size: the twin's
     stream joins the context's before the call returns its work to the caller's stream order"""
