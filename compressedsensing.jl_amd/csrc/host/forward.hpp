@@ -365,7 +365,7 @@ static int batch_impl(csmp_ctx* ctx, int algo, const void* B, int b_dtype, int64
     constexpr size_t kPairMinBytes = (size_t)4 << 20;  // two pipelines: 1 MiB -10 %, 8 MiB +35 %, 32 MiB +40 %, 64 MiB ... 1 GiB +5 ... +16 %
     csmp_ctx* tw = nullptr;
     // (forward regression too: its ticks under the same LDS request -- one workgroup per CU -- 6.28e3 -> 6.57e3 atoms/s at the benchmark
-    // shape; without the request 6.47e3.  An earlier measurement that found nothing, 5.99e3 against 5.96e3, was made without it.)
+    // shape; without the request 6.47e3.  With the sweep body as round 5 left it the same pairing had measured 5.99e3 against 5.96e3.)
     // ... and where a sweep is long enough for its tail to matter: dictionaries of kPairMinBytes and more (measured: tools/probes/
     // pair_sizes.py); csmp_tune(CSMP_TUNE_PIPELINES, 2) takes two pipelines whatever the size
     const size_t dict_bytes = (size_t)ctx->Mv * (size_t)ctx->N * (ctx->dtype == CSMP_F32 ? 4 : 8);
