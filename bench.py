@@ -105,7 +105,7 @@ def rocprof_row(kernel_substr, pattern="r*_bench_kernel_stats.csv"):
 LINE_BUDGET = 3000  # bytes: the driver keeps ~8 KB of stdout tail; round 3's 30 KB line was cut and the record did not parse
 DETAIL_FILE = "bench_secondary.json"
 _ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "launches_timed", "avg_launch_us",
-              "algorithmic_bytes_per_launch", "flops_per_launch", "launch_duration_us", "launches_in_flight")
+              "algorithmic_bytes_per_launch", "flops_per_launch", "launch_duration_us", "launches_in_flight", "whole_job_GBps", "whole_job_frac")
 _TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
              "dtype", "data", "signals_per_sec", "config", "roofline", "cpu_baseline", "secondary", "secondary_file", "gather_check",
              "ranks_seen", "devices", "matches_exact_path_on_sample", "batch_stats", "equals_unsharded_omp", "ranks_agree_on_first_support", "error")
@@ -1215,6 +1215,9 @@ def main():
                 "sweep_config": D.ctx.sweep_config(),
                 "launches_timed": int(window["launches"] if two else sweeps), "avg_launch_us": avg_sweep_s * 1e6, "algorithmic_bytes_per_launch": alg_bytes,
                 "launch_duration_us": duration_s * 1e6, "launches_in_flight": 2 if two else 1,
+                # the same bound from the wall clock alone: every atom moves the dictionary once, so the job's own throughput is a
+                # bandwidth -- appends, launch gaps and the pipelines' fill and drain included
+                "whole_job_GBps": atoms / tmax * alg_bytes / 1e9 / world, "whole_job_frac": atoms / tmax * alg_bytes / 1e9 / world / HBM_PEAK_GBS,
                 "timer": ("HIP events on BOTH pipelines' streams around every %d-th sweep launch of the timed region: avg_launch_us = (latest end - "
                           "earliest start) / (the %d launches from the first to the last timed one on each stream) -- the launches of the two streams "
                           "overlap, each lasting launch_duration_us (mean of the timed ones minus the reading of an empty event pair, %.2f us; the "
