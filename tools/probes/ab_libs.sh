@@ -1,3 +1,6 @@
+# Round 6 probe: A/B of TWO builds of libcsmp.so on one GPU box, twice each (boxes of the pool differ by 1-2 %, builds by less).
+# Before the gpurun call: keep the build to compare against as compressedsensing.jl_amd/csrc/libcsmp_prev.so (it travels with the
+# snapshot; *.so is git-ignored), build the new one in place.  Usage (GPU box): bash tools/probes/ab_libs.sh
 set -u
 L=compressedsensing.jl_amd/csrc
 O=gpurun_out/r06/ab_defer.txt
