@@ -98,7 +98,7 @@ INTERNAL_SIGNATURES = {
     "csmp_batch_layout": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.c_int)]),
     "csmp_batch_screen_kernel": (C.c_char_p, [vp]),
 }
-TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15, "sweep_short": 16, "phase_rows": 17, "fail_alloc": 18}  # CSMP_TUNE_* (include/csmp_internal.h)
+TUNE = {"sweep_grid": 2, "sweep_unit": 3, "tick_grid": 4, "batch_budget_mib": 5, "diag_split": 6, "swap_refuse": 7, "rebuild_direct": 8, "sweep_dyn": 9, "tick_order": 10, "claim_pools": 11, "pipelines": 12, "pair_lds_kib": 13, "pair_split": 14, "sweep_lds_kib": 15, "sweep_short": 16, "phase_rows": 17, "fail_alloc": 18, "screen_static": 19}  # CSMP_TUNE_* (include/csmp_internal.h)
 
 COMM_ID_BYTES = 128  # CSMP_COMM_ID_BYTES
 

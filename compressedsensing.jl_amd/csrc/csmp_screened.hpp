@@ -87,8 +87,10 @@ __device__ __forceinline__ int row16_sum(int v) {  // the same for the int8 swee
 template <int U, int D, bool FULL, int C, int IMG, int LC = kScrCand>
 __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int Mk, int64_t N, const double* __restrict__ r, int Mr,
                                                float* __restrict__ cand_val, int* __restrict__ cand_idx, DevState* st, double eps,
-                                               int check_eps, int skipmask, unsigned* __restrict__ tickets, float astep, char* smem) {
+                                               int check_eps_flags, int skipmask, unsigned* __restrict__ tickets, float astep, char* smem) {
     constexpr bool I8 = IMG == kOpI8;
+    const int check_eps = check_eps_flags & 1;
+    const bool stat = (check_eps_flags & 2) != 0;  // (csmp_tune screen_static: the groups dealt out statically, no tickets)
     constexpr int NW = kSweepThreads / kWave;
     static_assert(C == 2 || C == 4, "two or four columns side by side");
     constexpr int NL = NW * (kWave / 16);  // lists per workgroup (one per 16-lane row)
@@ -110,7 +112,8 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     const int part = nblk >= kScrPartWgs ? bid / kScrPartWgs : 0;
     const int wl = (bid - part * WPP) * NW + wave;  // the wave's number inside its partition
     unsigned* const ticket = tickets + part * kScrTicketStride;
-    const int64_t g0 = (int64_t)wl * NP + part;
+    const int64_t g0 = stat ? (int64_t)bid * NW + wave : (int64_t)wl * NP + part;
+    const int64_t gstride = (int64_t)nblk * NW;
     // the residual's loads go out FIRST: loads return in order, and behind the dictionary prefetch they would wait for 16 KiB
     // per wave of HBM traffic before the prologue could start
     constexpr int PR = 4;  // row quads per thread and pass (one pass at M <= 4096)
@@ -133,7 +136,7 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
     const char* lp = Ab + g0 * C * RB;
     int lb = 0;                      // its block
     unsigned tk = 0;                 // lane 0: the ticket for the group after `lg`
-    if (lg >= 0 && lane == 0) tk = atomicAdd(ticket, 1u);
+    if (!stat && lg >= 0 && lane == 0) tk = atomicAdd(ticket, 1u);
     auto load_next = [&](V (&dst)[U][C], int& slot_g) {
         slot_g = lg;
         if (lg >= 0) {
@@ -148,11 +151,11 @@ __device__ __forceinline__ void sweep_img_body(const char* __restrict__ Ab, int 
             }
             if (++lb == nblocks) {  // the following group: the ticket asked for a group ago, and the next request
                 lb = 0;
-                const int64_t g = ((int64_t)WPP * NW + (int64_t)__builtin_amdgcn_readfirstlane((int)tk)) * NP + part;
+                const int64_t g = stat ? (int64_t)lg + gstride : ((int64_t)WPP * NW + (int64_t)__builtin_amdgcn_readfirstlane((int)tk)) * NP + part;
                 lg = g < ngroups ? (int)g : -1;
                 if (lg >= 0) {
                     lp = Ab + g * C * RB;
-                    if (lane == 0) tk = atomicAdd(ticket, 1u);
+                    if (!stat && lane == 0) tk = atomicAdd(ticket, 1u);
                 }
             }
         }

@@ -215,6 +215,7 @@ struct csmp_ctx {
     int short_cpu = 0, short_nch = 0, short_KP = 0;  // k_sweep_short (stand-alone sweep of short columns): columns per reduction, chunks per column, image rows; 0 = the one-column body
     size_t short_lds = 0;
     int tune_phase_rows = 0;   // csmp_tune: most rows of a stage of the phased sweep (0: what the LDS holds)
+    int tune_screen_static = 0;  // csmp_tune: 1 = the screened sweep deals its column groups out statically (a measurement switch; tickets are the default)
     int tune_sweep_short = 0;  // csmp_tune: 1 = the one-column body for every shape
     size_t sweep_lds_req = 0;    // the stand-alone sweep's LDS request when larger than sweep_lds (residency control)
     int tune_sweep_lds_kib = 0;  // csmp_tune

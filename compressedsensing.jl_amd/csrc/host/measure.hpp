@@ -197,6 +197,7 @@ extern "C" int csmp_tune(csmp_ctx* ctx, int key, int64_t value) {
             if (value > 159) return fail(ctx, CSMP_EINVAL, "csmp_tune: at most 159 KiB of LDS");
             ctx->tune_pair_lds_kib = (int)value;
             return CSMP_OK;
+        case CSMP_TUNE_SCREEN_STATIC: ctx->tune_screen_static = value == 1 ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_PAIR_SPLIT: ctx->tune_pair_split = value == 1 ? 1 : 0; return CSMP_OK;
         case CSMP_TUNE_FAIL_ALLOC: ctx->tune_fail_alloc = (int)value; return CSMP_OK;
         case CSMP_TUNE_PIPELINES:

@@ -90,6 +90,10 @@ static hipError_t pickS_launch(csmp_ctx* ctx, int ncand, int S, int skipmask) { 
 
 // the sweep over the bf16 image: candidates of every workgroup into s.scr_val / s.scr_idx
 static int launch_sweep_bf16(csmp_ctx* ctx, double eps, int check_eps, int skip, bool wide = false) {
+    // bit 1 (csmp_tune(CSMP_TUNE_SCREEN_STATIC, 1), a measurement switch): the column groups dealt out STATICALLY, no ticket counters.
+    // Measured: a sweep that has the chip to itself needs the tickets (the 2-GiB image of configs[4]: 315 us against 357 with the
+    // static split); with three solves in flight the two forms are within 2 % of each other (11.5-11.9e3 atoms/s either way).
+    check_eps = (check_eps ? 1 : 0) | (ctx->tune_screen_static == 1 ? 2 : 0);
     Solver& s = ctx->s;
     Batch& b = ctx->bt;
     const bool timed = prof_pick(ctx);

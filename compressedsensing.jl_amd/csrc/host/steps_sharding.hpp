@@ -90,6 +90,7 @@ static void copy_options(csmp_ctx* dst, const csmp_ctx* src) {
     dst->tune_sweep_lds_kib = src->tune_sweep_lds_kib;
     dst->sweep_lds_req = src->sweep_lds_req;
     dst->tune_sweep_short = src->tune_sweep_short;
+    dst->tune_screen_static = src->tune_screen_static;
     dst->tune_phase_rows = src->tune_phase_rows;
     dst->tick_nblk = src->tick_nblk;
     dst->tune_swap_refuse = src->tune_swap_refuse;

@@ -48,6 +48,7 @@ int csmp_sweep_config(const csmp_ctx *ctx, int *unit_loads, int *phases, int *wo
 #define CSMP_TUNE_SWEEP_LDS_KIB 15 /* dynamic LDS (KiB) the stand-alone product sweep REQUESTS when that is more than it uses: above 80 = one workgroup per CU, 54 = two */
 #define CSMP_TUNE_SWEEP_SHORT 16  /* 1: the stand-alone sweep keeps one column per unit for every shape (default 0: columns of up to four 1-KiB chunks go two or four to a unit, k_sweep_short) */
 #define CSMP_TUNE_PHASE_ROWS 17   /* the phased sweep (a residual longer than the LDS): most rows of one stage; 0 = as many as the LDS holds */
+#define CSMP_TUNE_SCREEN_STATIC 19 /* 1: the screened (image) sweeps deal their column groups out statically; default 0: by ticket counters (measured: 12 % faster for a lone 2-GiB sweep, level with three solves in flight) */
 #define CSMP_TUNE_FAIL_ALLOC 18   /* test hook: the n-th device allocation of solver state from now fails for real (hipMalloc of an impossible size: hipErrorOutOfMemory stays pending); 0 = off */
 #define CSMP_TUNE_REBUILD_DIRECT 8 /* 1: the oblivious start of csmp_srr forms Q'A with its directions read from L2 per wave (k_fr_rebuild), not staged in the LDS */
 #define CSMP_TUNE_SWAP_REFUSE 7 /* 1: every exchange of csmp_ompr on the inverse Gram matrix fails its guard: the fallback to the QR path runs */
